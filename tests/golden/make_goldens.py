@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the *reference* Sound_Bubble model.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to
+the GPU box).  It imports the reference `Net` classes
+
+    src/models/tfgridnet_realtime_clean_dis_embd3/net.py:20   ("big" family)
+    src/models/tfgridnet_realtime_clean_optim/net.py:20       ("small" family)
+
+with three tiny stand-ins for third-party packages that are absent from this
+image (espnet2.get_layer, espnet2.AbsSeparator, asteroid_filterbanks.make_enc_dec
+-- see SURVEY.md Appendix B).  The stand-ins are written to a temp dir at run
+time and are never imported by the product or by the tests.
+
+What it emits (tests/golden/*.npz): seeded weights (the reference state_dict),
+seeded inputs, the reference outputs, per-stage intermediates captured with
+forward hooks, next_state, a 3-chunk streaming trace, and parameter gradients
+of the SNRLP pre-train loss.  Fixtures are data only; no reference source text
+is stored.
+
+PARITY CAVEAT: the STFT filter bank comes from the third-party
+`asteroid_filterbanks` (unpinned in requirements2.txt:15) which is not
+installed here.  The filter values in the fixtures come from the stand-in,
+which restates asteroid's published STFTFB formula.  The reference stores the
+filters as state_dict buffers (tfgridnet.{enc,dec}.filterbank._filters), so a
+real checkpoint overrides them; everything downstream of the filters is stock
+torch.nn and therefore a faithful oracle.
+
+Usage:  python tests/golden/make_goldens.py  [--out tests/golden]
+"""
+import argparse
+import importlib
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+
+REF = "/root/reference"
+
+
+def _write_shims(root):
+    def w(rel, body=""):
+        p = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(textwrap.dedent(body))
+
+    for pkg in ("espnet2", "espnet2/torch_utils", "espnet2/enh", "espnet2/enh/separator"):
+        w(pkg + "/__init__.py")
+    w("espnet2/torch_utils/get_layer_from_string.py", """
+        import torch
+        def get_layer(l_name, library=torch.nn):
+            for k in dir(library):
+                if k.lower() == l_name.lower():
+                    return getattr(library, k)
+            raise NotImplementedError(l_name)
+        """)
+    w("espnet2/enh/separator/abs_separator.py", """
+        import torch
+        class AbsSeparator(torch.nn.Module):
+            pass
+        """)
+    # asteroid_filterbanks stand-in: STFTFB + Encoder + Decoder (published formula)
+    w("asteroid_filterbanks/__init__.py", """
+        import numpy as np, torch, torch.nn as nn, torch.nn.functional as F
+        class STFTFB(nn.Module):
+            def __init__(self, n_filters, kernel_size, stride=None, window=None,
+                         sample_rate=8000.0, **kwargs):
+                super().__init__()
+                self.n_filters, self.kernel_size = n_filters, kernel_size
+                self.stride = stride if stride else kernel_size // 2
+                self.cutoff = int(n_filters / 2 + 1)
+                self.n_feats_out = 2 * self.cutoff
+                if window is None:
+                    window = np.hanning(kernel_size + 1)[:-1] ** 0.5
+                lpad = int((n_filters - kernel_size) // 2)
+                rpad = int(n_filters - kernel_size - lpad)
+                self.window = np.concatenate([np.zeros((lpad,)), window, np.zeros((rpad,))])
+                filters = np.fft.fft(np.eye(n_filters))
+                filters /= 0.5 * np.sqrt(kernel_size * n_filters / self.stride)
+                filters = np.vstack([np.real(filters[: self.cutoff, :]),
+                                     np.imag(filters[: self.cutoff, :])])
+                filters[0, :] /= np.sqrt(2)
+                filters[n_filters // 2, :] /= np.sqrt(2)
+                filters = torch.from_numpy(filters * self.window).unsqueeze(1).float()
+                self.register_buffer("_filters", filters)
+                self.register_buffer("_sample_rate", torch.zeros(1) + sample_rate)
+            def filters(self):
+                return self._filters
+        class Encoder(nn.Module):
+            def __init__(self, filterbank, padding=0):
+                super().__init__()
+                self.filterbank, self.stride, self.padding = filterbank, filterbank.stride, padding
+            def forward(self, x):
+                shp = x.shape
+                y = F.conv1d(x.reshape(-1, 1, shp[-1]), self.filterbank.filters(),
+                             stride=self.stride, padding=self.padding)
+                return y.view(shp[:-1] + y.shape[-2:])
+        class Decoder(nn.Module):
+            def __init__(self, filterbank, padding=0, output_padding=0):
+                super().__init__()
+                self.filterbank, self.stride = filterbank, filterbank.stride
+                self.padding, self.output_padding = padding, output_padding
+            def forward(self, spec):
+                shp = spec.shape
+                y = F.conv_transpose1d(spec.reshape(-1, shp[-2], shp[-1]), self.filterbank.filters(),
+                                       stride=self.stride, padding=self.padding,
+                                       output_padding=self.output_padding)
+                return y.view(shp[:-2] + (-1,))
+        def make_enc_dec(fb_name, n_filters, kernel_size, stride=None, sample_rate=8000.0,
+                         who_is_pinv=None, padding=0, output_padding=0, **kwargs):
+            assert fb_name == "stft"
+            kwargs.pop("window_type", None)   # upstream swallows it via **kwargs
+            enc = Encoder(STFTFB(n_filters, kernel_size, stride=stride, sample_rate=sample_rate), padding=padding)
+            dec = Decoder(STFTFB(n_filters, kernel_size, stride=stride, sample_rate=sample_rate),
+                          padding=padding, output_padding=output_padding)
+            return enc, dec
+        """)
+
+
+def _flatten_state(d, prefix=""):
+    out = {}
+    for k in sorted(d.keys()):
+        v = d[k]
+        if isinstance(v, dict):
+            out.update(_flatten_state(v, prefix + k + "::"))
+        else:
+            out[prefix + k] = v.detach().cpu().numpy().copy()
+    return out
+
+
+def snrlp_loss(torch, est, gt, neg_weight):
+    """SNRLPLoss restated for the generator (src/losses/SNRLP.py:17-42 with
+    asteroid SingleSrcNegSDR('snr'): zero-mean, EPS=1e-8).  The harness the
+    reference uses (PLModule) cannot be imported here (wandb/torchmetrics/...)."""
+    B = est.shape[0]
+    comp = torch.zeros(B, dtype=est.dtype)
+    mask = gt.abs().amax(dim=(1, 2)) == 0
+    if mask.any():
+        comp[mask] = (est[mask] - gt[mask]).abs().mean() * neg_weight
+    if (~mask).any():
+        e = est[~mask].reshape(-1, est.shape[-1])
+        t = gt[~mask].reshape(-1, gt.shape[-1])
+        e = e - e.mean(dim=1, keepdim=True)
+        t = t - t.mean(dim=1, keepdim=True)
+        ratio = (t ** 2).sum(1) / (((e - t) ** 2).sum(1) + 1e-8)
+        comp[~mask] = -10 * torch.log10(ratio + 1e-8)
+    return comp
+
+
+def make_case(torch, Net, name, params, B, n_frames, seed, needs_dis, out_dir,
+              with_grads=True, with_stream=True, with_stages=True):
+    torch.manual_seed(seed)
+    model = Net(**params).eval()
+    chunk, pad = params["stft_chunk_size"], params["stft_pad_size"]
+    N = n_frames * chunk - 37          # exercise mod_pad (not a multiple of 192)
+    g = torch.Generator().manual_seed(seed + 1)
+    base = 0.1 * torch.randn(B, 1, N + 8, generator=g)
+    mix = torch.cat([base[..., 4 - min(m, 4):4 - min(m, 4) + N] for m in range(params["num_ch"])], 1)
+    mix = (mix + 0.02 * torch.randn(B, params["num_ch"], N, generator=g)).clamp(-1, 1)
+    inputs = {"mixture": mix}
+    if needs_dis:
+        dis = torch.zeros(B, 3)
+        for b in range(B):
+            dis[b, (b + 1) % 3] = 1.0
+        inputs["dis_embed"] = dis
+
+    stages = {}
+    hooks = []
+    if with_stages:
+        tg = model.tfgridnet
+        hooks.append(tg.enc.register_forward_hook(lambda m, i, o: stages.__setitem__("stft", o.detach().numpy().copy())))
+        hooks.append(tg.conv.register_forward_hook(lambda m, i, o: stages.__setitem__("conv_ln", o.detach().numpy().copy())))
+        for bi, blk in enumerate(tg.blocks):
+            hooks.append(blk.register_forward_hook(
+                lambda m, i, o, bi=bi: stages.__setitem__(f"block{bi}", o[0].detach().numpy().copy())))
+        hooks.append(tg.deconv.register_forward_hook(lambda m, i, o: stages.__setitem__("deconv", o.detach().numpy().copy())))
+
+    with torch.no_grad():
+        res = model(dict(inputs))
+    for h in hooks:
+        h.remove()
+    out = res["output"].numpy().copy()
+    rec = {"output": out, "mixture": mix.numpy()}
+    if needs_dis:
+        rec["dis_embed"] = inputs["dis_embed"].numpy()
+    for k, v in stages.items():
+        rec["stage::" + k] = v
+    for k, v in _flatten_state(res["next_state"]).items():
+        rec["next_state::" + k] = v
+    for k, v in model.state_dict().items():
+        if k.endswith("filterbank._filters"):
+            continue                      # stored once in stft_filters.npz (enc == dec)
+        rec["param::" + k] = v.numpy().copy()
+
+    if with_grads:
+        model.train()
+        g2 = torch.Generator().manual_seed(seed + 2)
+        tgt = 0.05 * torch.randn(B, 1, N, generator=g2)
+        tgt[B - 1] = 0.0                                   # one silent-target sample
+        model.zero_grad()
+        est = model(dict(inputs))["output"]
+        loss_vec = snrlp_loss(torch, est, tgt, neg_weight=100.0)
+        loss = loss_vec.mean()
+        loss.backward()
+        rec["target"] = tgt.numpy()
+        rec["loss_vec"] = loss_vec.detach().numpy()
+        rec["loss"] = np.float32(loss.item())
+        for k, p in model.named_parameters():
+            rec["grad::" + k] = p.grad.numpy().copy()
+        model.eval()
+
+    if with_stream:
+        # causal_infer-style: 3 chunks of [B, M, chunk+pad], pad=False, carried state
+        x = mix[..., : 3 * chunk + pad]
+        state = model.init_buffers(B, "cpu")
+        outs = []
+        with torch.no_grad():
+            for c in range(3):
+                fr = {"mixture": x[..., c * chunk: c * chunk + chunk + pad]}
+                if needs_dis:
+                    fr["dis_embed"] = inputs["dis_embed"]
+                r = model(fr, state, pad=False)
+                state = r["next_state"]
+                outs.append(r["output"].numpy().copy())
+                if c == 2:
+                    for k, v in _flatten_state(state).items():
+                        rec["stream::state::" + k] = v
+        rec["stream::output"] = np.concatenate(outs, -1)
+        rec["stream::input"] = x.numpy().copy()
+
+    rec["meta::params"] = np.array(repr(sorted(params.items())))
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    nparam = sum(p.numel() for p in model.parameters())
+    print(f"{name}: params={nparam} out_rms={np.sqrt((out**2).mean()):.4e} -> {path} "
+          f"({os.path.getsize(path)/1e6:.2f} MB)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.dirname(os.path.abspath(__file__)))
+    args = ap.parse_args()
+    assert os.path.isdir(REF), "reference tree not present: goldens can only be made in the build container"
+    shim = tempfile.mkdtemp(prefix="sb_oracle_shims_")
+    _write_shims(shim)
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [shim, REF]
+    import torch
+    torch.set_num_threads(8)
+    NetBig = importlib.import_module("src.models.tfgridnet_realtime_clean_dis_embd3.net").Net
+    NetSmall = importlib.import_module("src.models.tfgridnet_realtime_clean_optim.net").Net
+
+    common = dict(stft_chunk_size=192, stft_pad_size=96, num_ch=6, L=4, I=1, J=1, H=64, E=2,
+                  use_attn=False, lookahead=True, chunk_causal=True, use_first_ln=True,
+                  merge_method="early_cat")
+    # parameter-count sanity: 501398 / 231125 / 498050
+    big = dict(common, D=32, B=6, local_atten_len=100, conv_lstm=False, dis_type="conv3")
+    small = dict(common, D=16, B=3, local_atten_len=50, conv_lstm=True, lstm_down=5)
+    orange = dict(common, D=32, B=6, local_atten_len=50, conv_lstm=False, lstm_down=5)
+    for nm, N_, p, want in (("big", NetBig, big, 501398), ("small", NetSmall, small, 231125),
+                            ("orange", NetSmall, orange, 498050)):
+        n = sum(q.numel() for q in N_(**p).parameters())
+        assert n == want, (nm, n, want)
+    print("parameter counts match SURVEY: 501398 / 231125 / 498050")
+
+    m0 = NetBig(**big)
+    fe = m0.tfgridnet.enc.filterbank._filters.numpy()
+    fd = m0.tfgridnet.dec.filterbank._filters.numpy()
+    assert np.array_equal(fe, fd)
+    np.savez_compressed(os.path.join(args.out, "stft_filters.npz"), filters=fe)
+
+    # tiny cases (2 blocks, 7 frames) -- full per-stage + grads + streaming
+    make_case(torch, NetBig, "tiny_big", dict(big, B=2), B=2, n_frames=7, seed=11, needs_dis=True, out_dir=args.out)
+    make_case(torch, NetSmall, "tiny_small", dict(small, B=2), B=2, n_frames=7, seed=12, needs_dis=False, out_dir=args.out)
+    make_case(torch, NetSmall, "tiny_orange", dict(orange, B=2), B=2, n_frames=7, seed=13, needs_dis=False, out_dir=args.out)
+    # dis_embd3 flavour of the conv-LSTM intra path (pads by 3 and crops)
+    make_case(torch, NetBig, "tiny_big_convlstm", dict(big, B=2, D=16, conv_lstm=True), B=2, n_frames=7, seed=14,
+              needs_dis=True, out_dir=args.out, with_stream=False)
+    # real small config, 1 s clip (125 frames), forward only
+    make_case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
+              with_grads=False, with_stream=False, with_stages=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""Pin the oracle (oracle/tfgridnet_oracle.py) against vectors produced by the real
+reference model (tests/golden/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_state_dict, rel_l2, flatten_state
+
+CASES = ["tiny_big", "tiny_small", "tiny_orange", "tiny_big_convlstm"]
+
+
+def build(rec, params, flavour, torch):
+    from oracle.tfgridnet_oracle import OracleNet
+    m = OracleNet(flavour, **params).eval()
+    m.load_state_dict(golden_state_dict(rec, torch), strict=True)   # reference key names
+    return m
+
+
+def inputs_of(rec, torch):
+    d = {"mixture": torch.from_numpy(rec["mixture"])}
+    if "dis_embed" in rec:
+        d["dis_embed"] = torch.from_numpy(rec["dis_embed"])
+    return d
+
+
+def test_stft_filters_match_fixture(torch_mod):
+    from oracle.tfgridnet_oracle import stft_filters
+    import os
+    from conftest import GOLDEN
+    f = np.load(os.path.join(GOLDEN, "stft_filters.npz"))["filters"]
+    assert f.shape == (290, 1, 288)
+    np.testing.assert_allclose(stft_filters(288, 192).numpy(), f, atol=2e-8)
+    # imaginary rows of DC / Nyquist are identically zero; real rows carry the 1/sqrt(2)
+    assert np.abs(f[145]).max() < 1e-9 and np.abs(f[289]).max() < 1e-7
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference(name, torch_mod):
+    torch = torch_mod
+    rec, params, flavour = load_golden(name)
+    m = build(rec, params, flavour, torch)
+    stages = {}
+    with torch.no_grad():
+        res = m(inputs_of(rec, torch), stages=stages)
+    assert res["output"].shape == rec["output"].shape
+    assert rel_l2(res["output"].numpy(), rec["output"]) < 2e-6
+    # intermediates (reference layouts: stft [B,M,2F,T]; conv/blocks [B,C,T,F] for dis_embd3,
+    # [B,T,F,C] inside the optim block loop)
+    assert rel_l2(stages["stft"].numpy(), rec["stage::stft"]) < 1e-6
+    conv = stages["conv_ln"].permute(0, 3, 1, 2).numpy()
+    assert rel_l2(conv, rec["stage::conv_ln"]) < 2e-6
+    nb = params["B"]
+    for i in range(nb):
+        got = stages[f"block{i}"]
+        got = got.permute(0, 3, 1, 2) if flavour == "dis_embd3" else got
+        assert rel_l2(got.numpy(), rec[f"stage::block{i}"]) < 2e-6
+    ns = flatten_state(res["next_state"])
+    for k, v in ns.items():
+        assert rel_l2(v, rec["next_state::" + k]) < 2e-6, k
+
+
+@pytest.mark.parametrize("name", ["tiny_big", "tiny_small", "tiny_orange"])
+def test_streaming_matches_reference(name, torch_mod):
+    torch = torch_mod
+    rec, params, flavour = load_golden(name)
+    m = build(rec, params, flavour, torch)
+    x = torch.from_numpy(rec["stream::input"])
+    st = m.init_buffers(x.shape[0], "cpu")
+    outs = []
+    with torch.no_grad():
+        for c in range(3):
+            fr = {"mixture": x[..., c * 192: c * 192 + 288]}
+            if "dis_embed" in rec:
+                fr["dis_embed"] = torch.from_numpy(rec["dis_embed"])
+            r = m(fr, st, pad=False)
+            st = r["next_state"]
+            outs.append(r["output"])
+    out = torch.cat(outs, -1).numpy()
+    assert out.shape[-1] == 3 * 192
+    assert rel_l2(out, rec["stream::output"]) < 2e-6
+    for k, v in flatten_state(st).items():
+        assert rel_l2(v, rec["stream::state::" + k]) < 2e-6, k
+    # streaming == first 3 chunks of the offline pass (edge/causal_infer.py self-check)
+    assert rel_l2(out, rec["output"][..., : 3 * 192]) < 1e-4
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_loss_and_grads_match_reference(name, torch_mod):
+    torch = torch_mod
+    from oracle.tfgridnet_oracle import snrlp_loss
+    rec, params, flavour = load_golden(name)
+    m = build(rec, params, flavour, torch).train()
+    est = m(inputs_of(rec, torch))["output"]
+    lv = snrlp_loss(est, torch.from_numpy(rec["target"]), 100.0)
+    np.testing.assert_allclose(lv.detach().numpy(), rec["loss_vec"], rtol=2e-5, atol=1e-5)
+    lv.mean().backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        g = rec["grad::" + k]
+        worst = max(worst, rel_l2(p.grad.numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max()))
+    assert worst < 5e-4, worst
+
+
+def test_small_config_1s(torch_mod):
+    torch = torch_mod
+    rec, params, flavour = load_golden("small_1s")
+    m = build(rec, params, flavour, torch)
+    assert sum(p.numel() for p in m.parameters()) == 231125          # README: 0.3 M
+    with torch.no_grad():
+        out = m(inputs_of(rec, torch))["output"].numpy()
+    assert rel_l2(out, rec["output"]) < 5e-6
+
+
+def test_param_counts(torch_mod):
+    from oracle.tfgridnet_oracle import OracleNet
+    common = dict(stft_chunk_size=192, stft_pad_size=96, num_ch=6, L=4, I=1, J=1, H=64, E=2, use_attn=False,
+                  lookahead=True, chunk_causal=True, use_first_ln=True, merge_method="early_cat")
+    big = OracleNet("dis_embd3", D=32, B=6, local_atten_len=100, conv_lstm=False, dis_type="conv3", **common)
+    orange = OracleNet("optim", D=32, B=6, local_atten_len=50, conv_lstm=False, lstm_down=5, **common)
+    n = lambda m: sum(p.numel() for p in m.parameters())
+    assert n(big) == 501398 and n(orange) == 498050
+
+
+def test_si_sdr_formula():
+    from oracle.tfgridnet_oracle import si_sdr_np
+    rng = np.random.default_rng(0)
+    gt = rng.standard_normal(1000)
+    est = 3.0 * gt + 0.1 * rng.standard_normal(1000)
+    # scale invariance: SI-SDR ignores the factor 3, plain SNR does not
+    assert abs(si_sdr_np(est, gt) - si_sdr_np(est / 3.0, gt)) < 1e-6
+    assert si_sdr_np(est, gt, scale_invariant=False) < 0 < si_sdr_np(est, gt)
