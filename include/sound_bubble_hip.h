@@ -1,0 +1,168 @@
+/* sound_bubble_hip.h -- C ABI of libsoundbubble_hip.so (gfx950 / MI355X).
+ *
+ * The reference (chentuochao/Sound_Bubble) has no FFI: its hot path is Python
+ * calling torch.nn modules.  Each entry point below replaces the torch op(s)
+ * the reference launches for one stage of that path; the reference line each
+ * one stands in for is cited.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the
+ *     library never allocates, frees or synchronises; scratch is passed in;
+ *   - fp32, contiguous unless a stride is given (strides are in floats);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - returns 0 on success, -(hipError_t) on a launch error, -1000-x on a
+ *     bad argument; never throws; re-entrant (no mutable globals).
+ * Activations are channels-last [B, T, F, C]; a "position" p is the dense
+ * index over that (b, t, f) grid (or (b, t, k) on the down-sampled intra grid).
+ */
+#ifndef SOUND_BUBBLE_HIP_H
+#define SOUND_BUBBLE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SB_H 64 /* LSTM hidden size the recurrent kernels are built for */
+
+/* ---- recurrent LSTM (forward) -------------------------------------------
+ * Replaces LayerNorm(C) + nn.LSTM forward of
+ *   intra: dis_embd3/tfgridnet_causal.py:819-823 (plain), :804-808 (conv-LSTM)
+ *          optim/tfgridnet_causal.py:690-695,700-703
+ *   inter: dis_embd3/tfgridnet_causal.py:832-843 ; optim :711-722
+ * Sequence n, step s live at position  (n / n_inner) * p_outer + (n % n_inner)
+ * * p_inner + s * p_step.  Direction 1 (bidirectional intra) walks s backwards.
+ * Gate order i,f,g,o (torch).  x is the PRE-LayerNorm input [P, C]; the
+ * kernel normalises over C (eps 1e-5) with ln_g/ln_b on the fly.
+ * hs: [P, ndir*64].  save_gates (nullable): [P, ndir, 5, 64] = i,f,g,o,c_prev
+ * (post-activation) for BPTT.  save_u (nullable): [P, C] LayerNorm output.
+ * h0/c0 (nullable = zeros), hN/cN (nullable): [nseq, 64], direction 0 only. */
+typedef struct {
+  int nseq, nsteps, n_inner, ndir, C;
+  int64_t p_outer, p_inner, p_step;
+  const float* x;
+  const float* ln_g; const float* ln_b;
+  const float* w_ih[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2];
+  const float* h0; const float* c0; float* hN; float* cN;
+  float* hs; float* save_gates; float* save_u;
+} sb_lstm_fwd_args;
+int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
+
+/* ---- recurrent LSTM (backward through time, recurrent part) --------------
+ * Autograd of the nn.LSTM calls above (loss.backward(), tain_val.py:75).
+ * Reads save_gates and dhs ([P, ndir*64], gradient w.r.t. hs), walks the
+ * steps in reverse and writes dgates [P, ndir, 4, 64] (gradient w.r.t. the
+ * pre-activation gates).  Input/weight gradients are then position-wise
+ * GEMMs (sb_linear_fwd / sb_wgrad). Initial state is assumed zero-grad. */
+typedef struct {
+  int nseq, nsteps, n_inner, ndir;
+  int64_t p_outer, p_inner, p_step;
+  const float* w_hh[2];
+  const float* save_gates; const float* dhs; float* dgates;
+} sb_lstm_bwd_args;
+int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
+
+/* ---- position-wise linear (MFMA, weights staged in LDS) -------------------
+ * out[p, n] = epi( sum_k in(p, k) * W[n, k] + bias[n] )  for every position
+ * p = (b, t, f) of a B x T x F grid.  in(p,k) = in[b*is_b + t*is_t + f*is_f +
+ * (k / kseg) * is_seg + k % kseg]  (kseg | 16; overlapping rows are allowed,
+ * which is how the STFT frames and the 3x3 convolutions are expressed).
+ * out row at b*os_b + t*os_t + f*os_f, features contiguous.  N, K multiples
+ * of 16 (N <= 128 per call).  n_valid <= N features are stored.
+ * Replaces nn.Linear / Conv1d(k=s) / ConvTranspose1d(k=s) / Conv2d(3x3) /
+ * asteroid Encoder+Decoder GEMMs: tfgridnet_causal.py:475,507,520,537,803-824,845. */
+enum {
+  SB_EPI_NONE = 0,   /* + bias                                              */
+  SB_EPI_RES = 1,    /* + bias + res[p]  (res addressed like out: rs_*)     */
+  SB_EPI_PRELU = 2,  /* prelu(+bias) with scalar slope *prelu_a; aux_out (nullable) gets the pre-activation */
+  SB_EPI_LN = 3,     /* LayerNorm over the N features of (+bias); aux_out (nullable) gets the pre-LN value */
+  SB_EPI_LNBWD = 4   /* acc = d(LN out); x = aux_in[p] (pre-LN input, optional PReLU of it when prelu_a);
+                        out = LN-backward (+ res[p]) (* prelu' when prelu_a); dgamma/dbeta/dprelu -> partials */
+};
+typedef struct {
+  int B, T, F, N, K, n_valid, kseg, epi;
+  const float* in; int64_t is_b, is_t, is_f, is_seg;
+  const float* w; const float* bias;
+  float* out; int64_t os_b, os_t, os_f;
+  const float* res; int64_t rs_b, rs_t, rs_f;
+  const float* prelu_a; const float* ln_g; const float* ln_b;
+  const float* aux_in; float* aux_out;      /* dense [P, N] */
+  float* partials;                          /* SB_EPI_LNBWD: [grid, 2N+1] floats */
+  int accumulate;                           /* out += instead of out = (EPI_NONE/RES only) */
+} sb_linear_args;
+int sb_linear_fwd(const sb_linear_args* a, void* stream);
+/* number of workgroups sb_linear_fwd launches for P positions (size of `partials`) */
+int sb_linear_grid(int64_t positions);
+
+/* ---- weight gradient (TN GEMM over positions) ----------------------------
+ * dW[n, k] (+)= sum_p g(p, n) * in(p, k), g dense-strided rows [P, ldg] at
+ * column offset, `in` addressed like sb_linear_args.  Rows whose index within
+ * a segment of seg_len positions is < skip_first or >= seg_len - skip_last
+ * are excluded (the "previous hidden state" of the first step).  If
+ * transpose_out the result is stored as dW[k, n].  Two-stage: per-workgroup
+ * partials in `scratch` ([sb_wgrad_grid(P), N*K] floats) then a reduction
+ * that ADDS into dW (gradients accumulate in the flat bucket). */
+typedef struct {
+  int B, T, F, N, K, kseg;
+  const float* g; int64_t ldg;
+  const float* in; int64_t is_b, is_t, is_f, is_seg;
+  int64_t in_shift;           /* element offset added to `in` rows (e.g. -H for h_prev) */
+  int seg_len, skip_first, skip_last;
+  int transpose_out;
+  float* dW; float* scratch;
+} sb_wgrad_args;
+int sb_wgrad(const sb_wgrad_args* a, void* stream);
+int sb_wgrad_grid(int64_t positions);
+
+/* column sums: out[n] += sum_p g[p*ldg + n], n < N (bias gradients) */
+int sb_colsum(const float* g, int64_t P, int64_t ldg, int N, float* out, float* scratch, void* stream);
+/* out[i] += sum_r partials[r*ld + i] for i < n */
+int sb_reduce_rows(const float* partials, int rows, int64_t ld, int n, float* out, void* stream);
+
+
+/* ---- front-end features --------------------------------------------------
+ * spec [B*M, T, ld_spec] (cols 0..F-1 real, F..2F-1 imag: asteroid Encoder
+ * layout) -> zp [B, T+2, F+2, 32] channels-last, written at time offset 2 and
+ * frequency offset 1 (zero borders for the 3x3 conv; channels 27..31 zero).
+ * Channel order: re x M, im x M, ILD x (M-1), (sin, cos) x (M-1).
+ * Replaces tfgridnet_causal.py:482-500 + MC_features_OMNX :72-93, IPD_OMNX :32-48. */
+int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int T, int F, void* stream);
+
+/* ---- FiLM (distance conditioning between blocks) --------------------------
+ * y[b,t,f,c] = x[b,t,f,c] * w[b,f,c] + bias[b,f,c]   (tfgridnet_causal.py:59-68,509-513)
+ * backward: dx = dy * w ; dw[b,f,c] = sum_t dy * x ; dbias[b,f,c] = sum_t dy. */
+int sb_film_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int F, int C, void* stream);
+int sb_film_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias,
+                int B, int T, int F, int C, void* stream);
+
+/* ---- iSTFT overlap-add ---------------------------------------------------
+ * frames [B, T+1, 288] (row 0 = carried istft_buf frame) -> wave [B, hop*T]:
+ * conv_transpose1d overlap-add, drop the first hop and the last (win-hop)
+ * samples (tfgridnet_causal.py:533-542).  bwd: dframes from dwave. */
+int sb_overlap_add(const float* frames, float* wave, int B, int T, int win, int hop, void* stream);
+int sb_overlap_add_bwd(const float* dwave, float* dframes, int B, int T, int win, int hop, void* stream);
+
+/* ---- output transposed-conv, data gradient --------------------------------
+ * dy [B, T, F, C] (gradient w.r.t. the last block's output) from dspec
+ * [B, T, F, 2] (interleaved re/im) and the ConvTranspose2d weight
+ * w[C, 2, 3, 3] (tfgridnet_causal.py:401,520).  The forward and the weight
+ * gradient of this layer are sb_linear_fwd / sb_wgrad over the padded grid. */
+int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int T, int F, int C, void* stream);
+
+/* ---- SNRLP loss (src/losses/SNRLP.py:17-42, asteroid SingleSrcNegSDR('snr')) ----
+ * est, gt [B, N].  stats [B, 8] scratch.  loss_vec [B].  Negative (all-zero gt)
+ * samples get neg_weight * mean|est| over ALL negative samples' elements.
+ * dest (nullable) = d mean_b(loss_vec) / d est. */
+int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight,
+                  float* stats, float* loss_vec, float* dest, void* stream);
+
+/* ---- optimiser ------------------------------------------------------------
+ * sumsq[0] += sum g^2 (grad-norm for clip_grad_norm_, hl_module:437-441). */
+int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+/* Adam step (torch.optim.Adam, no weight decay / amsgrad) over a flat bucket.
+ * grad is first scaled by gscale * min(1, clip / (sqrt(sumsq[0]) * gscale + 1e-6))
+ * when clip > 0 (clip_grad_norm_ semantics), else by gscale. */
+int sb_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, int step, float gscale, float clip, const float* sumsq, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

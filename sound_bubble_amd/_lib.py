@@ -1,0 +1,101 @@
+"""ctypes binding of libsoundbubble_hip.so (the C ABI in include/sound_bubble_hip.h).
+
+The product path has NO fallback: if the library is missing or a call returns a
+non-zero status this module raises.  Nothing here imports `oracle/`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsoundbubble_hip.so")
+
+c_fp = C.c_void_p          # device float*
+i64 = C.c_int64
+
+
+class LstmFwdArgs(C.Structure):
+    _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int), ("C", C.c_int),
+                ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
+                ("x", c_fp), ("ln_g", c_fp), ("ln_b", c_fp),
+                ("w_ih", c_fp * 2), ("w_hh", c_fp * 2), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
+                ("h0", c_fp), ("c0", c_fp), ("hN", c_fp), ("cN", c_fp),
+                ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp)]
+
+
+class LstmBwdArgs(C.Structure):
+    _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int),
+                ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
+                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("F", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("n_valid", C.c_int), ("kseg", C.c_int), ("epi", C.c_int),
+                ("inp", c_fp), ("is_b", i64), ("is_t", i64), ("is_f", i64), ("is_seg", i64),
+                ("w", c_fp), ("bias", c_fp),
+                ("out", c_fp), ("os_b", i64), ("os_t", i64), ("os_f", i64),
+                ("res", c_fp), ("rs_b", i64), ("rs_t", i64), ("rs_f", i64),
+                ("prelu_a", c_fp), ("ln_g", c_fp), ("ln_b", c_fp),
+                ("aux_in", c_fp), ("aux_out", c_fp), ("partials", c_fp), ("accumulate", C.c_int)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("F", C.c_int), ("N", C.c_int), ("K", C.c_int), ("kseg", C.c_int),
+                ("g", c_fp), ("ldg", i64),
+                ("inp", c_fp), ("is_b", i64), ("is_t", i64), ("is_f", i64), ("is_seg", i64),
+                ("in_shift", i64), ("seg_len", C.c_int), ("skip_first", C.c_int), ("skip_last", C.c_int),
+                ("transpose_out", C.c_int), ("dW", c_fp), ("scratch", c_fp)]
+
+
+EPI_NONE, EPI_RES, EPI_PRELU, EPI_LN, EPI_LNBWD = range(5)
+
+# every symbol include/sound_bubble_hip.h declares: name -> (restype, argtypes)
+_vp, _ci, _cf = C.c_void_p, C.c_int, C.c_float
+SYMBOLS = {
+    "sb_lstm_fwd": (_ci, [C.POINTER(LstmFwdArgs), _vp]),
+    "sb_lstm_bwd_rec": (_ci, [C.POINTER(LstmBwdArgs), _vp]),
+    "sb_linear_fwd": (_ci, [C.POINTER(LinearArgs), _vp]),
+    "sb_linear_grid": (_ci, [i64]),
+    "sb_wgrad": (_ci, [C.POINTER(WgradArgs), _vp]),
+    "sb_wgrad_grid": (_ci, [i64]),
+    "sb_colsum": (_ci, [c_fp, i64, i64, _ci, c_fp, c_fp, _vp]),
+    "sb_reduce_rows": (_ci, [c_fp, _ci, i64, _ci, c_fp, _vp]),
+    "sb_features": (_ci, [c_fp, i64, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_film_fwd": (_ci, [c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_film_bwd": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_snrlp_loss": (_ci, [c_fp, c_fp, _ci, i64, _cf, c_fp, c_fp, c_fp, _vp]),
+    "sb_sumsq": (_ci, [c_fp, i64, c_fp, _vp]),
+    "sb_adam_step": (_ci, [c_fp, c_fp, c_fp, c_fp, i64, _cf, _cf, _cf, _cf, _ci, _cf, _cf, c_fp, _vp]),
+}
+
+_lib = None
+
+
+class SoundBubbleHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (building nothing: see sound_bubble_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SoundBubbleHipError(
+            f"{LIB_PATH} is missing. Build it with `python -m sound_bubble_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SoundBubbleHipError(f"{what} failed with status {rc}")

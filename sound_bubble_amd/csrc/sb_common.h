@@ -1,0 +1,66 @@
+// Shared device helpers for the Sound-Bubble gfx950 kernels.
+//
+// MFMA convention used everywhere ("transposed form"):
+//   D[16 x 16] += A[16 x 4] * B[4 x 16]   via v_mfma_f32_16x16x4_f32 (exact fp32 fma chain)
+//   A operand : lane l holds A[i = l & 15][k = l >> 4]
+//   B operand : lane l holds B[k = l >> 4][j = l & 15]
+//   C/D       : lane l holds D[row = 4*(l >> 4) + r][col = l & 15], r = 0..3
+// Rows of D are output features (gate units / channels), columns are the 16
+// positions (sequences) a wave owns, so the weight matrix is the A operand and
+// can stay resident in registers or LDS, and a lane ends up with 4 consecutive
+// features of ONE position -> 16-byte coalesced loads/stores of activations.
+// The K dimension is consumed in chunks of 16 with the permutation
+//   k(chunk m, lane-quad q, sub-step r) = 16 m + 4 q + r
+// so that both operands are fetched as one float4 per lane per chunk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SB_DEVINL __device__ __forceinline__
+
+SB_DEVINL f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc += A4 (4 k-substeps of the A operand) x B4 (matching 4 k-substeps of B)
+SB_DEVINL f32x4 mfma16x4(const f32x4 a, const f32x4 b, f32x4 c) {
+  c = mfma16(a[0], b[0], c);
+  c = mfma16(a[1], b[1], c);
+  c = mfma16(a[2], b[2], c);
+  c = mfma16(a[3], b[3], c);
+  return c;
+}
+
+SB_DEVINL f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+SB_DEVINL void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+SB_DEVINL f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+SB_DEVINL float sigmoidf_fast(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+SB_DEVINL float tanhf_fast(float x) { return 2.0f * __fdividef(1.0f, 1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// sum over the 4 lanes {l, l^16, l^32, l^48} (same l & 15): the feature quads of one position
+SB_DEVINL float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// sum over the 16 lanes sharing l >> 4 (all positions of a tile)
+SB_DEVINL float row16_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+SB_DEVINL float wave_sum(float v) {
+  v = row16_sum(v);
+  return quad_sum(v);
+}
+
+#define SB_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return -(int)e__;                \
+  } while (0)

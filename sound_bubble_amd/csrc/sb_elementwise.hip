@@ -1,0 +1,342 @@
+// HBM-bound streaming kernels of the Sound-Bubble hot path (features, FiLM,
+// overlap-add, output-deconv data gradient, SNRLP loss, Adam).  All are
+// coalesced 4/16-byte-per-lane passes; none carries reuse worth LDS tiling.
+#include "sb_common.h"
+#include "../../include/sound_bubble_hip.h"
+
+namespace {
+
+constexpr int ZC = 32;   // padded channel count of the front-end feature tensor
+
+// one thread per (b, t, fp) of the padded frequency axis
+template <int M>
+__global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ spec, int64_t ld, float* __restrict__ zp,
+                                                       int B, int T, int F) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int FP = F + 2;
+  const int64_t total = (int64_t)B * T * FP;
+  if (idx >= total) return;
+  const int fp = (int)(idx % FP);
+  const int64_t bt = idx / FP;
+  const int t = (int)(bt % T);
+  const int b = (int)(bt / T);
+  float* o = zp + (((int64_t)b * (T + 2) + t + 2) * FP + fp) * ZC;
+  float v[ZC];
+#pragma unroll
+  for (int i = 0; i < ZC; ++i) v[i] = 0.f;
+  if (fp >= 1 && fp <= F) {
+    const int f = fp - 1;
+    float re[M], im[M], mag[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const float* s = spec + ((int64_t)(b * M + m) * T + t) * ld;
+      re[m] = s[f];
+      im[m] = s[F + f];
+      mag[m] = sqrtf(re[m] * re[m] + im[m] * im[m]);
+      v[m] = re[m];
+      v[M + m] = im[m];
+    }
+#pragma unroll
+    for (int m = 1; m < M; ++m) {
+      v[2 * M + m - 1] = log10f((mag[m] + 1e-6f) / (mag[0] + 1e-6f));
+      const float den = mag[m] * mag[0] + 1e-6f;
+      v[3 * M - 1 + 2 * (m - 1)] = (re[0] * im[m] - im[0] * re[m]) / den;       // sin
+      v[3 * M - 1 + 2 * (m - 1) + 1] = (re[m] * re[0] + im[m] * im[0]) / den;   // cos
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ZC; i += 4) {
+    f32x4 x = {v[i], v[i + 1], v[i + 2], v[i + 3]};
+    st4(o + i, x);
+  }
+}
+
+__global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                       int T, int F, int C) {
+  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t fc4 = (int64_t)F * C / 4;
+  const int64_t total = (int64_t)B * T * fc4;
+  if (i4 >= total) return;
+  const int64_t b = i4 / (T * fc4);
+  const int64_t r = i4 % fc4;
+  const f32x4 xv = ld4(x + i4 * 4), wv = ld4(w + (b * fc4 + r) * 4), bv = ld4(bias + (b * fc4 + r) * 4);
+  st4(y + i4 * 4, xv * wv + bv);
+}
+
+// thread = (b, f, c4); grid.y splits T; dw/dbias accumulated with atomics (pre-zeroed)
+__global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ dy, float* __restrict__ dx,
+                                                       float* __restrict__ dw, float* __restrict__ dbias, int B, int T,
+                                                       int F, int C, int tchunk) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t fc4 = (int64_t)F * C / 4;
+  if (i >= B * fc4) return;
+  const int64_t b = i / fc4, r = i % fc4;
+  const f32x4 wv = ld4(w + i * 4);
+  f32x4 aw = zero4(), ab = zero4();
+  const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
+  for (int t = t0; t < t1; ++t) {
+    const int64_t off = ((b * T + t) * fc4 + r) * 4;
+    const f32x4 g = ld4(dy + off), xv = ld4(x + off);
+    st4(dx + off, g * wv);
+    aw += g * xv;
+    ab += g;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    atomicAdd(dw + i * 4 + k, aw[k]);
+    atomicAdd(dbias + i * 4 + k, ab[k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ frames, float* __restrict__ wave,
+                                                          int B, int T, int win, int hop) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t L = (int64_t)hop * T;
+  if (i >= B * L) return;
+  const int64_t b = i / L, n = i % L;
+  const int64_t m = n + hop;
+  const int t1 = (int)(m / hop), j1 = (int)(m % hop);
+  const float* fb = frames + b * (int64_t)(T + 1) * win;
+  float v = fb[(int64_t)t1 * win + j1];
+  if (j1 < win - hop) v += fb[(int64_t)(t1 - 1) * win + j1 + hop];
+  wave[i] = v;
+}
+
+__global__ __launch_bounds__(256) void overlap_add_bwd_kernel(const float* __restrict__ dwave,
+                                                              float* __restrict__ dframes, int B, int T, int win,
+                                                              int hop) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)(T + 1) * win;
+  if (i >= B * per) return;
+  const int64_t b = i / per, r = i % per;
+  const int t = (int)(r / win), j = (int)(r % win);
+  const int64_t m = (int64_t)hop * t + j;
+  const int64_t L = (int64_t)hop * T;
+  dframes[i] = (m >= hop && m < hop + L) ? dwave[b * L + m - hop] : 0.f;
+}
+
+// dy[b,t,f,c] = sum_{a,d,o} dspec[b, t+2-a, f+1-d, o] * W[c, o, 2-a, 2-d]   (valid t', f' only)
+__global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __restrict__ dspec,
+                                                              const float* __restrict__ w, float* __restrict__ dy,
+                                                              int B, int T, int F, int C) {
+  extern __shared__ float ws[];   // [C][18]
+  for (int i = threadIdx.x; i < C * 18; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * T * F * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t p = i / C;
+  const int f = (int)(p % F);
+  const int64_t bt = p / F;
+  const int t = (int)(bt % T);
+  const int64_t b = bt / T;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int tt = t + 2 - a;
+    if (tt < 0 || tt >= T) continue;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int ff = f + 1 - d;
+      if (ff < 0 || ff >= F) continue;
+      const float* g = dspec + (((b * T + tt) * F) + ff) * 2;
+      // W[c][o][kt=2-a][kf=2-d]
+      acc += g[0] * ws[c * 18 + 0 * 9 + (2 - a) * 3 + (2 - d)] + g[1] * ws[c * 18 + 1 * 9 + (2 - a) * 3 + (2 - d)];
+    }
+  }
+  dy[i] = acc;
+}
+
+// ---------------- SNRLP loss ----------------
+// stats[b*8 + k]: 0 sum e, 1 sum t, 2 max|t| (as uint bits), 3 sum t'^2, 4 sum (e'-t')^2, 5 sum |e-t|
+__global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                         int64_t N, float* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const float* e = est + (int64_t)b * N;
+  const float* t = gt + (int64_t)b * N;
+  float se = 0.f, st = 0.f, mx = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    se += e[i]; st += t[i]; mx = fmaxf(mx, fabsf(t[i]));
+  }
+  se = wave_sum(se); st = wave_sum(st);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(stats + b * 8 + 0, se);
+    atomicAdd(stats + b * 8 + 1, st);
+    atomicMax(reinterpret_cast<unsigned int*>(stats + b * 8 + 2), __float_as_uint(mx));
+  }
+}
+__global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                         int64_t N, float* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const float* e = est + (int64_t)b * N;
+  const float* t = gt + (int64_t)b * N;
+  const float me = stats[b * 8 + 0] / (float)N, mt = stats[b * 8 + 1] / (float)N;
+  float s3 = 0.f, s4 = 0.f, s5 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float tt = t[i] - mt, d = (e[i] - me) - tt;
+    s3 += tt * tt; s4 += d * d; s5 += fabsf(e[i] - t[i]);
+  }
+  s3 = wave_sum(s3); s4 = wave_sum(s4); s5 = wave_sum(s5);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(stats + b * 8 + 3, s3);
+    atomicAdd(stats + b * 8 + 4, s4);
+    atomicAdd(stats + b * 8 + 5, s5);
+  }
+}
+// single block: per-sample loss; stats[b*8+6] = grad coefficient (positive) ; stats[b*8+7] = is_negative
+__global__ void loss_final_kernel(float* __restrict__ stats, int B, int64_t N, float neg_weight,
+                                  float* __restrict__ loss_vec) {
+  __shared__ float negsum;
+  __shared__ int nneg;
+  if (threadIdx.x == 0) {
+    float s = 0.f; int c = 0;
+    for (int b = 0; b < B; ++b)
+      if (stats[b * 8 + 2] == 0.f) { s += stats[b * 8 + 5]; ++c; }
+    negsum = s; nneg = c;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const bool neg = stats[b * 8 + 2] == 0.f;
+    if (neg) {
+      loss_vec[b] = neg_weight * negsum / ((float)nneg * (float)N);
+      stats[b * 8 + 6] = 0.f;
+      stats[b * 8 + 7] = 1.f;
+    } else {
+      const float St = stats[b * 8 + 3], Sn = stats[b * 8 + 4] + 1e-8f;
+      const float R = St / Sn;
+      loss_vec[b] = -10.f * log10f(R + 1e-8f);
+      // dL/de_n = coef * (e'_n - t'_n)
+      stats[b * 8 + 6] = (10.f / 2.302585092994046f) / (R + 1e-8f) * (St / (Sn * Sn)) * 2.f;
+      stats[b * 8 + 7] = 0.f;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                        int B, int64_t N, float neg_weight,
+                                                        const float* __restrict__ stats, float* __restrict__ dest) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * N) return;
+  const int b = (int)(i / N);
+  const float invB = 1.0f / (float)B;
+  if (stats[b * 8 + 7] != 0.f) {
+    const float d = est[i] - gt[i];
+    dest[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * neg_weight * invB / (float)N;
+  } else {
+    const float me = stats[b * 8 + 0] / (float)N, mt = stats[b * 8 + 1] / (float)N;
+    dest[i] = stats[b * 8 + 6] * ((est[i] - me) - (gt[i] - mt)) * invB;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2, float gscale,
+                                                   float clip, const float* __restrict__ sumsq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sc = gscale;
+  if (clip > 0.f) {
+    const float norm = sqrtf(sumsq[0]) * gscale;
+    const float coef = clip / (norm + 1e-6f);
+    sc *= coef < 1.f ? coef : 1.f;
+  }
+  const float gi = g[i] * sc;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int T, int F, void* stream) {
+  const int64_t total = (int64_t)B * T * (F + 2);
+  if (M == 6) hipLaunchKernelGGL(features_kernel<6>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, spec, ld_spec, zp, B, T, F);
+  else return -1002;
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_film_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int F, int C,
+                           void* stream) {
+  const int64_t total = (int64_t)B * T * F * C / 4;
+  hipLaunchKernelGGL(film_fwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, T, F, C);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_film_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias, int B,
+                           int T, int F, int C, void* stream) {
+  const int64_t n = (int64_t)B * F * C / 4;
+  const int tchunk = 25;
+  dim3 grid(nblk(n), (T + tchunk - 1) / tchunk);
+  hipLaunchKernelGGL(film_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, dy, dx, dw, dbias, B, T, F, C, tchunk);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_overlap_add(const float* frames, float* wave, int B, int T, int win, int hop, void* stream) {
+  if (win - hop > hop) return -1002;
+  hipLaunchKernelGGL(overlap_add_kernel, dim3(nblk((int64_t)B * hop * T)), dim3(256), 0, (hipStream_t)stream, frames, wave, B, T, win, hop);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sb_overlap_add_bwd(const float* dwave, float* dframes, int B, int T, int win, int hop, void* stream) {
+  hipLaunchKernelGGL(overlap_add_bwd_kernel, dim3(nblk((int64_t)B * (T + 1) * win)), dim3(256), 0, (hipStream_t)stream, dwave, dframes, B, T, win, hop);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int T, int F, int C,
+                                  void* stream) {
+  const int64_t total = (int64_t)B * T * F * C;
+  hipLaunchKernelGGL(deconv_bwd_data_kernel, dim3(nblk(total)), dim3(256), C * 18 * sizeof(float), (hipStream_t)stream, dspec, w, dy, B, T, F, C);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight, float* stats,
+                             float* loss_vec, float* dest, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(stats, 0, (size_t)B * 8 * sizeof(float), st);
+  unsigned gx = nblk(N, 256 * 8);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(loss_pass1_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
+  hipLaunchKernelGGL(loss_pass2_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, stats, B, N, neg_weight, loss_vec);
+  if (dest) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk((int64_t)B * N)), dim3(256), 0, st, est, gt, B, N, neg_weight, stats, dest);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
+  unsigned gx = nblk(n, 256 * 4);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int step, float gscale, float clip, const float* sumsq,
+                            void* stream) {
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, gscale, clip, sumsq);
+  SB_CHECK_LAUNCH();
+  return 0;
+}

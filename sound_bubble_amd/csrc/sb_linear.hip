@@ -1,0 +1,387 @@
+// Position-wise MFMA GEMMs for gfx950: every Linear / k=s Conv1d / 3x3 Conv2d /
+// STFT filter bank of the Sound-Bubble hot path is "out[p, :] = W * in(p, :)"
+// over the dense (b, t, f) position grid, and every weight gradient is the
+// matching "dW = sum_p g(p,:)^T in(p,:)".
+//
+// sb_linear_fwd : weights (<= 152 KB) staged ONCE per workgroup in LDS as the A
+//   operand; each wave streams 16 positions at a time, fetching its B operand
+//   (the activations) straight from HBM as 16-byte loads (64 B contiguous per
+//   position per K-chunk), and finishes with a fused epilogue (bias, residual,
+//   PReLU, LayerNorm forward, LayerNorm backward).  Persistent grid.
+// sb_wgrad      : TN GEMM over positions with per-workgroup register
+//   accumulators (no atomics; deterministic two-stage reduction).
+#include "sb_common.h"
+#include "../../include/sound_bubble_hip.h"
+
+namespace {
+
+constexpr int LIN_MAX_WG = 1024;   // persistent grid cap (4 WG/CU on 256 CUs)
+constexpr int WG_MAX_WG = 512;
+
+SB_DEVINL int64_t pos_off(int64_t p, int T, int F, int64_t sb, int64_t st, int64_t sf) {
+  const int64_t tf = (int64_t)T * F;
+  const int64_t b = p / tf;
+  const int64_t rem = p - b * tf;
+  const int64_t t = rem / F;
+  const int64_t f = rem - t * F;
+  return b * sb + t * st + f * sf;
+}
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P) {
+  extern __shared__ __attribute__((aligned(16))) float Wl[];   // [N][K+4]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int N = NT * 16, K = a.K, KP = K + 4;
+  // stage weights
+  for (int idx = tid * 4; idx < N * K; idx += 256 * 4) {
+    const int n = idx / K, k = idx - n * K;
+    st4(&Wl[n * KP + k], ld4(a.w + idx));
+  }
+  __syncthreads();
+
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = a.bias ? ld4(a.bias + 16 * nt + 4 * q) : zero4();
+
+  // LN-backward parameter-gradient accumulators (this lane's 4*NT features)
+  constexpr int NB = EPI == SB_EPI_LNBWD ? NT : 1;
+  f32x4 dgam[NB], dbet[NB];
+  float dalpha = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < NB; ++nt) { dgam[nt] = zero4(); dbet[nt] = zero4(); }
+  const float alpha = a.prelu_a ? a.prelu_a[0] : 0.f;
+
+  const int64_t ntiles = (P + 63) / 64;
+  const int nchunk = K / 16;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p = tile * 64 + 16 * w + j;
+    const bool valid = p < P;
+    const int64_t ioff = valid ? pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f) : 0;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = bias[nt];
+
+    auto load_b = [&](int m) -> f32x4 {
+      const int kk = 16 * m;
+      const int seg = kk / a.kseg;
+      const int kin = kk - seg * a.kseg;
+      return valid ? ld4(a.in + ioff + (int64_t)seg * a.is_seg + kin + 4 * q) : zero4();
+    };
+    f32x4 bcur = load_b(0);
+    for (int m = 0; m < nchunk; ++m) {
+      const f32x4 b4 = bcur;
+      if (m + 1 < nchunk) bcur = load_b(m + 1);
+      const float* wrow = &Wl[j * KP + 16 * m + 4 * q];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 a4 = ld4(wrow + nt * 16 * KP);
+        acc[nt] = mfma16x4(a4, b4, acc[nt]);
+      }
+    }
+
+    // ---------------- epilogue: lane holds features 16nt+4q..+3 of position p ----------------
+    const int64_t ooff = valid ? pos_off(p, a.T, a.F, a.os_b, a.os_t, a.os_f) : 0;
+    if constexpr (EPI == SB_EPI_RES) {
+      if (valid) {
+        const int64_t roff = pos_off(p, a.T, a.F, a.rs_b, a.rs_t, a.rs_f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] += ld4(a.res + roff + 16 * nt + 4 * q);
+      }
+    } else if constexpr (EPI == SB_EPI_PRELU) {
+      if (valid && a.aux_out)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) st4(a.aux_out + p * N + 16 * nt + 4 * q, acc[nt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nt][r] = acc[nt][r] > 0.f ? acc[nt][r] : alpha * acc[nt][r];
+    } else if constexpr (EPI == SB_EPI_LN) {
+      if (valid && a.aux_out)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) st4(a.aux_out + p * N + 16 * nt + 4 * q, acc[nt]);
+      float s = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) s += acc[nt][0] + acc[nt][1] + acc[nt][2] + acc[nt][3];
+      const float mean = quad_sum(s) * (1.0f / N);
+      float sq = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc[nt][r] - mean; sq += d * d; }
+      const float rstd = 1.0f / sqrtf(quad_sum(sq) * (1.0f / N) + 1e-5f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 g4 = ld4(a.ln_g + 16 * nt + 4 * q), b4 = ld4(a.ln_b + 16 * nt + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nt][r] = (acc[nt][r] - mean) * rstd * g4[r] + b4[r];
+      }
+    } else if constexpr (EPI == SB_EPI_LNBWD) {
+      // acc = dL/d(LN output).  x = pre-LN input (optionally PReLU of the stored pre-activation).
+      f32x4 raw[NT], xh[NT];
+      float s = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        raw[nt] = valid ? ld4(a.aux_in + p * N + 16 * nt + 4 * q) : zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = (a.prelu_a && raw[nt][r] <= 0.f) ? alpha * raw[nt][r] : raw[nt][r];
+          xh[nt][r] = x;
+          s += x;
+        }
+      }
+      const float mean = quad_sum(s) * (1.0f / N);
+      float sq = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = xh[nt][r] - mean; sq += d * d; }
+      const float rstd = 1.0f / sqrtf(quad_sum(sq) * (1.0f / N) + 1e-5f);
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 g4 = ld4(a.ln_g + 16 * nt + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xhat = (xh[nt][r] - mean) * rstd;
+          xh[nt][r] = xhat;
+          const float du = valid ? acc[nt][r] : 0.f;
+          dgam[nt][r] += du * xhat;
+          dbet[nt][r] += du;
+          const float gg = du * g4[r];
+          acc[nt][r] = gg;
+          m1 += gg;
+          m2 += gg * xhat;
+        }
+      }
+      m1 = quad_sum(m1) * (1.0f / N);
+      m2 = quad_sum(m2) * (1.0f / N);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float dx = rstd * (acc[nt][r] - m1 - xh[nt][r] * m2);
+          if (a.prelu_a) {
+            if (raw[nt][r] <= 0.f) { dalpha += valid ? dx * raw[nt][r] : 0.f; dx *= alpha; }
+          }
+          acc[nt][r] = dx;
+        }
+      if (valid && a.res) {
+        const int64_t roff = pos_off(p, a.T, a.F, a.rs_b, a.rs_t, a.rs_f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] += ld4(a.res + roff + 16 * nt + 4 * q);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = 16 * nt + 4 * q;
+        float* o = a.out + ooff + n0;
+        if (n0 + 4 <= a.n_valid) {
+          if (a.accumulate) st4(o, ld4(o) + acc[nt]); else st4(o, acc[nt]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < a.n_valid) o[r] = a.accumulate ? o[r] + acc[nt][r] : acc[nt][r];
+        }
+      }
+    }
+  }
+
+  if constexpr (EPI == SB_EPI_LNBWD) if (a.partials) {
+    float* part = a.partials + (size_t)blockIdx.x * (2 * N + 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float g = row16_sum(dgam[nt][r]), b = row16_sum(dbet[nt][r]);
+        if (j == 0) {
+          atomicAdd(part + 16 * nt + 4 * q + r, g);
+          atomicAdd(part + N + 16 * nt + 4 * q + r, b);
+        }
+      }
+    const float da = wave_sum(dalpha);
+    if (lane == 0 && a.prelu_a) atomicAdd(part + 2 * N, da);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NTW, int KT>
+__global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  f32x4 acc[NTW][KT];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = zero4();
+  int64_t koff[KT];
+  bool kval[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int k = 16 * kt + j;
+    const int seg = k / a.kseg;
+    koff[kt] = (int64_t)seg * a.is_seg + (k - seg * a.kseg) + a.in_shift;
+    kval[kt] = k < a.K;
+  }
+  int ncol[NTW];
+  bool nval[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) { ncol[nt] = 16 * (w * NTW + nt) + j; nval[nt] = ncol[nt] < a.N; }
+
+  const int64_t ntiles = (P + 15) / 16;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float av[NTW][4], bv[KT][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t p = tile * 16 + 4 * q + r;
+      bool ok = p < P;
+      if (ok) {
+        const int idx = (int)(p % a.seg_len);
+        ok = idx >= a.skip_first && idx < a.seg_len - a.skip_last;
+      }
+      const int64_t ioff = ok ? pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f) : 0;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) av[nt][r] = (ok && nval[nt]) ? a.g[p * a.ldg + ncol[nt]] : 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) bv[kt][r] = (ok && kval[kt]) ? a.in[ioff + koff[kt]] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = mfma16(av[nt][r], bv[kt][r], acc[nt][kt]);
+  }
+  float* part = a.scratch + (size_t)blockIdx.x * a.N * a.K;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * (w * NTW + nt) + 4 * q + r, k = 16 * kt + j;
+        if (n < a.N && k < a.K) part[(size_t)n * a.K + k] = acc[nt][kt][r];
+      }
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ partials, int rows, int64_t ld, int n,
+                                   float* __restrict__ out, int tr_N, int tr_K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += partials[(size_t)r * ld + i];
+  int o = i;
+  if (tr_N > 0) { const int nn = i / tr_K, kk = i - nn * tr_K; o = kk * tr_N + nn; }
+  out[o] += s;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int64_t P, int64_t ldg, int N,
+                                                     float* __restrict__ scratch) {
+  // block (x: row chunk, y: 64-column chunk): thread = (row lane rr 0..3, column c 0..63)
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), rr = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (c < N)
+    for (int64_t p = (int64_t)blockIdx.x * 4 + rr; p < P; p += (int64_t)gridDim.x * 4) s += g[p * ldg + c];
+  red[rr][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rr == 0 && c < N)
+    scratch[(size_t)blockIdx.x * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int NT, int EPI>
+int launch_linear2(const sb_linear_args& a, int64_t P, hipStream_t st) {
+  const size_t lds = (size_t)NT * 16 * (a.K + 4) * sizeof(float);
+  if (lds > 160 * 1024) return -1005;
+  (void)hipFuncSetAttribute((const void*)linear_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((linear_kernel<NT, EPI>), dim3(sb_linear_grid(P)), dim3(256), lds, st, a, P);
+  return 0;
+}
+template <int NT>
+int launch_linear(const sb_linear_args& a, int64_t P, hipStream_t st) {
+  switch (a.epi) {
+    case SB_EPI_NONE: return launch_linear2<NT, SB_EPI_NONE>(a, P, st);
+    case SB_EPI_RES: return launch_linear2<NT, SB_EPI_RES>(a, P, st);
+    case SB_EPI_PRELU: return launch_linear2<NT, SB_EPI_PRELU>(a, P, st);
+    case SB_EPI_LN: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LN>(a, P, st); else return -1006;
+    case SB_EPI_LNBWD: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LNBWD>(a, P, st); else return -1006;
+    default: return -1007;
+  }
+}
+
+}  // namespace
+
+extern "C" int sb_linear_grid(int64_t positions) {
+  const int64_t t = (positions + 63) / 64;
+  return (int)(t < LIN_MAX_WG ? (t < 1 ? 1 : t) : LIN_MAX_WG);
+}
+extern "C" int sb_wgrad_grid(int64_t positions) {
+  const int64_t t = (positions + 15) / 16;
+  return (int)(t < WG_MAX_WG ? (t < 1 ? 1 : t) : WG_MAX_WG);
+}
+
+extern "C" int sb_reduce_rows(const float* partials, int rows, int64_t ld, int n, float* out, void* stream) {
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, rows, ld,
+                     n, out, 0, 0);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_linear_fwd(const sb_linear_args* ap, void* stream) {
+  if (!ap) return -1001;
+  sb_linear_args a = *ap;
+  if (a.N % 16 || a.K % 16 || a.kseg % 16 || a.N <= 0 || a.K <= 0) return -1002;
+  if ((a.epi == SB_EPI_LN || a.epi == SB_EPI_LNBWD) && a.n_valid != a.N) return -1003;
+  const int64_t P = (int64_t)a.B * a.T * a.F;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = sb_linear_grid(P);
+  if (a.epi == SB_EPI_LNBWD && a.partials)
+    (void)hipMemsetAsync(a.partials, 0, (size_t)grid * (2 * a.N + 1) * sizeof(float), st);
+  int rc;
+  switch (a.N / 16) {
+    case 1: rc = launch_linear<1>(a, P, st); break;
+    case 2: rc = launch_linear<2>(a, P, st); break;
+    case 3: rc = launch_linear<3>(a, P, st); break;
+    case 4: rc = launch_linear<4>(a, P, st); break;
+    case 5: rc = launch_linear<5>(a, P, st); break;
+    case 6: rc = launch_linear<6>(a, P, st); break;
+    case 8: rc = launch_linear<8>(a, P, st); break;
+    default: return -1004;
+  }
+  if (rc) return rc;
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
+  if (!ap) return -1001;
+  const sb_wgrad_args& a = *ap;
+  const int64_t P = (int64_t)a.B * a.T * a.F;
+  const int nblk = (a.N + 15) / 16, kt = (a.K + 15) / 16, ntw = (nblk + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(sb_wgrad_grid(P)), block(256);
+#define SB_WG(NTW_, KT_) \
+  if (ntw == NTW_ && kt == KT_) { hipLaunchKernelGGL((wgrad_kernel<NTW_, KT_>), grid, block, 0, st, a, P); } else
+  SB_WG(4, 1) SB_WG(4, 2) SB_WG(4, 4) SB_WG(2, 1) SB_WG(2, 2) SB_WG(1, 1) SB_WG(1, 2) SB_WG(1, 4) SB_WG(1, 8) SB_WG(5, 1)
+  SB_WG(5, 2) SB_WG(2, 5) SB_WG(1, 5) SB_WG(2, 4) SB_WG(1, 6) SB_WG(1, 3) SB_WG(2, 3) SB_WG(2, 8) SB_WG(1, 18) SB_WG(1, 9) SB_WG(3, 8) SB_WG(1, 10) { return -1004; }
+#undef SB_WG
+  SB_CHECK_LAUNCH();
+  const int n = a.N * a.K;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.scratch, (int)grid.x,
+                     (int64_t)n, n, a.dW, a.transpose_out ? a.N : 0, a.K);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_colsum(const float* g, int64_t P, int64_t ldg, int N, float* out, float* scratch, void* stream) {
+  if (P <= 0 || N <= 0) return -1001;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t gx = (P + 3) / 4;
+  if (gx > 256) gx = 256;
+  dim3 grid((unsigned)gx, (N + 63) / 64), block(256);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, g, P, ldg, N, scratch);
+  SB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, (int)gx, (int64_t)N, N, out,
+                     0, 0);
+  SB_CHECK_LAUNCH();
+  return 0;
+}

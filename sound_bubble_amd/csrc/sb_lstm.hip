@@ -1,0 +1,277 @@
+// Recurrent LSTM kernels for gfx950 (MI355X): the intra-frame (over F) and
+// inter-frame (over T) LSTMs of the GridNet blocks -- 90 % of the model FLOPs.
+//
+// Design (not a translation of cuDNN/MIOpen's "hoist the input GEMM" scheme):
+//   * sequences are independent, so a workgroup owns a tile of 16 sequences for
+//     the whole time loop: no grid-wide per-step synchronisation;
+//   * transposed MFMA form: gates^T[256 x 16 seq] = W[256 x (C+64)] * [u;h]^T.
+//     W_ih and W_hh are the A operand and stay in VGPRs for the whole loop
+//     (96 VGPRs for C=32); the [C+H] input/hidden vectors are the B operand,
+//     exchanged through 2 x 5 KB of double-buffered LDS (one barrier per step);
+//   * wave w owns hidden units 16w..16w+15 for all four gates, so the cell
+//     update is lane-local (4 units x 1 sequence per lane), h is written back
+//     with one ds_write_b128 and one 16-byte global store;
+//   * the LayerNorm in front of every LSTM is fused into the loader (the input
+//     row is normalised while it is staged, one step ahead of its use);
+//   * v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fma chain), so the 1e-3
+//     parity bar of the north star holds without any mixed-precision risk.
+#include "sb_common.h"
+#include "../../include/sound_bubble_hip.h"
+
+namespace {
+
+constexpr int H = SB_H;
+constexpr int HP = H + 4;   // padded LDS row (conflict-free ds_read_b128 across 16 rows)
+
+template <int C>
+struct XVec { float v[C / 16]; };
+
+template <int C, bool SAVE>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
+  constexpr int KX = C / 16;     // 16-wide K chunks of the input part
+  constexpr int VPT = C / 16;    // floats per loader thread
+  constexpr int CP = C + 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int dir = blockIdx.y;
+  const int n0 = blockIdx.x * 16;
+  const int S = a.nsteps;
+  const bool rev = dir == 1;
+
+  __shared__ __attribute__((aligned(16))) float U[2][16][CP];
+  __shared__ __attribute__((aligned(16))) float Hb[2][16][HP];
+
+  // ---- weights -> registers (A operand fragments) ----
+  const float* __restrict__ wih = a.w_ih[dir];
+  const float* __restrict__ whh = a.w_hh[dir];
+  f32x4 Aih[4][KX], Ahh[4][4], bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int row = g * H + 16 * w + j;
+#pragma unroll
+    for (int m = 0; m < KX; ++m) Aih[g][m] = ld4(wih + (size_t)row * C + 16 * m + 4 * q);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) Ahh[g][m] = ld4(whh + (size_t)row * H + 16 * m + 4 * q);
+    const int u0 = g * H + 16 * w + 4 * q;
+    bias[g] = ld4(a.b_ih[dir] + u0) + ld4(a.b_hh[dir] + u0);
+  }
+
+  // ---- loader role: thread -> (sequence ls, channel slice) ----
+  const int ls = tid >> 4, cpart = tid & 15;
+  const int nl = n0 + ls;
+  const bool lvalid = nl < a.nseq;
+  const int64_t lbase = lvalid ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
+  float gam[VPT], bet[VPT];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; bet[v] = a.ln_b[cpart * VPT + v]; }
+
+  auto load_x = [&](int s) {
+    XVec<C> r;
+    const int st = rev ? S - 1 - s : s;
+    const float* p = a.x + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) r.v[v] = lvalid ? p[v] : 0.f;
+    return r;
+  };
+  auto ln_store = [&](const XVec<C>& xv, int buf, int s) {
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) sum += xv.v[v];
+    const float mean = row16_sum(sum) * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq += d * d; }
+    const float rstd = 1.0f / sqrtf(row16_sum(sq) * (1.0f / C) + 1e-5f);
+    float u[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      u[v] = (xv.v[v] - mean) * rstd * gam[v] + bet[v];
+      U[buf][ls][cpart * VPT + v] = u[v];
+    }
+    if (SAVE && dir == 0 && lvalid && a.save_u) {
+      const int st = rev ? S - 1 - s : s;
+      float* p = a.save_u + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) p[v] = u[v];
+    }
+  };
+
+  // ---- compute role: lane -> (sequence j, units 16w+4q..+3) ----
+  const int nc = n0 + j;
+  const bool cvalid = nc < a.nseq;
+  const int64_t cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+  const int uoff = 16 * w + 4 * q;
+  f32x4 c = zero4(), h = zero4();
+  if (dir == 0 && cvalid) {
+    if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
+    if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
+  }
+  st4(&Hb[0][j][uoff], h);
+
+  XVec<C> xnext = load_x(0);
+  ln_store(xnext, 0, 0);
+  if (S > 1) xnext = load_x(1);
+  __syncthreads();
+
+  const int ndir = a.ndir;
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    f32x4 acc[4] = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+    for (int m = 0; m < KX; ++m) {
+      const f32x4 b4 = ld4(&U[cur][j][16 * m + 4 * q]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma16(Aih[g][m][r], b4[r], acc[g]);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 b4 = ld4(&Hb[cur][j][16 * m + 4 * q]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma16(Ahh[g][m][r], b4[r], acc[g]);
+    }
+    // cell update: i,f,g,o for 4 units of one sequence
+    f32x4 gi, gf, gg, go, cprev = c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gi[r] = sigmoidf_fast(acc[0][r]);
+      gf[r] = sigmoidf_fast(acc[1][r]);
+      gg[r] = tanhf_fast(acc[2][r]);
+      go[r] = sigmoidf_fast(acc[3][r]);
+      c[r] = gf[r] * c[r] + gi[r] * gg[r];
+      h[r] = go[r] * tanhf_fast(c[r]);
+    }
+    st4(&Hb[cur ^ 1][j][uoff], h);
+    if (cvalid) {
+      const int st = rev ? S - 1 - s : s;
+      const int64_t pos = cbase + (int64_t)st * a.p_step;
+      st4(a.hs + (pos * ndir + dir) * H + uoff, h);
+      if (SAVE) {
+        float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
+        st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
+      }
+    }
+    if (s + 1 < S) {
+      ln_store(xnext, cur ^ 1, s + 1);
+      if (s + 2 < S) xnext = load_x(s + 2);
+    }
+    __syncthreads();
+  }
+  if (dir == 0 && cvalid) {
+    if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h);
+    if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c);
+  }
+}
+
+// Backward through time, recurrent part: dgates for every step and the
+// dh/dc recurrences.  Wave w owns gate rows {g*64+16w..+15}: its dgates are the
+// B operand straight from registers, partial dh^T = W_hh^T[:, slice] * dgates
+// is reduced across the 4 waves through LDS (one barrier per step).
+__global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int dir = blockIdx.y;
+  const int n0 = blockIdx.x * 16;
+  const int S = a.nsteps, ndir = a.ndir;
+  const bool rev = dir == 1;
+  __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
+
+  const float* __restrict__ whh = a.w_hh[dir];
+  f32x4 At[4][4];   // [out tile ot][gate g] over r : W_hh[g*64+16w+4q+r][16*ot + j]
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) At[ot][g][r] = whh[(size_t)(g * H + 16 * w + 4 * q + r) * H + 16 * ot + j];
+
+  const int nc = n0 + j;
+  const bool valid = nc < a.nseq;
+  const int64_t base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+  const int uoff = 16 * w + 4 * q;
+
+  struct Rec { f32x4 i, f, g, o, cp, dh; };
+  auto load_rec = [&](int s) {   // s = forward processing index
+    Rec r;
+    const int st = rev ? S - 1 - s : s;
+    const int64_t pos = base + (int64_t)st * a.p_step;
+    if (valid) {
+      const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
+      r.i = ld4(rec); r.f = ld4(rec + H); r.g = ld4(rec + 2 * H); r.o = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
+      r.dh = ld4(a.dhs + (pos * ndir + dir) * H + uoff);
+    } else {
+      r.i = r.f = r.g = r.o = r.cp = r.dh = zero4();
+    }
+    return r;
+  };
+
+  f32x4 dc = zero4(), dhrec = zero4();
+  Rec nxt = load_rec(S - 1);
+  for (int s = S - 1; s >= 0; --s) {
+    const int cur = s & 1;
+    const Rec rc = nxt;
+    if (s > 0) nxt = load_rec(s - 1);
+    f32x4 dG[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dh = rc.dh[r] + dhrec[r];
+      const float cc = rc.f[r] * rc.cp[r] + rc.i[r] * rc.g[r];
+      const float tc = tanhf_fast(cc);
+      const float dO = dh * tc;
+      const float dct = dc[r] + dh * rc.o[r] * (1.0f - tc * tc);
+      dG[0][r] = dct * rc.g[r] * rc.i[r] * (1.0f - rc.i[r]);
+      dG[1][r] = dct * rc.cp[r] * rc.f[r] * (1.0f - rc.f[r]);
+      dG[2][r] = dct * rc.i[r] * (1.0f - rc.g[r] * rc.g[r]);
+      dG[3][r] = dO * rc.o[r] * (1.0f - rc.o[r]);
+      dc[r] = dct * rc.f[r];
+    }
+    if (valid) {
+      const int st = rev ? S - 1 - s : s;
+      const int64_t pos = base + (int64_t)st * a.p_step;
+      float* dg = a.dgates + (pos * ndir + dir) * (4 * H) + uoff;
+      st4(dg, dG[0]); st4(dg + H, dG[1]); st4(dg + 2 * H, dG[2]); st4(dg + 3 * H, dG[3]);
+    }
+    if (s > 0) {
+      f32x4 part[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ot = 0; ot < 4; ++ot) part[ot] = mfma16(At[ot][g][r], dG[g][r], part[ot]);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) st4(&P[cur][w][ot][lane][0], part[ot]);
+      __syncthreads();
+      dhrec = ld4(&P[cur][0][w][lane][0]) + ld4(&P[cur][1][w][lane][0]) + ld4(&P[cur][2][w][lane][0]) +
+              ld4(&P[cur][3][w][lane][0]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
+  if (!a || a->nseq <= 0 || a->nsteps <= 0 || (a->ndir != 1 && a->ndir != 2)) return -1001;
+  if (a->C != 16 && a->C != 32) return -1002;
+  dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const bool save = a->save_gates != nullptr;
+  if (a->C == 32) {
+    if (save) hipLaunchKernelGGL((lstm_fwd_kernel<32, true>), grid, block, 0, st, *a);
+    else hipLaunchKernelGGL((lstm_fwd_kernel<32, false>), grid, block, 0, st, *a);
+  } else {
+    if (save) hipLaunchKernelGGL((lstm_fwd_kernel<16, true>), grid, block, 0, st, *a);
+    else hipLaunchKernelGGL((lstm_fwd_kernel<16, false>), grid, block, 0, st, *a);
+  }
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream) {
+  if (!a || a->nseq <= 0 || a->nsteps <= 0 || (a->ndir != 1 && a->ndir != 2)) return -1001;
+  dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
+  hipLaunchKernelGGL(lstm_bwd_rec_kernel, grid, block, 0, (hipStream_t)stream, *a);
+  SB_CHECK_LAUNCH();
+  return 0;
+}

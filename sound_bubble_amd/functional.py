@@ -1,0 +1,438 @@
+"""Stage-level autograd functions of the Sound-Bubble hot path on MI355X.
+
+One torch.autograd.Function per fused stage; forward and backward are sequences
+of HIP launches through the C ABI (sound_bubble_amd.ops).  Activations are
+channels-last [B, T, F, C] fp32 throughout (the `optim` layout of the reference,
+optim/tfgridnet_causal.py:398), so both the F-walk and the T-walk read contiguous
+C-vectors.  Tiny weight re-layouts (a few KB) are done with torch tensor ops.
+
+Reference lines each stage stands in for are cited in the docstrings.
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import Geom, H, dense
+
+ZC = 32          # padded channel count of the front-end feature tensor
+NSPEC = 304      # 290 STFT bins (re/im) padded to a multiple of 16
+
+
+def _lstm_param_grads(dg, ndir, geom_rows_steps, u, hs, Cc, shift_per_step, seg_len, skip, dirs_params):
+    """dW_ih, dW_hh, db for every direction from dgates [P, ndir, 4, 64].
+    hs: [P, ndir*64] hidden sequence; the previous-step hidden state of position p is
+    hs[p - shift] (direction 0) / hs[p + shift] (direction 1)."""
+    P = dg.shape[0]
+    ldg = ndir * 4 * H
+    grads = []
+    for d in range(ndir):
+        w_ih = dirs_params[d][0]
+        dW_ih = torch.zeros_like(w_ih)
+        dW_hh = torch.zeros(4 * H, H, device=dg.device, dtype=torch.float32)
+        db = torch.zeros(4 * H, device=dg.device, dtype=torch.float32)
+        g, s = dense(P, Cc)
+        ops.wgrad(dg, ldg, 4 * H, u, s, g, Cc, dW_ih, g_off=d * 4 * H)
+        g, s = dense(P, ndir * H)
+        sign = -1 if d == 0 else 1
+        ops.wgrad(dg, ldg, 4 * H, hs, s, g, H, dW_hh, g_off=d * 4 * H, in_off=d * H,
+                  in_shift=sign * shift_per_step * ndir * H, seg_len=seg_len,
+                  skip_first=skip if d == 0 else 0, skip_last=skip if d == 1 else 0)
+        ops.colsum(dg, P, ldg, 4 * H, db, g_off=d * 4 * H)
+        grads.append((dW_ih, dW_hh, db, db.clone()))
+    return grads
+
+
+class IntraPlainFn(torch.autograd.Function):
+    """y = x + Linear_{2H->C}(biLSTM_F(LN_C(x)))   -- dis_embd3/tfgridnet_causal.py:795,818-827;
+    optim/tfgridnet_causal.py:699-707."""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, lin_w, lin_b):
+        B, T, F, Cc = x.shape
+        x = x.contiguous()
+        P = B * T * F
+        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, ln_g, wif, lin_w))
+        geom = Geom.intra(B * T, F)
+        dirs = [(wif, whf, bif, bhf), (wir, whr, bir, bhr)]
+        hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train)
+        y = torch.empty_like(x)
+        g, s_in = dense(P, 2 * H)
+        _, s_out = dense(P, Cc)
+        ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, 2 * H, Cc, epi=L.EPI_RES, res=x)
+        if train:
+            ctx.save_for_backward(x, ln_g, wif, whf, wir, whr, lin_w, hs, gates, u)
+            ctx.dims = (B, T, F, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_g, wif, whf, wir, whr, lin_w, hs, gates, u = ctx.saved_tensors
+        B, T, F, Cc = ctx.dims
+        P = B * T * F
+        dy = dy.contiguous()
+        geom = Geom.intra(B * T, F)
+        gP, sC = dense(P, Cc)
+        _, s2H = dense(P, 2 * H)
+        # Linear backward
+        dhs = torch.empty(P, 2 * H, device=dy.device, dtype=torch.float32)
+        ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, s2H, Cc, 2 * H)
+        d_lin_w = torch.zeros_like(lin_w)
+        d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
+        ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, d_lin_w)
+        ops.colsum(dy, P, Cc, Cc, d_lin_b)
+        # BPTT
+        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
+        # input gradient through W_ih and the LayerNorm, + residual
+        wcat_t = torch.cat([wif, wir], 0).t().contiguous()            # [C, 512]
+        dx = torch.empty_like(x)
+        _, s8H = dense(P, 8 * H)
+        part = ops.linear(dg, wcat_t, None, dx, gP, s8H, sC, 8 * H, Cc, epi=L.EPI_LNBWD, aux_in=x, ln_g=ln_g,
+                          res=dy, want_partials=True)
+        d_g = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
+        d_b = torch.zeros_like(d_g)
+        ops.reduce_partials(part, Cc, d_g, 0)
+        ops.reduce_partials(part, Cc, d_b, Cc)
+        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(
+            dg, 2, None, u, hs, Cc, 1, F, 1, [(wif,), (wir,)])
+        return dx, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_lin_w, d_lin_b
+
+
+class InterFn(torch.autograd.Function):
+    """y = x + Linear_{H->C}(LSTM_T(LN_C(x)), carried (h0,c0))  -- dis_embd3/tfgridnet_causal.py:830-849;
+    optim :709-728.  Returns (y, hN, cN); the state rows are b*F+f as in the reference."""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0):
+        B, T, F, Cc = x.shape
+        x = x.contiguous()
+        P = B * T * F
+        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, ln_g, wi, lin_w))
+        geom = Geom.inter(B, T, F)
+        h0c = h0.reshape(B * F, H).contiguous() if h0 is not None else None
+        c0c = c0.reshape(B * F, H).contiguous() if c0 is not None else None
+        hs, (hN, cN), gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, [(wi, wh, bi, bh)], geom, h0=h0c, c0=c0c,
+                                              save=train, want_state=True)
+        y = torch.empty_like(x)
+        g, s_in = dense(P, H)
+        _, s_out = dense(P, Cc)
+        ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, H, Cc, epi=L.EPI_RES, res=x)
+        if train:
+            ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, gates, u)
+            ctx.dims = (B, T, F, Cc)
+        hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
+        ctx.mark_non_differentiable(hN, cN)
+        return y, hN, cN
+
+    @staticmethod
+    def backward(ctx, dy, _dh, _dc):
+        x, ln_g, wi, wh, lin_w, hs, gates, u = ctx.saved_tensors
+        B, T, F, Cc = ctx.dims
+        P = B * T * F
+        dy = dy.contiguous()
+        geom = Geom.inter(B, T, F)
+        gP, sC = dense(P, Cc)
+        _, sH = dense(P, H)
+        dhs = torch.empty(P, H, device=dy.device, dtype=torch.float32)
+        ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
+        d_lin_w = torch.zeros_like(lin_w)
+        d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
+        ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, d_lin_w)
+        ops.colsum(dy, P, Cc, Cc, d_lin_b)
+        dg = ops.lstm_bwd_rec([wh], gates, dhs, geom)
+        dx = torch.empty_like(x)
+        _, s4H = dense(P, 4 * H)
+        part = ops.linear(dg, wi.t().contiguous(), None, dx, gP, s4H, sC, 4 * H, Cc, epi=L.EPI_LNBWD, aux_in=x,
+                          ln_g=ln_g, res=dy, want_partials=True)
+        d_g = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
+        d_b = torch.zeros_like(d_g)
+        ops.reduce_partials(part, Cc, d_g, 0)
+        ops.reduce_partials(part, Cc, d_b, Cc)
+        # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
+        ((dwi, dwh, db1, db2),) = _lstm_param_grads(dg, 1, None, u, hs, Cc, F, T * F, F, [(wi,)])
+        return dx, d_g, d_b, dwi, dwh, db1, db2, d_lin_w, d_lin_b, None, None
+
+
+class IntraConvFn(torch.autograd.Function):
+    """Conv-LSTM intra path: Conv1d(C->C,k=s=down) -> PReLU -> LN -> biLSTM over F/down steps ->
+    ConvTranspose1d(2H->C,k=s=down) -> + x.   optim/tfgridnet_causal.py:684-697,706-707;
+    dis_embd3 :800-813 (bias_tail=False: frequencies beyond down*floor(F/down) get no deconv output)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, act_a, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, dec_w, dec_b,
+                down, bias_tail):
+        B, T, F, Cc = x.shape
+        x = x.contiguous()
+        Kd = F // down
+        Fm = Kd * down
+        P2 = B * T * Kd
+        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, conv_w, wif, dec_w))
+        dev = x.device
+        wc = conv_w.permute(0, 2, 1).reshape(Cc, down * Cc).contiguous()          # [co][j*C+ci]
+        v_pre = torch.empty(P2, Cc, device=dev, dtype=torch.float32) if train else None
+        a = torch.empty(P2, Cc, device=dev, dtype=torch.float32)
+        grid = (B * T, 1, Kd)
+        s_x = (F * Cc, 0, down * Cc)
+        s_a = (Kd * Cc, 0, Cc)
+        ops.linear(x, wc, conv_b, a, grid, s_x, s_a, down * Cc, Cc, epi=L.EPI_PRELU, prelu_a=act_a, aux_out=v_pre)
+        geom = Geom.intra(B * T, Kd)
+        dirs = [(wif, whf, bif, bhf), (wir, whr, bir, bhr)]
+        hs, _, gates, u = ops.lstm_fwd(a, ln_g, ln_b, dirs, geom, save=train)
+        wd = dec_w.permute(2, 1, 0).reshape(down * Cc, 2 * H).contiguous()        # [j*C+c][h]
+        bd = dec_b.repeat(down).contiguous()
+        y = torch.empty_like(x)
+        s_h = (Kd * 2 * H, 0, 2 * H)
+        ops.linear(hs, wd, bd, y, grid, s_h, s_x, 2 * H, down * Cc, epi=L.EPI_RES, res=x)
+        if Fm < F:      # tail frequencies: residual (+ bias when ConvTranspose1d has output_padding)
+            y[:, :, Fm:, :] = x[:, :, Fm:, :] + (dec_b if bias_tail else 0.0)
+        if train:
+            ctx.save_for_backward(x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, gates, u, v_pre)
+            ctx.dims = (B, T, F, Cc, down, Kd, bool(bias_tail))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, gates, u, v_pre = ctx.saved_tensors
+        B, T, F, Cc, down, Kd, bias_tail = ctx.dims
+        Fm = Kd * down
+        P2 = B * T * Kd
+        dev = dy.device
+        dy = dy.contiguous()
+        dym = dy if Fm == F else dy[:, :, :Fm, :].contiguous()        # dense rows [P2, down*C]
+        NC = down * Cc
+        grid = (B * T, 1, Kd)
+        gP2, sNC = dense(P2, NC)
+        _, s2H = dense(P2, 2 * H)
+        _, sC = dense(P2, Cc)
+        # ConvTranspose1d backward
+        dhs = torch.empty(P2, 2 * H, device=dev, dtype=torch.float32)
+        ops.linear(dym, wd.t().contiguous(), None, dhs, gP2, sNC, s2H, NC, 2 * H)
+        d_wd = torch.zeros(NC, 2 * H, device=dev, dtype=torch.float32)
+        ops.wgrad(dym, NC, NC, hs, s2H, gP2, 2 * H, d_wd)
+        d_bd = torch.zeros(NC, device=dev, dtype=torch.float32)
+        ops.colsum(dym, P2, NC, NC, d_bd)
+        d_dec_w = d_wd.view(down, Cc, 2 * H).permute(2, 1, 0).contiguous()
+        d_dec_b = d_bd.view(down, Cc).sum(0)
+        if Fm < F and bias_tail:
+            d_dec_b = d_dec_b + dy[:, :, Fm:, :].sum((0, 1, 2))
+        # BPTT
+        geom = Geom.intra(B * T, Kd)
+        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
+        # through W_ih, LayerNorm and PReLU -> gradient of the Conv1d output
+        wcat_t = torch.cat([wif, wir], 0).t().contiguous()
+        dv = torch.empty(P2, Cc, device=dev, dtype=torch.float32)
+        _, s8H = dense(P2, 8 * H)
+        part = ops.linear(dg, wcat_t, None, dv, gP2, s8H, sC, 8 * H, Cc, epi=L.EPI_LNBWD, aux_in=v_pre, ln_g=ln_g,
+                          prelu_a=act_a, want_partials=True)
+        d_g = torch.zeros(Cc, device=dev, dtype=torch.float32)
+        d_b = torch.zeros_like(d_g)
+        d_a = torch.zeros(1, device=dev, dtype=torch.float32)
+        ops.reduce_partials(part, Cc, d_g, 0)
+        ops.reduce_partials(part, Cc, d_b, Cc)
+        ops.reduce_partials(part, 1, d_a, 2 * Cc)
+        # Conv1d backward: dx = dy + dv . Wc ; dWc = dv^T x_rows
+        dx = torch.empty_like(x)
+        s_x = (F * Cc, 0, NC)
+        s_v = (Kd * Cc, 0, Cc)
+        ops.linear(dv, wc.t().contiguous(), None, dx, grid, s_v, s_x, Cc, NC, epi=L.EPI_RES, res=dy)
+        if Fm < F:
+            dx[:, :, Fm:, :] = dy[:, :, Fm:, :]
+        d_wc = torch.zeros(Cc, NC, device=dev, dtype=torch.float32)
+        ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, d_wc)
+        d_conv_w = d_wc.view(Cc, down, Cc).permute(0, 2, 1).contiguous()
+        d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
+        ops.colsum(dv, P2, Cc, Cc, d_conv_b)
+        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(
+            dg, 2, None, u, hs, Cc, 1, Kd, 1, [(wif,), (wir,)])
+        return (dx, d_conv_w, d_conv_b, d_a, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_dec_w,
+                d_dec_b, None, None)
+
+
+class FilmFn(torch.autograd.Function):
+    """y = x * w[b,f,c] + bias[b,f,c]  -- FilmLayer.forward, dis_embd3/tfgridnet_causal.py:59-68."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
+        ctx.save_for_backward(x, w)
+        return ops.film_fwd(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        return ops.film_bwd(x, w, dy.contiguous())
+
+
+def _stft_weight(filters):
+    """[290,1,288] asteroid filter bank -> [304, 288] analysis GEMM weight (zero rows 290..303)"""
+    f = filters.reshape(filters.shape[0], -1)
+    w = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
+    w[: f.shape[0]] = f
+    return w
+
+
+class FrontEndFn(torch.autograd.Function):
+    """STFT -> [re, im, ILD, IPD] features -> causal 3x3 Conv2d(27->C) -> LayerNorm(C).
+    dis_embd3/tfgridnet_causal.py:475-507 (+ :72-93, :32-48, :219-231, :332-354).
+    mix [B, M, Np] is already padded (net.py:70-74); conv_buf [B, 27, 2, F] is the carried
+    2-frame context.  Returns x0 [B,T,F,C] channels-last and the new conv_buf."""
+
+    @staticmethod
+    def forward(ctx, mix, enc_filters, conv_w, conv_b, ln_g, ln_b, conv_buf, use_ln, hop):
+        B, M, Np = mix.shape
+        win = enc_filters.shape[-1]
+        F = enc_filters.shape[0] // 2
+        Cc = conv_w.shape[0]
+        nfeat = conv_w.shape[1]
+        T = (Np - win) // hop + 1
+        dev = mix.device
+        mix = mix.contiguous()
+        train = torch.is_grad_enabled() and conv_w.requires_grad
+        # 1. STFT as a position-wise GEMM over overlapping rows
+        spec = torch.empty(B * M, T, NSPEC, device=dev, dtype=torch.float32)
+        ops.linear(mix, _stft_weight(enc_filters), None, spec, (B * M, T, 1), (Np, hop, 0), (T * NSPEC, NSPEC, 0),
+                   win, NSPEC)
+        # 2. features into the zero-bordered, channel-padded tensor zp [B, T+2, F+2, 32]
+        zp = torch.empty(B, T + 2, F + 2, ZC, device=dev, dtype=torch.float32)
+        zp[:, :2].zero_()
+        zp[:, :2, 1:F + 1, :nfeat] = conv_buf.permute(0, 2, 3, 1)
+        ops.features(spec, NSPEC, zp, B, M, T, F)
+        new_buf = zp[:, T:T + 2, 1:F + 1, :nfeat].permute(0, 3, 1, 2).contiguous()
+        # 3. 3x3 conv as 3 K-segments of 96 contiguous floats (+ fused LayerNorm)
+        wk = torch.zeros(Cc, 3, 3, ZC, device=dev, dtype=torch.float32)
+        wk[..., :nfeat] = conv_w.permute(0, 2, 3, 1)
+        wk = wk.view(Cc, 9 * ZC)
+        x0 = torch.empty(B, T, F, Cc, device=dev, dtype=torch.float32)
+        pre = torch.empty(B * T * F, Cc, device=dev, dtype=torch.float32) if (train and use_ln) else None
+        s_in = ((T + 2) * (F + 2) * ZC, (F + 2) * ZC, ZC)
+        s_out = (T * F * Cc, F * Cc, Cc)
+        ops.linear(zp, wk, conv_b, x0, (B, T, F), s_in, s_out, 9 * ZC, Cc, kseg=3 * ZC, is_seg=(F + 2) * ZC,
+                   epi=L.EPI_LN if use_ln else L.EPI_NONE, ln_g=ln_g if use_ln else None,
+                   ln_b=ln_b if use_ln else None, aux_out=pre)
+        if train:
+            ctx.save_for_backward(zp, pre, ln_g)
+            ctx.dims = (B, T, F, Cc, nfeat, bool(use_ln))
+        ctx.mark_non_differentiable(new_buf)
+        return x0, new_buf
+
+    @staticmethod
+    def backward(ctx, dx0, _dbuf):
+        zp, pre, ln_g = ctx.saved_tensors
+        B, T, F, Cc, nfeat, use_ln = ctx.dims
+        P = B * T * F
+        dev = dx0.device
+        dx0 = dx0.contiguous()
+        gP, sC = dense(P, Cc)
+        d_g = d_b = None
+        if use_ln:
+            dpre = torch.empty(P, Cc, device=dev, dtype=torch.float32)
+            eye = torch.eye(Cc, device=dev, dtype=torch.float32)
+            part = ops.linear(dx0, eye, None, dpre, gP, sC, sC, Cc, Cc, epi=L.EPI_LNBWD, aux_in=pre, ln_g=ln_g,
+                              want_partials=True)
+            d_g = torch.zeros(Cc, device=dev, dtype=torch.float32)
+            d_b = torch.zeros_like(d_g)
+            ops.reduce_partials(part, Cc, d_g, 0)
+            ops.reduce_partials(part, Cc, d_b, Cc)
+        else:
+            dpre = dx0.view(P, Cc)
+        d_wk = torch.zeros(Cc, 9 * ZC, device=dev, dtype=torch.float32)
+        s_in = ((T + 2) * (F + 2) * ZC, (F + 2) * ZC, ZC)
+        ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, d_wk, kseg=3 * ZC, is_seg=(F + 2) * ZC)
+        d_conv_w = d_wk.view(Cc, 3, 3, ZC)[..., :nfeat].permute(0, 3, 1, 2).contiguous()
+        d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
+        ops.colsum(dpre, P, Cc, Cc, d_conv_b)
+        return None, None, d_conv_w, d_conv_b, d_g, d_b, None, None, None
+
+
+def _istft_weights(dec_filters):
+    """asteroid synthesis bank [290,1,288] -> GEMM weights for interleaved (re,im) spectra rows:
+    w_syn [288, 304] (frames = spec_row . w_syn^T) and w_ana [304, 288] (its transpose, for the gradient)."""
+    f = dec_filters.reshape(dec_filters.shape[0], -1)               # [2F, win], rows: re(0..F-1), im(F..2F-1)
+    Fq = f.shape[0] // 2
+    inter = torch.stack([f[:Fq], f[Fq:]], dim=1).reshape(2 * Fq, -1)    # row 2f+o
+    w_ana = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
+    w_ana[: 2 * Fq] = inter
+    return w_ana.t().contiguous(), w_ana
+
+
+class BackEndFn(torch.autograd.Function):
+    """causal ConvTranspose2d(C->2,(3,3),padding(2,1)) -> iSTFT (conv_transpose1d overlap-add) -> crops.
+    dis_embd3/tfgridnet_causal.py:517-542.  y [B,T,F,C]; returns wave [B,1,hop*T], new deconv_buf [B,C,2,F],
+    new istft_buf [B,1,2F,1]."""
+
+    @staticmethod
+    def forward(ctx, y, dec_filters, dw, db, deconv_buf, istft_buf, hop):
+        B, T, F, Cc = y.shape
+        dev = y.device
+        win = dec_filters.shape[-1]
+        train = torch.is_grad_enabled() and (y.requires_grad or dw.requires_grad)
+        assert dw.shape[1] == 2, "num_src=1 only (every shipped config)"
+        yp = torch.zeros(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)
+        yp[:, :2, 1:F + 1] = deconv_buf.permute(0, 2, 3, 1)
+        yp[:, 2:, 1:F + 1] = y
+        new_dbuf = yp[:, T:T + 2, 1:F + 1].permute(0, 3, 1, 2).contiguous()
+        # spectrum rows [B, T+1, 304], interleaved (re,im) per frequency; row 0 = carried frame
+        rows = torch.zeros(B, T + 1, NSPEC, device=dev, dtype=torch.float32)
+        ib = istft_buf.reshape(B, 2, F)                                           # [re | im]
+        rows[:, 0, : 2 * F] = ib.permute(0, 2, 1).reshape(B, 2 * F)
+        wk = torch.zeros(16, 3, 3, Cc, device=dev, dtype=torch.float32)          # [o][a][d][c] = W[c,o,2-a,2-d]
+        wk[:2] = dw.flip(2, 3).permute(1, 2, 3, 0)
+        wk = wk.view(16, 9 * Cc)
+        bk = torch.zeros(16, device=dev, dtype=torch.float32)
+        bk[:2] = db
+        s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
+        ops.linear(yp, wk, bk, rows, (B, T, F), s_in, ((T + 1) * NSPEC, NSPEC, 2), 9 * Cc, 16, kseg=3 * Cc,
+                   is_seg=(F + 2) * Cc, n_valid=2, out_off=NSPEC)
+        w_syn, w_ana = _istft_weights(dec_filters)
+        frames = torch.empty(B, T + 1, win, device=dev, dtype=torch.float32)
+        g, s_r = dense(B * (T + 1), NSPEC)
+        _, s_f = dense(B * (T + 1), win)
+        ops.linear(rows, w_syn, None, frames, g, s_r, s_f, NSPEC, win)
+        wave = ops.overlap_add(frames, B, T, win, hop)
+        last = rows[:, T, : 2 * F].reshape(B, F, 2).permute(0, 2, 1)              # [B, 2, F]
+        new_ibuf = last.reshape(B, 1, 2 * F, 1).contiguous()
+        if train:
+            ctx.save_for_backward(yp, dw, w_ana)
+            ctx.dims = (B, T, F, Cc, win, hop)
+        ctx.mark_non_differentiable(new_dbuf, new_ibuf)
+        return wave.view(B, 1, hop * T), new_dbuf, new_ibuf
+
+    @staticmethod
+    def backward(ctx, dwave, _d1, _d2):
+        yp, dw, w_ana = ctx.saved_tensors
+        B, T, F, Cc, win, hop = ctx.dims
+        dev = dwave.device
+        dframes = ops.overlap_add_bwd(dwave.contiguous().view(B, hop * T), B, T, win, hop)
+        drows = torch.empty(B, T + 1, NSPEC, device=dev, dtype=torch.float32)
+        g, s_f = dense(B * (T + 1), win)
+        _, s_r = dense(B * (T + 1), NSPEC)
+        ops.linear(dframes, w_ana, None, drows, g, s_f, s_r, win, NSPEC)
+        dspec = drows[:, 1:, : 2 * F].contiguous()                                # [B,T,F,2]
+        dy = ops.deconv_bwd_data(dspec, dw.contiguous(), B, T, F, Cc)
+        P = B * T * F
+        d_wk = torch.zeros(2, 9 * Cc, device=dev, dtype=torch.float32)
+        s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
+        ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, d_wk, kseg=3 * Cc, is_seg=(F + 2) * Cc)
+        d_dw = d_wk.view(2, 3, 3, Cc).permute(3, 0, 1, 2).flip(2, 3).contiguous()
+        d_db = torch.zeros(2, device=dev, dtype=torch.float32)
+        ops.colsum(dspec, P, 2, 2, d_db)
+        return dy, None, d_dw, d_db, None, None, None
+
+
+class SnrlpLossFn(torch.autograd.Function):
+    """mean_b SNRLPLoss(est, gt)[b]  -- src/losses/SNRLP.py:17-42 + hl_module:321 (.mean())."""
+
+    @staticmethod
+    def forward(ctx, est, gt, neg_weight):
+        B = est.shape[0]
+        e = est.reshape(B, -1).contiguous()
+        t = gt.reshape(B, -1).contiguous()
+        lv, dest = ops.snrlp_loss(e, t, neg_weight, want_grad=est.requires_grad)
+        ctx.save_for_backward(dest)
+        ctx.shape = est.shape
+        ctx.mark_non_differentiable(lv)
+        return lv.mean(), lv
+
+    @staticmethod
+    def backward(ctx, gout, _glv):
+        (dest,) = ctx.saved_tensors
+        return (dest * gout).view(ctx.shape), None, None

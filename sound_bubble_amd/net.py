@@ -1,0 +1,250 @@
+"""Drop-in `Net` for the two Sound-Bubble model families, running on HIP kernels.
+
+Boundary kept from the reference:
+  * constructor keywords of  src/models/tfgridnet_realtime_clean_dis_embd3/net.py:21-26  (NetDisEmbd3)
+    and                      src/models/tfgridnet_realtime_clean_optim/net.py:21-26      (NetOptim);
+  * forward(inputs: dict, input_state=None, pad=True) -> {'output', 'next_state'}  (net.py:84-93);
+  * init_buffers(batch_size, device) with the reference's nested state layout (tfgridnet_causal.py:403-421,696-720);
+  * parameter / buffer names and shapes of the reference state_dict, so reference
+    checkpoints load with strict=True; parameters are created by the same torch initialisers in the
+    same order, so the same seed gives the same weights as the reference.
+The modules below only HOLD parameters; all arithmetic is in sound_bubble_amd.functional (HIP).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as tF
+
+from . import functional as Fn
+
+
+def stft_filter_bank(n_fft, stride):
+    """asteroid_filterbanks STFTFB(n_filters=kernel_size=n_fft, stride) restated: sqrt-periodic-hann x DFT,
+    scaled 1/(0.5*sqrt(n_fft*n_fft/stride)), DC/Nyquist real rows /sqrt(2).  (third-party)"""
+    n = np.arange(n_fft)
+    win = np.sqrt(0.5 - 0.5 * np.cos(2 * np.pi * n / n_fft))
+    k = np.arange(n_fft // 2 + 1)[:, None]
+    ang = 2 * np.pi * k * n[None, :] / n_fft
+    scale = 0.5 * np.sqrt(n_fft * n_fft / stride)
+    filt = np.vstack([np.cos(ang) / scale, -np.sin(ang) / scale])
+    filt[0] /= np.sqrt(2)
+    filt[n_fft // 2] /= np.sqrt(2)
+    return torch.from_numpy(filt * win[None, :]).float().unsqueeze(1)
+
+
+class _Params(nn.Module):
+    """Parameter holder: adopts the (freshly initialised) parameters of a torch module under the same
+    names; it has no forward -- the math runs in HIP."""
+
+    def __init__(self, module=None, **children):
+        super().__init__()
+        if module is not None:
+            for n, p in module.named_parameters(recurse=False):
+                self.register_parameter(n, p)
+        for n, c in children.items():
+            self.add_module(n, c)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter holder: the computation is done by sound_bubble_amd HIP kernels")
+
+
+class _FilterBank(nn.Module):
+    def __init__(self, n_fft, stride):
+        super().__init__()
+        self.register_buffer("_filters", stft_filter_bank(n_fft, stride))
+        self.register_buffer("_sample_rate", torch.zeros(1) + 8000.0)
+
+
+class _ParamList(nn.ModuleList):
+    pass
+
+
+def _block_params(C, H, conv_lstm, lstm_down, F_, flavour):
+    b = _Params()
+    if conv_lstm:
+        b.add_module("conv", _Params(nn.Conv1d(C, C, lstm_down, stride=lstm_down)))
+        b.add_module("act", _Params(nn.PReLU()))
+        b.add_module("norm", _Params(norm=_Params(nn.LayerNorm(C))))
+        b.add_module("intra_rnn", _Params(nn.LSTM(C, H, 1, batch_first=True, bidirectional=True)))
+        b.add_module("deconv", _Params(nn.ConvTranspose1d(2 * H, C, lstm_down, stride=lstm_down)))
+    else:
+        b.add_module("intra_norm", _Params(norm=_Params(nn.LayerNorm(C))))
+        b.add_module("intra_rnn", _Params(nn.LSTM(C, H, 1, batch_first=True, bidirectional=True)))
+        b.add_module("intra_linear", _Params(nn.Linear(2 * H, C)))
+    b.add_module("inter_norm", _Params(norm=_Params(nn.LayerNorm(C))))
+    b.add_module("inter_rnn", _Params(nn.LSTM(C, H, 1, batch_first=True)))
+    b.add_module("inter_linear", _Params(nn.Linear(H, C)))
+    return b
+
+
+class _TFGridNetParams(nn.Module):
+    def __init__(self, n_fft, stride, n_imics, C, n_layers, H, conv_lstm, lstm_down, flavour, n_srcs,
+                 use_first_ln, dis_type):
+        super().__init__()
+        F_ = n_fft // 2 + 1
+        n_feat = 2 * n_imics + 3 * (n_imics - 1)
+        self.enc = _Params(filterbank=_FilterBank(n_fft, stride))
+        self.dec = _Params(filterbank=_FilterBank(n_fft, stride))
+        conv = _ParamList([_Params(nn.Conv2d(n_feat, C, (3, 3), padding=(0, 1)))])
+        if use_first_ln:
+            conv.append(_Params(nn.LayerNorm(C)))
+        self.conv = conv
+        if flavour == "dis_embd3":
+            d_in = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8}[dis_type]
+            self.embed_net = _Params(dis_embedding=_ParamList([_Params(nn.Linear(3, F_ * d_in, bias=False))]),
+                                     dis_norm=_Params(nn.LayerNorm(d_in)))
+            self.d_in = d_in
+        self.blocks = _ParamList()
+        if flavour == "dis_embd3":
+            self.embeds = _ParamList()
+        for i in range(n_layers):
+            self.blocks.append(_block_params(C, H, conv_lstm, lstm_down, F_, flavour))
+            if flavour == "dis_embd3" and i > 0:
+                self.embeds.append(_Params(weight=_Params(nn.Conv1d(d_in, C, 1)), bias=_Params(nn.Conv1d(d_in, C, 1))))
+        self.deconv = _Params(nn.ConvTranspose2d(C, 2 * n_srcs, (3, 3), padding=(2, 1)))
+
+
+def _lstm_dir(p, rev):
+    s = "_reverse" if rev else ""
+    return (getattr(p, "weight_ih_l0" + s), getattr(p, "weight_hh_l0" + s),
+            getattr(p, "bias_ih_l0" + s), getattr(p, "bias_hh_l0" + s))
+
+
+class _NetBase(nn.Module):
+    flavour = None
+
+    def _build(self, stft_chunk_size, stft_pad_size, stft_back_pad, num_ch, D, B, I, J, L, H, use_attn, lookahead,
+               local_atten_len, E, chunk_causal, num_src, spectral_masking, use_first_ln, merge_method, directional,
+               conv_lstm, lstm_down, fb_type, dis_type):
+        if use_attn:
+            raise NotImplementedError("use_attn=True: full-band attention is off in every shipped config "
+                                      "(SURVEY.md F4) and not built yet")
+        if H != 64:
+            raise NotImplementedError("the recurrent HIP kernels are built for H=64 (every shipped config)")
+        if D not in (16, 32):
+            raise NotImplementedError("D must be 16 or 32 (shipped configs)")
+        if merge_method != "early_cat" or directional or spectral_masking or stft_back_pad != 0 or fb_type != "stft":
+            raise NotImplementedError("only merge_method='early_cat', omnidirectional, no spectral masking, "
+                                      "stft_back_pad=0 (every shipped config)")
+        if num_src != 1 or num_ch != 6:
+            raise NotImplementedError("num_src=1 and num_ch=6 only (every shipped config)")
+        self.stft_chunk_size, self.stft_pad_size, self.stft_back_pad = stft_chunk_size, stft_pad_size, stft_back_pad
+        self.num_ch, self.lookahead, self.embed_dim, self.E = num_ch, lookahead, D, E
+        self.nfft = stft_back_pad + stft_chunk_size + stft_pad_size
+        self.n_freqs = self.nfft // 2 + 1
+        self.n_layers, self.H, self.num_src = B, H, num_src
+        self.conv_lstm, self.lstm_down, self.use_first_ln = conv_lstm, lstm_down, use_first_ln
+        self.n_feat = 2 * num_ch + 3 * (num_ch - 1)
+        self.tfgridnet = _TFGridNetParams(self.nfft, stft_chunk_size, num_ch, D, B, H, conv_lstm, lstm_down,
+                                          self.flavour, num_src, use_first_ln, dis_type)
+        if self.nfft % 16 or (self.nfft // 2 + 1) * 2 > Fn.NSPEC:
+            raise NotImplementedError("n_fft must be a multiple of 16 and <= 302")
+
+    # ---- state (reference layout) ----
+    def init_buffers(self, batch_size, device):
+        F_, C = self.n_freqs, self.embed_dim
+        z = lambda *s: torch.zeros(*s, device=device)
+        bufs = {f"buf{i}": {"c0": z(1, batch_size * F_, self.H), "h0": z(1, batch_size * F_, self.H)}
+                for i in range(self.n_layers)}
+        return dict(conv_buf=z(batch_size, self.n_feat, 2, F_), deconv_buf=z(batch_size, C, 2, F_),
+                    istft_buf=z(batch_size, self.num_src, 2 * F_, 1), gridnet_bufs=bufs)
+
+    def _embed(self, dis_embed):
+        return None
+
+    def _film(self, x, e, i):
+        return x
+
+    def forward(self, inputs, input_state=None, pad=True):
+        x = inputs["mixture"]
+        if not x.is_cuda:
+            raise RuntimeError("sound_bubble_amd.Net runs on the GPU only (HIP kernels); move inputs to cuda")
+        if input_state is None:
+            input_state = self.init_buffers(x.shape[0], x.device)
+        mod = 0
+        if pad:
+            if x.shape[-1] % self.stft_chunk_size:
+                mod = self.stft_chunk_size - x.shape[-1] % self.stft_chunk_size
+            x = tF.pad(x, (0, mod + (self.stft_pad_size if self.lookahead else 0)))
+        tg = self.tfgridnet
+        st = input_state
+        e = self._embed(inputs.get("dis_embed"))
+        ln = tg.conv[1] if self.use_first_ln else None
+        y, st["conv_buf"] = Fn.FrontEndFn.apply(
+            x.float(), tg.enc.filterbank._filters, tg.conv[0].weight, tg.conv[0].bias,
+            ln.weight if ln is not None else None, ln.bias if ln is not None else None, st["conv_buf"],
+            self.use_first_ln, self.stft_chunk_size)
+        gb = st["gridnet_bufs"]
+        for i, blk in enumerate(tg.blocks):
+            y = self._film(y, e, i)
+            rnn = blk.intra_rnn
+            if self.conv_lstm:
+                y = Fn.IntraConvFn.apply(y, blk.conv.weight, blk.conv.bias, blk.act.weight, blk.norm.norm.weight,
+                                         blk.norm.norm.bias, *_lstm_dir(rnn, False), *_lstm_dir(rnn, True),
+                                         blk.deconv.weight, blk.deconv.bias, self.lstm_down,
+                                         self.flavour == "optim")
+            else:
+                y = Fn.IntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
+                                          *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
+                                          blk.intra_linear.bias)
+            b = gb[f"buf{i}"]
+            y, b["h0"], b["c0"] = Fn.InterFn.apply(y, blk.inter_norm.norm.weight, blk.inter_norm.norm.bias,
+                                                   *_lstm_dir(blk.inter_rnn, False), blk.inter_linear.weight,
+                                                   blk.inter_linear.bias, b["h0"], b["c0"])
+        out, st["deconv_buf"], st["istft_buf"] = Fn.BackEndFn.apply(
+            y, tg.dec.filterbank._filters, tg.deconv.weight, tg.deconv.bias, st["deconv_buf"], st["istft_buf"],
+            self.stft_chunk_size)
+        if mod:
+            out = out[..., :-mod]
+        return {"output": out, "next_state": st}
+
+
+class NetDisEmbd3(_NetBase):
+    """`src.models.tfgridnet_realtime_clean_dis_embd3.net.Net` (syn_experiments/*.json)."""
+    flavour = "dis_embd3"
+
+    def __init__(self, stft_chunk_size=160, stft_pad_size=120, stft_back_pad=0, num_ch=2, D=64, B=6, I=1, J=1, L=0,
+                 H=128, use_attn=False, lookahead=True, local_atten_len=100, E=4, chunk_causal=False, num_src=1,
+                 spectral_masking=False, use_first_ln=False, merge_method="None", directional=False, conv_lstm=True,
+                 fb_type="stft", dis_type="conv3"):
+        super().__init__()
+        # the dis_embd3 wrapper never forwards lstm_down: the core default 4 applies (tfgridnet_causal.py:282)
+        self._build(stft_chunk_size, stft_pad_size, stft_back_pad, num_ch, D, B, I, J, L, H, use_attn, lookahead,
+                    local_atten_len, E, chunk_causal, num_src, spectral_masking, use_first_ln, merge_method,
+                    directional, conv_lstm, 4, fb_type, dis_type)
+
+    def _embed(self, dis_embed):
+        # Dis_Embed_Conv (tfgridnet_causal.py:164-173): [B,3] -> LN_4(view [B,F,4]); a few KB, kept in torch
+        en = self.tfgridnet.embed_net
+        d_in = self.tfgridnet.d_in
+        e = tF.linear(dis_embed.float(), en.dis_embedding[0].weight).view(dis_embed.shape[0], self.n_freqs, d_in)
+        return tF.layer_norm(e, (d_in,), en.dis_norm.weight, en.dis_norm.bias, 1e-5)      # [B,F,4]
+
+    def _film(self, x, e, i):
+        if i == 0:
+            return x
+        fl = self.tfgridnet.embeds[i - 1]
+        w = tF.linear(e, fl.weight.weight[:, :, 0], fl.weight.bias)          # [B,F,C]
+        b = tF.linear(e, fl.bias.weight[:, :, 0], fl.bias.bias)
+        return Fn.FilmFn.apply(x, w, b)
+
+    def forward(self, inputs, input_state=None, pad=True):
+        if "dis_embed" not in inputs:
+            raise KeyError("dis_embed")
+        return super().forward(inputs, input_state, pad)
+
+
+class NetOptim(_NetBase):
+    """`src.models.tfgridnet_realtime_clean_optim.net.Net` (real_experiments/*.json, edge/)."""
+    flavour = "optim"
+
+    def __init__(self, stft_chunk_size=160, stft_pad_size=120, stft_back_pad=0, num_ch=2, D=64, B=6, I=1, J=1, L=0,
+                 H=128, use_attn=False, lookahead=True, local_atten_len=100, E=4, chunk_causal=False, num_src=1,
+                 spectral_masking=False, use_first_ln=False, merge_method="None", directional=False, conv_lstm=True,
+                 lstm_down=5, fb_type="stft"):
+        super().__init__()
+        self._build(stft_chunk_size, stft_pad_size, stft_back_pad, num_ch, D, B, I, J, L, H, use_attn, lookahead,
+                    local_atten_len, E, chunk_causal, num_src, spectral_masking, use_first_ln, merge_method,
+                    directional, conv_lstm, lstm_down, fb_type, None)

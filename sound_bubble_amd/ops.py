@@ -1,0 +1,234 @@
+"""Tensor-level wrappers over the C ABI (include/sound_bubble_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every wrapper
+checks that its tensors are fp32, contiguous and on a HIP device and raises
+otherwise -- there is no eager fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+H = 64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, name="tensor"):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise L.SoundBubbleHipError(f"{name}: expected a float32 tensor on the GPU, got "
+                                    f"{type(t).__name__} {getattr(t, 'dtype', '')} {getattr(t, 'device', '')}")
+    if not t.is_contiguous():
+        raise L.SoundBubbleHipError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _poff(t, off_floats):
+    """pointer to element `off_floats` of contiguous fp32 tensor t"""
+    _p(t)
+    return C.c_void_p(t.data_ptr() + 4 * int(off_floats))
+
+
+class Geom:
+    """Sequence geometry of one recurrent pass over the dense position grid."""
+
+    def __init__(self, nseq, nsteps, n_inner, p_outer, p_inner, p_step):
+        self.nseq, self.nsteps, self.n_inner = int(nseq), int(nsteps), int(n_inner)
+        self.p_outer, self.p_inner, self.p_step = int(p_outer), int(p_inner), int(p_step)
+        self.P = self.nseq * self.nsteps
+
+    @staticmethod
+    def intra(n_rows, n_steps):     # sequences = rows (b,t), steps along the last grid axis
+        return Geom(n_rows, n_steps, n_rows, 0, n_steps, 1)
+
+    @staticmethod
+    def inter(B, T, F):             # sequences = (b,f), steps along t
+        return Geom(B * F, T, F, T * F, 1, F)
+
+
+def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False):
+    """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
+    -> hs [P, ndir*64], (hN, cN) or None, save_gates or None, save_u or None"""
+    lib = L.load()
+    ndir, Cc = len(dirs), x.shape[-1]
+    assert x.numel() == geom.P * Cc
+    dev = x.device
+    hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float32)
+    gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32) if save else None
+    u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32) if save else None
+    hN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
+    cN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
+    a = L.LstmFwdArgs()
+    a.nseq, a.nsteps, a.n_inner, a.ndir, a.C = geom.nseq, geom.nsteps, geom.n_inner, ndir, Cc
+    a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
+    a.x, a.ln_g, a.ln_b = _p(x, "x"), _p(ln_g, "ln_g"), _p(ln_b, "ln_b")
+    for d, (wi, wh, bi, bh) in enumerate(dirs):
+        assert wi.shape == (4 * H, Cc) and wh.shape == (4 * H, H)
+        a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
+    a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
+    a.hs, a.save_gates, a.save_u = _p(hs), _p(gates), _p(u)
+    L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
+    return hs, ((hN, cN) if want_state else None), gates, u
+
+
+def lstm_bwd_rec(w_hh_list, gates, dhs, geom):
+    lib = L.load()
+    ndir = len(w_hh_list)
+    dg = torch.empty(geom.P, ndir, 4, H, device=dhs.device, dtype=torch.float32)
+    a = L.LstmBwdArgs()
+    a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, ndir
+    a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
+    for d, wh in enumerate(w_hh_list):
+        a.w_hh[d] = _p(wh)
+    a.save_gates, a.dhs, a.dgates = _p(gates), _p(dhs), _p(dg)
+    L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
+    return dg
+
+
+def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None, is_seg=0, n_valid=None,
+           epi=L.EPI_NONE, res=None, res_strides=None, prelu_a=None, ln_g=None, ln_b=None, aux_in=None,
+           aux_out=None, want_partials=False, accumulate=False, in_off=0, out_off=0, res_off=0):
+    """out[p, :N] = epi(W[N,K] . in(p, :K) + bias).  grid = (B, T, F); strides in floats.
+    N is chunked into <=128-wide launches when needed (not for LN epilogues)."""
+    lib = L.load()
+    B_, T_, F_ = grid
+    n_valid = N if n_valid is None else n_valid
+    assert w.shape == (N, K) and w.is_contiguous()
+    partials = None
+    n0 = 0
+    while n0 < N:
+        nc = min(128, N - n0)
+        if nc not in (16, 32, 48, 64, 80, 96, 128):       # NT in {1,2,3,4,5,6,8}
+            nc = 96 if nc > 96 else 64
+        a = L.LinearArgs()
+        a.B, a.T, a.F, a.N, a.K = B_, T_, F_, nc, K
+        a.n_valid = max(0, min(nc, n_valid - n0))
+        a.kseg = K if kseg is None else kseg
+        a.epi = epi
+        a.inp = _poff(inp, in_off)
+        a.is_b, a.is_t, a.is_f = in_strides
+        a.is_seg = is_seg
+        a.w = _poff(w, n0 * K)
+        a.bias = _poff(bias, n0) if bias is not None else None
+        a.out = _poff(out, out_off + n0)
+        a.os_b, a.os_t, a.os_f = out_strides
+        if res is not None:
+            a.res = _poff(res, res_off + n0)
+            a.rs_b, a.rs_t, a.rs_f = res_strides if res_strides is not None else out_strides
+        a.prelu_a, a.ln_g, a.ln_b = _p(prelu_a), _p(ln_g), _p(ln_b)
+        a.aux_in, a.aux_out = _p(aux_in), _p(aux_out)
+        if want_partials:
+            assert n0 == 0 and nc == N
+            g = lib.sb_linear_grid(B_ * T_ * F_)
+            partials = torch.empty(g, 2 * N + 1, device=out.device, dtype=torch.float32)
+            a.partials = _p(partials)
+        a.accumulate = 1 if accumulate else 0
+        if a.n_valid > 0:
+            L.check(lib.sb_linear_fwd(C.byref(a), _stream()), "sb_linear_fwd")
+        n0 += nc
+    return partials
+
+
+def dense(P, ld):
+    """(grid, strides) describing P dense rows of length ld"""
+    return (1, 1, int(P)), (0, 0, int(ld))
+
+
+def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=None, is_seg=0, in_shift=0,
+          seg_len=None, skip_first=0, skip_last=0, transpose_out=False):
+    """dW[N,K] += sum_p g[p, :N]^T in(p, :K)"""
+    lib = L.load()
+    B_, T_, F_ = grid
+    P = B_ * T_ * F_
+    ng = lib.sb_wgrad_grid(P)
+    scratch = torch.empty(ng, N * K, device=dW.device, dtype=torch.float32)
+    a = L.WgradArgs()
+    a.B, a.T, a.F, a.N, a.K = B_, T_, F_, N, K
+    a.kseg = ((K + 15) // 16) * 16 if kseg is None else kseg
+    a.g, a.ldg = _poff(g, g_off), ldg
+    a.inp = _poff(inp, in_off)
+    a.is_b, a.is_t, a.is_f = in_strides
+    a.is_seg, a.in_shift = is_seg, in_shift
+    a.seg_len = P if seg_len is None else seg_len
+    a.skip_first, a.skip_last = skip_first, skip_last
+    a.transpose_out = 1 if transpose_out else 0
+    a.dW, a.scratch = _p(dW, "dW"), _p(scratch)
+    L.check(lib.sb_wgrad(C.byref(a), _stream()), "sb_wgrad")
+
+
+def colsum(g, P, ldg, N, out, g_off=0):
+    """out[:N] += sum_p g[p*ldg + :N]"""
+    lib = L.load()
+    scratch = torch.empty(256, N, device=out.device, dtype=torch.float32)
+    L.check(lib.sb_colsum(_poff(g, g_off), P, ldg, N, _p(out), _p(scratch), _stream()), "sb_colsum")
+
+
+def reduce_partials(partials, n, out, col_off=0):
+    """out[:n] += sum_rows partials[:, col_off:col_off+n]"""
+    lib = L.load()
+    rows, ld = partials.shape
+    L.check(lib.sb_reduce_rows(_poff(partials, col_off), rows, ld, n, _p(out), _stream()), "sb_reduce_rows")
+
+
+def features(spec, ld_spec, zp, B, M, T, F):
+    L.check(L.load().sb_features(_p(spec), ld_spec, _p(zp), B, M, T, F, _stream()), "sb_features")
+
+
+def film_fwd(x, w, b):
+    B_, T_, F_, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().sb_film_fwd(_p(x), _p(w), _p(b), _p(y), B_, T_, F_, Cc, _stream()), "sb_film_fwd")
+    return y
+
+
+def film_bwd(x, w, dy):
+    B_, T_, F_, Cc = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.zeros(B_, F_, Cc, device=x.device, dtype=torch.float32)
+    db = torch.zeros_like(dw)
+    L.check(L.load().sb_film_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), B_, T_, F_, Cc, _stream()),
+            "sb_film_bwd")
+    return dx, dw, db
+
+
+def overlap_add(frames, B, T, win, hop):
+    wave = torch.empty(B, hop * T, device=frames.device, dtype=torch.float32)
+    L.check(L.load().sb_overlap_add(_p(frames), _p(wave), B, T, win, hop, _stream()), "sb_overlap_add")
+    return wave
+
+
+def overlap_add_bwd(dwave, B, T, win, hop):
+    df = torch.empty(B, T + 1, win, device=dwave.device, dtype=torch.float32)
+    L.check(L.load().sb_overlap_add_bwd(_p(dwave), _p(df), B, T, win, hop, _stream()), "sb_overlap_add_bwd")
+    return df
+
+
+def deconv_bwd_data(dspec, w, B, T, F, Cc):
+    dy = torch.empty(B, T, F, Cc, device=dspec.device, dtype=torch.float32)
+    L.check(L.load().sb_deconv_bwd_data(_p(dspec), _p(w), _p(dy), B, T, F, Cc, _stream()), "sb_deconv_bwd_data")
+    return dy
+
+
+def snrlp_loss(est, gt, neg_weight, want_grad):
+    """est, gt [B, N] -> loss_vec [B], d(mean loss)/d est or None"""
+    B_, N = est.shape
+    stats = torch.empty(B_, 8, device=est.device, dtype=torch.float32)
+    lv = torch.empty(B_, device=est.device, dtype=torch.float32)
+    dest = torch.empty_like(est) if want_grad else None
+    L.check(L.load().sb_snrlp_loss(_p(est), _p(gt), B_, N, float(neg_weight), _p(stats), _p(lv), _p(dest), _stream()),
+            "sb_snrlp_loss")
+    return lv, dest
+
+
+def sumsq(g, out):
+    L.check(L.load().sb_sumsq(_p(g), g.numel(), _p(out), _stream()), "sb_sumsq")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gscale=1.0, clip=0.0, sumsq_buf=None):
+    L.check(L.load().sb_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step),
+                                  float(gscale), float(clip), _p(sumsq_buf), _stream()), "sb_adam_step")

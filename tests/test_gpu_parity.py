@@ -1,0 +1,193 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI
+(sound_bubble_amd.ops -> libsoundbubble_hip.so); the oracle / golden vectors are the checker."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_state_dict, rel_l2, flatten_state
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = 2e-5        # measured ~1e-6; the north-star bar is 1e-3 relative L2
+TOL_GRAD = 2e-3
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from sound_bubble_amd import _lib
+    _lib.load()
+    return torch
+
+
+def _lstm_ref(torch, x, ln, lstm, h0=None, c0=None):
+    u = torch.nn.functional.layer_norm(x, (x.shape[-1],), ln[0], ln[1], 1e-5)
+    if h0 is None:
+        return lstm(u)
+    return lstm(u, (h0, c0))
+
+
+@pytest.mark.parametrize("C", [16, 32])
+def test_lstm_fwd_intra_bidirectional(torch_gpu, C):
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    torch.manual_seed(C)
+    nseq, S = 37, 29          # ragged: not a multiple of the 16-sequence tile
+    lstm = torch.nn.LSTM(C, 64, 1, batch_first=True, bidirectional=True)
+    g, b = torch.randn(C) * 0.5 + 1, torch.randn(C) * 0.1
+    x = torch.randn(nseq, S, C)
+    ref, _ = _lstm_ref(torch, x, (g, b), lstm)
+    d = lambda t: t.detach().cuda().contiguous()
+    dirs = [(d(lstm.weight_ih_l0), d(lstm.weight_hh_l0), d(lstm.bias_ih_l0), d(lstm.bias_hh_l0)),
+            (d(lstm.weight_ih_l0_reverse), d(lstm.weight_hh_l0_reverse), d(lstm.bias_ih_l0_reverse),
+             d(lstm.bias_hh_l0_reverse))]
+    hs, _, gates, u = ops.lstm_fwd(d(x).view(-1, C), d(g), d(b), dirs, ops.Geom.intra(nseq, S), save=True)
+    assert rel_l2(hs.cpu().view(nseq, S, 128).numpy(), ref.detach().numpy()) < 5e-6
+    uref = torch.nn.functional.layer_norm(x, (C,), g, b, 1e-5)
+    assert rel_l2(u.cpu().view(nseq, S, C).numpy(), uref.numpy()) < 2e-6
+    assert np.isfinite(gates.cpu().numpy()).all()
+
+
+def test_lstm_fwd_inter_with_state(torch_gpu):
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    torch.manual_seed(3)
+    B, T, F, C = 2, 11, 21, 32
+    lstm = torch.nn.LSTM(C, 64, 1, batch_first=True)
+    g, b = torch.randn(C) * 0.5 + 1, torch.randn(C) * 0.1
+    x = torch.randn(B, T, F, C)
+    h0, c0 = torch.randn(1, B * F, 64) * 0.3, torch.randn(1, B * F, 64) * 0.3
+    xs = x.transpose(1, 2).reshape(B * F, T, C)
+    ref, (hn, cn) = _lstm_ref(torch, xs, (g, b), lstm, h0, c0)
+    ref = ref.view(B, F, T, 64).transpose(1, 2)
+    d = lambda t: t.detach().cuda().contiguous()
+    dirs = [(d(lstm.weight_ih_l0), d(lstm.weight_hh_l0), d(lstm.bias_ih_l0), d(lstm.bias_hh_l0))]
+    hs, (hN, cN), _, _ = ops.lstm_fwd(d(x).view(-1, C), d(g), d(b), dirs, ops.Geom.inter(B, T, F),
+                                      h0=d(h0[0]), c0=d(c0[0]), want_state=True)
+    assert rel_l2(hs.cpu().view(B, T, F, 64).numpy(), ref.detach().numpy()) < 5e-6
+    assert rel_l2(hN.cpu().numpy(), hn[0].detach().numpy()) < 5e-6
+    assert rel_l2(cN.cpu().numpy(), cn[0].detach().numpy()) < 5e-6
+
+
+def test_linear_and_wgrad(torch_gpu):
+    torch = torch_gpu
+    from sound_bubble_amd import ops, _lib as L
+    torch.manual_seed(5)
+    P, K, N = 1000, 128, 32
+    x, w, b, r = torch.randn(P, K), torch.randn(N, K) * 0.1, torch.randn(N), torch.randn(P, N)
+    out = torch.empty(P, N).cuda()
+    g, si = ops.dense(P, K)
+    _, so = ops.dense(P, N)
+    ops.linear(x.cuda(), w.cuda(), b.cuda(), out, g, si, so, K, N, epi=L.EPI_RES, res=r.cuda())
+    ref = x @ w.t() + b + r
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < 2e-6
+    # weight gradient with the "previous row" shift and segment masking
+    gr = torch.randn(P, N)
+    dW = torch.zeros(N, K).cuda()
+    ops.wgrad(gr.cuda(), N, N, x.cuda(), si, g, K, dW, in_shift=-K, seg_len=100, skip_first=1)
+    xs = torch.zeros_like(x)
+    xs[1:] = x[:-1]
+    mask = (torch.arange(P) % 100 >= 1).float()[:, None]
+    ref = (gr * mask).t() @ xs
+    assert rel_l2(dW.cpu().numpy(), ref.numpy()) < 5e-6
+    cs = torch.zeros(N).cuda()
+    ops.colsum(gr.cuda(), P, N, N, cs)
+    assert rel_l2(cs.cpu().numpy(), gr.sum(0).numpy()) < 5e-6
+
+
+CASES = [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"), ("tiny_orange", "NetOptim"),
+         ("tiny_big_convlstm", "NetDisEmbd3")]
+
+
+def _build(torch, name, cls):
+    import sound_bubble_amd as sb
+    rec, params, flavour = load_golden(name)
+    m = getattr(sb, cls)(**params)
+    m.load_state_dict(golden_state_dict(rec, torch), strict=True)
+    return rec, params, m.cuda()
+
+
+def _inputs(torch, rec):
+    d = {"mixture": torch.from_numpy(rec["mixture"]).cuda()}
+    if "dis_embed" in rec:
+        d["dis_embed"] = torch.from_numpy(rec["dis_embed"]).cuda()
+    return d
+
+
+@pytest.mark.parametrize("name,cls", CASES)
+def test_forward_matches_reference_goldens(torch_gpu, name, cls):
+    torch = torch_gpu
+    rec, params, m = _build(torch, name, cls)
+    with torch.no_grad():
+        res = m(_inputs(torch, rec))
+    out = res["output"].cpu().numpy()
+    assert out.shape == rec["output"].shape
+    err = rel_l2(out, rec["output"])
+    assert err < TOL_FWD, err
+    for k, v in flatten_state(res["next_state"]).items():
+        e = rel_l2(v, rec["next_state::" + k])
+        assert e < TOL_FWD, (k, e)
+
+
+def test_forward_small_config_1s(torch_gpu):
+    torch = torch_gpu
+    rec, params, m = _build(torch, "small_1s", "NetOptim")
+    with torch.no_grad():
+        out = m(_inputs(torch, rec))["output"].cpu().numpy()
+    assert rel_l2(out, rec["output"]) < 5e-5
+
+
+@pytest.mark.parametrize("name,cls", CASES[:3])
+def test_streaming_matches_reference(torch_gpu, name, cls):
+    torch = torch_gpu
+    rec, params, m = _build(torch, name, cls)
+    x = torch.from_numpy(rec["stream::input"]).cuda()
+    st = m.init_buffers(x.shape[0], "cuda")
+    outs = []
+    with torch.no_grad():
+        for c in range(3):
+            fr = {"mixture": x[..., c * 192: c * 192 + 288].contiguous()}
+            if "dis_embed" in rec:
+                fr["dis_embed"] = torch.from_numpy(rec["dis_embed"]).cuda()
+            r = m(fr, st, pad=False)
+            st = r["next_state"]
+            outs.append(r["output"])
+    out = torch.cat(outs, -1).cpu().numpy()
+    assert rel_l2(out, rec["stream::output"]) < TOL_FWD
+    for k, v in flatten_state(st).items():
+        assert rel_l2(v, rec["stream::state::" + k]) < TOL_FWD, k
+
+
+@pytest.mark.parametrize("name,cls", CASES)
+def test_loss_and_gradients_match_reference(torch_gpu, name, cls):
+    torch = torch_gpu
+    from sound_bubble_amd.functional import SnrlpLossFn
+    rec, params, m = _build(torch, name, cls)
+    m.train()
+    est = m(_inputs(torch, rec))["output"]
+    loss, lv = SnrlpLossFn.apply(est, torch.from_numpy(rec["target"]).cuda(), 100.0)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), rec["loss_vec"], rtol=1e-4, atol=1e-4)
+    loss.backward()
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        g = rec["grad::" + k]
+        assert p.grad is not None, k
+        e = rel_l2(p.grad.cpu().numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max())
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < TOL_GRAD, worst
+
+
+def test_oracle_agrees_at_full_size_property(torch_gpu):
+    """Full BASELINE size (5 s clip) size-independent property: causality / prefix consistency
+    (the reference's own __main__ self-check, optim/net.py:94-140): the output on a prefix
+    equals the prefix of the output."""
+    torch = torch_gpu
+    rec, params, m = _build(torch, "small_1s", "NetOptim")
+    torch.manual_seed(0)
+    x = (0.1 * torch.randn(1, 6, 120000)).cuda()
+    with torch.no_grad():
+        y = m({"mixture": x}, pad=True)["output"]
+        y2 = m({"mixture": x[..., : 192 * 100 + 96].contiguous()}, pad=False)["output"]
+    assert y.shape == (1, 1, 120000) and torch.isfinite(y).all()
+    assert rel_l2(y[..., : 192 * 100].cpu().numpy(), y2.cpu().numpy()) < 1e-5
