@@ -51,7 +51,7 @@ class IntraPlainFn(torch.autograd.Function):
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
-        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, ln_g, wif, lin_w))
+        train = any(ctx.needs_input_grad)
         geom = Geom.intra(B * T, F)
         dirs = [(wif, whf, bif, bhf), (wir, whr, bir, bhr)]
         hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train)
@@ -106,7 +106,7 @@ class InterFn(torch.autograd.Function):
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
-        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, ln_g, wi, lin_w))
+        train = any(ctx.needs_input_grad)
         geom = Geom.inter(B, T, F)
         h0c = h0.reshape(B * F, H).contiguous() if h0 is not None else None
         c0c = c0.reshape(B * F, H).contiguous() if c0 is not None else None
@@ -165,7 +165,7 @@ class IntraConvFn(torch.autograd.Function):
         Kd = F // down
         Fm = Kd * down
         P2 = B * T * Kd
-        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, conv_w, wif, dec_w))
+        train = any(ctx.needs_input_grad)
         dev = x.device
         wc = conv_w.permute(0, 2, 1).reshape(Cc, down * Cc).contiguous()          # [co][j*C+ci]
         v_pre = torch.empty(P2, Cc, device=dev, dtype=torch.float32) if train else None
@@ -286,7 +286,7 @@ class FrontEndFn(torch.autograd.Function):
         T = (Np - win) // hop + 1
         dev = mix.device
         mix = mix.contiguous()
-        train = torch.is_grad_enabled() and conv_w.requires_grad
+        train = any(ctx.needs_input_grad)
         # 1. STFT as a position-wise GEMM over overlapping rows
         spec = torch.empty(B * M, T, NSPEC, device=dev, dtype=torch.float32)
         ops.linear(mix, _stft_weight(enc_filters), None, spec, (B * M, T, 1), (Np, hop, 0), (T * NSPEC, NSPEC, 0),
@@ -364,7 +364,7 @@ class BackEndFn(torch.autograd.Function):
         B, T, F, Cc = y.shape
         dev = y.device
         win = dec_filters.shape[-1]
-        train = torch.is_grad_enabled() and (y.requires_grad or dw.requires_grad)
+        train = any(ctx.needs_input_grad)
         assert dw.shape[1] == 2, "num_src=1 only (every shipped config)"
         yp = torch.zeros(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)
         yp[:, :2, 1:F + 1] = deconv_buf.permute(0, 2, 3, 1)
@@ -426,7 +426,7 @@ class SnrlpLossFn(torch.autograd.Function):
         B = est.shape[0]
         e = est.reshape(B, -1).contiguous()
         t = gt.reshape(B, -1).contiguous()
-        lv, dest = ops.snrlp_loss(e, t, neg_weight, want_grad=est.requires_grad)
+        lv, dest = ops.snrlp_loss(e, t, neg_weight, want_grad=ctx.needs_input_grad[0])
         ctx.save_for_backward(dest)
         ctx.shape = est.shape
         ctx.mark_non_differentiable(lv)
