@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Sound-Bubble hot-path benchmark on MI355X.
+
+Metric (BASELINE.json): utterances/s of one optimiser step (forward + SNRLP loss + backward +
+[RCCL all-reduce] + clip + Adam) on synthetic 6-ch x 24 kHz x 5 s utterances, whole job over N GPUs.
+Default workload = BASELINE configs[1]: the 0.3 M-param TFG_S model
+(real_experiments/raspberrypi_model_pretrain.json model_params), batch 32 per GPU (weak scaling).
+`--workload big` runs configs[2]/[3]: the 0.5 M-param model (syn_experiments/pretrain_stage.json),
+batch 16 per GPU.
+
+Launch: `python bench.py --gpus 1` or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+ bench.py --gpus N --steps K --warmup W`.
+
+One JSON line on rank 0; adds `roofline` (dominant kernel: the recurrent LSTM forward, timed live with
+HIP events on the launch stream) and `cpu_baseline` (the oracle -- a CPU port of the reference's
+algorithm -- timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+COMMON = dict(stft_chunk_size=192, stft_pad_size=96, num_ch=6, L=4, I=1, J=1, H=64, E=2, use_attn=False,
+              lookahead=True, chunk_causal=True, use_first_ln=True, merge_method="early_cat")
+WORKLOADS = {
+    # name: (class, model_params, batch/GPU, neg_weight, grad_clip, lr)
+    "small": ("NetOptim", dict(COMMON, D=16, B=3, conv_lstm=True, lstm_down=5, local_atten_len=50), 32, 50.0, 1.0,
+              2e-3),
+    "big": ("NetDisEmbd3", dict(COMMON, D=32, B=6, conv_lstm=False, local_atten_len=100, dis_type="conv3"), 16,
+            100.0, None, 1.2e-3),   # "grad_clip" sits at the JSON top level there -> PLModule does not clip (F10a)
+}
+N_SAMPLES = 120000
+MFMA_F32_PEAK = 157.3e12        # dense fp32 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def fwd_flops_per_utt(p, T=625, F=145, M=6):
+    """SURVEY.md 8(d) algorithmic FLOPs of one forward (1 MAC = 2)."""
+    C, H, nb = p["D"], p["H"], p["B"]
+    step = 2 * 4 * H * (C + H)
+    stft = 2 * 290 * 288 * T * M
+    conv = 2 * 27 * C * 9 * T * F
+    if p["conv_lstm"]:
+        K = F // p["lstm_down"]
+        intra = 2 * C * C * 5 * K * T + 2 * step * K * T + 2 * 2 * H * C * 5 * K * T
+    else:
+        intra = 2 * step * F * T + 2 * 2 * H * C * F * T
+    inter = step * T * F + 2 * H * C * T * F
+    return stft + conv + nb * (intra + inter) + 2 * C * 2 * 9 * T * F + 2 * 290 * 288 * (T + 1)
+
+
+def fwd_bytes_per_utt(p, T=625, F=145, M=6):
+    """SURVEY.md 8(d) compulsory HBM bytes of one forward."""
+    return 4 * (M * (N_SAMPLES + 96) + p["D"] * T * F * (2 + 4 * p["B"]) + N_SAMPLES)
+
+
+def synth_batch(torch, B, seed, device, with_dis):
+    g = torch.Generator().manual_seed(seed)
+    base = 0.1 * torch.randn(B, 1, N_SAMPLES + 8, generator=g)
+    mix = torch.cat([base[..., 4 - min(m, 4): 4 - min(m, 4) + N_SAMPLES] for m in range(6)], 1)
+    mix = (mix + 0.02 * torch.randn(B, 6, N_SAMPLES, generator=g)).clamp(-1, 1)
+    tgt = 0.05 * torch.randn(B, 1, N_SAMPLES, generator=g)
+    tgt[7::8] = 0.0                              # every 8th sample: silent target (negative branch)
+    inputs = {"mixture": mix.to(device)}
+    if with_dis:
+        dis = torch.zeros(B, 3)
+        dis[torch.arange(B), torch.arange(B) % 3] = 1.0
+        inputs["dis_embed"] = dis.to(device)
+    return inputs, tgt.to(device)
+
+
+def host_cores():
+    """Usable host cores: min(os.cpu_count, affinity mask, cgroup cpu.max quota).  The GPU box reports 256
+    CPUs but the pod is capped (cpu.max) -- oversubscribing OpenMP there is catastrophically slow."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(torch, wl, budget_s=20.0):
+    """Oracle (CPU port of the reference algorithm, oracle/tfgridnet_oracle.py) train step on host cores."""
+    from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
+    cls, params, _, negw, clip, lr = WORKLOADS[wl]
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = OracleNet("optim" if cls == "NetOptim" else "dis_embd3", **params).train()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    B = 1
+    inputs, tgt = synth_batch(torch, B, 1234, "cpu", cls != "NetOptim")
+
+    def step():
+        opt.zero_grad()
+        est = m(dict(inputs))["output"]
+        snrlp_loss(est, tgt, negw).mean().backward()
+        if clip:
+            torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+        opt.step()
+
+    step()                                       # warm-up
+    t0, n = time.time(), 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 8:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps of batch {B} ({wl} config, 5 s clips), oracle CPU port, after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="small", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="extra mode: inference forward utt/s")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.train import FlatBucket, FusedAdam, train_step
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    cls, params, B, negw, clip, lr = WORKLOADS[args.workload]
+    B = args.batch or B
+    torch.manual_seed(0)                                     # identical replicas
+    model = getattr(sb, cls)(**params).to(dev).train()
+    bucket = FlatBucket(model)
+    optim = FusedAdam(bucket, lr=lr)
+    inputs, target = synth_batch(torch, B, 1234 + rank, dev, cls != "NetOptim")
+
+    def step():
+        if args.forward_only:
+            with torch.no_grad():
+                return model(inputs)["output"]
+        return train_step(model, bucket, optim, inputs, target, negw, grad_clip=clip)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.PROFILE_LSTM = []                                    # HIP-event pairs around the dominant kernel
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev = ops.PROFILE_LSTM
+    ops.PROFILE_LSTM = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        utt_s = world * B * args.steps / dt
+        # dominant kernel: recurrent LSTM forward (all launches: intra + inter), HIP events on the launch stream
+        lstm_ms = [a.elapsed_time(b) for a, b, _ in ev]
+        lstm_flops = [f for _, _, f in ev]
+        tot_ms, tot_fl = sum(lstm_ms), sum(lstm_flops)
+        n_launch = max(1, len(ev))
+        ach = tot_fl / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
+        fpu, bpu = fwd_flops_per_utt(params), fwd_bytes_per_utt(params)
+        work_mult = 1.0 if args.forward_only else 3.0
+        out = {
+            "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if args.forward_only else "train-step"),
+            "value": utt_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cls} D={params['D']} B={params['B']} H=64 "
+                                   f"conv_lstm={params['conv_lstm']}, 6ch x 120000 samples, "
+                                   f"{'forward only' if args.forward_only else 'fwd+SNRLP+bwd+clip+Adam'}",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel (intra+inter launches)",
+                         "achieved": ach / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_F32_PEAK, "traffic": None,
+                         "launches": len(ev), "avg_launch_ms": tot_ms / n_launch,
+                         "algorithmic_flops_per_launch": tot_fl / n_launch,
+                         "step_flop_fraction": work_mult * fpu * utt_s / world / MFMA_F32_PEAK,
+                         "step_hbm_fraction": work_mult * bpu * utt_s / world / HBM_PEAK},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, args.workload)
+            out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

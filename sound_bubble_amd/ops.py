@@ -11,6 +11,7 @@ import torch
 from . import _lib as L
 
 H = 64
+PROFILE_LSTM = None     # bench.py: list collecting (start_event, end_event, algorithmic_flops) per launch
 
 
 def _stream():
@@ -72,7 +73,14 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
     a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
     a.hs, a.save_gates, a.save_u = _p(hs), _p(gates), _p(u)
+    prof = PROFILE_LSTM
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * 4 * H * (Cc + H) * geom.P * ndir))
     return hs, ((hN, cN) if want_state else None), gates, u
 
 
