@@ -92,21 +92,22 @@ int sb_linear_fwd(const sb_linear_args* a, void* stream);
 int sb_linear_grid(int64_t positions);
 
 /* ---- weight gradient (TN GEMM over positions) ----------------------------
- * dW[n, k] (+)= sum_p g(p, n) * in(p, k), g dense-strided rows [P, ldg] at
- * column offset, `in` addressed like sb_linear_args.  Rows whose index within
- * a segment of seg_len positions is < skip_first or >= seg_len - skip_last
- * are excluded (the "previous hidden state" of the first step).  If
- * transpose_out the result is stored as dW[k, n].  Two-stage: per-workgroup
- * partials in `scratch` ([sb_wgrad_grid(P), N*K] floats) then a reduction
- * that ADDS into dW (gradients accumulate in the flat bucket). */
+ * dW[n, k] += sum_p g(p, n) * in(p, k)            k <  K   (source 1, addressed like sb_linear_args)
+ * dW2[n, k] += sum_p g(p, n) * in2[p*ld2 + shift2 + k]  k < K2 (source 2, dense rows; optional)
+ * dbias[n] (+ dbias2[n]) += sum_p g(p, n)                      (optional)
+ * g: dense-strided rows [P, ldg].  Source-2 rows whose index within a segment of seg_len positions is
+ * < skip_first or >= seg_len - skip_last are excluded (h_{t-1} of the first step of a sequence).
+ * One pass over g serves both sources and the bias (dW_ih, dW_hh, db_ih, db_hh of an LSTM in one go).
+ * If transpose_out, dW is stored [K, N].  Two-stage: per-workgroup partials in `scratch`
+ * ([sb_wgrad_grid(P), N*(K+K2)+N] floats), then a reduction that ADDS into the outputs. */
 typedef struct {
   int B, T, F, N, K, kseg;
   const float* g; int64_t ldg;
   const float* in; int64_t is_b, is_t, is_f, is_seg;
-  int64_t in_shift;           /* element offset added to `in` rows (e.g. -H for h_prev) */
+  const float* in2; int64_t ld2, shift2; int K2;
   int seg_len, skip_first, skip_last;
   int transpose_out;
-  float* dW; float* scratch;
+  float* dW; float* dW2; float* dbias; float* dbias2; float* scratch;
 } sb_wgrad_args;
 int sb_wgrad(const sb_wgrad_args* a, void* stream);
 int sb_wgrad_grid(int64_t positions);

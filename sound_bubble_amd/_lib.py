@@ -43,8 +43,10 @@ class WgradArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("F", C.c_int), ("N", C.c_int), ("K", C.c_int), ("kseg", C.c_int),
                 ("g", c_fp), ("ldg", i64),
                 ("inp", c_fp), ("is_b", i64), ("is_t", i64), ("is_f", i64), ("is_seg", i64),
-                ("in_shift", i64), ("seg_len", C.c_int), ("skip_first", C.c_int), ("skip_last", C.c_int),
-                ("transpose_out", C.c_int), ("dW", c_fp), ("scratch", c_fp)]
+                ("in2", c_fp), ("ld2", i64), ("shift2", i64), ("K2", C.c_int),
+                ("seg_len", C.c_int), ("skip_first", C.c_int), ("skip_last", C.c_int),
+                ("transpose_out", C.c_int), ("dW", c_fp), ("dW2", c_fp), ("dbias", c_fp), ("dbias2", c_fp),
+                ("scratch", c_fp)]
 
 
 EPI_NONE, EPI_RES, EPI_PRELU, EPI_LN, EPI_LNBWD = range(5)

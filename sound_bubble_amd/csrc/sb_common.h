@@ -37,8 +37,9 @@ SB_DEVINL f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p);
 SB_DEVINL void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 SB_DEVINL f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
-SB_DEVINL float sigmoidf_fast(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
-SB_DEVINL float tanhf_fast(float x) { return 2.0f * __fdividef(1.0f, 1.0f + __expf(-2.0f * x)) - 1.0f; }
+// v_exp_f32 / v_rcp_f32 (1 ulp each): absolute error ~1e-7, far inside the 1e-3 parity bar
+SB_DEVINL float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+SB_DEVINL float tanhf_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // sum over the 4 lanes {l, l^16, l^32, l^48} (same l & 15): the feature quads of one position
 SB_DEVINL float quad_sum(float v) {
@@ -46,12 +47,18 @@ SB_DEVINL float quad_sum(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
-// sum over the 16 lanes sharing l >> 4 (all positions of a tile)
+// sum over the 16 lanes sharing l >> 4 (all positions of a tile): DPP butterflies (VALU latency) instead of
+// ds_bpermute shuffles (LDS crossbar round trips): quad xor-1, quad xor-2, half-row mirror, row mirror.
+template <int CTRL>
+SB_DEVINL float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return v + __int_as_float(t);
+}
 SB_DEVINL float row16_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
   return v;
 }
 SB_DEVINL float wave_sum(float v) {

@@ -205,21 +205,29 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NTW, int KT>
+// dW[n, k] = sum_p g(p, n) * [in1(p, :K1) | in2(p, :K2)][k]  (+ column sums of g = bias gradients).
+// Wave w owns n-blocks [w*NTW, (w+1)*NTW) and all K blocks; the A operand (g) is fetched ONCE for both
+// sources, so dW_ih, dW_hh and db of an LSTM cost a single pass over dgates.  Source 2 is a dense row
+// matrix addressed p*ld2 + shift2 with the per-segment first/last-row exclusion (h_{t-1} of step 0).
+template <int NTW, int KT1, int KT2>
 __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) {
+  constexpr int KT = KT1 + KT2;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   f32x4 acc[NTW][KT];
+  float csum[NTW];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt)
+  for (int nt = 0; nt < NTW; ++nt) {
+    csum[nt] = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = zero4();
-  int64_t koff[KT];
-  bool kval[KT];
+  }
+  int64_t koff[KT1 > 0 ? KT1 : 1];
+  bool kval[KT1 > 0 ? KT1 : 1];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
+  for (int kt = 0; kt < KT1; ++kt) {
     const int k = 16 * kt + j;
     const int seg = k / a.kseg;
-    koff[kt] = (int64_t)seg * a.is_seg + (k - seg * a.kseg) + a.in_shift;
+    koff[kt] = (int64_t)seg * a.is_seg + (k - seg * a.kseg);
     kval[kt] = k < a.K;
   }
   int ncol[NTW];
@@ -233,45 +241,85 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t p = tile * 16 + 4 * q + r;
-      bool ok = p < P;
-      if (ok) {
-        const int idx = (int)(p % a.seg_len);
-        ok = idx >= a.skip_first && idx < a.seg_len - a.skip_last;
-      }
+      const bool ok = p < P;
       const int64_t ioff = ok ? pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f) : 0;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) av[nt][r] = (ok && nval[nt]) ? a.g[p * a.ldg + ncol[nt]] : 0.f;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) bv[kt][r] = (ok && kval[kt]) ? a.in[ioff + koff[kt]] : 0.f;
+      for (int kt = 0; kt < KT1; ++kt) bv[kt][r] = (ok && kval[kt]) ? a.in[ioff + koff[kt]] : 0.f;
+      if constexpr (KT2 > 0) {
+        bool ok2 = ok;
+        if (ok) {
+          const int idx = (int)(p % a.seg_len);
+          ok2 = idx >= a.skip_first && idx < a.seg_len - a.skip_last;
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT2; ++kt) bv[KT1 + kt][r] = ok2 ? a.in2[p * a.ld2 + a.shift2 + 16 * kt + j] : 0.f;
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
+      for (int nt = 0; nt < NTW; ++nt) {
+        csum[nt] += av[nt][r];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = mfma16(av[nt][r], bv[kt][r], acc[nt][kt]);
+      }
   }
-  float* part = a.scratch + (size_t)blockIdx.x * a.N * a.K;
+  const int Ktot = a.K + a.K2;
+  float* part = a.scratch + (size_t)blockIdx.x * ((size_t)a.N * Ktot + a.N);
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt)
+  for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = 16 * (w * NTW + nt) + 4 * q + r, k = 16 * kt + j;
-        if (n < a.N && k < a.K) part[(size_t)n * a.K + k] = acc[nt][kt][r];
+        const int n = 16 * (w * NTW + nt) + 4 * q + r;
+        const int k = kt < KT1 ? 16 * kt + j : a.K + 16 * (kt - KT1) + j;
+        const bool kok = kt < KT1 ? (16 * kt + j < a.K) : true;
+        if (n < a.N && kok) part[(size_t)n * Ktot + k] = acc[nt][kt][r];
       }
+    const float cs = quad_sum(csum[nt]);
+    if (q == 0 && nval[nt]) part[(size_t)a.N * Ktot + ncol[nt]] = cs;
+  }
+}
+
+// out (+)= sum over partial rows; 2-D grid (columns x row-chunks) + atomics so that the reduction of
+// 512 x 24 K partials is itself a wide, short kernel.  Columns route to dW1 / dW2 / the bias gradients.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int rows, int N, int K1,
+                                                           int K2, float* __restrict__ dW1, float* __restrict__ dW2,
+                                                           float* __restrict__ db1, float* __restrict__ db2,
+                                                           int transpose_out) {
+  const int Ktot = K1 + K2;
+  const int total = N * Ktot + N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int rper = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += partials[(size_t)r * total + i];
+  if (i < N * Ktot) {
+    const int n = i / Ktot, k = i - n * Ktot;
+    if (k < K1) atomicAdd(dW1 + (transpose_out ? (size_t)k * N + n : (size_t)n * K1 + k), s);
+    else if (dW2) atomicAdd(dW2 + (size_t)n * K2 + (k - K1), s);
+  } else {
+    const int n = i - N * Ktot;
+    if (db1) atomicAdd(db1 + n, s);
+    if (db2) atomicAdd(db2 + n, s);
+  }
 }
 
 __global__ void reduce_rows_kernel(const float* __restrict__ partials, int rows, int64_t ld, int n,
                                    float* __restrict__ out, int tr_N, int tr_K) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int rper = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += partials[(size_t)r * ld + i];
+  for (int r = r0; r < r1; ++r) s += partials[(size_t)r * ld + i];
   int o = i;
   if (tr_N > 0) { const int nn = i / tr_K, kk = i - nn * tr_K; o = kk * tr_N + nn; }
-  out[o] += s;
+  atomicAdd(out + o, s);
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int64_t P, int64_t ldg, int N,
@@ -320,8 +368,8 @@ extern "C" int sb_wgrad_grid(int64_t positions) {
 }
 
 extern "C" int sb_reduce_rows(const float* partials, int rows, int64_t ld, int n, float* out, void* stream) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, rows, ld,
-                     n, out, 0, 0);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256, rows >= 64 ? 16 : 1), dim3(256), 0, (hipStream_t)stream,
+                     partials, rows, ld, n, out, 0, 0);
   SB_CHECK_LAUNCH();
   return 0;
 }
@@ -356,18 +404,20 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (!ap) return -1001;
   const sb_wgrad_args& a = *ap;
   const int64_t P = (int64_t)a.B * a.T * a.F;
-  const int nblk = (a.N + 15) / 16, kt = (a.K + 15) / 16, ntw = (nblk + 3) / 4;
+  const int nblk = (a.N + 15) / 16, kt1 = (a.K + 15) / 16, kt2 = a.K2 / 16, ntw = (nblk + 3) / 4;
+  if (a.K2 % 16 || (a.K2 && a.K % 16)) return -1002;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(sb_wgrad_grid(P)), block(256);
-#define SB_WG(NTW_, KT_) \
-  if (ntw == NTW_ && kt == KT_) { hipLaunchKernelGGL((wgrad_kernel<NTW_, KT_>), grid, block, 0, st, a, P); } else
-  SB_WG(4, 1) SB_WG(4, 2) SB_WG(4, 4) SB_WG(2, 1) SB_WG(2, 2) SB_WG(1, 1) SB_WG(1, 2) SB_WG(1, 4) SB_WG(1, 8) SB_WG(5, 1)
-  SB_WG(5, 2) SB_WG(2, 5) SB_WG(1, 5) SB_WG(2, 4) SB_WG(1, 6) SB_WG(1, 3) SB_WG(2, 3) SB_WG(2, 8) SB_WG(1, 18) SB_WG(1, 9) SB_WG(3, 8) SB_WG(1, 10) { return -1004; }
+#define SB_WG(NTW_, KT1_, KT2_) \
+  if (ntw == NTW_ && kt1 == KT1_ && kt2 == KT2_) { hipLaunchKernelGGL((wgrad_kernel<NTW_, KT1_, KT2_>), grid, block, 0, st, a, P); } else
+  SB_WG(4, 1, 4) SB_WG(4, 2, 4) SB_WG(4, 1, 0) SB_WG(4, 2, 0) SB_WG(4, 4, 0)
+  SB_WG(1, 1, 0) SB_WG(1, 2, 0) SB_WG(1, 4, 0) SB_WG(1, 8, 0) SB_WG(1, 5, 0) SB_WG(1, 10, 0) SB_WG(1, 9, 0) SB_WG(1, 18, 0)
+  SB_WG(2, 8, 0) SB_WG(3, 8, 0) SB_WG(2, 4, 0) SB_WG(2, 2, 0) SB_WG(2, 1, 0) { return -1004; }
 #undef SB_WG
   SB_CHECK_LAUNCH();
-  const int n = a.N * a.K;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.scratch, (int)grid.x,
-                     (int64_t)n, n, a.dW, a.transpose_out ? a.N : 0, a.K);
+  const int total = a.N * (a.K + a.K2) + a.N;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, grid.x >= 64 ? 16 : 1), dim3(256), 0, st, a.scratch,
+                     (int)grid.x, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out);
   SB_CHECK_LAUNCH();
   return 0;
 }
@@ -380,8 +430,8 @@ extern "C" int sb_colsum(const float* g, int64_t P, int64_t ldg, int N, float* o
   dim3 grid((unsigned)gx, (N + 63) / 64), block(256);
   hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, g, P, ldg, N, scratch);
   SB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, (int)gx, (int64_t)N, N, out,
-                     0, 0);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, st, scratch, (int)gx, (int64_t)N, N,
+                     out, 0, 0);
   SB_CHECK_LAUNCH();
   return 0;
 }

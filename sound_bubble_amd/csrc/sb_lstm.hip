@@ -26,7 +26,9 @@ constexpr int HP = H + 4;   // padded LDS row (conflict-free ds_read_b128 across
 template <int C>
 struct XVec { float v[C / 16]; };
 
-template <int C, bool SAVE>
+// FULL: nseq is a multiple of the 16-sequence tile -> no bounds checks, hence no exec-masked branches
+// around the global stores, hence counted (not zero) vmcnt waits in the time loop.
+template <int C, bool SAVE, bool FULL>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
   constexpr int KX = C / 16;     // 16-wide K chunks of the input part
   constexpr int VPT = C / 16;    // floats per loader thread
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
   // ---- loader role: thread -> (sequence ls, channel slice) ----
   const int ls = tid >> 4, cpart = tid & 15;
   const int nl = n0 + ls;
-  const bool lvalid = nl < a.nseq;
+  const bool lvalid = FULL || nl < a.nseq;
   const int64_t lbase = lvalid ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
   float gam[VPT], bet[VPT];
 #pragma unroll
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
       u[v] = (xv.v[v] - mean) * rstd * gam[v] + bet[v];
       U[buf][ls][cpart * VPT + v] = u[v];
     }
-    if (SAVE && dir == 0 && lvalid && a.save_u) {
+    // both directions write the (identical) normalised row: branch-free beats saving 1/10 of the store traffic
+    if (SAVE && lvalid) {
       const int st = rev ? S - 1 - s : s;
       float* p = a.save_u + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
 
   // ---- compute role: lane -> (sequence j, units 16w+4q..+3) ----
   const int nc = n0 + j;
-  const bool cvalid = nc < a.nseq;
+  const bool cvalid = FULL || nc < a.nseq;
   const int64_t cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
   const int uoff = 16 * w + 4 * q;
   f32x4 c = zero4(), h = zero4();
@@ -107,23 +110,36 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
   }
   st4(&Hb[0][j][uoff], h);
 
-  XVec<C> xnext = load_x(0);
-  ln_store(xnext, 0, 0);
-  if (S > 1) xnext = load_x(1);
+  // ---- software pipeline (per step s) ----
+  //   A: acc = accx + W_hh * h_{s-1}                (64 MFMAs, needs the barrier of step s-1)
+  //   B: accx' = bias + W_ih * u_{s+1}  (MFMAs, independent)  ||  cell update of step s (VALU on A's result)
+  //      || LayerNorm of the prefetched row x_{s+2} -> U (VALU)   => VALU work hides in the MFMA shadow
+  //   C: ds_write h_s, global stores of step s, prefetch x_{s+3}, barrier
+  // Indices clamp at the end of the sequence (redundant re-normalisation of the last row) so that the
+  // steady-state body is branch-free.
+  {
+    XVec<C> x0 = load_x(0);
+    XVec<C> x1 = load_x(min(1, S - 1));
+    ln_store(x0, 0, 0);
+    ln_store(x1, 1, min(1, S - 1));
+  }
+  XVec<C> xnext = load_x(min(2, S - 1));
   __syncthreads();
+  f32x4 accx[4] = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+  for (int m = 0; m < KX; ++m) {
+    const f32x4 b4 = ld4(&U[0][j][16 * m + 4 * q]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accx[g] = mfma16(Aih[g][m][r], b4[r], accx[g]);
+  }
 
   const int ndir = a.ndir;
   for (int s = 0; s < S; ++s) {
     const int cur = s & 1;
-    f32x4 acc[4] = {bias[0], bias[1], bias[2], bias[3]};
-#pragma unroll
-    for (int m = 0; m < KX; ++m) {
-      const f32x4 b4 = ld4(&U[cur][j][16 * m + 4 * q]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = mfma16(Aih[g][m][r], b4[r], acc[g]);
-    }
+    // ---- A ----
+    f32x4 acc[4] = {accx[0], accx[1], accx[2], accx[3]};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const f32x4 b4 = ld4(&Hb[cur][j][16 * m + 4 * q]);
@@ -132,7 +148,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = mfma16(Ahh[g][m][r], b4[r], acc[g]);
     }
-    // cell update: i,f,g,o for 4 units of one sequence
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B ----
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accx[g] = bias[g];
+#pragma unroll
+    for (int m = 0; m < KX; ++m) {
+      const f32x4 b4 = ld4(&U[cur ^ 1][j][16 * m + 4 * q]);      // u_{s+1}
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) accx[g] = mfma16(Aih[g][m][r], b4[r], accx[g]);
+    }
     f32x4 gi, gf, gg, go, cprev = c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -143,6 +170,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
       c[r] = gf[r] * c[r] + gi[r] * gg[r];
       h[r] = go[r] * tanhf_fast(c[r]);
     }
+    ln_store(xnext, cur, min(s + 2, S - 1));                    // u_{s+2} -> U[s & 1]
+    // interleave request for region B: the U reads first, then 1 MFMA : VPM VALU
+    __builtin_amdgcn_sched_group_barrier(0x100, KX, 0);
+#pragma unroll
+    for (int i = 0; i < 16 * KX; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, C == 32 ? 6 : 11, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C ----
     st4(&Hb[cur ^ 1][j][uoff], h);
     if (cvalid) {
       const int st = rev ? S - 1 - s : s;
@@ -153,10 +190,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
         st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
       }
     }
-    if (s + 1 < S) {
-      ln_store(xnext, cur ^ 1, s + 1);
-      if (s + 2 < S) xnext = load_x(s + 2);
-    }
+    xnext = load_x(min(s + 3, S - 1));
     __syncthreads();
   }
   if (dir == 0 && cvalid) {
@@ -169,6 +203,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
 // dh/dc recurrences.  Wave w owns gate rows {g*64+16w..+15}: its dgates are the
 // B operand straight from registers, partial dh^T = W_hh^T[:, slice] * dgates
 // is reduced across the 4 waves through LDS (one barrier per step).
+template <bool FULL>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -187,7 +222,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
       for (int r = 0; r < 4; ++r) At[ot][g][r] = whh[(size_t)(g * H + 16 * w + 4 * q + r) * H + 16 * ot + j];
 
   const int nc = n0 + j;
-  const bool valid = nc < a.nseq;
+  const bool valid = FULL || nc < a.nseq;
   const int64_t base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
   const int uoff = 16 * w + 4 * q;
 
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
   for (int s = S - 1; s >= 0; --s) {
     const int cur = s & 1;
     const Rec rc = nxt;
-    if (s > 0) nxt = load_rec(s - 1);
+    nxt = load_rec(max(s - 1, 0));
     f32x4 dG[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -232,7 +267,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
       float* dg = a.dgates + (pos * ndir + dir) * (4 * H) + uoff;
       st4(dg, dG[0]); st4(dg + H, dG[1]); st4(dg + 2 * H, dG[2]); st4(dg + 3 * H, dG[3]);
     }
-    if (s > 0) {
+    {
       f32x4 part[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -251,19 +286,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
 
 }  // namespace
 
+template <int C>
+static void launch_fwd(const sb_lstm_fwd_args& a, dim3 grid, hipStream_t st) {
+  const bool save = a.save_gates != nullptr, full = a.nseq % 16 == 0;
+  if (save) {
+    if (full) hipLaunchKernelGGL((lstm_fwd_kernel<C, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lstm_fwd_kernel<C, true, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (full) hipLaunchKernelGGL((lstm_fwd_kernel<C, false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lstm_fwd_kernel<C, false, false>), grid, dim3(256), 0, st, a);
+  }
+}
+
 extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
   if (!a || a->nseq <= 0 || a->nsteps <= 0 || (a->ndir != 1 && a->ndir != 2)) return -1001;
   if (a->C != 16 && a->C != 32) return -1002;
-  dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  const bool save = a->save_gates != nullptr;
-  if (a->C == 32) {
-    if (save) hipLaunchKernelGGL((lstm_fwd_kernel<32, true>), grid, block, 0, st, *a);
-    else hipLaunchKernelGGL((lstm_fwd_kernel<32, false>), grid, block, 0, st, *a);
-  } else {
-    if (save) hipLaunchKernelGGL((lstm_fwd_kernel<16, true>), grid, block, 0, st, *a);
-    else hipLaunchKernelGGL((lstm_fwd_kernel<16, false>), grid, block, 0, st, *a);
-  }
+  dim3 grid((a->nseq + 15) / 16, a->ndir);
+  if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);
+  else launch_fwd<16>(*a, grid, (hipStream_t)stream);
   SB_CHECK_LAUNCH();
   return 0;
 }
@@ -271,7 +311,8 @@ extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
 extern "C" int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream) {
   if (!a || a->nseq <= 0 || a->nsteps <= 0 || (a->ndir != 1 && a->ndir != 2)) return -1001;
   dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
-  hipLaunchKernelGGL(lstm_bwd_rec_kernel, grid, block, 0, (hipStream_t)stream, *a);
+  if (a->nseq % 16 == 0) hipLaunchKernelGGL(lstm_bwd_rec_kernel<true>, grid, block, 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(lstm_bwd_rec_kernel<false>, grid, block, 0, (hipStream_t)stream, *a);
   SB_CHECK_LAUNCH();
   return 0;
 }

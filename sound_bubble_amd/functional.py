@@ -18,27 +18,26 @@ ZC = 32          # padded channel count of the front-end feature tensor
 NSPEC = 304      # 290 STFT bins (re/im) padded to a multiple of 16
 
 
-def _lstm_param_grads(dg, ndir, geom_rows_steps, u, hs, Cc, shift_per_step, seg_len, skip, dirs_params):
-    """dW_ih, dW_hh, db for every direction from dgates [P, ndir, 4, 64].
-    hs: [P, ndir*64] hidden sequence; the previous-step hidden state of position p is
-    hs[p - shift] (direction 0) / hs[p + shift] (direction 1)."""
+def _lstm_param_grads(dg, ndir, u, hs, Cc, shift_per_step, seg_len, skip):
+    """(dW_ih, dW_hh, db_ih, db_hh) per direction from dgates [P, ndir, 4, 64] in ONE pass over dgates per
+    direction.  hs: [P, ndir*64] hidden sequence; the previous-step hidden state of position p is
+    hs[p - shift] (direction 0) / hs[p + shift] (direction 1); the first step of every sequence is excluded
+    (zero initial state in training, net.py:88-89)."""
     P = dg.shape[0]
     ldg = ndir * 4 * H
     grads = []
+    g, s = dense(P, Cc)
     for d in range(ndir):
-        w_ih = dirs_params[d][0]
-        dW_ih = torch.zeros_like(w_ih)
+        dW_ih = torch.zeros(4 * H, Cc, device=dg.device, dtype=torch.float32)
         dW_hh = torch.zeros(4 * H, H, device=dg.device, dtype=torch.float32)
-        db = torch.zeros(4 * H, device=dg.device, dtype=torch.float32)
-        g, s = dense(P, Cc)
-        ops.wgrad(dg, ldg, 4 * H, u, s, g, Cc, dW_ih, g_off=d * 4 * H)
-        g, s = dense(P, ndir * H)
+        db1 = torch.zeros(4 * H, device=dg.device, dtype=torch.float32)
+        db2 = torch.zeros(4 * H, device=dg.device, dtype=torch.float32)
         sign = -1 if d == 0 else 1
-        ops.wgrad(dg, ldg, 4 * H, hs, s, g, H, dW_hh, g_off=d * 4 * H, in_off=d * H,
-                  in_shift=sign * shift_per_step * ndir * H, seg_len=seg_len,
-                  skip_first=skip if d == 0 else 0, skip_last=skip if d == 1 else 0)
-        ops.colsum(dg, P, ldg, 4 * H, db, g_off=d * 4 * H)
-        grads.append((dW_ih, dW_hh, db, db.clone()))
+        ops.wgrad(dg, ldg, 4 * H, u, s, g, Cc, dW_ih, g_off=d * 4 * H,
+                  in2=hs, ld2=ndir * H, in2_off=d * H, shift2=sign * shift_per_step * ndir * H, K2=H, dW2=dW_hh,
+                  seg_len=seg_len, skip_first=skip if d == 0 else 0, skip_last=skip if d == 1 else 0,
+                  dbias=db1, dbias2=db2)
+        grads.append((dW_ih, dW_hh, db1, db2))
     return grads
 
 
@@ -78,8 +77,7 @@ class IntraPlainFn(torch.autograd.Function):
         ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, s2H, Cc, 2 * H)
         d_lin_w = torch.zeros_like(lin_w)
         d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
-        ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, d_lin_w)
-        ops.colsum(dy, P, Cc, Cc, d_lin_b)
+        ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, d_lin_w, dbias=d_lin_b)
         # BPTT
         dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
         # input gradient through W_ih and the LayerNorm, + residual
@@ -92,8 +90,7 @@ class IntraPlainFn(torch.autograd.Function):
         d_b = torch.zeros_like(d_g)
         ops.reduce_partials(part, Cc, d_g, 0)
         ops.reduce_partials(part, Cc, d_b, Cc)
-        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(
-            dg, 2, None, u, hs, Cc, 1, F, 1, [(wif,), (wir,)])
+        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(dg, 2, u, hs, Cc, 1, F, 1)
         return dx, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_lin_w, d_lin_b
 
 
@@ -136,8 +133,7 @@ class InterFn(torch.autograd.Function):
         ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
         d_lin_w = torch.zeros_like(lin_w)
         d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
-        ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, d_lin_w)
-        ops.colsum(dy, P, Cc, Cc, d_lin_b)
+        ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, d_lin_w, dbias=d_lin_b)
         dg = ops.lstm_bwd_rec([wh], gates, dhs, geom)
         dx = torch.empty_like(x)
         _, s4H = dense(P, 4 * H)
@@ -148,7 +144,7 @@ class InterFn(torch.autograd.Function):
         ops.reduce_partials(part, Cc, d_g, 0)
         ops.reduce_partials(part, Cc, d_b, Cc)
         # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
-        ((dwi, dwh, db1, db2),) = _lstm_param_grads(dg, 1, None, u, hs, Cc, F, T * F, F, [(wi,)])
+        ((dwi, dwh, db1, db2),) = _lstm_param_grads(dg, 1, u, hs, Cc, F, T * F, F)
         return dx, d_g, d_b, dwi, dwh, db1, db2, d_lin_w, d_lin_b, None, None
 
 
@@ -207,9 +203,8 @@ class IntraConvFn(torch.autograd.Function):
         dhs = torch.empty(P2, 2 * H, device=dev, dtype=torch.float32)
         ops.linear(dym, wd.t().contiguous(), None, dhs, gP2, sNC, s2H, NC, 2 * H)
         d_wd = torch.zeros(NC, 2 * H, device=dev, dtype=torch.float32)
-        ops.wgrad(dym, NC, NC, hs, s2H, gP2, 2 * H, d_wd)
         d_bd = torch.zeros(NC, device=dev, dtype=torch.float32)
-        ops.colsum(dym, P2, NC, NC, d_bd)
+        ops.wgrad(dym, NC, NC, hs, s2H, gP2, 2 * H, d_wd, dbias=d_bd)
         d_dec_w = d_wd.view(down, Cc, 2 * H).permute(2, 1, 0).contiguous()
         d_dec_b = d_bd.view(down, Cc).sum(0)
         if Fm < F and bias_tail:
@@ -237,12 +232,10 @@ class IntraConvFn(torch.autograd.Function):
         if Fm < F:
             dx[:, :, Fm:, :] = dy[:, :, Fm:, :]
         d_wc = torch.zeros(Cc, NC, device=dev, dtype=torch.float32)
-        ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, d_wc)
-        d_conv_w = d_wc.view(Cc, down, Cc).permute(0, 2, 1).contiguous()
         d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
-        ops.colsum(dv, P2, Cc, Cc, d_conv_b)
-        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(
-            dg, 2, None, u, hs, Cc, 1, Kd, 1, [(wif,), (wir,)])
+        ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, d_wc, dbias=d_conv_b)
+        d_conv_w = d_wc.view(Cc, down, Cc).permute(0, 2, 1).contiguous()
+        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(dg, 2, u, hs, Cc, 1, Kd, 1)
         return (dx, d_conv_w, d_conv_b, d_a, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_dec_w,
                 d_dec_b, None, None)
 
@@ -336,10 +329,9 @@ class FrontEndFn(torch.autograd.Function):
             dpre = dx0.view(P, Cc)
         d_wk = torch.zeros(Cc, 9 * ZC, device=dev, dtype=torch.float32)
         s_in = ((T + 2) * (F + 2) * ZC, (F + 2) * ZC, ZC)
-        ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, d_wk, kseg=3 * ZC, is_seg=(F + 2) * ZC)
-        d_conv_w = d_wk.view(Cc, 3, 3, ZC)[..., :nfeat].permute(0, 3, 1, 2).contiguous()
         d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
-        ops.colsum(dpre, P, Cc, Cc, d_conv_b)
+        ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, d_wk, kseg=3 * ZC, is_seg=(F + 2) * ZC, dbias=d_conv_b)
+        d_conv_w = d_wk.view(Cc, 3, 3, ZC)[..., :nfeat].permute(0, 3, 1, 2).contiguous()
         return None, None, d_conv_w, d_conv_b, d_g, d_b, None, None, None
 
 
@@ -411,10 +403,9 @@ class BackEndFn(torch.autograd.Function):
         P = B * T * F
         d_wk = torch.zeros(2, 9 * Cc, device=dev, dtype=torch.float32)
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
-        ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, d_wk, kseg=3 * Cc, is_seg=(F + 2) * Cc)
-        d_dw = d_wk.view(2, 3, 3, Cc).permute(3, 0, 1, 2).flip(2, 3).contiguous()
         d_db = torch.zeros(2, device=dev, dtype=torch.float32)
-        ops.colsum(dspec, P, 2, 2, d_db)
+        ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, d_wk, kseg=3 * Cc, is_seg=(F + 2) * Cc, dbias=d_db)
+        d_dw = d_wk.view(2, 3, 3, Cc).permute(3, 0, 1, 2).flip(2, 3).contiguous()
         return dy, None, d_dw, d_db, None, None, None
 
 

@@ -147,25 +147,29 @@ def dense(P, ld):
     return (1, 1, int(P)), (0, 0, int(ld))
 
 
-def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=None, is_seg=0, in_shift=0,
-          seg_len=None, skip_first=0, skip_last=0, transpose_out=False):
-    """dW[N,K] += sum_p g[p, :N]^T in(p, :K)"""
+def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=None, is_seg=0, in2=None, ld2=0,
+          in2_off=0, shift2=0, K2=0, dW2=None, seg_len=None, skip_first=0, skip_last=0, dbias=None, dbias2=None,
+          transpose_out=False):
+    """dW[N,K] += sum_p g[p,:N]^T in(p,:K);  dW2[N,K2] += sum_p g^T in2[p*ld2+shift2 : +K2] (segment-masked);
+    dbias (+dbias2) += column sums of g.  One pass over g."""
     lib = L.load()
     B_, T_, F_ = grid
     P = B_ * T_ * F_
     ng = lib.sb_wgrad_grid(P)
-    scratch = torch.empty(ng, N * K, device=dW.device, dtype=torch.float32)
+    scratch = torch.empty(ng, N * (K + K2) + N, device=dW.device, dtype=torch.float32)
     a = L.WgradArgs()
     a.B, a.T, a.F, a.N, a.K = B_, T_, F_, N, K
     a.kseg = ((K + 15) // 16) * 16 if kseg is None else kseg
     a.g, a.ldg = _poff(g, g_off), ldg
     a.inp = _poff(inp, in_off)
     a.is_b, a.is_t, a.is_f = in_strides
-    a.is_seg, a.in_shift = is_seg, in_shift
+    a.is_seg = is_seg
+    if in2 is not None:
+        a.in2, a.ld2, a.shift2, a.K2 = _poff(in2, in2_off), ld2, shift2, K2
     a.seg_len = P if seg_len is None else seg_len
     a.skip_first, a.skip_last = skip_first, skip_last
     a.transpose_out = 1 if transpose_out else 0
-    a.dW, a.scratch = _p(dW, "dW"), _p(scratch)
+    a.dW, a.dW2, a.dbias, a.dbias2, a.scratch = _p(dW, "dW"), _p(dW2), _p(dbias), _p(dbias2), _p(scratch)
     L.check(lib.sb_wgrad(C.byref(a), _stream()), "sb_wgrad")
 
 

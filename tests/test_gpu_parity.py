@@ -81,18 +81,29 @@ def test_linear_and_wgrad(torch_gpu):
     ops.linear(x.cuda(), w.cuda(), b.cuda(), out, g, si, so, K, N, epi=L.EPI_RES, res=r.cuda())
     ref = x @ w.t() + b + r
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 2e-6
-    # weight gradient with the "previous row" shift and segment masking
-    gr = torch.randn(P, N)
-    dW = torch.zeros(N, K).cuda()
-    ops.wgrad(gr.cuda(), N, N, x.cuda(), si, g, K, dW, in_shift=-K, seg_len=100, skip_first=1)
-    xs = torch.zeros_like(x)
-    xs[1:] = x[:-1]
+    # two-source weight gradient (the LSTM case: N=256 gate rows, K1=C, K2=H): source 1 plain rows,
+    # source 2 = "previous row" with segment masking, plus the fused column sums, one pass over g
+    G, Cc = 256, 32
+    gr, u, h = torch.randn(P, G), torch.randn(P, Cc), torch.randn(P, 64)
+    dW1, dW2 = torch.zeros(G, Cc).cuda(), torch.zeros(G, 64).cuda()
+    cs, cs2 = torch.zeros(G).cuda(), torch.zeros(G).cuda()
+    gg, su = ops.dense(P, Cc)
+    ops.wgrad(gr.cuda(), G, G, u.cuda(), su, gg, Cc, dW1, in2=h.cuda(), ld2=64, shift2=-64, K2=64, dW2=dW2,
+              seg_len=100, skip_first=1, dbias=cs, dbias2=cs2)
+    assert rel_l2(dW1.cpu().numpy(), (gr.t() @ u).numpy()) < 5e-6
+    hs_ = torch.zeros_like(h)
+    hs_[1:] = h[:-1]
     mask = (torch.arange(P) % 100 >= 1).float()[:, None]
-    ref = (gr * mask).t() @ xs
-    assert rel_l2(dW.cpu().numpy(), ref.numpy()) < 5e-6
-    cs = torch.zeros(N).cuda()
-    ops.colsum(gr.cuda(), P, N, N, cs)
+    assert rel_l2(dW2.cpu().numpy(), (gr.t() @ (hs_ * mask)).numpy()) < 5e-6
     assert rel_l2(cs.cpu().numpy(), gr.sum(0).numpy()) < 5e-6
+    assert rel_l2(cs2.cpu().numpy(), gr.sum(0).numpy()) < 5e-6
+    # single-source form with the bias (a Linear layer's dW, db)
+    dW = torch.zeros(N, K).cuda()
+    db = torch.zeros(N).cuda()
+    g1 = torch.randn(P, N)
+    ops.wgrad(g1.cuda(), N, N, x.cuda(), si, g, K, dW, dbias=db)
+    assert rel_l2(dW.cpu().numpy(), (g1.t() @ x).numpy()) < 5e-6
+    assert rel_l2(db.cpu().numpy(), g1.sum(0).numpy()) < 5e-6
 
 
 CASES = [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"), ("tiny_orange", "NetOptim"),
