@@ -118,6 +118,40 @@ int sb_colsum(const float* g, int64_t P, int64_t ldg, int N, float* out, float* 
 int sb_reduce_rows(const float* partials, int rows, int64_t ld, int n, float* out, void* stream);
 
 
+/* ---- LSTM backward, streaming part ---------------------------------------
+ * One pass over dgates [P, ndir, 4, 64] (written by sb_lstm_bwd_rec) per direction:
+ *   dW_ih[d] [256, C] += dgates_d^T u          (u [P, C]: saved LayerNorm output)
+ *   dW_hh[d] [256, 64] += dgates_d^T h_prev    (h_prev(p) = hs[p -/+ shift_pos], direction 0 / 1; positions whose
+ *                                               index in a segment of seg_len is < skip (dir 0) / >= seg_len-skip
+ *                                               (dir 1) are the first step of a sequence and are excluded)
+ *   db_ih[d], db_hh[d] [256] += column sums of dgates_d
+ *   du_part [P, ndir, C]   = dgates_d W_ih[d]  (gradient w.r.t. the LayerNorm output, per direction)
+ * scratch: [ndir * sb_lstm_stream_grid(P) * (256*(C+64) + 256)] floats.  Autograd of nn.LSTM + LayerNorm,
+ * tfgridnet_causal.py:819-823,832-840. */
+typedef struct {
+  int64_t P; int ndir, C;
+  int64_t shift_pos; int seg_len, skip;
+  const float* dgates; const float* u; const float* hs;
+  const float* w_ih[2];
+  float* dW_ih[2]; float* dW_hh[2]; float* db_ih[2]; float* db_hh[2];
+  float* du_part; float* scratch;
+} sb_lstm_stream_args;
+int sb_lstm_bwd_stream(const sb_lstm_stream_args* a, void* stream);
+int sb_lstm_stream_grid(int64_t positions);
+
+/* ---- LayerNorm (+PReLU) backward over C channels ---------------------------
+ * g = sum_d du_part[p, d, :];  x = xin[p] (PReLU(xin[p]) with slope *prelu_a when prelu_a != NULL);
+ * out[p] = LN_backward(g; x, ln_g) (* PReLU'(xin) when prelu_a) (+ res[p] when res != NULL).
+ * partials [sb_ln_bwd_grid(P), 2C+1]: per-workgroup sums of d(ln_g), d(ln_b), d(prelu_a) (reduce with
+ * sb_reduce_rows).  All tensors dense [P, C].  nn.LayerNorm / nn.PReLU backward of tfgridnet_causal.py:803-804,819,832. */
+typedef struct {
+  int64_t P; int ndir, C;
+  const float* du_part; const float* xin; const float* ln_g; const float* prelu_a; const float* res;
+  float* out; float* partials;
+} sb_ln_bwd_args;
+int sb_ln_bwd(const sb_ln_bwd_args* a, void* stream);
+int sb_ln_bwd_grid(int64_t positions);
+
 /* ---- front-end features --------------------------------------------------
  * spec [B*M, T, ld_spec] (cols 0..F-1 real, F..2F-1 imag: asteroid Encoder
  * layout) -> zp [B, T+2, F+2, 32] channels-last, written at time offset 2 and

@@ -49,6 +49,21 @@ class WgradArgs(C.Structure):
                 ("scratch", c_fp)]
 
 
+class LstmStreamArgs(C.Structure):
+    _fields_ = [("P", i64), ("ndir", C.c_int), ("C", C.c_int),
+                ("shift_pos", i64), ("seg_len", C.c_int), ("skip", C.c_int),
+                ("dgates", c_fp), ("u", c_fp), ("hs", c_fp),
+                ("w_ih", c_fp * 2),
+                ("dW_ih", c_fp * 2), ("dW_hh", c_fp * 2), ("db_ih", c_fp * 2), ("db_hh", c_fp * 2),
+                ("du_part", c_fp), ("scratch", c_fp)]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [("P", i64), ("ndir", C.c_int), ("C", C.c_int),
+                ("du_part", c_fp), ("xin", c_fp), ("ln_g", c_fp), ("prelu_a", c_fp), ("res", c_fp),
+                ("out", c_fp), ("partials", c_fp)]
+
+
 EPI_NONE, EPI_RES, EPI_PRELU, EPI_LN, EPI_LNBWD = range(5)
 
 # every symbol include/sound_bubble_hip.h declares: name -> (restype, argtypes)
@@ -60,6 +75,10 @@ SYMBOLS = {
     "sb_linear_grid": (_ci, [i64]),
     "sb_wgrad": (_ci, [C.POINTER(WgradArgs), _vp]),
     "sb_wgrad_grid": (_ci, [i64]),
+    "sb_lstm_bwd_stream": (_ci, [C.POINTER(LstmStreamArgs), _vp]),
+    "sb_lstm_stream_grid": (_ci, [i64]),
+    "sb_ln_bwd": (_ci, [C.POINTER(LnBwdArgs), _vp]),
+    "sb_ln_bwd_grid": (_ci, [i64]),
     "sb_colsum": (_ci, [c_fp, i64, i64, _ci, c_fp, c_fp, _vp]),
     "sb_reduce_rows": (_ci, [c_fp, _ci, i64, _ci, c_fp, _vp]),
     "sb_features": (_ci, [c_fp, i64, c_fp, _ci, _ci, _ci, _ci, _vp]),

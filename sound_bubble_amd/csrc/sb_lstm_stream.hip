@@ -1,0 +1,258 @@
+// Streaming (non-recurrent) half of the LSTM backward pass for gfx950:
+//   one pass over dgates produces   dW_ih, dW_hh, db_ih, db_hh   (TN GEMMs over positions)
+//                           and     dU = W_ih^T dgates            (gradient w.r.t. the LayerNorm output),
+// so dgates (1 KB / position / direction) is read from HBM exactly once after the recurrent kernel wrote it.
+// A second, light kernel folds the per-direction dU partials through the LayerNorm (and PReLU) backward.
+//
+// Layout trick: the MFMA contraction index of the weight gradients is the POSITION, so the operands need
+// "position on the k-lanes".  Instead of 4-byte loads, gate columns / hidden units are assigned to MFMA tiles
+// as  gate = 64*w + 4*i + tile  (unit = 4*i + tile), so ONE 16-byte load per lane per position yields the
+// operand of four tiles at once (4 x 256 B contiguous per wave-instruction instead of 16 x 64 B).
+#include "sb_common.h"
+#include "../../include/sound_bubble_hip.h"
+
+namespace {
+
+constexpr int H = SB_H;
+constexpr int STREAM_MAX_WG = 512;
+
+template <int C>
+__global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_args a) {
+  constexpr int CK = C / 16;            // u blocks
+  constexpr int KT = CK + 4;            // + 4 h_prev blocks
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int dir = blockIdx.y, ndir = a.ndir;
+  const int64_t P = a.P;
+  __shared__ __attribute__((aligned(16))) float R[2][4][CK][64][4];
+
+  // W_ih^T fragments for this wave's 64-gate slice: A[i = channel 16ct + j][k = gate 64w + 16m + 4q + r]
+  const float* __restrict__ wih = a.w_ih[dir];
+  f32x4 Awt[CK][4];
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Awt[ct][m][r] = wih[(size_t)(64 * w + 16 * m + 4 * q + r) * C + 16 * ct + j];
+
+  f32x4 acc[4][KT];
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = zero4();
+
+  const float* __restrict__ dg = a.dgates + (size_t)dir * 4 * H + 64 * w;
+  const float* __restrict__ hs = a.hs + (size_t)dir * H;
+  const int64_t ldg = (int64_t)ndir * 4 * H, ldh = (int64_t)ndir * H;
+  const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
+  const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
+
+  const int64_t ntiles = (P + 15) / 16;
+  int it = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+    const int64_t p0 = tile * 16;
+    // ---- weight-gradient operands: positions p0 + 4q + r ----
+    f32x4 a4[4], h4[4];
+    float uv[CK][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t p = p0 + 4 * q + r;
+      const bool ok = p < P;
+      a4[r] = ok ? ld4(dg + p * ldg + 4 * j) : zero4();
+      bool ok2 = ok;
+      if (ok) {
+        const int idx = (int)(p % a.seg_len);
+        ok2 = idx >= skip_first && idx < a.seg_len - skip_last;
+      }
+      h4[r] = ok2 ? ld4(hs + p * ldh + hshift + 4 * j) : zero4();
+      if constexpr (CK == 2) {
+        const float2 t = ok ? *reinterpret_cast<const float2*>(a.u + p * C + 2 * j) : make_float2(0.f, 0.f);
+        uv[0][r] = t.x; uv[1][r] = t.y;
+      } else {
+        uv[0][r] = ok ? a.u[p * C + j] : 0.f;
+      }
+    }
+    // ---- dU operand: dgates of position p0 + j, gate chunk m (same cache lines as above) ----
+    const int64_t pj = p0 + j;
+    f32x4 d4[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) d4[m] = pj < P ? ld4(dg + pj * ldg + 16 * m + 4 * q) : zero4();
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float av = a4[r][nt];
+        csum[nt] += av;
+#pragma unroll
+        for (int kt = 0; kt < CK; ++kt) acc[nt][kt] = mfma16(av, uv[kt][r], acc[nt][kt]);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[nt][CK + kt] = mfma16(av, h4[r][kt], acc[nt][CK + kt]);
+      }
+    f32x4 du[CK];
+#pragma unroll
+    for (int ct = 0; ct < CK; ++ct) du[ct] = zero4();
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) du[ct] = mfma16(Awt[ct][m][r], d4[m][r], du[ct]);
+    const int buf = it & 1;
+#pragma unroll
+    for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][ct][lane][0], du[ct]);
+    __syncthreads();
+    if (w < CK && pj < P) {
+      const f32x4 s = ld4(&R[buf][0][w][lane][0]) + ld4(&R[buf][1][w][lane][0]) + ld4(&R[buf][2][w][lane][0]) +
+                      ld4(&R[buf][3][w][lane][0]);
+      st4(a.du_part + (pj * ndir + dir) * C + 16 * w + 4 * q, s);
+    }
+  }
+
+  // ---- partial results: [N*(C+64) + N] per workgroup, true (un-permuted) indices ----
+  constexpr int Ktot = C + H;
+  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) * ((size_t)4 * H * Ktot + 4 * H);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gate = 64 * w + 4 * (4 * q + r) + nt;
+#pragma unroll
+      for (int kt = 0; kt < CK; ++kt) part[(size_t)gate * Ktot + (CK == 2 ? 2 * j + kt : j)] = acc[nt][kt][r];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) part[(size_t)gate * Ktot + C + 4 * j + kt] = acc[nt][CK + kt][r];
+    }
+    const float cs = quad_sum(csum[nt]);
+    if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs;
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restrict__ partials, int rows, int C,
+                                                            float* __restrict__ dW1, float* __restrict__ dW2,
+                                                            float* __restrict__ db1, float* __restrict__ db2) {
+  const int Ktot = C + H, N = 4 * H;
+  const int total = N * Ktot + N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int rper = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += partials[(size_t)r * total + i];
+  if (i < N * Ktot) {
+    const int n = i / Ktot, k = i - n * Ktot;
+    if (k < C) atomicAdd(dW1 + (size_t)n * C + k, s);
+    else atomicAdd(dW2 + (size_t)n * H + (k - C), s);
+  } else {
+    atomicAdd(db1 + (i - N * Ktot), s);
+    atomicAdd(db2 + (i - N * Ktot), s);
+  }
+}
+
+// LayerNorm (+ optional PReLU) backward over C channels per position, 16 lanes per position.
+//   g = sum_dir du_part[p, dir, :]   (gradient w.r.t. the LN output)
+//   x = xin[p] (pre-LN input; PReLU(xin) when prelu_a)        out = LN-bwd(g) (* prelu') (+ res[p])
+template <int C>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(sb_ln_bwd_args a) {
+  constexpr int VPT = C / 16;
+  const int tid = threadIdx.x, cpart = tid & 15;
+  const float alpha = a.prelu_a ? a.prelu_a[0] : 0.f;
+  float gam[VPT], dgam[VPT], dbet[VPT], dalpha = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; dgam[v] = 0.f; dbet[v] = 0.f; }
+  const int64_t nrow = a.P;
+  for (int64_t p = (int64_t)blockIdx.x * 16 + (tid >> 4); p < nrow; p += (int64_t)gridDim.x * 16) {
+    float g[VPT], raw[VPT], x[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int c = cpart * VPT + v;
+      float s = 0.f;
+      for (int d = 0; d < a.ndir; ++d) s += a.du_part[(p * a.ndir + d) * C + c];
+      g[v] = s;
+      raw[v] = a.xin[p * C + c];
+      x[v] = (a.prelu_a && raw[v] <= 0.f) ? alpha * raw[v] : raw[v];
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) sum += x[v];
+    const float mean = row16_sum(sum) * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) { const float d = x[v] - mean; sq += d * d; }
+    const float rstd = 1.0f / sqrtf(row16_sum(sq) * (1.0f / C) + 1e-5f);
+    float m1 = 0.f, m2 = 0.f, xh[VPT], gg[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      xh[v] = (x[v] - mean) * rstd;
+      dgam[v] += g[v] * xh[v];
+      dbet[v] += g[v];
+      gg[v] = g[v] * gam[v];
+      m1 += gg[v];
+      m2 += gg[v] * xh[v];
+    }
+    m1 = row16_sum(m1) * (1.0f / C);
+    m2 = row16_sum(m2) * (1.0f / C);
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int c = cpart * VPT + v;
+      float dx = rstd * (gg[v] - m1 - xh[v] * m2);
+      if (a.prelu_a && raw[v] <= 0.f) { dalpha += dx * raw[v]; dx *= alpha; }
+      if (a.res) dx += a.res[p * C + c];
+      a.out[p * C + c] = dx;
+    }
+  }
+  // per-block partials: [2C + 1]
+  __shared__ float red[16][2 * C + 1];
+  const int rowi = tid >> 4;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) { red[rowi][cpart * VPT + v] = dgam[v]; red[rowi][C + cpart * VPT + v] = dbet[v]; }
+  const float da = row16_sum(dalpha);
+  if (cpart == 0) red[rowi][2 * C] = da;
+  __syncthreads();
+  if (tid < 2 * C + 1) {
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += red[r][tid];
+    a.partials[(size_t)blockIdx.x * (2 * C + 1) + tid] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int sb_lstm_stream_grid(int64_t positions) {
+  const int64_t t = (positions + 15) / 16;
+  return (int)(t < STREAM_MAX_WG ? (t < 1 ? 1 : t) : STREAM_MAX_WG);
+}
+
+extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
+  if (!ap || ap->P <= 0 || (ap->ndir != 1 && ap->ndir != 2)) return -1001;
+  if (ap->C != 16 && ap->C != 32) return -1002;
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = sb_lstm_stream_grid(ap->P);
+  dim3 grid(gx, ap->ndir), block(256);
+  if (ap->C == 32) hipLaunchKernelGGL(lstm_bwd_stream_kernel<32>, grid, block, 0, st, *ap);
+  else hipLaunchKernelGGL(lstm_bwd_stream_kernel<16>, grid, block, 0, st, *ap);
+  SB_CHECK_LAUNCH();
+  const int total = 4 * H * (ap->C + H) + 4 * H;
+  for (int d = 0; d < ap->ndir; ++d) {
+    hipLaunchKernelGGL(stream_reduce_kernel, dim3((total + 255) / 256, gx >= 64 ? 16 : 1), dim3(256), 0, st,
+                       ap->scratch + (size_t)d * gx * total, gx, ap->C, ap->dW_ih[d], ap->dW_hh[d], ap->db_ih[d],
+                       ap->db_hh[d]);
+  }
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_ln_bwd_grid(int64_t positions) {
+  const int64_t t = (positions + 15) / 16;
+  return (int)(t < 2048 ? (t < 1 ? 1 : t) : 2048);
+}
+
+extern "C" int sb_ln_bwd(const sb_ln_bwd_args* ap, void* stream) {
+  if (!ap || ap->P <= 0 || ap->ndir < 1) return -1001;
+  dim3 grid(sb_ln_bwd_grid(ap->P)), block(256);
+  if (ap->C == 32) hipLaunchKernelGGL(ln_bwd_kernel<32>, grid, block, 0, (hipStream_t)stream, *ap);
+  else if (ap->C == 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, 0, (hipStream_t)stream, *ap);
+  else return -1002;
+  SB_CHECK_LAUNCH();
+  return 0;
+}

@@ -18,29 +18,6 @@ ZC = 32          # padded channel count of the front-end feature tensor
 NSPEC = 304      # 290 STFT bins (re/im) padded to a multiple of 16
 
 
-def _lstm_param_grads(dg, ndir, u, hs, Cc, shift_per_step, seg_len, skip):
-    """(dW_ih, dW_hh, db_ih, db_hh) per direction from dgates [P, ndir, 4, 64] in ONE pass over dgates per
-    direction.  hs: [P, ndir*64] hidden sequence; the previous-step hidden state of position p is
-    hs[p - shift] (direction 0) / hs[p + shift] (direction 1); the first step of every sequence is excluded
-    (zero initial state in training, net.py:88-89)."""
-    P = dg.shape[0]
-    ldg = ndir * 4 * H
-    grads = []
-    g, s = dense(P, Cc)
-    for d in range(ndir):
-        dW_ih = torch.zeros(4 * H, Cc, device=dg.device, dtype=torch.float32)
-        dW_hh = torch.zeros(4 * H, H, device=dg.device, dtype=torch.float32)
-        db1 = torch.zeros(4 * H, device=dg.device, dtype=torch.float32)
-        db2 = torch.zeros(4 * H, device=dg.device, dtype=torch.float32)
-        sign = -1 if d == 0 else 1
-        ops.wgrad(dg, ldg, 4 * H, u, s, g, Cc, dW_ih, g_off=d * 4 * H,
-                  in2=hs, ld2=ndir * H, in2_off=d * H, shift2=sign * shift_per_step * ndir * H, K2=H, dW2=dW_hh,
-                  seg_len=seg_len, skip_first=skip if d == 0 else 0, skip_last=skip if d == 1 else 0,
-                  dbias=db1, dbias2=db2)
-        grads.append((dW_ih, dW_hh, db1, db2))
-    return grads
-
-
 class IntraPlainFn(torch.autograd.Function):
     """y = x + Linear_{2H->C}(biLSTM_F(LN_C(x)))   -- dis_embd3/tfgridnet_causal.py:795,818-827;
     optim/tfgridnet_causal.py:699-707."""
@@ -80,17 +57,10 @@ class IntraPlainFn(torch.autograd.Function):
         ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, d_lin_w, dbias=d_lin_b)
         # BPTT
         dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
-        # input gradient through W_ih and the LayerNorm, + residual
-        wcat_t = torch.cat([wif, wir], 0).t().contiguous()            # [C, 512]
-        dx = torch.empty_like(x)
-        _, s8H = dense(P, 8 * H)
-        part = ops.linear(dg, wcat_t, None, dx, gP, s8H, sC, 8 * H, Cc, epi=L.EPI_LNBWD, aux_in=x, ln_g=ln_g,
-                          res=dy, want_partials=True)
-        d_g = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
-        d_b = torch.zeros_like(d_g)
-        ops.reduce_partials(part, Cc, d_g, 0)
-        ops.reduce_partials(part, Cc, d_b, Cc)
-        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(dg, 2, u, hs, Cc, 1, F, 1)
+        # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)
+        ((dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2)), du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1)
+        dx, d_g, d_b, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc))
+        dx = dx.view(B, T, F, Cc)
         return dx, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_lin_w, d_lin_b
 
 
@@ -135,16 +105,10 @@ class InterFn(torch.autograd.Function):
         d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
         ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, d_lin_w, dbias=d_lin_b)
         dg = ops.lstm_bwd_rec([wh], gates, dhs, geom)
-        dx = torch.empty_like(x)
-        _, s4H = dense(P, 4 * H)
-        part = ops.linear(dg, wi.t().contiguous(), None, dx, gP, s4H, sC, 4 * H, Cc, epi=L.EPI_LNBWD, aux_in=x,
-                          ln_g=ln_g, res=dy, want_partials=True)
-        d_g = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
-        d_b = torch.zeros_like(d_g)
-        ops.reduce_partials(part, Cc, d_g, 0)
-        ops.reduce_partials(part, Cc, d_b, Cc)
         # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
-        ((dwi, dwh, db1, db2),) = _lstm_param_grads(dg, 1, u, hs, Cc, F, T * F, F)
+        ((dwi, dwh, db1, db2),), du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F)
+        dx, d_g, d_b, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc))
+        dx = dx.view(B, T, F, Cc)
         return dx, d_g, d_b, dwi, dwh, db1, db2, d_lin_w, d_lin_b, None, None
 
 
@@ -212,18 +176,9 @@ class IntraConvFn(torch.autograd.Function):
         # BPTT
         geom = Geom.intra(B * T, Kd)
         dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
-        # through W_ih, LayerNorm and PReLU -> gradient of the Conv1d output
-        wcat_t = torch.cat([wif, wir], 0).t().contiguous()
-        dv = torch.empty(P2, Cc, device=dev, dtype=torch.float32)
-        _, s8H = dense(P2, 8 * H)
-        part = ops.linear(dg, wcat_t, None, dv, gP2, s8H, sC, 8 * H, Cc, epi=L.EPI_LNBWD, aux_in=v_pre, ln_g=ln_g,
-                          prelu_a=act_a, want_partials=True)
-        d_g = torch.zeros(Cc, device=dev, dtype=torch.float32)
-        d_b = torch.zeros_like(d_g)
-        d_a = torch.zeros(1, device=dev, dtype=torch.float32)
-        ops.reduce_partials(part, Cc, d_g, 0)
-        ops.reduce_partials(part, Cc, d_b, Cc)
-        ops.reduce_partials(part, 1, d_a, 2 * Cc)
+        # one pass over dgates (weight grads + dU), then LayerNorm + PReLU backward -> gradient of the Conv1d output
+        ((dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2)), du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, Kd, 1)
+        dv, d_g, d_b, d_a = ops.ln_bwd(du, v_pre, ln_g, prelu_a=act_a)
         # Conv1d backward: dx = dy + dv . Wc ; dWc = dv^T x_rows
         dx = torch.empty_like(x)
         s_x = (F * Cc, 0, NC)
@@ -235,7 +190,6 @@ class IntraConvFn(torch.autograd.Function):
         d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
         ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, d_wc, dbias=d_conv_b)
         d_conv_w = d_wc.view(Cc, down, Cc).permute(0, 2, 1).contiguous()
-        (dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2) = _lstm_param_grads(dg, 2, u, hs, Cc, 1, Kd, 1)
         return (dx, d_conv_w, d_conv_b, d_a, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_dec_w,
                 d_dec_b, None, None)
 
@@ -317,14 +271,7 @@ class FrontEndFn(torch.autograd.Function):
         gP, sC = dense(P, Cc)
         d_g = d_b = None
         if use_ln:
-            dpre = torch.empty(P, Cc, device=dev, dtype=torch.float32)
-            eye = torch.eye(Cc, device=dev, dtype=torch.float32)
-            part = ops.linear(dx0, eye, None, dpre, gP, sC, sC, Cc, Cc, epi=L.EPI_LNBWD, aux_in=pre, ln_g=ln_g,
-                              want_partials=True)
-            d_g = torch.zeros(Cc, device=dev, dtype=torch.float32)
-            d_b = torch.zeros_like(d_g)
-            ops.reduce_partials(part, Cc, d_g, 0)
-            ops.reduce_partials(part, Cc, d_b, Cc)
+            dpre, d_g, d_b, _ = ops.ln_bwd(dx0.view(P, 1, Cc), pre, ln_g)
         else:
             dpre = dx0.view(P, Cc)
         d_wk = torch.zeros(Cc, 9 * ZC, device=dev, dtype=torch.float32)

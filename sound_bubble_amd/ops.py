@@ -98,6 +98,58 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom):
     return dg
 
 
+def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip):
+    """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C]."""
+    lib = L.load()
+    P, ndir = dg.shape[0], dg.shape[1]
+    Cc = u.shape[-1]
+    dev = dg.device
+    a = L.LstmStreamArgs()
+    a.P, a.ndir, a.C = P, ndir, Cc
+    a.shift_pos, a.seg_len, a.skip = shift_pos, seg_len, skip
+    a.dgates, a.u, a.hs = _p(dg), _p(u), _p(hs)
+    grads = []
+    for d in range(ndir):
+        g = (torch.zeros(4 * H, Cc, device=dev), torch.zeros(4 * H, H, device=dev),
+             torch.zeros(4 * H, device=dev), torch.zeros(4 * H, device=dev))
+        grads.append(g)
+        a.w_ih[d] = _p(w_ih_list[d])
+        a.dW_ih[d], a.dW_hh[d], a.db_ih[d], a.db_hh[d] = _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3])
+    du = torch.empty(P, ndir, Cc, device=dev, dtype=torch.float32)
+    ng = lib.sb_lstm_stream_grid(P)
+    scratch = torch.empty(ndir * ng * (4 * H * (Cc + H) + 4 * H), device=dev, dtype=torch.float32)
+    a.du_part, a.scratch = _p(du), _p(scratch)
+    L.check(lib.sb_lstm_bwd_stream(C.byref(a), _stream()), "sb_lstm_bwd_stream")
+    return grads, du
+
+
+def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None):
+    """LayerNorm(+PReLU) backward.  du_part [P, ndir, C] (summed over ndir), xin [P, C] pre-LN input.
+    -> out [P, C], d_ln_g [C], d_ln_b [C], d_prelu [1] or None"""
+    lib = L.load()
+    Cc = xin.shape[-1]
+    P = xin.numel() // Cc
+    ndir = du_part.numel() // (P * Cc)
+    dev = xin.device
+    out = torch.empty(P, Cc, device=dev, dtype=torch.float32)
+    ng = lib.sb_ln_bwd_grid(P)
+    partials = torch.empty(ng, 2 * Cc + 1, device=dev, dtype=torch.float32)
+    a = L.LnBwdArgs()
+    a.P, a.ndir, a.C = P, ndir, Cc
+    a.du_part, a.xin, a.ln_g, a.prelu_a, a.res = _p(du_part), _p(xin), _p(ln_g), _p(prelu_a), _p(res)
+    a.out, a.partials = _p(out), _p(partials)
+    L.check(lib.sb_ln_bwd(C.byref(a), _stream()), "sb_ln_bwd")
+    d_g = torch.zeros(Cc, device=dev, dtype=torch.float32)
+    d_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
+    reduce_partials(partials, Cc, d_g, 0)
+    reduce_partials(partials, Cc, d_b, Cc)
+    d_a = None
+    if prelu_a is not None:
+        d_a = torch.zeros(1, device=dev, dtype=torch.float32)
+        reduce_partials(partials, 1, d_a, 2 * Cc)
+    return out, d_g, d_b, d_a
+
+
 def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None, is_seg=0, n_valid=None,
            epi=L.EPI_NONE, res=None, res_strides=None, prelu_a=None, ln_g=None, ln_b=None, aux_in=None,
            aux_out=None, want_partials=False, accumulate=False, in_off=0, out_off=0, res_off=0):
