@@ -188,6 +188,13 @@ int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int
 int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight,
                   float* stats, float* loss_vec, float* dest, void* stream);
 
+/* ---- metric moments (src/metrics/metrics.py:44-55, hl_module:326-373) -------
+ * One pass over est, gt [B, N] and the reference mixture channel (row b at mix + b*mix_stride):
+ * out[b, 0..7] = sum e, t, m, e*e, t*t, m*m, e*t, m*t.  SNR / SI-SNR / SI-SDR (and their improvements) and the
+ * decay metric follow in closed form on the host from ONE small D2H copy instead of O(batch x metrics) .item() syncs. */
+int sb_signal_stats(const float* est, const float* gt, const float* mix, int B, int64_t N, int64_t mix_stride,
+                    float* out, void* stream);
+
 /* ---- optimiser ------------------------------------------------------------
  * sumsq[0] += sum g^2 (grad-norm for clip_grad_norm_, hl_module:437-441). */
 int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream);

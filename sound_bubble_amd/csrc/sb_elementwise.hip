@@ -231,6 +231,27 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
   }
 }
 
+// per-sample first/second moments of (est, gt, mix): out[b*8 + k] = sum e, t, m, ee, tt, mm, et, mt
+__global__ __launch_bounds__(256) void signal_stats_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                           const float* __restrict__ mix, int64_t N,
+                                                           int64_t mix_stride, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const float* e = est + (int64_t)b * N;
+  const float* t = gt + (int64_t)b * N;
+  const float* m = mix + (int64_t)b * mix_stride;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float ev = e[i], tv = t[i], mv = m[i];
+    s[0] += ev; s[1] += tv; s[2] += mv; s[3] += ev * ev; s[4] += tv * tv; s[5] += mv * mv; s[6] += ev * tv;
+    s[7] += mv * tv;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + b * 8 + k, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -320,6 +341,17 @@ extern "C" int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N
   hipLaunchKernelGGL(loss_pass2_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, stats, B, N, neg_weight, loss_vec);
   if (dest) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk((int64_t)B * N)), dim3(256), 0, st, est, gt, B, N, neg_weight, stats, dest);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_signal_stats(const float* est, const float* gt, const float* mix, int B, int64_t N, int64_t mix_stride,
+                               float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(out, 0, (size_t)B * 8 * sizeof(float), st);
+  unsigned gx = nblk(N, 256 * 8);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(signal_stats_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, mix, N, mix_stride, out);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,219 @@
+"""Training / evaluation harness with the reference's protocol.
+
+Mirrors the object `train_pt.py` drives (src/hl_modules/distance_based_hl_module.py:21-441): same
+constructor keywords (so `pl_module_args` of the shipped JSONs pass through unchanged) and the same
+methods -- train(), eval(), training_step(), validation_step(), reset_grad(), backprop(),
+on_epoch_start(), on_epoch_end(best_path, wandb_run), dump_state(), load_state(), get_current_lr().
+
+MI355X-native differences:
+  * one process per GPU; gradients live in one flat bucket; `backprop()` = ONE RCCL all-reduce +
+    fused clip + Adam (HIP) instead of nn.DataParallel + per-tensor optimizer ops;
+  * metrics come from one fused moment kernel and ONE D2H copy per step instead of
+    O(batch x metrics) `.item()` syncs (hl_module:334-373);
+  * wandb is optional (no network on the GPU box).
+Checkpoints keep the reference layout {model, optimizer, current_epoch, metric_values, statistics
+[, scheduler]} with the reference's state_dict key names, so a reference `best.pt`'s model weights load.
+"""
+import importlib
+
+import numpy as np
+import torch
+
+from .metrics import batch_metrics
+from .train import FlatBucket, FusedAdam, allreduce_grads
+
+ALIASES = {
+    "src.models.tfgridnet_realtime_clean_dis_embd3.net.Net": "sound_bubble_amd.net.NetDisEmbd3",
+    "src.models.tfgridnet_realtime_clean_optim.net.Net": "sound_bubble_amd.net.NetOptim",
+    "src.losses.SNRLP.SNRLPLoss": "sound_bubble_amd.losses.SNRLPLoss",
+    "src.hl_modules.distance_based_hl_module.PLModule": "sound_bubble_amd.harness.PLModule",
+}
+
+
+def import_attr(path):
+    """utils.import_attr (src/utils.py:10-12) with the drop-in alias table."""
+    path = ALIASES.get(path, path)
+    module, attr = path.rsplit(".", 1)
+    return getattr(importlib.import_module(module), attr)
+
+
+class _LrCarrier(torch.optim.Optimizer):
+    """Minimal torch optimizer whose only job is to carry `lr` for torch.optim.lr_scheduler.*"""
+
+    def __init__(self, lr):
+        self._p = torch.nn.Parameter(torch.zeros(1))
+        super().__init__([self._p], dict(lr=lr))
+
+    def step(self, closure=None):
+        return None
+
+
+class PLModule(object):
+    def __init__(self, model, model_params, sr, optimizer, optimizer_params, scheduler=None, scheduler_params=None,
+                 loss=None, loss_params=None, metrics=[], init_ckpt=None, grad_clip=None, use_dp=True,
+                 val_log_interval=10, samples_per_speaker_number=3, device="cuda"):
+        self.model = import_attr(model)(**model_params).to(device)
+        self.use_dp = use_dp                    # kept for signature compatibility; DP = one process per GPU here
+        self.sr = sr
+        self.samples_per_speaker_number = samples_per_speaker_number
+        self.metric_names = [m for m in metrics if m not in ("PESQ", "STOI")]
+        self.metric_values, self.statistics = {}, {}
+        self.monitor, self.monitor_mode, self.mode = "val/loss", "min", None
+        self.loss_fn = import_attr(loss)(**(loss_params or {}))
+        if init_ckpt is not None:
+            state = torch.load(init_ckpt, map_location="cpu")
+            self.model.load_state_dict(state["model"] if "model" in state else state["state_dict"])
+        if optimizer not in ("torch.optim.Adam",):
+            raise NotImplementedError(f"optimizer {optimizer}: only torch.optim.Adam (every shipped config) is fused")
+        self.optim_name, self.opt_params = optimizer, dict(optimizer_params)
+        self.bucket = FlatBucket(self.model)
+        self.optimizer = FusedAdam(self.bucket, **self.opt_params)
+        self.grad_clip = grad_clip
+        if self.grad_clip is None:
+            print("NOT USING GRAD CLIP (pl_module_args.grad_clip is unset -- as in syn_experiments/pretrain_stage.json)")
+        self.scheduler_name, self.scheduler_params = scheduler, scheduler_params
+        self._lr_carrier = _LrCarrier(self.opt_params.get("lr", 1e-3))
+        self.scheduler = self.init_scheduler(scheduler, scheduler_params)
+        self._sync_lr()          # e.g. LinearLR applies its start_factor at construction
+        self.epoch = 0
+        self._loss = None
+
+    # ---- checkpoints (hl_module:115-156) ----
+    def dump_state(self, path):
+        state = dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(), current_epoch=self.epoch,
+                     metric_values=self.metric_values, statistics=self.statistics)
+        if self.scheduler is not None:
+            state["scheduler"] = self.scheduler.state_dict()
+        torch.save(state, path)
+
+    def load_state(self, path, map_location=None):
+        state = torch.load(path, map_location=map_location or "cpu", weights_only=False)
+        self.model.load_state_dict(state["model"])            # in-place copy_: bucket views stay valid
+        opt = state.get("optimizer")
+        if isinstance(opt, dict) and "m" in opt:
+            self.optimizer.load_state_dict(opt)
+        if self.scheduler is not None and "scheduler" in state:
+            self.scheduler = self.init_scheduler(self.scheduler_name, self.scheduler_params)
+            self.scheduler.load_state_dict(state["scheduler"])
+            # scheduler state does not carry the optimizer's lr (the reference restores it through the
+            # optimizer state_dict): push the saved lr back into the carrier the scheduler drives
+            for g in self._lr_carrier.param_groups:
+                g["lr"] = self.optimizer.param_groups[0]["lr"]
+        self.epoch = state.get("current_epoch", 0)
+        self.metric_values = state.get("metric_values", {})
+
+    def get_current_lr(self):
+        return self.optimizer.param_groups[0]["lr"]
+
+    def _sync_lr(self):
+        self.optimizer.param_groups[0]["lr"] = self._lr_carrier.param_groups[0]["lr"]
+
+    # ---- epoch bookkeeping (hl_module:162-264) ----
+    def on_epoch_start(self):
+        print("\n" + "=" * 25, "STARTING EPOCH", self.epoch, "=" * 25 + "\n")
+
+    def get_avg_metric_at_epoch(self, metric, epoch=None):
+        epoch = self.epoch if epoch is None else epoch
+        m = self.metric_values[epoch][metric]
+        return m["epoch"] / m["num_elements"]
+
+    def on_epoch_end(self, best_path, wandb_run=None):
+        last = self.get_avg_metric_at_epoch(self.monitor)
+        best = all(not (last > self.get_avg_metric_at_epoch(self.monitor, e)) for e in range(len(self.metric_values) - 1))
+        if best:
+            print("Current checkpoint is the best! Saving it...")
+            self.dump_state(best_path)
+        for k in sorted(self.metric_values[self.epoch]):
+            if k.startswith("val/"):
+                print(f"{k}: {self.get_avg_metric_at_epoch(k):.3f}")
+        if wandb_run is not None:
+            wandb_run.log({"lr-Adam": self.get_current_lr(), "epoch": self.epoch,
+                           **{k: self.get_avg_metric_at_epoch(k) for k in self.metric_values[self.epoch]}},
+                          step=self.epoch + 1)
+        if self.scheduler is not None:
+            if isinstance(self.scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
+                self.scheduler.step(last)
+            else:
+                self.scheduler.step()
+            self._sync_lr()
+        self.epoch += 1
+
+    def log_metric(self, name, value, batch_size=1, on_step=False, on_epoch=True, **_):
+        ev = self.metric_values.setdefault(self.epoch, {}).setdefault(name, dict(step=None, epoch=None))
+        if on_step:
+            ev["step"] = (ev["step"] or []) + [float(value)]
+        if on_epoch:
+            if ev["epoch"] is None:
+                ev["epoch"], ev["num_elements"] = 0.0, 0
+            ev["epoch"] += float(value) * batch_size
+            ev["num_elements"] += batch_size
+
+    # ---- steps (hl_module:303-428) ----
+    def _step(self, batch, batch_idx, step="train"):
+        inputs, targets = batch
+        B = inputs["mixture"].shape[0]
+        outputs = self.model(inputs)
+        est, gt = outputs["output"], targets["target"]
+        loss, loss_vec = self.loss_fn.mean_loss(est, gt)
+        with torch.no_grad():
+            n_spk = np.asarray(targets["num_target_speakers"].cpu() if torch.is_tensor(targets["num_target_speakers"])
+                               else targets["num_target_speakers"]).reshape(-1)
+            mix_ref = inputs["mixture"][:, 0, : est.shape[-1]]
+            mets = batch_metrics(est.detach(), gt, mix_ref, self.metric_names)       # ONE D2H copy
+            self._loss_host = None
+            for name in self.metric_names:
+                for i in range(B):
+                    if n_spk[i] > 0:
+                        self.log_metric(f"{step}/{name}", mets[name][i], 1)
+                        if name == "si_sdr_i":
+                            self.log_metric(f"{step}/{name}_{int(n_spk[i])}spk", mets[name][i], 1)
+            for i in range(B):
+                if n_spk[i] == 0:
+                    self.log_metric(f"{step}/decay", mets["decay"][i], 1)
+        self._pending = (step, loss.detach(), B)
+        return loss, B
+
+    def _flush_loss(self):
+        if getattr(self, "_pending", None) is not None:
+            step, l, B = self._pending
+            self.log_metric(f"{step}/loss", float(l), B, on_step=(step == "train"))
+            self._pending = None
+
+    def train(self):
+        self.model.train()
+        self.mode = "train"
+
+    def eval(self):
+        self.model.eval()
+        self.mode = "val"
+
+    def training_step(self, batch, batch_idx):
+        return self._step(batch, batch_idx, "train")
+
+    def validation_step(self, batch, batch_idx):
+        out = self._step(batch, batch_idx, "val")
+        self._flush_loss()
+        return out
+
+    def reset_grad(self):
+        self.bucket.zero_grad()
+
+    def backprop(self):
+        """all-reduce (one flat bucket) -> clip_grad_norm_(grad_clip) -> Adam, hl_module:430-441."""
+        world = allreduce_grads(self.bucket)
+        self.optimizer.step(grad_clip=self.grad_clip, world_size=world)
+        self._flush_loss()
+
+    def init_scheduler(self, scheduler, scheduler_params):
+        """hl_module:460-481 ('sequential' -> SequentialLR with cumulative milestones)."""
+        if scheduler is None:
+            return None
+        opt = self._lr_carrier
+        if scheduler == "sequential":
+            scheds, miles = [], []
+            for sp in scheduler_params:
+                scheds.append(import_attr(sp["name"])(opt, **sp["params"]))
+                miles.append(sp["epochs"])
+            miles = list(np.cumsum(miles))[:-1]
+            return torch.optim.lr_scheduler.SequentialLR(opt, scheds, [int(m) for m in miles])
+        return import_attr(scheduler)(opt, **scheduler_params)

@@ -289,6 +289,17 @@ def snrlp_loss(est, gt, neg_weight, want_grad):
     return lv, dest
 
 
+def signal_stats(est, gt, mix_ref):
+    """est, gt [B, N]; mix_ref [B, N] view (row stride given by mix_ref.stride(0)) -> moments [B, 8]"""
+    B_, N = est.shape
+    out = torch.empty(B_, 8, device=est.device, dtype=torch.float32)
+    assert mix_ref.stride(1) == 1
+    lib = L.load()
+    mp = C.c_void_p(mix_ref.data_ptr())
+    L.check(lib.sb_signal_stats(_p(est), _p(gt), mp, B_, N, mix_ref.stride(0), _p(out), _stream()), "sb_signal_stats")
+    return out
+
+
 def sumsq(g, out):
     L.check(L.load().sb_sumsq(_p(g), g.numel(), _p(out), _stream()), "sb_sumsq")
 

@@ -1,0 +1,1 @@
+from sound_bubble_amd.net import NetDisEmbd3 as Net  # noqa: F401  (JSON: pl_module_args.model)
