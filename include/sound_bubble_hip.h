@@ -31,8 +31,11 @@ extern "C" {
  * * p_inner + s * p_step.  Direction 1 (bidirectional intra) walks s backwards.
  * Gate order i,f,g,o (torch).  x is the PRE-LayerNorm input [P, C]; the
  * kernel normalises over C (eps 1e-5) with ln_g/ln_b on the fly.
- * hs: [P, ndir*64].  save_gates (nullable): [P, ndir, 5, 64] = i,f,g,o,c_prev
- * (post-activation) for BPTT.  save_u (nullable): [P, C] LayerNorm output.
+ * hs: [P, ndir*64].  BPTT record (training; nullable): either
+ *   save_gates [P, ndir, 5, 64] fp32 = i,f,g,o (post-activation), c_prev        (save_c == NULL), or
+ *   save_gates [P, ndir, 256] fp16 gates (opaque lane order) + save_c [P, ndir, 64] fp32 c_prev  (compact: 768
+ *   instead of 1280 B per step; gate values lie in [-1,1], fp16 rounding 2^-12 relative).
+ * save_u ([P, C] LayerNorm output) is required whenever save_gates is given.
  * h0/c0 (nullable = zeros), hN/cN (nullable): [nseq, 64], direction 0 only. */
 typedef struct {
   int nseq, nsteps, n_inner, ndir, C;
@@ -41,7 +44,7 @@ typedef struct {
   const float* ln_g; const float* ln_b;
   const float* w_ih[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2];
   const float* h0; const float* c0; float* hN; float* cN;
-  float* hs; float* save_gates; float* save_u;
+  float* hs; float* save_gates; float* save_u; float* save_c;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 
@@ -56,6 +59,7 @@ typedef struct {
   int64_t p_outer, p_inner, p_step;
   const float* w_hh[2];
   const float* save_gates; const float* dhs; float* dgates;
+  const float* save_c;        /* non-NULL: compact fp16 record (see sb_lstm_fwd_args) */
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

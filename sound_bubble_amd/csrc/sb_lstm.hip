@@ -25,10 +25,11 @@ constexpr int HP = H + 4;   // padded LDS row (conflict-free ds_read_b128 across
 
 template <int C>
 struct XVec { float v[C / 16]; };
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 // FULL: nseq is a multiple of the 16-sequence tile -> no bounds checks, hence no exec-masked branches
 // around the global stores, hence counted (not zero) vmcnt waits in the time loop.
-template <int C, bool SAVE, bool FULL>
+template <int C, int SAVE, bool FULL>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
   constexpr int KX = C / 16;     // 16-wide K chunks of the input part
   constexpr int VPT = C / 16;    // floats per loader thread
@@ -185,9 +186,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = cbase + (int64_t)st * a.p_step;
       st4(a.hs + (pos * ndir + dir) * H + uoff, h);
-      if (SAVE) {
+      if (SAVE == 1) {
         float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
         st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
+      } else if (SAVE == 2) {
+        // compact BPTT record: the four gates as fp16 (values in [-1,1]; 2^-12 relative rounding), c_prev in fp32;
+        // lane-contiguous 32 B: [w][q][gate][r]
+        h16x8 lo, hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[r] = (_Float16)gi[r]; lo[4 + r] = (_Float16)gf[r];
+          hi[r] = (_Float16)gg[r]; hi[4 + r] = (_Float16)go[r];
+        }
+        _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
+        *reinterpret_cast<h16x8*>(rec) = lo;
+        *reinterpret_cast<h16x8*>(rec + 8) = hi;
+        st4(a.save_c + (pos * ndir + dir) * H + uoff, cprev);
       }
     }
     xnext = load_x(min(s + 3, S - 1));
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
 // dh/dc recurrences.  Wave w owns gate rows {g*64+16w..+15}: its dgates are the
 // B operand straight from registers, partial dh^T = W_hh^T[:, slice] * dgates
 // is reduced across the 4 waves through LDS (one barrier per step).
-template <bool FULL>
+template <bool FULL, bool REC16>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -232,8 +246,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
     const int st = rev ? S - 1 - s : s;
     const int64_t pos = base + (int64_t)st * a.p_step;
     if (valid) {
-      const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
-      r.i = ld4(rec); r.f = ld4(rec + H); r.g = ld4(rec + 2 * H); r.o = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
+      if constexpr (REC16) {
+        const _Float16* rec = reinterpret_cast<const _Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
+        const h16x8 lo = *reinterpret_cast<const h16x8*>(rec), hi = *reinterpret_cast<const h16x8*>(rec + 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          r.i[k] = (float)lo[k]; r.f[k] = (float)lo[4 + k]; r.g[k] = (float)hi[k]; r.o[k] = (float)hi[4 + k];
+        }
+        r.cp = ld4(a.save_c + (pos * ndir + dir) * H + uoff);
+      } else {
+        const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
+        r.i = ld4(rec); r.f = ld4(rec + H); r.g = ld4(rec + 2 * H); r.o = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
+      }
       r.dh = ld4(a.dhs + (pos * ndir + dir) * H + uoff);
     } else {
       r.i = r.f = r.g = r.o = r.cp = r.dh = zero4();
@@ -288,19 +312,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
 
 template <int C>
 static void launch_fwd(const sb_lstm_fwd_args& a, dim3 grid, hipStream_t st) {
-  const bool save = a.save_gates != nullptr, full = a.nseq % 16 == 0;
-  if (save) {
-    if (full) hipLaunchKernelGGL((lstm_fwd_kernel<C, true, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lstm_fwd_kernel<C, true, false>), grid, dim3(256), 0, st, a);
-  } else {
-    if (full) hipLaunchKernelGGL((lstm_fwd_kernel<C, false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lstm_fwd_kernel<C, false, false>), grid, dim3(256), 0, st, a);
-  }
+  const bool full = a.nseq % 16 == 0;
+  const int save = a.save_gates == nullptr ? 0 : (a.save_c ? 2 : 1);
+#define SB_L(SV, FL) hipLaunchKernelGGL((lstm_fwd_kernel<C, SV, FL>), grid, dim3(256), 0, st, a)
+  if (save == 0) { if (full) SB_L(0, true); else SB_L(0, false); }
+  else if (save == 1) { if (full) SB_L(1, true); else SB_L(1, false); }
+  else { if (full) SB_L(2, true); else SB_L(2, false); }
+#undef SB_L
 }
 
 extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
   if (!a || a->nseq <= 0 || a->nsteps <= 0 || (a->ndir != 1 && a->ndir != 2)) return -1001;
   if (a->C != 16 && a->C != 32) return -1002;
+  if (a->save_gates && !a->save_u) return -1003;
   dim3 grid((a->nseq + 15) / 16, a->ndir);
   if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);
   else launch_fwd<16>(*a, grid, (hipStream_t)stream);
@@ -311,8 +335,12 @@ extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
 extern "C" int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream) {
   if (!a || a->nseq <= 0 || a->nsteps <= 0 || (a->ndir != 1 && a->ndir != 2)) return -1001;
   dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
-  if (a->nseq % 16 == 0) hipLaunchKernelGGL(lstm_bwd_rec_kernel<true>, grid, block, 0, (hipStream_t)stream, *a);
-  else hipLaunchKernelGGL(lstm_bwd_rec_kernel<false>, grid, block, 0, (hipStream_t)stream, *a);
+  hipStream_t st = (hipStream_t)stream;
+  const bool full = a->nseq % 16 == 0, r16 = a->save_c != nullptr;
+  if (full) { if (r16) hipLaunchKernelGGL((lstm_bwd_rec_kernel<true, true>), grid, block, 0, st, *a);
+              else hipLaunchKernelGGL((lstm_bwd_rec_kernel<true, false>), grid, block, 0, st, *a); }
+  else { if (r16) hipLaunchKernelGGL((lstm_bwd_rec_kernel<false, true>), grid, block, 0, st, *a);
+         else hipLaunchKernelGGL((lstm_bwd_rec_kernel<false, false>), grid, block, 0, st, *a); }
   SB_CHECK_LAUNCH();
   return 0;
 }

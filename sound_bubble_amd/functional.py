@@ -36,13 +36,14 @@ class IntraPlainFn(torch.autograd.Function):
         _, s_out = dense(P, Cc)
         ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, 2 * H, Cc, epi=L.EPI_RES, res=x)
         if train:
-            ctx.save_for_backward(x, ln_g, wif, whf, wir, whr, lin_w, hs, gates, u)
+            ctx.save_for_backward(x, ln_g, wif, whf, wir, whr, lin_w, hs, u, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, ln_g, wif, whf, wir, whr, lin_w, hs, gates, u = ctx.saved_tensors
+        x, ln_g, wif, whf, wir, whr, lin_w, hs, u, *g_ = ctx.saved_tensors
+        gates = (g_[0], g_[1] if len(g_) > 1 else None)
         B, T, F, Cc = ctx.dims
         P = B * T * F
         dy = dy.contiguous()
@@ -84,7 +85,7 @@ class InterFn(torch.autograd.Function):
         _, s_out = dense(P, Cc)
         ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, H, Cc, epi=L.EPI_RES, res=x)
         if train:
-            ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, gates, u)
+            ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, u, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
         hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
         ctx.mark_non_differentiable(hN, cN)
@@ -92,7 +93,8 @@ class InterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dh, _dc):
-        x, ln_g, wi, wh, lin_w, hs, gates, u = ctx.saved_tensors
+        x, ln_g, wi, wh, lin_w, hs, u, *g_ = ctx.saved_tensors
+        gates = (g_[0], g_[1] if len(g_) > 1 else None)
         B, T, F, Cc = ctx.dims
         P = B * T * F
         dy = dy.contiguous()
@@ -145,13 +147,14 @@ class IntraConvFn(torch.autograd.Function):
         if Fm < F:      # tail frequencies: residual (+ bias when ConvTranspose1d has output_padding)
             y[:, :, Fm:, :] = x[:, :, Fm:, :] + (dec_b if bias_tail else 0.0)
         if train:
-            ctx.save_for_backward(x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, gates, u, v_pre)
+            ctx.save_for_backward(x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc, down, Kd, bool(bias_tail))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, gates, u, v_pre = ctx.saved_tensors
+        x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, *g_ = ctx.saved_tensors
+        gates = (g_[0], g_[1] if len(g_) > 1 else None)
         B, T, F, Cc, down, Kd, bias_tail = ctx.dims
         Fm = Kd * down
         P2 = B * T * Kd

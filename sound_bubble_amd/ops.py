@@ -5,12 +5,15 @@ checks that its tensors are fp32, contiguous and on a HIP device and raises
 otherwise -- there is no eager fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
 
 H = 64
+# BPTT record format: compact (fp16 gates + fp32 c_prev, 768 B/step) unless SB_EXACT_BPTT=1 (fp32, 1280 B/step)
+COMPACT_BPTT = os.environ.get("SB_EXACT_BPTT", "0") != "1"
 PROFILE_LSTM = None     # bench.py: list collecting (start_event, end_event, algorithmic_flops) per launch
 
 
@@ -60,7 +63,12 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     assert x.numel() == geom.P * Cc
     dev = x.device
     hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float32)
-    gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32) if save else None
+    gates = cprev = None
+    if save and COMPACT_BPTT:
+        gates = torch.empty(geom.P, ndir, 4 * H, device=dev, dtype=torch.float16)
+        cprev = torch.empty(geom.P, ndir, H, device=dev, dtype=torch.float32)
+    elif save:
+        gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32)
     u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32) if save else None
     hN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
     cN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
@@ -72,7 +80,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         assert wi.shape == (4 * H, Cc) and wh.shape == (4 * H, H)
         a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
     a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
-    a.hs, a.save_gates, a.save_u = _p(hs), _p(gates), _p(u)
+    a.hs, a.save_u, a.save_c = _p(hs), _p(u), _p(cprev)
+    a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
     prof = PROFILE_LSTM
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,7 +90,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * 4 * H * (Cc + H) * geom.P * ndir))
-    return hs, ((hN, cN) if want_state else None), gates, u
+    return hs, ((hN, cN) if want_state else None), (gates, cprev), u
 
 
 def lstm_bwd_rec(w_hh_list, gates, dhs, geom):
@@ -93,7 +102,9 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom):
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
     for d, wh in enumerate(w_hh_list):
         a.w_hh[d] = _p(wh)
-    a.save_gates, a.dhs, a.dgates = _p(gates), _p(dhs), _p(dg)
+    rec, cprev = gates
+    a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), _p(cprev)
+    a.dhs, a.dgates = _p(dhs), _p(dg)
     L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
     return dg
 

@@ -45,7 +45,7 @@ def test_lstm_fwd_intra_bidirectional(torch_gpu, C):
     assert rel_l2(hs.cpu().view(nseq, S, 128).numpy(), ref.detach().numpy()) < 5e-6
     uref = torch.nn.functional.layer_norm(x, (C,), g, b, 1e-5)
     assert rel_l2(u.cpu().view(nseq, S, C).numpy(), uref.numpy()) < 2e-6
-    assert np.isfinite(gates.cpu().numpy()).all()
+    assert np.isfinite(gates[0].float().cpu().numpy()).all()
 
 
 def test_lstm_fwd_inter_with_state(torch_gpu):
@@ -169,10 +169,13 @@ def test_streaming_matches_reference(torch_gpu, name, cls):
         assert rel_l2(v, rec["stream::state::" + k]) < TOL_FWD, k
 
 
+@pytest.mark.parametrize("compact", [True, False], ids=["bptt-fp16-records", "bptt-fp32-records"])
 @pytest.mark.parametrize("name,cls", CASES)
-def test_loss_and_gradients_match_reference(torch_gpu, name, cls):
+def test_loss_and_gradients_match_reference(torch_gpu, name, cls, compact, monkeypatch):
     torch = torch_gpu
     from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd import ops
+    monkeypatch.setattr(ops, "COMPACT_BPTT", compact)
     rec, params, m = _build(torch, name, cls)
     m.train()
     est = m(_inputs(torch, rec))["output"]
@@ -186,7 +189,7 @@ def test_loss_and_gradients_match_reference(torch_gpu, name, cls):
         e = rel_l2(p.grad.cpu().numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max())
         if e > worst[1]:
             worst = (k, e)
-    assert worst[1] < TOL_GRAD, worst
+    assert worst[1] < (TOL_GRAD if compact else 2e-4), worst
 
 
 def test_oracle_agrees_at_full_size_property(torch_gpu):
