@@ -48,47 +48,53 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_arg
   const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
   const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
 
-  const int64_t ntiles = (P + 15) / 16;
-  int it = 0;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-    const int64_t p0 = tile * 16;
-    // ---- weight-gradient operands: positions p0 + 4q + r ----
-    f32x4 a4[4], h4[4];
-    float uv[CK][4];
+  // Operands of one 16-position tile.  Tiles are software-pipelined: the loads of tile t+1 are issued before the
+  // 128 MFMAs of tile t, so HBM latency hides under the matrix work.
+  struct Tile { f32x4 a4[4], h4[4], d4[4]; float uv[CK][4]; };
+  const int ntiles = (int)((P + 15) / 16);
+  const int Pi = (int)P;
+  auto load_tile = [&](int tile, Tile& t) {
+    const int p0 = tile * 16;
+    const int idx0 = p0 % a.seg_len;                     // wave-uniform
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t p = p0 + 4 * q + r;
-      const bool ok = p < P;
-      a4[r] = ok ? ld4(dg + p * ldg + 4 * j) : zero4();
-      bool ok2 = ok;
-      if (ok) {
-        const int idx = (int)(p % a.seg_len);
-        ok2 = idx >= skip_first && idx < a.seg_len - skip_last;
-      }
-      h4[r] = ok2 ? ld4(hs + p * ldh + hshift + 4 * j) : zero4();
+      const int p = p0 + 4 * q + r;
+      const bool ok = p < Pi;
+      t.a4[r] = ok ? ld4(dg + (int64_t)p * ldg + 4 * j) : zero4();
+      int idx = idx0 + 4 * q + r;
+      while (idx >= a.seg_len) idx -= a.seg_len;
+      const bool ok2 = ok && idx >= skip_first && idx < a.seg_len - skip_last;
+      t.h4[r] = ok2 ? ld4(hs + (int64_t)p * ldh + hshift + 4 * j) : zero4();
       if constexpr (CK == 2) {
-        const float2 t = ok ? *reinterpret_cast<const float2*>(a.u + p * C + 2 * j) : make_float2(0.f, 0.f);
-        uv[0][r] = t.x; uv[1][r] = t.y;
+        const float2 v = ok ? *reinterpret_cast<const float2*>(a.u + (int64_t)p * C + 2 * j) : make_float2(0.f, 0.f);
+        t.uv[0][r] = v.x; t.uv[1][r] = v.y;
       } else {
-        uv[0][r] = ok ? a.u[p * C + j] : 0.f;
+        t.uv[0][r] = ok ? a.u[(int64_t)p * C + j] : 0.f;
       }
     }
-    // ---- dU operand: dgates of position p0 + j, gate chunk m (same cache lines as above) ----
-    const int64_t pj = p0 + j;
-    f32x4 d4[4];
+    const int pj = p0 + j;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) d4[m] = pj < P ? ld4(dg + pj * ldg + 16 * m + 4 * q) : zero4();
+    for (int m = 0; m < 4; ++m) t.d4[m] = pj < Pi ? ld4(dg + (int64_t)pj * ldg + 16 * m + 4 * q) : zero4();
+  };
 
+  Tile cur;
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x, cur);
+  int it = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+    Tile nxt;
+    const int tn = tile + gridDim.x;
+    load_tile(tn < ntiles ? tn : tile, nxt);             // (re-loads the last tile at the tail: branch-free)
+    const int pj = tile * 16 + j;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const float av = a4[r][nt];
+        const float av = cur.a4[r][nt];
         csum[nt] += av;
 #pragma unroll
-        for (int kt = 0; kt < CK; ++kt) acc[nt][kt] = mfma16(av, uv[kt][r], acc[nt][kt]);
+        for (int kt = 0; kt < CK; ++kt) acc[nt][kt] = mfma16(av, cur.uv[kt][r], acc[nt][kt]);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) acc[nt][CK + kt] = mfma16(av, h4[r][kt], acc[nt][CK + kt]);
+        for (int kt = 0; kt < 4; ++kt) acc[nt][CK + kt] = mfma16(av, cur.h4[r][kt], acc[nt][CK + kt]);
       }
     f32x4 du[CK];
 #pragma unroll
@@ -98,16 +104,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_arg
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int ct = 0; ct < CK; ++ct) du[ct] = mfma16(Awt[ct][m][r], d4[m][r], du[ct]);
+        for (int ct = 0; ct < CK; ++ct) du[ct] = mfma16(Awt[ct][m][r], cur.d4[m][r], du[ct]);
     const int buf = it & 1;
 #pragma unroll
     for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][ct][lane][0], du[ct]);
     __syncthreads();
-    if (w < CK && pj < P) {
+    if (w < CK && pj < Pi) {
       const f32x4 s = ld4(&R[buf][0][w][lane][0]) + ld4(&R[buf][1][w][lane][0]) + ld4(&R[buf][2][w][lane][0]) +
                       ld4(&R[buf][3][w][lane][0]);
-      st4(a.du_part + (pj * ndir + dir) * C + 16 * w + 4 * q, s);
+      st4(a.du_part + ((int64_t)pj * ndir + dir) * C + 16 * w + 4 * q, s);
     }
+    cur = nxt;
   }
 
   // ---- partial results: [N*(C+64) + N] per workgroup, true (un-permuted) indices ----

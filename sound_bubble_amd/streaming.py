@@ -1,0 +1,101 @@
+"""Streaming causal inference (BASELINE config 5): 8 ms chunks, carried state, hipGraph-captured chunk step.
+
+Mirrors edge/causal_infer.py: `ModelWrapper.feed` (:15-26) keeps `internal_state` and calls
+`model(dict(mixture=frame), state, pad=False)`; `streaming_inference` (:28-47) rolls a
+[1, M, chunk+pad] window by `chunk` samples per call.  Here the whole per-chunk launch sequence
+(~10 kernels per block) is captured ONCE into a hipGraph; each `feed` is one copy of the 288-sample
+window + one graph replay, and the recurrent/conv/iSTFT state lives in static device buffers that the
+captured graph updates in place.
+"""
+import torch
+
+
+def flatten_state(d, prefix=""):
+    """'::'-joined names in sorted order (edge/flatbuf.py:8-25)."""
+    out = {}
+    for k in sorted(d):
+        if isinstance(d[k], dict):
+            out.update(flatten_state(d[k], prefix + k + "::"))
+        else:
+            out[prefix + k] = d[k]
+    return out
+
+
+def _clone_tree(d):
+    return {k: _clone_tree(v) if isinstance(v, dict) else v for k, v in d.items()}
+
+
+class StreamingSeparator(torch.nn.Module):
+    def __init__(self, model, batch_size=1, dis_embed=None, use_graph=True):
+        super().__init__()
+        self.model = model.eval()
+        dev = next(model.parameters()).device
+        self.chunk, self.pad = model.stft_chunk_size, model.stft_pad_size
+        self.frame = torch.zeros(batch_size, model.num_ch, self.chunk + self.pad, device=dev)
+        self.state = model.init_buffers(batch_size, dev)          # static buffers, updated in place
+        self.dis_embed = dis_embed.to(dev) if dis_embed is not None else None
+        self.out = None
+        self.graph = None
+        self.use_graph = use_graph
+
+    def _inputs(self):
+        d = {"mixture": self.frame}
+        if self.dis_embed is not None:
+            d["dis_embed"] = self.dis_embed
+        return d
+
+    def _step_inplace(self):
+        """one chunk; the new state is written back INTO the static state buffers"""
+        static = flatten_state(self.state)
+        st = _clone_tree(self.state)                               # shallow: same tensors, fresh dicts
+        out = self.model(self._inputs(), st, pad=False)["output"]
+        for k, v in flatten_state(st).items():
+            if v.data_ptr() != static[k].data_ptr():
+                static[k].copy_(v)
+        return out
+
+    def _capture(self):
+        static = flatten_state(self.state)
+        snap = {k: v.clone() for k, v in static.items()}
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():                # warm-up off-graph (allocator, lazy init)
+            for _ in range(2):
+                self._step_inplace()
+        torch.cuda.current_stream().wait_stream(s)
+        for k, v in static.items():                                # undo the warm-up's state updates
+            v.copy_(snap[k])
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self._step_inplace()
+        for k, v in static.items():
+            v.copy_(snap[k])
+
+    @torch.no_grad()
+    def feed(self, frame):
+        """frame: [B, M, chunk+pad] window (already rolled).  Returns [B, 1, chunk] (a static buffer when graphed)."""
+        self.frame.copy_(frame, non_blocking=True)
+        if not self.use_graph:
+            return self._step_inplace()
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        return self.out
+
+    def reset(self):
+        for v in flatten_state(self.state).values():
+            v.zero_()
+
+
+@torch.no_grad()
+def streaming_inference(sep, X):
+    """edge/causal_infer.py:28-47: X [B, M, k*chunk + pad] -> [B, 1, k*chunk]."""
+    T, P = sep.chunk, sep.pad
+    cur = torch.zeros(X.shape[0], X.shape[1], T + P, device=X.device)
+    cur[..., -P:] = X[..., :P]
+    outs = []
+    for i in range(P, X.shape[-1] - P + 1, T):
+        cur = torch.roll(cur, shifts=-T, dims=-1)
+        cur[..., -T:] = X[..., i:i + T]
+        outs.append(sep.feed(cur).clone())
+    return torch.cat(outs, dim=-1)

@@ -205,3 +205,24 @@ def test_oracle_agrees_at_full_size_property(torch_gpu):
         y2 = m({"mixture": x[..., : 192 * 100 + 96].contiguous()}, pad=False)["output"]
     assert y.shape == (1, 1, 120000) and torch.isfinite(y).all()
     assert rel_l2(y[..., : 192 * 100].cpu().numpy(), y2.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_streaming_separator_equals_offline(torch_gpu, use_graph):
+    """edge/causal_infer.py:49-86 self-check: chunked output == one-shot output (atol 1e-3 there)."""
+    torch = torch_gpu
+    from sound_bubble_amd.streaming import StreamingSeparator, streaming_inference
+    rec, params, m = _build(torch, "tiny_big", "NetDisEmbd3")
+    dis = torch.from_numpy(rec["dis_embed"][:1]).cuda()
+    torch.manual_seed(1)
+    X = (0.1 * torch.randn(1, 6, 192 * 12 + 96)).cuda()
+    with torch.no_grad():
+        Y = m({"mixture": X, "dis_embed": dis}, pad=False)["output"]
+    sep = StreamingSeparator(m, 1, dis_embed=dis, use_graph=use_graph)
+    Z = streaming_inference(sep, X)
+    assert Z.shape == Y.shape == (1, 1, 192 * 12)
+    assert rel_l2(Z.cpu().numpy(), Y.cpu().numpy()) < 2e-5
+    # a second utterance after reset() reproduces the first (state really lives in the static buffers)
+    sep.reset()
+    Z2 = streaming_inference(sep, X)
+    assert torch.equal(Z, Z2)
