@@ -239,6 +239,55 @@ def make_case(torch, Net, name, params, B, n_frames, seed, needs_dis, out_dir,
           f"({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def make_samples(torch, NetBig, out_dir, n_keep=36000):
+    """test_samples/syn_1m scenes (reference fixtures, MIT licence), trimmed to 1.5 s, pushed through the REFERENCE
+    model (weights of tiny_big.npz) with the reference's own NumPy metrics (helpers/eval_utils.py)."""
+    import json
+    import wave
+    import shutil
+    sys.path.insert(0, os.path.join(REF, "helpers"))
+    import eval_utils                                            # reference helpers/eval_utils.py
+    z = np.load(os.path.join(out_dir, "tiny_big.npz"))
+    params = dict(eval(str(z["meta::params"])))
+    model = NetBig(**params).eval()
+    sd = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param::")}
+    filt = torch.from_numpy(np.load(os.path.join(out_dir, "stft_filters.npz"))["filters"])
+    sd["tfgridnet.enc.filterbank._filters"] = filt
+    sd["tfgridnet.dec.filterbank._filters"] = filt.clone()
+    model.load_state_dict(sd)
+    rec = {}
+    for scene in ("00000", "00001", "00002"):
+        src = os.path.join(REF, "test_samples", "syn_1m", scene)
+        dst = os.path.join(out_dir, "test_samples", "syn_1m", scene)
+        os.makedirs(dst, exist_ok=True)
+        shutil.copyfile(os.path.join(src, "metadata.json"), os.path.join(dst, "metadata.json"))
+        for fn in sorted(os.listdir(src)):
+            if fn.endswith(".wav"):
+                with wave.open(os.path.join(src, fn), "rb") as w:
+                    par, data = w.getparams(), w.readframes(n_keep)
+                with wave.open(os.path.join(dst, fn), "wb") as w:
+                    w.setparams(par)
+                    w.writeframes(data)
+        meta = json.load(open(os.path.join(dst, "metadata.json")))
+        with wave.open(os.path.join(dst, "mixture.wav"), "rb") as w:
+            mix = np.frombuffer(w.readframes(n_keep), "<i2").reshape(-1, 6).T.astype(np.float32) / 32768.0
+        gt = np.zeros((1, mix.shape[1]), np.float32)
+        for spk in sorted(k for k in meta if k.startswith("voice")):
+            if meta[spk]["dis"] <= 1.0:
+                with wave.open(os.path.join(dst, f"mic00_{spk}.wav"), "rb") as w:
+                    gt[0] += np.frombuffer(w.readframes(n_keep), "<i2").astype(np.float32) / 32768.0
+        with torch.no_grad():
+            out = model({"mixture": torch.from_numpy(mix)[None], "dis_embed": torch.tensor([[0.0, 0.0, 1.0]])})["output"][0].numpy()
+        rec[scene + "::output"] = out
+        rec[scene + "::gt"] = gt
+        if np.abs(gt).max() > 0:
+            rec[scene + "::si_sdr"] = np.float64(eval_utils.si_sdr(out[0].astype(np.float64), gt[0].astype(np.float64)))
+            rec[scene + "::input_si_sdr"] = np.float64(eval_utils.si_sdr(mix[0].astype(np.float64), gt[0].astype(np.float64)))
+            rec[scene + "::snr"] = np.float64(eval_utils.snr(out[0].astype(np.float64), gt[0].astype(np.float64)))
+            print(scene, "SI-SDR", rec[scene + "::si_sdr"], "input", rec[scene + "::input_si_sdr"])
+    np.savez_compressed(os.path.join(out_dir, "samples_syn_1m.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.dirname(os.path.abspath(__file__)))
@@ -282,6 +331,7 @@ def main():
     # real small config, 1 s clip (125 frames), forward only
     make_case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
               with_grads=False, with_stream=False, with_stages=False)
+    make_samples(torch, NetBig, args.out)
 
 
 if __name__ == "__main__":

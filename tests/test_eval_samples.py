@@ -1,0 +1,75 @@
+"""BASELINE config 1 (plumbing + numerics): test_samples/syn_1m scenes (trimmed reference fixtures) through the
+WAV/metadata reader, the model with shared weights, and the SI-SDR formula.  Parity bar from the north star:
+output <= 1e-3 relative L2, SI-SDR within +-0.05 dB of the reference's value."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, golden_state_dict, rel_l2
+
+SAMPLES = os.path.join(GOLDEN, "test_samples", "syn_1m")
+
+
+def _golden():
+    z = np.load(os.path.join(GOLDEN, "samples_syn_1m.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_reader_assembles_ground_truth_like_the_reference():
+    from sound_bubble_amd.eval_samples import load_testcase
+    g = _golden()
+    counts = {}
+    for scene in ("00000", "00001", "00002"):
+        meta, mix, gt, tg = load_testcase(os.path.join(SAMPLES, scene), 1.0)
+        assert mix.shape == (6, 36000) and mix.dtype == np.float32 and np.abs(mix).max() <= 1.0
+        np.testing.assert_array_equal(gt, g[scene + "::gt"])
+        counts[scene] = len(tg)
+    assert counts == {"00000": 0, "00001": 1, "00002": 2}          # one scene each with 0 / 1 / 2 in-bubble speakers
+
+
+def test_wav_roundtrip(tmp_path):
+    from sound_bubble_amd.eval_samples import read_wav, write_wav
+    x, sr = read_wav(os.path.join(SAMPLES, "00001", "mixture.wav"))
+    write_wav(str(tmp_path / "a.wav"), x, sr)
+    y, _ = read_wav(str(tmp_path / "a.wav"))
+    np.testing.assert_array_equal(x, y)
+
+
+def test_oracle_on_samples_matches_reference(torch_mod):
+    torch = torch_mod
+    from oracle.tfgridnet_oracle import OracleNet
+    from sound_bubble_amd.eval_samples import load_testcase, si_sdr_np, snr_np
+    rec, params, flavour = load_golden("tiny_big")
+    m = OracleNet(flavour, **params).eval()
+    m.load_state_dict(golden_state_dict(rec, torch))
+    g = _golden()
+    for scene in ("00001", "00002"):
+        _, mix, gt, _ = load_testcase(os.path.join(SAMPLES, scene), 1.0)
+        with torch.no_grad():
+            out = m({"mixture": torch.from_numpy(mix)[None], "dis_embed": torch.tensor([[0.0, 0.0, 1.0]])})["output"][0].numpy()
+        assert rel_l2(out, g[scene + "::output"]) < 5e-6
+        assert abs(si_sdr_np(out[0], gt[0]) - float(g[scene + "::si_sdr"])) < 0.05
+        assert abs(si_sdr_np(mix[0], gt[0]) - float(g[scene + "::input_si_sdr"])) < 1e-6     # formula pinned
+        assert abs(snr_np(out[0], gt[0]) - float(g[scene + "::snr"])) < 0.05
+
+
+@pytest.mark.gpu
+def test_hip_model_on_samples_si_sdr_parity():
+    import torch
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.eval_samples import evaluate_dir, load_testcase, run_testcase
+    rec, params, _ = load_golden("tiny_big")
+    m = sb.NetDisEmbd3(**params)
+    m.load_state_dict(golden_state_dict(rec, torch))
+    m = m.cuda().eval()
+    g = _golden()
+    rows = {r["sample"]: r for r in evaluate_dir(m, SAMPLES, 1.0)}
+    assert rows["00000"]["n_targets"] == 0 and "decay" in rows["00000"]
+    for scene in ("00001", "00002"):
+        _, mix, gt, _ = load_testcase(os.path.join(SAMPLES, scene), 1.0)
+        out = run_testcase(m, mix, 1.0)
+        assert rel_l2(out, g[scene + "::output"]) < 2e-5                    # bar: 1e-3
+        assert abs(rows[scene]["si_sdr"] - float(g[scene + "::si_sdr"])) < 0.05
+    with pytest.raises(ValueError):
+        run_testcase(m, np.zeros((6, 960), np.float32), 1.2)
