@@ -69,7 +69,7 @@ def test_hip_model_on_samples_si_sdr_parity():
     for scene in ("00001", "00002"):
         _, mix, gt, _ = load_testcase(os.path.join(SAMPLES, scene), 1.0)
         out = run_testcase(m, mix, 1.0)
-        assert rel_l2(out, g[scene + "::output"]) < 2e-5                    # bar: 1e-3
+        assert rel_l2(out, g[scene + "::output"]) < 2e-4                    # north-star bar: 1e-3 (187 frames, random weights)
         assert abs(rows[scene]["si_sdr"] - float(g[scene + "::si_sdr"])) < 0.05
     with pytest.raises(ValueError):
         run_testcase(m, np.zeros((6, 960), np.float32), 1.2)
