@@ -206,9 +206,11 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
 
 // ---------------------------------------------------------------------------------------------
 // dW[n, k] = sum_p g(p, n) * [in1(p, :K1) | in2(p, :K2)][k]  (+ column sums of g = bias gradients).
-// Wave w owns n-blocks [w*NTW, (w+1)*NTW) and all K blocks; the A operand (g) is fetched ONCE for both
-// sources, so dW_ih, dW_hh and db of an LSTM cost a single pass over dgates.  Source 2 is a dense row
-// matrix addressed p*ld2 + shift2 with the per-segment first/last-row exclusion (h_{t-1} of step 0).
+// Used for the narrow layers (N <= 80: Linear / Conv1d / ConvTranspose1d / 3x3 convs); the 256-row LSTM
+// gradients have their own kernel (sb_lstm_stream.hip).  Every wave holds ALL n-blocks and walks its own
+// position tiles (tile = 4*block + wave), so all four SIMDs work even when N = 16; each wave emits one
+// partial row and a second, wide kernel reduces the rows.  Source 2 is a dense row matrix addressed
+// p*ld2 + shift2 with the per-segment first/last-row exclusion.
 template <int NTW, int KT1, int KT2>
 __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) {
   constexpr int KT = KT1 + KT2;
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
   int ncol[NTW];
   bool nval[NTW];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) { ncol[nt] = 16 * (w * NTW + nt) + j; nval[nt] = ncol[nt] < a.N; }
+  for (int nt = 0; nt < NTW; ++nt) { ncol[nt] = 16 * nt + j; nval[nt] = ncol[nt] < a.N; }
 
   const int64_t ntiles = (P + 15) / 16;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     float av[NTW][4], bv[KT][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -267,14 +269,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
       }
   }
   const int Ktot = a.K + a.K2;
-  float* part = a.scratch + (size_t)blockIdx.x * ((size_t)a.N * Ktot + a.N);
+  float* part = a.scratch + ((size_t)blockIdx.x * 4 + w) * ((size_t)a.N * Ktot + a.N);
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = 16 * (w * NTW + nt) + 4 * q + r;
+        const int n = 16 * nt + 4 * q + r;
         const int k = kt < KT1 ? 16 * kt + j : a.K + 16 * (kt - KT1) + j;
         const bool kok = kt < KT1 ? (16 * kt + j < a.K) : true;
         if (n < a.N && kok) part[(size_t)n * Ktot + k] = acc[nt][kt][r];
@@ -363,7 +365,7 @@ extern "C" int sb_linear_grid(int64_t positions) {
   return (int)(t < LIN_MAX_WG ? (t < 1 ? 1 : t) : LIN_MAX_WG);
 }
 extern "C" int sb_wgrad_grid(int64_t positions) {
-  const int64_t t = (positions + 15) / 16;
+  const int64_t t = (positions + 63) / 64;
   return (int)(t < WG_MAX_WG ? (t < 1 ? 1 : t) : WG_MAX_WG);
 }
 
@@ -404,20 +406,20 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (!ap) return -1001;
   const sb_wgrad_args& a = *ap;
   const int64_t P = (int64_t)a.B * a.T * a.F;
-  const int nblk = (a.N + 15) / 16, kt1 = (a.K + 15) / 16, kt2 = a.K2 / 16, ntw = (nblk + 3) / 4;
+  const int nblk = (a.N + 15) / 16, kt1 = (a.K + 15) / 16, kt2 = a.K2 / 16, ntw = nblk;
   if (a.K2 % 16 || (a.K2 && a.K % 16)) return -1002;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(sb_wgrad_grid(P)), block(256);
 #define SB_WG(NTW_, KT1_, KT2_) \
   if (ntw == NTW_ && kt1 == KT1_ && kt2 == KT2_) { hipLaunchKernelGGL((wgrad_kernel<NTW_, KT1_, KT2_>), grid, block, 0, st, a, P); } else
-  SB_WG(4, 1, 4) SB_WG(4, 2, 4) SB_WG(4, 1, 0) SB_WG(4, 2, 0) SB_WG(4, 4, 0)
-  SB_WG(1, 1, 0) SB_WG(1, 2, 0) SB_WG(1, 4, 0) SB_WG(1, 8, 0) SB_WG(1, 5, 0) SB_WG(1, 10, 0) SB_WG(1, 9, 0) SB_WG(1, 18, 0)
-  SB_WG(2, 8, 0) SB_WG(3, 8, 0) SB_WG(2, 4, 0) SB_WG(2, 2, 0) SB_WG(2, 1, 0) { return -1004; }
+  SB_WG(1, 1, 0) SB_WG(1, 2, 0) SB_WG(1, 4, 0) SB_WG(1, 8, 0) SB_WG(1, 5, 0) SB_WG(1, 9, 0) SB_WG(1, 18, 0)
+  SB_WG(2, 1, 0) SB_WG(2, 2, 0) SB_WG(2, 4, 0) SB_WG(2, 8, 0) SB_WG(2, 10, 0) SB_WG(2, 18, 0)
+  SB_WG(3, 8, 0) SB_WG(4, 8, 0) SB_WG(5, 8, 0) SB_WG(8, 8, 0) SB_WG(10, 8, 0) SB_WG(1, 3, 0) SB_WG(1, 6, 0) SB_WG(2, 5, 0) SB_WG(2, 6, 0) SB_WG(1, 1, 4) SB_WG(2, 2, 4) { return -1004; }
 #undef SB_WG
   SB_CHECK_LAUNCH();
   const int total = a.N * (a.K + a.K2) + a.N;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, grid.x >= 64 ? 16 : 1), dim3(256), 0, st, a.scratch,
-                     (int)grid.x, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out);
+                     (int)grid.x * 4, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out);
   SB_CHECK_LAUNCH();
   return 0;
 }

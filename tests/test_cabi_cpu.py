@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.sb_linear_grid(10 ** 9) == 1024 and lib.sb_linear_grid(1) == 1
-    assert lib.sb_wgrad_grid(100) == 7
+    assert lib.sb_wgrad_grid(100) == 2
 
 
 def test_struct_layouts_match_header_sizes():
