@@ -240,71 +240,88 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
   const int64_t base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
   const int uoff = 16 * w + 4 * q;
 
-  struct Rec { f32x4 i, f, g, o, cp, dh; };
-  auto load_rec = [&](int s) {   // s = forward processing index
-    Rec r;
+  // Raw (as stored) record of one step; converted to fp32 only at its point of use so that the prefetch of
+  // step s-1, issued before the MFMAs of step s, is not waited for inside step s.
+  struct Raw { f32x4 r0, r1, r2, r3, cp, dh; };
+  auto load_raw = [&](int s) {   // s = forward processing index
+    Raw r;
     const int st = rev ? S - 1 - s : s;
     const int64_t pos = base + (int64_t)st * a.p_step;
     if (valid) {
       if constexpr (REC16) {
-        const _Float16* rec = reinterpret_cast<const _Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
-        const h16x8 lo = *reinterpret_cast<const h16x8*>(rec), hi = *reinterpret_cast<const h16x8*>(rec + 8);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          r.i[k] = (float)lo[k]; r.f[k] = (float)lo[4 + k]; r.g[k] = (float)hi[k]; r.o[k] = (float)hi[4 + k];
-        }
+        const float* rec = a.save_gates + ((pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16) / 2;   // fp16 units -> floats
+        r.r0 = ld4(rec); r.r1 = ld4(rec + 4);
+        r.r2 = r.r3 = zero4();
         r.cp = ld4(a.save_c + (pos * ndir + dir) * H + uoff);
       } else {
         const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
-        r.i = ld4(rec); r.f = ld4(rec + H); r.g = ld4(rec + 2 * H); r.o = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
+        r.r0 = ld4(rec); r.r1 = ld4(rec + H); r.r2 = ld4(rec + 2 * H); r.r3 = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
       }
       r.dh = ld4(a.dhs + (pos * ndir + dir) * H + uoff);
     } else {
-      r.i = r.f = r.g = r.o = r.cp = r.dh = zero4();
+      r.r0 = r.r1 = r.r2 = r.r3 = r.cp = r.dh = zero4();
     }
     return r;
   };
+  struct Rec { f32x4 i, f, g, o; };
+  auto unpack = [&](const Raw& r) {
+    Rec c;
+    if constexpr (REC16) {
+      const h16x8 lo = __builtin_bit_cast(h16x8, r.r0), hi = __builtin_bit_cast(h16x8, r.r1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        c.i[k] = (float)lo[k]; c.f[k] = (float)lo[4 + k]; c.g[k] = (float)hi[k]; c.o[k] = (float)hi[4 + k];
+      }
+    } else {
+      c.i = r.r0; c.f = r.r1; c.g = r.r2; c.o = r.r3;
+    }
+    return c;
+  };
 
   f32x4 dc = zero4(), dhrec = zero4();
-  Rec nxt = load_rec(S - 1);
+  Raw nxt = load_raw(S - 1);
   for (int s = S - 1; s >= 0; --s) {
     const int cur = s & 1;
-    const Rec rc = nxt;
-    nxt = load_rec(max(s - 1, 0));
+    const Raw raw = nxt;
+    const Rec rc = unpack(raw);
+    // ---- cell backward (lane-local: 4 units of one sequence) ----
     f32x4 dG[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float dh = rc.dh[r] + dhrec[r];
-      const float cc = rc.f[r] * rc.cp[r] + rc.i[r] * rc.g[r];
+      const float dh = raw.dh[r] + dhrec[r];
+      const float cc = rc.f[r] * raw.cp[r] + rc.i[r] * rc.g[r];
       const float tc = tanhf_fast(cc);
       const float dO = dh * tc;
       const float dct = dc[r] + dh * rc.o[r] * (1.0f - tc * tc);
       dG[0][r] = dct * rc.g[r] * rc.i[r] * (1.0f - rc.i[r]);
-      dG[1][r] = dct * rc.cp[r] * rc.f[r] * (1.0f - rc.f[r]);
+      dG[1][r] = dct * raw.cp[r] * rc.f[r] * (1.0f - rc.f[r]);
       dG[2][r] = dct * rc.i[r] * (1.0f - rc.g[r] * rc.g[r]);
       dG[3][r] = dO * rc.o[r] * (1.0f - rc.o[r]);
       dc[r] = dct * rc.f[r];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dgates out, then prefetch the previous step's record (youngest ops = the loads) ----
     if (valid) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = base + (int64_t)st * a.p_step;
       float* dg = a.dgates + (pos * ndir + dir) * (4 * H) + uoff;
       st4(dg, dG[0]); st4(dg + H, dG[1]); st4(dg + 2 * H, dG[2]); st4(dg + 3 * H, dG[3]);
     }
-    {
-      f32x4 part[4] = {zero4(), zero4(), zero4(), zero4()};
+    nxt = load_raw(max(s - 1, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- partial dh^T = W_hh^T[:, this wave's gate rows] * dgates ; reduce over waves through LDS ----
+    f32x4 part[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int ot = 0; ot < 4; ++ot) part[ot] = mfma16(At[ot][g][r], dG[g][r], part[ot]);
+        for (int ot = 0; ot < 4; ++ot) part[ot] = mfma16(At[ot][g][r], dG[g][r], part[ot]);
 #pragma unroll
-      for (int ot = 0; ot < 4; ++ot) st4(&P[cur][w][ot][lane][0], part[ot]);
-      __syncthreads();
-      dhrec = ld4(&P[cur][0][w][lane][0]) + ld4(&P[cur][1][w][lane][0]) + ld4(&P[cur][2][w][lane][0]) +
-              ld4(&P[cur][3][w][lane][0]);
-    }
+    for (int ot = 0; ot < 4; ++ot) st4(&P[cur][w][ot][lane][0], part[ot]);
+    __syncthreads();
+    dhrec = ld4(&P[cur][0][w][lane][0]) + ld4(&P[cur][1][w][lane][0]) + ld4(&P[cur][2][w][lane][0]) +
+            ld4(&P[cur][3][w][lane][0]);
   }
 }
 
@@ -337,10 +354,10 @@ extern "C" int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream) {
   dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
   hipStream_t st = (hipStream_t)stream;
   const bool full = a->nseq % 16 == 0, r16 = a->save_c != nullptr;
-  if (full) { if (r16) hipLaunchKernelGGL((lstm_bwd_rec_kernel<true, true>), grid, block, 0, st, *a);
-              else hipLaunchKernelGGL((lstm_bwd_rec_kernel<true, false>), grid, block, 0, st, *a); }
-  else { if (r16) hipLaunchKernelGGL((lstm_bwd_rec_kernel<false, true>), grid, block, 0, st, *a);
-         else hipLaunchKernelGGL((lstm_bwd_rec_kernel<false, false>), grid, block, 0, st, *a); }
+#define SB_B(FL, R16) hipLaunchKernelGGL((lstm_bwd_rec_kernel<FL, R16>), grid, block, 0, st, *a)
+  if (full) { if (r16) SB_B(true, true); else SB_B(true, false); }
+  else { if (r16) SB_B(false, true); else SB_B(false, false); }
+#undef SB_B
   SB_CHECK_LAUNCH();
   return 0;
 }
