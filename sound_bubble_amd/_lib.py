@@ -55,7 +55,7 @@ class LstmStreamArgs(C.Structure):
                 ("dgates", c_fp), ("u", c_fp), ("hs", c_fp),
                 ("w_ih", c_fp * 2),
                 ("dW_ih", c_fp * 2), ("dW_hh", c_fp * 2), ("db_ih", c_fp * 2), ("db_hh", c_fp * 2),
-                ("du_part", c_fp), ("scratch", c_fp)]
+                ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int)]
 
 
 class LnBwdArgs(C.Structure):

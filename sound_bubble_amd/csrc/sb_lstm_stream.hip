@@ -135,6 +135,176 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_arg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Same computation on the bf16 matrix pipe with 3-term split products ("bf16x3"): every fp32 operand x is
+// split as x = hi + lo (hi = bf16(x), lo = bf16(x - hi)) and a*b ~= ah*bh + ah*bl + al*bh, each product exact
+// in the fp32 accumulator -- relative error ~2^-16 per term, i.e. fp32-class for a gradient reduction, at
+// 1/5 of the fp32-MFMA cycles.  v_mfma_f32_16x16x32_bf16 contracts 32 positions per instruction (8 per lane:
+// lane l holds k = 8*(l>>4)..+7), so a chunk is 32 positions; the tile-interleaved column assignment
+// (gate = 64w + 4i + tile) still gives one 16-byte load per lane per position.  With the matrix work cut 4x
+// the kernel becomes HBM-bound, so the next chunk's raw operands are prefetched into registers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct SplitBf { bf16x8 hi, lo; };
+SB_DEVINL SplitBf split8(const float (&x)[8]) {
+  SplitBf s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const __bf16 h = (__bf16)x[k];
+    s.hi[k] = h;
+    s.lo[k] = (__bf16)(x[k] - (float)h);
+  }
+  return s;
+}
+SB_DEVINL f32x4 mfma_bf3(const SplitBf& a, const SplitBf& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+  return c;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void lstm_bwd_stream_bf16_kernel(sb_lstm_stream_args a) {
+  constexpr int CK = C / 16, KT = CK + 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int dir = blockIdx.y, ndir = a.ndir;
+  const int Pi = (int)a.P;
+  __shared__ __attribute__((aligned(16))) float R[2][4][2][CK][64][4];
+
+  // W_ih^T, split once: A[i = channel 16ct + j][k = gate 64w + 32m + 8q + kk]
+  const float* __restrict__ wih = a.w_ih[dir];
+  SplitBf Awt[CK][2];
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = wih[(size_t)(64 * w + 32 * m + 8 * q + kk) * C + 16 * ct + j];
+      Awt[ct][m] = split8(t);
+    }
+
+  f32x4 acc[4][KT];
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = zero4();
+
+  const float* __restrict__ dg = a.dgates + (size_t)dir * 4 * H + 64 * w;
+  const float* __restrict__ hs = a.hs + (size_t)dir * H;
+  const int64_t ldg = (int64_t)ndir * 4 * H, ldh = (int64_t)ndir * H;
+  const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
+  const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
+
+  struct Chunk { f32x4 a4[8], h4[8], d4[2][2][2]; float uv[CK][8]; };     // raw fp32 operands of 32 positions
+  const int nchunks = (Pi + 31) / 32;
+  auto load_chunk = [&](int ch, Chunk& t) {
+    const int p0 = ch * 32;
+    const int idx0 = p0 % a.seg_len;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int p = p0 + 8 * q + kk;
+      const bool ok = p < Pi;
+      t.a4[kk] = ok ? ld4(dg + (int64_t)p * ldg + 4 * j) : zero4();
+      int idx = idx0 + 8 * q + kk;
+      while (idx >= a.seg_len) idx -= a.seg_len;
+      const bool ok2 = ok && idx >= skip_first && idx < a.seg_len - skip_last;
+      t.h4[kk] = ok2 ? ld4(hs + (int64_t)p * ldh + hshift + 4 * j) : zero4();
+      if constexpr (CK == 2) {
+        const float2 v = ok ? *reinterpret_cast<const float2*>(a.u + (int64_t)p * C + 2 * j) : make_float2(0.f, 0.f);
+        t.uv[0][kk] = v.x; t.uv[1][kk] = v.y;
+      } else {
+        t.uv[0][kk] = ok ? a.u[(int64_t)p * C + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {          // dU operand: position p0 + 16 sb + j, gates 32m + 8q .. +7
+      const int pj = p0 + 16 * sb + j;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          t.d4[sb][m][hh] = pj < Pi ? ld4(dg + (int64_t)pj * ldg + 32 * m + 8 * q + 4 * hh) : zero4();
+    }
+  };
+
+  Chunk cur;
+  if ((int)blockIdx.x < nchunks) load_chunk(blockIdx.x, cur);
+  int it = 0;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x, ++it) {
+    Chunk nxt;
+    const int cn = ch + gridDim.x;
+    load_chunk(cn < nchunks ? cn : ch, nxt);
+    // ---- weight gradients: 4 gate tiles x (CK + 4) column tiles, K = 32 positions ----
+    SplitBf Bop[KT];
+#pragma unroll
+    for (int kt = 0; kt < CK; ++kt) Bop[kt] = split8(cur.uv[kt]);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = cur.h4[kk][kt];
+      Bop[CK + kt] = split8(t);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) { t[kk] = cur.a4[kk][nt]; csum[nt] += t[kk]; }
+      const SplitBf Aop = split8(t);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = mfma_bf3(Aop, Bop[kt], acc[nt][kt]);
+    }
+    // ---- dU = W_ih^T dgates for the two 16-position sub-tiles ----
+    const int buf = it & 1;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      f32x4 du[CK];
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) du[ct] = zero4();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float t[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) t[kk] = cur.d4[sb][m][kk >> 2][kk & 3];
+        const SplitBf Dop = split8(t);
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) du[ct] = mfma_bf3(Awt[ct][m], Dop, du[ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
+    }
+    __syncthreads();
+    {   // 2 sub-tiles x CK channel tiles = 2*CK (<= 4) reductions: one per wave
+      const int sb = w / CK, ct = w % CK;
+      const int pj = ch * 32 + 16 * sb + j;
+      if (w < 2 * CK && pj < Pi) {
+        const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
+                         ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
+        st4(a.du_part + ((int64_t)pj * ndir + dir) * C + 16 * ct + 4 * q, s4);
+      }
+    }
+    cur = nxt;
+  }
+
+  constexpr int Ktot = C + H;
+  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) * ((size_t)4 * H * Ktot + 4 * H);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gate = 64 * w + 4 * (4 * q + r) + nt;
+#pragma unroll
+      for (int kt = 0; kt < CK; ++kt) part[(size_t)gate * Ktot + (CK == 2 ? 2 * j + kt : j)] = acc[nt][kt][r];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) part[(size_t)gate * Ktot + C + 4 * j + kt] = acc[nt][CK + kt][r];
+    }
+    const float cs = quad_sum(csum[nt]);
+    if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs;
+  }
+}
+
 __global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restrict__ partials, int rows, int C,
                                                             float* __restrict__ dW1, float* __restrict__ dW2,
                                                             float* __restrict__ db1, float* __restrict__ db2) {
@@ -236,8 +406,13 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int gx = sb_lstm_stream_grid(ap->P);
   dim3 grid(gx, ap->ndir), block(256);
-  if (ap->C == 32) hipLaunchKernelGGL(lstm_bwd_stream_kernel<32>, grid, block, 0, st, *ap);
-  else hipLaunchKernelGGL(lstm_bwd_stream_kernel<16>, grid, block, 0, st, *ap);
+  if (ap->split_bf16) {
+    if (ap->C == 32) hipLaunchKernelGGL(lstm_bwd_stream_bf16_kernel<32>, grid, block, 0, st, *ap);
+    else hipLaunchKernelGGL(lstm_bwd_stream_bf16_kernel<16>, grid, block, 0, st, *ap);
+  } else {
+    if (ap->C == 32) hipLaunchKernelGGL(lstm_bwd_stream_kernel<32>, grid, block, 0, st, *ap);
+    else hipLaunchKernelGGL(lstm_bwd_stream_kernel<16>, grid, block, 0, st, *ap);
+  }
   SB_CHECK_LAUNCH();
   const int total = 4 * H * (ap->C + H) + 4 * H;
   for (int d = 0; d < ap->ndir; ++d) {

@@ -130,6 +130,7 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip):
     ng = lib.sb_lstm_stream_grid(P)
     scratch = torch.empty(ndir * ng * (4 * H * (Cc + H) + 4 * H), device=dev, dtype=torch.float32)
     a.du_part, a.scratch = _p(du), _p(scratch)
+    a.split_bf16 = 1 if COMPACT_BPTT else 0       # exact mode (SB_EXACT_BPTT=1) keeps the fp32 matrix path
     L.check(lib.sb_lstm_bwd_stream(C.byref(a), _stream()), "sb_lstm_bwd_stream")
     return grads, du
 
