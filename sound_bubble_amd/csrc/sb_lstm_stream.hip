@@ -16,7 +16,9 @@ namespace {
 constexpr int H = SB_H;
 constexpr int STREAM_MAX_WG = 512;
 
-template <int C>
+// SMALLSEG: seg_len < 32 (tiny test shapes): segment index by modulo; otherwise by one/two conditional
+// subtractions, which keeps the loader branch-free (no inner loops -> one schedulable basic block).
+template <int C, bool SMALLSEG>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16;            // u blocks
   constexpr int KT = CK + 4;            // + 4 h_prev blocks
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_arg
   struct Tile { f32x4 a4[4], h4[4], d4[4]; float uv[CK][4]; };
   const int ntiles = (int)((P + 15) / 16);
   const int Pi = (int)P;
+  // branch-free loader: out-of-range / masked lanes read a valid (clamped) address and are zeroed by a select,
+  // so the loop body stays one basic block (exec-masked loads would put a branch around every load)
   auto load_tile = [&](int tile, Tile& t) {
     const int p0 = tile * 16;
     const int idx0 = p0 % a.seg_len;                     // wave-uniform
@@ -60,21 +64,29 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_arg
     for (int r = 0; r < 4; ++r) {
       const int p = p0 + 4 * q + r;
       const bool ok = p < Pi;
-      t.a4[r] = ok ? ld4(dg + (int64_t)p * ldg + 4 * j) : zero4();
+      const int pc = ok ? p : Pi - 1;
+      const f32x4 av = ld4(dg + (int64_t)pc * ldg + 4 * j);
+      t.a4[r] = ok ? av : zero4();
       int idx = idx0 + 4 * q + r;
-      while (idx >= a.seg_len) idx -= a.seg_len;
-      const bool ok2 = ok && idx >= skip_first && idx < a.seg_len - skip_last;
-      t.h4[r] = ok2 ? ld4(hs + (int64_t)p * ldh + hshift + 4 * j) : zero4();
+      if constexpr (SMALLSEG) idx %= a.seg_len; else idx -= idx >= a.seg_len ? a.seg_len : 0;
+      const bool ok2 = ok & (idx >= skip_first) & (idx < a.seg_len - skip_last);
+      const f32x4 hv = ld4(hs + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
+      t.h4[r] = ok2 ? hv : zero4();
       if constexpr (CK == 2) {
-        const float2 v = ok ? *reinterpret_cast<const float2*>(a.u + (int64_t)p * C + 2 * j) : make_float2(0.f, 0.f);
-        t.uv[0][r] = v.x; t.uv[1][r] = v.y;
+        const float2 v = *reinterpret_cast<const float2*>(a.u + (int64_t)pc * C + 2 * j);
+        t.uv[0][r] = ok ? v.x : 0.f; t.uv[1][r] = ok ? v.y : 0.f;
       } else {
-        t.uv[0][r] = ok ? a.u[(int64_t)p * C + j] : 0.f;
+        const float v = a.u[(int64_t)pc * C + j];
+        t.uv[0][r] = ok ? v : 0.f;
       }
     }
     const int pj = p0 + j;
+    const int pjc = pj < Pi ? pj : Pi - 1;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) t.d4[m] = pj < Pi ? ld4(dg + (int64_t)pj * ldg + 16 * m + 4 * q) : zero4();
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 dv = ld4(dg + (int64_t)pjc * ldg + 16 * m + 4 * q);
+      t.d4[m] = pj < Pi ? dv : zero4();
+    }
   };
 
   Tile cur;
@@ -163,7 +175,7 @@ SB_DEVINL f32x4 mfma_bf3(const SplitBf& a, const SplitBf& b, f32x4 c) {
   return c;
 }
 
-template <int C>
+template <int C, bool SMALLSEG>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_bf16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
@@ -199,33 +211,40 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_bf16_kernel(sb_lstm_strea
 
   struct Chunk { f32x4 a4[8], h4[8], d4[2][2][2]; float uv[CK][8]; };     // raw fp32 operands of 32 positions
   const int nchunks = (Pi + 31) / 32;
-  auto load_chunk = [&](int ch, Chunk& t) {
+  auto load_chunk = [&](int ch, Chunk& t) {          // branch-free (clamped address + select), see the fp32 kernel
     const int p0 = ch * 32;
     const int idx0 = p0 % a.seg_len;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int p = p0 + 8 * q + kk;
       const bool ok = p < Pi;
-      t.a4[kk] = ok ? ld4(dg + (int64_t)p * ldg + 4 * j) : zero4();
+      const int pc = ok ? p : Pi - 1;
+      const f32x4 av = ld4(dg + (int64_t)pc * ldg + 4 * j);
+      t.a4[kk] = ok ? av : zero4();
       int idx = idx0 + 8 * q + kk;
-      while (idx >= a.seg_len) idx -= a.seg_len;
-      const bool ok2 = ok && idx >= skip_first && idx < a.seg_len - skip_last;
-      t.h4[kk] = ok2 ? ld4(hs + (int64_t)p * ldh + hshift + 4 * j) : zero4();
+      if constexpr (SMALLSEG) idx %= a.seg_len; else idx -= idx >= a.seg_len ? a.seg_len : 0;
+      const bool ok2 = ok & (idx >= skip_first) & (idx < a.seg_len - skip_last);
+      const f32x4 hv = ld4(hs + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
+      t.h4[kk] = ok2 ? hv : zero4();
       if constexpr (CK == 2) {
-        const float2 v = ok ? *reinterpret_cast<const float2*>(a.u + (int64_t)p * C + 2 * j) : make_float2(0.f, 0.f);
-        t.uv[0][kk] = v.x; t.uv[1][kk] = v.y;
+        const float2 v = *reinterpret_cast<const float2*>(a.u + (int64_t)pc * C + 2 * j);
+        t.uv[0][kk] = ok ? v.x : 0.f; t.uv[1][kk] = ok ? v.y : 0.f;
       } else {
-        t.uv[0][kk] = ok ? a.u[(int64_t)p * C + j] : 0.f;
+        const float v = a.u[(int64_t)pc * C + j];
+        t.uv[0][kk] = ok ? v : 0.f;
       }
     }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {          // dU operand: position p0 + 16 sb + j, gates 32m + 8q .. +7
       const int pj = p0 + 16 * sb + j;
+      const int pjc = pj < Pi ? pj : Pi - 1;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-          t.d4[sb][m][hh] = pj < Pi ? ld4(dg + (int64_t)pj * ldg + 32 * m + 8 * q + 4 * hh) : zero4();
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x4 dv = ld4(dg + (int64_t)pjc * ldg + 32 * m + 8 * q + 4 * hh);
+          t.d4[sb][m][hh] = pj < Pi ? dv : zero4();
+        }
     }
   };
 
@@ -406,13 +425,12 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int gx = sb_lstm_stream_grid(ap->P);
   dim3 grid(gx, ap->ndir), block(256);
-  if (ap->split_bf16) {
-    if (ap->C == 32) hipLaunchKernelGGL(lstm_bwd_stream_bf16_kernel<32>, grid, block, 0, st, *ap);
-    else hipLaunchKernelGGL(lstm_bwd_stream_bf16_kernel<16>, grid, block, 0, st, *ap);
-  } else {
-    if (ap->C == 32) hipLaunchKernelGGL(lstm_bwd_stream_kernel<32>, grid, block, 0, st, *ap);
-    else hipLaunchKernelGGL(lstm_bwd_stream_kernel<16>, grid, block, 0, st, *ap);
-  }
+  const bool sm = ap->seg_len < 32;
+#define SB_S(K, CC) do { if (sm) hipLaunchKernelGGL((K<CC, true>), grid, block, 0, st, *ap); \
+                         else hipLaunchKernelGGL((K<CC, false>), grid, block, 0, st, *ap); } while (0)
+  if (ap->split_bf16) { if (ap->C == 32) SB_S(lstm_bwd_stream_bf16_kernel, 32); else SB_S(lstm_bwd_stream_bf16_kernel, 16); }
+  else { if (ap->C == 32) SB_S(lstm_bwd_stream_kernel, 32); else SB_S(lstm_bwd_stream_kernel, 16); }
+#undef SB_S
   SB_CHECK_LAUNCH();
   const int total = 4 * H * (ap->C + H) + 4 * H;
   for (int d = 0; d < ap->ndir; ++d) {
