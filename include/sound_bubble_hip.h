@@ -103,8 +103,8 @@ int sb_linear_grid(int64_t positions);
  * < skip_first or >= seg_len - skip_last are excluded (h_{t-1} of the first step of a sequence).
  * One pass over g serves both sources and the bias (dW_ih, dW_hh, db_ih, db_hh of an LSTM in one go).
  * If transpose_out, dW is stored [K, N].  Two-stage: per-workgroup partials in `scratch`
- * ([4*sb_wgrad_grid(P), N*(K+K2)+N] floats, ZERO-initialised: one row per wave), then a reduction that ADDS into
- * the outputs. */
+ * ([4*sb_wgrad_grid(P), N*(K+K2)+N] floats: one row per wave, fully written by the kernel), then a reduction
+ * that ADDS into the outputs. */
 typedef struct {
   int B, T, F, N, K, kseg;
   const float* g; int64_t ldg;

@@ -54,9 +54,12 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
   const int64_t ntiles = (P + 63) / 64;
   const int nchunk = K / 16;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t p = tile * 64 + 16 * w + j;
-    const bool valid = p < P;
-    const int64_t ioff = valid ? pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f) : 0;
+    const int64_t p_raw = tile * 64 + 16 * w + j;
+    const bool valid = p_raw < P;
+    // out-of-range lanes recompute the last position (columns of the MFMA are independent) and skip the store:
+    // no predicated loads, so the K loop stays one basic block
+    const int64_t p = valid ? p_raw : P - 1;
+    const int64_t ioff = pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f);
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = bias[nt];
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
       const int kk = 16 * m;
       const int seg = kk / a.kseg;
       const int kin = kk - seg * a.kseg;
-      return valid ? ld4(a.in + ioff + (int64_t)seg * a.is_seg + kin + 4 * q) : zero4();
+      return ld4(a.in + ioff + (int64_t)seg * a.is_seg + kin + 4 * q);
     };
     f32x4 bcur = load_b(0);
     for (int m = 0; m < nchunk; ++m) {
@@ -80,9 +83,9 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
     }
 
     // ---------------- epilogue: lane holds features 16nt+4q..+3 of position p ----------------
-    const int64_t ooff = valid ? pos_off(p, a.T, a.F, a.os_b, a.os_t, a.os_f) : 0;
+    const int64_t ooff = pos_off(p, a.T, a.F, a.os_b, a.os_t, a.os_f);
     if constexpr (EPI == SB_EPI_RES) {
-      if (valid) {
+      {
         const int64_t roff = pos_off(p, a.T, a.F, a.rs_b, a.rs_t, a.rs_f);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] += ld4(a.res + roff + 16 * nt + 4 * q);
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
       float s = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        raw[nt] = valid ? ld4(a.aux_in + p * N + 16 * nt + 4 * q) : zero4();
+        raw[nt] = ld4(a.aux_in + p * N + 16 * nt + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float x = (a.prelu_a && raw[nt][r] <= 0.f) ? alpha * raw[nt][r] : raw[nt][r];
@@ -242,21 +245,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
     float av[NTW][4], bv[KT][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t p = tile * 16 + 4 * q + r;
-      const bool ok = p < P;
-      const int64_t ioff = ok ? pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f) : 0;
+      const int64_t p_raw = tile * 16 + 4 * q + r;
+      const bool ok = p_raw < P;
+      const int64_t p = ok ? p_raw : P - 1;                  // clamped address + select: no predicated loads
+      const int64_t ioff = pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f);
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) av[nt][r] = (ok && nval[nt]) ? a.g[p * a.ldg + ncol[nt]] : 0.f;
+      for (int nt = 0; nt < NTW; ++nt) {
+        const float v = a.g[p * a.ldg + (nval[nt] ? ncol[nt] : 0)];
+        av[nt][r] = (ok & nval[nt]) ? v : 0.f;
+      }
 #pragma unroll
-      for (int kt = 0; kt < KT1; ++kt) bv[kt][r] = (ok && kval[kt]) ? a.in[ioff + koff[kt]] : 0.f;
+      for (int kt = 0; kt < KT1; ++kt) {
+        const float v = a.in[ioff + (kval[kt] ? koff[kt] : 0)];
+        bv[kt][r] = (ok & kval[kt]) ? v : 0.f;
+      }
       if constexpr (KT2 > 0) {
-        bool ok2 = ok;
-        if (ok) {
-          const int idx = (int)(p % a.seg_len);
-          ok2 = idx >= a.skip_first && idx < a.seg_len - a.skip_last;
-        }
+        const int idx = (int)(p % a.seg_len);
+        const bool ok2 = ok & (idx >= a.skip_first) & (idx < a.seg_len - a.skip_last);
 #pragma unroll
-        for (int kt = 0; kt < KT2; ++kt) bv[KT1 + kt][r] = ok2 ? a.in2[p * a.ld2 + a.shift2 + 16 * kt + j] : 0.f;
+        for (int kt = 0; kt < KT2; ++kt) {
+          const float v = a.in2[p * a.ld2 + (ok2 ? a.shift2 : 0) + 16 * kt + j];
+          bv[KT1 + kt][r] = ok2 ? v : 0.f;
+        }
       }
     }
 #pragma unroll

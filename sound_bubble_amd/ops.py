@@ -220,7 +220,7 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     B_, T_, F_ = grid
     P = B_ * T_ * F_
     ng = lib.sb_wgrad_grid(P)
-    scratch = torch.zeros(ng * 4, N * (K + K2) + N, device=dW.device, dtype=torch.float32)   # one row per wave
+    scratch = torch.empty(ng * 4, N * (K + K2) + N, device=dW.device, dtype=torch.float32)   # one row per wave (every wave writes its row)
     a = L.WgradArgs()
     a.B, a.T, a.F, a.N, a.K = B_, T_, F_, N, K
     a.kseg = ((K + 15) // 16) * 16 if kseg is None else kseg
