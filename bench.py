@@ -243,6 +243,13 @@ def main():
         ach = tot_fl / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
         fpu, bpu = fwd_flops_per_utt(params), fwd_bytes_per_utt(params)
         work_mult = 1.0 if args.forward_only else 3.0
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", f"r01_final_pmc_traffic_{args.workload}.json")
+        if os.path.exists(pmc) and not args.forward_only and B == WORKLOADS[args.workload][2]:
+            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if "lstm_fwd_kernel" in k]
+            if ks:                                            # HBM bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)
+                traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
+                traffic_src = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc pass of this command, committed)"
         out = {
             "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if args.forward_only else "train-step"),
             "value": utt_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,7 +261,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel (intra+inter launches)",
                          "achieved": ach / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK, "traffic": None,
+                         "frac": ach / MFMA_F32_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "launches": len(ev), "avg_launch_ms": tot_ms / n_launch,
                          "algorithmic_flops_per_launch": tot_fl / n_launch,
                          "step_flop_fraction": work_mult * fpu * utt_s / world / MFMA_F32_PEAK,
