@@ -45,6 +45,8 @@ typedef struct {
   const float* w_ih[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2];
   const float* h0; const float* c0; float* hN; float* cN;
   float* hs; float* save_gates; float* save_u; float* save_c;
+  int mma;   /* 0: fp32-input MFMA (exact fma chain); 1: bf16 matrix pipe, exact 3-way operand split, 6 products
+                (fp32-class rounding, ~2.7x fewer matrix cycles, overlaps the VALU) */
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 
@@ -60,6 +62,7 @@ typedef struct {
   const float* w_hh[2];
   const float* save_gates; const float* dhs; float* dgates;
   const float* save_c;        /* non-NULL: compact fp16 record (see sb_lstm_fwd_args) */
+  int mma;                    /* as sb_lstm_fwd_args.mma */
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

@@ -19,13 +19,13 @@ class LstmFwdArgs(C.Structure):
                 ("x", c_fp), ("ln_g", c_fp), ("ln_b", c_fp),
                 ("w_ih", c_fp * 2), ("w_hh", c_fp * 2), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
                 ("h0", c_fp), ("c0", c_fp), ("hN", c_fp), ("cN", c_fp),
-                ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp), ("save_c", c_fp)]
+                ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp), ("save_c", c_fp), ("mma", C.c_int)]
 
 
 class LstmBwdArgs(C.Structure):
     _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int),
                 ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
-                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("save_c", c_fp)]
+                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("save_c", c_fp), ("mma", C.c_int)]
 
 
 class LinearArgs(C.Structure):

@@ -15,8 +15,13 @@
 //     row is normalised while it is staged, one step ahead of its use);
 //   * v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fma chain), so the 1e-3
 //     parity bar of the north star holds without any mixed-precision risk.
+#include <stdlib.h>
 #include "sb_common.h"
 #include "../../include/sound_bubble_hip.h"
+
+// bf16 split-product variants (sb_lstm_bf.hip)
+int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st);
+int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a, hipStream_t st);
 
 namespace {
 
@@ -343,7 +348,8 @@ extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
   if (a->C != 16 && a->C != 32) return -1002;
   if (a->save_gates && !a->save_u) return -1003;
   dim3 grid((a->nseq + 15) / 16, a->ndir);
-  if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);
+  if (a->mma == 1) sb_launch_lstm_fwd_bf(*a, (hipStream_t)stream);
+  else if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);
   else launch_fwd<16>(*a, grid, (hipStream_t)stream);
   SB_CHECK_LAUNCH();
   return 0;
@@ -354,6 +360,7 @@ extern "C" int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream) {
   dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
   hipStream_t st = (hipStream_t)stream;
   const bool full = a->nseq % 16 == 0, r16 = a->save_c != nullptr;
+  if (a->mma == 1) { sb_launch_lstm_bwd_bf(*a, st); SB_CHECK_LAUNCH(); return 0; }
 #define SB_B(FL, R16) hipLaunchKernelGGL((lstm_bwd_rec_kernel<FL, R16>), grid, block, 0, st, *a)
   if (full) { if (r16) SB_B(true, true); else SB_B(true, false); }
   else { if (r16) SB_B(false, true); else SB_B(false, false); }

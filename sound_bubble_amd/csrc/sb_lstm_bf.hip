@@ -1,0 +1,396 @@
+// Recurrent LSTM kernels on the bf16 matrix pipe with EXACT-CLASS split products ("bf16x6").
+//
+// Why: on gfx950 the fp32-input MFMA runs at the fp32 vector rate and does not overlap the cell-update VALU work
+// of a co-resident wave (measured: two workgroups per CU give no throughput over one), so the fp32 kernels in
+// sb_lstm.hip top out at ~45-65 % of the 157 TFLOP/s fp32 peak.  The bf16 matrix pipe is 16x faster and truly
+// concurrent with the VALU.  Every fp32 operand is split EXACTLY into three bf16 terms
+//        x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (8 + 8 + 8 mantissa bits)
+// and a*b is evaluated as  l*h + h*l + m*m + m*h + h*m + h*h  (the three dropped terms are <= 2^-24 relative),
+// each bf16 x bf16 product being exact in the fp32 accumulator.  The result is fp32-class (same order of rounding
+// error as an fp32 fma chain) -- required here because the recurrence amplifies rounding noise over 625 steps and
+// the parity bar is 1e-3 on the output -- at 6/16 of the fp32-MFMA cycles per flop, overlappable with the VALU.
+//
+// v_mfma_f32_16x16x32_bf16: A lane l holds A[i = l&15][k = 8*(l>>4)..+7], B lane l holds B[k = 8*(l>>4)..+7][j = l&15],
+// C/D as in sb_common.h.  K is walked in chunks of 32: chunk 0 = the (LayerNormed) input u (zero-padded to 32),
+// chunks 1,2 = the hidden state.  The step pipeline (A: hidden part, B: next input part || cell update || next
+// LayerNorm, C: stores + prefetch + barrier) is the one of sb_lstm.hip.
+#include "sb_common.h"
+#include "../../include/sound_bubble_hip.h"
+
+namespace {
+
+constexpr int H = SB_H;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 { bf16x8 h, m, l; };
+
+SB_DEVINL void split1(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  float r = x - (float)h;
+  m = (__bf16)r;
+  r -= (float)m;
+  l = (__bf16)r;
+}
+SB_DEVINL Split3 split8(const float (&x)[8]) {
+  Split3 s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { __bf16 h, m, l; split1(x[k], h, m, l); s.h[k] = h; s.m[k] = m; s.l[k] = l; }
+  return s;
+}
+SB_DEVINL f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+constexpr int UP = 32 + 8;    // padded bf16 row of the input-term tiles  (80 B)
+constexpr int HP16 = 64 + 8;  // padded bf16 row of the hidden-term tiles (144 B)
+
+template <int C>
+struct XVec { float v[C / 16]; };
+
+template <int C, int SAVE, bool FULL>
+__global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
+  constexpr int VPT = C / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int dir = blockIdx.y;
+  const int n0 = blockIdx.x * 16;
+  const int S = a.nsteps;
+  const bool rev = dir == 1;
+
+  __shared__ __attribute__((aligned(16))) __bf16 U16[2][3][16][UP];      // [buf][term][seq][channel]
+  __shared__ __attribute__((aligned(16))) __bf16 H16[2][3][16][HP16];    // [buf][term][seq][unit]
+  __shared__ __attribute__((aligned(16))) float Bias[4][H];
+
+  // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
+  const float* __restrict__ wih = a.w_ih[dir];
+  const float* __restrict__ whh = a.w_hh[dir];
+  Split3 Wt[4][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int row = g * H + 16 * w + j;
+    float t[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) t[kk] = (8 * q + kk < C) ? wih[(size_t)row * C + 8 * q + kk] : 0.f;
+    Wt[g][0] = split8(t);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = whh[(size_t)row * H + 32 * c + 8 * q + kk];
+      Wt[g][1 + c] = split8(t);
+    }
+  }
+  if (tid < 4 * H) Bias[tid >> 6][tid & 63] = a.b_ih[dir][tid] + a.b_hh[dir][tid];
+  // zero the padded channels of the input tiles once (C = 16: channels 16..31 stay zero)
+  for (int i = tid; i < 2 * 3 * 16 * UP; i += 256) (&U16[0][0][0][0])[i] = (__bf16)0.f;
+  __syncthreads();
+
+  // ---- loader role ----
+  const int ls = tid >> 4, cpart = tid & 15;
+  const int nl = n0 + ls;
+  const bool lvalid = FULL || nl < a.nseq;
+  const int64_t lbase = lvalid ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
+  float gam[VPT], bet[VPT];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; bet[v] = a.ln_b[cpart * VPT + v]; }
+
+  auto load_x = [&](int s) {
+    XVec<C> r;
+    const int st = rev ? S - 1 - s : s;
+    const float* p = a.x + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) r.v[v] = lvalid ? p[v] : 0.f;
+    return r;
+  };
+  auto ln_store = [&](const XVec<C>& xv, int buf, int s) {
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) sum += xv.v[v];
+    const float mean = row16_sum(sum) * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq += d * d; }
+    const float rstd = 1.0f / sqrtf(row16_sum(sq) * (1.0f / C) + 1e-5f);
+    float u[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      u[v] = (xv.v[v] - mean) * rstd * gam[v] + bet[v];
+      __bf16 h, m, l;
+      split1(u[v], h, m, l);
+      U16[buf][0][ls][cpart * VPT + v] = h;
+      U16[buf][1][ls][cpart * VPT + v] = m;
+      U16[buf][2][ls][cpart * VPT + v] = l;
+    }
+    if (SAVE && lvalid) {
+      const int st = rev ? S - 1 - s : s;
+      float* p = a.save_u + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) p[v] = u[v];
+    }
+  };
+
+  // ---- compute role ----
+  const int nc = n0 + j;
+  const bool cvalid = FULL || nc < a.nseq;
+  const int64_t cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+  const int uoff = 16 * w + 4 * q;
+  f32x4 c = zero4(), h = zero4();
+  if (dir == 0 && cvalid) {
+    if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
+    if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
+  }
+  auto store_h = [&](int buf, const f32x4& hv) {       // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
+    bf16x4 th, tm, tl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { __bf16 x0, x1, x2; split1(hv[r], x0, x1, x2); th[r] = x0; tm[r] = x1; tl[r] = x2; }
+    *reinterpret_cast<bf16x4*>(&H16[buf][0][j][uoff]) = th;
+    *reinterpret_cast<bf16x4*>(&H16[buf][1][j][uoff]) = tm;
+    *reinterpret_cast<bf16x4*>(&H16[buf][2][j][uoff]) = tl;
+  };
+  // acc[g] += W[g][chunk] * B (6-term split product); B terms read from LDS rows of this lane's sequence
+  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].l, bh, acc[g]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bl, acc[g]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].m, bm, acc[g]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].m, bh, acc[g]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bm, acc[g]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bh, acc[g]);
+  };
+  auto x_part = [&](f32x4 (&acc)[4], int buf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = ld4(&Bias[g][uoff]);
+    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&U16[buf][0][j][8 * q]);
+    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&U16[buf][1][j][8 * q]);
+    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&U16[buf][2][j][8 * q]);
+    mma6(acc, 0, bh, bm, bl);
+  };
+
+  store_h(0, h);
+  {
+    XVec<C> x0 = load_x(0);
+    XVec<C> x1 = load_x(min(1, S - 1));
+    ln_store(x0, 0, 0);
+    ln_store(x1, 1, min(1, S - 1));
+  }
+  XVec<C> xnext = load_x(min(2, S - 1));
+  __syncthreads();
+  f32x4 accx[4];
+  x_part(accx, 0);
+
+  const int ndir = a.ndir;
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    // ---- A: hidden part ----
+    f32x4 acc[4] = {accx[0], accx[1], accx[2], accx[3]};
+#pragma unroll
+    for (int ck = 0; ck < 2; ++ck) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&H16[cur][0][j][32 * ck + 8 * q]);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&H16[cur][1][j][32 * ck + 8 * q]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&H16[cur][2][j][32 * ck + 8 * q]);
+      mma6(acc, 1 + ck, bh, bm, bl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B: input part of step s+1 (matrix pipe) || cell update of step s + LayerNorm of row s+2 (VALU) ----
+    x_part(accx, cur ^ 1);
+    f32x4 gi, gf, gg, go, cprev = c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gi[r] = sigmoidf_fast(acc[0][r]);
+      gf[r] = sigmoidf_fast(acc[1][r]);
+      gg[r] = tanhf_fast(acc[2][r]);
+      go[r] = sigmoidf_fast(acc[3][r]);
+      c[r] = gf[r] * c[r] + gi[r] * gg[r];
+      h[r] = go[r] * tanhf_fast(c[r]);
+    }
+    ln_store(xnext, cur, min(s + 2, S - 1));
+    store_h(cur ^ 1, h);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C ----
+    if (cvalid) {
+      const int st = rev ? S - 1 - s : s;
+      const int64_t pos = cbase + (int64_t)st * a.p_step;
+      st4(a.hs + (pos * ndir + dir) * H + uoff, h);
+      if (SAVE == 1) {
+        float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
+        st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
+      } else if (SAVE == 2) {
+        h16x8 lo, hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[r] = (_Float16)gi[r]; lo[4 + r] = (_Float16)gf[r];
+          hi[r] = (_Float16)gg[r]; hi[4 + r] = (_Float16)go[r];
+        }
+        _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
+        *reinterpret_cast<h16x8*>(rec) = lo;
+        *reinterpret_cast<h16x8*>(rec + 8) = hi;
+        st4(a.save_c + (pos * ndir + dir) * H + uoff, cprev);
+      }
+    }
+    xnext = load_x(min(s + 3, S - 1));
+    __syncthreads();
+  }
+  if (dir == 0 && cvalid) {
+    if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h);
+    if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BPTT recurrence on the bf16 pipe.  Wave w owns gate rows {g*64 + 16w + 4q + r}; its 16 dgates per lane are the
+// B operand straight from registers: K-chunk c covers gate types (2c, 2c+1), k = 8q + kk <-> gate 2c + (kk >> 2),
+// unit 16w + 4q + (kk & 3).
+template <bool FULL, bool REC16>
+__global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int dir = blockIdx.y;
+  const int n0 = blockIdx.x * 16;
+  const int S = a.nsteps, ndir = a.ndir;
+  const bool rev = dir == 1;
+  __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
+
+  const float* __restrict__ whh = a.w_hh[dir];
+  Split3 At[4][2];   // [out tile ot][chunk]: A[i = out unit 16ot + j][k] = W_hh[gate row(k)][16ot + j]
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+        t[kk] = whh[(size_t)((2 * c + (kk >> 2)) * H + 16 * w + 4 * q + (kk & 3)) * H + 16 * ot + j];
+      At[ot][c] = split8(t);
+    }
+
+  const int nc = n0 + j;
+  const bool valid = FULL || nc < a.nseq;
+  const int64_t base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+  const int uoff = 16 * w + 4 * q;
+
+  struct Raw { f32x4 r0, r1, r2, r3, cp, dh; };
+  auto load_raw = [&](int s) {
+    Raw r;
+    const int st = rev ? S - 1 - s : s;
+    const int64_t pos = base + (int64_t)st * a.p_step;
+    if (valid) {
+      if constexpr (REC16) {
+        const float* rec = a.save_gates + ((pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16) / 2;
+        r.r0 = ld4(rec); r.r1 = ld4(rec + 4);
+        r.r2 = r.r3 = zero4();
+        r.cp = ld4(a.save_c + (pos * ndir + dir) * H + uoff);
+      } else {
+        const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
+        r.r0 = ld4(rec); r.r1 = ld4(rec + H); r.r2 = ld4(rec + 2 * H); r.r3 = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
+      }
+      r.dh = ld4(a.dhs + (pos * ndir + dir) * H + uoff);
+    } else {
+      r.r0 = r.r1 = r.r2 = r.r3 = r.cp = r.dh = zero4();
+    }
+    return r;
+  };
+
+  f32x4 dc = zero4(), dhrec = zero4();
+  Raw nxt = load_raw(S - 1);
+  for (int s = S - 1; s >= 0; --s) {
+    const int cur = s & 1;
+    Raw raw = nxt;
+    // consume the prefetched record (forces its wait HERE), then immediately issue the prefetch of the
+    // previous step so that it has a whole step of latency cover
+    asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.cp), "+v"(raw.dh));
+    if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
+    __builtin_amdgcn_sched_barrier(0);
+    nxt = load_raw(max(s - 1, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 gi, gf, gg, go;
+    if constexpr (REC16) {
+      const h16x8 lo = __builtin_bit_cast(h16x8, raw.r0), hi = __builtin_bit_cast(h16x8, raw.r1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { gi[k] = (float)lo[k]; gf[k] = (float)lo[4 + k]; gg[k] = (float)hi[k]; go[k] = (float)hi[4 + k]; }
+    } else {
+      gi = raw.r0; gf = raw.r1; gg = raw.r2; go = raw.r3;
+    }
+    f32x4 dG[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dh = raw.dh[r] + dhrec[r];
+      const float cc = gf[r] * raw.cp[r] + gi[r] * gg[r];
+      const float tc = tanhf_fast(cc);
+      const float dO = dh * tc;
+      const float dct = dc[r] + dh * go[r] * (1.0f - tc * tc);
+      dG[0][r] = dct * gg[r] * gi[r] * (1.0f - gi[r]);
+      dG[1][r] = dct * raw.cp[r] * gf[r] * (1.0f - gf[r]);
+      dG[2][r] = dct * gi[r] * (1.0f - gg[r] * gg[r]);
+      dG[3][r] = dO * go[r] * (1.0f - go[r]);
+      dc[r] = dct * gf[r];
+    }
+    // split the 16 dgates of this lane into the two K-chunks of the B operand
+    Split3 Bop[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = dG[2 * c + (kk >> 2)][kk & 3];
+      Bop[c] = split8(t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (valid) {
+      const int st = rev ? S - 1 - s : s;
+      const int64_t pos = base + (int64_t)st * a.p_step;
+      float* dg = a.dgates + (pos * ndir + dir) * (4 * H) + uoff;
+      st4(dg, dG[0]); st4(dg + H, dG[1]); st4(dg + 2 * H, dG[2]); st4(dg + 3 * H, dG[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 part[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].l, Bop[c].h, part[ot]);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].h, Bop[c].l, part[ot]);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].m, Bop[c].m, part[ot]);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].m, Bop[c].h, part[ot]);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].h, Bop[c].m, part[ot]);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].h, Bop[c].h, part[ot]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) st4(&P[cur][w][ot][lane][0], part[ot]);
+    __syncthreads();
+    dhrec = ld4(&P[cur][0][w][lane][0]) + ld4(&P[cur][1][w][lane][0]) + ld4(&P[cur][2][w][lane][0]) +
+            ld4(&P[cur][3][w][lane][0]);
+  }
+}
+
+}  // namespace
+
+// launch helpers used by sb_lstm.hip's C entry points (same argument structs)
+int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
+  dim3 grid((a.nseq + 15) / 16, a.ndir);
+  const bool full = a.nseq % 16 == 0;
+  const int save = a.save_gates == nullptr ? 0 : (a.save_c ? 2 : 1);
+#define SB_L(CC, SV, FL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL>), grid, dim3(256), 0, st, a)
+#define SB_LC(CC) do { \
+    if (save == 0) { if (full) SB_L(CC, 0, true); else SB_L(CC, 0, false); } \
+    else if (save == 1) { if (full) SB_L(CC, 1, true); else SB_L(CC, 1, false); } \
+    else { if (full) SB_L(CC, 2, true); else SB_L(CC, 2, false); } } while (0)
+  if (a.C == 32) SB_LC(32); else SB_LC(16);
+#undef SB_LC
+#undef SB_L
+  return 0;
+}
+
+int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a, hipStream_t st) {
+  dim3 grid((a.nseq + 15) / 16, a.ndir), block(256);
+  const bool full = a.nseq % 16 == 0, r16 = a.save_c != nullptr;
+#define SB_B(FL, R16) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16>), grid, block, 0, st, a)
+  if (full) { if (r16) SB_B(true, true); else SB_B(true, false); }
+  else { if (r16) SB_B(false, true); else SB_B(false, false); }
+#undef SB_B
+  return 0;
+}

@@ -14,6 +14,8 @@ from . import _lib as L
 H = 64
 # BPTT record format: compact (fp16 gates + fp32 c_prev, 768 B/step) unless SB_EXACT_BPTT=1 (fp32, 1280 B/step)
 COMPACT_BPTT = os.environ.get("SB_EXACT_BPTT", "0") != "1"
+# recurrent GEMMs: bf16 matrix pipe with exact 3-way split / 6 products (fp32-class) unless SB_LSTM_FP32=1
+LSTM_MMA = 0 if os.environ.get("SB_LSTM_FP32", "0") == "1" else 1
 PROFILE_LSTM = None     # bench.py: list collecting (start_event, end_event, algorithmic_flops) per launch
 
 
@@ -81,6 +83,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
     a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
     a.hs, a.save_u, a.save_c = _p(hs), _p(u), _p(cprev)
+    a.mma = LSTM_MMA
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
     prof = PROFILE_LSTM
     if prof is not None:
@@ -105,6 +108,7 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom):
     rec, cprev = gates
     a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), _p(cprev)
     a.dhs, a.dgates = _p(dhs), _p(dg)
+    a.mma = LSTM_MMA
     L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
     return dg
 
