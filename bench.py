@@ -35,7 +35,8 @@ WORKLOADS = {
             100.0, None, 1.2e-3),   # "grad_clip" sits at the JSON top level there -> PLModule does not clip (F10a)
 }
 N_SAMPLES = 120000
-MFMA_F32_PEAK = 157.3e12        # dense fp32 MFMA peak, MI355X_MICROARCH.md
+MFMA_F32_PEAK = 157.3e12        # dense fp32-input MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
+MFMA_BF16_PEAK = 2500e12        # dense bf16 MFMA peak, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
 
@@ -250,6 +251,11 @@ def main():
             if ks:                                            # HBM bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)
                 traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 traffic_src = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc pass of this command, committed)"
+        # The recurrent kernels run on the bf16 matrix pipe with exact 3-way operand splits: 6 bf16 MFMA flops are
+        # ISSUED per algorithmic fp32 flop (ops.LSTM_MMA == 1); with SB_LSTM_FP32=1 they use the fp32-input MFMA.
+        bf = ops.LSTM_MMA == 1
+        issued = ach * (6.0 if bf else 1.0)
+        peak = MFMA_BF16_PEAK if bf else MFMA_F32_PEAK
         out = {
             "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if args.forward_only else "train-step"),
             "value": utt_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -259,9 +265,11 @@ def main():
                                    f"conv_lstm={params['conv_lstm']}, 6ch x 120000 samples, "
                                    f"{'forward only' if args.forward_only else 'fwd+SNRLP+bwd+clip+Adam'}",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel (intra+inter launches)",
-                         "achieved": ach / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("lstm_fwd_bf_kernel (bf16 MFMA, exact 3-way split, 6 products per fp32 MAC)" if bf
+                                    else "lstm_fwd_kernel (fp32-input MFMA)") + ", intra+inter launches",
+                         "achieved": issued / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": issued / peak,
+                         "algorithmic_tflops": ach / 1e12, "algorithmic_frac_of_fp32_peak": ach / MFMA_F32_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "launches": len(ev), "avg_launch_ms": tot_ms / n_launch,
                          "algorithmic_flops_per_launch": tot_fl / n_launch,
