@@ -92,13 +92,28 @@ class _DisEmbed(nn.Module):      # dis_embd3/tfgridnet_causal.py:150-173
         return self.dis_norm(e).transpose(1, 2)          # [B, n_in, F]
 
 
-class OracleBlock(nn.Module):
-    """One GridNet block on channels-last x[B,T,F,C]; attention is not restated
-    (use_attn is false in every shipped config)."""
+class _Seq(nn.Sequential):
+    pass
 
-    def __init__(self, C, F_, H, conv_lstm, lstm_down, flavour, eps=1e-5):
+
+class _LNCF(nn.Module):          # reference LayerNormalization4DCF: holds `.norm` over Q*C
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.norm = nn.LayerNorm(n, eps=eps)
+
+    def forward(self, x):
+        return self.norm(x)
+
+
+class OracleBlock(nn.Module):
+    """One GridNet block on channels-last x[B,T,F,C], including the (optional) local full-band
+    self-attention of dis_embd3/tfgridnet_causal.py:639-684,856-898."""
+
+    def __init__(self, C, F_, H, conv_lstm, lstm_down, flavour, eps=1e-5, use_attn=False, n_head=4, E=2,
+                 local_atten_len=100):
         super().__init__()
         self.C, self.F, self.H = C, F_, H
+        self.use_attn, self.n_head, self.E, self.L = use_attn, n_head, E, local_atten_len
         self.conv_lstm, self.down, self.flavour = conv_lstm, lstm_down, flavour
         if conv_lstm:
             self.conv = nn.Conv1d(C, C, lstm_down, stride=lstm_down)
@@ -114,10 +129,47 @@ class OracleBlock(nn.Module):
         self.inter_norm = _Norm(C, eps)
         self.inter_rnn = nn.LSTM(C, H, 1, batch_first=True)
         self.inter_linear = nn.Linear(H, C)
+        if use_attn:
+            Cv = C // n_head
+            self.Cv = Cv
+            # module indices mirror the reference Sequentials: 0 Linear, 1 PReLU, 2 Lambda (no params), 3 LayerNorm
+            self.attn_conv_Q = _Seq(nn.Linear(C, E * n_head), nn.PReLU(), nn.Identity(), _LNCF(F_ * E, eps))
+            self.attn_conv_K = _Seq(nn.Linear(C, E * n_head), nn.PReLU(), nn.Identity(), _LNCF(F_ * E, eps))
+            self.attn_conv_V = _Seq(nn.Linear(C, Cv * n_head), nn.PReLU(), nn.Identity(), _LNCF(F_ * Cv, eps))
+            self.attn_concat_proj = _Seq(nn.Linear(C, C), nn.PReLU(), nn.Identity(), _LNCF(F_ * C, eps))
 
     def init_buffers(self, B, device):
         z = lambda: torch.zeros(1, B * self.F, self.H, device=device)
-        return {"c0": z(), "h0": z()}
+        st = {}
+        if self.use_attn:
+            st["K_buf"] = torch.zeros(B * self.n_head, self.L - 1, self.E * self.F, device=device)
+            st["V_buf"] = torch.zeros(B * self.n_head, self.L - 1, self.Cv * self.F, device=device)
+        st["c0"], st["h0"] = z(), z()
+        return st
+
+    def _heads(self, seq, x, D):
+        """Linear -> PReLU -> [B,T,F,H,D] -> [B*H, T, F*D] -> LayerNorm(F*D)"""
+        B, T, Fq, _ = x.shape
+        y = seq[1](seq[0](x)).reshape(B, T, Fq, self.n_head, D).permute(0, 3, 1, 2, 4)
+        return seq[3](y.reshape(B * self.n_head, T, Fq * D))
+
+    def attention(self, x, st):
+        B, T, Fq, C = x.shape
+        L = self.L
+        Q = self._heads(self.attn_conv_Q, x, self.E)
+        K = torch.cat([st["K_buf"], self._heads(self.attn_conv_K, x, self.E)], 1)      # [BH, L-1+T, F*E]
+        V = torch.cat([st["V_buf"], self._heads(self.attn_conv_V, x, self.Cv)], 1)
+        st["K_buf"], st["V_buf"] = K[:, -(L - 1):], V[:, -(L - 1):]
+        # frame t attends to rows t .. t+L-1 of the concatenated sequence (zero-filled history rows are NOT masked)
+        Kw = K.unfold(1, L, 1)                                   # [BH, T, F*E, L]
+        Vw = V.unfold(1, L, 1)                                   # [BH, T, F*Cv, L]
+        att = torch.einsum("btd,btdl->btl", Q, Kw) / math.sqrt(Q.shape[-1])
+        att = torch.softmax(att, dim=-1)
+        o = torch.einsum("btl,btdl->btd", att, Vw)               # [BH, T, F*Cv]
+        o = o.view(B, self.n_head, T, Fq, self.Cv).permute(0, 2, 3, 1, 4).reshape(B, T, Fq, C)
+        p = self.attn_concat_proj
+        o = p[3](p[1](p[0](o)).reshape(B, T, Fq * C)).reshape(B, T, Fq, C)
+        return o
 
     def forward(self, x, st):
         B, T, Fq, C = x.shape
@@ -140,12 +192,16 @@ class OracleBlock(nn.Module):
         u, (h, c) = self.inter_rnn(u, (st["h0"], st["c0"]))
         st["h0"], st["c0"] = h, c
         u = self.inter_linear(u).view(B, Fq, T, C).transpose(1, 2)
-        return u + y, st
+        out = u + y
+        if self.use_attn:
+            out = out + self.attention(out, st)
+        return out, st
 
 
 class OracleTFGridNet(nn.Module):
     def __init__(self, n_fft, stride, n_imics, emb_dim, n_layers, H, conv_lstm, lstm_down,
-                 flavour, n_srcs=1, use_first_ln=True, dis_type="conv3", eps=1e-5):
+                 flavour, n_srcs=1, use_first_ln=True, dis_type="conv3", eps=1e-5, use_attn=False, n_head=4, E=2,
+                 local_atten_len=100):
         super().__init__()
         assert flavour in ("dis_embd3", "optim")
         self.flavour, self.n_layers, self.M = flavour, n_layers, n_imics
@@ -165,7 +221,8 @@ class OracleTFGridNet(nn.Module):
         if flavour == "dis_embd3":
             self.embeds = nn.ModuleList()
         for i in range(n_layers):
-            self.blocks.append(OracleBlock(emb_dim, self.F, H, conv_lstm, lstm_down, flavour, eps))
+            self.blocks.append(OracleBlock(emb_dim, self.F, H, conv_lstm, lstm_down, flavour, eps, use_attn, n_head, E,
+                                           local_atten_len))
             if flavour == "dis_embd3" and i > 0:
                 self.embeds.append(_Film(d_in, emb_dim))
         self.deconv = nn.ConvTranspose2d(emb_dim, 2 * n_srcs, (3, 3), padding=(2, 1))
@@ -246,7 +303,7 @@ class OracleNet(nn.Module):
                  merge_method="None", directional=False, conv_lstm=True, lstm_down=None,
                  fb_type="stft", dis_type="conv3"):
         super().__init__()
-        assert not use_attn and not spectral_masking and not directional and stft_back_pad == 0
+        assert not spectral_masking and not directional and stft_back_pad == 0
         assert merge_method == "early_cat" and fb_type == "stft"
         if lstm_down is None:       # dis_embd3 Net never forwards lstm_down: core default 4 (:282)
             lstm_down = 4 if flavour == "dis_embd3" else 5
@@ -254,7 +311,9 @@ class OracleNet(nn.Module):
         self.chunk, self.pad, self.lookahead = stft_chunk_size, stft_pad_size, lookahead
         self.tfgridnet = OracleTFGridNet(stft_chunk_size + stft_pad_size, stft_chunk_size, num_ch, D, B, H,
                                          conv_lstm, lstm_down, flavour, n_srcs=num_src,
-                                         use_first_ln=use_first_ln, dis_type=dis_type)
+                                         use_first_ln=use_first_ln, dis_type=dis_type, use_attn=use_attn, n_head=L,
+                                         E=E,   # block E = ceil(E*n_freqs / n_freqs) (tfgridnet_causal.py:591-593)
+                                         local_atten_len=local_atten_len)
 
     def init_buffers(self, batch_size, device):
         return self.tfgridnet.init_buffers(batch_size, device)

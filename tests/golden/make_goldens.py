@@ -328,6 +328,12 @@ def main():
     # dis_embd3 flavour of the conv-LSTM intra path (pads by 3 and crops)
     make_case(torch, NetBig, "tiny_big_convlstm", dict(big, B=2, D=16, conv_lstm=True), B=2, n_frames=7, seed=14,
               needs_dis=True, out_dir=args.out, with_stream=False)
+    # full-band local self-attention ON (off in every shipped JSON; tfgridnet_causal.py:639-684,856-898):
+    # window 100 (zero-filled, unmasked history dominates) and window 4 (windows inside the data)
+    make_case(torch, NetBig, "tiny_big_attn100", dict(big, B=2, use_attn=True), B=2, n_frames=7, seed=15,
+              needs_dis=True, out_dir=args.out, with_grads=False)
+    make_case(torch, NetSmall, "tiny_orange_attn4", dict(orange, B=2, use_attn=True, local_atten_len=4), B=2,
+              n_frames=7, seed=16, needs_dis=False, out_dir=args.out, with_grads=False)
     # real small config, 1 s clip (125 frames), forward only
     make_case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
               with_grads=False, with_stream=False, with_stages=False)

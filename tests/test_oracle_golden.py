@@ -6,6 +6,7 @@ import pytest
 from conftest import load_golden, golden_state_dict, rel_l2, flatten_state
 
 CASES = ["tiny_big", "tiny_small", "tiny_orange", "tiny_big_convlstm"]
+ATTN_CASES = ["tiny_big_attn100", "tiny_orange_attn4"]
 
 
 def build(rec, params, flavour, torch):
@@ -33,7 +34,7 @@ def test_stft_filters_match_fixture(torch_mod):
     assert np.abs(f[145]).max() < 1e-9 and np.abs(f[289]).max() < 1e-7
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ATTN_CASES)
 def test_forward_matches_reference(name, torch_mod):
     torch = torch_mod
     rec, params, flavour = load_golden(name)
@@ -58,7 +59,7 @@ def test_forward_matches_reference(name, torch_mod):
         assert rel_l2(v, rec["next_state::" + k]) < 2e-6, k
 
 
-@pytest.mark.parametrize("name", ["tiny_big", "tiny_small", "tiny_orange"])
+@pytest.mark.parametrize("name", ["tiny_big", "tiny_small", "tiny_orange"] + ATTN_CASES)
 def test_streaming_matches_reference(name, torch_mod):
     torch = torch_mod
     rec, params, flavour = load_golden(name)
