@@ -161,6 +161,23 @@ typedef struct {
 int sb_ln_bwd(const sb_ln_bwd_args* a, void* stream);
 int sb_ln_bwd_grid(int64_t positions);
 
+/* ---- full-band local self-attention (forward) -------------------------------
+ * tfgridnet_causal.py:639-684,856-898 (off in every shipped config; inference/streaming path only).
+ * sb_head_ln: per (b, t) LayerNorm over the (f, d) elements of each head of in [B, T, F, Hh*D] (eps 1e-5, gamma/beta
+ *   [F*D] shared by the heads), written head-major into out[(b*Hh + h) * rows + t_off + t][0..ldo) (columns beyond
+ *   F*D zeroed).  With Hh == 1 and res != NULL: out = res[b,t,:] + LN(in[b,t,:])  (the attn_concat_proj LayerNorm).
+ * sb_attn_core: Q [BH, T, ldk], K [BH, L-1+T, ldk], V [BH, L-1+T, ldv] (rows zero-padded to ldk / ldv, multiples of
+ *   16) -> out [B, T, F, Hh*Cv]: softmax_l(q_t . k_{t+l} * scale) over l in [0, L) of the concatenated rows, times V;
+ *   both contractions on the fp32-input MFMA.  NRp = 16*ceil((L+15)/16). */
+int sb_head_ln(const float* in, const float* gamma, const float* beta, float* out, const float* res, int B, int T, int F,
+               int Hh, int D, int rows, int t_off, int ldo, void* stream);
+typedef struct {
+  int BH, Hh, T, F, Cv, L, NRp, ldk, ldv;
+  float scale;
+  const float* Q; const float* K; const float* V; float* out;
+} sb_attn_args;
+int sb_attn_core(const sb_attn_args* a, void* stream);
+
 /* ---- front-end features --------------------------------------------------
  * spec [B*M, T, ld_spec] (cols 0..F-1 real, F..2F-1 imag: asteroid Encoder
  * layout) -> zp [B, T+2, F+2, 32] channels-last, written at time offset 2 and

@@ -14,6 +14,7 @@ from . import _lib as L
 from . import ops
 from .ops import Geom, H, dense
 
+GRAD_MODE = True     # set by the Net wrapper from torch.is_grad_enabled() (Function.forward runs with grad off)
 ZC = 32          # padded channel count of the front-end feature tensor
 NSPEC = 304      # 290 STFT bins (re/im) padded to a multiple of 16
 
@@ -27,7 +28,7 @@ class IntraPlainFn(torch.autograd.Function):
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
-        train = any(ctx.needs_input_grad)
+        train = GRAD_MODE and any(ctx.needs_input_grad)
         geom = Geom.intra(B * T, F)
         dirs = [(wif, whf, bif, bhf), (wir, whr, bir, bhr)]
         hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train)
@@ -74,7 +75,7 @@ class InterFn(torch.autograd.Function):
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
-        train = any(ctx.needs_input_grad)
+        train = GRAD_MODE and any(ctx.needs_input_grad)
         geom = Geom.inter(B, T, F)
         h0c = h0.reshape(B * F, H).contiguous() if h0 is not None else None
         c0c = c0.reshape(B * F, H).contiguous() if c0 is not None else None
@@ -127,7 +128,7 @@ class IntraConvFn(torch.autograd.Function):
         Kd = F // down
         Fm = Kd * down
         P2 = B * T * Kd
-        train = any(ctx.needs_input_grad)
+        train = GRAD_MODE and any(ctx.needs_input_grad)
         dev = x.device
         wc = conv_w.permute(0, 2, 1).reshape(Cc, down * Cc).contiguous()          # [co][j*C+ci]
         v_pre = torch.empty(P2, Cc, device=dev, dtype=torch.float32) if train else None
@@ -197,6 +198,64 @@ class IntraConvFn(torch.autograd.Function):
                 d_dec_b, None, None)
 
 
+class AttentionFn(torch.autograd.Function):
+    """y = x + LN_{F*C}(PReLU(Linear(local full-band self-attention(x))))  -- tfgridnet_causal.py:856-898
+    (modules :639-684, causal window :722-744).  Forward only: no shipped config enables attention, so its
+    backward is not built (training with use_attn=True raises).  Returns (y, new K_buf, new V_buf)."""
+
+    @staticmethod
+    def forward(ctx, x, K_buf, V_buf, wq, bq, aq, gq, eq, wk, bk, ak, gk, ek, wv, bv, av, gv, ev, wp, bp, ap_, gp, ep,
+                n_head, E, Lw):
+        if GRAD_MODE and any(ctx.needs_input_grad):
+            raise NotImplementedError("use_attn=True: the attention backward pass is not built (no shipped config "
+                                      "trains with attention); run under torch.no_grad() / eval")
+        B, T, F, Cc = x.shape
+        x = x.contiguous()
+        dev = x.device
+        P = B * T * F
+        Cv = Cc // n_head
+        HE = n_head * E
+        gP, sC = dense(P, Cc)
+
+        def proj(w, b, a, n_out):
+            npad = (n_out + 15) // 16 * 16
+            wpad = torch.zeros(npad, Cc, device=dev, dtype=torch.float32)
+            wpad[:n_out] = w
+            bpad = torch.zeros(npad, device=dev, dtype=torch.float32)
+            bpad[:n_out] = b
+            out = torch.empty(P, n_out, device=dev, dtype=torch.float32)
+            ops.linear(x, wpad, bpad, out, gP, sC, (0, 0, n_out), Cc, npad, n_valid=n_out, epi=L.EPI_PRELU, prelu_a=a)
+            return out
+
+        ldk = (F * E + 15) // 16 * 16
+        ldv = (F * Cv + 15) // 16 * 16
+        rows = Lw - 1 + T
+        BH = B * n_head
+        Qn = torch.empty(BH, T, ldk, device=dev, dtype=torch.float32)
+        Kc = torch.zeros(BH, rows, ldk, device=dev, dtype=torch.float32)
+        Vc = torch.zeros(BH, rows, ldv, device=dev, dtype=torch.float32)
+        Kc[:, : Lw - 1, : F * E] = K_buf
+        Vc[:, : Lw - 1, : F * Cv] = V_buf
+        ops.head_ln(proj(wq, bq, aq, HE), gq, eq, Qn, B, T, F, n_head, E, T, 0, ldk)
+        ops.head_ln(proj(wk, bk, ak, HE), gk, ek, Kc, B, T, F, n_head, E, rows, Lw - 1, ldk)
+        ops.head_ln(proj(wv, bv, av, Cc), gv, ev, Vc, B, T, F, n_head, Cv, rows, Lw - 1, ldv)
+        O = torch.empty(B, T, F, Cc, device=dev, dtype=torch.float32)
+        ops.attn_core(Qn, Kc, Vc, O, BH, n_head, T, F, Cv, Lw, ldk, ldv, 1.0 / float(F * E) ** 0.5)
+        # merge heads -> Linear + PReLU -> LayerNorm(F*C) -> + x
+        Yp = torch.empty(P, Cc, device=dev, dtype=torch.float32)
+        ops.linear(O, wp, bp, Yp, gP, sC, sC, Cc, Cc, epi=L.EPI_PRELU, prelu_a=ap_)
+        y = torch.empty_like(x)
+        ops.head_ln(Yp, gp, ep, y, B, T, F, 1, Cc, T, 0, F * Cc, res=x)
+        nK = Kc[:, rows - (Lw - 1):, : F * E].contiguous()
+        nV = Vc[:, rows - (Lw - 1):, : F * Cv].contiguous()
+        ctx.mark_non_differentiable(nK, nV)
+        return y, nK, nV
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("attention backward is not built")
+
+
 class FilmFn(torch.autograd.Function):
     """y = x * w[b,f,c] + bias[b,f,c]  -- FilmLayer.forward, dis_embd3/tfgridnet_causal.py:59-68."""
 
@@ -236,7 +295,7 @@ class FrontEndFn(torch.autograd.Function):
         T = (Np - win) // hop + 1
         dev = mix.device
         mix = mix.contiguous()
-        train = any(ctx.needs_input_grad)
+        train = GRAD_MODE and any(ctx.needs_input_grad)
         # 1. STFT as a position-wise GEMM over overlapping rows
         spec = torch.empty(B * M, T, NSPEC, device=dev, dtype=torch.float32)
         ops.linear(mix, _stft_weight(enc_filters), None, spec, (B * M, T, 1), (Np, hop, 0), (T * NSPEC, NSPEC, 0),
@@ -306,7 +365,7 @@ class BackEndFn(torch.autograd.Function):
         B, T, F, Cc = y.shape
         dev = y.device
         win = dec_filters.shape[-1]
-        train = any(ctx.needs_input_grad)
+        train = GRAD_MODE and any(ctx.needs_input_grad)
         assert dw.shape[1] == 2, "num_src=1 only (every shipped config)"
         yp = torch.zeros(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)
         yp[:, :2, 1:F + 1] = deconv_buf.permute(0, 2, 3, 1)

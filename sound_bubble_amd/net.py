@@ -61,7 +61,16 @@ class _ParamList(nn.ModuleList):
     pass
 
 
-def _block_params(C, H, conv_lstm, lstm_down, F_, flavour):
+def _attn_branch(C, n_out, n_ln):
+    """Sequential(Linear, PReLU, Lambda, LayerNormalization4DCF) of the reference: indices 0, 1, 3 hold parameters"""
+    seq = _Params()
+    seq.add_module("0", _Params(nn.Linear(C, n_out)))
+    seq.add_module("1", _Params(nn.PReLU()))
+    seq.add_module("3", _Params(norm=_Params(nn.LayerNorm(n_ln))))
+    return seq
+
+
+def _block_params(C, H, conv_lstm, lstm_down, F_, flavour, use_attn=False, n_head=4, E=2):
     b = _Params()
     if conv_lstm:
         b.add_module("conv", _Params(nn.Conv1d(C, C, lstm_down, stride=lstm_down)))
@@ -76,12 +85,18 @@ def _block_params(C, H, conv_lstm, lstm_down, F_, flavour):
     b.add_module("inter_norm", _Params(norm=_Params(nn.LayerNorm(C))))
     b.add_module("inter_rnn", _Params(nn.LSTM(C, H, 1, batch_first=True)))
     b.add_module("inter_linear", _Params(nn.Linear(H, C)))
+    if use_attn:                         # tfgridnet_causal.py:639-684 (same creation order -> same initial weights)
+        Cv = C // n_head
+        b.add_module("attn_conv_Q", _attn_branch(C, E * n_head, F_ * E))
+        b.add_module("attn_conv_K", _attn_branch(C, E * n_head, F_ * E))
+        b.add_module("attn_conv_V", _attn_branch(C, Cv * n_head, F_ * Cv))
+        b.add_module("attn_concat_proj", _attn_branch(C, C, F_ * C))
     return b
 
 
 class _TFGridNetParams(nn.Module):
     def __init__(self, n_fft, stride, n_imics, C, n_layers, H, conv_lstm, lstm_down, flavour, n_srcs,
-                 use_first_ln, dis_type):
+                 use_first_ln, dis_type, use_attn=False, n_head=4, E=2):
         super().__init__()
         F_ = n_fft // 2 + 1
         n_feat = 2 * n_imics + 3 * (n_imics - 1)
@@ -100,7 +115,7 @@ class _TFGridNetParams(nn.Module):
         if flavour == "dis_embd3":
             self.embeds = _ParamList()
         for i in range(n_layers):
-            self.blocks.append(_block_params(C, H, conv_lstm, lstm_down, F_, flavour))
+            self.blocks.append(_block_params(C, H, conv_lstm, lstm_down, F_, flavour, use_attn, n_head, E))
             if flavour == "dis_embd3" and i > 0:
                 self.embeds.append(_Params(weight=_Params(nn.Conv1d(d_in, C, 1)), bias=_Params(nn.Conv1d(d_in, C, 1))))
         self.deconv = _Params(nn.ConvTranspose2d(C, 2 * n_srcs, (3, 3), padding=(2, 1)))
@@ -118,9 +133,9 @@ class _NetBase(nn.Module):
     def _build(self, stft_chunk_size, stft_pad_size, stft_back_pad, num_ch, D, B, I, J, L, H, use_attn, lookahead,
                local_atten_len, E, chunk_causal, num_src, spectral_masking, use_first_ln, merge_method, directional,
                conv_lstm, lstm_down, fb_type, dis_type):
-        if use_attn:
-            raise NotImplementedError("use_attn=True: full-band attention is off in every shipped config "
-                                      "(SURVEY.md F4) and not built yet")
+        n_freqs = (stft_back_pad + stft_chunk_size + stft_pad_size) // 2 + 1
+        if use_attn and (L <= 0 or D % L or L > 8 or n_freqs * D > 5120):
+            raise NotImplementedError("use_attn=True needs 1 <= L <= 8 heads dividing D and F*D <= 5120")
         if H != 64:
             raise NotImplementedError("the recurrent HIP kernels are built for H=64 (every shipped config)")
         if D not in (16, 32):
@@ -137,8 +152,9 @@ class _NetBase(nn.Module):
         self.n_layers, self.H, self.num_src = B, H, num_src
         self.conv_lstm, self.lstm_down, self.use_first_ln = conv_lstm, lstm_down, use_first_ln
         self.n_feat = 2 * num_ch + 3 * (num_ch - 1)
+        self.use_attn, self.n_head, self.local_atten_len = use_attn, L, local_atten_len
         self.tfgridnet = _TFGridNetParams(self.nfft, stft_chunk_size, num_ch, D, B, H, conv_lstm, lstm_down,
-                                          self.flavour, num_src, use_first_ln, dis_type)
+                                          self.flavour, num_src, use_first_ln, dis_type, use_attn, L, E)
         if self.nfft % 16 or (self.nfft // 2 + 1) * 2 > Fn.NSPEC:
             raise NotImplementedError("n_fft must be a multiple of 16 and <= 302")
 
@@ -146,8 +162,14 @@ class _NetBase(nn.Module):
     def init_buffers(self, batch_size, device):
         F_, C = self.n_freqs, self.embed_dim
         z = lambda *s: torch.zeros(*s, device=device)
-        bufs = {f"buf{i}": {"c0": z(1, batch_size * F_, self.H), "h0": z(1, batch_size * F_, self.H)}
-                for i in range(self.n_layers)}
+        bufs = {}
+        for i in range(self.n_layers):
+            d = {}
+            if self.use_attn:       # tfgridnet_causal.py:699-708
+                d["K_buf"] = z(batch_size * self.n_head, self.local_atten_len - 1, self.E * F_)
+                d["V_buf"] = z(batch_size * self.n_head, self.local_atten_len - 1, (C // self.n_head) * F_)
+            d["c0"], d["h0"] = z(1, batch_size * F_, self.H), z(1, batch_size * F_, self.H)
+            bufs[f"buf{i}"] = d
         return dict(conv_buf=z(batch_size, self.n_feat, 2, F_), deconv_buf=z(batch_size, C, 2, F_),
                     istft_buf=z(batch_size, self.num_src, 2 * F_, 1), gridnet_bufs=bufs)
 
@@ -170,6 +192,7 @@ class _NetBase(nn.Module):
             x = tF.pad(x, (0, mod + (self.stft_pad_size if self.lookahead else 0)))
         tg = self.tfgridnet
         st = input_state
+        Fn.GRAD_MODE = torch.is_grad_enabled()      # BPTT records are written only when a backward pass can follow
         e = self._embed(inputs.get("dis_embed"))
         ln = tg.conv[1] if self.use_first_ln else None
         y, st["conv_buf"] = Fn.FrontEndFn.apply(
@@ -193,6 +216,14 @@ class _NetBase(nn.Module):
             y, b["h0"], b["c0"] = Fn.InterFn.apply(y, blk.inter_norm.norm.weight, blk.inter_norm.norm.bias,
                                                    *_lstm_dir(blk.inter_rnn, False), blk.inter_linear.weight,
                                                    blk.inter_linear.bias, b["h0"], b["c0"])
+            if self.use_attn:
+                args = []
+                for name in ("attn_conv_Q", "attn_conv_K", "attn_conv_V", "attn_concat_proj"):
+                    br = getattr(blk, name)
+                    lin, act, ln = getattr(br, "0"), getattr(br, "1"), getattr(br, "3").norm
+                    args += [lin.weight, lin.bias, act.weight, ln.weight, ln.bias]
+                y, b["K_buf"], b["V_buf"] = Fn.AttentionFn.apply(y, b["K_buf"], b["V_buf"], *args, self.n_head, self.E,
+                                                                 self.local_atten_len)
         out, st["deconv_buf"], st["istft_buf"] = Fn.BackEndFn.apply(
             y, tg.dec.filterbank._filters, tg.deconv.weight, tg.deconv.bias, st["deconv_buf"], st["istft_buf"],
             self.stft_chunk_size)

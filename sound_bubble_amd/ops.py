@@ -305,6 +305,20 @@ def snrlp_loss(est, gt, neg_weight, want_grad):
     return lv, dest
 
 
+def head_ln(x, gamma, beta, out, B, T, F, Hh, D, rows, t_off, ldo, res=None):
+    L.check(L.load().sb_head_ln(_p(x), _p(gamma), _p(beta), _p(out), _p(res), B, T, F, Hh, D, rows, t_off, ldo,
+                                _stream()), "sb_head_ln")
+
+
+def attn_core(Q, K, V, out, BH, Hh, T, F, Cv, Lw, ldk, ldv, scale):
+    a = L.AttnArgs()
+    a.BH, a.Hh, a.T, a.F, a.Cv, a.L = BH, Hh, T, F, Cv, Lw
+    a.NRp = (Lw + 15 + 15) // 16 * 16
+    a.ldk, a.ldv, a.scale = ldk, ldv, scale
+    a.Q, a.K, a.V, a.out = _p(Q), _p(K), _p(V), _p(out)
+    L.check(L.load().sb_attn_core(C.byref(a), _stream()), "sb_attn_core")
+
+
 def signal_stats(est, gt, mix_ref):
     """est, gt [B, N]; mix_ref [B, N] view (row stride given by mix_ref.stride(0)) -> moments [B, 8]"""
     B_, N = est.shape

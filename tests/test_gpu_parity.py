@@ -108,6 +108,7 @@ def test_linear_and_wgrad(torch_gpu):
 
 CASES = [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"), ("tiny_orange", "NetOptim"),
          ("tiny_big_convlstm", "NetDisEmbd3")]
+ATTN_CASES = [("tiny_big_attn100", "NetDisEmbd3"), ("tiny_orange_attn4", "NetOptim")]
 
 
 def _build(torch, name, cls):
@@ -125,7 +126,7 @@ def _inputs(torch, rec):
     return d
 
 
-@pytest.mark.parametrize("name,cls", CASES)
+@pytest.mark.parametrize("name,cls", CASES + ATTN_CASES)
 def test_forward_matches_reference_goldens(torch_gpu, name, cls):
     torch = torch_gpu
     rec, params, m = _build(torch, name, cls)
@@ -148,7 +149,7 @@ def test_forward_small_config_1s(torch_gpu):
     assert rel_l2(out, rec["output"]) < 5e-5
 
 
-@pytest.mark.parametrize("name,cls", CASES[:3])
+@pytest.mark.parametrize("name,cls", CASES[:3] + ATTN_CASES)
 def test_streaming_matches_reference(torch_gpu, name, cls):
     torch = torch_gpu
     rec, params, m = _build(torch, name, cls)
@@ -226,3 +227,11 @@ def test_streaming_separator_equals_offline(torch_gpu, use_graph):
     sep.reset()
     Z2 = streaming_inference(sep, X)
     assert torch.equal(Z, Z2)
+
+
+def test_attention_training_raises_clearly(torch_gpu):
+    torch = torch_gpu
+    rec, params, m = _build(torch, "tiny_orange_attn4", "NetOptim")
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(_inputs(torch, rec))
