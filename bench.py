@@ -247,7 +247,7 @@ def main():
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", f"r01_final_pmc_traffic_{args.workload}.json")
         if os.path.exists(pmc) and not args.forward_only and B == WORKLOADS[args.workload][2]:
-            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if "lstm_fwd_kernel" in k]
+            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if "lstm_fwd" in k]
             if ks:                                            # HBM bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)
                 traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 traffic_src = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc pass of this command, committed)"
