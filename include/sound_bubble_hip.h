@@ -63,6 +63,10 @@ typedef struct {
   const float* save_gates; const float* dhs; float* dgates;
   const float* save_c;        /* non-NULL: compact fp16 record (see sb_lstm_fwd_args) */
   int mma;                    /* as sb_lstm_fwd_args.mma */
+  /* optional fusion of the following Linear's backward (mma == 1 only): when dy != NULL, dhs is ignored and
+     d(hs)[p, dir*64 + u] = sum_c w_lin[c, dir*64 + u] * dy[p, c] is formed on the fly.  dy [P, C_lin] dense,
+     w_lin [C_lin, ndir*64] (nn.Linear weight), C_lin = 16 or 32. */
+  const float* dy; const float* w_lin; int C_lin;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

@@ -25,7 +25,8 @@ class LstmFwdArgs(C.Structure):
 class LstmBwdArgs(C.Structure):
     _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int),
                 ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
-                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("save_c", c_fp), ("mma", C.c_int)]
+                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("save_c", c_fp), ("mma", C.c_int),
+                ("dy", c_fp), ("w_lin", c_fp), ("C_lin", C.c_int)]
 
 
 class LinearArgs(C.Structure):

@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 // BPTT recurrence on the bf16 pipe.  Wave w owns gate rows {g*64 + 16w + 4q + r}; its 16 dgates per lane are the
 // B operand straight from registers: K-chunk c covers gate types (2c, 2c+1), k = 8q + kk <-> gate 2c + (kk >> 2),
 // unit 16w + 4q + (kk & 3).
-template <bool FULL, bool REC16>
+// FUSE_LIN (C = channels of dy): the gradient w.r.t. the hidden sequence is not read from memory but formed on
+// the fly as dh_ext = W_lin[:, dir*64 + unit]^T dy[pos] (the backward of the Linear that follows the LSTM), one
+// 16x16x32 tile per wave with a 2-term split (hi, lo) -- it enters the recurrence additively, un-amplified.
+template <bool FULL, bool REC16, int FUSE_C>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -270,7 +273,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   const int64_t base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
   const int uoff = 16 * w + 4 * q;
 
-  struct Raw { f32x4 r0, r1, r2, r3, cp, dh; };
+  // W_lin^T tile of this wave's units (FUSE): A[i = unit 16w + j][k = channel 8q + kk], 2-term split
+  bf16x8 Lh, Ll;
+  if constexpr (FUSE_C > 0) {
+    const int ldw = a.ndir * H;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int ch = 8 * q + kk;
+      const float v = ch < FUSE_C ? a.w_lin[(size_t)ch * ldw + dir * H + 16 * w + j] : 0.f;
+      const __bf16 hh = (__bf16)v;
+      Lh[kk] = hh;
+      Ll[kk] = (__bf16)(v - (float)hh);
+    }
+  }
+
+  struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; };
   auto load_raw = [&](int s) {
     Raw r;
     const int st = rev ? S - 1 - s : s;
@@ -285,9 +302,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
         r.r0 = ld4(rec); r.r1 = ld4(rec + H); r.r2 = ld4(rec + 2 * H); r.r3 = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
       }
-      r.dh = ld4(a.dhs + (pos * ndir + dir) * H + uoff);
+      if constexpr (FUSE_C > 0) {          // dy[pos][8q .. 8q+7] (channels beyond C are zero)
+        const bool okc = 8 * q < FUSE_C;
+        const float* dyp = a.dy + pos * FUSE_C + (okc ? 8 * q : 0);
+        const f32x4 d0 = ld4(dyp), d1 = ld4(dyp + 4);
+        r.dh = okc ? d0 : zero4();
+        r.dy1 = okc ? d1 : zero4();
+      } else {
+        r.dh = ld4(a.dhs + (pos * ndir + dir) * H + uoff);
+        r.dy1 = zero4();
+      }
     } else {
-      r.r0 = r.r1 = r.r2 = r.r3 = r.cp = r.dh = zero4();
+      r.r0 = r.r1 = r.r2 = r.r3 = r.cp = r.dh = r.dy1 = zero4();
     }
     return r;
   };
@@ -301,6 +327,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     // previous step so that it has a whole step of latency cover
     asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.cp), "+v"(raw.dh));
     if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
+    if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
     __builtin_amdgcn_sched_barrier(0);
     nxt = load_raw(max(s - 1, 0));
     __builtin_amdgcn_sched_barrier(0);
@@ -312,10 +339,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     } else {
       gi = raw.r0; gf = raw.r1; gg = raw.r2; go = raw.r3;
     }
+    f32x4 dhext = raw.dh;
+    if constexpr (FUSE_C > 0) {
+      bf16x8 bh, bl;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const float v = kk < 4 ? raw.dh[kk] : raw.dy1[kk - 4];
+        const __bf16 hh = (__bf16)v;
+        bh[kk] = hh;
+        bl[kk] = (__bf16)(v - (float)hh);
+      }
+      dhext = mma(Ll, bh, zero4());
+      dhext = mma(Lh, bl, dhext);
+      dhext = mma(Lh, bh, dhext);
+    }
     f32x4 dG[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float dh = raw.dh[r] + dhrec[r];
+      const float dh = dhext[r] + dhrec[r];
       const float cc = gf[r] * raw.cp[r] + gi[r] * gg[r];
       const float tc = tanhf_fast(cc);
       const float dO = dh * tc;
@@ -388,9 +429,12 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
 int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a, hipStream_t st) {
   dim3 grid((a.nseq + 15) / 16, a.ndir), block(256);
   const bool full = a.nseq % 16 == 0, r16 = a.save_c != nullptr;
-#define SB_B(FL, R16) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16>), grid, block, 0, st, a)
-  if (full) { if (r16) SB_B(true, true); else SB_B(true, false); }
-  else { if (r16) SB_B(false, true); else SB_B(false, false); }
+  const int fc = a.dy ? a.C_lin : 0;
+#define SB_B(FL, R16, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC>), grid, block, 0, st, a)
+#define SB_BF(FC) do { if (full) { if (r16) SB_B(true, true, FC); else SB_B(true, false, FC); } \
+                       else { if (r16) SB_B(false, true, FC); else SB_B(false, false, FC); } } while (0)
+  if (fc == 0) SB_BF(0); else if (fc == 16) SB_BF(16); else if (fc == 32) SB_BF(32); else return -1002;
+#undef SB_BF
 #undef SB_B
   return 0;
 }

@@ -51,14 +51,18 @@ class IntraPlainFn(torch.autograd.Function):
         geom = Geom.intra(B * T, F)
         gP, sC = dense(P, Cc)
         _, s2H = dense(P, 2 * H)
-        # Linear backward
-        dhs = torch.empty(P, 2 * H, device=dy.device, dtype=torch.float32)
-        ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, s2H, Cc, 2 * H)
+        # Linear backward (its data gradient d(hs) = dy . W_lin is formed inside the recurrent kernel when possible)
+        fuse = ops.can_fuse_linear_bwd()
+        dhs = None
+        if not fuse:
+            dhs = torch.empty(P, 2 * H, device=dy.device, dtype=torch.float32)
+            ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, s2H, Cc, 2 * H)
         d_lin_w = torch.zeros_like(lin_w)
         d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
         ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, d_lin_w, dbias=d_lin_b)
         # BPTT
-        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
+        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
+                              w_lin=lin_w if fuse else None)
         # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)
         ((dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2)), du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1)
         dx, d_g, d_b, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc))
@@ -102,12 +106,15 @@ class InterFn(torch.autograd.Function):
         geom = Geom.inter(B, T, F)
         gP, sC = dense(P, Cc)
         _, sH = dense(P, H)
-        dhs = torch.empty(P, H, device=dy.device, dtype=torch.float32)
-        ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
+        fuse = ops.can_fuse_linear_bwd()
+        dhs = None
+        if not fuse:
+            dhs = torch.empty(P, H, device=dy.device, dtype=torch.float32)
+            ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
         d_lin_w = torch.zeros_like(lin_w)
         d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
         ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, d_lin_w, dbias=d_lin_b)
-        dg = ops.lstm_bwd_rec([wh], gates, dhs, geom)
+        dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None, w_lin=lin_w if fuse else None)
         # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
         ((dwi, dwh, db1, db2),), du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F)
         dx, d_g, d_b, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc))

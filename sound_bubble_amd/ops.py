@@ -96,10 +96,17 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     return hs, ((hN, cN) if want_state else None), (gates, cprev), u
 
 
-def lstm_bwd_rec(w_hh_list, gates, dhs, geom):
+def can_fuse_linear_bwd():
+    """the recurrent backward can form d(hs) = dy . W_lin on the fly (bf16 split path, compact-BPTT mode)"""
+    return LSTM_MMA == 1 and COMPACT_BPTT
+
+
+def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
+    """dhs [P, ndir*64] -- or, fused: dhs=None, dy [P, C] and w_lin [C, ndir*64] (see can_fuse_linear_bwd)."""
     lib = L.load()
     ndir = len(w_hh_list)
-    dg = torch.empty(geom.P, ndir, 4, H, device=dhs.device, dtype=torch.float32)
+    dev = dhs.device if dhs is not None else dy.device
+    dg = torch.empty(geom.P, ndir, 4, H, device=dev, dtype=torch.float32)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, ndir
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
@@ -109,6 +116,9 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom):
     a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), _p(cprev)
     a.dhs, a.dgates = _p(dhs), _p(dg)
     a.mma = LSTM_MMA
+    if dy is not None:
+        assert can_fuse_linear_bwd() and w_lin.shape == (dy.shape[-1], ndir * H)
+        a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), dy.shape[-1]
     L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
     return dg
 
