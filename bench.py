@@ -124,6 +124,43 @@ def cpu_baseline(torch, wl, budget_s=20.0):
             "sample": f"{n} train steps of batch {B} ({wl} config, 5 s clips), oracle CPU port, after 1 warm-up"}
 
 
+def vendor_gpu_baseline(torch, wl, B, dev, steps=3):
+    """Second yardstick of SURVEY.md 8(d), measurement only: the same oracle restatement (stock torch.nn ops ->
+    MIOpen RNN / rocBLAS / ATen kernels) moved onto the GPU -- i.e. what running the reference unmodified on
+    PyTorch-ROCm gives.  Falls back to smaller batches if the library path runs out of memory."""
+    from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
+    cls, params, _, negw, clip, lr = WORKLOADS[wl]
+    torch.manual_seed(0)
+    m = OracleNet("optim" if cls == "NetOptim" else "dis_embd3", **params).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    while B >= 1:
+        try:
+            inputs, tgt = synth_batch(torch, B, 1234, dev, cls != "NetOptim")
+
+            def step():
+                opt.zero_grad()
+                est = m(dict(inputs))["output"]
+                snrlp_loss(est, tgt, negw).mean().backward()
+                if clip:
+                    torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+                opt.step()
+
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            return {"value": B / dt, "unit": "utterances/s", "batch": B, "ms_per_step": dt * 1e3,
+                    "kind": "oracle restatement on the GPU through stock torch.nn ops (MIOpen RNN, rocBLAS, ATen)",
+                    "sample": f"{steps} train steps of batch {B} after 1 warm-up"}
+        except torch.OutOfMemoryError:
+            B //= 2
+            torch.cuda.empty_cache()
+    return None
+
+
 def stream_bench(torch, sb, args, cls, params, dev):
     """Config 5: B=1, 625 chunks of [1, 6, 288] (8 ms hop) through the hipGraph-captured chunk step."""
     import numpy as np
@@ -168,6 +205,8 @@ def main():
     ap.add_argument("--workload", default="small", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vendor-gpu-baseline", action="store_true",
+                    help="extra leg: time the oracle restatement on the GPU through stock torch ops (MIOpen RNN)")
     ap.add_argument("--forward-only", action="store_true", help="extra mode: inference forward utt/s")
     ap.add_argument("--stream", action="store_true",
                     help="extra mode (BASELINE config 5): hipGraph-captured 8 ms chunk loop, chunks/s + p50 latency")
@@ -279,6 +318,12 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, args.workload)
             out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
+        if args.vendor_gpu_baseline and not args.forward_only:
+            del model, bucket, optim
+            torch.cuda.empty_cache()
+            out["vendor_gpu_baseline"] = vendor_gpu_baseline(torch, args.workload, B, dev)
+            if out["vendor_gpu_baseline"]:
+                out["vendor_gpu_baseline"]["ours_over_vendor"] = utt_s / out["vendor_gpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
