@@ -165,8 +165,8 @@ typedef struct {
 int sb_ln_bwd(const sb_ln_bwd_args* a, void* stream);
 int sb_ln_bwd_grid(int64_t positions);
 
-/* ---- full-band local self-attention (forward) -------------------------------
- * tfgridnet_causal.py:639-684,856-898 (off in every shipped config; inference/streaming path only).
+/* ---- full-band local self-attention ----------------------------------------
+ * tfgridnet_causal.py:639-684,856-898 (off in every shipped config).
  * sb_head_ln: per (b, t) LayerNorm over the (f, d) elements of each head of in [B, T, F, Hh*D] (eps 1e-5, gamma/beta
  *   [F*D] shared by the heads), written head-major into out[(b*Hh + h) * rows + t_off + t][0..ldo) (columns beyond
  *   F*D zeroed).  With Hh == 1 and res != NULL: out = res[b,t,:] + LN(in[b,t,:])  (the attn_concat_proj LayerNorm).
@@ -174,13 +174,34 @@ int sb_ln_bwd_grid(int64_t positions);
  *   16) -> out [B, T, F, Hh*Cv]: softmax_l(q_t . k_{t+l} * scale) over l in [0, L) of the concatenated rows, times V;
  *   both contractions on the fp32-input MFMA.  NRp = 16*ceil((L+15)/16). */
 int sb_head_ln(const float* in, const float* gamma, const float* beta, float* out, const float* res, int B, int T, int F,
-               int Hh, int D, int rows, int t_off, int ldo, void* stream);
+               int Hh, int D, int rows, int t_off, int ldo, int ldi /* row stride of in, >= Hh*D */,
+               const float* prelu_a /* nullable: PReLU(in) is what gets normalised */, void* stream);
 typedef struct {
   int BH, Hh, T, F, Cv, L, NRp, ldk, ldv;
   float scale;
   const float* Q; const float* K; const float* V; float* out;
+  float* lse;                 /* nullable: [BH, T] log-sum-exp of each query's scaled scores (kept for the backward) */
 } sb_attn_args;
 int sb_attn_core(const sb_attn_args* a, void* stream);
+
+/* ---- attention backward (training with use_attn=True) ----------------------
+ * sb_head_ln_bwd: backward of sb_head_ln incl. the PReLU applied on load.  dout is in the forward's head-major output
+ *   layout; din [B,T,F,ldi] (gradient w.r.t. the pre-activation); partials [sb_head_ln_bwd_grid(B,T), 2n+1] with
+ *   n = F*Hh*D: per-workgroup [dgamma_i][dbeta_i][dalpha] indexed by the flat (f, h, d) element -- reduce the rows with
+ *   sb_reduce_rows and fold the heads on the host.  The residual branch (res) passes dout through unchanged.
+ * sb_attn_core_bwd: dO [BH, T, ldv] head-major (zero-padded like V) -> dQ [BH, T, ldk], dK [BH, T, ldk], dV [BH, T, ldv]
+ *   (current-frame rows only; the carried K/V buffer rows are not differentiated), delta [BH, T] scratch.  Two launches
+ *   (per-query tile, per-key tile), probabilities recomputed from lse; no atomics on dQ/dK/dV. */
+int sb_head_ln_bwd_grid(int B, int T);
+int sb_head_ln_bwd(const float* in, const float* gamma, const float* dout, float* din, float* partials, int B, int T,
+                   int F, int Hh, int D, int rows, int t_off, int ldo, int ldi, const float* prelu_a, void* stream);
+typedef struct {
+  int BH, Hh, T, F, Cv, L, NRp, ldk, ldv;
+  float scale;
+  const float* Q; const float* K; const float* V; const float* dO; const float* lse;
+  float* delta; float* dQ; float* dK; float* dV;
+} sb_attn_bwd_args;
+int sb_attn_core_bwd(const sb_attn_bwd_args* a, void* stream);
 
 /* ---- front-end features --------------------------------------------------
  * spec [B*M, T, ld_spec] (cols 0..F-1 real, F..2F-1 imag: asteroid Encoder

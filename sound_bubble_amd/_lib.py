@@ -68,7 +68,14 @@ class LnBwdArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("BH", C.c_int), ("Hh", C.c_int), ("T", C.c_int), ("F", C.c_int), ("Cv", C.c_int), ("L", C.c_int),
                 ("NRp", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("scale", C.c_float),
-                ("Q", c_fp), ("K", c_fp), ("V", c_fp), ("out", c_fp)]
+                ("Q", c_fp), ("K", c_fp), ("V", c_fp), ("out", c_fp), ("lse", c_fp)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("BH", C.c_int), ("Hh", C.c_int), ("T", C.c_int), ("F", C.c_int), ("Cv", C.c_int), ("L", C.c_int),
+                ("NRp", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("scale", C.c_float),
+                ("Q", c_fp), ("K", c_fp), ("V", c_fp), ("dO", c_fp), ("lse", c_fp),
+                ("delta", c_fp), ("dQ", c_fp), ("dK", c_fp), ("dV", c_fp)]
 
 
 EPI_NONE, EPI_RES, EPI_PRELU, EPI_LN, EPI_LNBWD = range(5)
@@ -86,8 +93,11 @@ SYMBOLS = {
     "sb_lstm_stream_grid": (_ci, [i64]),
     "sb_ln_bwd": (_ci, [C.POINTER(LnBwdArgs), _vp]),
     "sb_ln_bwd_grid": (_ci, [i64]),
-    "sb_head_ln": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "sb_head_ln": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, c_fp, _vp]),
     "sb_attn_core": (_ci, [C.POINTER(AttnArgs), _vp]),
+    "sb_head_ln_bwd_grid": (_ci, [_ci, _ci]),
+    "sb_head_ln_bwd": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, c_fp, _vp]),
+    "sb_attn_core_bwd": (_ci, [C.POINTER(AttnBwdArgs), _vp]),
     "sb_colsum": (_ci, [c_fp, i64, i64, _ci, c_fp, c_fp, _vp]),
     "sb_reduce_rows": (_ci, [c_fp, _ci, i64, _ci, c_fp, _vp]),
     "sb_features": (_ci, [c_fp, i64, c_fp, _ci, _ci, _ci, _ci, _vp]),

@@ -17,17 +17,19 @@
 namespace {
 
 // LayerNorm over the (f, d) elements of each head for one (b, t) per workgroup.
-//   in  [B, T, F, Hh*D]  (head h, component d at column h*D + d)
+//   in  [B, T, F, ldi] (head h, component d at column h*D + d; ldi >= Hh*D); prelu_a (nullable): PReLU applied on load
 //   out row (b*Hh + h, t_off + t) of a [B*Hh, rows, ldo] matrix, element f*D + d; columns [F*D, ldo) zeroed
 //   res (nullable, Hh == 1 only): out = res[b,t,:] + LN(...)
 __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ in, const float* __restrict__ gam,
                                                       const float* __restrict__ bet, float* __restrict__ out,
                                                       const float* __restrict__ res, int B, int T, int F, int Hh, int D,
-                                                      int rows, int t_off, int ldo) {
+                                                      int rows, int t_off, int ldo, int ldi,
+                                                      const float* __restrict__ prelu_a) {
   constexpr int MAXV = 20;                       // F*Hh*D <= 256*MAXV  (145*32 = 4640 fits)
   const int bt = blockIdx.x, b = bt / T, t = bt % T;
   const int n = F * Hh * D, HD = Hh * D, FD = F * D;
-  const float* x = in + (size_t)bt * n;
+  const float* x = in + (size_t)bt * F * ldi;
+  const float pa = prelu_a ? prelu_a[0] : 1.0f;
   float v[MAXV];
   __shared__ float red[4][8];                    // [wave][head] (Hh <= 8)
   __shared__ float stat[8][2];
@@ -37,8 +39,10 @@ __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ 
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int i = threadIdx.x + 256 * k;
-    v[k] = i < n ? x[i] : 0.f;
+    v[k] = 0.f;
     if (i < n) {
+      const float xv = x[(size_t)(i / HD) * ldi + i % HD];
+      v[k] = xv > 0.f ? xv : pa * xv;
       const int h = (i % HD) / D;
 #pragma unroll
       for (int hh = 0; hh < 8; ++hh) part[hh] += hh == h ? v[k] : 0.f;
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
     float s = 0.f;
     for (int r = sub; r < NRp; r += 16) { const float e = __expf(PT[qi * ldp + r] - mx); PT[qi * ldp + r] = e; s += e; }
     s = row16_sum(s);
+    if (a.lse && sub == 0 && t0 + qi < a.T) a.lse[(size_t)bh * a.T + t0 + qi] = mx + __logf(s);
     const float inv = 1.0f / s;
     for (int r = sub; r < NRp; r += 16) PT[qi * ldp + r] *= inv;
   }
@@ -151,13 +156,289 @@ __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
   }
 }
 
+// Backward of head_ln_kernel (+ the PReLU applied on load).  One workgroup walks `rpb` consecutive (b, t) rows so the
+// gamma/beta/alpha gradients accumulate in registers; partials[blockIdx.x] = [dgamma_i (n)][dbeta_i (n)][dalpha], with
+// i the flat (f, h, d) element index (the host folds the heads: gamma/beta are shared by them).
+//   dout: head-major rows as written by the forward (row (b*Hh+h, t_off+t) of [B*Hh, rows, ldo]);  din [B,T,F,ldi]
+__global__ __launch_bounds__(256) void head_ln_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gam,
+                                                          const float* __restrict__ dout, float* __restrict__ din,
+                                                          float* __restrict__ partials, int B, int T, int F, int Hh,
+                                                          int D, int rows, int t_off, int ldo, int ldi,
+                                                          const float* __restrict__ prelu_a, int rpb) {
+  constexpr int MAXV = 20;
+  const int n = F * Hh * D, HD = Hh * D, FD = F * D;
+  const float pa = prelu_a ? prelu_a[0] : 1.0f;
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  __shared__ float red[4][8][2];
+  __shared__ float stat[8][2];
+  float dgam[MAXV], dbet[MAXV], dalpha = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) dgam[k] = dbet[k] = 0.f;
+
+  auto head_sums = [&](const float (&a0)[8], const float (&a1)[8], float scale0, float scale1, bool rs) {
+    // block-wide per-head sums of two quantities -> stat[h][0..1] (optionally transformed)
+    for (int h = 0; h < Hh; ++h) {
+      const float s0 = wave_sum(a0[h]), s1 = wave_sum(a1[h]);
+      if (ln == 0) { red[wv][h][0] = s0; red[wv][h][1] = s1; }
+    }
+    __syncthreads();
+    if (threadIdx.x < Hh) {
+      const int h = threadIdx.x;
+      const float s0 = red[0][h][0] + red[1][h][0] + red[2][h][0] + red[3][h][0];
+      const float s1 = red[0][h][1] + red[1][h][1] + red[2][h][1] + red[3][h][1];
+      stat[h][0] = s0 * scale0;
+      stat[h][1] = rs ? 1.0f / sqrtf(s1 * scale1 + 1e-5f) : s1 * scale1;
+    }
+    __syncthreads();
+  };
+
+  for (int bt = blockIdx.x * rpb; bt < min((blockIdx.x + 1) * rpb, B * T); ++bt) {
+    const int b = bt / T, t = bt % T;
+    const float* x = in + (size_t)bt * F * ldi;
+    float pr[MAXV], xh[MAXV], gy[MAXV];
+    float p0[8], p1[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) p0[h] = p1[h] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      pr[k] = 0.f; xh[k] = 0.f;
+      if (i < n) {
+        pr[k] = x[(size_t)(i / HD) * ldi + i % HD];
+        xh[k] = pr[k] > 0.f ? pr[k] : pa * pr[k];
+        const int h = (i % HD) / D;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) p0[hh] += hh == h ? xh[k] : 0.f;
+      }
+    }
+    head_sums(p0, p1, 1.0f / FD, 0.f, false);
+    float mean[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { mean[h] = h < Hh ? stat[h][0] : 0.f; p0[h] = p1[h] = 0.f; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < n) {
+        const int h = (i % HD) / D;
+        float mu = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) mu = hh == h ? mean[hh] : mu;
+        xh[k] -= mu;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) p1[hh] += hh == h ? xh[k] * xh[k] : 0.f;
+      }
+    }
+    head_sums(p0, p1, 0.f, 1.0f / FD, true);
+    float rstd[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { rstd[h] = h < Hh ? stat[h][1] : 0.f; p0[h] = p1[h] = 0.f; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      gy[k] = 0.f;
+      if (i < n) {
+        const int f = i / HD, hd = i % HD, h = hd / D, d = hd % D, e = f * D + d;
+        float rs = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) rs = hh == h ? rstd[hh] : rs;
+        xh[k] *= rs;                                             // normalised value
+        const float dy = dout[((size_t)(b * Hh + h) * rows + t_off + t) * ldo + e];
+        dgam[k] += dy * xh[k];
+        dbet[k] += dy;
+        gy[k] = dy * gam[e];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) { p0[hh] += hh == h ? gy[k] : 0.f; p1[hh] += hh == h ? gy[k] * xh[k] : 0.f; }
+      }
+    }
+    head_sums(p0, p1, 1.0f / FD, 1.0f / FD, false);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < n) {
+        const int h = (i % HD) / D;
+        float rs = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+          rs = hh == h ? rstd[hh] : rs;
+          m1 = hh == h ? stat[hh][0] : m1;
+          m2 = hh == h ? stat[hh][1] : m2;
+        }
+        const float dv = rs * (gy[k] - m1 - xh[k] * m2);
+        const bool pos = pr[k] > 0.f;
+        dalpha += pos ? 0.f : dv * pr[k];
+        din[(size_t)bt * F * ldi + (size_t)(i / HD) * ldi + i % HD] = pos ? dv : pa * dv;
+      }
+    }
+    __syncthreads();
+  }
+  float* prow = partials + (size_t)blockIdx.x * (2 * n + 1);
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < n) { prow[i] = dgam[k]; prow[n + i] = dbet[k]; }
+  }
+  const float da = wave_sum(dalpha);
+  __syncthreads();
+  if (ln == 0) red[wv][0][0] = da;
+  __syncthreads();
+  if (threadIdx.x == 0) prow[2 * n] = red[0][0][0] + red[1][0][0] + red[2][0][0] + red[3][0][0];
+}
+
+// D[i][j] = sum_k X[xrow(lane&15)][k] * Y[yrow(lane&15)][k] over ld features (both fetched as 16-byte row pieces);
+// lane (j, q) ends up with D[4q + r][j].
+__device__ __forceinline__ f32x4 rowdot_tile(const float* __restrict__ X, size_t xrow, const float* __restrict__ Y,
+                                             size_t yrow, int ld, int q) {
+  f32x4 acc = zero4();
+  for (int m = 0; m < ld / 16; ++m)
+    acc = mfma16x4(ld4(X + xrow * ld + 16 * m + 4 * q), ld4(Y + yrow * ld + 16 * m + 4 * q), acc);
+  return acc;
+}
+// D[i][j] = sum_k Pl[i][k] * Z[clamp(zrow0 + k)][col0 + j]  (Pl: LDS, leading dim ldp; k < 16*nk16)
+__device__ __forceinline__ f32x4 lds_times_rows(const float* Pl, int ldp, int nk16, const float* __restrict__ Z,
+                                                int zrow0, int zmax, int ld, int col, int j, int q) {
+  f32x4 acc = zero4();
+  for (int m = 0; m < nk16; ++m) {
+    const f32x4 a4 = ld4(&Pl[j * ldp + 16 * m + 4 * q]);
+    f32x4 b4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b4[r] = Z[(size_t)min(zrow0 + 16 * m + 4 * q + r, zmax) * ld + col];
+    acc = mfma16x4(a4, b4, acc);
+  }
+  return acc;
+}
+
+// dQ (+ delta_t = sum_l p_l dp_l): grid (ceil(T/16), B*Hh), same tiling as the forward.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(sb_attn_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) float SM[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int bh = blockIdx.y, t0 = blockIdx.x * 16;
+  const int L = a.L, NRp = a.NRp, ldp = NRp + 4, rows = L - 1 + a.T;
+  float* PT = SM;                       // [16 queries][ldp] probabilities
+  float* DP = SM + 16 * ldp;            // [16 queries][ldp] dP -> dS
+  const float* __restrict__ Kb = a.K + (size_t)bh * rows * a.ldk;
+  const float* __restrict__ Qb = a.Q + (size_t)bh * a.T * a.ldk;
+  const float* __restrict__ Vb = a.V + (size_t)bh * rows * a.ldv;
+  const float* __restrict__ Gb = a.dO + (size_t)bh * a.T * a.ldv;
+  const int nrt = NRp / 16;
+  const int tq = min(t0 + j, a.T - 1);
+  const float lse = a.lse[(size_t)bh * a.T + tq];
+  for (int rt = w; rt < nrt; rt += 4) {
+    const int krow = min(t0 + 16 * rt + j, rows - 1);
+    const f32x4 s = rowdot_tile(Kb, krow, Qb, tq, a.ldk, q);
+    const f32x4 dp = rowdot_tile(Vb, krow, Gb, tq, a.ldv, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * rt + 4 * q + r;
+      const bool ok = row >= j && row < j + L && (t0 + row) < rows;
+      PT[j * ldp + row] = ok ? __expf(s[r] * a.scale - lse) : 0.f;
+      DP[j * ldp + row] = dp[r];
+    }
+  }
+  __syncthreads();
+  {
+    const int qi = tid >> 4, sub = tid & 15;
+    float d = 0.f;
+    for (int r = sub; r < NRp; r += 16) d += PT[qi * ldp + r] * DP[qi * ldp + r];
+    d = row16_sum(d);
+    if (sub == 0 && t0 + qi < a.T) a.delta[(size_t)bh * a.T + t0 + qi] = d;
+    for (int r = sub; r < NRp; r += 16) DP[qi * ldp + r] = PT[qi * ldp + r] * (DP[qi * ldp + r] - d) * a.scale;
+  }
+  __syncthreads();
+  for (int nt = w; nt < a.ldk / 16; nt += 4) {
+    const f32x4 acc = lds_times_rows(DP, ldp, nrt, Kb, t0, rows - 1, a.ldk, 16 * nt + j, j, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = t0 + 4 * q + r;
+      if (t < a.T) a.dQ[((size_t)bh * a.T + t) * a.ldk + 16 * nt + j] = acc[r];
+    }
+  }
+}
+
+// dK, dV of the current-frame rows (the carried buffer rows get no gradient): grid (ceil(T/16), B*Hh); the tile of
+// 16 key rows r = L-1 + 16*bx + j gathers from the queries 16*bx .. 16*bx + L + 14 that attend to them.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(sb_attn_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) float SM[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int bh = blockIdx.y, tb = blockIdx.x * 16;
+  const int L = a.L, NRp = a.NRp, ldp = NRp + 4, rows = L - 1 + a.T;
+  float* PT = SM;                       // [16 key rows][ldp queries]
+  float* DS = SM + 16 * ldp;
+  const float* __restrict__ Kb = a.K + (size_t)bh * rows * a.ldk;
+  const float* __restrict__ Qb = a.Q + (size_t)bh * a.T * a.ldk;
+  const float* __restrict__ Vb = a.V + (size_t)bh * rows * a.ldv;
+  const float* __restrict__ Gb = a.dO + (size_t)bh * a.T * a.ldv;
+  const int nqt = NRp / 16;
+  const int r0 = L - 1 + tb;
+  const int krow = min(r0 + j, rows - 1);
+  for (int qt = w; qt < nqt; qt += 4) {
+    const int tqa = min(tb + 16 * qt + j, a.T - 1);             // A-operand row: query 16qt + j
+    const f32x4 s = rowdot_tile(Qb, tqa, Kb, krow, a.ldk, q);    // D[query 4q+r][row j]
+    const f32x4 dp = rowdot_tile(Gb, tqa, Vb, krow, a.ldv, q);
+    f32x4 p4, ds4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int wq = 16 * qt + 4 * q + r, tq = tb + wq;
+      const int off = L - 1 + j - wq;                            // position of row r0+j inside query tq's window
+      const bool ok = (tq < a.T) & (off >= 0) & (off < L) & (r0 + j < rows);
+      const int tqc = min(tq, a.T - 1);
+      const float p = ok ? __expf(s[r] * a.scale - a.lse[(size_t)bh * a.T + tqc]) : 0.f;
+      p4[r] = p;
+      ds4[r] = p * (dp[r] - a.delta[(size_t)bh * a.T + tqc]) * a.scale;
+    }
+    st4(&PT[j * ldp + 16 * qt + 4 * q], p4);
+    st4(&DS[j * ldp + 16 * qt + 4 * q], ds4);
+  }
+  __syncthreads();
+  const int nk = a.ldk / 16, nv = a.ldv / 16;
+  for (int nt = w; nt < nk + nv; nt += 4) {
+    const bool isk = nt < nk;
+    const int c = isk ? nt : nt - nk;
+    const f32x4 acc = isk ? lds_times_rows(DS, ldp, nqt, Qb, tb, a.T - 1, a.ldk, 16 * c + j, j, q)
+                          : lds_times_rows(PT, ldp, nqt, Gb, tb, a.T - 1, a.ldv, 16 * c + j, j, q);
+    float* o = isk ? a.dK : a.dV;
+    const int ld = isk ? a.ldk : a.ldv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = tb + 4 * q + r;
+      if (t < a.T) o[((size_t)bh * a.T + t) * ld + 16 * c + j] = acc[r];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sb_head_ln(const float* in, const float* gamma, const float* beta, float* out, const float* res, int B,
-                          int T, int F, int Hh, int D, int rows, int t_off, int ldo, void* stream) {
-  if (Hh > 8 || F * Hh * D > 256 * 20 || (res && Hh != 1)) return -1002;
+                          int T, int F, int Hh, int D, int rows, int t_off, int ldo, int ldi, const float* prelu_a,
+                          void* stream) {
+  if (Hh > 8 || F * Hh * D > 256 * 20 || (res && Hh != 1) || ldi < Hh * D) return -1002;
   hipLaunchKernelGGL(head_ln_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, in, gamma, beta, out, res, B, T, F,
-                     Hh, D, rows, t_off, ldo);
+                     Hh, D, rows, t_off, ldo, ldi, prelu_a);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_head_ln_bwd_grid(int B, int T) { return (B * T + 15) / 16; }
+
+extern "C" int sb_head_ln_bwd(const float* in, const float* gamma, const float* dout, float* din, float* partials, int B,
+                              int T, int F, int Hh, int D, int rows, int t_off, int ldo, int ldi, const float* prelu_a,
+                              void* stream) {
+  if (Hh > 8 || F * Hh * D > 256 * 20 || ldi < Hh * D) return -1002;
+  hipLaunchKernelGGL(head_ln_bwd_kernel, dim3(sb_head_ln_bwd_grid(B, T)), dim3(256), 0, (hipStream_t)stream, in, gamma,
+                     dout, din, partials, B, T, F, Hh, D, rows, t_off, ldo, ldi, prelu_a, 16);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_attn_core_bwd(const sb_attn_bwd_args* ap, void* stream) {
+  if (!ap || ap->ldk % 16 || ap->ldv % 16 || ap->NRp % 16 || ap->NRp < ap->L + 15) return -1002;
+  const size_t lds = (size_t)2 * 16 * (ap->NRp + 4) * sizeof(float);
+  if (lds > 64 * 1024) return -1005;
+  dim3 grid((ap->T + 15) / 16, ap->BH);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ap);
+  SB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ap);
   SB_CHECK_LAUNCH();
   return 0;
 }

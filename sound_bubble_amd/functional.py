@@ -207,15 +207,13 @@ class IntraConvFn(torch.autograd.Function):
 
 class AttentionFn(torch.autograd.Function):
     """y = x + LN_{F*C}(PReLU(Linear(local full-band self-attention(x))))  -- tfgridnet_causal.py:856-898
-    (modules :639-684, causal window :722-744).  Forward only: no shipped config enables attention, so its
-    backward is not built (training with use_attn=True raises).  Returns (y, new K_buf, new V_buf)."""
+    (modules :639-684, causal window :722-744).  Returns (y, new K_buf, new V_buf).  The carried K/V buffers are
+    state, not differentiated (the reference trains from zero-filled buffers)."""
 
     @staticmethod
     def forward(ctx, x, K_buf, V_buf, wq, bq, aq, gq, eq, wk, bk, ak, gk, ek, wv, bv, av, gv, ev, wp, bp, ap_, gp, ep,
                 n_head, E, Lw):
-        if GRAD_MODE and any(ctx.needs_input_grad):
-            raise NotImplementedError("use_attn=True: the attention backward pass is not built (no shipped config "
-                                      "trains with attention); run under torch.no_grad() / eval")
+        train = GRAD_MODE and any(ctx.needs_input_grad)
         B, T, F, Cc = x.shape
         x = x.contiguous()
         dev = x.device
@@ -224,15 +222,16 @@ class AttentionFn(torch.autograd.Function):
         HE = n_head * E
         gP, sC = dense(P, Cc)
 
-        def proj(w, b, a, n_out):
+        def proj(w, b, n_out):
+            """pre-activation of Linear(C -> n_out), stored with a 16-padded row stride (padding columns zero)"""
             npad = (n_out + 15) // 16 * 16
             wpad = torch.zeros(npad, Cc, device=dev, dtype=torch.float32)
             wpad[:n_out] = w
             bpad = torch.zeros(npad, device=dev, dtype=torch.float32)
             bpad[:n_out] = b
-            out = torch.empty(P, n_out, device=dev, dtype=torch.float32)
-            ops.linear(x, wpad, bpad, out, gP, sC, (0, 0, n_out), Cc, npad, n_valid=n_out, epi=L.EPI_PRELU, prelu_a=a)
-            return out
+            out = torch.zeros(P, npad, device=dev, dtype=torch.float32)
+            ops.linear(x, wpad, bpad, out, gP, sC, (0, 0, npad), Cc, npad, n_valid=n_out)
+            return out, npad
 
         ldk = (F * E + 15) // 16 * 16
         ldv = (F * Cv + 15) // 16 * 16
@@ -243,24 +242,74 @@ class AttentionFn(torch.autograd.Function):
         Vc = torch.zeros(BH, rows, ldv, device=dev, dtype=torch.float32)
         Kc[:, : Lw - 1, : F * E] = K_buf
         Vc[:, : Lw - 1, : F * Cv] = V_buf
-        ops.head_ln(proj(wq, bq, aq, HE), gq, eq, Qn, B, T, F, n_head, E, T, 0, ldk)
-        ops.head_ln(proj(wk, bk, ak, HE), gk, ek, Kc, B, T, F, n_head, E, rows, Lw - 1, ldk)
-        ops.head_ln(proj(wv, bv, av, Cc), gv, ev, Vc, B, T, F, n_head, Cv, rows, Lw - 1, ldv)
+        pq, ldq = proj(wq, bq, HE)
+        pk, _ = proj(wk, bk, HE)
+        pv, ldvp = proj(wv, bv, Cc)
+        ops.head_ln(pq, gq, eq, Qn, B, T, F, n_head, E, T, 0, ldk, ldi=ldq, prelu_a=aq)
+        ops.head_ln(pk, gk, ek, Kc, B, T, F, n_head, E, rows, Lw - 1, ldk, ldi=ldq, prelu_a=ak)
+        ops.head_ln(pv, gv, ev, Vc, B, T, F, n_head, Cv, rows, Lw - 1, ldv, ldi=ldvp, prelu_a=av)
         O = torch.empty(B, T, F, Cc, device=dev, dtype=torch.float32)
-        ops.attn_core(Qn, Kc, Vc, O, BH, n_head, T, F, Cv, Lw, ldk, ldv, 1.0 / float(F * E) ** 0.5)
-        # merge heads -> Linear + PReLU -> LayerNorm(F*C) -> + x
-        Yp = torch.empty(P, Cc, device=dev, dtype=torch.float32)
-        ops.linear(O, wp, bp, Yp, gP, sC, sC, Cc, Cc, epi=L.EPI_PRELU, prelu_a=ap_)
+        lse = torch.empty(BH, T, device=dev, dtype=torch.float32) if train else None
+        scale = 1.0 / float(F * E) ** 0.5
+        ops.attn_core(Qn, Kc, Vc, O, BH, n_head, T, F, Cv, Lw, ldk, ldv, scale, lse=lse)
+        # merge heads -> Linear -> PReLU -> LayerNorm(F*C) -> + x
+        pp = torch.empty(P, Cc, device=dev, dtype=torch.float32)
+        ops.linear(O, wp, bp, pp, gP, sC, sC, Cc, Cc)
         y = torch.empty_like(x)
-        ops.head_ln(Yp, gp, ep, y, B, T, F, 1, Cc, T, 0, F * Cc, res=x)
+        ops.head_ln(pp, gp, ep, y, B, T, F, 1, Cc, T, 0, F * Cc, res=x, prelu_a=ap_)
         nK = Kc[:, rows - (Lw - 1):, : F * E].contiguous()
         nV = Vc[:, rows - (Lw - 1):, : F * Cv].contiguous()
         ctx.mark_non_differentiable(nK, nV)
+        if train:
+            ctx.save_for_backward(x, pq, pk, pv, Qn, Kc, Vc, lse, O, pp, wq, aq, gq, wk, ak, gk, wv, av, gv, wp, ap_, gp)
+            ctx.cfg = (B, T, F, Cc, n_head, E, Lw, ldk, ldv, ldq, ldvp, scale)
         return y, nK, nV
 
     @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError("attention backward is not built")
+    def backward(ctx, dy, _dK, _dV):
+        x, pq, pk, pv, Qn, Kc, Vc, lse, O, pp, wq, aq, gq, wk, ak, gk, wv, av, gv, wp, ap_, gp = ctx.saved_tensors
+        B, T, F, Cc, n_head, E, Lw, ldk, ldv, ldq, ldvp, scale = ctx.cfg
+        dev = x.device
+        P = B * T * F
+        Cv = Cc // n_head
+        HE = n_head * E
+        BH = B * n_head
+        gP, sC = dense(P, Cc)
+        dy = dy.contiguous()
+        # LayerNorm(F*C) + PReLU of the output projection (the residual passes dy through)
+        dpp, d_gp, d_ep, d_ap = ops.head_ln_bwd(pp, gp, dy, B, T, F, 1, Cc, T, 0, F * Cc, Cc, prelu_a=ap_)
+        d_wp = torch.zeros_like(wp)
+        d_bp = torch.zeros(Cc, device=dev, dtype=torch.float32)
+        ops.wgrad(dpp, Cc, Cc, O, sC, gP, Cc, d_wp, dbias=d_bp)
+        dO = torch.empty(P, Cc, device=dev, dtype=torch.float32)
+        ops.linear(dpp, wp.t().contiguous(), None, dO, gP, sC, sC, Cc, Cc)
+        # head-major, zero-padded copy of dO (layout glue), then the attention core
+        dOh = torch.zeros(BH, T, ldv, device=dev, dtype=torch.float32)
+        dOh[:, :, : F * Cv] = dO.view(B, T, F, n_head, Cv).permute(0, 3, 1, 2, 4).reshape(BH, T, F * Cv)
+        dQn, dKn, dVn = ops.attn_core_bwd(Qn, Kc, Vc, dOh, lse, BH, n_head, T, F, Cv, Lw, ldk, ldv, scale)
+        # per-head LayerNorms + PReLUs of the three projections
+        dpq, d_gq, d_eq, d_aq = ops.head_ln_bwd(pq, gq, dQn, B, T, F, n_head, E, T, 0, ldk, ldq, prelu_a=aq)
+        dpk, d_gk, d_ek, d_ak = ops.head_ln_bwd(pk, gk, dKn, B, T, F, n_head, E, T, 0, ldk, ldq, prelu_a=ak)
+        dpv, d_gv, d_ev, d_av = ops.head_ln_bwd(pv, gv, dVn, B, T, F, n_head, Cv, T, 0, ldv, ldvp, prelu_a=av)
+        # projections: dx = dy + sum_j dpre_j W_j ; dW_j = dpre_j^T x
+        dx = torch.empty_like(x)
+        outs = []
+        first = True
+        for dpre, w, n_out, ld in ((dpq, wq, HE, ldq), (dpk, wk, HE, ldq), (dpv, wv, Cc, ldvp)):
+            wt = torch.zeros(Cc, ld, device=dev, dtype=torch.float32)
+            wt[:, :n_out] = w.t()
+            if first:
+                ops.linear(dpre, wt, None, dx, gP, (0, 0, ld), sC, ld, Cc, epi=L.EPI_RES, res=dy)
+            else:
+                ops.linear(dpre, wt, None, dx, gP, (0, 0, ld), sC, ld, Cc, accumulate=True)
+            first = False
+            dwp_ = torch.zeros(ld, Cc, device=dev, dtype=torch.float32)
+            dbp_ = torch.zeros(ld, device=dev, dtype=torch.float32)
+            ops.wgrad(dpre, ld, ld, x, sC, gP, Cc, dwp_, dbias=dbp_)
+            outs.append((dwp_[:n_out].contiguous(), dbp_[:n_out].contiguous()))
+        (d_wq, d_bq), (d_wk, d_bk), (d_wv, d_bv) = outs
+        return (dx, None, None, d_wq, d_bq, d_aq, d_gq, d_eq, d_wk, d_bk, d_ak, d_gk, d_ek, d_wv, d_bv, d_av, d_gv,
+                d_ev, d_wp, d_bp, d_ap, d_gp, d_ep, None, None, None)
 
 
 class FilmFn(torch.autograd.Function):

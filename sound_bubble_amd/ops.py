@@ -315,18 +315,51 @@ def snrlp_loss(est, gt, neg_weight, want_grad):
     return lv, dest
 
 
-def head_ln(x, gamma, beta, out, B, T, F, Hh, D, rows, t_off, ldo, res=None):
-    L.check(L.load().sb_head_ln(_p(x), _p(gamma), _p(beta), _p(out), _p(res), B, T, F, Hh, D, rows, t_off, ldo,
-                                _stream()), "sb_head_ln")
+def head_ln(x, gamma, beta, out, B, T, F, Hh, D, rows, t_off, ldo, res=None, ldi=None, prelu_a=None):
+    ldi = Hh * D if ldi is None else ldi
+    L.check(L.load().sb_head_ln(_p(x), _p(gamma), _p(beta), _p(out), _p(res), B, T, F, Hh, D, rows, t_off, ldo, ldi,
+                                _p(prelu_a), _stream()), "sb_head_ln")
 
 
-def attn_core(Q, K, V, out, BH, Hh, T, F, Cv, Lw, ldk, ldv, scale):
+def head_ln_bwd(x, gamma, dout, B, T, F, Hh, D, rows, t_off, ldo, ldi, prelu_a=None):
+    """-> (din [B*T*F, ldi] (columns beyond Hh*D zero), dgamma [F*D], dbeta [F*D], dalpha [1])"""
+    lib = L.load()
+    n = F * Hh * D
+    din = torch.zeros(B * T * F, ldi, device=x.device, dtype=torch.float32)
+    part = torch.empty(lib.sb_head_ln_bwd_grid(B, T), 2 * n + 1, device=x.device, dtype=torch.float32)
+    L.check(lib.sb_head_ln_bwd(_p(x), _p(gamma), _p(dout), _p(din), _p(part), B, T, F, Hh, D, rows, t_off, ldo, ldi,
+                               _p(prelu_a), _stream()), "sb_head_ln_bwd")
+    red = torch.zeros(2 * n + 1, device=x.device, dtype=torch.float32)
+    reduce_partials(part, 2 * n + 1, red)
+    dg = red[:n].view(F, Hh, D).sum(1).reshape(F * D)
+    db = red[n:2 * n].view(F, Hh, D).sum(1).reshape(F * D)
+    return din, dg, db, red[2 * n:2 * n + 1]
+
+
+def attn_core(Q, K, V, out, BH, Hh, T, F, Cv, Lw, ldk, ldv, scale, lse=None):
     a = L.AttnArgs()
     a.BH, a.Hh, a.T, a.F, a.Cv, a.L = BH, Hh, T, F, Cv, Lw
     a.NRp = (Lw + 15 + 15) // 16 * 16
     a.ldk, a.ldv, a.scale = ldk, ldv, scale
-    a.Q, a.K, a.V, a.out = _p(Q), _p(K), _p(V), _p(out)
+    a.Q, a.K, a.V, a.out, a.lse = _p(Q), _p(K), _p(V), _p(out), _p(lse)
     L.check(L.load().sb_attn_core(C.byref(a), _stream()), "sb_attn_core")
+
+
+def attn_core_bwd(Q, K, V, dO, lse, BH, Hh, T, F, Cv, Lw, ldk, ldv, scale):
+    """dO [BH, T, ldv] head-major -> dQ [BH,T,ldk], dK [BH,T,ldk], dV [BH,T,ldv] (current-frame rows)"""
+    dev = Q.device
+    a = L.AttnBwdArgs()
+    a.BH, a.Hh, a.T, a.F, a.Cv, a.L = BH, Hh, T, F, Cv, Lw
+    a.NRp = (Lw + 15 + 15) // 16 * 16
+    a.ldk, a.ldv, a.scale = ldk, ldv, scale
+    delta = torch.empty(BH, T, device=dev, dtype=torch.float32)
+    dQ = torch.empty(BH, T, ldk, device=dev, dtype=torch.float32)
+    dK = torch.empty(BH, T, ldk, device=dev, dtype=torch.float32)
+    dV = torch.empty(BH, T, ldv, device=dev, dtype=torch.float32)
+    a.Q, a.K, a.V, a.dO, a.lse = _p(Q), _p(K), _p(V), _p(dO), _p(lse)
+    a.delta, a.dQ, a.dK, a.dV = _p(delta), _p(dQ), _p(dK), _p(dV)
+    L.check(L.load().sb_attn_core_bwd(C.byref(a), _stream()), "sb_attn_core_bwd")
+    return dQ, dK, dV
 
 
 def signal_stats(est, gt, mix_ref):

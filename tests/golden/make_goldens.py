@@ -291,7 +291,12 @@ def make_samples(torch, NetBig, out_dir, n_keep=36000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.dirname(os.path.abspath(__file__)))
+    ap.add_argument("--only", default="", help="comma-separated case names (default: regenerate everything)")
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    def case(torch, cls, name, *a, **k):
+        if not only or name in only:
+            make_case(torch, cls, name, *a, **k)
     assert os.path.isdir(REF), "reference tree not present: goldens can only be made in the build container"
     shim = tempfile.mkdtemp(prefix="sb_oracle_shims_")
     _write_shims(shim)
@@ -322,22 +327,23 @@ def main():
     np.savez_compressed(os.path.join(args.out, "stft_filters.npz"), filters=fe)
 
     # tiny cases (2 blocks, 7 frames) -- full per-stage + grads + streaming
-    make_case(torch, NetBig, "tiny_big", dict(big, B=2), B=2, n_frames=7, seed=11, needs_dis=True, out_dir=args.out)
-    make_case(torch, NetSmall, "tiny_small", dict(small, B=2), B=2, n_frames=7, seed=12, needs_dis=False, out_dir=args.out)
-    make_case(torch, NetSmall, "tiny_orange", dict(orange, B=2), B=2, n_frames=7, seed=13, needs_dis=False, out_dir=args.out)
+    case(torch, NetBig, "tiny_big", dict(big, B=2), B=2, n_frames=7, seed=11, needs_dis=True, out_dir=args.out)
+    case(torch, NetSmall, "tiny_small", dict(small, B=2), B=2, n_frames=7, seed=12, needs_dis=False, out_dir=args.out)
+    case(torch, NetSmall, "tiny_orange", dict(orange, B=2), B=2, n_frames=7, seed=13, needs_dis=False, out_dir=args.out)
     # dis_embd3 flavour of the conv-LSTM intra path (pads by 3 and crops)
-    make_case(torch, NetBig, "tiny_big_convlstm", dict(big, B=2, D=16, conv_lstm=True), B=2, n_frames=7, seed=14,
+    case(torch, NetBig, "tiny_big_convlstm", dict(big, B=2, D=16, conv_lstm=True), B=2, n_frames=7, seed=14,
               needs_dis=True, out_dir=args.out, with_stream=False)
     # full-band local self-attention ON (off in every shipped JSON; tfgridnet_causal.py:639-684,856-898):
     # window 100 (zero-filled, unmasked history dominates) and window 4 (windows inside the data)
-    make_case(torch, NetBig, "tiny_big_attn100", dict(big, B=2, use_attn=True), B=2, n_frames=7, seed=15,
-              needs_dis=True, out_dir=args.out, with_grads=False)
-    make_case(torch, NetSmall, "tiny_orange_attn4", dict(orange, B=2, use_attn=True, local_atten_len=4), B=2,
-              n_frames=7, seed=16, needs_dis=False, out_dir=args.out, with_grads=False)
+    case(torch, NetBig, "tiny_big_attn100", dict(big, B=2, use_attn=True), B=2, n_frames=7, seed=15,
+              needs_dis=True, out_dir=args.out)
+    case(torch, NetSmall, "tiny_orange_attn4", dict(orange, B=2, use_attn=True, local_atten_len=4), B=2,
+              n_frames=7, seed=16, needs_dis=False, out_dir=args.out)
     # real small config, 1 s clip (125 frames), forward only
-    make_case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
+    case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
               with_grads=False, with_stream=False, with_stages=False)
-    make_samples(torch, NetBig, args.out)
+    if not only or "samples" in only:
+        make_samples(torch, NetBig, args.out)
 
 
 if __name__ == "__main__":

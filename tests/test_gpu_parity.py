@@ -171,7 +171,7 @@ def test_streaming_matches_reference(torch_gpu, name, cls):
 
 
 @pytest.mark.parametrize("compact", [True, False], ids=["bptt-fp16-records", "bptt-fp32-records"])
-@pytest.mark.parametrize("name,cls", CASES)
+@pytest.mark.parametrize("name,cls", CASES + ATTN_CASES)
 def test_loss_and_gradients_match_reference(torch_gpu, name, cls, compact, monkeypatch):
     torch = torch_gpu
     from sound_bubble_amd.functional import SnrlpLossFn
@@ -227,11 +227,3 @@ def test_streaming_separator_equals_offline(torch_gpu, use_graph):
     sep.reset()
     Z2 = streaming_inference(sep, X)
     assert torch.equal(Z, Z2)
-
-
-def test_attention_training_raises_clearly(torch_gpu):
-    torch = torch_gpu
-    rec, params, m = _build(torch, "tiny_orange_attn4", "NetOptim")
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m(_inputs(torch, rec))

@@ -84,7 +84,7 @@ def test_streaming_matches_reference(name, torch_mod):
     assert rel_l2(out, rec["output"][..., : 3 * 192]) < 1e-4
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ATTN_CASES)
 def test_loss_and_grads_match_reference(name, torch_mod):
     torch = torch_mod
     from oracle.tfgridnet_oracle import snrlp_loss
