@@ -227,3 +227,39 @@ def test_streaming_separator_equals_offline(torch_gpu, use_graph):
     sep.reset()
     Z2 = streaming_inference(sep, X)
     assert torch.equal(Z, Z2)
+
+
+@pytest.mark.parametrize("Lw", [20, 100], ids=["window20", "window100"])
+def test_attention_multi_tile_matches_oracle(torch_gpu, Lw):
+    """The attention goldens have 7 frames (one 16-frame tile).  Here: 75 frames, so the query / key tiles, the
+    window crossing tile borders and (window 100) the zero-filled unmasked history are all exercised -- forward,
+    loss and every parameter gradient against the CPU oracle on the same seeded weights and input."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
+    params = dict(stft_chunk_size=192, stft_pad_size=96, num_ch=6, L=4, I=1, J=1, H=64, E=2, use_attn=True,
+                  lookahead=True, chunk_causal=True, use_first_ln=True, merge_method="early_cat", D=32, B=1,
+                  local_atten_len=Lw, conv_lstm=False, lstm_down=5)
+    torch.manual_seed(3)
+    ref = OracleNet("optim", **params).train()
+    m = sb.NetOptim(**params)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda().train()
+    x = 0.1 * torch.randn(2, 6, 192 * 75)
+    tgt = 0.05 * torch.randn(2, 1, 192 * 75)
+    tgt[1] = 0.0
+    want = ref({"mixture": x})["output"]
+    snrlp_loss(want, tgt, 100.0).mean().backward()
+    got = m({"mixture": x.cuda()})["output"]
+    assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL_FWD
+    loss, _ = SnrlpLossFn.apply(got, tgt.cuda(), 100.0)
+    loss.backward()
+    worst = ("", 0.0)
+    refg = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        g = refg[k].grad.numpy()
+        e = rel_l2(p.grad.cpu().numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max())
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < TOL_GRAD, worst
