@@ -33,6 +33,9 @@ WORKLOADS = {
               2e-3),
     "big": ("NetDisEmbd3", dict(COMMON, D=32, B=6, conv_lstm=False, local_atten_len=100, dis_type="conv3"), 16,
             100.0, None, 1.2e-3),   # "grad_clip" sits at the JSON top level there -> PLModule does not clip (F10a)
+    # extra (not a BASELINE config): the big model with the full-band attention of row a10 switched on
+    "big-attn": ("NetDisEmbd3", dict(COMMON, D=32, B=6, conv_lstm=False, local_atten_len=100, dis_type="conv3",
+                                     use_attn=True), 16, 100.0, None, 1.2e-3),
 }
 N_SAMPLES = 120000
 MFMA_F32_PEAK = 157.3e12        # dense fp32-input MFMA (= fp32 vector) peak, MI355X_MICROARCH.md

@@ -160,130 +160,103 @@ __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
 // gamma/beta/alpha gradients accumulate in registers; partials[blockIdx.x] = [dgamma_i (n)][dbeta_i (n)][dalpha], with
 // i the flat (f, h, d) element index (the host folds the heads: gamma/beta are shared by them).
 //   dout: head-major rows as written by the forward (row (b*Hh+h, t_off+t) of [B*Hh, rows, ldo]);  din [B,T,F,ldi]
-__global__ __launch_bounds__(256) void head_ln_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gam,
+// Thread mapping: thread = (frequency lane tid / HD, column hd = tid % HD), so a thread's head is fixed and the
+// per-head statistics are scalars (Hh masked wave reductions + one LDS exchange per statistic pair).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void head_ln_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gam,
                                                           const float* __restrict__ dout, float* __restrict__ din,
                                                           float* __restrict__ partials, int B, int T, int F, int Hh,
                                                           int D, int rows, int t_off, int ldo, int ldi,
                                                           const float* __restrict__ prelu_a, int rpb) {
-  constexpr int MAXV = 20;
-  const int n = F * Hh * D, HD = Hh * D, FD = F * D;
+  constexpr int MAXV = 20;                       // ceil(F / (256 / (Hh*D))) <= MAXV
+  const int HD = Hh * D, n = F * HD;
+  const float invFD = 1.0f / (F * D);
   const float pa = prelu_a ? prelu_a[0] : 1.0f;
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-  __shared__ float red[4][8][2];
-  __shared__ float stat[8][2];
+  const int fpi = 256 / HD;
+  const bool active = (int)threadIdx.x < fpi * HD;
+  const int fl = threadIdx.x / HD, hd = threadIdx.x % HD, h = hd / D, d = hd % D;
+  __shared__ float red[2][4][8][2];
+  int phase = 0;
+  auto head_sums = [&](float& a0, float& a1) {    // per-head block sums of (a0, a1); every thread gets its head's
+    for (int hh = 0; hh < Hh; ++hh) {
+      const float s0 = wave_sum(h == hh ? a0 : 0.f), s1 = wave_sum(h == hh ? a1 : 0.f);
+      if (ln == 0) { red[phase][wv][hh][0] = s0; red[phase][wv][hh][1] = s1; }
+    }
+    __syncthreads();
+    a0 = red[phase][0][h][0] + red[phase][1][h][0] + red[phase][2][h][0] + red[phase][3][h][0];
+    a1 = red[phase][0][h][1] + red[phase][1][h][1] + red[phase][2][h][1] + red[phase][3][h][1];
+    phase ^= 1;
+  };
   float dgam[MAXV], dbet[MAXV], dalpha = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) dgam[k] = dbet[k] = 0.f;
 
-  auto head_sums = [&](const float (&a0)[8], const float (&a1)[8], float scale0, float scale1, bool rs) {
-    // block-wide per-head sums of two quantities -> stat[h][0..1] (optionally transformed)
-    for (int h = 0; h < Hh; ++h) {
-      const float s0 = wave_sum(a0[h]), s1 = wave_sum(a1[h]);
-      if (ln == 0) { red[wv][h][0] = s0; red[wv][h][1] = s1; }
-    }
-    __syncthreads();
-    if (threadIdx.x < Hh) {
-      const int h = threadIdx.x;
-      const float s0 = red[0][h][0] + red[1][h][0] + red[2][h][0] + red[3][h][0];
-      const float s1 = red[0][h][1] + red[1][h][1] + red[2][h][1] + red[3][h][1];
-      stat[h][0] = s0 * scale0;
-      stat[h][1] = rs ? 1.0f / sqrtf(s1 * scale1 + 1e-5f) : s1 * scale1;
-    }
-    __syncthreads();
-  };
-
   for (int bt = blockIdx.x * rpb; bt < min((blockIdx.x + 1) * rpb, B * T); ++bt) {
     const int b = bt / T, t = bt % T;
+    // uniform base pointers + 32-bit per-thread offsets (keeps the 40 in-flight loads off 64-bit address registers)
     const float* x = in + (size_t)bt * F * ldi;
-    float pr[MAXV], xh[MAXV], gy[MAXV];
-    float p0[8], p1[8];
-#pragma unroll
-    for (int h = 0; h < 8; ++h) p0[h] = p1[h] = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      pr[k] = 0.f; xh[k] = 0.f;
-      if (i < n) {
-        pr[k] = x[(size_t)(i / HD) * ldi + i % HD];
-        xh[k] = pr[k] > 0.f ? pr[k] : pa * pr[k];
-        const int h = (i % HD) / D;
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) p0[hh] += hh == h ? xh[k] : 0.f;
-      }
-    }
-    head_sums(p0, p1, 1.0f / FD, 0.f, false);
-    float mean[8];
-#pragma unroll
-    for (int h = 0; h < 8; ++h) { mean[h] = h < Hh ? stat[h][0] : 0.f; p0[h] = p1[h] = 0.f; }
-    __syncthreads();
+    const float* dy = dout + ((size_t)b * Hh * rows + t_off + t) * ldo;
+    float* dx = din + (size_t)bt * F * ldi;
+    const int xo = fl * ldi + hd, xs = fpi * ldi;
+    const int yo = h * rows * ldo + fl * D + d, ys = fpi * D;
+    float xh[MAXV], gy[MAXV];
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      if (i < n) {
-        const int h = (i % HD) / D;
-        float mu = 0.f;
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) mu = hh == h ? mean[hh] : mu;
-        xh[k] -= mu;
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) p1[hh] += hh == h ? xh[k] * xh[k] : 0.f;
-      }
+      const int f = k * fpi + fl;
+      const bool ok = active & (f < F);
+      const float pr = ok ? x[xo + k * xs] : 0.f;
+      gy[k] = ok ? dy[yo + k * ys] : 0.f;                         // raw dout for now
+      xh[k] = pr > 0.f ? pr : pa * pr;
+      s0 += xh[k];
     }
-    head_sums(p0, p1, 0.f, 1.0f / FD, true);
-    float rstd[8];
-#pragma unroll
-    for (int h = 0; h < 8; ++h) { rstd[h] = h < Hh ? stat[h][1] : 0.f; p0[h] = p1[h] = 0.f; }
-    __syncthreads();
+    head_sums(s0, s1);
+    const float mean = s0 * invFD;
+    s0 = 0.f; s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      gy[k] = 0.f;
-      if (i < n) {
-        const int f = i / HD, hd = i % HD, h = hd / D, d = hd % D, e = f * D + d;
-        float rs = 0.f;
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) rs = hh == h ? rstd[hh] : rs;
-        xh[k] *= rs;                                             // normalised value
-        const float dy = dout[((size_t)(b * Hh + h) * rows + t_off + t) * ldo + e];
-        dgam[k] += dy * xh[k];
-        dbet[k] += dy;
-        gy[k] = dy * gam[e];
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) { p0[hh] += hh == h ? gy[k] : 0.f; p1[hh] += hh == h ? gy[k] * xh[k] : 0.f; }
-      }
+      const bool ok = active & (k * fpi + fl < F);
+      xh[k] = ok ? xh[k] - mean : 0.f;
+      s1 += xh[k] * xh[k];
     }
-    head_sums(p0, p1, 1.0f / FD, 1.0f / FD, false);
+    head_sums(s0, s1);
+    const float rstd = 1.0f / sqrtf(s1 * invFD + 1e-5f);
+    s0 = 0.f; s1 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      if (i < n) {
-        const int h = (i % HD) / D;
-        float rs = 0.f, m1 = 0.f, m2 = 0.f;
+      const int f = min(k * fpi + fl, F - 1);
+      xh[k] *= rstd;                                              // normalised value (0 for inactive slots)
+      dgam[k] += gy[k] * xh[k];
+      dbet[k] += gy[k];
+      gy[k] *= gam[f * D + d];
+      s0 += gy[k];
+      s1 += gy[k] * xh[k];
+    }
+    head_sums(s0, s1);
+    const float m1 = s0 * invFD, m2 = s1 * invFD;
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-          rs = hh == h ? rstd[hh] : rs;
-          m1 = hh == h ? stat[hh][0] : m1;
-          m2 = hh == h ? stat[hh][1] : m2;
-        }
-        const float dv = rs * (gy[k] - m1 - xh[k] * m2);
-        const bool pos = pr[k] > 0.f;
-        dalpha += pos ? 0.f : dv * pr[k];
-        din[(size_t)bt * F * ldi + (size_t)(i / HD) * ldi + i % HD] = pos ? dv : pa * dv;
+    for (int k = 0; k < MAXV; ++k) {
+      const int f = k * fpi + fl;
+      if (active & (f < F)) {
+        const float dv = rstd * (gy[k] - m1 - xh[k] * m2);
+        const float pr = x[xo + k * xs];                            // pre-activation again (cache hit)
+        const bool pos = pr > 0.f;
+        dalpha += pos ? 0.f : dv * pr;
+        dx[xo + k * xs] = pos ? dv : pa * dv;
       }
     }
-    __syncthreads();
   }
   float* prow = partials + (size_t)blockIdx.x * (2 * n + 1);
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    if (i < n) { prow[i] = dgam[k]; prow[n + i] = dbet[k]; }
+    const int f = k * fpi + fl;
+    if (active & (f < F)) { prow[f * HD + hd] = dgam[k]; prow[n + f * HD + hd] = dbet[k]; }
   }
   const float da = wave_sum(dalpha);
   __syncthreads();
-  if (ln == 0) red[wv][0][0] = da;
+  if (ln == 0) red[0][wv][0][0] = da;
   __syncthreads();
-  if (threadIdx.x == 0) prow[2 * n] = red[0][0][0] + red[1][0][0] + red[2][0][0] + red[3][0][0];
+  if (threadIdx.x == 0) prow[2 * n] = red[0][0][0][0] + red[0][1][0][0] + red[0][2][0][0] + red[0][3][0][0];
 }
 
 // D[i][j] = sum_k X[xrow(lane&15)][k] * Y[yrow(lane&15)][k] over ld features (both fetched as 16-byte row pieces);
@@ -419,14 +392,16 @@ extern "C" int sb_head_ln(const float* in, const float* gamma, const float* beta
   return 0;
 }
 
-extern "C" int sb_head_ln_bwd_grid(int B, int T) { return (B * T + 15) / 16; }
+static constexpr int kHeadLnBwdRows = 8;          // (b, t) rows walked by one workgroup
+extern "C" int sb_head_ln_bwd_grid(int B, int T) { return (B * T + kHeadLnBwdRows - 1) / kHeadLnBwdRows; }
 
 extern "C" int sb_head_ln_bwd(const float* in, const float* gamma, const float* dout, float* din, float* partials, int B,
                               int T, int F, int Hh, int D, int rows, int t_off, int ldo, int ldi, const float* prelu_a,
                               void* stream) {
-  if (Hh > 8 || F * Hh * D > 256 * 20 || ldi < Hh * D) return -1002;
+  if (Hh > 8 || Hh * D > 256 || ldi < Hh * D) return -1002;
+  if ((F + 256 / (Hh * D) - 1) / (256 / (Hh * D)) > 20) return -1002;
   hipLaunchKernelGGL(head_ln_bwd_kernel, dim3(sb_head_ln_bwd_grid(B, T)), dim3(256), 0, (hipStream_t)stream, in, gamma,
-                     dout, din, partials, B, T, F, Hh, D, rows, t_off, ldo, ldi, prelu_a, 16);
+                     dout, din, partials, B, T, F, Hh, D, rows, t_off, ldo, ldi, prelu_a, kHeadLnBwdRows);
   SB_CHECK_LAUNCH();
   return 0;
 }
