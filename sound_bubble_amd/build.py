@@ -28,6 +28,7 @@ def build(force=False, verbose=True):
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
+            cmd[2:2] = os.environ.get("SB_EXTRA_HIPCC_FLAGS", "").split()     # e.g. -DSB_PHASE_TIMING (dev tool)
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

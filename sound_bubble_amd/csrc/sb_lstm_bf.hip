@@ -14,8 +14,18 @@
 // C/D as in sb_common.h.  K is walked in chunks of 32: chunk 0 = the (LayerNormed) input u (zero-padded to 32),
 // chunks 1,2 = the hidden state.  The step pipeline (A: hidden part, B: next input part || cell update || next
 // LayerNorm, C: stores + prefetch + barrier) is the one of sb_lstm.hip.
+#include <cstdlib>
 #include "sb_common.h"
 #include "../../include/sound_bubble_hip.h"
+
+// Phase timing (developer tool): build with -DSB_PHASE_TIMING and pass a scratch buffer (fwd: save_u with
+// save_gates == NULL; bwd: dhs with dy == NULL) -- lane 0 of every wave of the first 4 tiles writes the average
+// s_memtime cycles per step of each phase.  scripts/phase_timing.py prints them.
+#ifdef SB_PHASE_TIMING
+#define SB_TICK(name) const unsigned long long name = __builtin_readcyclecounter()
+#else
+#define SB_TICK(name) do {} while (0)
+#endif
 
 namespace {
 
@@ -47,17 +57,20 @@ constexpr int HP16 = 64 + 8;  // padded bf16 row of the hidden-term tiles (144 B
 template <int C>
 struct XVec { float v[C / 16]; };
 
-template <int C, int SAVE, bool FULL>
+// TILES = 1 or 2 tiles of 16 sequences per workgroup.  With two tiles the waves carry two independent recurrence
+// chains that share the weight registers; the instruction stream of one tile's cell update fills the issue gaps
+// of the other tile's MFMAs (a single wave issues about one instruction per 4 cycles, so a lone chain is issue-
+// and latency-bound).  Used when the grid has more tiles than the chip has CUs.
+template <int C, int SAVE, bool FULL, int TILES>
 __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   constexpr int VPT = C / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
-  const int n0 = blockIdx.x * 16;
   const int S = a.nsteps;
   const bool rev = dir == 1;
 
-  __shared__ __attribute__((aligned(16))) __bf16 U16[2][3][16][UP];      // [buf][term][seq][channel]
-  __shared__ __attribute__((aligned(16))) __bf16 H16[2][3][16][HP16];    // [buf][term][seq][unit]
+  __shared__ __attribute__((aligned(16))) __bf16 U16[TILES][2][3][16][UP];      // [tile][buf][term][seq][channel]
+  __shared__ __attribute__((aligned(16))) __bf16 H16[TILES][2][3][16][HP16];    // [tile][buf][term][seq][unit]
   __shared__ __attribute__((aligned(16))) float Bias[4][H];
 
   // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
@@ -80,27 +93,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   }
   if (tid < 4 * H) Bias[tid >> 6][tid & 63] = a.b_ih[dir][tid] + a.b_hh[dir][tid];
   // zero the padded channels of the input tiles once (C = 16: channels 16..31 stay zero)
-  for (int i = tid; i < 2 * 3 * 16 * UP; i += 256) (&U16[0][0][0][0])[i] = (__bf16)0.f;
+  for (int i = tid; i < TILES * 2 * 3 * 16 * UP; i += 256) (&U16[0][0][0][0][0])[i] = (__bf16)0.f;
   __syncthreads();
 
   // ---- loader role ----
   const int ls = tid >> 4, cpart = tid & 15;
-  const int nl = n0 + ls;
-  const bool lvalid = FULL || nl < a.nseq;
-  const int64_t lbase = lvalid ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
+  bool lvalid[TILES];
+  int64_t lbase[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int nl = (blockIdx.x * TILES + t) * 16 + ls;
+    lvalid[t] = FULL || nl < a.nseq;
+    lbase[t] = lvalid[t] ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
+  }
   float gam[VPT], bet[VPT];
 #pragma unroll
   for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; bet[v] = a.ln_b[cpart * VPT + v]; }
 
-  auto load_x = [&](int s) {
+  auto load_x = [&](int t, int s) {
     XVec<C> r;
     const int st = rev ? S - 1 - s : s;
-    const float* p = a.x + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+    const float* p = a.x + (lbase[t] + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) r.v[v] = lvalid ? p[v] : 0.f;
+    for (int v = 0; v < VPT; ++v) r.v[v] = lvalid[t] ? p[v] : 0.f;
     return r;
   };
-  auto ln_store = [&](const XVec<C>& xv, int buf, int s) {
+  auto ln_store = [&](int t, const XVec<C>& xv, int buf, int s) {
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) sum += xv.v[v];
@@ -108,134 +126,196 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     float sq = 0.f;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq += d * d; }
-    const float rstd = 1.0f / sqrtf(row16_sum(sq) * (1.0f / C) + 1e-5f);
+    const float rstd = __builtin_amdgcn_rsqf(row16_sum(sq) * (1.0f / C) + 1e-5f);   // v_rsq_f32, 1 ulp
     float u[VPT];
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       u[v] = (xv.v[v] - mean) * rstd * gam[v] + bet[v];
       __bf16 h, m, l;
       split1(u[v], h, m, l);
-      U16[buf][0][ls][cpart * VPT + v] = h;
-      U16[buf][1][ls][cpart * VPT + v] = m;
-      U16[buf][2][ls][cpart * VPT + v] = l;
+      U16[t][buf][0][ls][cpart * VPT + v] = h;
+      U16[t][buf][1][ls][cpart * VPT + v] = m;
+      U16[t][buf][2][ls][cpart * VPT + v] = l;
     }
-    if (SAVE && lvalid) {
+    if (SAVE && lvalid[t]) {
       const int st = rev ? S - 1 - s : s;
-      float* p = a.save_u + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+      float* p = a.save_u + (lbase[t] + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll
       for (int v = 0; v < VPT; ++v) p[v] = u[v];
     }
   };
 
   // ---- compute role ----
-  const int nc = n0 + j;
-  const bool cvalid = FULL || nc < a.nseq;
-  const int64_t cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
   const int uoff = 16 * w + 4 * q;
-  f32x4 c = zero4(), h = zero4();
-  if (dir == 0 && cvalid) {
-    if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
-    if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
+  bool cvalid[TILES];
+  int64_t cbase[TILES];
+  f32x4 c[TILES], h[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int nc = (blockIdx.x * TILES + t) * 16 + j;
+    cvalid[t] = FULL || nc < a.nseq;
+    cbase[t] = cvalid[t] ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    c[t] = zero4();
+    h[t] = zero4();
+    if (dir == 0 && cvalid[t]) {
+      if (a.c0) c[t] = ld4(a.c0 + (size_t)nc * H + uoff);
+      if (a.h0) h[t] = ld4(a.h0 + (size_t)nc * H + uoff);
+    }
   }
-  auto store_h = [&](int buf, const f32x4& hv) {       // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
+  auto store_h = [&](int t, int buf, const f32x4& hv) {   // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
     bf16x4 th, tm, tl;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { __bf16 x0, x1, x2; split1(hv[r], x0, x1, x2); th[r] = x0; tm[r] = x1; tl[r] = x2; }
-    *reinterpret_cast<bf16x4*>(&H16[buf][0][j][uoff]) = th;
-    *reinterpret_cast<bf16x4*>(&H16[buf][1][j][uoff]) = tm;
-    *reinterpret_cast<bf16x4*>(&H16[buf][2][j][uoff]) = tl;
+    *reinterpret_cast<bf16x4*>(&H16[t][buf][0][j][uoff]) = th;
+    *reinterpret_cast<bf16x4*>(&H16[t][buf][1][j][uoff]) = tm;
+    *reinterpret_cast<bf16x4*>(&H16[t][buf][2][j][uoff]) = tl;
   };
-  // acc[g] += W[g][chunk] * B (6-term split product); B terms read from LDS rows of this lane's sequence
+  // acc[g] += W[g][chunk] * B (6-term split product).  The four gate accumulators are walked round-robin and the
+  // groups are fenced against MFMA reordering (mask: everything but MFMA may cross): hipcc otherwise chains all 12
+  // products of a gate back to back on one accumulator, and any VALU instruction that lands between two MFMAs on
+  // the SAME accumulator costs ~40 cycles.
+  constexpr int kNoMfmaCross = 0x7F6;
   auto mma6 = [&](f32x4 (&acc)[4], int chunk, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].l, bh, acc[g]);
+    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bl, acc[g]);
+    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].m, bm, acc[g]);
+    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].m, bh, acc[g]);
+    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bm, acc[g]);
+    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bh, acc[g]);
+    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
   };
-  auto x_part = [&](f32x4 (&acc)[4], int buf) {
+  auto x_part = [&](int t, f32x4 (&acc)[4], int buf) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = ld4(&Bias[g][uoff]);
-    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&U16[buf][0][j][8 * q]);
-    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&U16[buf][1][j][8 * q]);
-    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&U16[buf][2][j][8 * q]);
+    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&U16[t][buf][0][j][8 * q]);
+    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&U16[t][buf][1][j][8 * q]);
+    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&U16[t][buf][2][j][8 * q]);
     mma6(acc, 0, bh, bm, bl);
   };
-
-  store_h(0, h);
-  {
-    XVec<C> x0 = load_x(0);
-    XVec<C> x1 = load_x(min(1, S - 1));
-    ln_store(x0, 0, 0);
-    ln_store(x1, 1, min(1, S - 1));
-  }
-  XVec<C> xnext = load_x(min(2, S - 1));
-  __syncthreads();
-  f32x4 accx[4];
-  x_part(accx, 0);
-
-  const int ndir = a.ndir;
-  for (int s = 0; s < S; ++s) {
-    const int cur = s & 1;
-    // ---- A: hidden part ----
-    f32x4 acc[4] = {accx[0], accx[1], accx[2], accx[3]};
+  auto h_part = [&](int t, f32x4 (&acc)[4], int buf) {
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&H16[cur][0][j][32 * ck + 8 * q]);
-      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&H16[cur][1][j][32 * ck + 8 * q]);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&H16[cur][2][j][32 * ck + 8 * q]);
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&H16[t][buf][0][j][32 * ck + 8 * q]);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&H16[t][buf][1][j][32 * ck + 8 * q]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&H16[t][buf][2][j][32 * ck + 8 * q]);
       mma6(acc, 1 + ck, bh, bm, bl);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- B: input part of step s+1 (matrix pipe) || cell update of step s + LayerNorm of row s+2 (VALU) ----
-    x_part(accx, cur ^ 1);
-    f32x4 gi, gf, gg, go, cprev = c;
+  };
+
+  XVec<C> xnext[TILES];
+  f32x4 accx[TILES][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      gi[r] = sigmoidf_fast(acc[0][r]);
-      gf[r] = sigmoidf_fast(acc[1][r]);
-      gg[r] = tanhf_fast(acc[2][r]);
-      go[r] = sigmoidf_fast(acc[3][r]);
-      c[r] = gf[r] * c[r] + gi[r] * gg[r];
-      h[r] = go[r] * tanhf_fast(c[r]);
+  for (int t = 0; t < TILES; ++t) {
+    store_h(t, 0, h[t]);
+    XVec<C> x0 = load_x(t, 0);
+    XVec<C> x1 = load_x(t, min(1, S - 1));
+    ln_store(t, x0, 0, 0);
+    ln_store(t, x1, 1, min(1, S - 1));
+    xnext[t] = load_x(t, min(2, S - 1));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) x_part(t, accx[t], 0);
+
+  const int ndir = a.ndir;
+#ifdef SB_PHASE_TIMING
+  unsigned long long tph[5] = {0, 0, 0, 0, 0};
+#endif
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    SB_TICK(c0);
+    // ---- A: hidden part on the matrix pipe || LayerNorm of row s+2 in the issue gaps (it does not depend on
+    //         this step; its U16[cur] buffer was last read in phase B of step s-1) ----
+    f32x4 acc[TILES][4];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[t][g] = accx[t][g];
+      ln_store(t, xnext[t], cur, min(s + 2, S - 1));
+      h_part(t, acc[t], cur);
     }
-    ln_store(xnext, cur, min(s + 2, S - 1));
-    store_h(cur ^ 1, h);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- C ----
-    if (cvalid) {
-      const int st = rev ? S - 1 - s : s;
-      const int64_t pos = cbase + (int64_t)st * a.p_step;
-      st4(a.hs + (pos * ndir + dir) * H + uoff, h);
-      if (SAVE == 1) {
-        float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
-        st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
-      } else if (SAVE == 2) {
-        h16x8 lo, hi;
+    if (TILES == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          lo[r] = (_Float16)gi[r]; lo[4 + r] = (_Float16)gf[r];
-          hi[r] = (_Float16)gg[r]; hi[4 + r] = (_Float16)go[r];
-        }
-        _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
-        *reinterpret_cast<h16x8*>(rec) = lo;
-        *reinterpret_cast<h16x8*>(rec + 8) = hi;
-        st4(a.save_c + (pos * ndir + dir) * H + uoff, cprev);
+    for (int t = 0; t < TILES; ++t) xnext[t] = load_x(t, min(s + 3, S - 1));      // a whole step of latency cover
+    SB_TICK(c1);
+    // ---- B: input part of step s+1 (matrix pipe) || cell update of step s (VALU) ----
+    f32x4 gi[TILES], gf[TILES], gg[TILES], go[TILES], cprev[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      x_part(t, accx[t], cur ^ 1);
+      cprev[t] = c[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[t][r] = sigmoidf_fast(acc[t][0][r]);
+        gf[t][r] = sigmoidf_fast(acc[t][1][r]);
+        gg[t][r] = tanhf_fast(acc[t][2][r]);
+        go[t][r] = sigmoidf_fast(acc[t][3][r]);
+        c[t][r] = gf[t][r] * c[t][r] + gi[t][r] * gg[t][r];
+        h[t][r] = go[t][r] * tanhf_fast(c[t][r]);
       }
     }
-    xnext = load_x(min(s + 3, S - 1));
+    if (TILES == 1) __builtin_amdgcn_sched_barrier(0);
+    SB_TICK(c2);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) store_h(t, cur ^ 1, h[t]);
+    if (TILES == 1) __builtin_amdgcn_sched_barrier(0);
+    SB_TICK(c3);
+    // ---- C ----
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      if (cvalid[t]) {
+        const int st = rev ? S - 1 - s : s;
+        const int64_t pos = cbase[t] + (int64_t)st * a.p_step;
+        st4(a.hs + (pos * ndir + dir) * H + uoff, h[t]);
+        if (SAVE == 1) {
+          float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
+          st4(rec, gi[t]); st4(rec + H, gf[t]); st4(rec + 2 * H, gg[t]); st4(rec + 3 * H, go[t]); st4(rec + 4 * H, cprev[t]);
+        } else if (SAVE == 2) {
+          h16x8 lo, hi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            lo[r] = (_Float16)gi[t][r]; lo[4 + r] = (_Float16)gf[t][r];
+            hi[r] = (_Float16)gg[t][r]; hi[4 + r] = (_Float16)go[t][r];
+          }
+          _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
+          *reinterpret_cast<h16x8*>(rec) = lo;
+          *reinterpret_cast<h16x8*>(rec + 8) = hi;
+          st4(a.save_c + (pos * ndir + dir) * H + uoff, cprev[t]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SB_TICK(c4);
     __syncthreads();
+#ifdef SB_PHASE_TIMING
+    SB_TICK(c5);
+    tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
+#endif
   }
-  if (dir == 0 && cvalid) {
-    if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h);
-    if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c);
+#ifdef SB_PHASE_TIMING
+  if (SAVE == 0 && a.save_u && lane == 0 && blockIdx.x < 4) {
+    float* d = a.save_u + (blockIdx.x * 4 + w) * 8;
+    for (int i = 0; i < 5; ++i) d[i] = (float)tph[i] / S;
+  }
+#endif
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int nc = (blockIdx.x * TILES + t) * 16 + j;
+    if (dir == 0 && cvalid[t]) {
+      if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h[t]);
+      if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c[t]);
+    }
   }
 }
 
@@ -412,16 +492,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 
 // launch helpers used by sb_lstm.hip's C entry points (same argument structs)
 int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
-  dim3 grid((a.nseq + 15) / 16, a.ndir);
-  const bool full = a.nseq % 16 == 0;
+  const int ntiles = (a.nseq + 15) / 16;
+  // SB_LSTM_TILES=2: two tiles per workgroup (experimental; measured slower than two co-resident workgroups
+  // except for the training-mode inter-frame pass of the small config, +8 %)
+  static const int forced = [] { const char* e = getenv("SB_LSTM_TILES"); return e ? atoi(e) : 0; }();
+  const int tiles = forced == 2 ? 2 : 1;
+  const bool full = a.nseq % (16 * tiles) == 0;
   const int save = a.save_gates == nullptr ? 0 : (a.save_c ? 2 : 1);
-#define SB_L(CC, SV, FL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL>), grid, dim3(256), 0, st, a)
+  dim3 grid((ntiles + tiles - 1) / tiles, a.ndir);
+#define SB_L(CC, SV, FL, TL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, TL>), grid, dim3(256), 0, st, a)
+#define SB_LT(CC, SV, FL) do { if (tiles == 2) SB_L(CC, SV, FL, 2); else SB_L(CC, SV, FL, 1); } while (0)
 #define SB_LC(CC) do { \
-    if (save == 0) { if (full) SB_L(CC, 0, true); else SB_L(CC, 0, false); } \
-    else if (save == 1) { if (full) SB_L(CC, 1, true); else SB_L(CC, 1, false); } \
-    else { if (full) SB_L(CC, 2, true); else SB_L(CC, 2, false); } } while (0)
+    if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
+    else if (save == 1) { if (full) SB_LT(CC, 1, true); else SB_LT(CC, 1, false); } \
+    else { if (full) SB_LT(CC, 2, true); else SB_LT(CC, 2, false); } } while (0)
   if (a.C == 32) SB_LC(32); else SB_LC(16);
 #undef SB_LC
+#undef SB_LT
 #undef SB_L
   return 0;
 }

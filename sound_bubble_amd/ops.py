@@ -57,6 +57,9 @@ class Geom:
         return Geom(B * F, T, F, T * F, 1, F)
 
 
+PHASE_TIMING_BUF = None   # developer hook: scratch for a -DSB_PHASE_TIMING build (scripts/phase_timing.py)
+
+
 def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
     -> hs [P, ndir*64], (hN, cN) or None, save_gates or None, save_u or None"""
@@ -82,7 +85,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         assert wi.shape == (4 * H, Cc) and wh.shape == (4 * H, H)
         a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
     a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
-    a.hs, a.save_u, a.save_c = _p(hs), _p(u), _p(cprev)
+    a.hs, a.save_u, a.save_c = _p(hs), _p(u if u is not None else PHASE_TIMING_BUF), _p(cprev)
     a.mma = LSTM_MMA
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
     prof = PROFILE_LSTM
