@@ -35,8 +35,8 @@ def runb(name, C, geom, ndir):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.lstm_bwd_rec([d[1] for d in dirs], gates, dhs, geom); e1.record(); torch.cuda.synchronize()
-    d = dhs.view(-1)[:128].view(16, 8)[:, :6].cpu()
-    print("BWD", name, "us/step %.3f" % (e0.elapsed_time(e1) * 1e3 / geom.nsteps), "A(wait raw+prefetch) B(unpack+cell) C(split) D(dg store+48 mfma issue) E(P store) F(barrier+reduce):",
+    d = dhs.view(-1)[:128].view(16, 8)[:, :5].cpu()
+    print("BWD", name, "us/step %.3f" % (e0.elapsed_time(e1) * 1e3 / geom.nsteps), "A(wait record + prefetch) B(cell backward + split) C(dgates store + 48 mfma issue) D(partials -> LDS) E(barrier + reduce):",
           d[:2].numpy().round(0).tolist(), "sum", float(d[0].sum()), flush=True)
 runb("big inter", 32, ops.Geom.inter(16, T, F), 1)
 runb("big intra", 32, ops.Geom.intra(16 * T, F), 2)

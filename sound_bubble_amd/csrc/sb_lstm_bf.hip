@@ -400,8 +400,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 
   f32x4 dc = zero4(), dhrec = zero4();
   Raw nxt = load_raw(S - 1);
+#ifdef SB_PHASE_TIMING
+  unsigned long long tph[5] = {0, 0, 0, 0, 0};
+#endif
   for (int s = S - 1; s >= 0; --s) {
     const int cur = s & 1;
+    SB_TICK(c0);
     Raw raw = nxt;
     // consume the prefetched record (forces its wait HERE), then immediately issue the prefetch of the
     // previous step so that it has a whole step of latency cover
@@ -411,6 +415,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     __builtin_amdgcn_sched_barrier(0);
     nxt = load_raw(max(s - 1, 0));
     __builtin_amdgcn_sched_barrier(0);
+    SB_TICK(c1);
     f32x4 gi, gf, gg, go;
     if constexpr (REC16) {
       const h16x8 lo = __builtin_bit_cast(h16x8, raw.r0), hi = __builtin_bit_cast(h16x8, raw.r1);
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       Bop[c] = split8(t);
     }
     __builtin_amdgcn_sched_barrier(0);
+    SB_TICK(c2);
     if (valid) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = base + (int64_t)st * a.p_step;
@@ -480,12 +486,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].h, Bop[c].h, part[ot]);
     }
+    SB_TICK(c3);
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) st4(&P[cur][w][ot][lane][0], part[ot]);
+    SB_TICK(c4);
     __syncthreads();
     dhrec = ld4(&P[cur][0][w][lane][0]) + ld4(&P[cur][1][w][lane][0]) + ld4(&P[cur][2][w][lane][0]) +
             ld4(&P[cur][3][w][lane][0]);
+#ifdef SB_PHASE_TIMING
+    asm volatile("" : "+v"(dhrec));
+    SB_TICK(c5);
+    tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
+#endif
   }
+#ifdef SB_PHASE_TIMING
+  if (a.dhs && !a.dy && lane == 0 && blockIdx.x < 4) {
+    float* d = const_cast<float*>(a.dhs) + (blockIdx.x * 4 + w) * 8;
+    for (int i = 0; i < 5; ++i) d[i] = (float)tph[i] / S;
+  }
+#endif
 }
 
 }  // namespace
