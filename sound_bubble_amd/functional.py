@@ -15,6 +15,31 @@ from . import ops
 from .ops import Geom, H, dense
 
 GRAD_MODE = True     # set by the Net wrapper from torch.is_grad_enabled() (Function.forward runs with grad off)
+DIRECT_GRADS = True  # accumulate parameter gradients straight into pre-allocated .grad buffers (see _gt)
+
+
+class _GradTargets:
+    """Where the HIP reductions put d(loss)/d(param).  All weight-gradient kernels ACCUMULATE (atomicAdd) into their
+    output, so when a parameter already owns a .grad buffer (train.FlatBucket points every .grad into one flat,
+    once-per-step zeroed buffer) they add into it directly and autograd is handed None: no zero-fill and no
+    AccumulateGrad add per parameter (~180 tiny launches per step).  Without a .grad buffer a fresh zero tensor is
+    used and returned to autograd as usual."""
+
+    def __init__(self):
+        self.ret = {}
+
+    def __call__(self, name, p):
+        g = p.grad
+        if (DIRECT_GRADS and g is not None and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous()
+                and g.device == p.device):
+            self.ret[name] = None
+            return g
+        z = torch.zeros_like(p, dtype=torch.float32)
+        self.ret[name] = z
+        return z
+
+    def __getitem__(self, name):
+        return self.ret[name]
 ZC = 32          # padded channel count of the front-end feature tensor
 NSPEC = 304      # 290 STFT bins (re/im) padded to a multiple of 16
 
@@ -37,14 +62,16 @@ class IntraPlainFn(torch.autograd.Function):
         _, s_out = dense(P, Cc)
         ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, 2 * H, Cc, epi=L.EPI_RES, res=x)
         if train:
-            ctx.save_for_backward(x, ln_g, wif, whf, wir, whr, lin_w, hs, u, *[t for t in gates if t is not None])
+            ctx.save_for_backward(x, ln_g, wif, whf, wir, whr, lin_w, hs, u, ln_b, bif, bhf, bir, bhr, lin_b,
+                                  *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, ln_g, wif, whf, wir, whr, lin_w, hs, u, *g_ = ctx.saved_tensors
+        x, ln_g, wif, whf, wir, whr, lin_w, hs, u, ln_b, bif, bhf, bir, bhr, lin_b, *g_ = ctx.saved_tensors
         gates = (g_[0], g_[1] if len(g_) > 1 else None)
+        gt = _GradTargets()
         B, T, F, Cc = ctx.dims
         P = B * T * F
         dy = dy.contiguous()
@@ -57,17 +84,18 @@ class IntraPlainFn(torch.autograd.Function):
         if not fuse:
             dhs = torch.empty(P, 2 * H, device=dy.device, dtype=torch.float32)
             ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, s2H, Cc, 2 * H)
-        d_lin_w = torch.zeros_like(lin_w)
-        d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
-        ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, d_lin_w, dbias=d_lin_b)
+        ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
         # BPTT
         dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
                               w_lin=lin_w if fuse else None)
         # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)
-        ((dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2)), du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1)
-        dx, d_g, d_b, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc))
+        tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
+              (gt("wir", wir), gt("whr", whr), gt("bir", bir), gt("bhr", bhr))]
+        _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1, targets=tg)
+        dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b))
         dx = dx.view(B, T, F, Cc)
-        return dx, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_lin_w, d_lin_b
+        return (dx, gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"], gt["wir"], gt["whr"], gt["bir"],
+                gt["bhr"], gt["lin_w"], gt["lin_b"])
 
 
 class InterFn(torch.autograd.Function):
@@ -90,7 +118,7 @@ class InterFn(torch.autograd.Function):
         _, s_out = dense(P, Cc)
         ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, H, Cc, epi=L.EPI_RES, res=x)
         if train:
-            ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, u, *[t for t in gates if t is not None])
+            ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
         hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
         ctx.mark_non_differentiable(hN, cN)
@@ -98,8 +126,9 @@ class InterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dh, _dc):
-        x, ln_g, wi, wh, lin_w, hs, u, *g_ = ctx.saved_tensors
+        x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *g_ = ctx.saved_tensors
         gates = (g_[0], g_[1] if len(g_) > 1 else None)
+        gt = _GradTargets()
         B, T, F, Cc = ctx.dims
         P = B * T * F
         dy = dy.contiguous()
@@ -111,15 +140,14 @@ class InterFn(torch.autograd.Function):
         if not fuse:
             dhs = torch.empty(P, H, device=dy.device, dtype=torch.float32)
             ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
-        d_lin_w = torch.zeros_like(lin_w)
-        d_lin_b = torch.zeros(Cc, device=dy.device, dtype=torch.float32)
-        ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, d_lin_w, dbias=d_lin_b)
+        ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
         dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None, w_lin=lin_w if fuse else None)
         # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
-        ((dwi, dwh, db1, db2),), du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F)
-        dx, d_g, d_b, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc))
+        tg = [(gt("wi", wi), gt("wh", wh), gt("bi", bi), gt("bh", bh))]
+        _, du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F, targets=tg)
+        dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b))
         dx = dx.view(B, T, F, Cc)
-        return dx, d_g, d_b, dwi, dwh, db1, db2, d_lin_w, d_lin_b, None, None
+        return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"], None, None)
 
 
 class IntraConvFn(torch.autograd.Function):
@@ -155,14 +183,16 @@ class IntraConvFn(torch.autograd.Function):
         if Fm < F:      # tail frequencies: residual (+ bias when ConvTranspose1d has output_padding)
             y[:, :, Fm:, :] = x[:, :, Fm:, :] + (dec_b if bias_tail else 0.0)
         if train:
-            ctx.save_for_backward(x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, *[t for t in gates if t is not None])
+            ctx.save_for_backward(x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, ln_b, bif, bhf, bir, bhr,
+                                  *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc, down, Kd, bool(bias_tail))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, *g_ = ctx.saved_tensors
+        x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, ln_b, bif, bhf, bir, bhr, *g_ = ctx.saved_tensors
         gates = (g_[0], g_[1] if len(g_) > 1 else None)
+        gt = _GradTargets()
         B, T, F, Cc, down, Kd, bias_tail = ctx.dims
         Fm = Kd * down
         P2 = B * T * Kd
@@ -188,8 +218,11 @@ class IntraConvFn(torch.autograd.Function):
         geom = Geom.intra(B * T, Kd)
         dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
         # one pass over dgates (weight grads + dU), then LayerNorm + PReLU backward -> gradient of the Conv1d output
-        ((dwif, dwhf, dbf, dbf2), (dwir, dwhr, dbr, dbr2)), du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, Kd, 1)
-        dv, d_g, d_b, d_a = ops.ln_bwd(du, v_pre, ln_g, prelu_a=act_a)
+        tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
+              (gt("wir", wir), gt("whr", whr), gt("bir", bir), gt("bhr", bhr))]
+        _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, Kd, 1, targets=tg)
+        dv, _, _, _ = ops.ln_bwd(du, v_pre, ln_g, prelu_a=act_a, d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
+                                 d_a=gt("act_a", act_a))
         # Conv1d backward: dx = dy + dv . Wc ; dWc = dv^T x_rows
         dx = torch.empty_like(x)
         s_x = (F * Cc, 0, NC)
@@ -201,8 +234,8 @@ class IntraConvFn(torch.autograd.Function):
         d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
         ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, d_wc, dbias=d_conv_b)
         d_conv_w = d_wc.view(Cc, down, Cc).permute(0, 2, 1).contiguous()
-        return (dx, d_conv_w, d_conv_b, d_a, d_g, d_b, dwif, dwhf, dbf, dbf2, dwir, dwhr, dbr, dbr2, d_dec_w,
-                d_dec_b, None, None)
+        return (dx, d_conv_w, d_conv_b, gt["act_a"], gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"],
+                gt["wir"], gt["whr"], gt["bir"], gt["bhr"], d_dec_w, d_dec_b, None, None)
 
 
 class AttentionFn(torch.autograd.Function):

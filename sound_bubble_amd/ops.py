@@ -126,8 +126,9 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
     return dg
 
 
-def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip):
-    """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C]."""
+def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None):
+    """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C].
+    targets (optional): per direction 4 buffers the gradients are ACCUMULATED into (instead of fresh zero tensors)."""
     lib = L.load()
     P, ndir = dg.shape[0], dg.shape[1]
     Cc = u.shape[-1]
@@ -138,8 +139,9 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip):
     a.dgates, a.u, a.hs = _p(dg), _p(u), _p(hs)
     grads = []
     for d in range(ndir):
-        g = (torch.zeros(4 * H, Cc, device=dev), torch.zeros(4 * H, H, device=dev),
-             torch.zeros(4 * H, device=dev), torch.zeros(4 * H, device=dev))
+        g = targets[d] if targets is not None else (
+            torch.zeros(4 * H, Cc, device=dev), torch.zeros(4 * H, H, device=dev),
+            torch.zeros(4 * H, device=dev), torch.zeros(4 * H, device=dev))
         grads.append(g)
         a.w_ih[d] = _p(w_ih_list[d])
         a.dW_ih[d], a.dW_hh[d], a.db_ih[d], a.db_hh[d] = _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3])
@@ -152,9 +154,9 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip):
     return grads, du
 
 
-def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None):
+def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=None):
     """LayerNorm(+PReLU) backward.  du_part [P, ndir, C] (summed over ndir), xin [P, C] pre-LN input.
-    -> out [P, C], d_ln_g [C], d_ln_b [C], d_prelu [1] or None"""
+    -> out [P, C], d_ln_g [C], d_ln_b [C], d_prelu [1] or None  (d_g / d_b / d_a: optional accumulation targets)"""
     lib = L.load()
     Cc = xin.shape[-1]
     P = xin.numel() // Cc
@@ -168,14 +170,15 @@ def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None):
     a.du_part, a.xin, a.ln_g, a.prelu_a, a.res = _p(du_part), _p(xin), _p(ln_g), _p(prelu_a), _p(res)
     a.out, a.partials = _p(out), _p(partials)
     L.check(lib.sb_ln_bwd(C.byref(a), _stream()), "sb_ln_bwd")
-    d_g = torch.zeros(Cc, device=dev, dtype=torch.float32)
-    d_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
+    d_g = torch.zeros(Cc, device=dev, dtype=torch.float32) if d_g is None else d_g
+    d_b = torch.zeros(Cc, device=dev, dtype=torch.float32) if d_b is None else d_b
     reduce_partials(partials, Cc, d_g, 0)
     reduce_partials(partials, Cc, d_b, Cc)
-    d_a = None
     if prelu_a is not None:
-        d_a = torch.zeros(1, device=dev, dtype=torch.float32)
+        d_a = torch.zeros(1, device=dev, dtype=torch.float32) if d_a is None else d_a
         reduce_partials(partials, 1, d_a, 2 * Cc)
+    else:
+        d_a = None
     return out, d_g, d_b, d_a
 
 

@@ -263,3 +263,35 @@ def test_attention_multi_tile_matches_oracle(torch_gpu, Lw):
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < TOL_GRAD, worst
+
+
+@pytest.mark.parametrize("name,cls", [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim")])
+def test_direct_grad_accumulation_equals_autograd_path(torch_gpu, name, cls, monkeypatch):
+    """With a FlatBucket the weight-gradient kernels accumulate straight into the parameters' .grad views (autograd
+    gets None); without one they return tensors.  Both must give the same gradients, and a second backward must
+    accumulate (x2) like autograd does."""
+    torch = torch_gpu
+    from sound_bubble_amd import functional as Fn
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd.train import FlatBucket
+    rec, params, m = _build(torch, name, cls)
+    m.train()
+    tgt = torch.from_numpy(rec["target"]).cuda()
+
+    def backward_once():
+        loss, _ = SnrlpLossFn.apply(m(_inputs(torch, rec))["output"], tgt, 100.0)
+        loss.backward()
+
+    monkeypatch.setattr(Fn, "DIRECT_GRADS", False)
+    backward_once()
+    want = {k: p.grad.clone() for k, p in m.named_parameters()}
+    monkeypatch.setattr(Fn, "DIRECT_GRADS", True)
+    bucket = FlatBucket(m)
+    bucket.zero_grad()
+    backward_once()
+    for k, p in m.named_parameters():
+        assert p.grad.data_ptr() >= bucket.grad.data_ptr()          # still the bucket view
+        assert rel_l2(p.grad.cpu().numpy(), want[k].cpu().numpy()) < 1e-5 or float(want[k].abs().max()) == 0, k
+    backward_once()
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), 2 * want[k].cpu().numpy()) < 1e-5 or float(want[k].abs().max()) == 0, k
