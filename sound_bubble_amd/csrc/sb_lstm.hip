@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
       U[buf][ls][cpart * VPT + v] = u[v];
     }
     // both directions write the (identical) normalised row: branch-free beats saving 1/10 of the store traffic
-    if (SAVE && lvalid) {
+    if (SAVE && lvalid && dir == 0) {
       const int st = rev ? S - 1 - s : s;
       float* p = a.save_u + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll

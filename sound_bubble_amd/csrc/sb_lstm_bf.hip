@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       U16[t][buf][1][ls][cpart * VPT + v] = m;
       U16[t][buf][2][ls][cpart * VPT + v] = l;
     }
-    if (SAVE && lvalid[t]) {
+    if (SAVE && lvalid[t] && dir == 0) {      // both directions normalise the same rows: one copy is enough
       const int st = rev ? S - 1 - s : s;
       float* p = a.save_u + (lbase[t] + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll

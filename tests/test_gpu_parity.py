@@ -295,3 +295,50 @@ def test_direct_grad_accumulation_equals_autograd_path(torch_gpu, name, cls, mon
     backward_once()
     for k, p in m.named_parameters():
         assert rel_l2(p.grad.cpu().numpy(), 2 * want[k].cpu().numpy()) < 1e-5 or float(want[k].abs().max()) == 0, k
+
+
+@pytest.mark.parametrize("N", [1, 100, 192, 193, 1000])
+@pytest.mark.parametrize("flavour", ["optim", "dis_embd3"])
+def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, monkeypatch):
+    """mod_pad (net.py:8-18) edge cases: clips shorter than one hop, exactly one hop, one sample more, ragged --
+    a single STFT frame makes every recurrence a one-step walk.  Forward and parameter gradients vs the oracle
+    (fp32 BPTT records: this is a logic test; scalar gradients such as PReLU slopes are cancellation-prone)."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import ops
+    monkeypatch.setattr(ops, "COMPACT_BPTT", False)
+    from oracle.tfgridnet_oracle import OracleNet
+    params = dict(stft_chunk_size=192, stft_pad_size=96, num_ch=6, L=4, I=1, J=1, H=64, E=2, use_attn=False,
+                  lookahead=True, chunk_causal=True, use_first_ln=True, merge_method="early_cat", B=2,
+                  local_atten_len=50)
+    if flavour == "optim":
+        params.update(D=16, conv_lstm=True, lstm_down=5)
+        cls = sb.NetOptim
+    else:
+        params.update(D=32, conv_lstm=False, dis_type="conv3")
+        cls = sb.NetDisEmbd3
+    torch.manual_seed(N)
+    ref = OracleNet(flavour, **params).train()
+    m = cls(**params)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda().train()
+    x = 0.1 * torch.randn(3, 6, N)
+    inp = {"mixture": x}
+    if flavour == "dis_embd3":
+        inp["dis_embed"] = torch.eye(3)
+    want = ref(dict(inp))["output"]
+    got = m({k: v.cuda() for k, v in inp.items()})["output"]
+    assert got.shape == want.shape == (3, 1, N)
+    assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < TOL_FWD
+    want.square().sum().backward()
+    got.square().sum().backward()
+    refg = dict(ref.named_parameters())
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        g = refg[k].grad
+        if g is None or float(g.abs().max()) == 0:
+            continue
+        e = rel_l2(p.grad.cpu().numpy(), g.numpy())
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < TOL_GRAD, worst
