@@ -67,6 +67,10 @@ typedef struct {
      d(hs)[p, dir*64 + u] = sum_c w_lin[c, dir*64 + u] * dy[p, c] is formed on the fly.  dy [P, C_lin] dense,
      w_lin [C_lin, ndir*64] (nn.Linear weight), C_lin = 16 or 32. */
   const float* dy; const float* w_lin; int C_lin;
+  /* compact dgates (mma == 1, compact records only): when gmax != NULL, dgates is written as fp16 [P, ndir, 4, 64]
+     holding S * dgates with S = 2^-ceil(log2(*gmax)) -- *gmax = max |incoming gradient| from sb_absmax -- the whole
+     backward recurrence is linear in that gradient, so it simply runs on the scaled values. */
+  const float* gmax;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 
@@ -148,6 +152,9 @@ typedef struct {
   float* dW_ih[2]; float* dW_hh[2]; float* db_ih[2]; float* db_hh[2];
   float* du_part; float* scratch;
   int split_bf16;     /* 1: bf16 matrix pipe with 3-term split products (fp32-class accuracy, ~4x fewer MFMA cycles) */
+  const float* gmax;  /* != NULL: dgates is the scaled fp16 tensor written by sb_lstm_bwd_rec with the same gmax; the
+                         fp16 matrix pipe is used (dgates exact, the fp32 operands as fp16 hi + lo) and every output
+                         is multiplied by 1/S */
 } sb_lstm_stream_args;
 int sb_lstm_bwd_stream(const sb_lstm_stream_args* a, void* stream);
 int sb_lstm_stream_grid(int64_t positions);
@@ -248,6 +255,8 @@ int sb_signal_stats(const float* est, const float* gt, const float* mix, int B, 
 
 /* ---- optimiser ------------------------------------------------------------
  * sumsq[0] += sum g^2 (grad-norm for clip_grad_norm_, hl_module:437-441). */
+/* max |x| over n (multiple of 4) floats -> out[0] (device scalar, set by the call) */
+int sb_absmax(const float* x, int64_t n, float* out, void* stream);
 int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
 /* Adam step (torch.optim.Adam, no weight decay / amsgrad) over a flat bucket.
  * grad is first scaled by gscale * min(1, clip / (sqrt(sumsq[0]) * gscale + 1e-6))

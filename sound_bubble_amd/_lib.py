@@ -26,7 +26,7 @@ class LstmBwdArgs(C.Structure):
     _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int),
                 ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
                 ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("save_c", c_fp), ("mma", C.c_int),
-                ("dy", c_fp), ("w_lin", c_fp), ("C_lin", C.c_int)]
+                ("dy", c_fp), ("w_lin", c_fp), ("C_lin", C.c_int), ("gmax", c_fp)]
 
 
 class LinearArgs(C.Structure):
@@ -56,7 +56,7 @@ class LstmStreamArgs(C.Structure):
                 ("dgates", c_fp), ("u", c_fp), ("hs", c_fp),
                 ("w_ih", c_fp * 2),
                 ("dW_ih", c_fp * 2), ("dW_hh", c_fp * 2), ("db_ih", c_fp * 2), ("db_hh", c_fp * 2),
-                ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int)]
+                ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int), ("gmax", c_fp)]
 
 
 class LnBwdArgs(C.Structure):
@@ -109,6 +109,7 @@ SYMBOLS = {
     "sb_snrlp_loss": (_ci, [c_fp, c_fp, _ci, i64, _cf, c_fp, c_fp, c_fp, _vp]),
     "sb_signal_stats": (_ci, [c_fp, c_fp, c_fp, _ci, i64, i64, c_fp, _vp]),
     "sb_sumsq": (_ci, [c_fp, i64, c_fp, _vp]),
+    "sb_absmax": (_ci, [c_fp, i64, c_fp, _vp]),
     "sb_adam_step": (_ci, [c_fp, c_fp, c_fp, c_fp, i64, _cf, _cf, _cf, _cf, _ci, _cf, _cf, c_fp, _vp]),
 }
 

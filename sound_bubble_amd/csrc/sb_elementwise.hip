@@ -260,6 +260,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+// max |x| (bit pattern of a non-negative float orders like an unsigned integer)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = ld4(x + 4 * i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2, float gscale,
@@ -360,6 +371,17 @@ extern "C" int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
   unsigned gx = nblk(n, 256 * 4);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL(sumsq_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_absmax(const float* x, int64_t n, float* out, void* stream) {
+  if (n % 4) return -1002;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(out, 0, sizeof(float), st);
+  unsigned gx = nblk(n / 4, 256 * 4);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(absmax_kernel, dim3(gx), dim3(256), 0, st, x, n / 4, reinterpret_cast<unsigned*>(out));
   SB_CHECK_LAUNCH();
   return 0;
 }

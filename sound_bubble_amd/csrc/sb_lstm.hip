@@ -360,7 +360,13 @@ extern "C" int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream) {
   dim3 grid((a->nseq + 15) / 16, a->ndir), block(256);
   hipStream_t st = (hipStream_t)stream;
   const bool full = a->nseq % 16 == 0, r16 = a->save_c != nullptr;
-  if (a->mma == 1) { sb_launch_lstm_bwd_bf(*a, st); SB_CHECK_LAUNCH(); return 0; }
+  if (a->mma == 1) {
+    const int rc = sb_launch_lstm_bwd_bf(*a, st);
+    if (rc) return rc;
+    SB_CHECK_LAUNCH();
+    return 0;
+  }
+  if (a->gmax) return -1003;                       // compact fp16 dgates: bf16 path only
 #define SB_B(FL, R16) hipLaunchKernelGGL((lstm_bwd_rec_kernel<FL, R16>), grid, block, 0, st, *a)
   if (full) { if (r16) SB_B(true, true); else SB_B(true, false); }
   else { if (r16) SB_B(false, true); else SB_B(false, false); }

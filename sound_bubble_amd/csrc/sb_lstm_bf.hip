@@ -33,6 +33,7 @@ constexpr int H = SB_H;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 struct Split3 { bf16x8 h, m, l; };
 
@@ -326,7 +327,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 // FUSE_LIN (C = channels of dy): the gradient w.r.t. the hidden sequence is not read from memory but formed on
 // the fly as dh_ext = W_lin[:, dir*64 + unit]^T dy[pos] (the backward of the Linear that follows the LSTM), one
 // 16x16x32 tile per wave with a 2-term split (hi, lo) -- it enters the recurrence additively, un-amplified.
-template <bool FULL, bool REC16, int FUSE_C>
+// DG16: dgates leave as fp16 of S * dgates, S = 2^-ceil(log2 max|incoming gradient|) (see sb_lstm_bwd_args.gmax): the
+// recurrence is linear in the incoming gradient, so scaling it once at the entry scales everything consistently.
+SB_DEVINL float grad_scale(const float* gmax) {
+  const float m = gmax[0];
+  return (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f;
+}
+
+template <bool FULL, bool REC16, int FUSE_C, bool DG16>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -353,6 +361,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   const int64_t base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
   const int uoff = 16 * w + 4 * q;
 
+  const float gS = DG16 ? grad_scale(a.gmax) : 1.0f;
   // W_lin^T tile of this wave's units (FUSE): A[i = unit 16w + j][k = channel 8q + kk], 2-term split
   bf16x8 Lh, Ll;
   if constexpr (FUSE_C > 0) {
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int ch = 8 * q + kk;
-      const float v = ch < FUSE_C ? a.w_lin[(size_t)ch * ldw + dir * H + 16 * w + j] : 0.f;
+      const float v = ch < FUSE_C ? gS * a.w_lin[(size_t)ch * ldw + dir * H + 16 * w + j] : 0.f;
       const __bf16 hh = (__bf16)v;
       Lh[kk] = hh;
       Ll[kk] = (__bf16)(v - (float)hh);
@@ -425,6 +434,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       gi = raw.r0; gf = raw.r1; gg = raw.r2; go = raw.r3;
     }
     f32x4 dhext = raw.dh;
+    if constexpr (DG16 && FUSE_C == 0) dhext *= gS;
     if constexpr (FUSE_C > 0) {
       bf16x8 bh, bl;
 #pragma unroll
@@ -466,8 +476,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     if (valid) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = base + (int64_t)st * a.p_step;
-      float* dg = a.dgates + (pos * ndir + dir) * (4 * H) + uoff;
-      st4(dg, dG[0]); st4(dg + H, dG[1]); st4(dg + 2 * H, dG[2]); st4(dg + 3 * H, dG[3]);
+      if constexpr (DG16) {
+        _Float16* dg = reinterpret_cast<_Float16*>(a.dgates) + (pos * ndir + dir) * (4 * H) + uoff;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          h16x4 t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = (_Float16)dG[g][r];
+          *reinterpret_cast<h16x4*>(dg + g * H) = t;
+        }
+      } else {
+        float* dg = a.dgates + (pos * ndir + dir) * (4 * H) + uoff;
+        st4(dg, dG[0]); st4(dg + H, dG[1]); st4(dg + 2 * H, dG[2]); st4(dg + 3 * H, dG[3]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 part[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -534,13 +555,16 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
 
 int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a, hipStream_t st) {
   dim3 grid((a.nseq + 15) / 16, a.ndir), block(256);
-  const bool full = a.nseq % 16 == 0, r16 = a.save_c != nullptr;
+  const bool full = a.nseq % 16 == 0, r16 = a.save_c != nullptr, dg16 = a.gmax != nullptr;
+  if (dg16 && !r16) return -1003;
   const int fc = a.dy ? a.C_lin : 0;
-#define SB_B(FL, R16, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC>), grid, block, 0, st, a)
-#define SB_BF(FC) do { if (full) { if (r16) SB_B(true, true, FC); else SB_B(true, false, FC); } \
-                       else { if (r16) SB_B(false, true, FC); else SB_B(false, false, FC); } } while (0)
+#define SB_B(FL, R16, FC, D16) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16>), grid, block, 0, st, a)
+#define SB_BR(FL, FC) do { if (dg16) SB_B(FL, true, FC, true); else if (r16) SB_B(FL, true, FC, false); \
+                           else SB_B(FL, false, FC, false); } while (0)
+#define SB_BF(FC) do { if (full) SB_BR(true, FC); else SB_BR(false, FC); } while (0)
   if (fc == 0) SB_BF(0); else if (fc == 16) SB_BF(16); else if (fc == 32) SB_BF(32); else return -1002;
 #undef SB_BF
+#undef SB_BR
 #undef SB_B
   return 0;
 }

@@ -324,6 +324,186 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_bf16_kernel(sb_lstm_strea
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp16 variant for the compact dgates of sb_lstm_bwd_rec (fp16, scaled by S = 2^-ceil(log2 gmax)): dgates go to
+// the matrix pipe as they are (exact), the fp32 operands (u, h_prev, W_ih) as fp16 hi + lo (22 mantissa bits), so
+// every product needs 2 MFMAs instead of 3 and no dgates split; half the dgates bytes.  Outputs are multiplied by
+// 1/S.  Tiling, prefetch and output layout are those of the bf16 kernel above.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+struct SplitH { h16x8 hi, lo; };
+SB_DEVINL SplitH splith8(const float (&x)[8]) {
+  SplitH s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const _Float16 h = (_Float16)x[k];
+    s.hi[k] = h;
+    s.lo[k] = (_Float16)(x[k] - (float)h);
+  }
+  return s;
+}
+SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+template <int C, bool SMALLSEG>
+__global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
+  constexpr int CK = C / 16, KT = CK + 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int dir = blockIdx.y, ndir = a.ndir;
+  const int Pi = (int)a.P;
+  __shared__ __attribute__((aligned(16))) float R[2][4][2][CK][64][4];
+  float invS = 1.0f;
+  {
+    const float m = a.gmax[0];
+    if (m > 0.f && m < 3.0e38f) invS = exp2f(ceilf(log2f(m)));
+  }
+
+  // W_ih^T, split once: A[i = channel 16ct + j][k = gate 64w + 32m + 8q + kk]
+  const float* __restrict__ wih = a.w_ih[dir];
+  SplitH Awt[CK][2];
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = wih[(size_t)(64 * w + 32 * m + 8 * q + kk) * C + 16 * ct + j];
+      Awt[ct][m] = splith8(t);
+    }
+
+  f32x4 acc[4][KT];
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = zero4();
+
+  const _Float16* __restrict__ dg = reinterpret_cast<const _Float16*>(a.dgates) + (size_t)dir * 4 * H + 64 * w;
+  const float* __restrict__ hs = a.hs + (size_t)dir * H;
+  const int64_t ldg = (int64_t)ndir * 4 * H, ldh = (int64_t)ndir * H;
+  const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
+  const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
+
+  struct Chunk { h16x4 a4[8]; f32x4 h4[8]; h16x8 d8[2][2]; float uv[CK][8]; };     // raw operands of 32 positions
+  const int nchunks = (Pi + 31) / 32;
+  const h16x4 hz4 = {0, 0, 0, 0};
+  const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_chunk = [&](int ch, Chunk& t) {          // branch-free (clamped address + select)
+    const int p0 = ch * 32;
+    const int idx0 = p0 % a.seg_len;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int p = p0 + 8 * q + kk;
+      const bool ok = p < Pi;
+      const int pc = ok ? p : Pi - 1;
+      const h16x4 av = *reinterpret_cast<const h16x4*>(dg + (int64_t)pc * ldg + 4 * j);
+      t.a4[kk] = ok ? av : hz4;
+      int idx = idx0 + 8 * q + kk;
+      if constexpr (SMALLSEG) idx %= a.seg_len; else idx -= idx >= a.seg_len ? a.seg_len : 0;
+      const bool ok2 = ok & (idx >= skip_first) & (idx < a.seg_len - skip_last);
+      const f32x4 hv = ld4(hs + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
+      t.h4[kk] = ok2 ? hv : zero4();
+      if constexpr (CK == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(a.u + (int64_t)pc * C + 2 * j);
+        t.uv[0][kk] = ok ? v.x : 0.f; t.uv[1][kk] = ok ? v.y : 0.f;
+      } else {
+        const float v = a.u[(int64_t)pc * C + j];
+        t.uv[0][kk] = ok ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {          // dU operand: position p0 + 16 sb + j, gates 32m + 8q .. +7 (one 16-byte load)
+      const int pj = p0 + 16 * sb + j;
+      const int pjc = pj < Pi ? pj : Pi - 1;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const h16x8 dv = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 32 * m + 8 * q);
+        t.d8[sb][m] = pj < Pi ? dv : hz8;
+      }
+    }
+  };
+
+  const h16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+  Chunk cur;
+  if ((int)blockIdx.x < nchunks) load_chunk(blockIdx.x, cur);
+  int it = 0;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x, ++it) {
+    Chunk nxt;
+    const int cn = ch + gridDim.x;
+    load_chunk(cn < nchunks ? cn : ch, nxt);
+    // ---- weight gradients: 4 gate tiles x (CK + 4) column tiles, K = 32 positions ----
+    SplitH Bop[KT];
+#pragma unroll
+    for (int kt = 0; kt < CK; ++kt) Bop[kt] = splith8(cur.uv[kt]);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = cur.h4[kk][kt];
+      Bop[CK + kt] = splith8(t);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      h16x8 Aop;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) Aop[kk] = cur.a4[kk][nt];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr)         // bias gradient: running sum of the 8 dgates (2 per v_dot2)
+        csum[nt] = __builtin_amdgcn_fdot2(h16x2{Aop[2 * pr], Aop[2 * pr + 1]}, ones, csum[nt], false);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        acc[nt][kt] = mfma_h(Aop, Bop[kt].lo, acc[nt][kt]);
+        acc[nt][kt] = mfma_h(Aop, Bop[kt].hi, acc[nt][kt]);
+      }
+    }
+    // ---- dU = W_ih^T dgates for the two 16-position sub-tiles ----
+    const int buf = it & 1;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      f32x4 du[CK];
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) du[ct] = zero4();
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) {
+          du[ct] = mfma_h(Awt[ct][m].lo, cur.d8[sb][m], du[ct]);
+          du[ct] = mfma_h(Awt[ct][m].hi, cur.d8[sb][m], du[ct]);
+        }
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
+    }
+    __syncthreads();
+    {   // 2 sub-tiles x CK channel tiles = 2*CK (<= 4) reductions: one per wave
+      const int sb = w / CK, ct = w % CK;
+      const int pj = ch * 32 + 16 * sb + j;
+      if (w < 2 * CK && pj < Pi) {
+        const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
+                         ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
+        st4(a.du_part + ((int64_t)pj * ndir + dir) * C + 16 * ct + 4 * q, s4 * invS);
+      }
+    }
+    cur = nxt;
+  }
+
+  constexpr int Ktot = C + H;
+  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) * ((size_t)4 * H * Ktot + 4 * H);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gate = 64 * w + 4 * (4 * q + r) + nt;
+#pragma unroll
+      for (int kt = 0; kt < CK; ++kt) part[(size_t)gate * Ktot + (CK == 2 ? 2 * j + kt : j)] = acc[nt][kt][r] * invS;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) part[(size_t)gate * Ktot + C + 4 * j + kt] = acc[nt][CK + kt][r] * invS;
+    }
+    const float cs = quad_sum(csum[nt]);
+    if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
+  }
+}
+
 __global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restrict__ partials, int rows, int C,
                                                             float* __restrict__ dW1, float* __restrict__ dW2,
                                                             float* __restrict__ db1, float* __restrict__ db2) {
@@ -428,7 +608,8 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   const bool sm = ap->seg_len < 32;
 #define SB_S(K, CC) do { if (sm) hipLaunchKernelGGL((K<CC, true>), grid, block, 0, st, *ap); \
                          else hipLaunchKernelGGL((K<CC, false>), grid, block, 0, st, *ap); } while (0)
-  if (ap->split_bf16) { if (ap->C == 32) SB_S(lstm_bwd_stream_bf16_kernel, 32); else SB_S(lstm_bwd_stream_bf16_kernel, 16); }
+  if (ap->gmax) { if (ap->C == 32) SB_S(lstm_bwd_stream_f16_kernel, 32); else SB_S(lstm_bwd_stream_f16_kernel, 16); }
+  else if (ap->split_bf16) { if (ap->C == 32) SB_S(lstm_bwd_stream_bf16_kernel, 32); else SB_S(lstm_bwd_stream_bf16_kernel, 16); }
   else { if (ap->C == 32) SB_S(lstm_bwd_stream_kernel, 32); else SB_S(lstm_bwd_stream_kernel, 16); }
 #undef SB_S
   SB_CHECK_LAUNCH();

@@ -104,39 +104,65 @@ def can_fuse_linear_bwd():
     return LSTM_MMA == 1 and COMPACT_BPTT
 
 
+# compact-BPTT mode on the bf16 path: dgates travel between the two backward kernels as fp16, scaled by a power of
+# two derived from max |incoming gradient| (SB_DGATES_FP32=1 keeps them fp32)
+DGATES_FP16 = os.environ.get("SB_DGATES_FP32", "0") != "1"
+
+
+class DGates:
+    """dgates [P, ndir, 4, 64] (+ the device scalar max|incoming gradient| when they are the scaled fp16 form)"""
+
+    def __init__(self, data, gmax=None):
+        self.data, self.gmax = data, gmax
+
+
+def absmax(x):
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    L.check(L.load().sb_absmax(_p(x), x.numel(), _p(out), _stream()), "sb_absmax")
+    return out
+
+
 def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
-    """dhs [P, ndir*64] -- or, fused: dhs=None, dy [P, C] and w_lin [C, ndir*64] (see can_fuse_linear_bwd)."""
+    """dhs [P, ndir*64] -- or, fused: dhs=None, dy [P, C] and w_lin [C, ndir*64] (see can_fuse_linear_bwd).
+    -> DGates"""
     lib = L.load()
     ndir = len(w_hh_list)
     dev = dhs.device if dhs is not None else dy.device
-    dg = torch.empty(geom.P, ndir, 4, H, device=dev, dtype=torch.float32)
+    rec, cprev = gates
+    dg16 = DGATES_FP16 and LSTM_MMA == 1 and cprev is not None
+    gmax = absmax(dy if dy is not None else dhs) if dg16 else None
+    dg = torch.empty(geom.P, ndir, 4, H, device=dev, dtype=torch.float16 if dg16 else torch.float32)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, ndir
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
     for d, wh in enumerate(w_hh_list):
         a.w_hh[d] = _p(wh)
-    rec, cprev = gates
     a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), _p(cprev)
-    a.dhs, a.dgates = _p(dhs), _p(dg)
+    a.dhs, a.dgates = _p(dhs), C.c_void_p(dg.data_ptr())
+    a.gmax = _p(gmax)
     a.mma = LSTM_MMA
     if dy is not None:
         assert can_fuse_linear_bwd() and w_lin.shape == (dy.shape[-1], ndir * H)
         a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), dy.shape[-1]
     L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
-    return dg
+    return DGates(dg, gmax)
 
 
 def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None):
     """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C].
     targets (optional): per direction 4 buffers the gradients are ACCUMULATED into (instead of fresh zero tensors)."""
     lib = L.load()
+    if not isinstance(dg, DGates):
+        dg = DGates(dg)
+    gmax, dg = dg.gmax, dg.data
     P, ndir = dg.shape[0], dg.shape[1]
     Cc = u.shape[-1]
     dev = dg.device
     a = L.LstmStreamArgs()
     a.P, a.ndir, a.C = P, ndir, Cc
     a.shift_pos, a.seg_len, a.skip = shift_pos, seg_len, skip
-    a.dgates, a.u, a.hs = _p(dg), _p(u), _p(hs)
+    a.dgates, a.u, a.hs = C.c_void_p(dg.data_ptr()), _p(u), _p(hs)
+    a.gmax = _p(gmax)
     grads = []
     for d in range(ndir):
         g = targets[d] if targets is not None else (
