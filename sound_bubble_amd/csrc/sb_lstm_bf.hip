@@ -51,6 +51,17 @@ SB_DEVINL Split3 split8(const float (&x)[8]) {
   return s;
 }
 SB_DEVINL f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+struct SplitH { h16x8 hi, lo; };            // fp32 = fp16 hi + fp16 lo (22 mantissa bits)
+SB_DEVINL SplitH splith8(const float (&x)[8]) {
+  SplitH s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const _Float16 h = (_Float16)x[k];
+    s.hi[k] = h;
+    s.lo[k] = (_Float16)(x[k] - (float)h);
+  }
+  return s;
+}
 
 constexpr int UP = 32 + 8;    // padded bf16 row of the input-term tiles  (80 B)
 constexpr int HP16 = 64 + 8;  // padded bf16 row of the hidden-term tiles (144 B)
@@ -344,7 +355,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
 
   const float* __restrict__ whh = a.w_hh[dir];
-  Split3 At[4][2];   // [out tile ot][chunk]: A[i = out unit 16ot + j][k] = W_hh[gate row(k)][16ot + j]
+  // [out tile ot][chunk]: A[i = out unit 16ot + j][k] = W_hh[gate row(k)][16ot + j].  DG16: the dgates enter the
+  // product as the fp16 values that are stored (one term), W_hh as fp16 hi + lo -> 2 MFMAs per tile and chunk
+  // instead of 6 and no operand split on the critical path.
+  Split3 At[4][2];
+  SplitH Ah[4][2];
 #pragma unroll
   for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk)
         t[kk] = whh[(size_t)((2 * c + (kk >> 2)) * H + 16 * w + 4 * q + (kk & 3)) * H + 16 * ot + j];
-      At[ot][c] = split8(t);
+      if constexpr (DG16) Ah[ot][c] = splith8(t); else At[ot][c] = split8(t);
     }
 
   const int nc = n0 + j;
@@ -462,14 +477,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       dG[3][r] = dO * go[r] * (1.0f - go[r]);
       dc[r] = dct * gf[r];
     }
-    // split the 16 dgates of this lane into the two K-chunks of the B operand
+    // the 16 dgates of this lane are the two K-chunks of the B operand (3-way bf16 split, or the fp16 values)
     Split3 Bop[2];
+    h16x8 Bh[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       float t[8];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) t[kk] = dG[2 * c + (kk >> 2)][kk & 3];
-      Bop[c] = split8(t);
+      if constexpr (DG16) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) Bh[c][kk] = (_Float16)t[kk];
+      } else {
+        Bop[c] = split8(t);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c2);
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         for (int g = 0; g < 4; ++g) {
           h16x4 t;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = (_Float16)dG[g][r];
+          for (int r = 0; r < 4; ++r) t[r] = Bh[g >> 1][4 * (g & 1) + r];
           *reinterpret_cast<h16x4*>(dg + g * H) = t;
         }
       } else {
@@ -492,6 +513,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 part[4] = {zero4(), zero4(), zero4(), zero4()};
+    if constexpr (DG16) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) part[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ot][c].lo, Bh[c], part[ot], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) part[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ot][c].hi, Bh[c], part[ot], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
