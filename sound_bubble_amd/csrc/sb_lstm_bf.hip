@@ -423,21 +423,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   };
 
   f32x4 dc = zero4(), dhrec = zero4();
-  Raw nxt = load_raw(S - 1);
 #ifdef SB_PHASE_TIMING
   unsigned long long tph[5] = {0, 0, 0, 0, 0};
 #endif
-  for (int s = S - 1; s >= 0; --s) {
+  // Records are fetched TWO steps ahead: along the inter-frame walk consecutive steps are F positions (tens of KB,
+  // a new page) apart, and the measured load-to-use latency there exceeds one step.  `slot` holds the record of
+  // step s and is refilled with that of step s-2; the loop is unrolled by two so the two slots need no copies.
+  auto step = [&](int s, Raw& slot) {
     const int cur = s & 1;
     SB_TICK(c0);
-    Raw raw = nxt;
-    // consume the prefetched record (forces its wait HERE), then immediately issue the prefetch of the
-    // previous step so that it has a whole step of latency cover
+    Raw raw = slot;
+    // consume the prefetched record (pins its s_waitcnt HERE), then immediately issue the next prefetch
     asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.cp), "+v"(raw.dh));
     if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
     __builtin_amdgcn_sched_barrier(0);
-    nxt = load_raw(max(s - 1, 0));
+    slot = load_raw(max(s - 2, 0));
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c1);
     f32x4 gi, gf, gg, go;
@@ -549,7 +550,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     SB_TICK(c5);
     tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
 #endif
+  };
+  Raw rA = load_raw(S - 1), rB = load_raw(max(S - 2, 0));
+  int s = S - 1;
+  for (; s >= 1; s -= 2) {
+    step(s, rA);
+    step(s - 1, rB);
   }
+  if (s == 0) step(0, rA);
 #ifdef SB_PHASE_TIMING
   if (a.dhs && !a.dy && lane == 0 && blockIdx.x < 4) {
     float* d = const_cast<float*>(a.dhs) + (blockIdx.x * 4 + w) * 8;

@@ -268,8 +268,8 @@ def test_attention_multi_tile_matches_oracle(torch_gpu, Lw):
 @pytest.mark.parametrize("name,cls", [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim")])
 def test_direct_grad_accumulation_equals_autograd_path(torch_gpu, name, cls, monkeypatch):
     """With a FlatBucket the weight-gradient kernels accumulate straight into the parameters' .grad views (autograd
-    gets None); without one they return tensors.  Both must give the same gradients, and a second backward must
-    accumulate (x2) like autograd does."""
+    gets None); without one they return tensors.  Both must give the same gradients (up to the summation order of the
+    atomic reductions, ~2e-5), and a second backward must accumulate (x2) like autograd does."""
     torch = torch_gpu
     from sound_bubble_amd import functional as Fn
     from sound_bubble_amd.functional import SnrlpLossFn
@@ -291,10 +291,10 @@ def test_direct_grad_accumulation_equals_autograd_path(torch_gpu, name, cls, mon
     backward_once()
     for k, p in m.named_parameters():
         assert p.grad.data_ptr() >= bucket.grad.data_ptr()          # still the bucket view
-        assert rel_l2(p.grad.cpu().numpy(), want[k].cpu().numpy()) < 1e-5 or float(want[k].abs().max()) == 0, k
+        assert rel_l2(p.grad.cpu().numpy(), want[k].cpu().numpy()) < 1e-4 or float(want[k].abs().max()) == 0, k
     backward_once()
     for k, p in m.named_parameters():
-        assert rel_l2(p.grad.cpu().numpy(), 2 * want[k].cpu().numpy()) < 1e-5 or float(want[k].abs().max()) == 0, k
+        assert rel_l2(p.grad.cpu().numpy(), 2 * want[k].cpu().numpy()) < 1e-4 or float(want[k].abs().max()) == 0, k
 
 
 @pytest.mark.parametrize("N", [1, 100, 192, 193, 1000])
