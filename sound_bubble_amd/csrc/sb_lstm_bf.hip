@@ -427,19 +427,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   unsigned long long tph[5] = {0, 0, 0, 0, 0};
 #endif
   // Records are fetched TWO steps ahead: along the inter-frame walk consecutive steps are F positions (tens of KB,
-  // a new page) apart, and the measured load-to-use latency there exceeds one step.  `slot` holds the record of
-  // step s and is refilled with that of step s-2; the loop is unrolled by two so the two slots need no copies.
-  auto step = [&](int s, Raw& slot) {
-    const int cur = s & 1;
-    SB_TICK(c0);
-    Raw raw = slot;
-    // consume the prefetched record (pins its s_waitcnt HERE), then immediately issue the next prefetch
+  // a new page) apart and the measured load-to-use latency there exceeds one step.  The loop body covers a PAIR of
+  // steps and issues both records of the next pair at its top, so the register copies hipcc places at the end of
+  // the body (loop-carried values) only touch loads that are two steps old.
+  auto consume = [&](Raw& raw) {      // pins the s_waitcnt of this record here
     asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.cp), "+v"(raw.dh));
     if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
-    __builtin_amdgcn_sched_barrier(0);
-    slot = load_raw(max(s - 2, 0));
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto step = [&](int s, const Raw& raw) {
+    const int cur = s & 1;
+    SB_TICK(c0);
     SB_TICK(c1);
     f32x4 gi, gf, gg, go;
     if constexpr (REC16) {
@@ -554,10 +552,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   Raw rA = load_raw(S - 1), rB = load_raw(max(S - 2, 0));
   int s = S - 1;
   for (; s >= 1; s -= 2) {
-    step(s, rA);
-    step(s - 1, rB);
+    Raw curA = rA, curB = rB;
+    consume(curA);
+    __builtin_amdgcn_sched_barrier(0);
+    rA = load_raw(max(s - 2, 0));
+    rB = load_raw(max(s - 3, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    step(s, curA);
+    consume(curB);
+    step(s - 1, curB);
   }
-  if (s == 0) step(0, rA);
+  if (s == 0) { consume(rA); step(0, rA); }
 #ifdef SB_PHASE_TIMING
   if (a.dhs && !a.dy && lane == 0 && blockIdx.x < 4) {
     float* d = const_cast<float*>(a.dhs) + (blockIdx.x * 4 + w) * 8;
