@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
   };
 
-  XVec<C> xnext[TILES];
+  // input rows are fetched two steps before their LayerNorm; the loop body covers a pair of steps and issues the
+  // rows of the next pair at its top (see the backward kernel)
+  XVec<C> xa[TILES], xb[TILES];
   f32x4 accx[TILES][4];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
@@ -234,7 +236,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     XVec<C> x1 = load_x(t, min(1, S - 1));
     ln_store(t, x0, 0, 0);
     ln_store(t, x1, 1, min(1, S - 1));
-    xnext[t] = load_x(t, min(2, S - 1));
+    xa[t] = load_x(t, min(2, S - 1));
+    xb[t] = load_x(t, min(3, S - 1));
   }
   __syncthreads();
 #pragma unroll
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #ifdef SB_PHASE_TIMING
   unsigned long long tph[5] = {0, 0, 0, 0, 0};
 #endif
-  for (int s = 0; s < S; ++s) {
+  auto step = [&](int s, const XVec<C> (&xrow)[TILES]) {        // xrow: input row s+2
     const int cur = s & 1;
     SB_TICK(c0);
     // ---- A: hidden part on the matrix pipe || LayerNorm of row s+2 in the issue gaps (it does not depend on
@@ -254,12 +257,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[t][g] = accx[t][g];
-      ln_store(t, xnext[t], cur, min(s + 2, S - 1));
+      ln_store(t, xrow[t], cur, min(s + 2, S - 1));
       h_part(t, acc[t], cur);
     }
     if (TILES == 1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) xnext[t] = load_x(t, min(s + 3, S - 1));      // a whole step of latency cover
     SB_TICK(c1);
     // ---- B: input part of step s+1 (matrix pipe) || cell update of step s (VALU) ----
     f32x4 gi[TILES], gf[TILES], gg[TILES], go[TILES], cprev[TILES];
@@ -314,7 +315,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     SB_TICK(c5);
     tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
 #endif
+  };
+  int s = 0;
+  for (; s + 1 < S; s += 2) {
+    XVec<C> ca[TILES], cb[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) { ca[t] = xa[t]; cb[t] = xb[t]; }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) { xa[t] = load_x(t, min(s + 4, S - 1)); xb[t] = load_x(t, min(s + 5, S - 1)); }
+    step(s, ca);
+    step(s + 1, cb);
   }
+  if (s < S) step(s, xa);
 #ifdef SB_PHASE_TIMING
   if (SAVE == 0 && a.save_u && lane == 0 && blockIdx.x < 4) {
     float* d = a.save_u + (blockIdx.x * 4 + w) * 8;
