@@ -263,7 +263,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // max |x| (bit pattern of a non-negative float orders like an unsigned integer)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, unsigned* __restrict__ out) {
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {               // four independent 16-byte loads in flight
+    const f32x4 v0 = ld4(x + 4 * i), v1 = ld4(x + 4 * (i + stride)), v2 = ld4(x + 4 * (i + 2 * stride)),
+                v3 = ld4(x + 4 * (i + 3 * stride));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(fmaxf(m, fmaxf(fabsf(v0[r]), fabsf(v1[r]))), fmaxf(fabsf(v2[r]), fabsf(v3[r])));
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = ld4(x + 4 * i);
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
@@ -380,7 +388,7 @@ extern "C" int sb_absmax(const float* x, int64_t n, float* out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(out, 0, sizeof(float), st);
   unsigned gx = nblk(n / 4, 256 * 4);
-  if (gx > 1024) gx = 1024;
+  if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(absmax_kernel, dim3(gx), dim3(256), 0, st, x, n / 4, reinterpret_cast<unsigned*>(out));
   SB_CHECK_LAUNCH();
   return 0;

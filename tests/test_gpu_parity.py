@@ -342,3 +342,34 @@ def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, monkeypatch):
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < TOL_GRAD, worst
+
+
+def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu):
+    """sb_absmax feeds the power-of-two scale of the compact (fp16) dgates: exact max |x|, and the backward pair
+    (recurrence -> stream) gives the same weight gradients / dU as the fp32-dgates pair within fp16 rounding,
+    also for gradients far outside the fp16 range (1e-9 and 1e+6 magnitudes)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(4 * 1237, device="cuda") * 3
+    x[1000] = -17.5
+    assert float(ops.absmax(x)) == 17.5
+    C_, F_, T_ = 32, 145, 20
+    geom = ops.Geom.inter(2, T_, F_)
+    xin = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.ones(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    dirs = [tuple(t.cuda() for t in (torch.randn(256, C_) * 0.2, torch.randn(256, 64) * 0.2, torch.zeros(256), torch.zeros(256)))]
+    hs, _, gates, u = ops.lstm_fwd(xin, g, b, dirs, geom, save=True)
+    for mag in (1e-9, 1.0, 1e6):
+        dhs = torch.randn_like(hs) * mag
+        outs = []
+        for fp16 in (False, True):
+            ops.DGATES_FP16 = fp16
+            dg = ops.lstm_bwd_rec([dirs[0][1]], gates, dhs, geom)
+            assert (dg.gmax is not None) == fp16
+            grads, du = ops.lstm_bwd_stream(dg, u, hs, [dirs[0][0]], F_, T_ * F_, F_)
+            outs.append([t.cpu().numpy() for t in grads[0]] + [du.cpu().numpy()])
+        ops.DGATES_FP16 = True
+        for a_, b_ in zip(*outs):
+            assert np.isfinite(b_).all()
+            assert rel_l2(b_, a_) < 1e-3, mag
