@@ -293,10 +293,12 @@ def main():
             if ks:                                            # HBM bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)
                 traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 traffic_src = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc pass of this command, committed)"
-        # The recurrent kernels run on the bf16 matrix pipe with exact 3-way operand splits: 6 bf16 MFMA flops are
-        # ISSUED per algorithmic fp32 flop (ops.LSTM_MMA == 1); with SB_LSTM_FP32=1 they use the fp32-input MFMA.
-        bf = ops.LSTM_MMA == 1
-        issued = ach * (6.0 if bf else 1.0)
+        # The recurrent forward runs on the 16-bit matrix pipe with split operands: fp16 hi+lo, 3 products per fp32 MAC
+        # (default, ops.LSTM_MMA == 1) or bf16 3-way, 6 products (SB_LSTM_BF16X6=1) -- that many MFMA flops are ISSUED
+        # per algorithmic flop; with SB_LSTM_FP32=1 the fp32-input MFMA is used.
+        bf = ops.LSTM_MMA in (1, 2)
+        nprod = {0: 1.0, 1: 3.0, 2: 6.0}[ops.LSTM_MMA]
+        issued = ach * nprod
         peak = MFMA_BF16_PEAK if bf else MFMA_F32_PEAK
         out = {
             "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if args.forward_only else "train-step"),
@@ -308,8 +310,9 @@ def main():
                                    f"{'forward only' if args.forward_only else 'fwd+SNRLP+bwd+clip+Adam'}",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("lstm_fwd_bf_kernel (bf16 MFMA, exact 3-way split, 6 products per fp32 MAC)" if bf
-                                    else "lstm_fwd_kernel (fp32-input MFMA)") + ", intra+inter launches",
+                         "kernel": ({1: "lstm_fwd_bf_kernel (fp16 MFMA, hi+lo operand split, 3 products per fp32 MAC)",
+                                     2: "lstm_fwd_bf_kernel (bf16 MFMA, 3-way operand split, 6 products per fp32 MAC)",
+                                     0: "lstm_fwd_kernel (fp32-input MFMA)"}[ops.LSTM_MMA]) + ", intra+inter launches",
                          "achieved": issued / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": issued / peak,
                          "algorithmic_tflops": ach / 1e12, "algorithmic_frac_of_fp32_peak": ach / MFMA_F32_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

@@ -45,8 +45,9 @@ typedef struct {
   const float* w_ih[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2];
   const float* h0; const float* c0; float* hN; float* cN;
   float* hs; float* save_gates; float* save_u; float* save_c;
-  int mma;   /* 0: fp32-input MFMA (exact fma chain); 1: bf16 matrix pipe, exact 3-way operand split, 6 products
-                (fp32-class rounding, ~2.7x fewer matrix cycles, overlaps the VALU) */
+  int mma;   /* 0: fp32-input MFMA (exact fma chain); 1: fp16 matrix pipe, operands split hi+lo (11+11 bits), 3 products
+                per MAC (dropped term <= 2^-22; default); 2: bf16 matrix pipe, 3-way split (8+8+8 bits), 6 products
+                (dropped terms <= 2^-24) */
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 

@@ -63,7 +63,50 @@ SB_DEVINL SplitH splith8(const float (&x)[8]) {
   return s;
 }
 
-constexpr int UP = 32 + 8;    // padded bf16 row of the input-term tiles  (80 B)
+// Operand format of the forward split products.
+//   F16 = false: bf16, x = t0 + t1 + t2 (8+8+8 bits), six products, dropped terms <= 2^-24  ("bf16x6", fp32-exact class)
+//   F16 = true : fp16, x = t0 + t1      (11+11 bits), three products, dropped term   <= 2^-22  ("fp16x3"): half the
+//                MFMAs and a cheaper split; fp16 range is ample for LayerNorm outputs, hidden states in (-1, 1) and
+//                the weights, and an underflowing low term costs < 6e-8 absolute.
+template <bool F16> struct Prec;
+template <> struct Prec<false> {
+  typedef __bf16 elem;
+  typedef bf16x8 vec8;
+  typedef bf16x4 vec4;
+  static constexpr int NT = 3;
+  static SB_DEVINL f32x4 mma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Prec<true> {
+  typedef _Float16 elem;
+  typedef h16x8 vec8;
+  typedef h16x4 vec4;
+  static constexpr int NT = 2;
+  static SB_DEVINL f32x4 mma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <bool F16> struct SplitN { typename Prec<F16>::vec8 t[Prec<F16>::NT]; };      // t[0] = leading term
+template <bool F16>
+SB_DEVINL void splitn1(float x, typename Prec<F16>::elem (&out)[Prec<F16>::NT]) {
+  float r = x;
+#pragma unroll
+  for (int k = 0; k < Prec<F16>::NT; ++k) {
+    out[k] = (typename Prec<F16>::elem)r;
+    r -= (float)out[k];
+  }
+}
+template <bool F16>
+SB_DEVINL SplitN<F16> splitn8(const float (&x)[8]) {
+  SplitN<F16> s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    typename Prec<F16>::elem e[Prec<F16>::NT];
+    splitn1<F16>(x[k], e);
+#pragma unroll
+    for (int n = 0; n < Prec<F16>::NT; ++n) s.t[n][k] = e[n];
+  }
+  return s;
+}
+
+constexpr int UP = 32 + 8;    // padded 16-bit row of the input-term tiles  (80 B)
 constexpr int HP16 = 64 + 8;  // padded bf16 row of the hidden-term tiles (144 B)
 
 template <int C>
@@ -73,39 +116,44 @@ struct XVec { float v[C / 16]; };
 // chains that share the weight registers; the instruction stream of one tile's cell update fills the issue gaps
 // of the other tile's MFMAs (a single wave issues about one instruction per 4 cycles, so a lone chain is issue-
 // and latency-bound).  Used when the grid has more tiles than the chip has CUs.
-template <int C, int SAVE, bool FULL, int TILES>
+template <int C, int SAVE, bool FULL, int TILES, bool F16>
 __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
+  typedef Prec<F16> PR;
+  typedef typename PR::elem elem;
+  typedef typename PR::vec8 vec8;
+  typedef typename PR::vec4 vec4;
+  constexpr int NT = PR::NT;
   constexpr int VPT = C / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int S = a.nsteps;
   const bool rev = dir == 1;
 
-  __shared__ __attribute__((aligned(16))) __bf16 U16[TILES][2][3][16][UP];      // [tile][buf][term][seq][channel]
-  __shared__ __attribute__((aligned(16))) __bf16 H16[TILES][2][3][16][HP16];    // [tile][buf][term][seq][unit]
+  __shared__ __attribute__((aligned(16))) elem U16[TILES][2][NT][16][UP];      // [tile][buf][term][seq][channel]
+  __shared__ __attribute__((aligned(16))) elem H16[TILES][2][NT][16][HP16];    // [tile][buf][term][seq][unit]
   __shared__ __attribute__((aligned(16))) float Bias[4][H];
 
   // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
   const float* __restrict__ wih = a.w_ih[dir];
   const float* __restrict__ whh = a.w_hh[dir];
-  Split3 Wt[4][3];
+  SplitN<F16> Wt[4][3];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int row = g * H + 16 * w + j;
     float t[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) t[kk] = (8 * q + kk < C) ? wih[(size_t)row * C + 8 * q + kk] : 0.f;
-    Wt[g][0] = split8(t);
+    Wt[g][0] = splitn8<F16>(t);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) t[kk] = whh[(size_t)row * H + 32 * c + 8 * q + kk];
-      Wt[g][1 + c] = split8(t);
+      Wt[g][1 + c] = splitn8<F16>(t);
     }
   }
   if (tid < 4 * H) Bias[tid >> 6][tid & 63] = a.b_ih[dir][tid] + a.b_hh[dir][tid];
   // zero the padded channels of the input tiles once (C = 16: channels 16..31 stay zero)
-  for (int i = tid; i < TILES * 2 * 3 * 16 * UP; i += 256) (&U16[0][0][0][0][0])[i] = (__bf16)0.f;
+  for (int i = tid; i < TILES * 2 * NT * 16 * UP; i += 256) (&U16[0][0][0][0][0])[i] = (elem)0.f;
   __syncthreads();
 
   // ---- loader role ----
@@ -143,11 +191,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       u[v] = (xv.v[v] - mean) * rstd * gam[v] + bet[v];
-      __bf16 h, m, l;
-      split1(u[v], h, m, l);
-      U16[t][buf][0][ls][cpart * VPT + v] = h;
-      U16[t][buf][1][ls][cpart * VPT + v] = m;
-      U16[t][buf][2][ls][cpart * VPT + v] = l;
+      elem e[NT];
+      splitn1<F16>(u[v], e);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) U16[t][buf][n][ls][cpart * VPT + v] = e[n];
     }
     if (SAVE && lvalid[t] && dir == 0) {      // both directions normalise the same rows: one copy is enough
       const int st = rev ? S - 1 - s : s;
@@ -175,53 +222,49 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
   }
   auto store_h = [&](int t, int buf, const f32x4& hv) {   // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
-    bf16x4 th, tm, tl;
+    vec4 tv[NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { __bf16 x0, x1, x2; split1(hv[r], x0, x1, x2); th[r] = x0; tm[r] = x1; tl[r] = x2; }
-    *reinterpret_cast<bf16x4*>(&H16[t][buf][0][j][uoff]) = th;
-    *reinterpret_cast<bf16x4*>(&H16[t][buf][1][j][uoff]) = tm;
-    *reinterpret_cast<bf16x4*>(&H16[t][buf][2][j][uoff]) = tl;
+    for (int r = 0; r < 4; ++r) {
+      elem e[NT];
+      splitn1<F16>(hv[r], e);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) tv[n][r] = e[n];
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) *reinterpret_cast<vec4*>(&H16[t][buf][n][j][uoff]) = tv[n];
   };
   // acc[g] += W[g][chunk] * B (6-term split product).  The four gate accumulators are walked round-robin and the
   // groups are fenced against MFMA reordering (mask: everything but MFMA may cross): hipcc otherwise chains all 12
   // products of a gate back to back on one accumulator, and any VALU instruction that lands between two MFMAs on
   // the SAME accumulator costs ~40 cycles.
   constexpr int kNoMfmaCross = 0x7F6;
-  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const vec8 (&b)[NT]) {
+    // (weight term, operand term) pairs, smallest products first
+    constexpr int NP = F16 ? 3 : 6;
+    constexpr int WT[6] = {F16 ? 1 : 2, F16 ? 0 : 0, F16 ? 0 : 1, 1, 0, 0};
+    constexpr int XT[6] = {F16 ? 0 : 0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].l, bh, acc[g]);
-    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
+    for (int pi = 0; pi < NP; ++pi) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bl, acc[g]);
-    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].m, bm, acc[g]);
-    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].m, bh, acc[g]);
-    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bm, acc[g]);
-    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = mma(Wt[g][chunk].h, bh, acc[g]);
-    __builtin_amdgcn_sched_barrier(kNoMfmaCross);
+      for (int g = 0; g < 4; ++g) acc[g] = PR::mma(Wt[g][chunk].t[WT[pi]], b[XT[pi]], acc[g]);
+      __builtin_amdgcn_sched_barrier(kNoMfmaCross);
+    }
   };
   auto x_part = [&](int t, f32x4 (&acc)[4], int buf) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = ld4(&Bias[g][uoff]);
-    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&U16[t][buf][0][j][8 * q]);
-    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&U16[t][buf][1][j][8 * q]);
-    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&U16[t][buf][2][j][8 * q]);
-    mma6(acc, 0, bh, bm, bl);
+    vec8 b[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&U16[t][buf][n][j][8 * q]);
+    mma6(acc, 0, b);
   };
   auto h_part = [&](int t, f32x4 (&acc)[4], int buf) {
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&H16[t][buf][0][j][32 * ck + 8 * q]);
-      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&H16[t][buf][1][j][32 * ck + 8 * q]);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&H16[t][buf][2][j][32 * ck + 8 * q]);
-      mma6(acc, 1 + ck, bh, bm, bl);
+      vec8 b[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[t][buf][n][j][32 * ck + 8 * q]);
+      mma6(acc, 1 + ck, b);
     }
   };
 
@@ -588,15 +631,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 // launch helpers used by sb_lstm.hip's C entry points (same argument structs)
 int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
   const int ntiles = (a.nseq + 15) / 16;
-  // SB_LSTM_TILES=2: two tiles per workgroup (experimental; measured slower than two co-resident workgroups
-  // except for the training-mode inter-frame pass of the small config, +8 %)
-  static const int forced = [] { const char* e = getenv("SB_LSTM_TILES"); return e ? atoi(e) : 0; }();
-  const int tiles = forced == 2 ? 2 : 1;
-  const bool full = a.nseq % (16 * tiles) == 0;
+  const bool full = a.nseq % 16 == 0;
+  const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
   const int save = a.save_gates == nullptr ? 0 : (a.save_c ? 2 : 1);
-  dim3 grid((ntiles + tiles - 1) / tiles, a.ndir);
-#define SB_L(CC, SV, FL, TL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, TL>), grid, dim3(256), 0, st, a)
-#define SB_LT(CC, SV, FL) do { if (tiles == 2) SB_L(CC, SV, FL, 2); else SB_L(CC, SV, FL, 1); } while (0)
+  dim3 grid(ntiles, a.ndir);
+#define SB_L(CC, SV, FL, HF) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, 1, HF>), grid, dim3(256), 0, st, a)
+#define SB_LT(CC, SV, FL) do { if (f16) SB_L(CC, SV, FL, true); else SB_L(CC, SV, FL, false); } while (0)
 #define SB_LC(CC) do { \
     if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
     else if (save == 1) { if (full) SB_LT(CC, 1, true); else SB_LT(CC, 1, false); } \

@@ -15,7 +15,8 @@ H = 64
 # BPTT record format: compact (fp16 gates + fp32 c_prev, 768 B/step) unless SB_EXACT_BPTT=1 (fp32, 1280 B/step)
 COMPACT_BPTT = os.environ.get("SB_EXACT_BPTT", "0") != "1"
 # recurrent GEMMs: bf16 matrix pipe with exact 3-way split / 6 products (fp32-class) unless SB_LSTM_FP32=1
-LSTM_MMA = 0 if os.environ.get("SB_LSTM_FP32", "0") == "1" else 1
+# forward operand split: fp16 hi+lo, 3 products (default, 2^-22) or SB_LSTM_BF16X6=1: bf16 3-way, 6 products (2^-24)
+LSTM_MMA = 0 if os.environ.get("SB_LSTM_FP32", "0") == "1" else (2 if os.environ.get("SB_LSTM_BF16X6", "0") == "1" else 1)
 PROFILE_LSTM = None     # bench.py: list collecting (start_event, end_event, algorithmic_flops) per launch
 
 
@@ -101,7 +102,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
 
 def can_fuse_linear_bwd():
     """the recurrent backward can form d(hs) = dy . W_lin on the fly (bf16 split path, compact-BPTT mode)"""
-    return LSTM_MMA == 1 and COMPACT_BPTT
+    return LSTM_MMA in (1, 2) and COMPACT_BPTT
 
 
 # compact-BPTT mode on the bf16 path: dgates travel between the two backward kernels as fp16, scaled by a power of
@@ -129,7 +130,7 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
     ndir = len(w_hh_list)
     dev = dhs.device if dhs is not None else dy.device
     rec, cprev = gates
-    dg16 = DGATES_FP16 and LSTM_MMA == 1 and cprev is not None
+    dg16 = DGATES_FP16 and LSTM_MMA in (1, 2) and cprev is not None
     gmax = absmax(dy if dy is not None else dhs) if dg16 else None
     dg = torch.empty(geom.P, ndir, 4, H, device=dev, dtype=torch.float16 if dg16 else torch.float32)
     a = L.LstmBwdArgs()
