@@ -347,7 +347,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
           *reinterpret_cast<h16x8*>(rec) = lo;
           *reinterpret_cast<h16x8*>(rec + 8) = hi;
-          st4(a.save_c + (pos * ndir + dir) * H + uoff, cprev[t]);
+          h16x4 c16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c16[r] = (_Float16)cprev[t][r];
+          *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.save_c) + (pos * ndir + dir) * H + uoff) = c16;
         }
       }
     }
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
   }
 
-  struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; };
+  struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; h16x4 cp16; };
   auto load_raw = [&](int s) {
     Raw r;
     const int st = rev ? S - 1 - s : s;
@@ -455,8 +458,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       if constexpr (REC16) {
         const float* rec = a.save_gates + ((pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16) / 2;
         r.r0 = ld4(rec); r.r1 = ld4(rec + 4);
-        r.r2 = r.r3 = zero4();
-        r.cp = ld4(a.save_c + (pos * ndir + dir) * H + uoff);
+        r.r2 = r.r3 = r.cp = zero4();
+        r.cp16 = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(a.save_c) + (pos * ndir + dir) * H + uoff);
       } else {
         const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
         r.r0 = ld4(rec); r.r1 = ld4(rec + H); r.r2 = ld4(rec + 2 * H); r.r3 = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
@@ -473,6 +476,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       }
     } else {
       r.r0 = r.r1 = r.r2 = r.r3 = r.cp = r.dh = r.dy1 = zero4();
+      r.cp16 = h16x4{0, 0, 0, 0};
     }
     return r;
   };
@@ -486,7 +490,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // steps and issues both records of the next pair at its top, so the register copies hipcc places at the end of
   // the body (loop-carried values) only touch loads that are two steps old.
   auto consume = [&](Raw& raw) {      // pins the s_waitcnt of this record here
-    asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.cp), "+v"(raw.dh));
+    asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.dh));
+    if constexpr (REC16) asm volatile("" : "+v"(raw.cp16)); else asm volatile("" : "+v"(raw.cp));
     if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
   };
@@ -521,12 +526,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float dh = dhext[r] + dhrec[r];
-      const float cc = gf[r] * raw.cp[r] + gi[r] * gg[r];
+      const float cpr = REC16 ? (float)raw.cp16[r] : raw.cp[r];
+      const float cc = gf[r] * cpr + gi[r] * gg[r];
       const float tc = tanhf_fast(cc);
       const float dO = dh * tc;
       const float dct = dc[r] + dh * go[r] * (1.0f - tc * tc);
       dG[0][r] = dct * gg[r] * gi[r] * (1.0f - gi[r]);
-      dG[1][r] = dct * raw.cp[r] * gf[r] * (1.0f - gf[r]);
+      dG[1][r] = dct * cpr * gf[r] * (1.0f - gf[r]);
       dG[2][r] = dct * gi[r] * (1.0f - gg[r] * gg[r]);
       dG[3][r] = dO * go[r] * (1.0f - go[r]);
       dc[r] = dct * gf[r];

@@ -72,7 +72,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     gates = cprev = None
     if save and COMPACT_BPTT:
         gates = torch.empty(geom.P, ndir, 4 * H, device=dev, dtype=torch.float16)
-        cprev = torch.empty(geom.P, ndir, H, device=dev, dtype=torch.float32)
+        cprev = torch.empty(geom.P, ndir, H, device=dev, dtype=torch.float16 if LSTM_MMA else torch.float32)
     elif save:
         gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32)
     u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32) if save else None
@@ -86,7 +86,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         assert wi.shape == (4 * H, Cc) and wh.shape == (4 * H, H)
         a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
     a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
-    a.hs, a.save_u, a.save_c = _p(hs), _p(u if u is not None else PHASE_TIMING_BUF), _p(cprev)
+    a.hs, a.save_u = _p(hs), _p(u if u is not None else PHASE_TIMING_BUF)
+    a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.mma = LSTM_MMA
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
     prof = PROFILE_LSTM
@@ -138,7 +139,8 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
     for d, wh in enumerate(w_hh_list):
         a.w_hh[d] = _p(wh)
-    a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), _p(cprev)
+    a.save_gates = C.c_void_p(rec.data_ptr())
+    a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.dhs, a.dgates = _p(dhs), C.c_void_p(dg.data_ptr())
     a.gmax = _p(gmax)
     a.mma = LSTM_MMA
