@@ -1,19 +1,20 @@
-// Recurrent LSTM kernels on the bf16 matrix pipe with EXACT-CLASS split products ("bf16x6").
+// Recurrent LSTM kernels on the 16-bit matrix pipes with split fp32 operands.
 //
 // Why: on gfx950 the fp32-input MFMA runs at the fp32 vector rate and does not overlap the cell-update VALU work
 // of a co-resident wave (measured: two workgroups per CU give no throughput over one), so the fp32 kernels in
-// sb_lstm.hip top out at ~45-65 % of the 157 TFLOP/s fp32 peak.  The bf16 matrix pipe is 16x faster and truly
-// concurrent with the VALU.  Every fp32 operand is split EXACTLY into three bf16 terms
-//        x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (8 + 8 + 8 mantissa bits)
-// and a*b is evaluated as  l*h + h*l + m*m + m*h + h*m + h*h  (the three dropped terms are <= 2^-24 relative),
-// each bf16 x bf16 product being exact in the fp32 accumulator.  The result is fp32-class (same order of rounding
-// error as an fp32 fma chain) -- required here because the recurrence amplifies rounding noise over 625 steps and
-// the parity bar is 1e-3 on the output -- at 6/16 of the fp32-MFMA cycles per flop, overlappable with the VALU.
+// sb_lstm.hip top out at ~45-65 % of the 157 TFLOP/s fp32 peak.  The bf16 / fp16 matrix pipes are 16x faster and
+// truly concurrent with the VALU.  Every fp32 operand is split into 16-bit terms and the product evaluated term by
+// term, each 16-bit x 16-bit product being exact in the fp32 accumulator:
+//   fp16x3 (default):      x = hi + lo  (11 + 11 mantissa bits),  a*b = lo*hi + hi*lo + hi*hi   (dropped <= 2^-22)
+//   bf16x6 (SB_LSTM_BF16X6): x = h + m + l (8 + 8 + 8 bits),  a*b = l*h + h*l + m*m + m*h + h*m + h*h (<= 2^-24)
+// Both are fp32-class for this network (identical measured error against the reference goldens, 9e-7 .. 3e-6 rel-L2
+// on the output): required because the recurrence amplifies rounding noise over 625 steps and the parity bar is 1e-3.
+// In compact-BPTT mode the backward recurrence additionally carries its dgates as (scaled) fp16 -- see below.
 //
-// v_mfma_f32_16x16x32_bf16: A lane l holds A[i = l&15][k = 8*(l>>4)..+7], B lane l holds B[k = 8*(l>>4)..+7][j = l&15],
+// v_mfma_f32_16x16x32_{bf16,f16}: A lane l holds A[i = l&15][k = 8*(l>>4)..+7], B lane l holds B[k = 8*(l>>4)..+7][j = l&15],
 // C/D as in sb_common.h.  K is walked in chunks of 32: chunk 0 = the (LayerNormed) input u (zero-padded to 32),
-// chunks 1,2 = the hidden state.  The step pipeline (A: hidden part, B: next input part || cell update || next
-// LayerNorm, C: stores + prefetch + barrier) is the one of sb_lstm.hip.
+// chunks 1,2 = the hidden state.  Step pipeline: A: hidden part (MFMA) with the LayerNorm of row s+2 in its issue
+// gaps; B: input part of step s+1 (MFMA) || cell update; C: h -> LDS, stores, barrier.
 #include <cstdlib>
 #include "sb_common.h"
 #include "../../include/sound_bubble_hip.h"
@@ -107,16 +108,12 @@ SB_DEVINL SplitN<F16> splitn8(const float (&x)[8]) {
 }
 
 constexpr int UP = 32 + 8;    // padded 16-bit row of the input-term tiles  (80 B)
-constexpr int HP16 = 64 + 8;  // padded bf16 row of the hidden-term tiles (144 B)
+constexpr int HP16 = 64 + 8;  // padded 16-bit row of the hidden-term tiles (144 B)
 
 template <int C>
 struct XVec { float v[C / 16]; };
 
-// TILES = 1 or 2 tiles of 16 sequences per workgroup.  With two tiles the waves carry two independent recurrence
-// chains that share the weight registers; the instruction stream of one tile's cell update fills the issue gaps
-// of the other tile's MFMAs (a single wave issues about one instruction per 4 cycles, so a lone chain is issue-
-// and latency-bound).  Used when the grid has more tiles than the chip has CUs.
-template <int C, int SAVE, bool FULL, int TILES, bool F16>
+template <int C, int SAVE, bool FULL, bool F16>
 __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   typedef Prec<F16> PR;
   typedef typename PR::elem elem;
@@ -129,8 +126,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   const int S = a.nsteps;
   const bool rev = dir == 1;
 
-  __shared__ __attribute__((aligned(16))) elem U16[TILES][2][NT][16][UP];      // [tile][buf][term][seq][channel]
-  __shared__ __attribute__((aligned(16))) elem H16[TILES][2][NT][16][HP16];    // [tile][buf][term][seq][unit]
+  __shared__ __attribute__((aligned(16))) elem U16[2][NT][16][UP];      // [buf][term][seq][channel]
+  __shared__ __attribute__((aligned(16))) elem H16[2][NT][16][HP16];    // [buf][term][seq][unit]
   __shared__ __attribute__((aligned(16))) float Bias[4][H];
 
   // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
@@ -153,32 +150,31 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   }
   if (tid < 4 * H) Bias[tid >> 6][tid & 63] = a.b_ih[dir][tid] + a.b_hh[dir][tid];
   // zero the padded channels of the input tiles once (C = 16: channels 16..31 stay zero)
-  for (int i = tid; i < TILES * 2 * NT * 16 * UP; i += 256) (&U16[0][0][0][0][0])[i] = (elem)0.f;
+  for (int i = tid; i < 2 * NT * 16 * UP; i += 256) (&U16[0][0][0][0])[i] = (elem)0.f;
   __syncthreads();
 
   // ---- loader role ----
   const int ls = tid >> 4, cpart = tid & 15;
-  bool lvalid[TILES];
-  int64_t lbase[TILES];
-#pragma unroll
-  for (int t = 0; t < TILES; ++t) {
-    const int nl = (blockIdx.x * TILES + t) * 16 + ls;
-    lvalid[t] = FULL || nl < a.nseq;
-    lbase[t] = lvalid[t] ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
+  bool lvalid;
+  int64_t lbase;
+  {
+    const int nl = blockIdx.x * 16 + ls;
+    lvalid = FULL || nl < a.nseq;
+    lbase = lvalid ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
   }
   float gam[VPT], bet[VPT];
 #pragma unroll
   for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; bet[v] = a.ln_b[cpart * VPT + v]; }
 
-  auto load_x = [&](int t, int s) {
+  auto load_x = [&](int s) {
     XVec<C> r;
     const int st = rev ? S - 1 - s : s;
-    const float* p = a.x + (lbase[t] + (int64_t)st * a.p_step) * C + cpart * VPT;
+    const float* p = a.x + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) r.v[v] = lvalid[t] ? p[v] : 0.f;
+    for (int v = 0; v < VPT; ++v) r.v[v] = lvalid ? p[v] : 0.f;
     return r;
   };
-  auto ln_store = [&](int t, const XVec<C>& xv, int buf, int s) {
+  auto ln_store = [&](const XVec<C>& xv, int buf, int s) {
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) sum += xv.v[v];
@@ -194,11 +190,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       elem e[NT];
       splitn1<F16>(u[v], e);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) U16[t][buf][n][ls][cpart * VPT + v] = e[n];
+      for (int n = 0; n < NT; ++n) U16[buf][n][ls][cpart * VPT + v] = e[n];
     }
-    if (SAVE && lvalid[t] && dir == 0) {      // both directions normalise the same rows: one copy is enough
+    if (SAVE && lvalid && dir == 0) {      // both directions normalise the same rows: one copy is enough
       const int st = rev ? S - 1 - s : s;
-      float* p = a.save_u + (lbase[t] + (int64_t)st * a.p_step) * C + cpart * VPT;
+      float* p = a.save_u + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll
       for (int v = 0; v < VPT; ++v) p[v] = u[v];
     }
@@ -206,22 +202,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 
   // ---- compute role ----
   const int uoff = 16 * w + 4 * q;
-  bool cvalid[TILES];
-  int64_t cbase[TILES];
-  f32x4 c[TILES], h[TILES];
-#pragma unroll
-  for (int t = 0; t < TILES; ++t) {
-    const int nc = (blockIdx.x * TILES + t) * 16 + j;
-    cvalid[t] = FULL || nc < a.nseq;
-    cbase[t] = cvalid[t] ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
-    c[t] = zero4();
-    h[t] = zero4();
-    if (dir == 0 && cvalid[t]) {
-      if (a.c0) c[t] = ld4(a.c0 + (size_t)nc * H + uoff);
-      if (a.h0) h[t] = ld4(a.h0 + (size_t)nc * H + uoff);
+  bool cvalid;
+  int64_t cbase;
+  f32x4 c, h;
+  {
+    const int nc = blockIdx.x * 16 + j;
+    cvalid = FULL || nc < a.nseq;
+    cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    c = zero4();
+    h = zero4();
+    if (dir == 0 && cvalid) {
+      if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
+      if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
     }
   }
-  auto store_h = [&](int t, int buf, const f32x4& hv) {   // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
+  auto store_h = [&](int buf, const f32x4& hv) {   // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
     vec4 tv[NT];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -231,7 +226,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       for (int n = 0; n < NT; ++n) tv[n][r] = e[n];
     }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) *reinterpret_cast<vec4*>(&H16[t][buf][n][j][uoff]) = tv[n];
+    for (int n = 0; n < NT; ++n) *reinterpret_cast<vec4*>(&H16[buf][n][j][uoff]) = tv[n];
   };
   // acc[g] += W[g][chunk] * B (6-term split product).  The four gate accumulators are walked round-robin and the
   // groups are fenced against MFMA reordering (mask: everything but MFMA may cross): hipcc otherwise chains all 12
@@ -250,106 +245,100 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       __builtin_amdgcn_sched_barrier(kNoMfmaCross);
     }
   };
-  auto x_part = [&](int t, f32x4 (&acc)[4], int buf) {
+  auto x_part = [&](f32x4 (&acc)[4], int buf) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = ld4(&Bias[g][uoff]);
     vec8 b[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&U16[t][buf][n][j][8 * q]);
+    for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&U16[buf][n][j][8 * q]);
     mma6(acc, 0, b);
   };
-  auto h_part = [&](int t, f32x4 (&acc)[4], int buf) {
+  auto h_part = [&](f32x4 (&acc)[4], int buf) {
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
       vec8 b[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[t][buf][n][j][32 * ck + 8 * q]);
+      for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[buf][n][j][32 * ck + 8 * q]);
       mma6(acc, 1 + ck, b);
     }
   };
 
   // input rows are fetched two steps before their LayerNorm; the loop body covers a pair of steps and issues the
   // rows of the next pair at its top (see the backward kernel)
-  XVec<C> xa[TILES], xb[TILES];
-  f32x4 accx[TILES][4];
-#pragma unroll
-  for (int t = 0; t < TILES; ++t) {
-    store_h(t, 0, h[t]);
-    XVec<C> x0 = load_x(t, 0);
-    XVec<C> x1 = load_x(t, min(1, S - 1));
-    ln_store(t, x0, 0, 0);
-    ln_store(t, x1, 1, min(1, S - 1));
-    xa[t] = load_x(t, min(2, S - 1));
-    xb[t] = load_x(t, min(3, S - 1));
+  XVec<C> xa, xb;
+  f32x4 accx[4];
+  {
+    store_h(0, h);
+    XVec<C> x0 = load_x(0);
+    XVec<C> x1 = load_x(min(1, S - 1));
+    ln_store(x0, 0, 0);
+    ln_store(x1, 1, min(1, S - 1));
+    xa = load_x(min(2, S - 1));
+    xb = load_x(min(3, S - 1));
   }
   __syncthreads();
-#pragma unroll
-  for (int t = 0; t < TILES; ++t) x_part(t, accx[t], 0);
+  x_part(accx, 0);
 
   const int ndir = a.ndir;
 #ifdef SB_PHASE_TIMING
   unsigned long long tph[5] = {0, 0, 0, 0, 0};
 #endif
-  auto step = [&](int s, const XVec<C> (&xrow)[TILES]) {        // xrow: input row s+2
+  auto step = [&](int s, const XVec<C>& xrow) {        // xrow: input row s+2
     const int cur = s & 1;
     SB_TICK(c0);
     // ---- A: hidden part on the matrix pipe || LayerNorm of row s+2 in the issue gaps (it does not depend on
     //         this step; its U16[cur] buffer was last read in phase B of step s-1) ----
-    f32x4 acc[TILES][4];
+    f32x4 acc[4];
+    {
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[t][g] = accx[t][g];
-      ln_store(t, xrow[t], cur, min(s + 2, S - 1));
-      h_part(t, acc[t], cur);
+      for (int g = 0; g < 4; ++g) acc[g] = accx[g];
+      ln_store(xrow, cur, min(s + 2, S - 1));
+      h_part(acc, cur);
     }
-    if (TILES == 1) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c1);
     // ---- B: input part of step s+1 (matrix pipe) || cell update of step s (VALU) ----
-    f32x4 gi[TILES], gf[TILES], gg[TILES], go[TILES], cprev[TILES];
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-      x_part(t, accx[t], cur ^ 1);
-      cprev[t] = c[t];
+    f32x4 gi, gf, gg, go, cprev;
+    {
+      x_part(accx, cur ^ 1);
+      cprev = c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        gi[t][r] = sigmoidf_fast(acc[t][0][r]);
-        gf[t][r] = sigmoidf_fast(acc[t][1][r]);
-        gg[t][r] = tanhf_fast(acc[t][2][r]);
-        go[t][r] = sigmoidf_fast(acc[t][3][r]);
-        c[t][r] = gf[t][r] * c[t][r] + gi[t][r] * gg[t][r];
-        h[t][r] = go[t][r] * tanhf_fast(c[t][r]);
+        gi[r] = sigmoidf_fast(acc[0][r]);
+        gf[r] = sigmoidf_fast(acc[1][r]);
+        gg[r] = tanhf_fast(acc[2][r]);
+        go[r] = sigmoidf_fast(acc[3][r]);
+        c[r] = gf[r] * c[r] + gi[r] * gg[r];
+        h[r] = go[r] * tanhf_fast(c[r]);
       }
     }
-    if (TILES == 1) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c2);
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) store_h(t, cur ^ 1, h[t]);
-    if (TILES == 1) __builtin_amdgcn_sched_barrier(0);
+    store_h(cur ^ 1, h);
+    __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c3);
     // ---- C ----
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-      if (cvalid[t]) {
+    {
+      if (cvalid) {
         const int st = rev ? S - 1 - s : s;
-        const int64_t pos = cbase[t] + (int64_t)st * a.p_step;
-        st4(a.hs + (pos * ndir + dir) * H + uoff, h[t]);
+        const int64_t pos = cbase + (int64_t)st * a.p_step;
+        st4(a.hs + (pos * ndir + dir) * H + uoff, h);
         if (SAVE == 1) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
-          st4(rec, gi[t]); st4(rec + H, gf[t]); st4(rec + 2 * H, gg[t]); st4(rec + 3 * H, go[t]); st4(rec + 4 * H, cprev[t]);
+          st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
         } else if (SAVE == 2) {
           h16x8 lo, hi;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            lo[r] = (_Float16)gi[t][r]; lo[4 + r] = (_Float16)gf[t][r];
-            hi[r] = (_Float16)gg[t][r]; hi[4 + r] = (_Float16)go[t][r];
+            lo[r] = (_Float16)gi[r]; lo[4 + r] = (_Float16)gf[r];
+            hi[r] = (_Float16)gg[r]; hi[4 + r] = (_Float16)go[r];
           }
           _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
           *reinterpret_cast<h16x8*>(rec) = lo;
           *reinterpret_cast<h16x8*>(rec + 8) = hi;
           h16x4 c16;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) c16[r] = (_Float16)cprev[t][r];
+          for (int r = 0; r < 4; ++r) c16[r] = (_Float16)cprev[r];
           *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.save_c) + (pos * ndir + dir) * H + uoff) = c16;
         }
       }
@@ -364,11 +353,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   };
   int s = 0;
   for (; s + 1 < S; s += 2) {
-    XVec<C> ca[TILES], cb[TILES];
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) { ca[t] = xa[t]; cb[t] = xb[t]; }
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) { xa[t] = load_x(t, min(s + 4, S - 1)); xb[t] = load_x(t, min(s + 5, S - 1)); }
+    XVec<C> ca, cb;
+    { ca = xa; cb = xb; }
+    { xa = load_x(min(s + 4, S - 1)); xb = load_x(min(s + 5, S - 1)); }
     step(s, ca);
     step(s + 1, cb);
   }
@@ -379,12 +366,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     for (int i = 0; i < 5; ++i) d[i] = (float)tph[i] / S;
   }
 #endif
-#pragma unroll
-  for (int t = 0; t < TILES; ++t) {
-    const int nc = (blockIdx.x * TILES + t) * 16 + j;
-    if (dir == 0 && cvalid[t]) {
-      if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h[t]);
-      if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c[t]);
+  {
+    const int nc = blockIdx.x * 16 + j;
+    if (dir == 0 && cvalid) {
+      if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h);
+      if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c);
     }
   }
 }
@@ -641,7 +627,7 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
   const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
   const int save = a.save_gates == nullptr ? 0 : (a.save_c ? 2 : 1);
   dim3 grid(ntiles, a.ndir);
-#define SB_L(CC, SV, FL, HF) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, 1, HF>), grid, dim3(256), 0, st, a)
+#define SB_L(CC, SV, FL, HF) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF>), grid, dim3(256), 0, st, a)
 #define SB_LT(CC, SV, FL) do { if (f16) SB_L(CC, SV, FL, true); else SB_L(CC, SV, FL, false); } while (0)
 #define SB_LC(CC) do { \
     if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
