@@ -276,7 +276,11 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)                      // one atomic per workgroup: same-address atomics serialise in L2
+    atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -388,7 +392,7 @@ extern "C" int sb_absmax(const float* x, int64_t n, float* out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(out, 0, sizeof(float), st);
   unsigned gx = nblk(n / 4, 256 * 4);
-  if (gx > 2048) gx = 2048;
+  if (gx > 1024) gx = 1024;
   hipLaunchKernelGGL(absmax_kernel, dim3(gx), dim3(256), 0, st, x, n / 4, reinterpret_cast<unsigned*>(out));
   SB_CHECK_LAUNCH();
   return 0;
