@@ -49,6 +49,10 @@ typedef struct {
   int mma;   /* 0: fp32-input MFMA (exact fma chain); 1: fp16 matrix pipe, operands split hi+lo (11+11 bits), 3 products
                 per MAC (dropped term <= 2^-22; default); 2: bf16 matrix pipe, 3-way split (8+8+8 bits), 6 products
                 (dropped terms <= 2^-24) */
+  /* optional fusion of the Linear(64 -> C) + residual that follows a single-direction LSTM (mma == 1, ndir == 1):
+     when lin_w != NULL, y[p, :] = x[p, :] + lin_w[C, 64] . hs[p, :] + lin_b is written as well, and hs may be NULL
+     (inference).  tfgridnet_causal.py:843-849. */
+  const float* lin_w; const float* lin_b; float* y;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 

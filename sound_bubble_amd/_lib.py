@@ -19,7 +19,8 @@ class LstmFwdArgs(C.Structure):
                 ("x", c_fp), ("ln_g", c_fp), ("ln_b", c_fp),
                 ("w_ih", c_fp * 2), ("w_hh", c_fp * 2), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
                 ("h0", c_fp), ("c0", c_fp), ("hN", c_fp), ("cN", c_fp),
-                ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp), ("save_c", c_fp), ("mma", C.c_int)]
+                ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp), ("save_c", c_fp), ("mma", C.c_int),
+                ("lin_w", c_fp), ("lin_b", c_fp), ("y", c_fp)]
 
 
 class LstmBwdArgs(C.Structure):

@@ -348,7 +348,8 @@ extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
   if (a->C != 16 && a->C != 32) return -1002;
   if (a->save_gates && !a->save_u) return -1003;
   dim3 grid((a->nseq + 15) / 16, a->ndir);
-  if (a->mma == 1 || a->mma == 2) sb_launch_lstm_fwd_bf(*a, (hipStream_t)stream);
+  if (a->lin_w && a->mma != 1) return -1003;                         // fused Linear: fp16 path only
+  if (a->mma == 1 || a->mma == 2) { const int rc = sb_launch_lstm_fwd_bf(*a, (hipStream_t)stream); if (rc) return rc; }
   else if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);
   else launch_fwd<16>(*a, grid, (hipStream_t)stream);
   SB_CHECK_LAUNCH();

@@ -113,7 +113,10 @@ constexpr int HP16 = 64 + 8;  // padded 16-bit row of the hidden-term tiles (144
 template <int C>
 struct XVec { float v[C / 16]; };
 
-template <int C, int SAVE, bool FULL, bool F16>
+// LIN (single-direction passes): the Linear(64 -> C) + residual that follows the LSTM is applied in the kernel,
+// y[p] = x[p] + W_lin h[p] + b_lin, one step behind the recurrence from the hidden-state tiles that are in LDS anyway
+// (waves w < C/16 own channel tile w); hs is then only written when the caller wants it (training).
+template <int C, int SAVE, bool FULL, bool F16, bool LIN>
 __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   typedef Prec<F16> PR;
   typedef typename PR::elem elem;
@@ -149,6 +152,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
   }
   if (tid < 4 * H) Bias[tid >> 6][tid & 63] = a.b_ih[dir][tid] + a.b_hh[dir][tid];
+  const bool linw = LIN && w < C / 16;                  // this wave owns output channels 16w .. 16w+15 of y
+  SplitN<F16> Wl[2];
+  f32x4 lbias = zero4(), yacc = zero4(), xres = zero4();
+  if constexpr (LIN) {
+#pragma unroll
+    for (int ck = 0; ck < 2; ++ck) {
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = linw ? a.lin_w[(size_t)(16 * w + j) * H + 32 * ck + 8 * q + kk] : 0.f;
+      Wl[ck] = splitn8<F16>(t);
+    }
+    if (linw) lbias = ld4(a.lin_b + 16 * w + 4 * q);
+  }
   // zero the padded channels of the input tiles once (C = 16: channels 16..31 stay zero)
   for (int i = tid; i < 2 * NT * 16 * UP; i += 256) (&U16[0][0][0][0])[i] = (elem)0.f;
   __syncthreads();
@@ -260,6 +276,31 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[buf][n][j][32 * ck + 8 * q]);
       mma6(acc, 1 + ck, b);
+      if constexpr (LIN) {                             // W_lin . h of the step that produced this buffer
+        if (linw) {
+          if (ck == 0) yacc = zero4();
+          if constexpr (F16) {
+            yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
+            yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
+            yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
+          }
+        }
+      }
+    }
+  };
+  // y of step sy (its W_lin h is in yacc, its residual row in xres)
+  auto store_y = [&](int sy) {
+    if (linw && cvalid) {
+      const int st = rev ? S - 1 - sy : sy;
+      const int64_t pos = cbase + (int64_t)st * a.p_step;
+      st4(a.y + pos * C + 16 * w + 4 * q, yacc + lbias + xres);
+    }
+  };
+  auto load_res = [&](int sy) {
+    if (linw && cvalid) {
+      const int st = rev ? S - 1 - sy : sy;
+      const int64_t pos = cbase + (int64_t)st * a.p_step;
+      xres = ld4(a.x + pos * C + 16 * w + 4 * q);
     }
   };
 
@@ -322,7 +363,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       if (cvalid) {
         const int st = rev ? S - 1 - s : s;
         const int64_t pos = cbase + (int64_t)st * a.p_step;
-        st4(a.hs + (pos * ndir + dir) * H + uoff, h);
+        if (!LIN || a.hs) st4(a.hs + (pos * ndir + dir) * H + uoff, h);
         if (SAVE == 1) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
           st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
@@ -343,6 +384,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         }
       }
     }
+    if constexpr (LIN) {
+      if (s > 0) store_y(s - 1);
+      load_res(s);
+    }
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c4);
     __syncthreads();
@@ -360,6 +405,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     step(s + 1, cb);
   }
   if (s < S) step(s, xa);
+  if constexpr (LIN) {                                 // y of the last step from the final hidden-state tiles
+    f32x4 dummy[4] = {zero4(), zero4(), zero4(), zero4()};
+    if (linw) {
+#pragma unroll
+      for (int ck = 0; ck < 2; ++ck) {
+        vec8 b[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[S & 1][n][j][32 * ck + 8 * q]);
+        if (ck == 0) yacc = zero4();
+        if constexpr (F16) {
+          yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
+          yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
+          yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
+        }
+      }
+    }
+    (void)dummy;
+    store_y(S - 1);
+  }
 #ifdef SB_PHASE_TIMING
   if (SAVE == 0 && a.save_u && lane == 0 && blockIdx.x < 4) {
     float* d = a.save_u + (blockIdx.x * 4 + w) * 8;
@@ -627,8 +691,12 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
   const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
   const int save = a.save_gates == nullptr ? 0 : (a.save_c ? 2 : 1);
   dim3 grid(ntiles, a.ndir);
-#define SB_L(CC, SV, FL, HF) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF>), grid, dim3(256), 0, st, a)
-#define SB_LT(CC, SV, FL) do { if (f16) SB_L(CC, SV, FL, true); else SB_L(CC, SV, FL, false); } while (0)
+  const bool lin = a.lin_w != nullptr;
+  if (lin && (!f16 || a.ndir != 1 || !a.lin_b || !a.y)) return -1003;
+  if (!lin && !a.hs) return -1003;
+#define SB_L(CC, SV, FL, HF, LN) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN>), grid, dim3(256), 0, st, a)
+#define SB_LT(CC, SV, FL) do { if (lin) SB_L(CC, SV, FL, true, true); else if (f16) SB_L(CC, SV, FL, true, false); \
+                               else SB_L(CC, SV, FL, false, false); } while (0)
 #define SB_LC(CC) do { \
     if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
     else if (save == 1) { if (full) SB_LT(CC, 1, true); else SB_LT(CC, 1, false); } \

@@ -111,12 +111,16 @@ class InterFn(torch.autograd.Function):
         geom = Geom.inter(B, T, F)
         h0c = h0.reshape(B * F, H).contiguous() if h0 is not None else None
         c0c = c0.reshape(B * F, H).contiguous() if c0 is not None else None
-        hs, (hN, cN), gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, [(wi, wh, bi, bh)], geom, h0=h0c, c0=c0c,
-                                              save=train, want_state=True)
         y = torch.empty_like(x)
-        g, s_in = dense(P, H)
-        _, s_out = dense(P, Cc)
-        ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, H, Cc, epi=L.EPI_RES, res=x)
+        fuse = ops.can_fuse_linear_fwd()            # Linear + residual applied inside the recurrent kernel
+        hs, (hN, cN), gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, [(wi, wh, bi, bh)], geom, h0=h0c, c0=c0c,
+                                              save=train, want_state=True,
+                                              lin=(lin_w.contiguous(), lin_b, y) if fuse else None,
+                                              want_hs=train or not fuse)
+        if not fuse:
+            g, s_in = dense(P, H)
+            _, s_out = dense(P, Cc)
+            ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, H, Cc, epi=L.EPI_RES, res=x)
         if train:
             ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)

@@ -61,14 +61,22 @@ class Geom:
 PHASE_TIMING_BUF = None   # developer hook: scratch for a -DSB_PHASE_TIMING build (scripts/phase_timing.py)
 
 
-def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False):
+def can_fuse_linear_fwd():
+    """the single-direction forward kernel can apply the following Linear + residual itself (fp16 split path)"""
+    return LSTM_MMA == 1
+
+
+def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
-    -> hs [P, ndir*64], (hN, cN) or None, save_gates or None, save_u or None"""
+    lin = (lin_w [C, 64], lin_b [C], y [P, C]): fused  y = x + lin_w . hs + lin_b  (single direction,
+    can_fuse_linear_fwd()); with want_hs=False hs is then not materialised.
+    -> hs [P, ndir*64] (or None), (hN, cN) or None, save_gates or None, save_u or None"""
     lib = L.load()
     ndir, Cc = len(dirs), x.shape[-1]
     assert x.numel() == geom.P * Cc
     dev = x.device
-    hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float32)
+    assert want_hs or lin is not None
+    hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float32) if want_hs else None
     gates = cprev = None
     if save and COMPACT_BPTT:
         gates = torch.empty(geom.P, ndir, 4 * H, device=dev, dtype=torch.float16)
@@ -89,6 +97,9 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     a.hs, a.save_u = _p(hs), _p(u if u is not None else PHASE_TIMING_BUF)
     a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.mma = LSTM_MMA
+    if lin is not None:
+        assert can_fuse_linear_fwd() and ndir == 1 and lin[0].shape == (Cc, H)
+        a.lin_w, a.lin_b, a.y = _p(lin[0]), _p(lin[1]), _p(lin[2])
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
     prof = PROFILE_LSTM
     if prof is not None:
