@@ -279,9 +279,9 @@ def main():
         ms = dt / args.steps * 1e3
         utt_s = world * B * args.steps / dt
         # dominant kernel: recurrent LSTM forward (all launches: intra + inter), HIP events on the launch stream
-        lstm_ms = [a.elapsed_time(b) for a, b, _ in ev]
-        lstm_flops = [f for _, _, f in ev]
-        tot_ms, tot_fl = sum(lstm_ms), sum(lstm_flops)
+        lstm_ms = [e[0].elapsed_time(e[1]) for e in ev]
+        lstm_flops = [e[2] for e in ev]
+        tot_ms, tot_fl, tot_by = sum(lstm_ms), sum(lstm_flops), sum(e[3] for e in ev)
         n_launch = max(1, len(ev))
         ach = tot_fl / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
         fpu, bpu = fwd_flops_per_utt(params), fwd_bytes_per_utt(params)
@@ -293,13 +293,21 @@ def main():
             if ks:                                            # HBM bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)
                 traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 traffic_src = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc pass of this command, committed)"
-        # The recurrent forward runs on the 16-bit matrix pipe with split operands: fp16 hi+lo, 3 products per fp32 MAC
-        # (default, ops.LSTM_MMA == 1) or bf16 3-way, 6 products (SB_LSTM_BF16X6=1) -- that many MFMA flops are ISSUED
-        # per algorithmic flop; with SB_LSTM_FP32=1 the fp32-input MFMA is used.
-        bf = ops.LSTM_MMA in (1, 2)
+        # Which roof binds the dominant kernel (recurrent LSTM forward, intra + inter launches)?
+        #  * train step: it writes the BPTT records -- the intra-frame launches are HBM-write bound, the PMC traffic equals
+        #    the algorithmic bytes (profiles/) -> "hbm": algorithmic bytes per launch / launch time against 8 TB/s;
+        #  * forward only: nothing but hs / y leaves the chip -> "mfma": the kernel runs on the 16-bit matrix pipe with
+        #    split operands (fp16 hi+lo, 3 products per fp32 MAC by default; bf16 3-way, 6 products with SB_LSTM_BF16X6=1;
+        #    fp32-input MFMA with SB_LSTM_FP32=1): ISSUED matrix flops against the dense peak of that pipe.
         nprod = {0: 1.0, 1: 3.0, 2: 6.0}[ops.LSTM_MMA]
+        mfma_peak = MFMA_BF16_PEAK if ops.LSTM_MMA else MFMA_F32_PEAK
         issued = ach * nprod
-        peak = MFMA_BF16_PEAK if bf else MFMA_F32_PEAK
+        gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        if args.forward_only:
+            roof = {"bound": "mfma", "achieved": issued / 1e12, "peak": mfma_peak / 1e12, "unit": "TFLOP/s",
+                    "frac": issued / mfma_peak}
+        else:
+            roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbs * 1e9 / HBM_PEAK}
         out = {
             "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if args.forward_only else "train-step"),
             "value": utt_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -309,17 +317,19 @@ def main():
                                    f"conv_lstm={params['conv_lstm']}, 6ch x 120000 samples, "
                                    f"{'forward only' if args.forward_only else 'fwd+SNRLP+bwd+clip+Adam'}",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma",
-                         "kernel": ({1: "lstm_fwd_bf_kernel (fp16 MFMA, hi+lo operand split, 3 products per fp32 MAC)",
-                                     2: "lstm_fwd_bf_kernel (bf16 MFMA, 3-way operand split, 6 products per fp32 MAC)",
-                                     0: "lstm_fwd_kernel (fp32-input MFMA)"}[ops.LSTM_MMA]) + ", intra+inter launches",
-                         "achieved": issued / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": issued / peak,
-                         "algorithmic_tflops": ach / 1e12, "algorithmic_frac_of_fp32_peak": ach / MFMA_F32_PEAK, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "launches": len(ev), "avg_launch_ms": tot_ms / n_launch,
-                         "algorithmic_flops_per_launch": tot_fl / n_launch,
-                         "step_flop_fraction": work_mult * fpu * utt_s / world / MFMA_F32_PEAK,
-                         "step_hbm_fraction": work_mult * bpu * utt_s / world / HBM_PEAK},
+            "roofline": dict(roof, **{
+                "kernel": ({1: "lstm_fwd_bf_kernel (fp16 MFMA, hi+lo operand split, 3 products per fp32 MAC)",
+                            2: "lstm_fwd_bf_kernel (bf16 MFMA, 3-way operand split, 6 products per fp32 MAC)",
+                            0: "lstm_fwd_kernel (fp32-input MFMA)"}[ops.LSTM_MMA]) + ", intra+inter launches",
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "launches": len(ev), "avg_launch_ms": tot_ms / n_launch,
+                "algorithmic_bytes_per_launch": tot_by / n_launch,
+                "algorithmic_flops_per_launch": tot_fl / n_launch,
+                "algorithmic_tflops": ach / 1e12, "algorithmic_frac_of_fp32_mfma_peak": ach / MFMA_F32_PEAK,
+                "issued_matrix_tflops": issued / 1e12, "issued_frac_of_matrix_peak": issued / mfma_peak,
+                "hbm_gbs": gbs, "hbm_frac": gbs * 1e9 / HBM_PEAK,
+                "step_flop_fraction": work_mult * fpu * utt_s / world / MFMA_F32_PEAK,
+                "step_hbm_fraction": work_mult * bpu * utt_s / world / HBM_PEAK}),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, args.workload)

@@ -108,7 +108,15 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * 4 * H * (Cc + H) * geom.P * ndir))
+        # algorithmic flops and compulsory HBM bytes of this launch
+        by = 4.0 * Cc * geom.P                                               # x rows (both directions share them)
+        by += geom.P * ndir * (4.0 * H if hs is not None else 0.0)           # hidden sequence out
+        if gates is not None:                                                # BPTT records + saved LayerNorm output
+            by += geom.P * ndir * (gates.element_size() * gates[0, 0].numel()
+                                   + (cprev.element_size() * H if cprev is not None else 0)) + 4.0 * Cc * geom.P
+        if lin is not None:
+            by += 2 * 4.0 * Cc * geom.P                                      # residual rows in, y out
+        prof.append((e0, e1, 2.0 * 4 * H * (Cc + H) * geom.P * ndir, by))
     return hs, ((hN, cN) if want_state else None), (gates, cprev), u
 
 
