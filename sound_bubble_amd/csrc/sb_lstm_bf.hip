@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   typedef typename PR::vec4 vec4;
   constexpr int NT = PR::NT;
   constexpr int VPT = C / 16;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int S = a.nsteps;
   const bool rev = dir == 1;
@@ -455,7 +455,7 @@ SB_DEVINL float grad_scale(const float* gmax) {
 
 template <bool FULL, bool REC16, int FUSE_C, bool DG16>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int n0 = blockIdx.x * 16;
   const int S = a.nsteps, ndir = a.ndir;
