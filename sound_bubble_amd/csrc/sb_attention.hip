@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ 
       for (int hh = 0; hh < 8; ++hh) part[hh] += hh == h ? v[k] : 0.f;
     }
   }
-  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = threadIdx.x & 63;
   for (int h = 0; h < Hh; ++h) { const float s = wave_sum(part[h]); if (ln == 0) red[wv][h] = s; }
   __syncthreads();
   if (threadIdx.x < Hh) stat[threadIdx.x][0] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / FD;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ 
 // attention core: grid (ceil(T/16), B*Hh)
 __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
   extern __shared__ __attribute__((aligned(16))) float PT[];     // [16 queries][NRp + 4]  scores -> probabilities
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int bh = blockIdx.y, t0 = blockIdx.x * 16;
   const int L = a.L, NRp = a.NRp, ldp = NRp + 4;
   const int rows = L - 1 + a.T;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
   const int HD = Hh * D, n = F * HD;
   const float invFD = 1.0f / (F * D);
   const float pa = prelu_a ? prelu_a[0] : 1.0f;
-  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = threadIdx.x & 63;
   const int fpi = 256 / HD;
   const bool active = (int)threadIdx.x < fpi * HD;
   const int fl = threadIdx.x / HD, hd = threadIdx.x % HD, h = hd / D, d = hd % D;
@@ -285,7 +285,7 @@ __device__ __forceinline__ f32x4 lds_times_rows(const float* Pl, int ldp, int nk
 // dQ (+ delta_t = sum_l p_l dp_l): grid (ceil(T/16), B*Hh), same tiling as the forward.
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(sb_attn_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) float SM[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int bh = blockIdx.y, t0 = blockIdx.x * 16;
   const int L = a.L, NRp = a.NRp, ldp = NRp + 4, rows = L - 1 + a.T;
   float* PT = SM;                       // [16 queries][ldp] probabilities
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(sb_attn_bwd_args a) {
 // 16 key rows r = L-1 + 16*bx + j gathers from the queries 16*bx .. 16*bx + L + 14 that attend to them.
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(sb_attn_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) float SM[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int bh = blockIdx.y, tb = blockIdx.x * 16;
   const int L = a.L, NRp = a.NRp, ldp = NRp + 4, rows = L - 1 + a.T;
   float* PT = SM;                       // [16 key rows][ldp queries]

@@ -30,7 +30,7 @@ SB_DEVINL int64_t pos_off(int64_t p, int T, int F, int64_t sb, int64_t st, int64
 template <int NT, int EPI>
 __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P) {
   extern __shared__ __attribute__((aligned(16))) float Wl[];   // [N][K+4]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int N = NT * 16, K = a.K, KP = K + 4;
   // stage weights
   for (int idx = tid * 4; idx < N * K; idx += 256 * 4) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
 template <int NTW, int KT1, int KT2>
 __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) {
   constexpr int KT = KT1 + KT2;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   f32x4 acc[NTW][KT];
   float csum[NTW];
 #pragma unroll

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
   constexpr int KX = C / 16;     // 16-wide K chunks of the input part
   constexpr int VPT = C / 16;    // floats per loader thread
   constexpr int CP = C + 4;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int n0 = blockIdx.x * 16;
   const int S = a.nsteps;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(sb_lstm_fwd_args a) {
 // is reduced across the 4 waves through LDS (one barrier per step).
 template <bool FULL, bool REC16>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_kernel(sb_lstm_bwd_args a) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int n0 = blockIdx.x * 16;
   const int S = a.nsteps, ndir = a.ndir;

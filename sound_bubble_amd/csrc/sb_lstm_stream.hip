@@ -22,7 +22,7 @@ template <int C, bool SMALLSEG>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16;            // u blocks
   constexpr int KT = CK + 4;            // + 4 h_prev blocks
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y, ndir = a.ndir;
   const int64_t P = a.P;
   __shared__ __attribute__((aligned(16))) float R[2][4][CK][64][4];
@@ -178,7 +178,7 @@ SB_DEVINL f32x4 mfma_bf3(const SplitBf& a, const SplitBf& b, f32x4 c) {
 template <int C, bool SMALLSEG>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_bf16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y, ndir = a.ndir;
   const int Pi = (int)a.P;
   __shared__ __attribute__((aligned(16))) float R[2][4][2][CK][64][4];
@@ -349,7 +349,7 @@ SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma
 template <int C, bool SMALLSEG>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y, ndir = a.ndir;
   const int Pi = (int)a.P;
   __shared__ __attribute__((aligned(16))) float R[2][4][2][CK][64][4];
