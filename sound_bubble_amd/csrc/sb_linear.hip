@@ -308,8 +308,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (i >= total) return;
   const int rper = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += partials[(size_t)r * total + i];
+  float s = 0.f, sa = 0.f, sb = 0.f, sc = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {                        // four independent loads in flight
+    s += partials[(size_t)r * total + i];
+    sa += partials[(size_t)(r + 1) * total + i];
+    sb += partials[(size_t)(r + 2) * total + i];
+    sc += partials[(size_t)(r + 3) * total + i];
+  }
+  for (; r < r1; ++r) s += partials[(size_t)r * total + i];
+  s += sa + sb + sc;
   if (i < N * Ktot) {
     const int n = i / Ktot, k = i - n * Ktot;
     if (k < K1) atomicAdd(dW1 + (transpose_out ? (size_t)k * N + n : (size_t)n * K1 + k), s);
@@ -321,17 +329,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ partials, int rows, int64_t ld, int n,
-                                   float* __restrict__ out, int tr_N, int tr_K) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[o(i)] += sum over rows of partials[r][i].  Block = 8 row lanes x 32 columns: eight rows are in flight per column
+// (a single thread per column walking all rows is latency-bound: ~180 ns per dependent load).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partials, int rows, int64_t ld, int n,
+                                                          float* __restrict__ out, int tr_N, int tr_K) {
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + col;
   const int rper = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += partials[(size_t)r * ld + i];
-  int o = i;
-  if (tr_N > 0) { const int nn = i / tr_K, kk = i - nn * tr_K; o = kk * tr_N + nn; }
-  atomicAdd(out + o, s);
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int r = r0 + rl;
+    for (; r + 8 < r1; r += 16) { s0 += partials[(size_t)r * ld + i]; s1 += partials[(size_t)(r + 8) * ld + i]; }
+    if (r < r1) s0 += partials[(size_t)r * ld + i];
+  }
+  __shared__ float red[8][32];
+  red[rl][col] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][col];
+    int o = i;
+    if (tr_N > 0) { const int nn = i / tr_K, kk = i - nn * tr_K; o = kk * tr_N + nn; }
+    atomicAdd(out + o, s);
+  }
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int64_t P, int64_t ldg, int N,
@@ -380,7 +402,7 @@ extern "C" int sb_wgrad_grid(int64_t positions) {
 }
 
 extern "C" int sb_reduce_rows(const float* partials, int rows, int64_t ld, int n, float* out, void* stream) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256, rows >= 64 ? 16 : 1), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 31) / 32, rows >= 512 ? 8 : 1), dim3(256), 0, (hipStream_t)stream,
                      partials, rows, ld, n, out, 0, 0);
   SB_CHECK_LAUNCH();
   return 0;
@@ -442,7 +464,7 @@ extern "C" int sb_colsum(const float* g, int64_t P, int64_t ldg, int N, float* o
   dim3 grid((unsigned)gx, (N + 63) / 64), block(256);
   hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, g, P, ldg, N, scratch);
   SB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, st, scratch, (int)gx, (int64_t)N, N,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 31) / 32, 1), dim3(256), 0, st, scratch, (int)gx, (int64_t)N, N,
                      out, 0, 0);
   SB_CHECK_LAUNCH();
   return 0;

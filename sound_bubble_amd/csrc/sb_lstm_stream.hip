@@ -513,8 +513,16 @@ __global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restr
   if (i >= total) return;
   const int rper = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += partials[(size_t)r * total + i];
+  float s = 0.f, sa = 0.f, sb = 0.f, sc = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {                        // four independent loads in flight
+    s += partials[(size_t)r * total + i];
+    sa += partials[(size_t)(r + 1) * total + i];
+    sb += partials[(size_t)(r + 2) * total + i];
+    sc += partials[(size_t)(r + 3) * total + i];
+  }
+  for (; r < r1; ++r) s += partials[(size_t)r * total + i];
+  s += sa + sb + sc;
   if (i < N * Ktot) {
     const int n = i / Ktot, k = i - n * Ktot;
     if (k < C) atomicAdd(dW1 + (size_t)n * C + k, s);
