@@ -38,8 +38,13 @@ SB_DEVINL void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 SB_DEVINL f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each): absolute error ~1e-7, far inside the 1e-3 parity bar
-SB_DEVINL float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-SB_DEVINL float tanhf_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// (v_exp_f32 is 2^x: the log2(e) factor and the sign are one multiply -- or none at all when the caller has folded
+//  them into the weights: *_pre take z = -log2(e) * x  resp.  z = -2 log2(e) * x)
+constexpr float SB_NLOG2E = -1.4426950408889634f;
+SB_DEVINL float sigmoid_pre(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)); }
+SB_DEVINL float tanh_pre(float z) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)) - 1.0f; }
+SB_DEVINL float sigmoidf_fast(float x) { return sigmoid_pre(SB_NLOG2E * x); }
+SB_DEVINL float tanhf_fast(float x) { return tanh_pre(2.0f * SB_NLOG2E * x); }
 
 // sum over the 4 lanes {l, l^16, l^32, l^48} (same l & 15): the feature quads of one position
 SB_DEVINL float quad_sum(float v) {

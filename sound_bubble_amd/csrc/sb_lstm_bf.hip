@@ -136,22 +136,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
   const float* __restrict__ wih = a.w_ih[dir];
   const float* __restrict__ whh = a.w_hh[dir];
+  // The activations are evaluated as rcp(1 + 2^z): the factors z = -log2(e) x (sigmoid gates i, f, o) and
+  // z = -2 log2(e) x (tanh gate g) are folded into the weight and bias rows here, once, instead of a multiply
+  // per gate value and step.
   SplitN<F16> Wt[4][3];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int row = g * H + 16 * w + j;
+    const float gsc = (g == 2 ? 2.0f : 1.0f) * SB_NLOG2E;
     float t[8];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) t[kk] = (8 * q + kk < C) ? wih[(size_t)row * C + 8 * q + kk] : 0.f;
+    for (int kk = 0; kk < 8; ++kk) t[kk] = (8 * q + kk < C) ? gsc * wih[(size_t)row * C + 8 * q + kk] : 0.f;
     Wt[g][0] = splitn8<F16>(t);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) t[kk] = whh[(size_t)row * H + 32 * c + 8 * q + kk];
+      for (int kk = 0; kk < 8; ++kk) t[kk] = gsc * whh[(size_t)row * H + 32 * c + 8 * q + kk];
       Wt[g][1 + c] = splitn8<F16>(t);
     }
   }
-  if (tid < 4 * H) Bias[tid >> 6][tid & 63] = a.b_ih[dir][tid] + a.b_hh[dir][tid];
+  if (tid < 4 * H) Bias[tid >> 6][tid & 63] = ((tid >> 6) == 2 ? 2.0f : 1.0f) * SB_NLOG2E * (a.b_ih[dir][tid] + a.b_hh[dir][tid]);
   const bool linw = LIN && w < C / 16;                  // this wave owns output channels 16w .. 16w+15 of y
   SplitN<F16> Wl[2];
   f32x4 lbias = zero4(), yacc = zero4(), xres = zero4();
@@ -345,10 +349,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       cprev = c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        gi[r] = sigmoidf_fast(acc[0][r]);
-        gf[r] = sigmoidf_fast(acc[1][r]);
-        gg[r] = tanhf_fast(acc[2][r]);
-        go[r] = sigmoidf_fast(acc[3][r]);
+        gi[r] = sigmoid_pre(acc[0][r]);
+        gf[r] = sigmoid_pre(acc[1][r]);
+        gg[r] = tanh_pre(acc[2][r]);
+        go[r] = sigmoid_pre(acc[3][r]);
         c[r] = gf[r] * c[r] + gi[r] * gg[r];
         h[r] = go[r] * tanhf_fast(c[r]);
       }
