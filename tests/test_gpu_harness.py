@@ -56,6 +56,40 @@ def test_two_train_steps_match_oracle_adam(torch_gpu, clip, monkeypatch):
     assert worst < 2e-4, worst
 
 
+def test_training_trajectory_matches_oracle_in_default_mode(torch_gpu):
+    """What a user of the reference cares about: with the DEFAULT kernel set (fp16x3 forward, compact fp16 BPTT
+    records, scaled fp16 dgates) a short training run follows the oracle's loss curve.  12 clip+Adam steps on a
+    fixed batch; per-step loss within 2e-3 relative (the curve drops by far more than that, so it is really the
+    same optimisation), final SI-SDR-style quantity (the loss itself) within 0.05 dB."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.train import FlatBucket, FusedAdam, train_step
+    from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
+    rec, params, flavour = load_golden("tiny_small")
+    sd = golden_state_dict(rec, torch)
+    m = sb.NetOptim(**params)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    bucket = FlatBucket(m)
+    opt = FusedAdam(bucket, lr=1e-3)
+    o = OracleNet(flavour, **params).train()
+    o.load_state_dict(sd)
+    oopt = torch.optim.Adam(o.parameters(), lr=1e-3)
+    mix, tgt = torch.from_numpy(rec["mixture"]), torch.from_numpy(rec["target"])
+    ours, ref = [], []
+    for _ in range(12):
+        ours.append(float(train_step(m, bucket, opt, {"mixture": mix.cuda()}, tgt.cuda(), 100.0, grad_clip=1.0)))
+        oopt.zero_grad()
+        ol = snrlp_loss(o({"mixture": mix})["output"], tgt, 100.0).mean()
+        ol.backward()
+        torch.nn.utils.clip_grad_norm_(o.parameters(), 1.0)
+        oopt.step()
+        ref.append(float(ol.detach()))
+    ours, ref = np.array(ours), np.array(ref)
+    assert abs(ref[0] - ref[-1]) > 20 * 2e-3 * abs(ref[0]), "the run must actually optimise something"
+    np.testing.assert_allclose(ours, ref, rtol=2e-3, atol=0.05)
+
+
 def test_batch_metrics_match_definitions(torch_gpu):
     torch = torch_gpu
     from sound_bubble_amd.metrics import batch_metrics
