@@ -18,6 +18,12 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# The recurrent kernels keep few accumulators: MFMA results straight into VGPRs saves the v_accvgpr_read copies (and
+# their hazard nops) in front of every cell update (+2-3 % on the inference forward, training neutral; same-box A/B).
+# The streaming / GEMM kernels hold ~100 accumulator registers and are better off with AGPRs (hipcc's default).
+PER_FILE_FLAGS = {"sb_lstm_bf.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIBDIR, exist_ok=True)
@@ -29,6 +35,7 @@ def build(force=False, verbose=True):
         if force or _stale(o, [s] + HEADERS):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
             cmd[2:2] = os.environ.get("SB_EXTRA_HIPCC_FLAGS", "").split()     # e.g. -DSB_PHASE_TIMING (dev tool)
+            cmd[2:2] = PER_FILE_FLAGS.get(src, [])
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
