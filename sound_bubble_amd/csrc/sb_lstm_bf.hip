@@ -308,9 +308,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
   };
 
-  // input rows are fetched two steps before their LayerNorm; the loop body covers a pair of steps and issues the
-  // rows of the next pair at its top (see the backward kernel)
-  XVec<C> xa, xb;
+  // Input rows are fetched FOUR steps before their LayerNorm: loads and stores share one in-order counter (vmcnt),
+  // so waiting for a row also waits for every older store, and in training the record stores of the inter-frame walk
+  // take longer than two steps to be acknowledged (measured: SQ_WAIT_ANY 1050 cycles per step against 310 without
+  // the stores).  The loop body covers four steps and issues the rows of the next four at its top.
+  XVec<C> xa, xb, xc, xd;
   f32x4 accx[4];
   {
     store_h(0, h);
@@ -320,6 +322,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     ln_store(x1, 1, min(1, S - 1));
     xa = load_x(min(2, S - 1));
     xb = load_x(min(3, S - 1));
+    xc = load_x(min(4, S - 1));
+    xd = load_x(min(5, S - 1));
   }
   __syncthreads();
   x_part(accx, 0);
@@ -401,14 +405,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #endif
   };
   int s = 0;
-  for (; s + 1 < S; s += 2) {
-    XVec<C> ca, cb;
-    { ca = xa; cb = xb; }
-    { xa = load_x(min(s + 4, S - 1)); xb = load_x(min(s + 5, S - 1)); }
+  for (; s + 3 < S; s += 4) {
+    const XVec<C> ca = xa, cb = xb, cc = xc, cd = xd;
+    xa = load_x(min(s + 6, S - 1));
+    xb = load_x(min(s + 7, S - 1));
+    xc = load_x(min(s + 8, S - 1));
+    xd = load_x(min(s + 9, S - 1));
     step(s, ca);
     step(s + 1, cb);
+    step(s + 2, cc);
+    step(s + 3, cd);
   }
   if (s < S) step(s, xa);
+  if (s + 1 < S) step(s + 1, xb);
+  if (s + 2 < S) step(s + 2, xc);
   if constexpr (LIN) {                                 // y of the last step from the final hidden-state tiles
     f32x4 dummy[4] = {zero4(), zero4(), zero4(), zero4()};
     if (linw) {
