@@ -433,16 +433,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     const int cn = ch + gridDim.x;
     load_chunk(cn < nchunks ? cn : ch, nxt);
     // ---- weight gradients: 4 gate tiles x (CK + 4) column tiles, K = 32 positions ----
-    SplitH Bop[KT];
+    // u (LayerNorm output) and h_prev enter as single fp16 terms: like the dgates they multiply, they carry 2^-12
+    // relative rounding noise, unbiased and averaged over millions of positions in these sums
+    h16x8 Bop[KT];
 #pragma unroll
-    for (int kt = 0; kt < CK; ++kt) Bop[kt] = splith8(cur.uv[kt]);
+    for (int kt = 0; kt < CK; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      float t[8];
+      for (int kk = 0; kk < 8; ++kk) Bop[kt][kk] = (_Float16)cur.uv[kt][kk];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) t[kk] = cur.h4[kk][kt];
-      Bop[CK + kt] = splith8(t);
-    }
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) Bop[CK + kt][kk] = (_Float16)cur.h4[kk][kt];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       h16x8 Aop;
@@ -452,10 +453,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       for (int pr = 0; pr < 4; ++pr)         // bias gradient: running sum of the 8 dgates (2 per v_dot2)
         csum[nt] = __builtin_amdgcn_fdot2(h16x2{Aop[2 * pr], Aop[2 * pr + 1]}, ones, csum[nt], false);
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        acc[nt][kt] = mfma_h(Aop, Bop[kt].lo, acc[nt][kt]);
-        acc[nt][kt] = mfma_h(Aop, Bop[kt].hi, acc[nt][kt]);
-      }
+      for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = mfma_h(Aop, Bop[kt], acc[nt][kt]);
     }
     // ---- dU = W_ih^T dgates for the two 16-position sub-tiles ----
     const int buf = it & 1;
