@@ -331,7 +331,7 @@ def main():
                 "step_flop_fraction": work_mult * fpu * utt_s / world / MFMA_F32_PEAK,
                 "step_hbm_fraction": work_mult * bpu * utt_s / world / HBM_PEAK}),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(torch, args.workload)
             out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
         if args.vendor_gpu_baseline and not args.forward_only:
