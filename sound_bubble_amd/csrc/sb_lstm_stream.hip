@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     for (int kk = 0; kk < 8; ++kk) {
       const int p = p0 + 8 * q + kk;
       const bool ok = p < Pi;
-      const int pc = ok ? p : Pi - 1;
+      const int pc = min(p, Pi - 1);
+      // positions beyond P are cancelled through their (zeroed) dgates alone; u / h_prev of the clamped row are finite
       const h16x4 av = *reinterpret_cast<const h16x4*>(dg + (int64_t)pc * ldg + 4 * j);
       t.a4[kk] = ok ? av : hz4;
       int idx = idx0 + 8 * q + kk;
@@ -406,21 +407,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       t.h4[kk] = ok2 ? hv : zero4();
       if constexpr (CK == 2) {
         const float2 v = *reinterpret_cast<const float2*>(a.u + (int64_t)pc * C + 2 * j);
-        t.uv[0][kk] = ok ? v.x : 0.f; t.uv[1][kk] = ok ? v.y : 0.f;
+        t.uv[0][kk] = v.x; t.uv[1][kk] = v.y;
       } else {
-        const float v = a.u[(int64_t)pc * C + j];
-        t.uv[0][kk] = ok ? v : 0.f;
+        t.uv[0][kk] = a.u[(int64_t)pc * C + j];
       }
     }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {          // dU operand: position p0 + 16 sb + j, gates 32m + 8q .. +7 (one 16-byte load)
-      const int pj = p0 + 16 * sb + j;
-      const int pjc = pj < Pi ? pj : Pi - 1;
+      const int pjc = min(p0 + 16 * sb + j, Pi - 1);      // dU of positions beyond P is computed but never stored
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const h16x8 dv = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 32 * m + 8 * q);
-        t.d8[sb][m] = pj < Pi ? dv : hz8;
-      }
+      for (int m = 0; m < 2; ++m) t.d8[sb][m] = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 32 * m + 8 * q);
     }
   };
 
