@@ -382,9 +382,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
             lo[r] = (_Float16)gi[r]; lo[4 + r] = (_Float16)gf[r];
             hi[r] = (_Float16)gg[r]; hi[4 + r] = (_Float16)go[r];
           }
-          _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16;
+          // per wave the (i, f) halves of its four lane groups are contiguous (64 B), then the (g, o) halves: every
+          // store instruction writes whole 32-byte sectors
+          _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + (pos * ndir + dir) * (4 * H) + (w * 8 + q) * 8;
           *reinterpret_cast<h16x8*>(rec) = lo;
-          *reinterpret_cast<h16x8*>(rec + 8) = hi;
+          *reinterpret_cast<h16x8*>(rec + 32) = hi;
           h16x4 c16;
 #pragma unroll
           for (int r = 0; r < 4; ++r) c16[r] = (_Float16)cprev[r];
@@ -520,8 +522,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     const int64_t pos = base + (int64_t)st * a.p_step;
     if (valid) {
       if constexpr (REC16) {
-        const float* rec = a.save_gates + ((pos * ndir + dir) * (4 * H) + (w * 4 + q) * 16) / 2;
-        r.r0 = ld4(rec); r.r1 = ld4(rec + 4);
+        const float* rec = a.save_gates + ((pos * ndir + dir) * (4 * H) + (w * 8 + q) * 8) / 2;
+        r.r0 = ld4(rec); r.r1 = ld4(rec + 16);
         r.r2 = r.r3 = r.cp = zero4();
         r.cp16 = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(a.save_c) + (pos * ndir + dir) * H + uoff);
       } else {
