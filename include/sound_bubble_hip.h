@@ -53,6 +53,10 @@ typedef struct {
      when lin_w != NULL, y[p, :] = x[p, :] + lin_w[C, 64] . hs[p, :] + lin_b is written as well, and hs may be NULL
      (inference).  tfgridnet_causal.py:843-849. */
   const float* lin_w; const float* lin_b; float* y;
+  /* optional scratch for time-segmented scheduling of single-direction passes with more 16-sequence tiles than the
+     chip has CUs (mma == 1): seg_state [ceil(nseq/16) * 2 * 16 * 64] floats, seg_flags [ceil(nseq/16)] ints (zeroed by
+     the call).  seg_count / seg_len are filled in by the library; pass 0. */
+  float* seg_state; int* seg_flags; int seg_count, seg_len;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 

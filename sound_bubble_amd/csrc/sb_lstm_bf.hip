@@ -15,6 +15,7 @@
 // C/D as in sb_common.h.  K is walked in chunks of 32: chunk 0 = the (LayerNormed) input u (zero-padded to 32),
 // chunks 1,2 = the hidden state.  Step pipeline: A: hidden part (MFMA) with the LayerNorm of row s+2 in its issue
 // gaps; B: input part of step s+1 (MFMA) || cell update; C: h -> LDS, stores, barrier.
+#include <cstdio>
 #include <cstdlib>
 #include "sb_common.h"
 #include "../../include/sound_bubble_hip.h"
@@ -116,7 +117,14 @@ struct XVec { float v[C / 16]; };
 // LIN (single-direction passes): the Linear(64 -> C) + residual that follows the LSTM is applied in the kernel,
 // y[p] = x[p] + W_lin h[p] + b_lin, one step behind the recurrence from the hidden-state tiles that are in LDS anyway
 // (waves w < C/16 own channel tile w); hs is then only written when the caller wants it (training).
-template <int C, int SAVE, bool FULL, bool F16, bool LIN>
+// SEG (single-direction passes with more tiles than CUs): the time axis of every tile is cut into a.seg_count
+// segments and the (tile, segment) items are dealt round-robin to one resident workgroup per CU; a segment starts from
+// the (h, c) state its predecessor left in a.seg_state, published through a.seg_flags (release / acquire at agent
+// scope).  A tile is an indivisible serial chain, and a second co-resident tile costs ~1.8x, so 290 tiles on 256 CUs
+// run 1.8 T with most CUs idle half the time; cut into k segments the makespan is ceil(290 k / 256) / k ~ 1.14 T.
+// Item i = segment * ntiles + tile goes to workgroup i mod W in increasing order; its predecessor i - ntiles lies in an
+// earlier round (ntiles >= W), so every wait is on an item some resident workgroup is already past or working on.
+template <int C, int SAVE, bool FULL, bool F16, bool LIN, bool SEG>
 __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   typedef Prec<F16> PR;
   typedef typename PR::elem elem;
@@ -175,13 +183,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 
   // ---- loader role ----
   const int ls = tid >> 4, cpart = tid & 15;
-  bool lvalid;
-  int64_t lbase;
-  {
-    const int nl = blockIdx.x * 16 + ls;
+  bool lvalid = false, cvalid = false;          // per work item (tile): set by set_tile()
+  int64_t lbase = 0, cbase = 0;
+  int nc = 0;
+  auto set_tile = [&](int tile) {
+    const int nl = tile * 16 + ls;
     lvalid = FULL || nl < a.nseq;
     lbase = lvalid ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
-  }
+    nc = tile * 16 + j;
+    cvalid = FULL || nc < a.nseq;
+    cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+  };
   float gam[VPT], bet[VPT];
 #pragma unroll
   for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; bet[v] = a.ln_b[cpart * VPT + v]; }
@@ -222,20 +234,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 
   // ---- compute role ----
   const int uoff = 16 * w + 4 * q;
-  bool cvalid;
-  int64_t cbase;
-  f32x4 c, h;
-  {
-    const int nc = blockIdx.x * 16 + j;
-    cvalid = FULL || nc < a.nseq;
-    cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
-    c = zero4();
-    h = zero4();
-    if (dir == 0 && cvalid) {
-      if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
-      if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
-    }
-  }
+  f32x4 c = zero4(), h = zero4();
   auto store_h = [&](int buf, const f32x4& hv) {   // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
     vec4 tv[NT];
 #pragma unroll
@@ -314,19 +313,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // the stores).  The loop body covers four steps and issues the rows of the next four at its top.
   XVec<C> xa, xb, xc, xd;
   f32x4 accx[4];
-  {
-    store_h(0, h);
-    XVec<C> x0 = load_x(0);
-    XVec<C> x1 = load_x(min(1, S - 1));
-    ln_store(x0, 0, 0);
-    ln_store(x1, 1, min(1, S - 1));
-    xa = load_x(min(2, S - 1));
-    xb = load_x(min(3, S - 1));
-    xc = load_x(min(4, S - 1));
-    xd = load_x(min(5, S - 1));
-  }
-  __syncthreads();
-  x_part(accx, 0);
+  int s_begin = 0;                              // first step of the current work item
 
   const int ndir = a.ndir;
 #ifdef SB_PHASE_TIMING
@@ -395,7 +382,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       }
     }
     if constexpr (LIN) {
-      if (s > 0) store_y(s - 1);
+      if (s > s_begin) store_y(s - 1);
       load_res(s);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -406,39 +393,103 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
 #endif
   };
-  int s = 0;
-  for (; s + 3 < S; s += 4) {
-    const XVec<C> ca = xa, cb = xb, cc = xc, cd = xd;
-    xa = load_x(min(s + 6, S - 1));
-    xb = load_x(min(s + 7, S - 1));
-    xc = load_x(min(s + 8, S - 1));
-    xd = load_x(min(s + 9, S - 1));
-    step(s, ca);
-    step(s + 1, cb);
-    step(s + 2, cc);
-    step(s + 3, cd);
-  }
-  if (s < S) step(s, xa);
-  if (s + 1 < S) step(s + 1, xb);
-  if (s + 2 < S) step(s + 2, xc);
-  if constexpr (LIN) {                                 // y of the last step from the final hidden-state tiles
-    f32x4 dummy[4] = {zero4(), zero4(), zero4(), zero4()};
-    if (linw) {
+  const int ntiles = (a.nseq + 15) / 16;
+  const int nitems = SEG ? ntiles * a.seg_count : ntiles;          // !SEG: gridDim.x == ntiles, one item each
+  float* const seg_hc = SEG ? a.seg_state : nullptr;               // [ntiles][2][16][64]: c, h
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int seg = SEG ? item / ntiles : 0;
+    const int tile = SEG ? item - seg * ntiles : item;
+    s_begin = SEG ? seg * a.seg_len : 0;
+    const int s_end = SEG ? min(S, s_begin + a.seg_len) : S;
+    set_tile(tile);
+    // ---- initial state of this item ----
+    c = zero4();
+    h = zero4();
+    if (seg == 0) {
+      if (dir == 0 && cvalid) {
+        if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
+        if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
+      }
+    } else if constexpr (SEG) {
+      // wait until the previous segment of this tile has published its state.  Flag and state travel as agent-scope
+      // (sc1, write-through / cache-bypassing) accesses ordered by s_waitcnt + barrier -- no release / acquire fences:
+      // those write back / invalidate the whole L2, which is full of this kernel's own record stores.
+      if (tid == 0)
+        while (__hip_atomic_load(a.seg_flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg)
+          __builtin_amdgcn_s_sleep(4);
+      __syncthreads();
+      const float* st = seg_hc + ((size_t)tile * 2 * 16 + j) * H + uoff;
 #pragma unroll
-      for (int ck = 0; ck < 2; ++ck) {
-        vec8 b[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[S & 1][n][j][32 * ck + 8 * q]);
-        if (ck == 0) yacc = zero4();
-        if constexpr (F16) {
-          yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
-          yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
-          yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
-        }
+      for (int r = 0; r < 4; ++r) {
+        c[r] = __hip_atomic_load(st + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h[r] = __hip_atomic_load(st + 16 * H + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    (void)dummy;
-    store_y(S - 1);
+    // ---- prologue: state and the first two normalised rows into LDS, four rows in flight ----
+    {
+      store_h(s_begin & 1, h);
+      XVec<C> x0 = load_x(s_begin);
+      XVec<C> x1 = load_x(min(s_begin + 1, S - 1));
+      ln_store(x0, s_begin & 1, s_begin);
+      ln_store(x1, (s_begin + 1) & 1, min(s_begin + 1, S - 1));
+      xa = load_x(min(s_begin + 2, S - 1));
+      xb = load_x(min(s_begin + 3, S - 1));
+      xc = load_x(min(s_begin + 4, S - 1));
+      xd = load_x(min(s_begin + 5, S - 1));
+    }
+    __syncthreads();
+    x_part(accx, s_begin & 1);
+
+    int s = s_begin;
+    for (; s + 3 < s_end; s += 4) {
+      const XVec<C> ca = xa, cb = xb, cc = xc, cd = xd;
+      xa = load_x(min(s + 6, S - 1));
+      xb = load_x(min(s + 7, S - 1));
+      xc = load_x(min(s + 8, S - 1));
+      xd = load_x(min(s + 9, S - 1));
+      step(s, ca);
+      step(s + 1, cb);
+      step(s + 2, cc);
+      step(s + 3, cd);
+    }
+    if (s < s_end) step(s, xa);
+    if (s + 1 < s_end) step(s + 1, xb);
+    if (s + 2 < s_end) step(s + 2, xc);
+    if constexpr (LIN) {                               // y of the item's last step from the final hidden-state tiles
+      if (linw) {
+#pragma unroll
+        for (int ck = 0; ck < 2; ++ck) {
+          vec8 b[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[s_end & 1][n][j][32 * ck + 8 * q]);
+          if (ck == 0) yacc = zero4();
+          if constexpr (F16) {
+            yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
+            yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
+            yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
+          }
+        }
+      }
+      store_y(s_end - 1);
+    }
+    // ---- final state: to the caller after the last step, to the next segment otherwise ----
+    if (s_end == S) {
+      if (dir == 0 && cvalid) {
+        if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h);
+        if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c);
+      }
+    } else if constexpr (SEG) {
+      float* st = seg_hc + ((size_t)tile * 2 * 16 + j) * H + uoff;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        __hip_atomic_store(st + r, c[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(st + 16 * H + r, h[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_s_waitcnt(0);                   // ... acknowledged at the device-coherent level ...
+      __syncthreads();                                 // ... by every wave, before the flag goes up
+      if (tid == 0) __hip_atomic_store(a.seg_flags + tile, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (SEG) __syncthreads();                // LDS tiles are reused by the next item
   }
 #ifdef SB_PHASE_TIMING
   if (SAVE == 0 && a.save_u && lane == 0 && blockIdx.x < 4) {
@@ -446,13 +497,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     for (int i = 0; i < 5; ++i) d[i] = (float)tph[i] / S;
   }
 #endif
-  {
-    const int nc = blockIdx.x * 16 + j;
-    if (dir == 0 && cvalid) {
-      if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h);
-      if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c);
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -701,7 +745,30 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 }  // namespace
 
 // launch helpers used by sb_lstm.hip's C entry points (same argument structs)
-int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
+// Number of (tile, time-segment) work items per workgroup slot: pick the segment count k that minimises the makespan
+// ceil(ntiles * k / W) / k (in units of one tile's serial time) plus a small per-hand-off cost.
+static int choose_segments(int ntiles, int W, int S, double* cost_out) {
+  int best = 1;
+  double best_cost = (double)((ntiles + W - 1) / W);
+  for (int k = 2; k <= 16 && S / k >= 24; ++k) {
+    const double cost = (double)(((long)ntiles * k + W - 1) / W) / k + 0.006 * k;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = k; }
+  }
+  *cost_out = best_cost;
+  return best;
+}
+static int device_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }();
+  return n;
+}
+
+int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
+  sb_lstm_fwd_args a = a_in;
   const int ntiles = (a.nseq + 15) / 16;
   const bool full = a.nseq % 16 == 0;
   const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
@@ -710,9 +777,29 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st) {
   const bool lin = a.lin_w != nullptr;
   if (lin && (!f16 || a.ndir != 1 || !a.lin_b || !a.y)) return -1003;
   if (!lin && !a.hs) return -1003;
-#define SB_L(CC, SV, FL, HF, LN) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN>), grid, dim3(256), 0, st, a)
-#define SB_LT(CC, SV, FL) do { if (lin) SB_L(CC, SV, FL, true, true); else if (f16) SB_L(CC, SV, FL, true, false); \
-                               else SB_L(CC, SV, FL, false, false); } while (0)
+  // time-segmented scheduling (see the kernel): single direction, scratch provided, more tiles than CUs
+  int W = device_cu_count(), kforce = 0;
+  if (const char* e = getenv("SB_LSTM_SEG_TEST")) sscanf(e, "%d,%d", &W, &kforce);   // test hook: "workers,segments"
+  bool seg = f16 && a.ndir == 1 && a.seg_state && a.seg_flags && ntiles >= W &&
+             ((ntiles > W && ntiles <= 2 * W) || kforce > 0);
+  if (seg) {
+    double cost = 0.0;
+    const int k = kforce > 0 ? kforce : choose_segments(ntiles, W, a.nsteps, &cost);
+    // two co-resident tiles per CU cost ~1.4-1.6 T on the CUs that get them; only segment when clearly below that
+    if (k < 2 || (kforce == 0 && cost > 1.30)) seg = false;
+    else {
+      a.seg_count = k;
+      a.seg_len = (a.nsteps + k - 1) / k;
+      a.seg_count = (a.nsteps + a.seg_len - 1) / a.seg_len;      // drop empty trailing segments
+      grid.x = W;
+      (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
+    }
+  }
+#define SB_L(CC, SV, FL, HF, LN, SG) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>), grid, dim3(256), 0, st, a)
+#define SB_LT(CC, SV, FL) do { \
+    if (seg) { if (lin) SB_L(CC, SV, FL, true, true, true); else SB_L(CC, SV, FL, true, false, true); } \
+    else if (lin) SB_L(CC, SV, FL, true, true, false); else if (f16) SB_L(CC, SV, FL, true, false, false); \
+    else SB_L(CC, SV, FL, false, false, false); } while (0)
 #define SB_LC(CC) do { \
     if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
     else if (save == 1) { if (full) SB_LT(CC, 1, true); else SB_LT(CC, 1, false); } \

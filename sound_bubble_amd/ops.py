@@ -101,6 +101,12 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         assert can_fuse_linear_fwd() and ndir == 1 and lin[0].shape == (Cc, H)
         a.lin_w, a.lin_b, a.y = _p(lin[0]), _p(lin[1]), _p(lin[2])
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
+    seg_scratch = None
+    if ndir == 1 and LSTM_MMA == 1 and TIME_SEGMENTS:       # scratch for time-segmented scheduling (used when it pays)
+        ntiles = (geom.nseq + 15) // 16
+        seg_scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
+                       torch.empty(ntiles, device=dev, dtype=torch.int32))
+        a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
     prof = PROFILE_LSTM
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -128,6 +134,9 @@ def can_fuse_linear_bwd():
 # compact-BPTT mode on the bf16 path: dgates travel between the two backward kernels as fp16, scaled by a power of
 # two derived from max |incoming gradient| (SB_DGATES_FP32=1 keeps them fp32)
 DGATES_FP16 = os.environ.get("SB_DGATES_FP32", "0") != "1"
+# single-direction (inter-frame) passes with more tiles than CUs: (tile, time-segment) work items over one resident
+# workgroup per CU (SB_NO_TIME_SEGMENTS=1: one workgroup per tile as everywhere else)
+TIME_SEGMENTS = os.environ.get("SB_NO_TIME_SEGMENTS", "0") != "1"
 
 
 class DGates:
