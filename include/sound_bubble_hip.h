@@ -81,6 +81,8 @@ typedef struct {
      holding S * dgates with S = 2^-ceil(log2(*gmax)) -- *gmax = max |incoming gradient| from sb_absmax -- the whole
      backward recurrence is linear in that gradient, so it simply runs on the scaled values. */
   const float* gmax;
+  /* optional scratch for time-segmented scheduling, as in sb_lstm_fwd_args (needs gmax != NULL) */
+  float* seg_state; int* seg_flags; int seg_count, seg_len;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

@@ -28,7 +28,8 @@ class LstmBwdArgs(C.Structure):
     _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int),
                 ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
                 ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("save_c", c_fp), ("mma", C.c_int),
-                ("dy", c_fp), ("w_lin", c_fp), ("C_lin", C.c_int), ("gmax", c_fp)]
+                ("dy", c_fp), ("w_lin", c_fp), ("C_lin", C.c_int), ("gmax", c_fp),
+                ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int)]
 
 
 class LinearArgs(C.Structure):

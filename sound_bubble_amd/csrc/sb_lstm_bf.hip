@@ -513,11 +513,12 @@ SB_DEVINL float grad_scale(const float* gmax) {
   return (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f;
 }
 
-template <bool FULL, bool REC16, int FUSE_C, bool DG16>
+// SEG: (tile, time-segment) work items as in the forward kernel; here a tile is walked from its last step down and
+// the state handed from segment to segment is (dc, dh_rec).
+template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
-  const int n0 = blockIdx.x * 16;
   const int S = a.nsteps, ndir = a.ndir;
   const bool rev = dir == 1;
   __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
@@ -539,9 +540,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       if constexpr (DG16) Ah[ot][c] = splith8(t); else At[ot][c] = split8(t);
     }
 
-  const int nc = n0 + j;
-  const bool valid = FULL || nc < a.nseq;
-  const int64_t base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+  bool valid = false;                            // per work item (tile): set_tile()
+  int64_t base = 0;
+  auto set_tile = [&](int tile) {
+    const int nc = tile * 16 + j;
+    valid = FULL || nc < a.nseq;
+    base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+  };
   const int uoff = 16 * w + 4 * q;
 
   const float gS = DG16 ? grad_scale(a.gmax) : 1.0f;
@@ -720,20 +725,59 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
 #endif
   };
-  Raw rA = load_raw(S - 1), rB = load_raw(max(S - 2, 0));
-  int s = S - 1;
-  for (; s >= 1; s -= 2) {
-    Raw curA = rA, curB = rB;
-    consume(curA);
-    __builtin_amdgcn_sched_barrier(0);
-    rA = load_raw(max(s - 2, 0));
-    rB = load_raw(max(s - 3, 0));
-    __builtin_amdgcn_sched_barrier(0);
-    step(s, curA);
-    consume(curB);
-    step(s - 1, curB);
+  const int ntiles = (a.nseq + 15) / 16;
+  const int nitems = SEG ? ntiles * a.seg_count : ntiles;          // !SEG: gridDim.x == ntiles, one item each
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int seg = SEG ? item / ntiles : 0;
+    const int tile = SEG ? item - seg * ntiles : item;
+    const int s_hi = SEG ? S - 1 - seg * a.seg_len : S - 1;        // this item walks steps s_hi .. s_lo
+    const int s_lo = SEG ? max(0, s_hi - a.seg_len + 1) : 0;
+    set_tile(tile);
+    dc = zero4();
+    dhrec = zero4();
+    if constexpr (SEG) {
+      float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
+      if (seg > 0) {                                   // see the forward kernel for the hand-off protocol
+        if (tid == 0)
+          while (__hip_atomic_load(a.seg_flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg)
+            __builtin_amdgcn_s_sleep(4);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dc[r] = __hip_atomic_load(st + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dhrec[r] = __hip_atomic_load(st + 16 * H + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    Raw rA = load_raw(s_hi), rB = load_raw(max(s_hi - 1, 0));
+    int s = s_hi;
+    for (; s >= s_lo + 1; s -= 2) {
+      Raw curA = rA, curB = rB;
+      consume(curA);
+      __builtin_amdgcn_sched_barrier(0);
+      rA = load_raw(max(s - 2, 0));
+      rB = load_raw(max(s - 3, 0));
+      __builtin_amdgcn_sched_barrier(0);
+      step(s, curA);
+      consume(curB);
+      step(s - 1, curB);
+    }
+    if (s == s_lo) { consume(rA); step(s_lo, rA); }
+    if constexpr (SEG) {
+      if (s_lo > 0) {
+        float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          __hip_atomic_store(st + r, dc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(st + 16 * H + r, dhrec[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.seg_flags + tile, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();                                 // the LDS exchange buffers are reused by the next item
+    }
   }
-  if (s == 0) { consume(rA); step(0, rA); }
 #ifdef SB_PHASE_TIMING
   if (a.dhs && !a.dy && lane == 0 && blockIdx.x < 4) {
     float* d = const_cast<float*>(a.dhs) + (blockIdx.x * 4 + w) * 8;
@@ -811,14 +855,31 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   return 0;
 }
 
-int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a, hipStream_t st) {
-  dim3 grid((a.nseq + 15) / 16, a.ndir), block(256);
+int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
+  sb_lstm_bwd_args a = a_in;
+  const int ntiles = (a.nseq + 15) / 16;
+  dim3 grid(ntiles, a.ndir), block(256);
   const bool full = a.nseq % 16 == 0, r16 = a.save_c != nullptr, dg16 = a.gmax != nullptr;
   if (dg16 && !r16) return -1003;
   const int fc = a.dy ? a.C_lin : 0;
-#define SB_B(FL, R16, FC, D16) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16>), grid, block, 0, st, a)
-#define SB_BR(FL, FC) do { if (dg16) SB_B(FL, true, FC, true); else if (r16) SB_B(FL, true, FC, false); \
-                           else SB_B(FL, false, FC, false); } while (0)
+  int W = device_cu_count(), kforce = 0;
+  if (const char* e = getenv("SB_LSTM_SEG_TEST")) sscanf(e, "%d,%d", &W, &kforce);
+  bool seg = dg16 && a.ndir == 1 && a.seg_state && a.seg_flags && ntiles >= W &&
+             ((ntiles > W && ntiles <= 2 * W) || kforce > 0);
+  if (seg) {
+    double cost = 0.0;
+    const int k = kforce > 0 ? kforce : choose_segments(ntiles, W, a.nsteps, &cost);
+    if (k < 2 || (kforce == 0 && cost > 1.30)) seg = false;
+    else {
+      a.seg_len = (a.nsteps + k - 1) / k;
+      a.seg_count = (a.nsteps + a.seg_len - 1) / a.seg_len;
+      grid.x = W;
+      (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
+    }
+  }
+#define SB_B(FL, R16, FC, D16, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a)
+#define SB_BR(FL, FC) do { if (seg) SB_B(FL, true, FC, true, true); else if (dg16) SB_B(FL, true, FC, true, false); \
+                           else if (r16) SB_B(FL, true, FC, false, false); else SB_B(FL, false, FC, false, false); } while (0)
 #define SB_BF(FC) do { if (full) SB_BR(true, FC); else SB_BR(false, FC); } while (0)
   if (fc == 0) SB_BF(0); else if (fc == 16) SB_BF(16); else if (fc == 32) SB_BF(32); else return -1002;
 #undef SB_BF

@@ -172,6 +172,12 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
     a.dhs, a.dgates = _p(dhs), C.c_void_p(dg.data_ptr())
     a.gmax = _p(gmax)
     a.mma = LSTM_MMA
+    seg_scratch = None
+    if ndir == 1 and dg16 and TIME_SEGMENTS:                # scratch for time-segmented scheduling (see lstm_fwd)
+        ntiles = (geom.nseq + 15) // 16
+        seg_scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
+                       torch.empty(ntiles, device=dev, dtype=torch.int32))
+        a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
     if dy is not None:
         assert can_fuse_linear_bwd() and w_lin.shape == (dy.shape[-1], ndir * H)
         a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), dy.shape[-1]
