@@ -21,7 +21,9 @@ def _stale(target, deps):
 # The recurrent kernels keep few accumulators: MFMA results straight into VGPRs saves the v_accvgpr_read copies (and
 # their hazard nops) in front of every cell update (+2-3 % on the inference forward, training neutral; same-box A/B).
 # The streaming / GEMM kernels hold ~100 accumulator registers and are better off with AGPRs (hipcc's default).
-PER_FILE_FLAGS = {"sb_lstm_bf.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# -ffp-contract=off: every fused multiply-add in the recurrent kernels is written out (__builtin_fmaf), so all template
+# variants of a kernel (e.g. the time-segmented and the plain schedule) round identically -- bit-exact outputs.
+PER_FILE_FLAGS = {"sb_lstm_bf.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffp-contract=off"]}
 
 
 def build(force=False, verbose=True):

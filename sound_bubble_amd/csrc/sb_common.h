@@ -42,7 +42,7 @@ SB_DEVINL f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 //  them into the weights: *_pre take z = -log2(e) * x  resp.  z = -2 log2(e) * x)
 constexpr float SB_NLOG2E = -1.4426950408889634f;
 SB_DEVINL float sigmoid_pre(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)); }
-SB_DEVINL float tanh_pre(float z) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)) - 1.0f; }
+SB_DEVINL float tanh_pre(float z) { return __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), -1.0f); }
 SB_DEVINL float sigmoidf_fast(float x) { return sigmoid_pre(SB_NLOG2E * x); }
 SB_DEVINL float tanhf_fast(float x) { return tanh_pre(2.0f * SB_NLOG2E * x); }
 

@@ -213,12 +213,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     const float mean = row16_sum(sum) * (1.0f / C);
     float sq = 0.f;
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq += d * d; }
-    const float rstd = __builtin_amdgcn_rsqf(row16_sum(sq) * (1.0f / C) + 1e-5f);   // v_rsq_f32, 1 ulp
+    for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq = __builtin_fmaf(d, d, sq); }
+    const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(row16_sum(sq), 1.0f / C, 1e-5f));   // v_rsq_f32, 1 ulp
     float u[VPT];
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-      u[v] = (xv.v[v] - mean) * rstd * gam[v] + bet[v];
+      u[v] = __builtin_fmaf((xv.v[v] - mean) * rstd, gam[v], bet[v]);
       elem e[NT];
       splitn1<F16>(u[v], e);
 #pragma unroll
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         gf[r] = sigmoid_pre(acc[1][r]);
         gg[r] = tanh_pre(acc[2][r]);
         go[r] = sigmoid_pre(acc[3][r]);
-        c[r] = gf[r] * c[r] + gi[r] * gg[r];
+        c[r] = __builtin_fmaf(gf[r], c[r], gi[r] * gg[r]);
         h[r] = go[r] * tanhf_fast(c[r]);
       }
     }
@@ -642,10 +642,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     for (int r = 0; r < 4; ++r) {
       const float dh = dhext[r] + dhrec[r];
       const float cpr = REC16 ? (float)raw.cp16[r] : raw.cp[r];
-      const float cc = gf[r] * cpr + gi[r] * gg[r];
+      const float cc = __builtin_fmaf(gf[r], cpr, gi[r] * gg[r]);
       const float tc = tanhf_fast(cc);
       const float dO = dh * tc;
-      const float dct = dc[r] + dh * go[r] * (1.0f - tc * tc);
+      const float dct = __builtin_fmaf(dh * go[r], __builtin_fmaf(-tc, tc, 1.0f), dc[r]);
       dG[0][r] = dct * gg[r] * gi[r] * (1.0f - gi[r]);
       dG[1][r] = dct * cpr * gf[r] * (1.0f - gf[r]);
       dG[2][r] = dct * gi[r] * (1.0f - gg[r] * gg[r]);

@@ -432,3 +432,40 @@ def test_full_size_train_step_properties(torch_gpu):
     for a_, b_ in zip(g1, g2):
         assert torch.isfinite(a_).all() and torch.isfinite(b_).all()
         assert rel_l2((2 * a_).cpu().numpy(), b_.cpu().numpy()) < 1e-4 or float(a_.abs().max()) == 0
+
+
+@pytest.mark.parametrize("workers,segments", [(4, 3), (7, 2), (16, 5)])
+def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, monkeypatch):
+    """Single-direction passes with more tiles than CUs are cut into (tile, time-segment) work items that hand the
+    recurrent state from workgroup to workgroup (sb_lstm_fwd_args.seg_state).  The arithmetic is unchanged, so the
+    forward outputs, the fused Linear output, the final state and the backward dgates must be bit-identical to the
+    one-workgroup-per-tile schedule (forced here on a small problem through the SB_LSTM_SEG_TEST hook)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    if ops.LSTM_MMA != 1 or not ops.COMPACT_BPTT or not ops.DGATES_FP16:
+        pytest.skip("time-segmented scheduling exists on the default fp16 path only")
+    torch.manual_seed(9)
+    C_, F_, T_, B_ = 32, 145, 47, 2
+    geom = ops.Geom.inter(B_, T_, F_)                       # 19 tiles (the last one partial), 47 steps
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    dirs = [tuple(t.cuda() for t in (torch.randn(256, C_) * 0.2, torch.randn(256, 64) * 0.2, torch.randn(256) * 0.1,
+                                     torch.randn(256) * 0.1))]
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    h0, c0 = torch.randn(geom.nseq, 64, device="cuda") * 0.3, torch.randn(geom.nseq, 64, device="cuda") * 0.3
+    dy = torch.randn(geom.P, C_, device="cuda") * 0.01
+
+    def run():
+        y = torch.empty(geom.P, C_, device="cuda")
+        hs, (hN, cN), gates, u = ops.lstm_fwd(x, g, b, dirs, geom, h0=h0, c0=c0, save=True, want_state=True,
+                                              lin=(lin_w, lin_b, y))
+        dg = ops.lstm_bwd_rec([dirs[0][1]], gates, None, geom, dy=dy, w_lin=lin_w)
+        torch.cuda.synchronize()
+        return [hs, y, hN, cN, gates[0], gates[1], u, dg.data]
+
+    monkeypatch.delenv("SB_LSTM_SEG_TEST", raising=False)
+    ref = run()
+    monkeypatch.setenv("SB_LSTM_SEG_TEST", f"{workers},{segments}")
+    got = run()
+    for a_, b_ in zip(ref, got):
+        assert torch.equal(a_, b_)
