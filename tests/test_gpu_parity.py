@@ -344,7 +344,7 @@ def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, monkeypatch):
     assert worst[1] < TOL_GRAD, worst
 
 
-def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu):
+def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu, monkeypatch):
     """sb_absmax feeds the power-of-two scale of the compact (fp16) dgates: exact max |x|, and the backward pair
     (recurrence -> stream) gives the same weight gradients / dU as the fp32-dgates pair within fp16 rounding,
     also for gradients far outside the fp16 range (1e-9 and 1e+6 magnitudes)."""
@@ -366,12 +366,11 @@ def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu):
         dhs = torch.randn_like(hs) * mag
         outs = []
         for fp16 in (False, True):
-            ops.DGATES_FP16 = fp16
+            monkeypatch.setattr(ops, "DGATES_FP16", fp16)
             dg = ops.lstm_bwd_rec([dirs[0][1]], gates, dhs, geom)
             assert (dg.gmax is not None) == fp16
             grads, du = ops.lstm_bwd_stream(dg, u, hs, [dirs[0][0]], F_, T_ * F_, F_)
             outs.append([t.cpu().numpy() for t in grads[0]] + [du.cpu().numpy()])
-        ops.DGATES_FP16 = True
         for a_, b_ in zip(*outs):
             assert np.isfinite(b_).all()
             assert rel_l2(b_, a_) < 1e-3, mag
