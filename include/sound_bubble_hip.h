@@ -33,9 +33,11 @@ extern "C" {
  * kernel normalises over C (eps 1e-5) with ln_g/ln_b on the fly.
  * hs: [P, ndir*64].  BPTT record (training; nullable): either
  *   save_gates [P, ndir, 5, 64] fp32 = i,f,g,o (post-activation), c_prev        (save_c == NULL), or
- *   save_gates [P, ndir, 256] fp16 gates (opaque lane order) + save_c [P, ndir, 64] c_prev, fp32 with mma == 0 and
- *   fp16 with mma >= 1  (compact: 768 / 640
- *   instead of 1280 B per step; gate values lie in [-1,1], fp16 rounding 2^-12 relative).
+ *   save_gates [R, ndir, 256] fp16 gates + save_c [R, ndir, 64] c_prev (compact: 768 / 640 instead of 1280 B per
+ *   step; gate values lie in [-1,1], fp16 rounding 2^-12 relative).  Opaque to the caller, to be handed unchanged to
+ *   sb_lstm_bwd_rec with the same mma: with mma == 0 R = P, position-major, c_prev fp32; with mma >= 1 c_prev is
+ *   fp16 and both are blocked per (16-sequence tile, step, direction) in the kernels' lane order, so every store /
+ *   load instruction moves one contiguous KB:  R = ceil(nseq / 16) * 16 * nsteps rows.
  * save_u ([P, C] LayerNorm output) is required whenever save_gates is given.
  * h0/c0 (nullable = zeros), hN/cN (nullable): [nseq, 64], direction 0 only. */
 typedef struct {

@@ -79,8 +79,11 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float32) if want_hs else None
     gates = cprev = None
     if save and COMPACT_BPTT:
-        gates = torch.empty(geom.P, ndir, 4 * H, device=dev, dtype=torch.float16)
-        cprev = torch.empty(geom.P, ndir, H, device=dev, dtype=torch.float16 if LSTM_MMA else torch.float32)
+        # opaque to the host: on the 16-bit matrix path the records are blocked per (16-sequence tile, step, direction)
+        # in the kernels' lane order (include/sound_bubble_hip.h), hence the rows padded to whole tiles
+        Pr = (geom.nseq + 15) // 16 * 16 * geom.nsteps if LSTM_MMA else geom.P
+        gates = torch.empty(Pr, ndir, 4 * H, device=dev, dtype=torch.float16)
+        cprev = torch.empty(Pr, ndir, H, device=dev, dtype=torch.float16 if LSTM_MMA else torch.float32)
     elif save:
         gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32)
     u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32) if save else None
