@@ -59,6 +59,11 @@ typedef struct {
      chip has CUs (mma == 1): seg_state [ceil(nseq/16) * 2 * 16 * 64] floats, seg_flags [ceil(nseq/16)] ints (zeroed by
      the call).  seg_count / seg_len are filled in by the library; pass 0. */
   float* seg_state; int* seg_flags; int seg_count, seg_len;
+  /* training, compact records (save_c != NULL) on the 16-bit matrix path (mma >= 1): the two tensors that only the
+     backward kernels read are written as fp16 -- save_u [P, C], and hs [P, 64] when the fused Linear is on (lin_w !=
+     NULL; y carries the fp32 result forward).  sb_lstm_bwd_stream consumes them as single fp16 terms anyway (u_f16 /
+     hs_f16 there), sb_wgrad takes the fp16 hs through in_f16. */
+  int aux_f16;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 
@@ -138,6 +143,8 @@ typedef struct {
   int seg_len, skip_first, skip_last;
   int transpose_out;
   float* dW; float* dW2; float* dbias; float* dbias2; float* scratch;
+  int in_f16;   /* 1: `in` points at fp16 elements (strides in elements), e.g. the fp16 hs of sb_lstm_fwd (aux_f16);
+                   supported for K == 64, K2 == 0, N <= 32 */
 } sb_wgrad_args;
 int sb_wgrad(const sb_wgrad_args* a, void* stream);
 int sb_wgrad_grid(int64_t positions);
@@ -169,6 +176,7 @@ typedef struct {
   const float* gmax;  /* != NULL: dgates is the scaled fp16 tensor written by sb_lstm_bwd_rec with the same gmax; the
                          fp16 matrix pipe is used (dgates exact, the fp32 operands as fp16 hi + lo) and every output
                          is multiplied by 1/S */
+  int u_f16, hs_f16;  /* gmax != NULL only: u / hs are the fp16 tensors written by sb_lstm_fwd with aux_f16 */
 } sb_lstm_stream_args;
 int sb_lstm_bwd_stream(const sb_lstm_stream_args* a, void* stream);
 int sb_lstm_stream_grid(int64_t positions);

@@ -21,7 +21,8 @@ class LstmFwdArgs(C.Structure):
                 ("h0", c_fp), ("c0", c_fp), ("hN", c_fp), ("cN", c_fp),
                 ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp), ("save_c", c_fp), ("mma", C.c_int),
                 ("lin_w", c_fp), ("lin_b", c_fp), ("y", c_fp),
-                ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int)]
+                ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int),
+                ("aux_f16", C.c_int)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -50,7 +51,7 @@ class WgradArgs(C.Structure):
                 ("in2", c_fp), ("ld2", i64), ("shift2", i64), ("K2", C.c_int),
                 ("seg_len", C.c_int), ("skip_first", C.c_int), ("skip_last", C.c_int),
                 ("transpose_out", C.c_int), ("dW", c_fp), ("dW2", c_fp), ("dbias", c_fp), ("dbias2", c_fp),
-                ("scratch", c_fp)]
+                ("scratch", c_fp), ("in_f16", C.c_int)]
 
 
 class LstmStreamArgs(C.Structure):
@@ -59,7 +60,8 @@ class LstmStreamArgs(C.Structure):
                 ("dgates", c_fp), ("u", c_fp), ("hs", c_fp),
                 ("w_ih", c_fp * 2),
                 ("dW_ih", c_fp * 2), ("dW_hh", c_fp * 2), ("db_ih", c_fp * 2), ("db_hh", c_fp * 2),
-                ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int), ("gmax", c_fp)]
+                ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int), ("gmax", c_fp),
+                ("u_f16", C.c_int), ("hs_f16", C.c_int)]
 
 
 class LnBwdArgs(C.Structure):

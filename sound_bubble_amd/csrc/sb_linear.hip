@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
 // position tiles (tile = 4*block + wave), so all four SIMDs work even when N = 16; each wave emits one
 // partial row and a second, wide kernel reduces the rows.  Source 2 is a dense row matrix addressed
 // p*ld2 + shift2 with the per-segment first/last-row exclusion.
-template <int NTW, int KT1, int KT2>
+// IN16: source 1 holds fp16 elements (the fp16 hs written by the forward recurrence for the backward kernels)
+template <int NTW, int KT1, int KT2, bool IN16 = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) {
   constexpr int KT = KT1 + KT2;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
@@ -256,7 +257,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
       }
 #pragma unroll
       for (int kt = 0; kt < KT1; ++kt) {
-        const float v = a.in[ioff + (kval[kt] ? koff[kt] : 0)];
+        float v;
+        if constexpr (IN16) v = (float)reinterpret_cast<const _Float16*>(a.in)[ioff + (kval[kt] ? koff[kt] : 0)];
+        else v = a.in[ioff + (kval[kt] ? koff[kt] : 0)];
         bv[kt][r] = (ok & kval[kt]) ? v : 0.f;
       }
       if constexpr (KT2 > 0) {
@@ -442,6 +445,11 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (a.K2 % 16 || (a.K2 && a.K % 16)) return -1002;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(sb_wgrad_grid(P)), block(256);
+  if (a.in_f16) {
+    if (kt1 != 4 || kt2 != 0 || ntw > 2) return -1004;
+    if (ntw == 1) hipLaunchKernelGGL((wgrad_kernel<1, 4, 0, true>), grid, block, 0, st, a, P);
+    else hipLaunchKernelGGL((wgrad_kernel<2, 4, 0, true>), grid, block, 0, st, a, P);
+  } else
 #define SB_WG(NTW_, KT1_, KT2_) \
   if (ntw == NTW_ && kt1 == KT1_ && kt2 == KT2_) { hipLaunchKernelGGL((wgrad_kernel<NTW_, KT1_, KT2_>), grid, block, 0, st, a, P); } else
   SB_WG(1, 1, 0) SB_WG(1, 2, 0) SB_WG(1, 4, 0) SB_WG(1, 8, 0) SB_WG(1, 5, 0) SB_WG(1, 9, 0) SB_WG(1, 18, 0)

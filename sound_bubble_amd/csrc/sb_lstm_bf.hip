@@ -39,6 +39,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 struct Split3 { bf16x8 h, m, l; };
 
@@ -231,9 +232,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
     if (SAVE && lvalid && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
       const int st = rev ? S - 1 - s : s;
-      float* p = a.save_u + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+      const int64_t uo = (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+      if constexpr (SAVE == 3) {            // only the streaming backward reads u, as a single fp16 term
+        _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + uo;
+        if constexpr (VPT == 2) *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)u[0], (_Float16)u[1]};
+        else p[0] = (_Float16)u[0];
+      } else {
+        float* p = a.save_u + uo;
 #pragma unroll
-      for (int v = 0; v < VPT; ++v) p[v] = u[v];
+        for (int v = 0; v < VPT; ++v) p[v] = u[v];
+      }
     }
   };
 
@@ -363,11 +371,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       if (cvalid) {
         const int st = rev ? S - 1 - s : s;
         const int64_t pos = cbase + (int64_t)st * a.p_step;
-        if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + (pos * ndir + dir) * H + uoff, h);
+        if constexpr (LIN && SAVE == 3) {   // the Linear is applied here: hs only feeds the backward kernels (fp16 terms)
+          h16x4 h16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h16[r] = (_Float16)h[r];
+          if (a.hs && !(SB_EXP_SKIP & 4)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.hs) + (pos * ndir + dir) * H + uoff) = h16;
+        } else {
+          if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + (pos * ndir + dir) * H + uoff, h);
+        }
         if (SAVE == 1) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
           st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
-        } else if (SAVE == 2) {
+        } else if (SAVE >= 2) {
           h16x8 lo, hi;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -831,7 +846,8 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   const int ntiles = (a.nseq + 15) / 16;
   const bool full = a.nseq % 16 == 0;
   const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
-  const int save = a.save_gates == nullptr ? 0 : (a.save_c ? 2 : 1);
+  if (a.aux_f16 && (!a.save_gates || !a.save_c)) return -1003;
+  const int save = a.save_gates == nullptr ? 0 : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
   dim3 grid(ntiles, a.ndir);
   const bool lin = a.lin_w != nullptr;
   if (lin && (!f16 || a.ndir != 1 || !a.lin_b || !a.y)) return -1003;
@@ -847,8 +863,9 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
     // two co-resident tiles per CU cost ~1.4-1.6 T on the CUs that get them; only segment when clearly below that
     if (k < 2 || (kforce == 0 && cost > 1.30)) seg = false;
     else {
-      a.seg_count = k;
-      a.seg_len = (a.nsteps + k - 1) / k;
+      // segment starts on multiples of 4 steps: every step then runs through the same copy of the 4-step unrolled
+      // loop body (or the same tail code) as in the plain schedule, which keeps the two schedules bit-identical
+      a.seg_len = ((a.nsteps + k - 1) / k + 3) & ~3;
       a.seg_count = (a.nsteps + a.seg_len - 1) / a.seg_len;      // drop empty trailing segments
       grid.x = W;
       (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
@@ -862,7 +879,8 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
 #define SB_LC(CC) do { \
     if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
     else if (save == 1) { if (full) SB_LT(CC, 1, true); else SB_LT(CC, 1, false); } \
-    else { if (full) SB_LT(CC, 2, true); else SB_LT(CC, 2, false); } } while (0)
+    else if (save == 2) { if (full) SB_LT(CC, 2, true); else SB_LT(CC, 2, false); } \
+    else { if (full) SB_LT(CC, 3, true); else SB_LT(CC, 3, false); } } while (0)
   if (a.C == 32) SB_LC(32); else SB_LC(16);
 #undef SB_LC
 #undef SB_LT
@@ -886,7 +904,7 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     const int k = kforce > 0 ? kforce : choose_segments(ntiles, W, a.nsteps, &cost);
     if (k < 2 || (kforce == 0 && cost > 1.30)) seg = false;
     else {
-      a.seg_len = (a.nsteps + k - 1) / k;
+      a.seg_len = ((a.nsteps + k - 1) / k + 3) & ~3;              // as in the forward launcher (pair-unrolled loop here)
       a.seg_count = (a.nsteps + a.seg_len - 1) / a.seg_len;
       grid.x = W;
       (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);

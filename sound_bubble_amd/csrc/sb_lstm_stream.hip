@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_kernel(sb_lstm_stream_arg
 
   const float* __restrict__ dg = a.dgates + (size_t)dir * 4 * H + 64 * w;
   const float* __restrict__ hs = a.hs + (size_t)dir * H;
+  const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs) + (size_t)dir * H;
+  const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
   const int64_t ldg = (int64_t)ndir * 4 * H, ldh = (int64_t)ndir * H;
   const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
   const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_bf16_kernel(sb_lstm_strea
 
   const float* __restrict__ dg = a.dgates + (size_t)dir * 4 * H + 64 * w;
   const float* __restrict__ hs = a.hs + (size_t)dir * H;
+  const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs) + (size_t)dir * H;
+  const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
   const int64_t ldg = (int64_t)ndir * 4 * H, ldh = (int64_t)ndir * H;
   const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
   const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
@@ -346,7 +350,8 @@ SB_DEVINL SplitH splith8(const float (&x)[8]) {
 }
 SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-template <int C, bool SMALLSEG>
+// U16 / HS16: u / hs arrive as the fp16 tensors the forward kernel wrote for this purpose (sb_lstm_fwd_args.aux_f16)
+template <int C, bool SMALLSEG, bool U16, bool HS16>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
@@ -381,11 +386,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
 
   const _Float16* __restrict__ dg = reinterpret_cast<const _Float16*>(a.dgates) + (size_t)dir * 4 * H + 64 * w;
   const float* __restrict__ hs = a.hs + (size_t)dir * H;
+  const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs) + (size_t)dir * H;
+  const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
   const int64_t ldg = (int64_t)ndir * 4 * H, ldh = (int64_t)ndir * H;
   const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
   const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
 
-  struct Chunk { h16x4 a4[8]; f32x4 h4[8]; h16x8 d8[2][2]; float uv[CK][8]; };     // raw operands of 32 positions
+  struct Chunk {                                                                   // raw operands of 32 positions
+    h16x4 a4[8]; f32x4 h4[HS16 ? 1 : 8]; h16x4 hh4[HS16 ? 8 : 1]; h16x8 d8[2][2];
+    float uv[U16 ? 1 : CK][8]; _Float16 uh[U16 ? CK : 1][8];
+  };
   const int nchunks = (Pi + 31) / 32;
   const h16x4 hz4 = {0, 0, 0, 0};
   const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -403,9 +413,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       int idx = idx0 + 8 * q + kk;
       if constexpr (SMALLSEG) idx %= a.seg_len; else idx -= idx >= a.seg_len ? a.seg_len : 0;
       const bool ok2 = ok & (idx >= skip_first) & (idx < a.seg_len - skip_last);
-      const f32x4 hv = ld4(hs + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
-      t.h4[kk] = ok2 ? hv : zero4();
-      if constexpr (CK == 2) {
+      if constexpr (HS16) {
+        const h16x4 hv = *reinterpret_cast<const h16x4*>(hs16 + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
+        t.hh4[kk] = ok2 ? hv : hz4;
+      } else {
+        const f32x4 hv = ld4(hs + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
+        t.h4[kk] = ok2 ? hv : zero4();
+      }
+      if constexpr (U16) {
+        if constexpr (CK == 2) {
+          const h16x2 v = *reinterpret_cast<const h16x2*>(u16 + (int64_t)pc * C + 2 * j);
+          t.uh[0][kk] = v[0]; t.uh[1][kk] = v[1];
+        } else {
+          t.uh[0][kk] = u16[(int64_t)pc * C + j];
+        }
+      } else if constexpr (CK == 2) {
         const float2 v = *reinterpret_cast<const float2*>(a.u + (int64_t)pc * C + 2 * j);
         t.uv[0][kk] = v.x; t.uv[1][kk] = v.y;
       } else {
@@ -435,11 +457,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
 #pragma unroll
     for (int kt = 0; kt < CK; ++kt)
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) Bop[kt][kk] = (_Float16)cur.uv[kt][kk];
+      for (int kk = 0; kk < 8; ++kk) {
+        if constexpr (U16) Bop[kt][kk] = cur.uh[kt][kk]; else Bop[kt][kk] = (_Float16)cur.uv[kt][kk];
+      }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) Bop[CK + kt][kk] = (_Float16)cur.h4[kk][kt];
+      for (int kk = 0; kk < 8; ++kk) {
+        if constexpr (HS16) Bop[CK + kt][kk] = cur.hh4[kk][kt]; else Bop[CK + kt][kk] = (_Float16)cur.h4[kk][kt];
+      }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       h16x8 Aop;
@@ -610,9 +636,16 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   const bool sm = ap->seg_len < 32;
 #define SB_S(K, CC) do { if (sm) hipLaunchKernelGGL((K<CC, true>), grid, block, 0, st, *ap); \
                          else hipLaunchKernelGGL((K<CC, false>), grid, block, 0, st, *ap); } while (0)
-  if (ap->gmax) { if (ap->C == 32) SB_S(lstm_bwd_stream_f16_kernel, 32); else SB_S(lstm_bwd_stream_f16_kernel, 16); }
+#define SB_SH(CC, U, HH) do { if (sm) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, true, U, HH>), grid, block, 0, st, *ap); \
+                              else hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, U, HH>), grid, block, 0, st, *ap); } while (0)
+#define SB_SHC(CC) do { if (ap->u_f16 && ap->hs_f16) SB_SH(CC, true, true); else if (ap->u_f16) SB_SH(CC, true, false); \
+                        else SB_SH(CC, false, false); } while (0)
+  if ((ap->u_f16 || ap->hs_f16) && (!ap->gmax || !ap->u_f16)) return -1003;      // fp16 hs comes with fp16 u
+  if (ap->gmax) { if (ap->C == 32) SB_SHC(32); else SB_SHC(16); }
   else if (ap->split_bf16) { if (ap->C == 32) SB_S(lstm_bwd_stream_bf16_kernel, 32); else SB_S(lstm_bwd_stream_bf16_kernel, 16); }
   else { if (ap->C == 32) SB_S(lstm_bwd_stream_kernel, 32); else SB_S(lstm_bwd_stream_kernel, 16); }
+#undef SB_SHC
+#undef SB_SH
 #undef SB_S
   SB_CHECK_LAUNCH();
   const int total = 4 * H * (ap->C + H) + 4 * H;

@@ -35,6 +35,15 @@ def _p(t, name="tensor"):
     return C.c_void_p(t.data_ptr())
 
 
+def _ph(t, name="tensor"):
+    """pointer of a contiguous GPU tensor that may be fp32 or fp16 (the fp16 side outputs of lstm_fwd)"""
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.float16) and t.is_contiguous()):
+        raise L.SoundBubbleHipError(f"{name}: expected a contiguous float32 / float16 tensor on the GPU")
+    return C.c_void_p(t.data_ptr())
+
+
 def _poff(t, off_floats):
     """pointer to element `off_floats` of contiguous fp32 tensor t"""
     _p(t)
@@ -76,7 +85,11 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     assert x.numel() == geom.P * Cc
     dev = x.device
     assert want_hs or lin is not None
-    hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float32) if want_hs else None
+    # training on the default path: the tensors only the backward kernels read (LayerNorm output u; hs when the Linear
+    # is fused here) are written as fp16 -- the streaming backward takes them as single fp16 terms anyway
+    aux16 = bool(save and AUX_FP16 and COMPACT_BPTT and DGATES_FP16 and LSTM_MMA in (1, 2))
+    hs16 = aux16 and lin is not None
+    hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float16 if hs16 else torch.float32) if want_hs else None
     gates = cprev = None
     if save and COMPACT_BPTT:
         # opaque to the host: on the 16-bit matrix path the records are blocked per (16-sequence tile, step, direction)
@@ -86,7 +99,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         cprev = torch.empty(Pr, ndir, H, device=dev, dtype=torch.float16 if LSTM_MMA else torch.float32)
     elif save:
         gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32)
-    u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32) if save else None
+    u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float16 if aux16 else torch.float32) if save else None
     hN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
     cN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
     a = L.LstmFwdArgs()
@@ -97,7 +110,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         assert wi.shape == (4 * H, Cc) and wh.shape == (4 * H, H)
         a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
     a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
-    a.hs, a.save_u = _p(hs), _p(u if u is not None else PHASE_TIMING_BUF)
+    a.hs, a.save_u = _ph(hs), _ph(u if u is not None else PHASE_TIMING_BUF)
+    a.aux_f16 = 1 if aux16 else 0
     a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.mma = LSTM_MMA
     if lin is not None:
@@ -119,10 +133,10 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         e1.record()
         # algorithmic flops and compulsory HBM bytes of this launch
         by = 4.0 * Cc * geom.P                                               # x rows (both directions share them)
-        by += geom.P * ndir * (4.0 * H if hs is not None else 0.0)           # hidden sequence out
+        by += geom.P * ndir * (hs.element_size() * H if hs is not None else 0.0)    # hidden sequence out
         if gates is not None:                                                # BPTT records + saved LayerNorm output
             by += geom.P * ndir * (gates.element_size() * gates[0, 0].numel()
-                                   + (cprev.element_size() * H if cprev is not None else 0)) + 4.0 * Cc * geom.P
+                                   + (cprev.element_size() * H if cprev is not None else 0)) + u.element_size() * Cc * geom.P
         if lin is not None:
             by += 2 * 4.0 * Cc * geom.P                                      # residual rows in, y out
         prof.append((e0, e1, 2.0 * 4 * H * (Cc + H) * geom.P * ndir, by))
@@ -137,6 +151,8 @@ def can_fuse_linear_bwd():
 # compact-BPTT mode on the bf16 path: dgates travel between the two backward kernels as fp16, scaled by a power of
 # two derived from max |incoming gradient| (SB_DGATES_FP32=1 keeps them fp32)
 DGATES_FP16 = os.environ.get("SB_DGATES_FP32", "0") != "1"
+# ... and the forward pass writes u (and hs of the inter-frame pass) as fp16 for them (SB_AUX_FP32=1: fp32)
+AUX_FP16 = os.environ.get("SB_AUX_FP32", "0") != "1"
 # single-direction (inter-frame) passes with more tiles than CUs: (tile, time-segment) work items over one resident
 # workgroup per CU (SB_NO_TIME_SEGMENTS=1: one workgroup per tile as everywhere else)
 TIME_SEGMENTS = os.environ.get("SB_NO_TIME_SEGMENTS", "0") != "1"
@@ -201,8 +217,9 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None
     a = L.LstmStreamArgs()
     a.P, a.ndir, a.C = P, ndir, Cc
     a.shift_pos, a.seg_len, a.skip = shift_pos, seg_len, skip
-    a.dgates, a.u, a.hs = C.c_void_p(dg.data_ptr()), _p(u), _p(hs)
+    a.dgates, a.u, a.hs = C.c_void_p(dg.data_ptr()), _ph(u), _ph(hs)
     a.gmax = _p(gmax)
+    a.u_f16, a.hs_f16 = int(u.dtype == torch.float16), int(hs.dtype == torch.float16)
     grads = []
     for d in range(ndir):
         g = targets[d] if targets is not None else (
@@ -311,7 +328,11 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     a.B, a.T, a.F, a.N, a.K = B_, T_, F_, N, K
     a.kseg = ((K + 15) // 16) * 16 if kseg is None else kseg
     a.g, a.ldg = _poff(g, g_off), ldg
-    a.inp = _poff(inp, in_off)
+    if inp.dtype == torch.float16:
+        assert in_off == 0
+        a.inp, a.in_f16 = _ph(inp), 1
+    else:
+        a.inp = _poff(inp, in_off)
     a.is_b, a.is_t, a.is_f = in_strides
     a.is_seg = is_seg
     if in2 is not None:

@@ -44,7 +44,8 @@ def test_lstm_fwd_intra_bidirectional(torch_gpu, C):
     hs, _, gates, u = ops.lstm_fwd(d(x).view(-1, C), d(g), d(b), dirs, ops.Geom.intra(nseq, S), save=True)
     assert rel_l2(hs.cpu().view(nseq, S, 128).numpy(), ref.detach().numpy()) < 5e-6
     uref = torch.nn.functional.layer_norm(x, (C,), g, b, 1e-5)
-    assert rel_l2(u.cpu().view(nseq, S, C).numpy(), uref.numpy()) < 2e-6
+    # u is a backward-only side output: fp16 on the default training path (sb_lstm_fwd_args.aux_f16)
+    assert rel_l2(u.float().cpu().view(nseq, S, C).numpy(), uref.numpy()) < (5e-4 if u.dtype == torch.float16 else 2e-6)
     assert gates[0] is not None          # opaque BPTT records (blocked per tile; checked through the backward tests)
 
 
@@ -369,7 +370,8 @@ def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu, monkeypatch):
             monkeypatch.setattr(ops, "DGATES_FP16", fp16)
             dg = ops.lstm_bwd_rec([dirs[0][1]], gates, dhs, geom)
             assert (dg.gmax is not None) == fp16
-            grads, du = ops.lstm_bwd_stream(dg, u, hs, [dirs[0][0]], F_, T_ * F_, F_)
+            # (the forward wrote u as fp16 for the fp16 pair; the fp32-dgates kernel takes fp32 operands)
+            grads, du = ops.lstm_bwd_stream(dg, u if fp16 else u.float(), hs, [dirs[0][0]], F_, T_ * F_, F_)
             outs.append([t.cpu().numpy() for t in grads[0]] + [du.cpu().numpy()])
         for a_, b_ in zip(*outs):
             assert np.isfinite(b_).all()
@@ -474,5 +476,6 @@ def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, mo
     ref = run()
     monkeypatch.setenv("SB_LSTM_SEG_TEST", f"{workers},{segments}")
     got = run()
-    for a_, b_ in zip(ref, got):
-        assert torch.equal(a_, b_)
+    names = ["hs", "y", "hN", "cN", "gate records", "c_prev records", "u", "dgates"]
+    for name, a_, b_ in zip(names, ref, got):
+        assert torch.equal(a_, b_), (name, float((a_.float() - b_.float()).abs().max()))
