@@ -16,10 +16,10 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
   const int FP = F + 2;
   const int64_t total = (int64_t)B * T * FP;
   if (idx >= total) return;
-  const int fp = (int)(idx % FP);
-  const int64_t bt = idx / FP;
-  const int t = (int)(bt % T);
-  const int b = (int)(bt / T);
+  const unsigned bt = (unsigned)idx / (unsigned)FP;       // 32-bit index split (launcher: total < 2^31)
+  const int fp = (int)((unsigned)idx - bt * FP);
+  const int b = (int)(bt / (unsigned)T);
+  const int t = (int)(bt - (unsigned)b * T);
   float* o = zp + (((int64_t)b * (T + 2) + t + 2) * FP + fp) * ZC;
   float v[ZC];
 #pragma unroll
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__
   const int64_t fc4 = (int64_t)F * C / 4;
   const int64_t total = (int64_t)B * T * fc4;
   if (i4 >= total) return;
-  const int64_t b = i4 / (T * fc4);
-  const int64_t r = i4 % fc4;
+  const int64_t b = (unsigned)i4 / (unsigned)(T * fc4);      // 32-bit index split (launcher: total < 2^31)
+  const int64_t r = (unsigned)i4 % (unsigned)fc4;
   const f32x4 xv = ld4(x + i4 * 4), wv = ld4(w + (b * fc4 + r) * 4), bv = ld4(bias + (b * fc4 + r) * 4);
   st4(y + i4 * 4, xv * wv + bv);
 }
@@ -124,16 +124,18 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __res
   extern __shared__ float ws[];   // [C][18]
   for (int i = threadIdx.x; i < C * 18; i += blockDim.x) ws[i] = w[i];
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)B * T * F * C;
-  if (i >= total) return;
-  const int c = (int)(i % C);
-  const int64_t p = i / C;
-  const int f = (int)(p % F);
-  const int64_t bt = p / F;
-  const int t = (int)(bt % T);
-  const int64_t b = bt / T;
-  float acc = 0.f;
+  // one thread per (position, 4 channels): the 9 x 2 gradient taps of a position serve all its channels, and the
+  // index split is three 32-bit divisions per thread instead of four 64-bit ones per element (the launcher checks
+  // that the element count fits 31 bits) -- the kernel was bound by that integer arithmetic, not by its 4 B/element
+  const unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned c4n = (unsigned)C / 4, total = (unsigned)B * T * F * c4n;
+  if (i4 >= total) return;
+  const unsigned p = i4 / c4n, c = (i4 - p * c4n) * 4;
+  const unsigned bt = p / (unsigned)F;
+  const int f = (int)(p - bt * F);
+  const unsigned b = bt / (unsigned)T;
+  const int t = (int)(bt - b * T);
+  f32x4 acc = zero4();
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int tt = t + 2 - a;
@@ -142,12 +144,15 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __res
     for (int d = 0; d < 3; ++d) {
       const int ff = f + 1 - d;
       if (ff < 0 || ff >= F) continue;
-      const float* g = dspec + (((b * T + tt) * F) + ff) * 2;
+      const float2 g = *reinterpret_cast<const float2*>(dspec + (((int64_t)b * T + tt) * F + ff) * 2);
       // W[c][o][kt=2-a][kf=2-d]
-      acc += g[0] * ws[c * 18 + 0 * 9 + (2 - a) * 3 + (2 - d)] + g[1] * ws[c * 18 + 1 * 9 + (2 - a) * 3 + (2 - d)];
+      const int tap = (2 - a) * 3 + (2 - d);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        acc[k] = __builtin_fmaf(g.x, ws[(c + k) * 18 + tap], __builtin_fmaf(g.y, ws[(c + k) * 18 + 9 + tap], acc[k]));
     }
   }
-  dy[i] = acc;
+  st4(dy + (int64_t)i4 * 4, acc);
 }
 
 // ---------------- SNRLP loss ----------------
@@ -310,6 +315,7 @@ inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) /
 
 extern "C" int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int T, int F, void* stream) {
   const int64_t total = (int64_t)B * T * (F + 2);
+  if (total <= 0 || total >= (1ll << 31)) return -1002;
   if (M == 6) hipLaunchKernelGGL(features_kernel<6>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, spec, ld_spec, zp, B, T, F);
   else return -1002;
   SB_CHECK_LAUNCH();
@@ -319,6 +325,7 @@ extern "C" int sb_features(const float* spec, int64_t ld_spec, float* zp, int B,
 extern "C" int sb_film_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int F, int C,
                            void* stream) {
   const int64_t total = (int64_t)B * T * F * C / 4;
+  if (total <= 0 || total >= (1ll << 31)) return -1002;
   hipLaunchKernelGGL(film_fwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, T, F, C);
   SB_CHECK_LAUNCH();
   return 0;
@@ -349,7 +356,8 @@ extern "C" int sb_overlap_add_bwd(const float* dwave, float* dframes, int B, int
 extern "C" int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int T, int F, int C,
                                   void* stream) {
   const int64_t total = (int64_t)B * T * F * C;
-  hipLaunchKernelGGL(deconv_bwd_data_kernel, dim3(nblk(total)), dim3(256), C * 18 * sizeof(float), (hipStream_t)stream, dspec, w, dy, B, T, F, C);
+  if (C % 4 || total <= 0 || total >= (1ll << 31)) return -1002;
+  hipLaunchKernelGGL(deconv_bwd_data_kernel, dim3(nblk(total / 4)), dim3(256), C * 18 * sizeof(float), (hipStream_t)stream, dspec, w, dy, B, T, F, C);
   SB_CHECK_LAUNCH();
   return 0;
 }

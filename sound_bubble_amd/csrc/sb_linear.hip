@@ -18,13 +18,33 @@ namespace {
 constexpr int LIN_MAX_WG = 1024;   // persistent grid cap (4 WG/CU on 256 CUs)
 constexpr int WG_MAX_WG = 512;
 
-SB_DEVINL int64_t pos_off(int64_t p, int T, int F, int64_t sb, int64_t st, int64_t sf) {
-  const int64_t tf = (int64_t)T * F;
-  const int64_t b = p / tf;
-  const int64_t rem = p - b * tf;
-  const int64_t t = rem / F;
-  const int64_t f = rem - t * F;
-  return b * sb + t * st + f * sf;
+// Position p = (b*T + t)*F + f  ->  element offset b*sb + t*st + f*sf.  Two 64-bit integer divisions per position and
+// lane cost several hundred VALU instructions and dominated the narrow kernels of this file, so: positions are 32-bit
+// (checked by the launchers), a dense operand (st == F*sf, sb == T*st) needs no division at all (offset = p*sf), one
+// (b, t, f) split serves all operands of a position, and the weight-gradient kernels split once per 16-position tile
+// and walk the lanes' positions from there by carry.
+struct Pos3 { unsigned b, t, f; };
+SB_DEVINL Pos3 split_pos(unsigned p, unsigned T, unsigned F) {
+  const unsigned tf = T * F;
+  Pos3 r;
+  r.b = p / tf;
+  const unsigned rem = p - r.b * tf;
+  r.t = rem / F;
+  r.f = rem - r.t * F;
+  return r;
+}
+SB_DEVINL bool dense_strides(int T, int F, int64_t sb, int64_t st, int64_t sf) {
+  return st == (int64_t)F * sf && sb == (int64_t)T * st;
+}
+SB_DEVINL int64_t off3(const Pos3& x, int64_t sb, int64_t st, int64_t sf) {
+  return (int64_t)x.b * sb + (int64_t)x.t * st + (int64_t)x.f * sf;
+}
+// offset of position (base + delta), 0 <= delta < 16, from the split of `base`
+SB_DEVINL int64_t off3_delta(const Pos3& base, unsigned delta, unsigned T, unsigned F, int64_t sb, int64_t st, int64_t sf) {
+  unsigned f = base.f + delta, t = base.t, b = base.b;
+  while (f >= F) { f -= F; ++t; }
+  while (t >= T) { t -= T; ++b; }
+  return (int64_t)b * sb + (int64_t)t * st + (int64_t)f * sf;
 }
 
 template <int NT, int EPI>
@@ -53,27 +73,35 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
 
   const int64_t ntiles = (P + 63) / 64;
   const int nchunk = K / 16;
+  const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
+  const bool out_dense = dense_strides(a.T, a.F, a.os_b, a.os_t, a.os_f);
+  const bool res_dense = !a.res || dense_strides(a.T, a.F, a.rs_b, a.rs_t, a.rs_f);
+  const bool all_dense = in_dense && out_dense && res_dense;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p_raw = tile * 64 + 16 * w + j;
     const bool valid = p_raw < P;
     // out-of-range lanes recompute the last position (columns of the MFMA are independent) and skip the store:
     // no predicated loads, so the K loop stays one basic block
     const int64_t p = valid ? p_raw : P - 1;
-    const int64_t ioff = pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f);
+    Pos3 ps = {0, 0, 0};
+    if (!all_dense) ps = split_pos((unsigned)p, a.T, a.F);
+    const int64_t ioff = in_dense ? p * a.is_f : off3(ps, a.is_b, a.is_t, a.is_f);
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = bias[nt];
 
-    auto load_b = [&](int m) -> f32x4 {
-      const int kk = 16 * m;
-      const int seg = kk / a.kseg;
-      const int kin = kk - seg * a.kseg;
-      return ld4(a.in + ioff + (int64_t)seg * a.is_seg + kin + 4 * q);
+    int kin_n = 0;                                   // K chunks are walked in order: segment / offset by carry
+    int64_t seg_off = 0;
+    auto load_next = [&]() -> f32x4 {
+      const f32x4 v = ld4(a.in + ioff + seg_off + kin_n + 4 * q);
+      kin_n += 16;
+      if (kin_n >= a.kseg) { kin_n = 0; seg_off += a.is_seg; }
+      return v;
     };
-    f32x4 bcur = load_b(0);
+    f32x4 bcur = load_next();
     for (int m = 0; m < nchunk; ++m) {
       const f32x4 b4 = bcur;
-      if (m + 1 < nchunk) bcur = load_b(m + 1);
+      if (m + 1 < nchunk) bcur = load_next();
       const float* wrow = &Wl[j * KP + 16 * m + 4 * q];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -83,10 +111,10 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
     }
 
     // ---------------- epilogue: lane holds features 16nt+4q..+3 of position p ----------------
-    const int64_t ooff = pos_off(p, a.T, a.F, a.os_b, a.os_t, a.os_f);
+    const int64_t ooff = out_dense ? p * a.os_f : off3(ps, a.os_b, a.os_t, a.os_f);
     if constexpr (EPI == SB_EPI_RES) {
       {
-        const int64_t roff = pos_off(p, a.T, a.F, a.rs_b, a.rs_t, a.rs_f);
+        const int64_t roff = res_dense ? p * a.rs_f : off3(ps, a.rs_b, a.rs_t, a.rs_f);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] += ld4(a.res + roff + 16 * nt + 4 * q);
       }
@@ -169,7 +197,7 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
           acc[nt][r] = dx;
         }
       if (valid && a.res) {
-        const int64_t roff = pos_off(p, a.T, a.F, a.rs_b, a.rs_t, a.rs_f);
+        const int64_t roff = res_dense ? p * a.rs_f : off3(ps, a.rs_b, a.rs_t, a.rs_f);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] += ld4(a.res + roff + 16 * nt + 4 * q);
       }
@@ -242,14 +270,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
   for (int nt = 0; nt < NTW; ++nt) { ncol[nt] = 16 * nt + j; nval[nt] = ncol[nt] < a.N; }
 
   const int64_t ntiles = (P + 15) / 16;
+  const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     float av[NTW][4], bv[KT][4];
+    Pos3 base = {0, 0, 0};
+    if (!in_dense) base = split_pos((unsigned)(tile * 16), a.T, a.F);      // wave-uniform: once per tile
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t p_raw = tile * 16 + 4 * q + r;
       const bool ok = p_raw < P;
       const int64_t p = ok ? p_raw : P - 1;                  // clamped address + select: no predicated loads
-      const int64_t ioff = pos_off(p, a.T, a.F, a.is_b, a.is_t, a.is_f);
+      const int64_t ioff = in_dense ? p * a.is_f
+                                    : off3_delta(base, (unsigned)(p - tile * 16), a.T, a.F, a.is_b, a.is_t, a.is_f);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const float v = a.g[p * a.ldg + (nval[nt] ? ncol[nt] : 0)];
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
         bv[kt][r] = (ok & kval[kt]) ? v : 0.f;
       }
       if constexpr (KT2 > 0) {
-        const int idx = (int)(p % a.seg_len);
+        const int idx = (int)((unsigned)p % (unsigned)a.seg_len);
         const bool ok2 = ok & (idx >= a.skip_first) & (idx < a.seg_len - a.skip_last);
 #pragma unroll
         for (int kt = 0; kt < KT2; ++kt) {
@@ -296,6 +328,129 @@ __global__ __launch_bounds__(256) void wgrad_kernel(sb_wgrad_args a, int64_t P) 
       }
     const float cs = quad_sum(csum[nt]);
     if (q == 0 && nval[nt]) part[(size_t)a.N * Ktot + ncol[nt]] = cs;
+  }
+}
+
+// Wide-load variant (single source, whole 16-column tiles): the tiles of a K segment (and of N) are grouped 4 / 2 / 1 at
+// a time and lane j loads the G consecutive columns 16*gs + G*j .. of a group with ONE 16 / 8 / 4-byte load, which
+// serves tile gs + e as its column for e = 0 .. G-1.  A tile is then the column set {16*gs + G*j + e}, a permutation
+// that only shows up in the index the partial sums are written to.  3-4x fewer load instructions than one element
+// per load: these narrow GEMMs are bound by the latency and count of their loads, not by bytes or MFMA time.
+struct TileGroup { int gs, G, e; };
+SB_DEVINL constexpr TileGroup tile_group(int t, int TS) {      // greedy groups of 4, 2, 1 over the TS tiles of a segment
+  int s = 0;
+  while (TS - s >= 4) { if (t < s + 4) return {s, 4, t - s}; s += 4; }
+  if (TS - s >= 2) { if (t < s + 2) return {s, 2, t - s}; s += 2; }
+  return {s, 1, t - s};
+}
+
+template <bool IN16, int G>
+SB_DEVINL void load_group(const float* base, int64_t off, float (&out)[4]) {
+  if constexpr (IN16) {
+    const _Float16* hp = reinterpret_cast<const _Float16*>(base) + off;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    if constexpr (G == 4) { const h4 v = *reinterpret_cast<const h4*>(hp); for (int e = 0; e < 4; ++e) out[e] = (float)v[e]; }
+    else if constexpr (G == 2) { const h2 v = *reinterpret_cast<const h2*>(hp); out[0] = (float)v[0]; out[1] = (float)v[1]; }
+    else out[0] = (float)hp[0];
+  } else {
+    if constexpr (G == 4) { const f32x4 v = ld4(base + off); for (int e = 0; e < 4; ++e) out[e] = v[e]; }
+    else if constexpr (G == 2) { const float2 v = *reinterpret_cast<const float2*>(base + off); out[0] = v.x; out[1] = v.y; }
+    else out[0] = base[off];
+  }
+}
+
+// U position tiles are fetched per loop trip before any of them is multiplied: one 16-position tile is a few KB, far
+// less than a wave must keep in flight to cover the memory latency at two waves per SIMD.
+template <int NTW, int KT1, int TS, bool IN16>
+__global__ __launch_bounds__(256) void wgrad_wide_kernel(sb_wgrad_args a, int64_t P) {
+  constexpr int KT = KT1, NSEG = KT1 / TS;
+  constexpr int U = NTW * KT1 <= 8 ? 4 : 1;
+  static_assert(KT1 % TS == 0, "whole segments");
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
+  f32x4 acc[NTW][KT];
+  float csum[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    csum[nt] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = zero4();
+  }
+  const int64_t ntiles = (P + 15) / 16, tstride = (int64_t)gridDim.x * 4;
+  const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
+  for (int64_t tile0 = (int64_t)blockIdx.x * 4 + w; tile0 < ntiles; tile0 += tstride * U) {
+    float av[U][NTW][4], bv[U][KT][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int64_t tile_u = tile0 + u * tstride, tile_c = tile_u < ntiles ? tile_u : ntiles - 1;
+    Pos3 base = {0, 0, 0};
+    if (!in_dense) base = split_pos((unsigned)(tile_c * 16), a.T, a.F);    // wave-uniform: once per tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t p_raw = tile_u * 16 + 4 * q + r;
+      const bool ok = p_raw < P;
+      const int64_t p = ok ? p_raw : P - 1;                  // clamped address + select: no predicated loads
+      const int64_t ioff = in_dense ? p * a.is_f
+                                    : off3_delta(base, (unsigned)(p - tile_c * 16), a.T, a.F, a.is_b, a.is_t, a.is_f);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const TileGroup tg = tile_group(nt, NTW);
+        if (tg.e == 0) {
+          float v[4];
+          if (tg.G == 4) load_group<false, 4>(a.g, p * a.ldg + 16 * tg.gs + 4 * j, v);
+          else if (tg.G == 2) load_group<false, 2>(a.g, p * a.ldg + 16 * tg.gs + 2 * j, v);
+          else load_group<false, 1>(a.g, p * a.ldg + 16 * tg.gs + j, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < tg.G) av[u][tg.gs + e][r] = ok ? v[e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+          const TileGroup tg = tile_group(t, TS);
+          if (tg.e == 0) {
+            float v[4];
+            const int64_t o = ioff + (int64_t)sg * a.is_seg + 16 * tg.gs;
+            if (tg.G == 4) load_group<IN16, 4>(a.in, o + 4 * j, v);
+            else if (tg.G == 2) load_group<IN16, 2>(a.in, o + 2 * j, v);
+            else load_group<IN16, 1>(a.in, o + j, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < tg.G) bv[u][sg * TS + tg.gs + e][r] = ok ? v[e] : 0.f;
+          }
+        }
+    }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        csum[nt] += av[u][nt][r];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = mfma16(av[u][nt][r], bv[u][kt][r], acc[nt][kt]);
+      }
+  }
+  const int Ktot = a.K;
+  float* part = a.scratch + ((size_t)blockIdx.x * 4 + w) * ((size_t)a.N * Ktot + a.N);
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const TileGroup ng = tile_group(nt, NTW);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const TileGroup kg = tile_group(kt % TS, TS);
+      const int k = (kt / TS) * a.kseg + 16 * kg.gs + kg.G * j + kg.e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * ng.gs + ng.G * (4 * q + r) + ng.e;
+        part[(size_t)n * Ktot + k] = acc[nt][kt][r];
+      }
+    }
+    const float cs = quad_sum(csum[nt]);
+    if (q == 0) part[(size_t)a.N * Ktot + 16 * ng.gs + ng.G * j + ng.e] = cs;
   }
 }
 
@@ -417,6 +572,7 @@ extern "C" int sb_linear_fwd(const sb_linear_args* ap, void* stream) {
   if (a.N % 16 || a.K % 16 || a.kseg % 16 || a.N <= 0 || a.K <= 0) return -1002;
   if ((a.epi == SB_EPI_LN || a.epi == SB_EPI_LNBWD) && a.n_valid != a.N) return -1003;
   const int64_t P = (int64_t)a.B * a.T * a.F;
+  if (P <= 0 || P >= (1ll << 31)) return -1001;          // 32-bit position arithmetic in the kernel
   hipStream_t st = (hipStream_t)stream;
   const int grid = sb_linear_grid(P);
   if (a.epi == SB_EPI_LNBWD && a.partials)
@@ -441,11 +597,30 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (!ap) return -1001;
   const sb_wgrad_args& a = *ap;
   const int64_t P = (int64_t)a.B * a.T * a.F;
+  if (P <= 0 || P >= (1ll << 31)) return -1001;          // 32-bit position arithmetic in the kernels
   const int nblk = (a.N + 15) / 16, kt1 = (a.K + 15) / 16, kt2 = a.K2 / 16, ntw = nblk;
   if (a.K2 % 16 || (a.K2 && a.K % 16)) return -1002;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(sb_wgrad_grid(P)), block(256);
-  if (a.in_f16) {
+  // wide-load kernel: single source, whole tiles, whole segments, rows aligned for 16-byte (fp16: 8-byte) loads
+  const int ts = a.kseg % 16 == 0 ? a.kseg / 16 : 0;
+  const int64_t es = a.in_f16 ? 2 : 4;
+  const bool wide = kt2 == 0 && a.K % 16 == 0 && a.N % 16 == 0 && ts > 0 && kt1 % ts == 0 && a.is_b % 4 == 0 &&
+                    a.is_t % 4 == 0 && a.is_f % 4 == 0 && a.is_seg % 4 == 0 && a.ldg % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.in) % (4 * es)) == 0 && (reinterpret_cast<uintptr_t>(a.g) % 16) == 0;
+  bool launched = false;
+#define SB_WW(NTW_, KT1_, TS_, H16_) \
+  if (!launched && wide && ntw == NTW_ && kt1 == KT1_ && ts == TS_ && (a.in_f16 != 0) == H16_) { \
+    hipLaunchKernelGGL((wgrad_wide_kernel<NTW_, KT1_, TS_, H16_>), grid, block, 0, st, a, P); launched = true; }
+  SB_WW(1, 4, 4, true) SB_WW(2, 4, 4, true)
+  SB_WW(1, 1, 1, false) SB_WW(1, 2, 2, false) SB_WW(1, 4, 4, false) SB_WW(1, 8, 8, false) SB_WW(1, 5, 5, false)
+  SB_WW(1, 9, 3, false) SB_WW(1, 18, 6, false) SB_WW(2, 1, 1, false) SB_WW(2, 2, 2, false) SB_WW(2, 4, 4, false)
+  SB_WW(2, 18, 6, false) 
+  SB_WW(1, 3, 3, false) SB_WW(1, 6, 6, false)
+  SB_WW(2, 5, 5, false) SB_WW(2, 6, 6, false)
+#undef SB_WW
+  if (launched) {
+  } else if (a.in_f16) {
     if (kt1 != 4 || kt2 != 0 || ntw > 2) return -1004;
     if (ntw == 1) hipLaunchKernelGGL((wgrad_kernel<1, 4, 0, true>), grid, block, 0, st, a, P);
     else hipLaunchKernelGGL((wgrad_kernel<2, 4, 0, true>), grid, block, 0, st, a, P);
