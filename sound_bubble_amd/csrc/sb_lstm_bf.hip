@@ -633,7 +633,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // Records are fetched TWO steps ahead: along the inter-frame walk consecutive steps are F positions (tens of KB,
   // a new page) apart and the measured load-to-use latency there exceeds one step.  The loop body covers a PAIR of
   // steps and issues both records of the next pair at its top, so the register copies hipcc places at the end of
-  // the body (loop-carried values) only touch loads that are two steps old.
+  // the body (loop-carried values) only touch loads that are two steps old.  (Four steps ahead with a 4-step body:
+  // -4 % on the small inter-frame pass, +2..6 % on the others -- the big intra-frame variant crosses 256 VGPRs.)
   auto consume = [&](Raw& raw) {      // pins the s_waitcnt of this record here
     asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.dh));
     if constexpr (REC16) asm volatile("" : "+v"(raw.cp16)); else asm volatile("" : "+v"(raw.cp));
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c2);
-    if (valid) {
+    if (valid && !(SB_EXP_SKIP & 256)) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = base + (int64_t)st * a.p_step;
       if constexpr (DG16) {
