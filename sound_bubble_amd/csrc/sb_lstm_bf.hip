@@ -542,13 +542,25 @@ SB_DEVINL float grad_scale(const float* gmax) {
 
 // SEG: (tile, time-segment) work items as in the forward kernel; here a tile is walked from its last step down and
 // the state handed from segment to segment is (dc, dh_rec).
-template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG>
+// FST (= channels C of u; single-direction passes): the streaming part of the backward (sb_lstm_stream.hip) runs inside
+// this kernel.  The fp16 dgates of a step go to an LDS tile instead of HBM; after every second step the workgroup
+// multiplies the 32 (step, sequence) rows it holds -- wave w = gate type w, exactly the chunk arithmetic of
+// lstm_bwd_stream_f16_kernel -- into running dW_ih / dW_hh / db sums (registers, one partial row per workgroup at the
+// end) and into du = W_ih^T dgates (partial sums over the four waves through LDS, stored one step later).  u and
+// h_prev arrive as the fp16 side outputs of the forward kernel.  Saves the 512 B/position dgates round trip (the
+// store alone was 17-45 % of this kernel) and the whole streaming launch.
+constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four position groups of a load hit distinct banks)
+template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int S = a.nsteps, ndir = a.ndir;
   const bool rev = dir == 1;
   __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
+  constexpr int CK = FST > 0 ? FST / 16 : 1, KT = CK + 4;
+  __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
+  __shared__ __attribute__((aligned(16))) float R[FST > 0 ? 2 : 1][4][2][CK][FST > 0 ? 64 : 1][4];
+  static_assert(FST == 0 || (DG16 && REC16), "fused streaming part: compact fp16 path only");
 
   const float* __restrict__ whh = a.w_hh[dir];
   // [out tile ot][chunk]: A[i = out unit 16ot + j][k] = W_hh[gate row(k)][16ot + j].  DG16: the dgates enter the
@@ -569,11 +581,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 
   bool valid = false;                            // per work item (tile): set_tile()
   int64_t base = 0, rec_tile = 0;
+  int posb[FST > 0 ? 8 : 1];                      // FST: step-0 position of sequence 8 (q & 1) + kk (chunk slot 8q + kk)
   auto set_tile = [&](int tile) {
     rec_tile = (int64_t)tile * S;
     const int nc = tile * 16 + j;
     valid = FULL || nc < a.nseq;
     base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    if constexpr (FST > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int n2 = tile * 16 + 8 * (q & 1) + kk;
+        // sequences beyond nseq: any readable position (their dgates rows are zero)
+        posb[kk] = (FULL || n2 < a.nseq) ? (int)((int64_t)(n2 / a.n_inner) * a.p_outer + (int64_t)(n2 % a.n_inner) * a.p_inner) : 0;
+      }
+    }
   };
   const int uoff = 16 * w + 4 * q;
 
@@ -591,6 +612,107 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       Ll[kk] = (__bf16)(v - (float)hh);
     }
   }
+
+  // ---- fused streaming part: state and helpers (see lstm_bwd_stream_f16_kernel for the chunk arithmetic) ----
+  SplitH Awt[CK][2];                               // W_ih^T: A[i = channel 16ct + j][k = gate 64w + 32m + 8q + kk]
+  f32x4 wacc[4][KT];                               // dW rows of gate type w: [nt][u tiles | h_prev tiles]
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (FST > 0) {
+#pragma unroll
+    for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float t[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) t[kk] = a.w_ih[(size_t)(64 * w + 32 * m + 8 * q + kk) * FST + 16 * ct + j];
+        Awt[ct][m] = splith8(t);
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) wacc[nt][kt] = zero4();
+  }
+  struct PairOps { h16x4 hh4[8]; _Float16 uh[CK][8]; };       // u / h_prev rows of the 32 slots of a chunk
+  const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs);
+  const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
+  // slot 8q + kk of the chunk of steps (sa, sa - 1): step sa - (q >> 1), sequence 8 (q & 1) + kk.  `two` = false: the
+  // second step does not exist (its dgates rows are zero; addresses clamped to the first)
+  auto pair_loads = [&](int sa, bool two) {
+    PairOps o;
+    const int st = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
+    const h16x4 hz4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int64_t pos = (int64_t)posb[kk] + (int64_t)st * a.p_step;
+      const bool hp = st > 0;                      // h_prev of step 0 is the (zero) initial state
+      const h16x4 hv = *reinterpret_cast<const h16x4*>(hs16 + (pos - (hp ? a.p_step : 0)) * H + 4 * j);
+      o.hh4[kk] = hp ? hv : hz4;
+      if constexpr (CK == 2) {
+        const h16x2 v = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
+        o.uh[0][kk] = v[0]; o.uh[1][kk] = v[1];
+      } else {
+        o.uh[0][kk] = u16[pos * FST + j];
+      }
+    }
+    return o;
+  };
+  const h16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
+  // chunk arithmetic on the dgates rows in LDS slots (sl, sl + 1); du partial sums -> R[buf]
+  auto chunk = [&](int sl, int buf, const PairOps& o) {
+    h16x8 Bop[KT];
+#pragma unroll
+    for (int kt = 0; kt < CK; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) Bop[kt][kk] = o.uh[kt][kk];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) Bop[CK + kt][kk] = o.hh4[kk][kt];
+    h16x4 a4[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      a4[kk] = *reinterpret_cast<const h16x4*>(&DG[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      h16x8 Aop;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) Aop[kk] = a4[kk][nt];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr)
+        csum[nt] = __builtin_amdgcn_fdot2(h16x2{Aop[2 * pr], Aop[2 * pr + 1]}, ones2, csum[nt], false);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aop, Bop[kt], wacc[nt][kt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      f32x4 du[CK];
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) du[ct] = zero4();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const h16x8 d8 = *reinterpret_cast<const h16x8*>(&DG[sl + sb][j][64 * w + 32 * m + 8 * q]);
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) {
+          du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].lo, d8, du[ct], 0, 0, 0);
+          du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8, du[ct], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
+    }
+  };
+  const float invS = 1.0f / gS;                    // gS is a power of two
+  // du rows of a finished chunk (its R[buf] is complete after the barrier that followed it): wave w < 2 CK reduces
+  // sub-tile sb = w / CK (step sa - sb), channel tile ct = w % CK
+  auto flush = [&](int sa, int nsteps_in_chunk, int buf) {
+    const int sb = w / CK, ct = w % CK;
+    if (w < 2 * CK && sb < nsteps_in_chunk && valid) {
+      const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
+                       ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
+      const int64_t pos = base + (int64_t)(sa - sb) * a.p_step;
+      st4(a.du + pos * FST + 16 * ct + 4 * q, s4 * invS);
+    }
+  };
 
   struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; h16x4 cp16; };
   auto load_raw = [&](int s) {
@@ -641,7 +763,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
   };
-  auto step = [&](int s, const Raw& raw) {
+  auto step = [&](int s, const Raw& raw, int slot = 0) {    // slot: LDS dgates tile of this step (FST)
     const int cur = s & 1;
     SB_TICK(c0);
     SB_TICK(c1);
@@ -700,6 +822,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c2);
+    if constexpr (FST > 0) {
+      // rows of sequences beyond nseq carry zeros (their records are zero), so every lane writes
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h16x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = Bh[g >> 1][4 * (g & 1) + r];
+        *reinterpret_cast<h16x4*>(&DG[slot][j][g * H + uoff]) = t;
+      }
+    } else
     if (valid && !(SB_EXP_SKIP & 256)) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = base + (int64_t)st * a.p_step;
@@ -782,6 +914,42 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
     Raw rA = load_raw(s_hi), rB = load_raw(max(s_hi - 1, 0));
     int s = s_hi;
+    if constexpr (FST > 0) {
+      // pair k: dgates of its two steps -> LDS slots 2 (k & 1), +1; chunk after the second step's barrier (every wave
+      // has written both rows by then); its du partial sums are reduced after the NEXT barrier (flush).  The slots of
+      // pair k are rewritten by pair k + 2, two barriers after every wave has finished chunk k.
+      int pk = 0, pend_s = 0, pend_n = 0;
+      for (; s >= s_lo + 1; s -= 2, pk ^= 1) {
+        Raw curA = rA, curB = rB;
+        consume(curA);
+        __builtin_amdgcn_sched_barrier(0);
+        rA = load_raw(max(s - 2, 0));
+        rB = load_raw(max(s - 3, 0));
+        const PairOps ops2 = pair_loads(s, true);
+        __builtin_amdgcn_sched_barrier(0);
+        step(s, curA, 2 * pk);
+        if (pend_n) flush(pend_s, pend_n, pk ^ 1);
+        consume(curB);
+        step(s - 1, curB, 2 * pk + 1);
+        chunk(2 * pk, pk, ops2);
+        pend_s = s; pend_n = 2;
+      }
+      if (s == s_lo) {                                   // odd step count: a chunk with an empty second half
+        consume(rA);
+        const PairOps ops1 = pair_loads(s_lo, false);
+        step(s_lo, rA, 2 * pk);
+        if (pend_n) flush(pend_s, pend_n, pk ^ 1);
+        const h16x4 hz = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<h16x4*>(&DG[2 * pk + 1][j][g * H + uoff]) = hz;
+        __syncthreads();
+        chunk(2 * pk, pk, ops1);
+        pend_s = s_lo; pend_n = 1;
+        pk ^= 1;
+      }
+      __syncthreads();                                   // R of the last chunk complete
+      if (pend_n) flush(pend_s, pend_n, pk ^ 1);
+    } else {
     for (; s >= s_lo + 1; s -= 2) {
       Raw curA = rA, curB = rB;
       consume(curA);
@@ -794,6 +962,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       step(s - 1, curB);
     }
     if (s == s_lo) { consume(rA); step(s_lo, rA); }
+    }
     if constexpr (SEG) {
       if (s_lo > 0) {
         float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
@@ -809,6 +978,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       __syncthreads();                                 // the LDS exchange buffers are reused by the next item
     }
   }
+  if constexpr (FST > 0) {                           // this workgroup's partial row of the weight / bias gradients
+    constexpr int Ktot = FST + H;
+    float* part = a.wpart + (size_t)blockIdx.x * ((size_t)4 * H * Ktot + 4 * H);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gate = 64 * w + 4 * (4 * q + r) + nt;
+#pragma unroll
+        for (int kt = 0; kt < CK; ++kt) part[(size_t)gate * Ktot + (CK == 2 ? 2 * j + kt : j)] = wacc[nt][kt][r] * invS;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) part[(size_t)gate * Ktot + FST + 4 * j + kt] = wacc[nt][CK + kt][r] * invS;
+      }
+      const float cs = quad_sum(csum[nt]);
+      if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
+    }
+  }
 #ifdef SB_PHASE_TIMING
   if (a.dhs && !a.dy && lane == 0 && blockIdx.x < 4) {
     float* d = const_cast<float*>(a.dhs) + (blockIdx.x * 4 + w) * 8;
@@ -818,6 +1004,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 }
 
 }  // namespace
+
+// defined in sb_lstm_stream.hip: dW_ih / dW_hh / db += sum over `rows` partial rows of [256 * (C + 64) + 256] floats
+int sb_launch_stream_reduce(const float* partials, int rows, int C, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                            hipStream_t st);
 
 // launch helpers used by sb_lstm.hip's C entry points (same argument structs)
 // Number of (tile, time-segment) work items per workgroup slot: pick the segment count k that minimises the makespan
@@ -910,6 +1100,20 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
       grid.x = W;
       (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
     }
+  }
+  // fused streaming part (see the kernel): single direction, fused Linear backward with the same channel count
+  const bool fst = a.wpart != nullptr;
+  if (fst) {
+    if (!dg16 || a.ndir != 1 || !a.u || !a.hs || !a.w_ih || !a.du || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
+        (a.C != 16 && a.C != 32) || fc != a.C || (int64_t)a.nseq * a.nsteps >= (1ll << 31))
+      return -1003;
+#define SB_F(FL, CC, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC>), grid, block, 0, st, a)
+#define SB_FC(CC) do { if (full) { if (seg) SB_F(true, CC, true); else SB_F(true, CC, false); } \
+                       else { if (seg) SB_F(false, CC, true); else SB_F(false, CC, false); } } while (0)
+    if (a.C == 16) SB_FC(16); else SB_FC(32);
+#undef SB_FC
+#undef SB_F
+    return sb_launch_stream_reduce(a.wpart, (int)grid.x, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
   }
 #define SB_B(FL, R16, FC, D16, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a)
 #define SB_BR(FL, FC) do { if (seg) SB_B(FL, true, FC, true, true); else if (dg16) SB_B(FL, true, FC, true, false); \

@@ -658,6 +658,16 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   return 0;
 }
 
+// shared with the fused backward recurrence (sb_lstm_bf.hip), which emits the same partial rows
+int sb_launch_stream_reduce(const float* partials, int rows, int C, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
+                            hipStream_t st) {
+  const int total = 4 * H * (C + H) + 4 * H;
+  hipLaunchKernelGGL(stream_reduce_kernel, dim3((total + 255) / 256, rows >= 64 ? 16 : 1), dim3(256), 0, st, partials,
+                     rows, C, dW_ih, dW_hh, db_ih, db_hh);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sb_ln_bwd_grid(int64_t positions) {
   const int64_t t = (positions + 15) / 16;
   return (int)(t < 2048 ? (t < 1 ? 1 : t) : 2048);

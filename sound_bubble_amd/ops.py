@@ -204,6 +204,65 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
     return DGates(dg, gmax)
 
 
+# single-direction passes on the default path: the streaming part runs inside the backward recurrence (the dgates stay in
+# LDS); SB_NO_FUSED_BPTT=1 keeps the two-kernel form
+FUSED_BPTT = os.environ.get("SB_NO_FUSED_BPTT", "0") != "1"
+
+
+_CU_COUNT = {}
+
+
+def _cu_count(dev):
+    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    if i not in _CU_COUNT:
+        _CU_COUNT[i] = torch.cuda.get_device_properties(i).multi_processor_count
+    return _CU_COUNT[i]
+
+
+def can_fuse_stream(u, hs, geom=None):
+    """fp16 side outputs present (default training path).  With a geometry: also whether fusing pays -- the extra chunk
+    arithmetic lengthens the serial chain of every tile, which only wins where the pass is memory-bound, i.e. the tiles
+    fill the chip (measured: 290 tiles on 256 CUs +7.5 % train step, 145 tiles -1.2 %)."""
+    ok = (FUSED_BPTT and DGATES_FP16 and COMPACT_BPTT and LSTM_MMA in (1, 2) and u is not None and hs is not None
+          and u.dtype == torch.float16 and hs.dtype == torch.float16 and u.shape[-1] in (16, 32))
+    if ok and geom is not None and os.environ.get("SB_FORCE_FUSED_BPTT", "0") != "1":
+        ok = 4 * ((geom.nseq + 15) // 16) >= 3 * _cu_count(u.device)
+    return ok
+
+
+def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets):
+    """Backward of a single-direction LSTM whose Linear is fused (see lstm_fwd(lin=...)): recurrence + streaming part in
+    one launch.  dy [P, C]; u [P, C], hs [P, 64] fp16 side outputs of the forward; targets = (dW_ih, dW_hh, db_ih,
+    db_hh) accumulated into.  -> du [P, C] (gradient w.r.t. the LayerNorm output)"""
+    lib = L.load()
+    rec, cprev = gates
+    dev = dy.device
+    Cc = dy.shape[-1]
+    assert can_fuse_stream(u, hs) and cprev is not None and w_lin.shape == (Cc, H) and u.shape[-1] == Cc
+    gmax = absmax(dy)
+    a = L.LstmBwdArgs()
+    a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 1
+    a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
+    a.w_hh[0] = _p(w_hh)
+    a.save_gates = C.c_void_p(rec.data_ptr())
+    a.save_c = C.c_void_p(cprev.data_ptr())
+    a.gmax, a.mma = _p(gmax), LSTM_MMA
+    a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
+    ntiles = (geom.nseq + 15) // 16
+    seg_scratch = None
+    if TIME_SEGMENTS:
+        seg_scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
+                       torch.empty(ntiles, device=dev, dtype=torch.int32))
+        a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
+    du = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32)
+    wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H, device=dev, dtype=torch.float32)
+    a.u, a.hs, a.w_ih, a.C = _ph(u), _ph(hs), _p(w_ih), Cc
+    a.du, a.wpart = _p(du), _p(wpart)
+    a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets)
+    L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
+    return du
+
+
 def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None):
     """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C].
     targets (optional): per direction 4 buffers the gradients are ACCUMULATED into (instead of fresh zero tensors)."""

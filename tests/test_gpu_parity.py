@@ -479,3 +479,43 @@ def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, mo
     names = ["hs", "y", "hN", "cN", "gate records", "c_prev records", "u", "dgates"]
     for name, a_, b_ in zip(names, ref, got):
         assert torch.equal(a_, b_), (name, float((a_.float() - b_.float()).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_,hook", [(16, None), (32, None), (16, "2,3"), (32, "3,2")])
+def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch):
+    """Single-direction passes run the streaming part of the backward (dW_ih, dW_hh, db, dU) inside the recurrence
+    kernel, from dgates that stay in LDS (sb_lstm_bwd_args.wpart).  Same arithmetic on the same fp16 dgates as the
+    recurrence -> stream kernel pair, only the summation order differs: weight gradients and dU must agree to fp32
+    rounding.  Odd step count, a partial last tile, and the time-segmented schedule are covered."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    if not (ops.FUSED_BPTT and ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.LSTM_MMA in (1, 2)):
+        pytest.skip("fused BPTT exists on the default compact fp16 path only")
+    if hook and ops.LSTM_MMA != 1:
+        pytest.skip("time-segmented scheduling exists on the default fp16 path only")
+    torch.manual_seed(11)
+    B_, T_, F_ = 2, 47, 21                                   # 42 sequences = 3 tiles, the last one partial
+    geom = ops.Geom.inter(B_, T_, F_)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    wi, wh = torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2
+    dirs = [(wi, wh, torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)]
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    dy = torch.randn(geom.P, C_, device="cuda") * 0.01
+    if hook:
+        monkeypatch.setenv("SB_LSTM_SEG_TEST", hook)
+    else:
+        monkeypatch.delenv("SB_LSTM_SEG_TEST", raising=False)
+    y = torch.empty(geom.P, C_, device="cuda")
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, y))
+    assert ops.can_fuse_stream(u, hs)
+    tg = [torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+          torch.zeros(256, device="cuda")]
+    du = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg)
+    dg = ops.lstm_bwd_rec([wh], gates, None, geom, dy=dy, w_lin=lin_w)
+    ref, du_ref = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_)
+    torch.cuda.synchronize()
+    assert rel_l2(du.cpu().numpy(), du_ref.view(geom.P, C_).cpu().numpy()) < 2e-6
+    for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh"), tg, ref[0]):
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-5, name
