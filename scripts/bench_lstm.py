@@ -5,6 +5,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sound_bubble_amd import _lib as _L  # noqa: E402
+if os.environ.get("SB_LIB_VARIANT"):      # experiment builds under lib/exp/
+    _L.LIB_PATH = os.path.join(os.path.dirname(_L.LIB_PATH), "exp", f"lib_{os.environ['SB_LIB_VARIANT']}.so")
 from sound_bubble_amd import ops  # noqa: E402
 
 H = 64

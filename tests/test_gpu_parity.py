@@ -490,10 +490,8 @@ def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch
     rounding.  Odd step count, a partial last tile, and the time-segmented schedule are covered."""
     torch = torch_gpu
     from sound_bubble_amd import ops
-    if not (ops.FUSED_BPTT and ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.LSTM_MMA in (1, 2)):
-        pytest.skip("fused BPTT exists on the default compact fp16 path only")
-    if hook and ops.LSTM_MMA != 1:
-        pytest.skip("time-segmented scheduling exists on the default fp16 path only")
+    if not (ops.FUSED_BPTT and ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.can_fuse_linear_fwd()):
+        pytest.skip("fused BPTT exists on the default compact fp16 path only (it needs the fused forward Linear)")
     torch.manual_seed(11)
     B_, T_, F_ = 2, 47, 21                                   # 42 sequences = 3 tiles, the last one partial
     geom = ops.Geom.inter(B_, T_, F_)
