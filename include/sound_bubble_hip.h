@@ -94,12 +94,15 @@ typedef struct {
      u [P, C] and hs [P, 64] the fp16 side outputs of sb_lstm_fwd (aux_f16).  When wpart != NULL the dgates never leave
      the chip: every two steps the workgroup multiplies the 32 (step, sequence) dgates rows it holds in LDS into
      running dW_ih / dW_hh / db sums and forms du [P, C] = dgates . W_ih (gradient w.r.t. the LayerNorm output);
-     `dgates` is not written.  h_prev of (sequence, step) is hs at step - 1 (zero at step 0).  wpart: one row of
-     256*(C+64)+256 floats per workgroup, at most ceil(nseq/16) rows; they are ADDED into dW_ih [256, C],
-     dW_hh [256, 64], db_ih / db_hh [256] by a reduction the call launches itself. */
+     `dgates` is not written.  h_prev of (sequence, step) is hs at step - 1 (zero at step 0).  The weight gradient of
+     the fused Linear rides along (dW_lin [C, 64] += dy^T hs, db_lin [C] += column sums of dy; dy enters as a single
+     scaled fp16 term like the dgates).  wpart: one row of 256*(C+64)+256 + C*64 + C floats per workgroup, at most
+     ceil(nseq/16) rows; they are ADDED into dW_ih [256, C], dW_hh [256, 64], db_ih / db_hh [256] (and dW_lin / db_lin
+     when non-NULL) by reductions the call launches itself. */
   const void* u; const void* hs; const float* w_ih; int C;
   float* du; float* wpart;
   float* dW_ih; float* dW_hh; float* db_ih; float* db_hh;
+  float* dW_lin; float* db_lin;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

@@ -582,15 +582,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   bool valid = false;                            // per work item (tile): set_tile()
   int64_t base = 0, rec_tile = 0;
   int posb[FST > 0 ? 8 : 1];                      // FST: step-0 position of sequence 8 (q & 1) + kk (chunk slot 8q + kk)
+  unsigned slotv = 0;                             // ... and whether that sequence exists (bit kk)
   auto set_tile = [&](int tile) {
     rec_tile = (int64_t)tile * S;
     const int nc = tile * 16 + j;
     valid = FULL || nc < a.nseq;
     base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
     if constexpr (FST > 0) {
+      slotv = 0;
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const int n2 = tile * 16 + 8 * (q & 1) + kk;
+        if (FULL || n2 < a.nseq) slotv |= 1u << kk;
         // sequences beyond nseq: any readable position (their dgates rows are zero)
         posb[kk] = (FULL || n2 < a.nseq) ? (int)((int64_t)(n2 / a.n_inner) * a.p_outer + (int64_t)(n2 % a.n_inner) * a.p_inner) : 0;
       }
@@ -632,7 +635,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) wacc[nt][kt] = zero4();
   }
-  struct PairOps { h16x4 hh4[8]; _Float16 uh[CK][8]; };       // u / h_prev rows of the 32 slots of a chunk
+  // u / h_prev rows of the 32 slots of a chunk; dyv: dy of the h_prev rows' own positions (Linear weight gradient)
+  // RAW loaded registers only: any arithmetic on them here would pin an s_waitcnt behind the loads at the top of the
+  // loop body (the select of the first version did, and doubled the kernel time once the dy loads joined)
+  struct PairOps { h16x4 hh4[8]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8]; float dyv[CK][8]; };
+  f32x4 lacc[CK];                                  // dW_lin tile: channels 16ct + 4q + r x units 4j + w
+  float lbs[CK];                                   // db_lin: channel 16ct + j, this lane's positions
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct) { lacc[ct] = zero4(); lbs[ct] = 0.f; }
+  const float* __restrict__ dyj = a.dy + j;
   const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs);
   const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
   // slot 8q + kk of the chunk of steps (sa, sa - 1): step sa - (q >> 1), sequence 8 (q & 1) + kk.  `two` = false: the
@@ -640,34 +651,52 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   auto pair_loads = [&](int sa, bool two) {
     PairOps o;
     const int st = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
-    const h16x4 hz4 = {0, 0, 0, 0};
+    const bool hp = st > 0;                        // h_prev of step 0 is the (zero) initial state: masked in chunk()
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int64_t pos = (int64_t)posb[kk] + (int64_t)st * a.p_step;
-      const bool hp = st > 0;                      // h_prev of step 0 is the (zero) initial state
-      const h16x4 hv = *reinterpret_cast<const h16x4*>(hs16 + (pos - (hp ? a.p_step : 0)) * H + 4 * j);
-      o.hh4[kk] = hp ? hv : hz4;
-      if constexpr (CK == 2) {
-        const h16x2 v = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
-        o.uh[0][kk] = v[0]; o.uh[1][kk] = v[1];
-      } else {
-        o.uh[0][kk] = u16[pos * FST + j];
-      }
+      const int64_t posh = pos - (hp ? a.p_step : 0);
+      o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * H + 4 * j);
+      if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
+      else o.uh1[kk] = u16[pos * FST + j];
+      // the Linear's weight gradient pairs h of a position with dy of the SAME position (step st - 1)
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) o.dyv[ct][kk] = dyj[posh * FST + 16 * ct];
     }
     return o;
   };
   const h16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
   // chunk arithmetic on the dgates rows in LDS slots (sl, sl + 1); du partial sums -> R[buf]
-  auto chunk = [&](int sl, int buf, const PairOps& o) {
+  auto chunk = [&](int sl, int buf, const PairOps& o, int sa, bool two) {
+    const int st = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
+    const bool hp = st > 0;
+    const h16x4 hz4 = {0, 0, 0, 0};
     h16x8 Bop[KT];
 #pragma unroll
-    for (int kt = 0; kt < CK; ++kt)
+    for (int kk = 0; kk < 8; ++kk) {
+      if constexpr (CK == 2) { Bop[0][kk] = o.uh2[kk][0]; Bop[1][kk] = o.uh2[kk][1]; }
+      else Bop[0][kk] = o.uh1[kk];
+    }
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) Bop[kt][kk] = o.uh[kt][kk];
+    for (int kk = 0; kk < 8; ++kk) {
+      const h16x4 hm = hp ? o.hh4[kk] : hz4;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = hm[kt];
+    }
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) Bop[CK + kt][kk] = o.hh4[kk][kt];
+    for (int ct = 0; ct < CK; ++ct) {              // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
+      h16x8 Ad;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        // slots of a missing second step and of sequences beyond nseq must not count
+        const bool dv = hp && (two || q < 2) && ((slotv >> kk) & 1u);
+        const float v = dv ? o.dyv[ct][kk] * gS : 0.f;
+        Ad[kk] = (_Float16)v;
+        lbs[ct] += v;
+      }
+      const h16x8 Bw = w == 0 ? Bop[CK] : (w == 1 ? Bop[CK + 1] : (w == 2 ? Bop[CK + 2] : Bop[CK + 3]));
+      lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ad, Bw, lacc[ct], 0, 0, 0);
+    }
     h16x4 a4[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
@@ -699,6 +728,31 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       }
 #pragma unroll
       for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
+    }
+  };
+  // the chunks pair dy with h at steps 0 .. S-2 (the h_prev rows); the last step of a tile is added here
+  auto lin_top = [&]() {
+    h16x8 Bw;
+    float lin_top_dy[CK][8];
+    const h16x4 hz4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int64_t pos = (int64_t)posb[kk] + (int64_t)(S - 1) * a.p_step;
+      const h16x4 hv = *reinterpret_cast<const h16x4*>(hs16 + pos * H + 4 * j);
+      const h16x4 hm = q < 2 ? hv : hz4;
+      Bw[kk] = w == 0 ? hm[0] : (w == 1 ? hm[1] : (w == 2 ? hm[2] : hm[3]));
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) {
+        const float v = dyj[pos * FST + 16 * ct];
+        lin_top_dy[ct][kk] = (q < 2 && ((slotv >> kk) & 1u)) ? v * gS : 0.f;
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CK; ++ct) {
+      h16x8 Ad;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) { Ad[kk] = (_Float16)lin_top_dy[ct][kk]; lbs[ct] += lin_top_dy[ct][kk]; }
+      lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ad, Bw, lacc[ct], 0, 0, 0);
     }
   };
   const float invS = 1.0f / gS;                    // gS is a power of two
@@ -919,6 +973,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       // has written both rows by then); its du partial sums are reduced after the NEXT barrier (flush).  The slots of
       // pair k are rewritten by pair k + 2, two barriers after every wave has finished chunk k.
       int pk = 0, pend_s = 0, pend_n = 0;
+      if (s_hi == S - 1) lin_top();
       for (; s >= s_lo + 1; s -= 2, pk ^= 1) {
         Raw curA = rA, curB = rB;
         consume(curA);
@@ -931,7 +986,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         if (pend_n) flush(pend_s, pend_n, pk ^ 1);
         consume(curB);
         step(s - 1, curB, 2 * pk + 1);
-        chunk(2 * pk, pk, ops2);
+        chunk(2 * pk, pk, ops2, s, true);
         pend_s = s; pend_n = 2;
       }
       if (s == s_lo) {                                   // odd step count: a chunk with an empty second half
@@ -943,7 +998,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<h16x4*>(&DG[2 * pk + 1][j][g * H + uoff]) = hz;
         __syncthreads();
-        chunk(2 * pk, pk, ops1);
+        chunk(2 * pk, pk, ops1, s_lo, false);
         pend_s = s_lo; pend_n = 1;
         pk ^= 1;
       }
@@ -980,7 +1035,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   }
   if constexpr (FST > 0) {                           // this workgroup's partial row of the weight / bias gradients
     constexpr int Ktot = FST + H;
-    float* part = a.wpart + (size_t)blockIdx.x * ((size_t)4 * H * Ktot + 4 * H);
+    float* part = a.wpart + (size_t)blockIdx.x * ((size_t)4 * H * Ktot + 4 * H + FST * H + FST);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -994,6 +1049,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       const float cs = quad_sum(csum[nt]);
       if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
     }
+    float* plin = part + (size_t)4 * H * Ktot + 4 * H;           // [C][64] dW_lin, then [C] db_lin
+#pragma unroll
+    for (int ct = 0; ct < CK; ++ct) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) plin[(size_t)(16 * ct + 4 * q + r) * H + 4 * j + w] = lacc[ct][r] * invS;
+      const float bs = quad_sum(lbs[ct]);
+      if (w == 0 && q == 0) plin[(size_t)FST * H + 16 * ct + j] = bs * invS;
+    }
   }
 #ifdef SB_PHASE_TIMING
   if (a.dhs && !a.dy && lane == 0 && blockIdx.x < 4) {
@@ -1006,8 +1069,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 }  // namespace
 
 // defined in sb_lstm_stream.hip: dW_ih / dW_hh / db += sum over `rows` partial rows of [256 * (C + 64) + 256] floats
-int sb_launch_stream_reduce(const float* partials, int rows, int C, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
-                            hipStream_t st);
+int sb_launch_stream_reduce(const float* partials, int rows, int64_t ld, int C, float* dW_ih, float* dW_hh, float* db_ih,
+                            float* db_hh, hipStream_t st);
 
 // launch helpers used by sb_lstm.hip's C entry points (same argument structs)
 // Number of (tile, time-segment) work items per workgroup slot: pick the segment count k that minimises the makespan
@@ -1113,7 +1176,12 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     if (a.C == 16) SB_FC(16); else SB_FC(32);
 #undef SB_FC
 #undef SB_F
-    return sb_launch_stream_reduce(a.wpart, (int)grid.x, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
+    const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + a.C * H + a.C;
+    int rc = sb_launch_stream_reduce(a.wpart, (int)grid.x, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
+    const float* plin = a.wpart + (size_t)4 * H * (a.C + H) + 4 * H;
+    if (!rc && a.dW_lin) rc = sb_reduce_rows(plin, (int)grid.x, ld, a.C * H, a.dW_lin, st);
+    if (!rc && a.db_lin) rc = sb_reduce_rows(plin + a.C * H, (int)grid.x, ld, a.C, a.db_lin, st);
+    return rc;
   }
 #define SB_B(FL, R16, FC, D16, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a)
 #define SB_BR(FL, FC) do { if (seg) SB_B(FL, true, FC, true, true); else if (dg16) SB_B(FL, true, FC, true, false); \

@@ -524,13 +524,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   }
 }
 
-__global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restrict__ partials, int rows, int C,
+__global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restrict__ partials_in, int rows, int C,
                                                             float* __restrict__ dW1, float* __restrict__ dW2,
-                                                            float* __restrict__ db1, float* __restrict__ db2) {
+                                                            float* __restrict__ db1, float* __restrict__ db2,
+                                                            int64_t ld = 0) {
   const int Ktot = C + H, N = 4 * H;
-  const int total = N * Ktot + N;
+  const int total_ = N * Ktot + N;
+  // rows are `ld` floats apart (0: packed); the index arithmetic below uses `total` as the row pitch
+  const int64_t total = ld > 0 ? ld : total_;
+  const float* __restrict__ partials = partials_in;
+  if ((int)(blockIdx.x * blockDim.x + threadIdx.x) >= total_) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
   const int rper = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
   float s = 0.f, sa = 0.f, sb = 0.f, sc = 0.f;
@@ -659,11 +663,11 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
 }
 
 // shared with the fused backward recurrence (sb_lstm_bf.hip), which emits the same partial rows
-int sb_launch_stream_reduce(const float* partials, int rows, int C, float* dW_ih, float* dW_hh, float* db_ih, float* db_hh,
-                            hipStream_t st) {
+int sb_launch_stream_reduce(const float* partials, int rows, int64_t ld, int C, float* dW_ih, float* dW_hh, float* db_ih,
+                            float* db_hh, hipStream_t st) {
   const int total = 4 * H * (C + H) + 4 * H;
   hipLaunchKernelGGL(stream_reduce_kernel, dim3((total + 255) / 256, rows >= 64 ? 16 : 1), dim3(256), 0, st, partials,
-                     rows, C, dW_ih, dW_hh, db_ih, db_hh);
+                     rows, C, dW_ih, dW_hh, db_ih, db_hh, ld);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -144,12 +144,14 @@ class InterFn(torch.autograd.Function):
         if not fuse:
             dhs = torch.empty(P, H, device=dy.device, dtype=torch.float32)
             ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
-        ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
         # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
         tg = [(gt("wi", wi), gt("wh", wh), gt("bi", bi), gt("bh", bh))]
-        if fuse and ops.can_fuse_stream(u, hs, geom):  # recurrence + streaming part in one launch (where it pays)
-            du = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0]).view(P, 1, Cc)
+        if fuse and ops.can_fuse_stream(u, hs, geom):
+            # recurrence + streaming part + the Linear's weight gradient in one launch (where it pays)
+            du = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
+                                    lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b))).view(P, 1, Cc)
         else:
+            ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
             dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
                                   w_lin=lin_w if fuse else None)
             _, du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F, targets=tg)

@@ -230,10 +230,11 @@ def can_fuse_stream(u, hs, geom=None):
     return ok
 
 
-def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets):
+def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets=None):
     """Backward of a single-direction LSTM whose Linear is fused (see lstm_fwd(lin=...)): recurrence + streaming part in
     one launch.  dy [P, C]; u [P, C], hs [P, 64] fp16 side outputs of the forward; targets = (dW_ih, dW_hh, db_ih,
-    db_hh) accumulated into.  -> du [P, C] (gradient w.r.t. the LayerNorm output)"""
+    db_hh), lin_targets = (dW_lin [C, 64], db_lin [C]) (optional): accumulated into.
+    -> du [P, C] (gradient w.r.t. the LayerNorm output)"""
     lib = L.load()
     rec, cprev = gates
     dev = dy.device
@@ -255,10 +256,13 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets):
                        torch.empty(ntiles, device=dev, dtype=torch.int32))
         a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
     du = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32)
-    wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H, device=dev, dtype=torch.float32)
+    wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H + Cc * H + Cc, device=dev, dtype=torch.float32)
     a.u, a.hs, a.w_ih, a.C = _ph(u), _ph(hs), _p(w_ih), Cc
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets)
+    if lin_targets is not None:
+        assert lin_targets[0].shape == (Cc, H)
+        a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
     L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
     return du
 

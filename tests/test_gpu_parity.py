@@ -510,10 +510,15 @@ def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch
     assert ops.can_fuse_stream(u, hs)
     tg = [torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
           torch.zeros(256, device="cuda")]
-    du = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg)
+    ltg = [torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")]
+    du = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg, lin_targets=ltg)
     dg = ops.lstm_bwd_rec([wh], gates, None, geom, dy=dy, w_lin=lin_w)
     ref, du_ref = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_)
     torch.cuda.synchronize()
     assert rel_l2(du.cpu().numpy(), du_ref.view(geom.P, C_).cpu().numpy()) < 2e-6
     for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh"), tg, ref[0]):
         assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-5, name
+    # the fused Linear's weight gradient: dy enters as one scaled fp16 term (2^-12 relative, unbiased)
+    dwl = dy.double().t() @ hs.double()
+    assert rel_l2(ltg[0].cpu().numpy(), dwl.cpu().numpy()) < 1e-3
+    assert rel_l2(ltg[1].cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-3
