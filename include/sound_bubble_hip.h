@@ -133,6 +133,8 @@ typedef struct {
   const float* aux_in; float* aux_out;      /* dense [P, N] */
   float* partials;                          /* SB_EPI_LNBWD: [grid, 2N+1] floats */
   int accumulate;                           /* out += instead of out = (EPI_NONE/RES only) */
+  float* absmax_out;                        /* optional (EPI_NONE/RES): *absmax_out = max(*absmax_out, max |out|), the
+                                               scalar sb_lstm_bwd_rec wants as gmax; zero it before the call */
 } sb_linear_args;
 int sb_linear_fwd(const sb_linear_args* a, void* stream);
 /* number of workgroups sb_linear_fwd launches for P positions (size of `partials`) */

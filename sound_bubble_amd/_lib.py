@@ -43,7 +43,8 @@ class LinearArgs(C.Structure):
                 ("out", c_fp), ("os_b", i64), ("os_t", i64), ("os_f", i64),
                 ("res", c_fp), ("rs_b", i64), ("rs_t", i64), ("rs_f", i64),
                 ("prelu_a", c_fp), ("ln_g", c_fp), ("ln_b", c_fp),
-                ("aux_in", c_fp), ("aux_out", c_fp), ("partials", c_fp), ("accumulate", C.c_int)]
+                ("aux_in", c_fp), ("aux_out", c_fp), ("partials", c_fp), ("accumulate", C.c_int),
+                ("absmax_out", c_fp)]
 
 
 class WgradArgs(C.Structure):

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
   for (int nt = 0; nt < NB; ++nt) { dgam[nt] = zero4(); dbet[nt] = zero4(); }
   const float alpha = a.prelu_a ? a.prelu_a[0] : 0.f;
 
+  float amax = 0.f;                                  // max |stored value| (a.absmax_out)
   const int64_t ntiles = (P + 63) / 64;
   const int nchunk = K / 16;
   const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
@@ -208,16 +209,32 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
         const int n0 = 16 * nt + 4 * q;
         float* o = a.out + ooff + n0;
         if (n0 + 4 <= a.n_valid) {
-          if (a.accumulate) st4(o, ld4(o) + acc[nt]); else st4(o, acc[nt]);
+          if (a.accumulate) { acc[nt] += ld4(o); st4(o, acc[nt]); } else st4(o, acc[nt]);
+          if constexpr (EPI == SB_EPI_NONE || EPI == SB_EPI_RES)
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[nt][0]), fabsf(acc[nt][1]))), fmaxf(fabsf(acc[nt][2]), fabsf(acc[nt][3])));
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n0 + r < a.n_valid) o[r] = a.accumulate ? o[r] + acc[nt][r] : acc[nt][r];
+            if (n0 + r < a.n_valid) {
+              const float v = a.accumulate ? o[r] + acc[nt][r] : acc[nt][r];
+              o[r] = v;
+              amax = fmaxf(amax, fabsf(v));
+            }
         }
       }
     }
   }
 
+  if constexpr (EPI == SB_EPI_NONE || EPI == SB_EPI_RES) {
+    if (a.absmax_out) {                                // one atomic per workgroup (same-address atomics serialise in L2)
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      __shared__ float wm[4];
+      if (lane == 0) wm[w] = amax;
+      __syncthreads();
+      if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out),
+                              __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    }
+  }
   if constexpr (EPI == SB_EPI_LNBWD) if (a.partials) {
     float* part = a.partials + (size_t)blockIdx.x * (2 * N + 1);
 #pragma unroll

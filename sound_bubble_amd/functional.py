@@ -216,7 +216,8 @@ class IntraConvFn(torch.autograd.Function):
         _, sC = dense(P2, Cc)
         # ConvTranspose1d backward
         dhs = torch.empty(P2, 2 * H, device=dev, dtype=torch.float32)
-        ops.linear(dym, wd.t().contiguous(), None, dhs, gP2, sNC, s2H, NC, 2 * H)
+        gm_dhs = torch.zeros(1, device=dev, dtype=torch.float32) if ops.ABSMAX_HINTS else None   # max |dhs| on the fly
+        ops.linear(dym, wd.t().contiguous(), None, dhs, gP2, sNC, s2H, NC, 2 * H, absmax_out=gm_dhs)
         d_wd = torch.zeros(NC, 2 * H, device=dev, dtype=torch.float32)
         d_bd = torch.zeros(NC, device=dev, dtype=torch.float32)
         ops.wgrad(dym, NC, NC, hs, s2H, gP2, 2 * H, d_wd, dbias=d_bd)
@@ -226,7 +227,7 @@ class IntraConvFn(torch.autograd.Function):
             d_dec_b = d_dec_b + dy[:, :, Fm:, :].sum((0, 1, 2))
         # BPTT
         geom = Geom.intra(B * T, Kd)
-        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom)
+        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, gmax=gm_dhs)
         # one pass over dgates (weight grads + dU), then LayerNorm + PReLU backward -> gradient of the Conv1d output
         tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
               (gt("wir", wir), gt("whr", whr), gt("bir", bir), gt("bhr", bhr))]
@@ -237,9 +238,13 @@ class IntraConvFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         s_x = (F * Cc, 0, NC)
         s_v = (Kd * Cc, 0, Cc)
-        ops.linear(dv, wc.t().contiguous(), None, dx, grid, s_v, s_x, Cc, NC, epi=L.EPI_RES, res=dy)
+        # dx is the dy of the inter-frame backward of the previous block: its max |.| is measured here
+        gm_dx = torch.zeros(1, device=dev, dtype=torch.float32) if (ops.ABSMAX_HINTS and Fm == F) else None
+        ops.linear(dv, wc.t().contiguous(), None, dx, grid, s_v, s_x, Cc, NC, epi=L.EPI_RES, res=dy, absmax_out=gm_dx)
         if Fm < F:
             dx[:, :, Fm:, :] = dy[:, :, Fm:, :]
+        if gm_dx is not None:
+            ops.absmax_hint_put(dx, gm_dx)
         d_wc = torch.zeros(Cc, NC, device=dev, dtype=torch.float32)
         d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
         ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, d_wc, dbias=d_conv_b)

@@ -171,7 +171,33 @@ def absmax(x):
     return out
 
 
-def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
+# max |x| of a gradient tensor that the kernel which PRODUCED it already measured (sb_linear_args.absmax_out): saves the
+# separate pass over the tensor in the next backward recurrence.  Keyed by data pointer; the entry keeps the tensor
+# alive, so the address cannot be reused by another tensor while the hint exists.  Entries are consumed on use and the
+# table is cleared at every train step.
+_ABSMAX_HINTS = {}
+ABSMAX_HINTS = os.environ.get("SB_NO_ABSMAX_HINTS", "0") != "1"
+
+
+def absmax_hint_put(t, gmax):
+    if ABSMAX_HINTS:
+        if len(_ABSMAX_HINTS) > 64:
+            _ABSMAX_HINTS.clear()
+        _ABSMAX_HINTS[t.data_ptr()] = (t, gmax, t._version)
+
+
+def absmax_hints_clear():
+    _ABSMAX_HINTS.clear()
+
+
+def absmax_or_hint(x):
+    ent = _ABSMAX_HINTS.pop(x.data_ptr(), None)
+    if ent is not None and ent[0].numel() == x.numel() and ent[0].dtype == x.dtype and ent[0]._version == ent[2]:
+        return ent[1]
+    return absmax(x)
+
+
+def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
     """dhs [P, ndir*64] -- or, fused: dhs=None, dy [P, C] and w_lin [C, ndir*64] (see can_fuse_linear_bwd).
     -> DGates"""
     lib = L.load()
@@ -179,7 +205,7 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None):
     dev = dhs.device if dhs is not None else dy.device
     rec, cprev = gates
     dg16 = DGATES_FP16 and LSTM_MMA in (1, 2) and cprev is not None
-    gmax = absmax(dy if dy is not None else dhs) if dg16 else None
+    gmax = (gmax if gmax is not None else absmax_or_hint(dy if dy is not None else dhs)) if dg16 else None
     dg = torch.empty(geom.P, ndir, 4, H, device=dev, dtype=torch.float16 if dg16 else torch.float32)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, ndir
@@ -240,7 +266,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     dev = dy.device
     Cc = dy.shape[-1]
     assert can_fuse_stream(u, hs) and cprev is not None and w_lin.shape == (Cc, H) and u.shape[-1] == Cc
-    gmax = absmax(dy)
+    gmax = absmax_or_hint(dy)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 1
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
@@ -330,9 +356,10 @@ def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=N
 
 def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None, is_seg=0, n_valid=None,
            epi=L.EPI_NONE, res=None, res_strides=None, prelu_a=None, ln_g=None, ln_b=None, aux_in=None,
-           aux_out=None, want_partials=False, accumulate=False, in_off=0, out_off=0, res_off=0):
+           aux_out=None, want_partials=False, accumulate=False, in_off=0, out_off=0, res_off=0, absmax_out=None):
     """out[p, :N] = epi(W[N,K] . in(p, :K) + bias).  grid = (B, T, F); strides in floats.
-    N is chunked into <=128-wide launches when needed (not for LN epilogues)."""
+    N is chunked into <=128-wide launches when needed (not for LN epilogues).
+    absmax_out (EPI_NONE / EPI_RES): zeroed [1] tensor that receives max |out| (the gmax of a following lstm_bwd_rec)."""
     lib = L.load()
     B_, T_, F_ = grid
     n_valid = N if n_valid is None else n_valid
@@ -359,6 +386,9 @@ def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None,
             a.res = _poff(res, res_off + n0)
             a.rs_b, a.rs_t, a.rs_f = res_strides if res_strides is not None else out_strides
         a.prelu_a, a.ln_g, a.ln_b = _p(prelu_a), _p(ln_g), _p(ln_b)
+        if absmax_out is not None:
+            assert epi in (L.EPI_NONE, L.EPI_RES)
+            a.absmax_out = _p(absmax_out)
         a.aux_in, a.aux_out = _p(aux_in), _p(aux_out)
         if want_partials:
             assert n0 == 0 and nc == N

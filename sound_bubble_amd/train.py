@@ -86,10 +86,13 @@ def train_step(model, bucket, optim, inputs, target, neg_weight, grad_clip=None)
     """zero_grad -> forward -> SNRLP loss.mean() -> backward -> all-reduce -> clip -> Adam
     (tain_val.py:66-80 + hl_module:303-321,430-441).  Returns the (device) loss scalar."""
     from .functional import SnrlpLossFn
+    from . import ops
     bucket.zero_grad()
     est = model(inputs)["output"]
     loss, _ = SnrlpLossFn.apply(est, target, neg_weight)
+    ops.absmax_hints_clear()
     loss.backward()
+    ops.absmax_hints_clear()
     world = allreduce_grads(bucket)
     optim.step(grad_clip=grad_clip, world_size=world)
     return loss.detach()

@@ -522,3 +522,30 @@ def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch
     dwl = dy.double().t() @ hs.double()
     assert rel_l2(ltg[0].cpu().numpy(), dwl.cpu().numpy()) < 1e-3
     assert rel_l2(ltg[1].cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_linear_reports_absmax_of_its_output(torch_gpu):
+    """sb_linear_args.absmax_out: the kernel that writes a gradient tensor also measures max |.| of what it stored
+    (bit-exact, atomicMax over workgroups), which the next backward recurrence takes as its gmax instead of a separate
+    sb_absmax pass (ops.absmax_hint_put / absmax_or_hint)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops, _lib as L
+    from sound_bubble_amd.functional import dense
+    torch.manual_seed(2)
+    P, K, N = 5 * 7 * 29, 80, 128
+    x, w = torch.randn(P, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.3
+    res = torch.randn(P, N, device="cuda")
+    g, sK = dense(P, K)
+    _, sN = dense(P, N)
+    for epi, r in ((L.EPI_NONE, None), (L.EPI_RES, res)):
+        out = torch.empty(P, N, device="cuda")
+        gm = torch.zeros(1, device="cuda")
+        ops.linear(x, w, None, out, g, sK, sN, K, N, epi=epi, res=r, absmax_out=gm)
+        assert float(gm) == float(out.abs().max())
+        ops.absmax_hint_put(out, gm)
+        assert ops.absmax_or_hint(out) is gm                     # consumed ...
+        assert float(ops.absmax_or_hint(out)) == float(gm)       # ... then measured again
+        ops.absmax_hint_put(out, gm)
+        out.add_(1.0)                                            # modified after the hint: not trusted
+        assert ops.absmax_or_hint(out) is not gm
