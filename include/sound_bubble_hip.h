@@ -160,6 +160,11 @@ typedef struct {
   float* dW; float* dW2; float* dbias; float* dbias2; float* scratch;
   int in_f16;   /* 1: `in` points at fp16 elements (strides in elements), e.g. the fp16 hs of sb_lstm_fwd (aux_f16);
                    supported for K == 64, K2 == 0, N <= 32 */
+  /* output index remapping of the reduction, so that gradients land in a parameter's native layout (no transposed
+     copies on the host): with perm_k = c > 0 column k = j*c + i is written as i*(K/c) + j; with perm_n = c > 0 row
+     n = j*c + i as i*(N/c) + j (Conv1d / ConvTranspose1d weights [out, in, k] addressed as [out][k*in + i]);
+     bias_mod = c > 0 folds the bias gradient: dbias[n % c] += ... */
+  int perm_k, perm_n, bias_mod;
 } sb_wgrad_args;
 int sb_wgrad(const sb_wgrad_args* a, void* stream);
 int sb_wgrad_grid(int64_t positions);

@@ -54,7 +54,7 @@ class WgradArgs(C.Structure):
                 ("in2", c_fp), ("ld2", i64), ("shift2", i64), ("K2", C.c_int),
                 ("seg_len", C.c_int), ("skip_first", C.c_int), ("skip_last", C.c_int),
                 ("transpose_out", C.c_int), ("dW", c_fp), ("dW2", c_fp), ("dbias", c_fp), ("dbias2", c_fp),
-                ("scratch", c_fp), ("in_f16", C.c_int)]
+                ("scratch", c_fp), ("in_f16", C.c_int), ("perm_k", C.c_int), ("perm_n", C.c_int), ("bias_mod", C.c_int)]
 
 
 class LstmStreamArgs(C.Structure):

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(sb_wgrad_args a, int64_
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int rows, int N, int K1,
                                                            int K2, float* __restrict__ dW1, float* __restrict__ dW2,
                                                            float* __restrict__ db1, float* __restrict__ db2,
-                                                           int transpose_out) {
+                                                           int transpose_out, int perm_k, int perm_n, int bias_mod) {
   const int Ktot = K1 + K2;
   const int total = N * Ktot + N;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -495,12 +495,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   s += sa + sb + sc;
   if (i < N * Ktot) {
     const int n = i / Ktot, k = i - n * Ktot;
-    if (k < K1) atomicAdd(dW1 + (transpose_out ? (size_t)k * N + n : (size_t)n * K1 + k), s);
-    else if (dW2) atomicAdd(dW2 + (size_t)n * K2 + (k - K1), s);
+    if (k < K1) {
+      // destination in the parameter's native layout (sb_wgrad_args.perm_k / perm_n)
+      const int kd = perm_k > 0 ? (k % perm_k) * (K1 / perm_k) + k / perm_k : k;
+      const int nd = perm_n > 0 ? (n % perm_n) * (N / perm_n) + n / perm_n : n;
+      atomicAdd(dW1 + (transpose_out ? (size_t)kd * N + nd : (size_t)nd * K1 + kd), s);
+    } else if (dW2) atomicAdd(dW2 + (size_t)n * K2 + (k - K1), s);
   } else {
     const int n = i - N * Ktot;
-    if (db1) atomicAdd(db1 + n, s);
-    if (db2) atomicAdd(db2 + n, s);
+    const int nb = bias_mod > 0 ? n % bias_mod : n;
+    if (db1) atomicAdd(db1 + nb, s);
+    if (db2) atomicAdd(db2 + nb, s);
   }
 }
 
@@ -617,6 +622,8 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (P <= 0 || P >= (1ll << 31)) return -1001;          // 32-bit position arithmetic in the kernels
   const int nblk = (a.N + 15) / 16, kt1 = (a.K + 15) / 16, kt2 = a.K2 / 16, ntw = nblk;
   if (a.K2 % 16 || (a.K2 && a.K % 16)) return -1002;
+  if ((a.perm_k > 0 && a.K % a.perm_k) || (a.perm_n > 0 && a.N % a.perm_n) || a.perm_k < 0 || a.perm_n < 0 || a.bias_mod < 0)
+    return -1002;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(sb_wgrad_grid(P)), block(256);
   // wide-load kernel: single source, whole tiles, whole segments, rows aligned for 16-byte (fp16: 8-byte) loads
@@ -651,7 +658,8 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   SB_CHECK_LAUNCH();
   const int total = a.N * (a.K + a.K2) + a.N;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, grid.x >= 64 ? 16 : 1), dim3(256), 0, st, a.scratch,
-                     (int)grid.x * 4, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out);
+                     (int)grid.x * 4, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out, a.perm_k, a.perm_n,
+                     a.bias_mod);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -194,13 +194,14 @@ class IntraConvFn(torch.autograd.Function):
             y[:, :, Fm:, :] = x[:, :, Fm:, :] + (dec_b if bias_tail else 0.0)
         if train:
             ctx.save_for_backward(x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, ln_b, bif, bhf, bir, bhr,
-                                  *[t for t in gates if t is not None])
+                                  conv_w, conv_b, dec_w, dec_b, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc, down, Kd, bool(bias_tail))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, ln_b, bif, bhf, bir, bhr, *g_ = ctx.saved_tensors
+        (x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, ln_b, bif, bhf, bir, bhr, conv_w, conv_b, dec_w, dec_b,
+         *g_) = ctx.saved_tensors
         gates = (g_[0], g_[1] if len(g_) > 1 else None)
         gt = _GradTargets()
         B, T, F, Cc, down, Kd, bias_tail = ctx.dims
@@ -218,13 +219,12 @@ class IntraConvFn(torch.autograd.Function):
         dhs = torch.empty(P2, 2 * H, device=dev, dtype=torch.float32)
         gm_dhs = torch.zeros(1, device=dev, dtype=torch.float32) if ops.ABSMAX_HINTS else None   # max |dhs| on the fly
         ops.linear(dym, wd.t().contiguous(), None, dhs, gP2, sNC, s2H, NC, 2 * H, absmax_out=gm_dhs)
-        d_wd = torch.zeros(NC, 2 * H, device=dev, dtype=torch.float32)
-        d_bd = torch.zeros(NC, device=dev, dtype=torch.float32)
-        ops.wgrad(dym, NC, NC, hs, s2H, gP2, 2 * H, d_wd, dbias=d_bd)
-        d_dec_w = d_wd.view(down, Cc, 2 * H).permute(2, 1, 0).contiguous()
-        d_dec_b = d_bd.view(down, Cc).sum(0)
+        # dW[n = j*C + c][k = h] and its bias sums land in the parameters' native layout: dec_w [2H, C, down] (transposed,
+        # rows n -> c*down + j), dec_b [C] (rows folded mod C) -- straight into the .grad buffers when they exist
+        t_dec_w, t_dec_b = gt("dec_w", dec_w), gt("dec_b", dec_b)
+        ops.wgrad(dym, NC, NC, hs, s2H, gP2, 2 * H, t_dec_w, dbias=t_dec_b, transpose_out=True, perm_n=Cc, bias_mod=Cc)
         if Fm < F and bias_tail:
-            d_dec_b = d_dec_b + dy[:, :, Fm:, :].sum((0, 1, 2))
+            t_dec_b += dy[:, :, Fm:, :].sum((0, 1, 2))
         # BPTT
         geom = Geom.intra(B * T, Kd)
         dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, gmax=gm_dhs)
@@ -245,12 +245,10 @@ class IntraConvFn(torch.autograd.Function):
             dx[:, :, Fm:, :] = dy[:, :, Fm:, :]
         if gm_dx is not None:
             ops.absmax_hint_put(dx, gm_dx)
-        d_wc = torch.zeros(Cc, NC, device=dev, dtype=torch.float32)
-        d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
-        ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, d_wc, dbias=d_conv_b)
-        d_conv_w = d_wc.view(Cc, down, Cc).permute(0, 2, 1).contiguous()
-        return (dx, d_conv_w, d_conv_b, gt["act_a"], gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"],
-                gt["wir"], gt["whr"], gt["bir"], gt["bhr"], d_dec_w, d_dec_b, None, None)
+        # dW[co][k = j*C + ci] -> conv_w [co, ci, j]
+        ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, gt("conv_w", conv_w), dbias=gt("conv_b", conv_b), perm_k=Cc)
+        return (dx, gt["conv_w"], gt["conv_b"], gt["act_a"], gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"],
+                gt["bhf"], gt["wir"], gt["whr"], gt["bir"], gt["bhr"], gt["dec_w"], gt["dec_b"], None, None)
 
 
 class AttentionFn(torch.autograd.Function):

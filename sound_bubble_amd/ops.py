@@ -409,7 +409,7 @@ def dense(P, ld):
 
 def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=None, is_seg=0, in2=None, ld2=0,
           in2_off=0, shift2=0, K2=0, dW2=None, seg_len=None, skip_first=0, skip_last=0, dbias=None, dbias2=None,
-          transpose_out=False):
+          transpose_out=False, perm_k=0, perm_n=0, bias_mod=0):
     """dW[N,K] += sum_p g[p,:N]^T in(p,:K);  dW2[N,K2] += sum_p g^T in2[p*ld2+shift2 : +K2] (segment-masked);
     dbias (+dbias2) += column sums of g.  One pass over g."""
     lib = L.load()
@@ -433,6 +433,7 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     a.seg_len = P if seg_len is None else seg_len
     a.skip_first, a.skip_last = skip_first, skip_last
     a.transpose_out = 1 if transpose_out else 0
+    a.perm_k, a.perm_n, a.bias_mod = perm_k, perm_n, bias_mod     # native-layout destinations (see the header)
     a.dW, a.dW2, a.dbias, a.dbias2, a.scratch = _p(dW, "dW"), _p(dW2), _p(dbias), _p(dbias2), _p(scratch)
     L.check(lib.sb_wgrad(C.byref(a), _stream()), "sb_wgrad")
 
