@@ -96,13 +96,17 @@ typedef struct {
      running dW_ih / dW_hh / db sums and forms du [P, C] = dgates . W_ih (gradient w.r.t. the LayerNorm output);
      `dgates` is not written.  h_prev of (sequence, step) is hs at step - 1 (zero at step 0).  The weight gradient of
      the fused Linear rides along (dW_lin [C, 64] += dy^T hs, db_lin [C] += column sums of dy; dy enters as a single
-     scaled fp16 term like the dgates).  wpart: one row of 256*(C+64)+256 + C*64 + C floats per workgroup, at most
+     scaled fp16 term like the dgates).  wpart: one row of 256*(C+64)+256 + C*64 + C (+ 2*C with dx) floats per workgroup, at most
      ceil(nseq/16) rows; they are ADDED into dW_ih [256, C], dW_hh [256, 64], db_ih / db_hh [256] (and dW_lin / db_lin
      when non-NULL) by reductions the call launches itself. */
   const void* u; const void* hs; const float* w_ih; int C;
   float* du; float* wpart;
   float* dW_ih; float* dW_hh; float* db_ih; float* db_hh;
   float* dW_lin; float* db_lin;
+  /* ... and (C == 16) the LayerNorm backward that follows: when dx != NULL, du is not written; instead
+     dx [P, C] = LN-backward(du; ln_x, ln_g) + dy (the residual branch), ln_x [P, C] the pre-LayerNorm input, and
+     d_ln_g / d_ln_b [C] += the parameter gradients (wpart rows grow by 2*C floats). */
+  const float* ln_x; const float* ln_g; float* dx; float* d_ln_g; float* d_ln_b;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

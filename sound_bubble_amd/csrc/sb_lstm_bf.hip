@@ -550,7 +550,9 @@ SB_DEVINL float grad_scale(const float* gmax) {
 // h_prev arrive as the fp16 side outputs of the forward kernel.  Saves the 512 B/position dgates round trip (the
 // store alone was 17-45 % of this kernel) and the whole streaming launch.
 constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four position groups of a load hit distinct banks)
-template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0>
+// LNB (FST == 16): the LayerNorm backward of the block runs in the flush of the du rows (one wave holds all 16 channels
+// of its 16 positions), dx = LN-backward(du) + dy goes out instead of du.
+template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -583,11 +585,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   int64_t base = 0, rec_tile = 0;
   int posb[FST > 0 ? 8 : 1];                      // FST: step-0 position of sequence 8 (q & 1) + kk (chunk slot 8q + kk)
   unsigned slotv = 0;                             // ... and whether that sequence exists (bit kk)
+  int posq[2] = {0, 0};                           // LNB: step-0 position of this lane's two flush sequences
+  bool fvalid[2] = {false, false};
   auto set_tile = [&](int tile) {
     rec_tile = (int64_t)tile * S;
     const int nc = tile * 16 + j;
     valid = FULL || nc < a.nseq;
     base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    if constexpr (LNB) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int n3 = tile * 16 + 8 * (w & 1) + 2 * q + r;
+        fvalid[r] = FULL || n3 < a.nseq;
+        posq[r] = fvalid[r] ? (int)((int64_t)(n3 / a.n_inner) * a.p_outer + (int64_t)(n3 % a.n_inner) * a.p_inner) : 0;
+      }
+    }
     if constexpr (FST > 0) {
       slotv = 0;
 #pragma unroll
@@ -638,7 +650,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // u / h_prev rows of the 32 slots of a chunk; dyv: dy of the h_prev rows' own positions (Linear weight gradient)
   // RAW loaded registers only: any arithmetic on them here would pin an s_waitcnt behind the loads at the top of the
   // loop body (the select of the first version did, and doubled the kernel time once the dy loads joined)
-  struct PairOps { h16x4 hh4[8]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8]; float dyv[CK][8]; };
+  struct PairOps { h16x4 hh4[8]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8]; float dyv[CK][8];
+                   float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
+  static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
+  // LNB: the du tile is formed TRANSPOSED (positions as rows, channels as columns: the two MFMA operands swapped), so a
+  // lane holds channel j of positions 4q..4q+3 and the LayerNorm sums over the 16 channels are DPP sums within a
+  // 16-lane row.  (With channels along the rows they were __shfl chains across rows: ~1000 exposed cycles per pair.)
+  // The 32 positions of a chunk are split over all four waves: wave w takes step sa - (w >> 1), sequences
+  // 8 (w & 1) + 2q + r, r = 0, 1.
+  float lng = 0.f, dgam = 0.f, dbet = 0.f;
+  if constexpr (LNB) lng = a.ln_g[j];
   f32x4 lacc[CK];                                  // dW_lin tile: channels 16ct + 4q + r x units 4j + w
   float lbs[CK];                                   // db_lin: channel 16ct + j, this lane's positions
 #pragma unroll
@@ -662,6 +683,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       // the Linear's weight gradient pairs h of a position with dy of the SAME position (step st - 1)
 #pragma unroll
       for (int ct = 0; ct < CK; ++ct) o.dyv[ct][kk] = dyj[posh * FST + 16 * ct];
+    }
+    if constexpr (LNB) {                           // channel j of (step sa - (w >> 1), sequences 8 (w & 1) + 2q + r)
+      const int stf = sa - ((w >> 1) && two ? 1 : 0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int64_t posf = (int64_t)posq[r] + (int64_t)stf * a.p_step;
+        o.xq[r] = a.ln_x[posf * FST + j];
+        o.rq[r] = a.dy[posf * FST + j];
+      }
     }
     return o;
   };
@@ -722,8 +752,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         const h16x8 d8 = *reinterpret_cast<const h16x8*>(&DG[sl + sb][j][64 * w + 32 * m + 8 * q]);
 #pragma unroll
         for (int ct = 0; ct < CK; ++ct) {
-          du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].lo, d8, du[ct], 0, 0, 0);
-          du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8, du[ct], 0, 0, 0);
+          if constexpr (LNB) {                     // du^T: rows = positions, columns = channels
+            du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].lo, du[ct], 0, 0, 0);
+            du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].hi, du[ct], 0, 0, 0);
+          } else {
+            du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].lo, d8, du[ct], 0, 0, 0);
+            du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8, du[ct], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
@@ -758,13 +793,39 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   const float invS = 1.0f / gS;                    // gS is a power of two
   // du rows of a finished chunk (its R[buf] is complete after the barrier that followed it): wave w < 2 CK reduces
   // sub-tile sb = w / CK (step sa - sb), channel tile ct = w % CK
-  auto flush = [&](int sa, int nsteps_in_chunk, int buf) {
-    const int sb = w / CK, ct = w % CK;
-    if (w < 2 * CK && sb < nsteps_in_chunk && valid) {
-      const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
-                       ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
-      const int64_t pos = base + (int64_t)(sa - sb) * a.p_step;
-      st4(a.du + pos * FST + 16 * ct + 4 * q, s4 * invS);
+  auto flush = [&](int sa, int nsteps_in_chunk, int buf, const float (&xq)[2], const float (&rq)[2]) {
+    if constexpr (LNB) {
+      const int sbf = w >> 1;
+      if (sbf < nsteps_in_chunk) {
+        const int st = sa - sbf;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          // du of (sequence n0, channel j): element n0 & 3 of lane (n0 >> 2, j) of the transposed tile, summed over waves
+          const int n0 = 8 * (w & 1) + 2 * q + r;
+          const int sl = (n0 >> 2) * 16 + j, el = n0 & 3;
+          const float du = (R[buf][0][sbf][0][sl][el] + R[buf][1][sbf][0][sl][el] + R[buf][2][sbf][0][sl][el] +
+                            R[buf][3][sbf][0][sl][el]) * invS;
+          const float x = xq[r];
+          const float mean = row16_sum(x) * (1.0f / 16);
+          const float d = x - mean;
+          const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(row16_sum(d * d), 1.0f / 16, 1e-5f));   // v_rsq_f32, 1 ulp
+          const float xh = d * rstd, gg = du * lng;
+          dgam = __builtin_fmaf(du, xh, dgam);
+          dbet += du;
+          const float m1 = row16_sum(gg) * (1.0f / 16), m2 = row16_sum(gg * xh) * (1.0f / 16);
+          const float dxv = (gg - m1 - xh * m2) * rstd + rq[r];
+          const int64_t pos = (int64_t)posq[r] + (int64_t)st * a.p_step;
+          if (fvalid[r]) a.dx[pos * FST + j] = dxv;
+        }
+      }
+    } else {
+      const int sb = w / CK, ct = w % CK;
+      if (w < 2 * CK && sb < nsteps_in_chunk && valid) {
+        const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
+                         ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
+        const int64_t pos = base + (int64_t)(sa - sb) * a.p_step;
+        st4(a.du + pos * FST + 16 * ct + 4 * q, s4 * invS);
+      }
     }
   };
 
@@ -973,6 +1034,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       // has written both rows by then); its du partial sums are reduced after the NEXT barrier (flush).  The slots of
       // pair k are rewritten by pair k + 2, two barriers after every wave has finished chunk k.
       int pk = 0, pend_s = 0, pend_n = 0;
+      float pend_x[2] = {0.f, 0.f}, pend_r[2] = {0.f, 0.f};
       if (s_hi == S - 1) lin_top();
       for (; s >= s_lo + 1; s -= 2, pk ^= 1) {
         Raw curA = rA, curB = rB;
@@ -983,27 +1045,29 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         const PairOps ops2 = pair_loads(s, true);
         __builtin_amdgcn_sched_barrier(0);
         step(s, curA, 2 * pk);
-        if (pend_n) flush(pend_s, pend_n, pk ^ 1);
+        if (pend_n) flush(pend_s, pend_n, pk ^ 1, pend_x, pend_r);
         consume(curB);
         step(s - 1, curB, 2 * pk + 1);
         chunk(2 * pk, pk, ops2, s, true);
         pend_s = s; pend_n = 2;
+        pend_x[0] = ops2.xq[0]; pend_x[1] = ops2.xq[1]; pend_r[0] = ops2.rq[0]; pend_r[1] = ops2.rq[1];
       }
       if (s == s_lo) {                                   // odd step count: a chunk with an empty second half
         consume(rA);
         const PairOps ops1 = pair_loads(s_lo, false);
         step(s_lo, rA, 2 * pk);
-        if (pend_n) flush(pend_s, pend_n, pk ^ 1);
+        if (pend_n) flush(pend_s, pend_n, pk ^ 1, pend_x, pend_r);
         const h16x4 hz = {0, 0, 0, 0};
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<h16x4*>(&DG[2 * pk + 1][j][g * H + uoff]) = hz;
         __syncthreads();
         chunk(2 * pk, pk, ops1, s_lo, false);
         pend_s = s_lo; pend_n = 1;
+        pend_x[0] = ops1.xq[0]; pend_x[1] = ops1.xq[1]; pend_r[0] = ops1.rq[0]; pend_r[1] = ops1.rq[1];
         pk ^= 1;
       }
       __syncthreads();                                   // R of the last chunk complete
-      if (pend_n) flush(pend_s, pend_n, pk ^ 1);
+      if (pend_n) flush(pend_s, pend_n, pk ^ 1, pend_x, pend_r);
     } else {
     for (; s >= s_lo + 1; s -= 2) {
       Raw curA = rA, curB = rB;
@@ -1035,7 +1099,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   }
   if constexpr (FST > 0) {                           // this workgroup's partial row of the weight / bias gradients
     constexpr int Ktot = FST + H;
-    float* part = a.wpart + (size_t)blockIdx.x * ((size_t)4 * H * Ktot + 4 * H + FST * H + FST);
+    float* part = a.wpart + (size_t)blockIdx.x * ((size_t)4 * H * Ktot + 4 * H + FST * H + FST + (LNB ? 2 * FST : 0));
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -1056,6 +1120,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       for (int r = 0; r < 4; ++r) plin[(size_t)(16 * ct + 4 * q + r) * H + 4 * j + w] = lacc[ct][r] * invS;
       const float bs = quad_sum(lbs[ct]);
       if (w == 0 && q == 0) plin[(size_t)FST * H + 16 * ct + j] = bs * invS;
+    }
+    if constexpr (LNB) {                             // LayerNorm parameter gradients: waves 0 / 1 hold the two steps' sums
+      __syncthreads();
+      float* red = &R[0][0][0][0][0][0];
+      const float g = quad_sum(dgam), b = quad_sum(dbet);      // over the four lane rows
+      if (q == 0) { red[w * 32 + j] = g; red[w * 32 + 16 + j] = b; }
+      __syncthreads();
+      if (tid < 32) plin[(size_t)FST * H + FST + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
     }
   }
 #ifdef SB_PHASE_TIMING
@@ -1167,20 +1239,25 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   // fused streaming part (see the kernel): single direction, fused Linear backward with the same channel count
   const bool fst = a.wpart != nullptr;
   if (fst) {
-    if (!dg16 || a.ndir != 1 || !a.u || !a.hs || !a.w_ih || !a.du || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
+    if (!dg16 || a.ndir != 1 || !a.u || !a.hs || !a.w_ih || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
         (a.C != 16 && a.C != 32) || fc != a.C || (int64_t)a.nseq * a.nsteps >= (1ll << 31))
       return -1003;
-#define SB_F(FL, CC, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC>), grid, block, 0, st, a)
-#define SB_FC(CC) do { if (full) { if (seg) SB_F(true, CC, true); else SB_F(true, CC, false); } \
-                       else { if (seg) SB_F(false, CC, true); else SB_F(false, CC, false); } } while (0)
-    if (a.C == 16) SB_FC(16); else SB_FC(32);
+    const bool lnb = a.dx != nullptr;
+    if (lnb && (a.C != 16 || !a.ln_x || !a.ln_g)) return -1003;
+    if (!lnb && !a.du) return -1003;
+#define SB_F(FL, CC, SG, LB) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC, LB>), grid, block, 0, st, a)
+#define SB_FC(CC, LB) do { if (full) { if (seg) SB_F(true, CC, true, LB); else SB_F(true, CC, false, LB); } \
+                           else { if (seg) SB_F(false, CC, true, LB); else SB_F(false, CC, false, LB); } } while (0)
+    if (a.C == 16) { if (lnb) SB_FC(16, true); else SB_FC(16, false); } else SB_FC(32, false);
 #undef SB_FC
 #undef SB_F
-    const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + a.C * H + a.C;
+    const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + a.C * H + a.C + (lnb ? 2 * a.C : 0);
     int rc = sb_launch_stream_reduce(a.wpart, (int)grid.x, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
     const float* plin = a.wpart + (size_t)4 * H * (a.C + H) + 4 * H;
     if (!rc && a.dW_lin) rc = sb_reduce_rows(plin, (int)grid.x, ld, a.C * H, a.dW_lin, st);
     if (!rc && a.db_lin) rc = sb_reduce_rows(plin + a.C * H, (int)grid.x, ld, a.C, a.db_lin, st);
+    if (!rc && lnb && a.d_ln_g) rc = sb_reduce_rows(plin + a.C * H + a.C, (int)grid.x, ld, a.C, a.d_ln_g, st);
+    if (!rc && lnb && a.d_ln_b) rc = sb_reduce_rows(plin + a.C * H + 2 * a.C, (int)grid.x, ld, a.C, a.d_ln_b, st);
     return rc;
   }
 #define SB_B(FL, R16, FC, D16, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a)

@@ -148,8 +148,13 @@ class InterFn(torch.autograd.Function):
         tg = [(gt("wi", wi), gt("wh", wh), gt("bi", bi), gt("bh", bh))]
         if fuse and ops.can_fuse_stream(u, hs, geom):
             # recurrence + streaming part + the Linear's weight gradient in one launch (where it pays)
+            ln = (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)) if (Cc == 16 and ops.FUSED_LN_BWD) else None
             du = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
-                                    lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b))).view(P, 1, Cc)
+                                    lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)), ln=ln).view(P, 1, Cc)
+            if ln is not None:                         # ... and the LayerNorm backward + residual: du is dx already
+                dx = du.view(B, T, F, Cc)
+                return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
+                        None, None)
         else:
             ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
             dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,

@@ -233,6 +233,7 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
 # single-direction passes on the default path: the streaming part runs inside the backward recurrence (the dgates stay in
 # LDS); SB_NO_FUSED_BPTT=1 keeps the two-kernel form
 FUSED_BPTT = os.environ.get("SB_NO_FUSED_BPTT", "0") != "1"
+FUSED_LN_BWD = os.environ.get("SB_NO_FUSED_LN", "0") != "1"      # ... and the block's LayerNorm backward with it (C = 16)
 
 
 _CU_COUNT = {}
@@ -256,11 +257,13 @@ def can_fuse_stream(u, hs, geom=None):
     return ok
 
 
-def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets=None):
+def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets=None, ln=None):
     """Backward of a single-direction LSTM whose Linear is fused (see lstm_fwd(lin=...)): recurrence + streaming part in
     one launch.  dy [P, C]; u [P, C], hs [P, 64] fp16 side outputs of the forward; targets = (dW_ih, dW_hh, db_ih,
     db_hh), lin_targets = (dW_lin [C, 64], db_lin [C]) (optional): accumulated into.
-    -> du [P, C] (gradient w.r.t. the LayerNorm output)"""
+    ln = (x [P, C] pre-LayerNorm input, ln_g, d_ln_g, d_ln_b) (C == 16 only): the LayerNorm backward runs in the
+    kernel as well and the result is dx = LN-backward(du) + dy instead of du.
+    -> du [P, C] (gradient w.r.t. the LayerNorm output), or dx [P, C] with ln"""
     lib = L.load()
     rec, cprev = gates
     dev = dy.device
@@ -282,9 +285,15 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
                        torch.empty(ntiles, device=dev, dtype=torch.int32))
         a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
     du = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32)
-    wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H + Cc * H + Cc, device=dev, dtype=torch.float32)
+    wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H + Cc * H + Cc + (2 * Cc if ln is not None else 0), device=dev,
+                        dtype=torch.float32)
     a.u, a.hs, a.w_ih, a.C = _ph(u), _ph(hs), _p(w_ih), Cc
-    a.du, a.wpart = _p(du), _p(wpart)
+    a.wpart = _p(wpart)
+    if ln is not None:
+        assert Cc == 16
+        a.ln_x, a.ln_g, a.dx, a.d_ln_g, a.d_ln_b = _p(ln[0]), _p(ln[1]), _p(du), _p(ln[2]), _p(ln[3])
+    else:
+        a.du = _p(du)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets)
     if lin_targets is not None:
         assert lin_targets[0].shape == (Cc, H)

@@ -522,6 +522,19 @@ def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch
     dwl = dy.double().t() @ hs.double()
     assert rel_l2(ltg[0].cpu().numpy(), dwl.cpu().numpy()) < 1e-3
     assert rel_l2(ltg[1].cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-3
+    if C_ == 16:
+        # ... and with the LayerNorm backward + residual in the same launch: dx, d_gamma, d_beta against sb_ln_bwd on du
+        dgr, dbr = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+        dx_ref, _, _, _ = ops.ln_bwd(du_ref, x, g, res=dy, d_g=dgr, d_b=dbr)
+        tg2 = [torch.zeros_like(t) for t in tg]
+        dgf, dbf = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+        dx = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg2, ln=(x, g, dgf, dbf))
+        torch.cuda.synchronize()
+        assert rel_l2(dx.cpu().numpy(), dx_ref.cpu().numpy()) < 2e-6
+        assert rel_l2(dgf.cpu().numpy(), dgr.cpu().numpy()) < 2e-5
+        assert rel_l2(dbf.cpu().numpy(), dbr.cpu().numpy()) < 2e-5
+        for a_, b_ in zip(tg2, tg):
+            assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-6
 
 
 @pytest.mark.gpu
