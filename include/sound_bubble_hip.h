@@ -107,6 +107,10 @@ typedef struct {
      dx [P, C] = LN-backward(du; ln_x, ln_g) + dy (the residual branch), ln_x [P, C] the pre-LayerNorm input, and
      d_ln_g / d_ln_b [C] += the parameter gradients (wpart rows grow by 2*C floats). */
   const float* ln_x; const float* ln_g; float* dx; float* d_ln_g; float* d_ln_b;
+  /* Bidirectional passes (ndir == 2) fuse the same way with hs [P, 128] in fp32 (it feeds the following Linear), u fp16,
+     du [P, 2, C] per direction, no Linear / LayerNorm riders; direction 1 takes w_ih1 and accumulates into the *1
+     targets.  wpart: 2 * min(ceil(nseq/16), CUs/2) rows of 256*(C+64)+256 floats (persistent workgroups). */
+  const float* w_ih1; float* dW_ih1; float* dW_hh1; float* db_ih1; float* db_hh1;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

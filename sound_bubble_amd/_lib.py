@@ -33,7 +33,8 @@ class LstmBwdArgs(C.Structure):
                 ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int),
                 ("u", c_fp), ("hs", c_fp), ("w_ih", c_fp), ("C", C.c_int), ("du", c_fp), ("wpart", c_fp),
                 ("dW_ih", c_fp), ("dW_hh", c_fp), ("db_ih", c_fp), ("db_hh", c_fp), ("dW_lin", c_fp), ("db_lin", c_fp),
-                ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp)]
+                ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
+                ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp)]
 
 
 class LinearArgs(C.Structure):

@@ -552,7 +552,9 @@ SB_DEVINL float grad_scale(const float* gmax) {
 constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four position groups of a load hit distinct banks)
 // LNB (FST == 16): the LayerNorm backward of the block runs in the flush of the du rows (one wave holds all 16 channels
 // of its 16 positions), dx = LN-backward(du) + dy goes out instead of du.
-template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false>
+// BI (FST > 0, two directions): hs is the fp32 [P, 128] tensor, du goes to [P, 2, C], no Linear / LayerNorm riders;
+// persistent workgroups (gridDim.x <= tiles) walk several tiles.
+template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -639,7 +641,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       for (int m = 0; m < 2; ++m) {
         float t[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) t[kk] = a.w_ih[(size_t)(64 * w + 32 * m + 8 * q + kk) * FST + 16 * ct + j];
+        for (int kk = 0; kk < 8; ++kk)
+          t[kk] = (dir == 0 ? a.w_ih : a.w_ih1)[(size_t)(64 * w + 32 * m + 8 * q + kk) * FST + 16 * ct + j];
         Awt[ct][m] = splith8(t);
       }
 #pragma unroll
@@ -650,7 +653,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // u / h_prev rows of the 32 slots of a chunk; dyv: dy of the h_prev rows' own positions (Linear weight gradient)
   // RAW loaded registers only: any arithmetic on them here would pin an s_waitcnt behind the loads at the top of the
   // loop body (the select of the first version did, and doubled the kernel time once the dy loads joined)
-  struct PairOps { h16x4 hh4[8]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8]; float dyv[CK][8];
+  static_assert(!BI || (!LNB && !SEG), "bidirectional fused form: no riders, no time segments");
+  struct PairOps { h16x4 hh4[BI ? 1 : 8]; f32x4 hh32[BI ? 8 : 1]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8];
+                   float dyv[CK][BI ? 1 : 8];
                    float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
   static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
   // LNB: the du tile is formed TRANSPOSED (positions as rows, channels as columns: the two MFMA operands swapped), so a
@@ -666,23 +671,30 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   for (int ct = 0; ct < CK; ++ct) { lacc[ct] = zero4(); lbs[ct] = 0.f; }
   const float* __restrict__ dyj = a.dy + j;
   const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs);
+  const float* __restrict__ hs32 = reinterpret_cast<const float*>(a.hs) + dir * H;
+  // walk index s of this direction <-> time step; the step before walk index s (its h is h_prev) is walk index s - 1
+  auto st_of = [&](int s) { return rev ? S - 1 - s : s; };
   const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
   // slot 8q + kk of the chunk of steps (sa, sa - 1): step sa - (q >> 1), sequence 8 (q & 1) + kk.  `two` = false: the
   // second step does not exist (its dgates rows are zero; addresses clamped to the first)
   auto pair_loads = [&](int sa, bool two) {
     PairOps o;
-    const int st = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
-    const bool hp = st > 0;                        // h_prev of step 0 is the (zero) initial state: masked in chunk()
+    const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
+    const bool hp = sw > 0;                        // h_prev of the first step is the (zero) initial state: masked in chunk()
+    const int st = st_of(sw), sth = st_of(hp ? sw - 1 : sw);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int64_t pos = (int64_t)posb[kk] + (int64_t)st * a.p_step;
-      const int64_t posh = pos - (hp ? a.p_step : 0);
-      o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * H + 4 * j);
+      const int64_t posh = (int64_t)posb[kk] + (int64_t)sth * a.p_step;
+      if constexpr (BI) o.hh32[kk] = ld4(hs32 + posh * (2 * H) + 4 * j);
+      else o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * H + 4 * j);
       if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
       else o.uh1[kk] = u16[pos * FST + j];
-      // the Linear's weight gradient pairs h of a position with dy of the SAME position (step st - 1)
+      // the Linear's weight gradient pairs h of a position with dy of the SAME position (the h_prev row's)
+      if constexpr (!BI) {
 #pragma unroll
-      for (int ct = 0; ct < CK; ++ct) o.dyv[ct][kk] = dyj[posh * FST + 16 * ct];
+        for (int ct = 0; ct < CK; ++ct) o.dyv[ct][kk] = dyj[posh * FST + 16 * ct];
+      }
     }
     if constexpr (LNB) {                           // channel j of (step sa - (w >> 1), sequences 8 (w & 1) + 2q + r)
       const int stf = sa - ((w >> 1) && two ? 1 : 0);
@@ -698,8 +710,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   const h16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
   // chunk arithmetic on the dgates rows in LDS slots (sl, sl + 1); du partial sums -> R[buf]
   auto chunk = [&](int sl, int buf, const PairOps& o, int sa, bool two) {
-    const int st = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
-    const bool hp = st > 0;
+    const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
+    const bool hp = sw > 0;
     const h16x4 hz4 = {0, 0, 0, 0};
     h16x8 Bop[KT];
 #pragma unroll
@@ -709,10 +721,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const h16x4 hm = hp ? o.hh4[kk] : hz4;
+      if constexpr (BI) {
+        const f32x4 hm = hp ? o.hh32[kk] : zero4();
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = hm[kt];
+        for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = (_Float16)hm[kt];
+      } else {
+        const h16x4 hm = hp ? o.hh4[kk] : hz4;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = hm[kt];
+      }
     }
+    if constexpr (!BI)
 #pragma unroll
     for (int ct = 0; ct < CK; ++ct) {              // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
       h16x8 Ad;
@@ -823,8 +842,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       if (w < 2 * CK && sb < nsteps_in_chunk && valid) {
         const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
                          ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
-        const int64_t pos = base + (int64_t)(sa - sb) * a.p_step;
-        st4(a.du + pos * FST + 16 * ct + 4 * q, s4 * invS);
+        const int64_t pos = base + (int64_t)st_of(sa - sb) * a.p_step;
+        st4(a.du + (pos * ndir + dir) * FST + 16 * ct + 4 * q, s4 * invS);
       }
     }
   };
@@ -1035,7 +1054,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       // pair k are rewritten by pair k + 2, two barriers after every wave has finished chunk k.
       int pk = 0, pend_s = 0, pend_n = 0;
       float pend_x[2] = {0.f, 0.f}, pend_r[2] = {0.f, 0.f};
-      if (s_hi == S - 1) lin_top();
+      if constexpr (!BI) { if (s_hi == S - 1) lin_top(); }
       for (; s >= s_lo + 1; s -= 2, pk ^= 1) {
         Raw curA = rA, curB = rB;
         consume(curA);
@@ -1095,11 +1114,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         if (tid == 0) __hip_atomic_store(a.seg_flags + tile, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();                                 // the LDS exchange buffers are reused by the next item
+    } else if constexpr (FST > 0) {
+      __syncthreads();                                 // persistent workgroups: same, between tiles
     }
   }
   if constexpr (FST > 0) {                           // this workgroup's partial row of the weight / bias gradients
     constexpr int Ktot = FST + H;
-    float* part = a.wpart + (size_t)blockIdx.x * ((size_t)4 * H * Ktot + 4 * H + FST * H + FST + (LNB ? 2 * FST : 0));
+    float* part = a.wpart + ((size_t)dir * gridDim.x + blockIdx.x) *
+                  ((size_t)4 * H * Ktot + 4 * H + (BI ? 0 : FST * H + FST) + (LNB ? 2 * FST : 0));
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -1114,6 +1136,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
     }
     float* plin = part + (size_t)4 * H * Ktot + 4 * H;           // [C][64] dW_lin, then [C] db_lin
+    if constexpr (!BI)
 #pragma unroll
     for (int ct = 0; ct < CK; ++ct) {
 #pragma unroll
@@ -1238,6 +1261,24 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   }
   // fused streaming part (see the kernel): single direction, fused Linear backward with the same channel count
   const bool fst = a.wpart != nullptr;
+  if (fst && a.ndir == 2) {                          // bidirectional fused form: persistent workgroups, one per CU
+    if (!dg16 || !a.u || !a.hs || !a.w_ih || !a.w_ih1 || !a.du || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
+        !a.dW_ih1 || !a.dW_hh1 || !a.db_ih1 || !a.db_hh1 || (int64_t)a.nseq * a.nsteps * H >= (1ll << 31))
+      return -1003;
+    int gx = device_cu_count() / 2;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    dim3 g2(gx, 2);
+#define SB_FB(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true>), g2, block, 0, st, a)
+    if (a.C == 16 && fc == 0) { if (full) SB_FB(true, 0, 16); else SB_FB(false, 0, 16); }
+    else if (a.C == 32 && fc == 32) { if (full) SB_FB(true, 32, 32); else SB_FB(false, 32, 32); }
+    else return -1003;
+#undef SB_FB
+    const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H;
+    int rc = sb_launch_stream_reduce(a.wpart, gx, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
+    if (!rc) rc = sb_launch_stream_reduce(a.wpart + (size_t)gx * ld, gx, ld, a.C, a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1, st);
+    return rc;
+  }
   if (fst) {
     if (!dg16 || a.ndir != 1 || !a.u || !a.hs || !a.w_ih || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
         (a.C != 16 && a.C != 32) || fc != a.C || (int64_t)a.nseq * a.nsteps >= (1ll << 31))

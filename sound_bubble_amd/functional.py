@@ -86,12 +86,16 @@ class IntraPlainFn(torch.autograd.Function):
             ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, s2H, Cc, 2 * H)
         ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
         # BPTT
-        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
-                              w_lin=lin_w if fuse else None)
-        # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)
         tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
               (gt("wir", wir), gt("whr", whr), gt("bir", bir), gt("bhr", bhr))]
-        _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1, targets=tg)
+        if fuse and Cc == 32 and ops.can_fuse_stream_bi(u, hs):
+            # recurrence + streaming part in one launch (dgates stay in LDS)
+            du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w)
+        else:
+            dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
+                                  w_lin=lin_w if fuse else None)
+            # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)
+            _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1, targets=tg)
         dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b))
         dx = dx.view(B, T, F, Cc)
         return (dx, gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"], gt["wir"], gt["whr"], gt["bir"],
@@ -232,11 +236,14 @@ class IntraConvFn(torch.autograd.Function):
             t_dec_b += dy[:, :, Fm:, :].sum((0, 1, 2))
         # BPTT
         geom = Geom.intra(B * T, Kd)
-        dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, gmax=gm_dhs)
-        # one pass over dgates (weight grads + dU), then LayerNorm + PReLU backward -> gradient of the Conv1d output
         tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
               (gt("wir", wir), gt("whr", whr), gt("bir", bir), gt("bhr", bhr))]
-        _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, Kd, 1, targets=tg)
+        if Cc == 16 and ops.can_fuse_stream_bi(u, hs):
+            du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dhs=dhs, gmax=gm_dhs)
+        else:
+            dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, gmax=gm_dhs)
+            # one pass over dgates (weight grads + dU), then LayerNorm + PReLU backward -> gradient of the Conv1d output
+            _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, Kd, 1, targets=tg)
         dv, _, _, _ = ops.ln_bwd(du, v_pre, ln_g, prelu_a=act_a, d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
                                  d_a=gt("act_a", act_a))
         # Conv1d backward: dx = dy + dv . Wc ; dWc = dv^T x_rows

@@ -302,6 +302,51 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     return du
 
 
+FUSED_BPTT_BI = os.environ.get("SB_NO_FUSED_BPTT_BI", "0") != "1"
+
+
+def can_fuse_stream_bi(u, hs):
+    """bidirectional passes: fused form with fp32 hs (see lstm_bwd_fused_bi)"""
+    return (FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and COMPACT_BPTT and LSTM_MMA in (1, 2) and u is not None
+            and u.dtype == torch.float16 and hs.dtype == torch.float32 and u.shape[-1] in (16, 32))
+
+
+def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=None, dy=None, w_lin=None, gmax=None):
+    """Backward of a bidirectional LSTM pass, recurrence + streaming part in one launch (persistent workgroups, dgates in
+    LDS).  Incoming gradient: dhs [P, 128], or dy [P, C] with w_lin [C, 128] (fused Linear backward, C == 32).
+    u [P, C] fp16, hs [P, 128] fp32; targets[d] = (dW_ih, dW_hh, db_ih, db_hh) accumulated into.  -> du [P, 2, C]"""
+    lib = L.load()
+    rec, cprev = gates
+    dev = u.device
+    Cc = u.shape[-1]
+    assert can_fuse_stream_bi(u, hs) and cprev is not None and len(w_hh_list) == 2
+    if gmax is None:
+        gmax = absmax_or_hint(dy if dy is not None else dhs)
+    a = L.LstmBwdArgs()
+    a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 2
+    a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
+    a.w_hh[0], a.w_hh[1] = _p(w_hh_list[0]), _p(w_hh_list[1])
+    a.save_gates = C.c_void_p(rec.data_ptr())
+    a.save_c = C.c_void_p(cprev.data_ptr())
+    a.gmax, a.mma = _p(gmax), LSTM_MMA
+    if dy is not None:
+        assert w_lin.shape == (Cc, 2 * H) and dy.shape[-1] == Cc
+        a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
+    else:
+        a.dhs = _p(dhs)
+    ntiles = (geom.nseq + 15) // 16
+    rows = 2 * min(ntiles, max(1, _cu_count(dev) // 2))
+    du = torch.empty(geom.P, 2, Cc, device=dev, dtype=torch.float32)
+    wpart = torch.empty(rows, 4 * H * (Cc + H) + 4 * H, device=dev, dtype=torch.float32)
+    a.u, a.hs, a.C = _ph(u), _p(hs), Cc
+    a.w_ih, a.w_ih1 = _p(w_ih_list[0]), _p(w_ih_list[1])
+    a.du, a.wpart = _p(du), _p(wpart)
+    a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
+    a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
+    L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused, bidirectional)")
+    return du
+
+
 def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None):
     """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C].
     targets (optional): per direction 4 buffers the gradients are ACCUMULATED into (instead of fresh zero tensors)."""

@@ -28,7 +28,7 @@ def test_struct_layouts_match_header_sizes():
     from sound_bubble_amd import _lib
     # compile-free cross-check: field counts/sizes as laid out by the C rules ctypes follows
     assert C.sizeof(_lib.LstmFwdArgs) == 5 * 4 + 4 + 3 * 8 + 3 * 8 + 8 * 8 + 4 * 8 + 4 * 8 + 8 + 3 * 8 + 2 * 8 + 8 + 8
-    assert C.sizeof(_lib.LstmBwdArgs) == 4 * 4 + 3 * 8 + 2 * 8 + 4 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 8 + 3 * 8 + 8 + 13 * 8
+    assert C.sizeof(_lib.LstmBwdArgs) == 4 * 4 + 3 * 8 + 2 * 8 + 4 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 8 + 3 * 8 + 8 + 18 * 8
     assert C.sizeof(_lib.WgradArgs) % 8 == 0 and C.sizeof(_lib.LinearArgs) % 8 == 0
 
 

@@ -562,3 +562,40 @@ def test_linear_reports_absmax_of_its_output(torch_gpu):
         ops.absmax_hint_put(out, gm)
         out.add_(1.0)                                            # modified after the hint: not trusted
         assert ops.absmax_or_hint(out) is not gm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_,fuse_lin", [(16, False), (32, True)])
+def test_fused_bptt_bidirectional_matches_two_kernel_backward(torch_gpu, C_, fuse_lin):
+    """The bidirectional (intra-frame) form of the fused backward: fp32 hs, two directions, persistent workgroups that
+    walk several tiles, odd step count and a partial last tile -- against the recurrence -> stream kernel pair."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.LSTM_MMA in (1, 2) and ops.FUSED_BPTT
+            and ops.FUSED_BPTT_BI and (not fuse_lin or ops.can_fuse_linear_bwd())):
+        pytest.skip("fused BPTT exists on the default compact fp16 path only")
+    torch.manual_seed(12)
+    nseq, S = 16 * 300 + 5, 29                              # more tiles than persistent workgroups, partial last tile
+    geom = ops.Geom.intra(nseq, S)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    mk = lambda: (torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2,
+                  torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)
+    dirs = [mk(), mk()]
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True)
+    assert ops.can_fuse_stream_bi(u, hs)
+    lin_w = torch.randn(C_, 128, device="cuda") * 0.2
+    dy = torch.randn(geom.P, C_, device="cuda") * 0.01
+    dhs = torch.randn(geom.P, 128, device="cuda") * 0.01
+    kw = dict(dy=dy, w_lin=lin_w) if fuse_lin else dict(dhs=dhs)
+    tg = [[torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+           torch.zeros(256, device="cuda")] for _ in range(2)]
+    du = ops.lstm_bwd_fused_bi([dirs[0][1], dirs[1][1]], gates, geom, u, hs, [dirs[0][0], dirs[1][0]], tg, **kw)
+    dg = ops.lstm_bwd_rec([dirs[0][1], dirs[1][1]], gates, None if fuse_lin else dhs, geom,
+                          dy=dy if fuse_lin else None, w_lin=lin_w if fuse_lin else None)
+    ref, du_ref = ops.lstm_bwd_stream(dg, u, hs, [dirs[0][0], dirs[1][0]], 1, S, 1)
+    torch.cuda.synchronize()
+    assert rel_l2(du.cpu().numpy(), du_ref.cpu().numpy()) < 2e-6
+    for d in range(2):
+        for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh"), tg[d], ref[d]):
+            assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-5, (d, name)
