@@ -653,9 +653,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // u / h_prev rows of the 32 slots of a chunk; dyv: dy of the h_prev rows' own positions (Linear weight gradient)
   // RAW loaded registers only: any arithmetic on them here would pin an s_waitcnt behind the loads at the top of the
   // loop body (the select of the first version did, and doubled the kernel time once the dy loads joined)
-  static_assert(!BI || (!LNB && !SEG), "bidirectional fused form: no riders, no time segments");
+  static_assert(!BI || (!LNB && !SEG), "bidirectional fused form: no LayerNorm rider, no time segments");
+  constexpr bool LINW = !BI || FUSE_C > 0;        // the fused Linear's weight gradient rides along (needs dy)
   struct PairOps { h16x4 hh4[BI ? 1 : 8]; f32x4 hh32[BI ? 8 : 1]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8];
-                   float dyv[CK][BI ? 1 : 8];
+                   float dyv[CK][LINW ? 8 : 1];
                    float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
   static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
   // LNB: the du tile is formed TRANSPOSED (positions as rows, channels as columns: the two MFMA operands swapped), so a
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
       else o.uh1[kk] = u16[pos * FST + j];
       // the Linear's weight gradient pairs h of a position with dy of the SAME position (the h_prev row's)
-      if constexpr (!BI) {
+      if constexpr (LINW) {
 #pragma unroll
         for (int ct = 0; ct < CK; ++ct) o.dyv[ct][kk] = dyj[posh * FST + 16 * ct];
       }
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = hm[kt];
       }
     }
-    if constexpr (!BI)
+    if constexpr (LINW)
 #pragma unroll
     for (int ct = 0; ct < CK; ++ct) {              // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
       h16x8 Ad;
@@ -791,8 +792,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     const h16x4 hz4 = {0, 0, 0, 0};
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const int64_t pos = (int64_t)posb[kk] + (int64_t)(S - 1) * a.p_step;
-      const h16x4 hv = *reinterpret_cast<const h16x4*>(hs16 + pos * H + 4 * j);
+      const int64_t pos = (int64_t)posb[kk] + (int64_t)st_of(S - 1) * a.p_step;       // walk index S - 1
+      h16x4 hv;
+      if constexpr (BI) {
+        const f32x4 h32 = ld4(hs32 + pos * (2 * H) + 4 * j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (_Float16)h32[r];
+      } else {
+        hv = *reinterpret_cast<const h16x4*>(hs16 + pos * H + 4 * j);
+      }
       const h16x4 hm = q < 2 ? hv : hz4;
       Bw[kk] = w == 0 ? hm[0] : (w == 1 ? hm[1] : (w == 2 ? hm[2] : hm[3]));
 #pragma unroll
@@ -1054,7 +1062,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       // pair k are rewritten by pair k + 2, two barriers after every wave has finished chunk k.
       int pk = 0, pend_s = 0, pend_n = 0;
       float pend_x[2] = {0.f, 0.f}, pend_r[2] = {0.f, 0.f};
-      if constexpr (!BI) { if (s_hi == S - 1) lin_top(); }
+      if constexpr (LINW) { if (s_hi == S - 1) lin_top(); }
       for (; s >= s_lo + 1; s -= 2, pk ^= 1) {
         Raw curA = rA, curB = rB;
         consume(curA);
@@ -1120,8 +1128,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   }
   if constexpr (FST > 0) {                           // this workgroup's partial row of the weight / bias gradients
     constexpr int Ktot = FST + H;
+    constexpr int LW = BI ? 2 * H : H;               // row length of the dW_lin partial: both directions' columns
     float* part = a.wpart + ((size_t)dir * gridDim.x + blockIdx.x) *
-                  ((size_t)4 * H * Ktot + 4 * H + (BI ? 0 : FST * H + FST) + (LNB ? 2 * FST : 0));
+                  ((size_t)4 * H * Ktot + 4 * H + (LINW ? FST * LW + FST : 0) + (LNB ? 2 * FST : 0));
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -1136,13 +1145,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
     }
     float* plin = part + (size_t)4 * H * Ktot + 4 * H;           // [C][64] dW_lin, then [C] db_lin
-    if constexpr (!BI)
+    if constexpr (LINW)
 #pragma unroll
     for (int ct = 0; ct < CK; ++ct) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) plin[(size_t)(16 * ct + 4 * q + r) * H + 4 * j + w] = lacc[ct][r] * invS;
-      const float bs = quad_sum(lbs[ct]);
-      if (w == 0 && q == 0) plin[(size_t)FST * H + 16 * ct + j] = bs * invS;
+      for (int r = 0; r < 4; ++r) {
+        plin[(size_t)(16 * ct + 4 * q + r) * LW + dir * H + 4 * j + w] = lacc[ct][r] * invS;
+        if constexpr (BI) plin[(size_t)(16 * ct + 4 * q + r) * LW + (1 - dir) * H + 4 * j + w] = 0.f;   // other direction's columns
+      }
+      const float bs = quad_sum(lbs[ct]);              // both directions see every dy row: direction 0 reports the sum
+      if (w == 0 && q == 0) plin[(size_t)FST * LW + 16 * ct + j] = dir == 0 ? bs * invS : 0.f;
     }
     if constexpr (LNB) {                             // LayerNorm parameter gradients: waves 0 / 1 hold the two steps' sums
       __syncthreads();
@@ -1274,9 +1286,14 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     else if (a.C == 32 && fc == 32) { if (full) SB_FB(true, 32, 32); else SB_FB(false, 32, 32); }
     else return -1003;
 #undef SB_FB
-    const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H;
+    const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + (fc > 0 ? a.C * 2 * H + a.C : 0);
     int rc = sb_launch_stream_reduce(a.wpart, gx, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
     if (!rc) rc = sb_launch_stream_reduce(a.wpart + (size_t)gx * ld, gx, ld, a.C, a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1, st);
+    if (fc > 0) {                                     // dW_lin [C, 128] / db_lin over the rows of both directions
+      const float* plin = a.wpart + (size_t)4 * H * (a.C + H) + 4 * H;
+      if (!rc && a.dW_lin) rc = sb_reduce_rows(plin, 2 * gx, ld, a.C * 2 * H, a.dW_lin, st);
+      if (!rc && a.db_lin) rc = sb_reduce_rows(plin + a.C * 2 * H, 2 * gx, ld, a.C, a.db_lin, st);
+    }
     return rc;
   }
   if (fst) {

@@ -84,14 +84,15 @@ class IntraPlainFn(torch.autograd.Function):
         if not fuse:
             dhs = torch.empty(P, 2 * H, device=dy.device, dtype=torch.float32)
             ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, s2H, Cc, 2 * H)
-        ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
         # BPTT
         tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
               (gt("wir", wir), gt("whr", whr), gt("bir", bir), gt("bhr", bhr))]
         if fuse and Cc == 32 and ops.can_fuse_stream_bi(u, hs):
-            # recurrence + streaming part in one launch (dgates stay in LDS)
-            du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w)
+            # recurrence + streaming part + the Linear's weight gradient in one launch (dgates stay in LDS)
+            du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w,
+                                       lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)))
         else:
+            ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
             dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
                                   w_lin=lin_w if fuse else None)
             # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)

@@ -311,7 +311,8 @@ def can_fuse_stream_bi(u, hs):
             and u.dtype == torch.float16 and hs.dtype == torch.float32 and u.shape[-1] in (16, 32))
 
 
-def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=None, dy=None, w_lin=None, gmax=None):
+def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=None, dy=None, w_lin=None, gmax=None,
+                      lin_targets=None):
     """Backward of a bidirectional LSTM pass, recurrence + streaming part in one launch (persistent workgroups, dgates in
     LDS).  Incoming gradient: dhs [P, 128], or dy [P, C] with w_lin [C, 128] (fused Linear backward, C == 32).
     u [P, C] fp16, hs [P, 128] fp32; targets[d] = (dW_ih, dW_hh, db_ih, db_hh) accumulated into.  -> du [P, 2, C]"""
@@ -337,7 +338,11 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     ntiles = (geom.nseq + 15) // 16
     rows = 2 * min(ntiles, max(1, _cu_count(dev) // 2))
     du = torch.empty(geom.P, 2, Cc, device=dev, dtype=torch.float32)
-    wpart = torch.empty(rows, 4 * H * (Cc + H) + 4 * H, device=dev, dtype=torch.float32)
+    wpart = torch.empty(rows, 4 * H * (Cc + H) + 4 * H + (Cc * 2 * H + Cc if dy is not None else 0), device=dev,
+                        dtype=torch.float32)
+    if lin_targets is not None:          # (dW_lin [C, 128], db_lin [C]) of the fused Linear (dy form only)
+        assert dy is not None and lin_targets[0].shape == (Cc, 2 * H)
+        a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
     a.u, a.hs, a.C = _ph(u), _p(hs), Cc
     a.w_ih, a.w_ih1 = _p(w_ih_list[0]), _p(w_ih_list[1])
     a.du, a.wpart = _p(du), _p(wpart)

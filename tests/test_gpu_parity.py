@@ -590,7 +590,9 @@ def test_fused_bptt_bidirectional_matches_two_kernel_backward(torch_gpu, C_, fus
     kw = dict(dy=dy, w_lin=lin_w) if fuse_lin else dict(dhs=dhs)
     tg = [[torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
            torch.zeros(256, device="cuda")] for _ in range(2)]
-    du = ops.lstm_bwd_fused_bi([dirs[0][1], dirs[1][1]], gates, geom, u, hs, [dirs[0][0], dirs[1][0]], tg, **kw)
+    ltg = [torch.zeros(C_, 128, device="cuda"), torch.zeros(C_, device="cuda")] if fuse_lin else None
+    du = ops.lstm_bwd_fused_bi([dirs[0][1], dirs[1][1]], gates, geom, u, hs, [dirs[0][0], dirs[1][0]], tg,
+                               lin_targets=ltg, **kw)
     dg = ops.lstm_bwd_rec([dirs[0][1], dirs[1][1]], gates, None if fuse_lin else dhs, geom,
                           dy=dy if fuse_lin else None, w_lin=lin_w if fuse_lin else None)
     ref, du_ref = ops.lstm_bwd_stream(dg, u, hs, [dirs[0][0], dirs[1][0]], 1, S, 1)
@@ -599,3 +601,6 @@ def test_fused_bptt_bidirectional_matches_two_kernel_backward(torch_gpu, C_, fus
     for d in range(2):
         for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh"), tg[d], ref[d]):
             assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-5, (d, name)
+    if fuse_lin:           # the Linear's weight gradient rides along (dy as a scaled fp16 term, h as fp16)
+        assert rel_l2(ltg[0].cpu().numpy(), (dy.double().t() @ hs.double()).cpu().numpy()) < 1e-3
+        assert rel_l2(ltg[1].cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-3
