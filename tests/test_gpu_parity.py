@@ -556,6 +556,8 @@ def test_linear_reports_absmax_of_its_output(torch_gpu):
         gm = torch.zeros(1, device="cuda")
         ops.linear(x, w, None, out, g, sK, sN, K, N, epi=epi, res=r, absmax_out=gm)
         assert float(gm) == float(out.abs().max())
+        if not ops.ABSMAX_HINTS:                                 # SB_NO_ABSMAX_HINTS=1: the table is off
+            continue
         ops.absmax_hint_put(out, gm)
         assert ops.absmax_or_hint(out) is gm                     # consumed ...
         assert float(ops.absmax_or_hint(out)) == float(gm)       # ... then measured again
