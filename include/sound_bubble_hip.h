@@ -218,6 +218,7 @@ typedef struct {
   int64_t P; int ndir, C;
   const float* du_part; const float* xin; const float* ln_g; const float* prelu_a; const float* res;
   float* out; float* partials;
+  float* absmax_out;     /* optional: *absmax_out = max(*absmax_out, max |out|) (see sb_linear_args.absmax_out) */
 } sb_ln_bwd_args;
 int sb_ln_bwd(const sb_ln_bwd_args* a, void* stream);
 int sb_ln_bwd_grid(int64_t positions);
@@ -273,7 +274,8 @@ int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int
  * backward: dx = dy * w ; dw[b,f,c] = sum_t dy * x ; dbias[b,f,c] = sum_t dy. */
 int sb_film_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int F, int C, void* stream);
 int sb_film_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias,
-                int B, int T, int F, int C, void* stream);
+                int B, int T, int F, int C, float* absmax_out /* optional: max |dx|, as sb_linear_args.absmax_out */,
+                void* stream);
 
 /* ---- iSTFT overlap-add ---------------------------------------------------
  * frames [B, T+1, 288] (row 0 = carried istft_buf frame) -> wave [B, hop*T]:

@@ -72,7 +72,7 @@ class LstmStreamArgs(C.Structure):
 class LnBwdArgs(C.Structure):
     _fields_ = [("P", i64), ("ndir", C.c_int), ("C", C.c_int),
                 ("du_part", c_fp), ("xin", c_fp), ("ln_g", c_fp), ("prelu_a", c_fp), ("res", c_fp),
-                ("out", c_fp), ("partials", c_fp)]
+                ("out", c_fp), ("partials", c_fp), ("absmax_out", c_fp)]
 
 
 class AttnArgs(C.Structure):
@@ -112,7 +112,7 @@ SYMBOLS = {
     "sb_reduce_rows": (_ci, [c_fp, _ci, i64, _ci, c_fp, _vp]),
     "sb_features": (_ci, [c_fp, i64, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_film_fwd": (_ci, [c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
-    "sb_film_bwd": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_film_bwd": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, c_fp, _vp]),
     "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),

@@ -68,25 +68,37 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ dy, float* __restrict__ dx,
                                                        float* __restrict__ dw, float* __restrict__ dbias, int B, int T,
-                                                       int F, int C, int tchunk) {
+                                                       int F, int C, int tchunk, float* __restrict__ absmax_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t fc4 = (int64_t)F * C / 4;
-  if (i >= B * fc4) return;
-  const int64_t b = i / fc4, r = i % fc4;
-  const f32x4 wv = ld4(w + i * 4);
-  f32x4 aw = zero4(), ab = zero4();
-  const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
-  for (int t = t0; t < t1; ++t) {
-    const int64_t off = ((b * T + t) * fc4 + r) * 4;
-    const f32x4 g = ld4(dy + off), xv = ld4(x + off);
-    st4(dx + off, g * wv);
-    aw += g * xv;
-    ab += g;
-  }
+  float amax = 0.f;
+  if (i < B * fc4) {
+    const int64_t b = i / fc4, r = i % fc4;
+    const f32x4 wv = ld4(w + i * 4);
+    f32x4 aw = zero4(), ab = zero4();
+    const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
+    for (int t = t0; t < t1; ++t) {
+      const int64_t off = ((b * T + t) * fc4 + r) * 4;
+      const f32x4 g = ld4(dy + off), xv = ld4(x + off);
+      const f32x4 d = g * wv;
+      st4(dx + off, d);
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+      aw += g * xv;
+      ab += g;
+    }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    atomicAdd(dw + i * 4 + k, aw[k]);
-    atomicAdd(dbias + i * 4 + k, ab[k]);
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(dw + i * 4 + k, aw[k]);
+      atomicAdd(dbias + i * 4 + k, ab[k]);
+    }
+  }
+  if (absmax_out) {                                  // max |dx|: one atomic per workgroup
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(absmax_out),
+                                    __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
   }
 }
 
@@ -332,11 +344,11 @@ extern "C" int sb_film_fwd(const float* x, const float* w, const float* bias, fl
 }
 
 extern "C" int sb_film_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias, int B,
-                           int T, int F, int C, void* stream) {
+                           int T, int F, int C, float* absmax_out, void* stream) {
   const int64_t n = (int64_t)B * F * C / 4;
   const int tchunk = 25;
   dim3 grid(nblk(n), (T + tchunk - 1) / tchunk);
-  hipLaunchKernelGGL(film_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, dy, dx, dw, dbias, B, T, F, C, tchunk);
+  hipLaunchKernelGGL(film_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, dy, dx, dw, dbias, B, T, F, C, tchunk, absmax_out);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(sb_ln_bwd_args a) {
 #pragma unroll
   for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; dgam[v] = 0.f; dbet[v] = 0.f; }
   const int64_t nrow = a.P;
+  float amax = 0.f;                                  // max |out| (a.absmax_out)
   for (int64_t p = (int64_t)blockIdx.x * 16 + (tid >> 4); p < nrow; p += (int64_t)gridDim.x * 16) {
     float g[VPT], raw[VPT], x[VPT];
 #pragma unroll
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(sb_ln_bwd_args a) {
       if (a.prelu_a && raw[v] <= 0.f) { dalpha += dx * raw[v]; dx *= alpha; }
       if (a.res) dx += a.res[p * C + c];
       a.out[p * C + c] = dx;
+      amax = fmaxf(amax, fabsf(dx));
     }
   }
   // per-block partials: [2C + 1]
@@ -621,6 +623,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(sb_ln_bwd_args a) {
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += red[r][tid];
     a.partials[(size_t)blockIdx.x * (2 * C + 1) + tid] = s;
+  }
+  if (a.absmax_out) {                                // one atomic per workgroup
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    __shared__ float wm[4];
+    if ((tid & 63) == 0) wm[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out),
+                            __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
   }
 }
 

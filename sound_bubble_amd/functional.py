@@ -97,7 +97,8 @@ class IntraPlainFn(torch.autograd.Function):
                                   w_lin=lin_w if fuse else None)
             # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)
             _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1, targets=tg)
-        dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b))
+        dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
+                                 hint=True)
         dx = dx.view(B, T, F, Cc)
         return (dx, gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"], gt["wir"], gt["whr"], gt["bir"],
                 gt["bhr"], gt["lin_w"], gt["lin_b"])
@@ -165,7 +166,8 @@ class InterFn(torch.autograd.Function):
             dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
                                   w_lin=lin_w if fuse else None)
             _, du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F, targets=tg)
-        dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b))
+        dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
+                                 hint=True)
         dx = dx.view(B, T, F, Cc)
         return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"], None, None)
 

@@ -385,7 +385,7 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None
     return grads, du
 
 
-def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=None):
+def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=None, hint=False):
     """LayerNorm(+PReLU) backward.  du_part [P, ndir, C] (summed over ndir), xin [P, C] pre-LN input.
     -> out [P, C], d_ln_g [C], d_ln_b [C], d_prelu [1] or None  (d_g / d_b / d_a: optional accumulation targets)"""
     lib = L.load()
@@ -400,7 +400,13 @@ def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=N
     a.P, a.ndir, a.C = P, ndir, Cc
     a.du_part, a.xin, a.ln_g, a.prelu_a, a.res = _p(du_part), _p(xin), _p(ln_g), _p(prelu_a), _p(res)
     a.out, a.partials = _p(out), _p(partials)
+    gm = None
+    if hint and ABSMAX_HINTS:          # out is the dy of the next backward recurrence: measure max |out| on the way
+        gm = torch.zeros(1, device=dev, dtype=torch.float32)
+        a.absmax_out = _p(gm)
     L.check(lib.sb_ln_bwd(C.byref(a), _stream()), "sb_ln_bwd")
+    if gm is not None:
+        absmax_hint_put(out, gm)
     d_g = torch.zeros(Cc, device=dev, dtype=torch.float32) if d_g is None else d_g
     d_b = torch.zeros(Cc, device=dev, dtype=torch.float32) if d_b is None else d_b
     reduce_partials(partials, Cc, d_g, 0)
@@ -527,8 +533,11 @@ def film_bwd(x, w, dy):
     dx = torch.empty_like(x)
     dw = torch.zeros(B_, F_, Cc, device=x.device, dtype=torch.float32)
     db = torch.zeros_like(dw)
-    L.check(L.load().sb_film_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), B_, T_, F_, Cc, _stream()),
+    gm = torch.zeros(1, device=x.device, dtype=torch.float32) if ABSMAX_HINTS else None   # dx is a next dy
+    L.check(L.load().sb_film_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), B_, T_, F_, Cc, _p(gm), _stream()),
             "sb_film_bwd")
+    if gm is not None:
+        absmax_hint_put(dx, gm)
     return dx, dw, db
 
 
