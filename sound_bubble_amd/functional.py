@@ -388,12 +388,31 @@ class FilmFn(torch.autograd.Function):
         return ops.film_bwd(x, w, dy.contiguous())
 
 
+# GEMM forms of the fixed STFT / iSTFT filter banks (module buffers, never trained): built once per (tensor, version)
+_FILTER_CACHE = {}
+
+
+def _cached_filter_form(filters, tag, build):
+    if filters.requires_grad:
+        return build(filters)
+    key = (tag, filters.data_ptr(), filters._version, str(filters.device), tuple(filters.shape))
+    ent = _FILTER_CACHE.get(key)
+    if ent is None:
+        if len(_FILTER_CACHE) > 16:
+            _FILTER_CACHE.clear()
+        ent = (filters, build(filters))          # the entry keeps `filters` alive, so the address stays its own
+        _FILTER_CACHE[key] = ent
+    return ent[1]
+
+
 def _stft_weight(filters):
     """[290,1,288] asteroid filter bank -> [304, 288] analysis GEMM weight (zero rows 290..303)"""
-    f = filters.reshape(filters.shape[0], -1)
-    w = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
-    w[: f.shape[0]] = f
-    return w
+    def build(flt):
+        f = flt.reshape(flt.shape[0], -1)
+        w = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
+        w[: f.shape[0]] = f
+        return w
+    return _cached_filter_form(filters, "stft", build)
 
 
 class FrontEndFn(torch.autograd.Function):
@@ -464,12 +483,14 @@ class FrontEndFn(torch.autograd.Function):
 def _istft_weights(dec_filters):
     """asteroid synthesis bank [290,1,288] -> GEMM weights for interleaved (re,im) spectra rows:
     w_syn [288, 304] (frames = spec_row . w_syn^T) and w_ana [304, 288] (its transpose, for the gradient)."""
-    f = dec_filters.reshape(dec_filters.shape[0], -1)               # [2F, win], rows: re(0..F-1), im(F..2F-1)
-    Fq = f.shape[0] // 2
-    inter = torch.stack([f[:Fq], f[Fq:]], dim=1).reshape(2 * Fq, -1)    # row 2f+o
-    w_ana = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
-    w_ana[: 2 * Fq] = inter
-    return w_ana.t().contiguous(), w_ana
+    def build(flt):
+        f = flt.reshape(flt.shape[0], -1)                               # [2F, win], rows: re(0..F-1), im(F..2F-1)
+        Fq = f.shape[0] // 2
+        inter = torch.stack([f[:Fq], f[Fq:]], dim=1).reshape(2 * Fq, -1)    # row 2f+o
+        w_ana = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
+        w_ana[: 2 * Fq] = inter
+        return w_ana.t().contiguous(), w_ana
+    return _cached_filter_form(dec_filters, "istft", build)
 
 
 class BackEndFn(torch.autograd.Function):
@@ -484,7 +505,9 @@ class BackEndFn(torch.autograd.Function):
         win = dec_filters.shape[-1]
         train = GRAD_MODE and any(ctx.needs_input_grad)
         assert dw.shape[1] == 2, "num_src=1 only (every shipped config)"
-        yp = torch.zeros(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)
+        yp = torch.empty(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)      # only the frequency borders are zero
+        yp[:, :, 0].zero_()
+        yp[:, :, F + 1].zero_()
         yp[:, :2, 1:F + 1] = deconv_buf.permute(0, 2, 3, 1)
         yp[:, 2:, 1:F + 1] = y
         new_dbuf = yp[:, T:T + 2, 1:F + 1].permute(0, 3, 1, 2).contiguous()
