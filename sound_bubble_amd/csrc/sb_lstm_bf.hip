@@ -1177,7 +1177,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 
 // defined in sb_lstm_stream.hip: dW_ih / dW_hh / db += sum over `rows` partial rows of [256 * (C + 64) + 256] floats
 int sb_launch_stream_reduce(const float* partials, int rows, int64_t ld, int C, float* dW_ih, float* dW_hh, float* db_ih,
-                            float* db_hh, hipStream_t st);
+                            float* db_hh, hipStream_t st, int n_extra = 0, const int* ex_off = nullptr,
+                            const int* ex_n = nullptr, float* const* ex_out = nullptr);
 
 // launch helpers used by sb_lstm.hip's C entry points (same argument structs)
 // Number of (tile, time-segment) work items per workgroup slot: pick the segment count k that minimises the makespan
@@ -1310,13 +1311,13 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
 #undef SB_FC
 #undef SB_F
     const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + a.C * H + a.C + (lnb ? 2 * a.C : 0);
-    int rc = sb_launch_stream_reduce(a.wpart, (int)grid.x, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
-    const float* plin = a.wpart + (size_t)4 * H * (a.C + H) + 4 * H;
-    if (!rc && a.dW_lin) rc = sb_reduce_rows(plin, (int)grid.x, ld, a.C * H, a.dW_lin, st);
-    if (!rc && a.db_lin) rc = sb_reduce_rows(plin + a.C * H, (int)grid.x, ld, a.C, a.db_lin, st);
-    if (!rc && lnb && a.d_ln_g) rc = sb_reduce_rows(plin + a.C * H + a.C, (int)grid.x, ld, a.C, a.d_ln_g, st);
-    if (!rc && lnb && a.d_ln_b) rc = sb_reduce_rows(plin + a.C * H + 2 * a.C, (int)grid.x, ld, a.C, a.d_ln_b, st);
-    return rc;
+    // one reduction launch for the LSTM part and the riders' column ranges
+    const int o0 = 4 * H * (a.C + H) + 4 * H;
+    const int ex_off[4] = {o0, o0 + a.C * H, o0 + a.C * H + a.C, o0 + a.C * H + 2 * a.C};
+    const int ex_n[4] = {a.C * H, a.C, a.C, a.C};
+    float* const ex_out[4] = {a.dW_lin, a.db_lin, lnb ? a.d_ln_g : nullptr, lnb ? a.d_ln_b : nullptr};
+    return sb_launch_stream_reduce(a.wpart, (int)grid.x, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st, 4, ex_off, ex_n,
+                                   ex_out);
   }
 #define SB_B(FL, R16, FC, D16, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a)
 #define SB_BR(FL, FC) do { if (seg) SB_B(FL, true, FC, true, true); else if (dg16) SB_B(FL, true, FC, true, false); \

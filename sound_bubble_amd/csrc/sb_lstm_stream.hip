@@ -524,17 +524,36 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   }
 }
 
+// extra column ranges of the partial rows that ride along in the same launch (the fused backward's Linear / LayerNorm
+// parameter gradients): columns [off, off + n) are summed into out[0 .. n)
+struct ReduceExtras { int count; int off[4]; int n[4]; float* out[4]; };
+
 __global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restrict__ partials_in, int rows, int C,
                                                             float* __restrict__ dW1, float* __restrict__ dW2,
                                                             float* __restrict__ db1, float* __restrict__ db2,
-                                                            int64_t ld = 0) {
+                                                            int64_t ld = 0, ReduceExtras ex = ReduceExtras{}) {
   const int Ktot = C + H, N = 4 * H;
   const int total_ = N * Ktot + N;
   // rows are `ld` floats apart (0: packed); the index arithmetic below uses `total` as the row pitch
   const int64_t total = ld > 0 ? ld : total_;
   const float* __restrict__ partials = partials_in;
-  if ((int)(blockIdx.x * blockDim.x + threadIdx.x) >= total_) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total_) {                                  // threads past the LSTM part: the extra ranges, back to back
+    int e = gi - total_;
+    for (int x = 0; x < ex.count; ++x) {
+      if (e < ex.n[x]) {
+        const int rper = (rows + gridDim.y - 1) / gridDim.y;
+        const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += partials[(size_t)r * total + ex.off[x] + e];
+        atomicAdd(ex.out[x] + e, s);
+        return;
+      }
+      e -= ex.n[x];
+    }
+    return;
+  }
+  const int i = gi;
   const int rper = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rper, r1 = min(rows, r0 + rper);
   float s = 0.f, sa = 0.f, sb = 0.f, sc = 0.f;
@@ -674,10 +693,19 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
 
 // shared with the fused backward recurrence (sb_lstm_bf.hip), which emits the same partial rows
 int sb_launch_stream_reduce(const float* partials, int rows, int64_t ld, int C, float* dW_ih, float* dW_hh, float* db_ih,
-                            float* db_hh, hipStream_t st) {
+                            float* db_hh, hipStream_t st, int n_extra, const int* ex_off, const int* ex_n,
+                            float* const* ex_out) {
   const int total = 4 * H * (C + H) + 4 * H;
-  hipLaunchKernelGGL(stream_reduce_kernel, dim3((total + 255) / 256, rows >= 64 ? 16 : 1), dim3(256), 0, st, partials,
-                     rows, C, dW_ih, dW_hh, db_ih, db_hh, ld);
+  ReduceExtras ex{};
+  int extra_cols = 0;
+  for (int x = 0; x < n_extra && ex.count < 4; ++x) {
+    if (!ex_out[x]) continue;
+    ex.off[ex.count] = ex_off[x]; ex.n[ex.count] = ex_n[x]; ex.out[ex.count] = ex_out[x];
+    extra_cols += ex_n[x];
+    ++ex.count;
+  }
+  hipLaunchKernelGGL(stream_reduce_kernel, dim3((total + extra_cols + 255) / 256, rows >= 64 ? 16 : 1), dim3(256), 0, st,
+                     partials, rows, C, dW_ih, dW_hh, db_ih, db_hh, ld, ex);
   SB_CHECK_LAUNCH();
   return 0;
 }
