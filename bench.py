@@ -3,18 +3,21 @@
 
 Metric (BASELINE.json): utterances/s of one optimiser step (forward + SNRLP loss + backward +
 [RCCL all-reduce] + clip + Adam) on synthetic 6-ch x 24 kHz x 5 s utterances, whole job over N GPUs.
-Default workload = BASELINE configs[1]: the 0.3 M-param TFG_S model
-(real_experiments/raspberrypi_model_pretrain.json model_params), batch 32 per GPU (weak scaling).
-`--workload big` runs configs[2]/[3]: the 0.5 M-param model (syn_experiments/pretrain_stage.json),
-batch 16 per GPU.
+The HEADLINE (last JSON line) is the configuration the metric's 1/2/4/8-GPU series is quoted on:
+BASELINE configs[2]/[3], the 0.5 M-param "big" model (syn_experiments/pretrain_stage.json model_params),
+batch 16 per GPU (weak scaling; 8 GPUs = global batch 128).
 
 Launch: `python bench.py --gpus 1` or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
  bench.py --gpus N --steps K --warmup W`.
 
-One JSON line on rank 0; adds `roofline` (dominant kernel: the recurrent LSTM forward, timed live with
-HIP events on the launch stream) and `cpu_baseline` (the oracle -- a CPU port of the reference's
-algorithm -- timed on the host cores on a bounded sample).
+At N = 1 the default run first prints the secondary lines (one JSON object each, all driver-observable):
+streaming chunk loop (configs[4], both model sizes), forward-only utt/s (both), the small config's train step
+(configs[1], B = 32) -- then the headline.  `--workload small|big|big-attn` prints that single train line only;
+`--headline-only` skips the secondary lines.  Every train line carries `roofline` (the kernel with the largest total
+time of the timed region, HIP events on the launch stream, per-kernel table alongside), `exact_bptt` (the same step with
+SB_EXACT_BPTT=1 arithmetic: fp32 BPTT records and dgates) and, at N = 1, `cpu_baseline` (the oracle -- a CPU port of
+the reference's algorithm -- timed on the host cores on a bounded sample).
 """
 import argparse
 import json
@@ -164,7 +167,7 @@ def vendor_gpu_baseline(torch, wl, B, dev, steps=3):
     return None
 
 
-def stream_bench(torch, sb, args, cls, params, dev):
+def stream_bench(torch, sb, args, wl, cls, params, dev):
     """Config 5: B=1, 625 chunks of [1, 6, 288] (8 ms hop) through the hipGraph-captured chunk step."""
     import numpy as np
     from sound_bubble_amd.streaming import StreamingSeparator
@@ -190,8 +193,8 @@ def stream_bench(torch, sb, args, cls, params, dev):
     print(json.dumps({
         "metric": "streaming chunks/sec (8 ms hop, 6 mics, B=1)", "value": 625 / dt, "unit": "chunks/s", "n_gpus": 1,
         "steps": 625, "warmup": 20, "ms_per_step": dt / 625 * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"stream-{args.workload}: {cls} D={params['D']} B={params['B']}, chunk [1,6,288] -> [1,1,192], "
+        "vs_baseline": None, "dtype": DTYPE_FWD, "data": "synthetic",
+        "config": {"workload": f"stream-{wl} (BASELINE configs[4]): {cls} D={params['D']} B={params['B']}, chunk [1,6,288] -> [1,1,192], "
                                f"{'eager launches' if args.no_graph else 'hipGraph replay'}"},
         "latency_ms": {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)),
                        "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
@@ -200,19 +203,208 @@ def stream_bench(torch, sb, args, cls, params, dev):
         "chunk_mflop": fpu / 1e6}), flush=True)
 
 
+DTYPE_TRAIN = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo split operands (3 products per MAC, " \
+              "fp32-class); BPTT state (gate / c_prev records, dgates, LayerNorm-output and hs side outputs) fp16"
+DTYPE_EXACT = "f32 storage/accumulate; forward products fp16 hi+lo split (fp32-class); BPTT state fp32 (SB_EXACT_BPTT=1)"
+DTYPE_FWD = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo split operands (3 products per MAC, fp32-class)"
+
+# rocprof kernel-name patterns of the labels ops.PROFILE uses (for the committed PMC traffic JSONs)
+PMC_PATTERNS = [
+    ("intra-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, false, \d+, false, true>"),
+    ("inter-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, (16|32), \w+, false>"),
+    ("recurrence only", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, 0, false, false>"),
+    ("lstm_bwd_stream", r"lstm_bwd_stream_f16_kernel"),
+    ("intra-frame (bidirectional)", r"lstm_fwd_bf_kernel<\d+, \d, \w+, true, false, false>"),
+    ("inter-frame (Linear fused)", r"lstm_fwd_bf_kernel<\d+, \d, \w+, true, true, \w+>"),
+]
+
+
+def pmc_traffic(workload, label):
+    """HBM bytes per launch of the kernel behind `label` from the newest committed rocprofv3 --pmc summary
+    (profiles/r*_pmc_traffic_<workload>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}.json")))
+    pat = next((p for key, p in PMC_PATTERNS if key in label), None)
+    if not files or pat is None:
+        return None, None
+    ks = [v for k, v in json.load(open(files[-1]))["kernels"].items() if re.search(pat, k)]
+    if not ks:
+        return None, None
+    return (sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks),
+            os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc passes of `bench.py --workload " + workload + "`, committed)")
+
+
+def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only=False, exact=False, steps=None,
+                 warmup=None, profile=True):
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks.
+    -> (seconds per step, per-kernel profile dict, batch per GPU, params, class name)"""
+    from sound_bubble_amd.train import FlatBucket, FusedAdam, train_step
+    cls, params, B, negw, clip, lr = WORKLOADS[wl]
+    B = args.batch or B
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    old_compact = ops.COMPACT_BPTT
+    ops.COMPACT_BPTT = not exact
+    torch.manual_seed(0)                                     # identical replicas
+    model = getattr(sb, cls)(**params).to(dev).train()
+    bucket = FlatBucket(model)
+    optim = FusedAdam(bucket, lr=lr)
+    inputs, target = synth_batch(torch, B, 1234 + rank, dev, cls != "NetOptim")
+
+    def step():
+        if forward_only:
+            with torch.no_grad():
+                return model(inputs)["output"]
+        return train_step(model, bucket, optim, inputs, target, negw, grad_clip=clip)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    try:
+        for _ in range(warmup):
+            step()
+        ops.PROFILE = {} if profile else None                # HIP-event pairs around every recurrent-kernel launch
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = ops.PROFILE or {}
+        ops.PROFILE = None
+        ops.check_sched_status()                             # a time-segmented launch that bailed out voids the run
+    finally:
+        ops.PROFILE = None
+        ops.COMPACT_BPTT = old_compact
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    table = {}
+    for label, evs in prof.items():
+        ms = sum(e[0].elapsed_time(e[1]) for e in evs)
+        table[label] = dict(launches=len(evs), total_ms=ms, flops=sum(e[2] for e in evs),
+                            compulsory_bytes=sum(e[3] for e in evs), design_bytes=sum(e[4] for e in evs))
+    del model, bucket, optim, inputs, target
+    torch.cuda.empty_cache()
+    return dt / steps, table, B, params, cls
+
+
+def roofline_of(table, wl, step_s, steps, forward_only, utt_s_per_gpu, params):
+    """`roofline` object: the recurrent kernel with the largest total time in the timed region."""
+    fpu, bpu = fwd_flops_per_utt(params), fwd_bytes_per_utt(params)
+    work_mult = 1.0 if forward_only else 3.0
+    extra = {"step_flop_fraction_of_fp32_peak": work_mult * fpu * utt_s_per_gpu / MFMA_F32_PEAK,
+             "step_flop_fraction_issued_of_fp16_peak": 3.0 * work_mult * fpu * utt_s_per_gpu / MFMA_BF16_PEAK,
+             "step_hbm_fraction": work_mult * bpu * utt_s_per_gpu / HBM_PEAK}
+    if not table:
+        return dict(bound="hbm", achieved=None, peak=HBM_PEAK / 1e9, unit="GB/s", frac=None, traffic=None, **extra)
+    per = {}
+    for label, t in table.items():
+        n, sec = t["launches"], t["total_ms"] * 1e-3
+        traffic, src = pmc_traffic(wl, label) if not forward_only else (None, None)
+        per[label] = {
+            "launches_per_step": n / steps, "avg_launch_ms": t["total_ms"] / n,
+            "share_of_step": sec / (step_s * steps),
+            "compulsory_gbs": t["compulsory_bytes"] / sec / 1e9, "frac_compulsory_bytes": t["compulsory_bytes"] / sec / HBM_PEAK,
+            "design_gbs": t["design_bytes"] / sec / 1e9, "frac_design_bytes": t["design_bytes"] / sec / HBM_PEAK,
+            "traffic_bytes_per_launch": traffic,
+            "frac_hbm_counter": (traffic * n / sec / HBM_PEAK) if traffic else None,
+            "algorithmic_tflops": t["flops"] / sec / 1e12,
+            "frac_compute_issued": 3.0 * t["flops"] / sec / MFMA_BF16_PEAK,
+            "traffic_source": src}
+    top = max(table, key=lambda k: table[k]["total_ms"])
+    t, p = table[top], per[top]
+    sec = t["total_ms"] * 1e-3
+    if forward_only:       # nothing but hs / y leaves the chip: the matrix pipe is the nearest roof
+        roof = {"bound": "mfma", "achieved": 3.0 * t["flops"] / sec / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": p["frac_compute_issued"],
+                "note": "achieved = matrix flops ISSUED on the fp16 pipe (3 products per algorithmic MAC, hi+lo operands)"}
+    else:
+        roof = {"bound": "hbm", "achieved": p["compulsory_gbs"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": p["frac_compulsory_bytes"],
+                "note": "achieved = SURVEY 8(d) compulsory bytes (4C in + 4C out per position of the pass) / launch time; "
+                        "frac_design_bytes counts what this implementation moves (BPTT records, side outputs), "
+                        "frac_hbm_counter is the PMC-measured traffic; the gap between compulsory and counter is record "
+                        "traffic.  The kernel sits below both roofs: a serial chain of single-wave instruction issue"}
+    roof.update({"kernel": top, "traffic": p["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                 "traffic_source": p["traffic_source"], "launches": t["launches"], "avg_launch_ms": p["avg_launch_ms"],
+                 "share_of_step": p["share_of_step"],
+                 "algorithmic_bytes_per_launch": t["compulsory_bytes"] / t["launches"],
+                 "design_bytes_per_launch": t["design_bytes"] / t["launches"],
+                 "algorithmic_flops_per_launch": t["flops"] / t["launches"],
+                 "frac_compulsory_bytes": p["frac_compulsory_bytes"], "frac_design_bytes": p["frac_design_bytes"],
+                 "frac_hbm_counter": p["frac_hbm_counter"], "frac_compute_issued": p["frac_compute_issued"],
+                 "algorithmic_tflops": p["algorithmic_tflops"], "kernels": per})
+    roof.update(extra)
+    return roof
+
+
+def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only=False, with_exact=True, with_cpu=True):
+    step_s, table, B, params, cls = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, forward_only=forward_only)
+    if rank != 0:
+        if with_exact and not forward_only:                  # every rank runs the sibling (collectives inside)
+            run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, exact=True, steps=max(3, args.steps // 2),
+                         warmup=min(2, args.warmup), profile=False)
+        return None
+    utt_s = world * B / step_s
+    out = {
+        "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if forward_only else "train-step"),
+        "value": utt_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE_FWD if forward_only else DTYPE_TRAIN, "data": "synthetic",
+        "config": {"workload": f"{wl}: {cls} D={params['D']} B={params['B']} H=64 conv_lstm={params['conv_lstm']}, "
+                               f"6ch x 120000 samples, {'forward only' if forward_only else 'fwd+SNRLP+bwd+clip+Adam'}"
+                               + (" (BASELINE configs[2]; per-GPU workload of configs[3])" if wl == "big" else
+                                  " (BASELINE configs[1])" if wl == "small" else ""),
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+        "roofline": roofline_of(table, wl, step_s, args.steps, forward_only, utt_s / world, params),
+    }
+    if forward_only:
+        # north-star target: >= 30 % of the HBM roofline on the forward.  The forward is 292 (big) / 223 (small) FLOP per
+        # compulsory byte, so an exact-fp32 MFMA implementation tops out at 6.7 % / 8.8 % (SURVEY F8); on the fp16 pipe
+        # with 3 products per MAC the ceiling is 2500/3 TFLOP/s -> ~35 % / ~47 % of the HBM roof.
+        fpu, bpu = fwd_flops_per_utt(params), fwd_bytes_per_utt(params)
+        hbm_roof_utt = HBM_PEAK / bpu
+        out["forward_roofline"] = {
+            "hbm_frac": utt_s / world / hbm_roof_utt, "north_star_target_hbm_frac": 0.30,
+            "ceiling_fp32_mfma_hbm_frac": (MFMA_F32_PEAK / fpu) / hbm_roof_utt,
+            "ceiling_fp16x3_hbm_frac": (MFMA_BF16_PEAK / 3.0 / fpu) / hbm_roof_utt,
+            "frac_of_fp16x3_ceiling": (utt_s / world) / (MFMA_BF16_PEAK / 3.0 / fpu),
+            "gap": "the recurrent kernels issue ~1 instruction per 4 cycles from ONE wave per SIMD over a serial time "
+                   "loop; the cell update (40 quarter-rate transcendentals + ~100 VALU ops per step) and the LDS hidden-"
+                   "state exchange, not the MFMA issue, set the step time (profiles/: SQ_VALU_MFMA_BUSY vs SQ_BUSY)"}
+    if with_exact and not forward_only:
+        es, _, _, _, _ = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, exact=True,
+                                      steps=max(3, args.steps // 2), warmup=min(2, args.warmup), profile=False)
+        out["exact_bptt"] = {"value": world * B / es, "unit": "utterances/s", "ms_per_step": es * 1e3,
+                             "steps": max(3, args.steps // 2), "dtype": DTYPE_EXACT,
+                             "ratio_to_default": (world * B / es) / utt_s}
+    if with_cpu and world == 1:                               # reported baseline: rank 0 at N=1 only
+        out["cpu_baseline"] = cpu_baseline(torch, wl)
+        out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="small", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="all", choices=["all"] + list(WORKLOADS),
+                    help="all (default): secondary lines, then the headline (big); a name: that train line only")
+    ap.add_argument("--headline-only", action="store_true", help="with --workload all: only the headline line")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the SB_EXACT_BPTT=1 sibling measurement")
     ap.add_argument("--vendor-gpu-baseline", action="store_true",
                     help="extra leg: time the oracle restatement on the GPU through stock torch ops (MIOpen RNN)")
-    ap.add_argument("--forward-only", action="store_true", help="extra mode: inference forward utt/s")
+    ap.add_argument("--forward-only", action="store_true", help="single-workload mode: inference forward utt/s")
     ap.add_argument("--stream", action="store_true",
-                    help="extra mode (BASELINE config 5): hipGraph-captured 8 ms chunk loop, chunks/s + p50 latency")
+                    help="single-workload mode (BASELINE configs[4]): hipGraph-captured 8 ms chunk loop")
     ap.add_argument("--no-graph", action="store_true", help="with --stream: eager launches instead of hipGraph replay")
     args = ap.parse_args()
 
@@ -220,7 +412,6 @@ def main():
     import torch.distributed as dist
     import sound_bubble_amd as sb
     from sound_bubble_amd import ops
-    from sound_bubble_amd.train import FlatBucket, FusedAdam, train_step
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -238,109 +429,35 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    cls, params, B, negw, clip, lr = WORKLOADS[args.workload]
-    B = args.batch or B
+    def emit(obj):
+        if rank == 0 and obj is not None:
+            print(json.dumps(obj), flush=True)
+
+    single = args.workload != "all"
+    wl = args.workload if single else "big"
     if args.stream:
-        return stream_bench(torch, sb, args, cls, params, dev)
-    torch.manual_seed(0)                                     # identical replicas
-    model = getattr(sb, cls)(**params).to(dev).train()
-    bucket = FlatBucket(model)
-    optim = FusedAdam(bucket, lr=lr)
-    inputs, target = synth_batch(torch, B, 1234 + rank, dev, cls != "NetOptim")
-
-    def step():
-        if args.forward_only:
-            with torch.no_grad():
-                return model(inputs)["output"]
-        return train_step(model, bucket, optim, inputs, target, negw, grad_clip=clip)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ops.PROFILE_LSTM = []                                    # HIP-event pairs around the dominant kernel
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev = ops.PROFILE_LSTM
-    ops.PROFILE_LSTM = None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        ms = dt / args.steps * 1e3
-        utt_s = world * B * args.steps / dt
-        # dominant kernel: recurrent LSTM forward (all launches: intra + inter), HIP events on the launch stream
-        lstm_ms = [e[0].elapsed_time(e[1]) for e in ev]
-        lstm_flops = [e[2] for e in ev]
-        tot_ms, tot_fl, tot_by = sum(lstm_ms), sum(lstm_flops), sum(e[3] for e in ev)
-        n_launch = max(1, len(ev))
-        ach = tot_fl / (tot_ms * 1e-3) if tot_ms > 0 else 0.0
-        fpu, bpu = fwd_flops_per_utt(params), fwd_bytes_per_utt(params)
-        work_mult = 1.0 if args.forward_only else 3.0
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", f"r01_final_pmc_traffic_{args.workload}.json")
-        if os.path.exists(pmc) and not args.forward_only and B == WORKLOADS[args.workload][2]:
-            ks = [v for k, v in json.load(open(pmc))["kernels"].items() if "lstm_fwd" in k]
-            if ks:                                            # HBM bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)
-                traffic = sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
-                traffic_src = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc pass of this command, committed)"
-        # Which roof binds the dominant kernel (recurrent LSTM forward, intra + inter launches)?
-        #  * train step: it writes the BPTT records -- the intra-frame launches are HBM-write bound, the PMC traffic equals
-        #    the algorithmic bytes (profiles/) -> "hbm": algorithmic bytes per launch / launch time against 8 TB/s;
-        #  * forward only: nothing but hs / y leaves the chip -> "mfma": the kernel runs on the 16-bit matrix pipe with
-        #    split operands (fp16 hi+lo, 3 products per fp32 MAC by default; bf16 3-way, 6 products with SB_LSTM_BF16X6=1;
-        #    fp32-input MFMA with SB_LSTM_FP32=1): ISSUED matrix flops against the dense peak of that pipe.
-        nprod = {0: 1.0, 1: 3.0, 2: 6.0}[ops.LSTM_MMA]
-        mfma_peak = MFMA_BF16_PEAK if ops.LSTM_MMA else MFMA_F32_PEAK
-        issued = ach * nprod
-        gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-        if args.forward_only:
-            roof = {"bound": "mfma", "achieved": issued / 1e12, "peak": mfma_peak / 1e12, "unit": "TFLOP/s",
-                    "frac": issued / mfma_peak}
-        else:
-            roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gbs * 1e9 / HBM_PEAK}
-        out = {
-            "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if args.forward_only else "train-step"),
-            "value": utt_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cls} D={params['D']} B={params['B']} H=64 "
-                                   f"conv_lstm={params['conv_lstm']}, 6ch x 120000 samples, "
-                                   f"{'forward only' if args.forward_only else 'fwd+SNRLP+bwd+clip+Adam'}",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "roofline": dict(roof, **{
-                "kernel": ({1: "lstm_fwd_bf_kernel (fp16 MFMA, hi+lo operand split, 3 products per fp32 MAC)",
-                            2: "lstm_fwd_bf_kernel (bf16 MFMA, 3-way operand split, 6 products per fp32 MAC)",
-                            0: "lstm_fwd_kernel (fp32-input MFMA)"}[ops.LSTM_MMA]) + ", intra+inter launches",
-                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                "launches": len(ev), "avg_launch_ms": tot_ms / n_launch,
-                "algorithmic_bytes_per_launch": tot_by / n_launch,
-                "algorithmic_flops_per_launch": tot_fl / n_launch,
-                "algorithmic_tflops": ach / 1e12, "algorithmic_frac_of_fp32_mfma_peak": ach / MFMA_F32_PEAK,
-                "issued_matrix_tflops": issued / 1e12, "issued_frac_of_matrix_peak": issued / mfma_peak,
-                "hbm_gbs": gbs, "hbm_frac": gbs * 1e9 / HBM_PEAK,
-                "step_flop_fraction": work_mult * fpu * utt_s / world / MFMA_F32_PEAK,
-                "step_hbm_fraction": work_mult * bpu * utt_s / world / HBM_PEAK}),
-        }
-        if not args.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(torch, args.workload)
-            out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
-        if args.vendor_gpu_baseline and not args.forward_only:
-            del model, bucket, optim
-            torch.cuda.empty_cache()
-            out["vendor_gpu_baseline"] = vendor_gpu_baseline(torch, args.workload, B, dev)
+        cls, params = WORKLOADS[wl if single else "small"][:2]
+        stream_bench(torch, sb, args, wl if single else "small", cls, params, dev)
+    elif args.forward_only:
+        emit(train_line(torch, dist, sb, ops, wl if single else "big", args, dev, world, rank, forward_only=True,
+                        with_cpu=False))
+    else:
+        if not single and not args.headline_only and world == 1:
+            # secondary lines (driver-observable): streaming, forward-only, the small config's train step
+            for w2 in ("small", "big"):
+                stream_bench(torch, sb, args, w2, WORKLOADS[w2][0], WORKLOADS[w2][1], dev)
+            for w2 in ("small", "big"):
+                emit(train_line(torch, dist, sb, ops, w2, args, dev, world, rank, forward_only=True, with_cpu=False))
+            emit(train_line(torch, dist, sb, ops, "small", args, dev, world, rank, with_exact=not args.no_exact,
+                            with_cpu=False))
+        out = train_line(torch, dist, sb, ops, wl, args, dev, world, rank, with_exact=not args.no_exact,
+                         with_cpu=not args.no_cpu_baseline)
+        if rank == 0 and args.vendor_gpu_baseline:
+            B = args.batch or WORKLOADS[wl][2]
+            out["vendor_gpu_baseline"] = vendor_gpu_baseline(torch, wl, B, dev)
             if out["vendor_gpu_baseline"]:
-                out["vendor_gpu_baseline"]["ours_over_vendor"] = utt_s / out["vendor_gpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+                out["vendor_gpu_baseline"]["ours_over_vendor"] = out["value"] / out["vendor_gpu_baseline"]["value"]
+        emit(out)                                            # the headline is the LAST line
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

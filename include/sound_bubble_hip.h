@@ -59,6 +59,16 @@ typedef struct {
      chip has CUs (mma == 1): seg_state [ceil(nseq/16) * 2 * 16 * 64] floats, seg_flags [ceil(nseq/16)] ints (zeroed by
      the call).  seg_count / seg_len are filled in by the library; pass 0. */
   float* seg_state; int* seg_flags; int seg_count, seg_len;
+  /* Time-segmented scheduling needs its `sched_workers` workgroups co-resident (one per CU): a segment waits for the
+     state its predecessor publishes.  sched_status (one int, zeroed once by the caller and then left alone; REQUIRED for
+     the segmented schedule, which is otherwise not used) is the watchdog word: a wait that exceeds ~2^22 polls (seconds)
+     sets *sched_status = 1 and every workgroup of the launch (and of later launches that see the word set) bails out
+     instead of hanging -- the outputs of such a launch are garbage, and the caller must check the word after its next
+     synchronisation (sound_bubble_amd.ops.check_sched_status).  sched_workers / sched_segments: 0 = automatic (CU count
+     of the device, checked against the kernel's occupancy; segment count minimising the makespan); > 0 overrides them,
+     e.g. for a CU-masked / partitioned device where fewer workgroups are guaranteed co-resident, or to force the
+     schedule on a small problem (the parity tests do). */
+  int* sched_status; int sched_workers, sched_segments;
   /* training, compact records (save_c != NULL) on the 16-bit matrix path (mma >= 1): the two tensors that only the
      backward kernels read are written as fp16 -- save_u [P, C], and hs [P, 64] when the fused Linear is on (lin_w !=
      NULL; y carries the fp32 result forward).  sb_lstm_bwd_stream consumes them as single fp16 terms anyway (u_f16 /
@@ -90,6 +100,7 @@ typedef struct {
   const float* gmax;
   /* optional scratch for time-segmented scheduling, as in sb_lstm_fwd_args (needs gmax != NULL) */
   float* seg_state; int* seg_flags; int seg_count, seg_len;
+  int* sched_status; int sched_workers, sched_segments;     /* watchdog word + overrides, as in sb_lstm_fwd_args */
   /* optional fusion of the streaming part (sb_lstm_bwd_stream) into the recurrence: single direction, gmax != NULL,
      u [P, C] and hs [P, 64] the fp16 side outputs of sb_lstm_fwd (aux_f16).  When wpart != NULL the dgates never leave
      the chip: every two steps the workgroup multiplies the 32 (step, sequence) dgates rows it holds in LDS into

@@ -27,10 +27,7 @@ def timed(fn, iters=6):
 
 
 def run(B, C, hook):
-    if hook:
-        os.environ["SB_LSTM_SEG_TEST"] = hook
-    else:
-        os.environ.pop("SB_LSTM_SEG_TEST", None)
+    ops.SCHED_OVERRIDE = tuple(int(v) for v in hook.split(",")) if hook else None     # (workers, segments)
     dev = "cuda"
     geom = ops.Geom.inter(B, T, F)
     torch.manual_seed(0)

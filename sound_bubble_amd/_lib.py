@@ -22,6 +22,7 @@ class LstmFwdArgs(C.Structure):
                 ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp), ("save_c", c_fp), ("mma", C.c_int),
                 ("lin_w", c_fp), ("lin_b", c_fp), ("y", c_fp),
                 ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int),
+                ("sched_status", c_fp), ("sched_workers", C.c_int), ("sched_segments", C.c_int),
                 ("aux_f16", C.c_int)]
 
 
@@ -31,6 +32,7 @@ class LstmBwdArgs(C.Structure):
                 ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("save_c", c_fp), ("mma", C.c_int),
                 ("dy", c_fp), ("w_lin", c_fp), ("C_lin", C.c_int), ("gmax", c_fp),
                 ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int),
+                ("sched_status", c_fp), ("sched_workers", C.c_int), ("sched_segments", C.c_int),
                 ("u", c_fp), ("hs", c_fp), ("w_ih", c_fp), ("C", C.c_int), ("du", c_fp), ("wpart", c_fp),
                 ("dW_ih", c_fp), ("dW_hh", c_fp), ("db_ih", c_fp), ("db_hh", c_fp), ("dW_lin", c_fp), ("db_lin", c_fp),
                 ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),

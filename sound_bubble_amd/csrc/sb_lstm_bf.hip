@@ -15,8 +15,6 @@
 // C/D as in sb_common.h.  K is walked in chunks of 32: chunk 0 = the (LayerNormed) input u (zero-padded to 32),
 // chunks 1,2 = the hidden state.  Step pipeline: A: hidden part (MFMA) with the LayerNorm of row s+2 in its issue
 // gaps; B: input part of step s+1 (MFMA) || cell update; C: h -> LDS, stores, barrier.
-#include <cstdio>
-#include <cstdlib>
 #include "sb_common.h"
 #ifndef SB_EXP_SKIP
 #define SB_EXP_SKIP 0
@@ -110,6 +108,34 @@ SB_DEVINL SplitN<F16> splitn8(const float (&x)[8]) {
     for (int n = 0; n < Prec<F16>::NT; ++n) s.t[n][k] = e[n];
   }
   return s;
+}
+
+// Hand-off wait of the time-segmented schedule: thread 0 polls the tile's flag until the predecessor segment has published
+// its state.  Bounded: progress depends on all workgroups of the launch being co-resident, which the launcher checks
+// against the kernel's occupancy but cannot guarantee on a shared / CU-masked device -- after kSegSpinLimit polls (seconds)
+// the watchdog word is set and the whole workgroup leaves; every other waiter sees the word and leaves too, so the
+// launch ends with garbage outputs and *status != 0 instead of hanging the process.  Returns false on abort (uniform
+// over the workgroup).
+constexpr unsigned kSegSpinLimit = 1u << 22;
+SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status) {
+  __shared__ int seg_abort;
+  if (threadIdx.x == 0) {
+    int bad = 0;
+    unsigned spins = 0;
+    while (__hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+      ++spins;
+      if ((spins & 63u) == 0 &&
+          (spins > kSegSpinLimit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    seg_abort = bad;
+  }
+  __syncthreads();
+  return seg_abort == 0;
 }
 
 constexpr int UP = 32 + 8;    // padded 16-bit row of the input-term tiles  (80 B)
@@ -441,10 +467,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       // wait until the previous segment of this tile has published its state.  Flag and state travel as agent-scope
       // (sc1, write-through / cache-bypassing) accesses ordered by s_waitcnt + barrier -- no release / acquire fences:
       // those write back / invalidate the whole L2, which is full of this kernel's own record stores.
-      if (tid == 0)
-        while (__hip_atomic_load(a.seg_flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg)
-          __builtin_amdgcn_s_sleep(4);
-      __syncthreads();
+      if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return;
       const float* st = seg_hc + ((size_t)tile * 2 * 16 + j) * H + uoff;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1043,10 +1066,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     if constexpr (SEG) {
       float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
       if (seg > 0) {                                   // see the forward kernel for the hand-off protocol
-        if (tid == 0)
-          while (__hip_atomic_load(a.seg_flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg)
-            __builtin_amdgcn_s_sleep(4);
-        __syncthreads();
+        if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           dc[r] = __hip_atomic_load(st + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1193,6 +1213,15 @@ static int choose_segments(int ntiles, int W, int S, double* cost_out) {
   *cost_out = best_cost;
   return best;
 }
+// one resident workgroup per CU is what the segmented schedule relies on: refuse it when the kernel does not fit a CU
+template <auto Kern>
+static bool fits_one_per_cu() {
+  static const bool ok = [] {
+    int n = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, Kern, 256, 0) == hipSuccess && n >= 1;
+  }();
+  return ok;
+}
 static int device_cu_count() {
   static const int n = [] {
     int dev = 0, cus = 0;
@@ -1215,9 +1244,10 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   if (lin && (!f16 || a.ndir != 1 || !a.lin_b || !a.y)) return -1003;
   if (!lin && !a.hs) return -1003;
   // time-segmented scheduling (see the kernel): single direction, scratch provided, more tiles than CUs
-  int W = device_cu_count(), kforce = 0;
-  if (const char* e = getenv("SB_LSTM_SEG_TEST")) sscanf(e, "%d,%d", &W, &kforce);   // test hook: "workers,segments"
-  bool seg = f16 && a.ndir == 1 && a.seg_state && a.seg_flags && ntiles >= W &&
+  const int cus = device_cu_count();
+  if (a.sched_workers < 0 || a.sched_segments < 0 || a.sched_workers > cus) return -1003;
+  const int W = a.sched_workers > 0 ? a.sched_workers : cus, kforce = a.sched_segments;
+  bool seg = f16 && a.ndir == 1 && a.seg_state && a.seg_flags && a.sched_status && ntiles >= W &&
              ((ntiles > W && ntiles <= 2 * W) || kforce > 0);
   if (seg) {
     double cost = 0.0;
@@ -1233,7 +1263,9 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
       (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
     }
   }
-#define SB_L(CC, SV, FL, HF, LN, SG) hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>), grid, dim3(256), 0, st, a)
+#define SB_L(CC, SV, FL, HF, LN, SG) do { \
+    if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>), grid, dim3(256), 0, st, a); } while (0)
 #define SB_LT(CC, SV, FL) do { \
     if (seg) { if (lin) SB_L(CC, SV, FL, true, true, true); else SB_L(CC, SV, FL, true, false, true); } \
     else if (lin) SB_L(CC, SV, FL, true, true, false); else if (f16) SB_L(CC, SV, FL, true, false, false); \
@@ -1257,9 +1289,10 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   const bool full = a.nseq % 16 == 0, r16 = a.save_c != nullptr, dg16 = a.gmax != nullptr;
   if (dg16 && !r16) return -1003;
   const int fc = a.dy ? a.C_lin : 0;
-  int W = device_cu_count(), kforce = 0;
-  if (const char* e = getenv("SB_LSTM_SEG_TEST")) sscanf(e, "%d,%d", &W, &kforce);
-  bool seg = dg16 && a.ndir == 1 && a.seg_state && a.seg_flags && ntiles >= W &&
+  const int cus = device_cu_count();
+  if (a.sched_workers < 0 || a.sched_segments < 0 || a.sched_workers > cus) return -1003;
+  const int W = a.sched_workers > 0 ? a.sched_workers : cus, kforce = a.sched_segments;
+  bool seg = dg16 && a.ndir == 1 && a.seg_state && a.seg_flags && a.sched_status && ntiles >= W &&
              ((ntiles > W && ntiles <= 2 * W) || kforce > 0);
   if (seg) {
     double cost = 0.0;
@@ -1304,7 +1337,9 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     const bool lnb = a.dx != nullptr;
     if (lnb && (a.C != 16 || !a.ln_x || !a.ln_g)) return -1003;
     if (!lnb && !a.du) return -1003;
-#define SB_F(FL, CC, SG, LB) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC, LB>), grid, block, 0, st, a)
+#define SB_F(FL, CC, SG, LB) do { \
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC, LB>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC, LB>), grid, block, 0, st, a); } while (0)
 #define SB_FC(CC, LB) do { if (full) { if (seg) SB_F(true, CC, true, LB); else SB_F(true, CC, false, LB); } \
                            else { if (seg) SB_F(false, CC, true, LB); else SB_F(false, CC, false, LB); } } while (0)
     if (a.C == 16) { if (lnb) SB_FC(16, true); else SB_FC(16, false); } else SB_FC(32, false);
@@ -1319,7 +1354,9 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     return sb_launch_stream_reduce(a.wpart, (int)grid.x, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st, 4, ex_off, ex_n,
                                    ex_out);
   }
-#define SB_B(FL, R16, FC, D16, SG) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a)
+#define SB_B(FL, R16, FC, D16, SG) do { \
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a); } while (0)
 #define SB_BR(FL, FC) do { if (seg) SB_B(FL, true, FC, true, true); else if (dg16) SB_B(FL, true, FC, true, false); \
                            else if (r16) SB_B(FL, true, FC, false, false); else SB_B(FL, false, FC, false, false); } while (0)
 #define SB_BF(FC) do { if (full) SB_BR(true, FC); else SB_BR(false, FC); } while (0)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .metrics import batch_metrics
-from .train import FlatBucket, FusedAdam, allreduce_grads
+from .train import FlatBucket, FusedAdam, allreduce_grads, broadcast_replica
 
 ALIASES = {
     "src.models.tfgridnet_realtime_clean_dis_embd3.net.Net": "sound_bubble_amd.net.NetDisEmbd3",
@@ -35,6 +35,17 @@ def import_attr(path):
     path = ALIASES.get(path, path)
     module, attr = path.rsplit(".", 1)
     return getattr(importlib.import_module(module), attr)
+
+
+def load_model_weights(path):
+    """state_dict of a reference checkpoint: `last.pt` / `best.pt` ({'model': ...}, hl_module:88-93) or a Lightning-era
+    `.ckpt` ({'state_dict': ...} whose keys carry the `model.` prefix the reference strips through FakeModel,
+    hl_module:74-86)."""
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    if "model" in state:
+        return state["model"]
+    sd = state["state_dict"]
+    return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
 
 
 class _LrCarrier(torch.optim.Optimizer):
@@ -61,8 +72,7 @@ class PLModule(object):
         self.monitor, self.monitor_mode, self.mode = "val/loss", "min", None
         self.loss_fn = import_attr(loss)(**(loss_params or {}))
         if init_ckpt is not None:
-            state = torch.load(init_ckpt, map_location="cpu")
-            self.model.load_state_dict(state["model"] if "model" in state else state["state_dict"])
+            self.model.load_state_dict(load_model_weights(init_ckpt))
         if optimizer not in ("torch.optim.Adam",):
             raise NotImplementedError(f"optimizer {optimizer}: only torch.optim.Adam (every shipped config) is fused")
         self.optim_name, self.opt_params = optimizer, dict(optimizer_params)
@@ -77,6 +87,7 @@ class PLModule(object):
         self._sync_lr()          # e.g. LinearLR applies its start_factor at construction
         self.epoch = 0
         self._loss = None
+        broadcast_replica(self.bucket, self.optimizer)      # N > 1: every rank starts as rank 0's replica
 
     # ---- checkpoints (hl_module:115-156) ----
     def dump_state(self, path):
@@ -87,20 +98,28 @@ class PLModule(object):
         torch.save(state, path)
 
     def load_state(self, path, map_location=None):
+        """hl_module:115-139.  Reads the reference's own last.pt / best.pt: `optimizer` in torch.optim.Adam.state_dict()
+        layout is converted into the flat moment buffers (FusedAdam.load_state_dict), so a resumed run continues with
+        the saved moments, step count and learning rate."""
         state = torch.load(path, map_location=map_location or "cpu", weights_only=False)
         self.model.load_state_dict(state["model"])            # in-place copy_: bucket views stay valid
         opt = state.get("optimizer")
-        if isinstance(opt, dict) and "m" in opt:
+        if isinstance(opt, dict):
             self.optimizer.load_state_dict(opt)
+        elif opt is not None:
+            raise ValueError(f"{path}: unrecognised optimizer state ({type(opt).__name__})")
         if self.scheduler is not None and "scheduler" in state:
             self.scheduler = self.init_scheduler(self.scheduler_name, self.scheduler_params)
             self.scheduler.load_state_dict(state["scheduler"])
-            # scheduler state does not carry the optimizer's lr (the reference restores it through the
-            # optimizer state_dict): push the saved lr back into the carrier the scheduler drives
-            for g in self._lr_carrier.param_groups:
-                g["lr"] = self.optimizer.param_groups[0]["lr"]
+        # scheduler state does not carry the optimizer's lr (the reference restores it through the
+        # optimizer state_dict): push the saved lr back into the carrier the scheduler drives
+        for g in self._lr_carrier.param_groups:
+            g["lr"] = self.optimizer.param_groups[0]["lr"]
         self.epoch = state.get("current_epoch", 0)
         self.metric_values = state.get("metric_values", {})
+        if "statistics" in state:
+            self.statistics = state["statistics"]
+        broadcast_replica(self.bucket, self.optimizer)
 
     def get_current_lr(self):
         return self.optimizer.param_groups[0]["lr"]
@@ -117,7 +136,33 @@ class PLModule(object):
         m = self.metric_values[epoch][metric]
         return m["epoch"] / m["num_elements"]
 
+    def sync_epoch_metrics(self):
+        """N > 1: merge this epoch's (sum, count) pairs of every logged metric over the ranks, so that the plateau
+        scheduler, the best-checkpoint decision and the printed / logged epoch means see the WHOLE train / val set on
+        every rank (the reference has one process, hl_module:174-202).  Ranks may hold different metric names (e.g.
+        `si_sdr_i_2spk` only where a 2-speaker scene fell) or an empty val shard: the union of names is kept."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        mine = {k: (v["epoch"], v["num_elements"]) for k, v in self.metric_values.get(self.epoch, {}).items()
+                if v.get("epoch") is not None}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        merged = {}
+        for d in gathered:
+            for k, (s_, n_) in d.items():
+                a = merged.setdefault(k, [0.0, 0])
+                a[0] += s_
+                a[1] += n_
+        ep = self.metric_values.setdefault(self.epoch, {})
+        for k, (s_, n_) in merged.items():
+            ev = ep.setdefault(k, dict(step=None, epoch=None))
+            ev["epoch"], ev["num_elements"] = s_, n_
+
     def on_epoch_end(self, best_path, wandb_run=None):
+        self.sync_epoch_metrics()
+        from . import ops
+        ops.check_sched_status()              # one sync per epoch: did a time-segmented launch bail out?
         last = self.get_avg_metric_at_epoch(self.monitor)
         best = all(not (last > self.get_avg_metric_at_epoch(self.monitor, e)) for e in range(len(self.metric_values) - 1))
         if best:

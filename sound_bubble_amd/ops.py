@@ -17,7 +17,28 @@ COMPACT_BPTT = os.environ.get("SB_EXACT_BPTT", "0") != "1"
 # recurrent GEMMs: bf16 matrix pipe with exact 3-way split / 6 products (fp32-class) unless SB_LSTM_FP32=1
 # forward operand split: fp16 hi+lo, 3 products (default, 2^-22) or SB_LSTM_BF16X6=1: bf16 3-way, 6 products (2^-24)
 LSTM_MMA = 0 if os.environ.get("SB_LSTM_FP32", "0") == "1" else (2 if os.environ.get("SB_LSTM_BF16X6", "0") == "1" else 1)
-PROFILE_LSTM = None     # bench.py: list collecting (start_event, end_event, algorithmic_flops) per launch
+# bench.py: dict  kernel label -> list of (start_event, end_event, algorithmic_flops, compulsory_bytes, design_bytes)
+# per launch of the recurrent kernels, HIP events on the launch stream.  compulsory = SURVEY.md 8(d): 4C in + 4C out per
+# position of a fused pass; design = what this implementation must move (BPTT records, side outputs, dgates).
+PROFILE = None
+
+
+class _Prof:
+    def __init__(self, label, flops, cbytes, dbytes):
+        self.rec = PROFILE.setdefault(label, []) if PROFILE is not None else None
+        self.vals = (flops, cbytes, dbytes)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None and exc[0] is None:
+            self.e1.record()
+            self.rec.append((self.e0, self.e1) + self.vals)
+        return False
 
 
 def _stream():
@@ -65,6 +86,47 @@ class Geom:
     @staticmethod
     def inter(B, T, F):             # sequences = (b,f), steps along t
         return Geom(B * F, T, F, T * F, 1, F)
+
+
+# ---- time-segmented scheduling of single-direction passes (include/sound_bubble_hip.h: seg_state / sched_status) ----
+# SCHED_OVERRIDE = (workers, segments): force the schedule with that many resident workgroups / segments (API fields
+# sched_workers / sched_segments; the parity tests force it on small problems, a CU-masked deployment would lower
+# `workers`).  None = automatic.
+SCHED_OVERRIDE = None
+_SCHED_STATUS = {}
+
+
+def sched_status(dev):
+    """the per-device watchdog word of the segmented schedule (one int32, zeroed once)"""
+    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _SCHED_STATUS.get(i)
+    if t is None:
+        t = _SCHED_STATUS[i] = torch.zeros(1, device=dev, dtype=torch.int32)
+    return t
+
+
+def check_sched_status():
+    """Synchronises and raises if a segmented launch gave up waiting for a co-resident workgroup (its outputs are then
+    garbage).  Called after the timed region by bench.py, once per epoch by the harness, and by the tests."""
+    for i, t in _SCHED_STATUS.items():
+        if int(t.item()) != 0:
+            t.zero_()
+            raise L.SoundBubbleHipError(
+                f"cuda:{i}: a time-segmented LSTM launch aborted (its workgroups were not co-resident -- GPU shared or "
+                "CU-masked?).  Results since the last check are invalid; set SB_NO_TIME_SEGMENTS=1 or "
+                "ops.SCHED_OVERRIDE = (guaranteed_resident_workgroups, 0).")
+
+
+def _seg_scratch(a, geom, dev):
+    """scratch + watchdog word + overrides of the segmented schedule into an LstmFwdArgs / LstmBwdArgs"""
+    ntiles = (geom.nseq + 15) // 16
+    scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
+               torch.empty(ntiles, device=dev, dtype=torch.int32))
+    a.seg_state, a.seg_flags = _p(scratch[0]), C.c_void_p(scratch[1].data_ptr())
+    a.sched_status = C.c_void_p(sched_status(dev).data_ptr())
+    if SCHED_OVERRIDE is not None:
+        a.sched_workers, a.sched_segments = int(SCHED_OVERRIDE[0]), int(SCHED_OVERRIDE[1])
+    return scratch
 
 
 PHASE_TIMING_BUF = None   # developer hook: scratch for a -DSB_PHASE_TIMING build (scripts/phase_timing.py)
@@ -120,26 +182,20 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
     seg_scratch = None
     if ndir == 1 and LSTM_MMA == 1 and TIME_SEGMENTS:       # scratch for time-segmented scheduling (used when it pays)
-        ntiles = (geom.nseq + 15) // 16
-        seg_scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
-                       torch.empty(ntiles, device=dev, dtype=torch.int32))
-        a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
-    prof = PROFILE_LSTM
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
-    if prof is not None:
-        e1.record()
-        # algorithmic flops and compulsory HBM bytes of this launch
-        by = 4.0 * Cc * geom.P                                               # x rows (both directions share them)
-        by += geom.P * ndir * (hs.element_size() * H if hs is not None else 0.0)    # hidden sequence out
-        if gates is not None:                                                # BPTT records + saved LayerNorm output
-            by += geom.P * ndir * (gates.element_size() * gates[0, 0].numel()
-                                   + (cprev.element_size() * H if cprev is not None else 0)) + u.element_size() * Cc * geom.P
-        if lin is not None:
-            by += 2 * 4.0 * Cc * geom.P                                      # residual rows in, y out
-        prof.append((e0, e1, 2.0 * 4 * H * (Cc + H) * geom.P * ndir, by))
+        seg_scratch = _seg_scratch(a, geom, dev)
+    # design bytes of this launch
+    by = 4.0 * Cc * geom.P                                               # x rows (both directions share them)
+    by += geom.P * ndir * (hs.element_size() * H if hs is not None else 0.0)    # hidden sequence out
+    if gates is not None:                                                # BPTT records + saved LayerNorm output
+        by += geom.P * ndir * (gates.element_size() * gates[0, 0].numel()
+                               + (cprev.element_size() * H if cprev is not None else 0)) + u.element_size() * Cc * geom.P
+    if lin is not None:
+        by += 2 * 4.0 * Cc * geom.P                                      # residual rows in, y out
+    label = f"lstm_fwd_bf_kernel C={Cc} " + ("intra-frame (bidirectional)" if ndir == 2 else "inter-frame (Linear fused)"
+                                             if lin is not None else "inter-frame")
+    with _Prof(label, 2.0 * 4 * H * (Cc + H) * geom.P * ndir + (2.0 * H * Cc * geom.P if lin is not None else 0.0),
+               8.0 * Cc * geom.P, by):
+        L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
     return hs, ((hN, cN) if want_state else None), (gates, cprev), u
 
 
@@ -219,14 +275,16 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
     a.mma = LSTM_MMA
     seg_scratch = None
     if ndir == 1 and dg16 and TIME_SEGMENTS:                # scratch for time-segmented scheduling (see lstm_fwd)
-        ntiles = (geom.nseq + 15) // 16
-        seg_scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
-                       torch.empty(ntiles, device=dev, dtype=torch.int32))
-        a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
+        seg_scratch = _seg_scratch(a, geom, dev)
     if dy is not None:
         assert can_fuse_linear_bwd() and w_lin.shape == (dy.shape[-1], ndir * H)
         a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), dy.shape[-1]
-    L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
+    Cl = dy.shape[-1] if dy is not None else 0
+    rec_b = (rec.element_size() * rec[0, 0].numel() + (cprev.element_size() * H if cprev is not None else 0))
+    by = geom.P * ndir * (rec_b + dg.element_size() * 4 * H) + (4.0 * Cl * geom.P if dy is not None else 4.0 * H * ndir * geom.P)
+    with _Prof(f"lstm_bwd_rec_bf_kernel ndir={ndir} (recurrence only, dgates to HBM)",
+               (2.0 * 4 * H * H + 2.0 * H * Cl) * geom.P * ndir, 8.0 * max(Cl, 16) * geom.P, by):
+        L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
     return DGates(dg, gmax)
 
 
@@ -281,9 +339,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     ntiles = (geom.nseq + 15) // 16
     seg_scratch = None
     if TIME_SEGMENTS:
-        seg_scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
-                       torch.empty(ntiles, device=dev, dtype=torch.int32))
-        a.seg_state, a.seg_flags = _p(seg_scratch[0]), C.c_void_p(seg_scratch[1].data_ptr())
+        seg_scratch = _seg_scratch(a, geom, dev)
     du = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32)
     wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H + Cc * H + Cc + (2 * Cc if ln is not None else 0), device=dev,
                         dtype=torch.float32)
@@ -298,7 +354,11 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     if lin_targets is not None:
         assert lin_targets[0].shape == (Cc, H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
-    L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
+    by = geom.P * (640.0 + 4.0 * Cc + 2.0 * H + 2.0 * Cc + 4.0 * Cc + (8.0 * Cc if ln is not None else 0.0))
+    fl = (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc + 2.0 * H * Cc) * geom.P
+    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else ""),
+               fl, 8.0 * Cc * geom.P, by):
+        L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
     return du
 
 
@@ -348,7 +408,12 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
     a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
-    L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused, bidirectional)")
+    by = geom.P * (2 * 640.0 + (4.0 * Cc if dy is not None else 8.0 * H) + 8.0 * H + 2.0 * Cc + 8.0 * Cc)
+    fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
+              + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
+    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)", fl,
+               8.0 * Cc * geom.P, by):
+        L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused, bidirectional)")
     return du
 
 
@@ -381,7 +446,10 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None
     scratch = torch.empty(ndir * ng * (4 * H * (Cc + H) + 4 * H), device=dev, dtype=torch.float32)
     a.du_part, a.scratch = _p(du), _p(scratch)
     a.split_bf16 = 1 if COMPACT_BPTT else 0       # exact mode (SB_EXACT_BPTT=1) keeps the fp32 matrix path
-    L.check(lib.sb_lstm_bwd_stream(C.byref(a), _stream()), "sb_lstm_bwd_stream")
+    by = P * ndir * (dg.element_size() * 4.0 * H + hs.element_size() * H + 4.0 * Cc) + u.element_size() * Cc * P
+    with _Prof(f"lstm_bwd_stream kernel C={Cc} ndir={ndir}", (2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P * ndir,
+               8.0 * Cc * P, by):
+        L.check(lib.sb_lstm_bwd_stream(C.byref(a), _stream()), "sb_lstm_bwd_stream")
     return grads, du
 
 

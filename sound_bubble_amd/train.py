@@ -64,20 +64,102 @@ class FusedAdam:
                       gscale=1.0 / world_size, clip=clip, sumsq_buf=self.sumsq)
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
+        """torch.optim.Adam.state_dict() layout (what the reference's dump_state stores under 'optimizer',
+        hl_module:141-156): per-parameter {step, exp_avg, exp_avg_sq} indexed in model.parameters() order, sliced out of
+        the flat moment buffers, plus one param_group -- so the reference's load_state can resume from our last.pt."""
+        b = self.bucket
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(b.params, b.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.m[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.v[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(b.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        self.step_count = int(sd["step"])
-        self.param_groups[0]["lr"] = sd["lr"]
+        """Accepts torch.optim.Adam's layout (a reference last.pt / best.pt) and this class's round-1 private layout
+        {m, v, step, lr}."""
+        b = self.bucket
+        if "m" in sd and "param_groups" not in sd:                  # round-1 layout
+            self.m.copy_(sd["m"])
+            self.v.copy_(sd["v"])
+            self.step_count = int(sd["step"])
+            self.param_groups[0]["lr"] = sd["lr"]
+            return
+        groups = sd["param_groups"]
+        order = [i for g in groups for i in g["params"]]
+        if len(order) != len(b.params):
+            raise ValueError(f"optimizer state covers {len(order)} parameters, the model has {len(b.params)}")
+        g0 = groups[0]
+        if g0.get("weight_decay", 0) or g0.get("amsgrad", False) or g0.get("maximize", False):
+            raise NotImplementedError("weight_decay / amsgrad / maximize optimizer states are not supported")
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        for slot, (p, o) in zip(order, zip(b.params, b.offsets)):
+            st = sd["state"].get(slot)
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {slot}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+            n = p.numel()
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter Adam step counts differ ({sorted(steps)}): one shared step is supported")
+        self.step_count = steps.pop() if steps else 0
+        self.param_groups[0]["lr"] = g0["lr"]
+        self.betas, self.eps = tuple(g0.get("betas", self.betas)), g0.get("eps", self.eps)
+
+
+def _via_host(t):
+    """gloo (CPU tests; several ranks on one GPU in the -m gpu tests) moves device tensors through the host"""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _broadcast(t, src):
+    import torch.distributed as dist
+    if _via_host(t):
+        h = t.cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src)
+
+
+def broadcast_replica(bucket, optim=None, src=0):
+    """Make every rank an identical replica of rank `src` (start of training / after a resume): parameters, and the Adam
+    moments + step when an optimizer is given.  nn.DataParallel re-broadcasts the parameters every step
+    (hl_module:34-35); with one process per GPU once is enough, because every rank applies the same update."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    _broadcast(bucket.flat, src)
+    if optim is not None:
+        _broadcast(optim.m, src)
+        _broadcast(optim.v, src)
+        meta = torch.tensor([float(optim.step_count), float(optim.param_groups[0]["lr"])], device=bucket.flat.device,
+                            dtype=torch.float64)
+        _broadcast(meta, src)
+        optim.step_count, optim.param_groups[0]["lr"] = int(meta[0].item()), float(meta[1].item())
 
 
 def allreduce_grads(bucket):
     """One RCCL all-reduce (sum) of the whole gradient bucket (no-op without torch.distributed)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(bucket.grad, op=dist.ReduceOp.SUM)
+        if _via_host(bucket.grad):
+            h = bucket.grad.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            bucket.grad.copy_(h)
+        else:
+            dist.all_reduce(bucket.grad, op=dist.ReduceOp.SUM)      # ONE RCCL all-reduce of the whole bucket
         return dist.get_world_size()
     return 1
 

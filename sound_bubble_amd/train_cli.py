@@ -78,6 +78,37 @@ def make_dataset(params, key, split, synthetic, with_dis):
                                   with_dis_embed=with_dis, split=split)
 
 
+def per_rank_batch(json_batch, world, batch_per_gpu=False):
+    """The reference's nn.DataParallel SPLITS the JSON batch_size over the GPUs (hl_module:34-35), so the JSON value is
+    the global batch: each of `world` ranks takes batch_size / world (default; unchanged JSONs keep their optimisation
+    behaviour).  --batch_per_gpu reads it as the per-GPU batch instead (weak scaling, as bench.py measures)."""
+    if batch_per_gpu or world == 1:
+        return json_batch
+    if json_batch % world:
+        raise ValueError(f"batch_size {json_batch} is not divisible by {world} ranks (or pass --batch_per_gpu)")
+    return json_batch // world
+
+
+def make_loaders(data_train, data_val, params, world, rank, batch_per_gpu=False):
+    """Train: DistributedSampler (equal shard sizes by padding, reshuffled every epoch through set_epoch), drop_last so
+    that every rank steps the same number of equal batches (mean-of-local-means == global mean).
+    Val: rank r takes items r, r + world, ... with NO padding and NO dropping -- shards may be ragged or empty; the
+    harness merges (sum, count) pairs over the ranks (PLModule.sync_epoch_metrics), so the epoch means are exact."""
+    nw = min(os.cpu_count() or 1, params.get("num_workers", 0), 8)
+    bs = per_rank_batch(params["batch_size"], world, batch_per_gpu)
+    if world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(data_train, world, rank, shuffle=True)
+        train_loader = torch.utils.data.DataLoader(data_train, batch_size=bs, sampler=sampler, num_workers=nw,
+                                                   pin_memory=True, drop_last=True)
+        data_val = torch.utils.data.Subset(data_val, list(range(rank, len(data_val), world)))
+    else:
+        train_loader = torch.utils.data.DataLoader(data_train, batch_size=bs, shuffle=True, num_workers=nw,
+                                                   pin_memory=True)
+    test_loader = torch.utils.data.DataLoader(data_val, batch_size=params["eval_batch_size"], num_workers=nw,
+                                              pin_memory=True)
+    return train_loader, test_loader
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
@@ -87,6 +118,9 @@ def main(argv=None):
     ap.add_argument("--project_name", default="AcousticBubble")
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--epochs", type=int, default=None, help="override params['epochs']")
+    ap.add_argument("--batch_per_gpu", action="store_true",
+                    help="read the JSON batch_size as the per-GPU batch (default: the global batch, split over the ranks "
+                         "like the reference's nn.DataParallel does)")
     ap.add_argument("--wandb", action="store_true", help="log to wandb if importable (off by default: no network)")
     args = ap.parse_args(argv)
 
@@ -104,14 +138,7 @@ def main(argv=None):
     data_train = make_dataset(params, "train", "train", args.synthetic, with_dis)
     data_val = make_dataset(params, "val", "val", args.synthetic, with_dis)
 
-    def loader(ds, bs, shuffle):
-        sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=shuffle) if world > 1 else None
-        return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=shuffle and sampler is None, sampler=sampler,
-                                           num_workers=min(os.cpu_count() or 1, params.get("num_workers", 0), 8),
-                                           pin_memory=True, drop_last=world > 1)
-
-    train_loader = loader(data_train, params["batch_size"], True)
-    test_loader = loader(data_val, params["eval_batch_size"], False)
+    train_loader, test_loader = make_loaders(data_train, data_val, params, world, rank, args.batch_per_gpu)
     hl = import_attr(params["pl_module"])(**params["pl_module_args"])
     ckdir = os.path.join(args.run_dir, "checkpoints")
     if rank == 0:
@@ -132,6 +159,8 @@ def main(argv=None):
     n_epochs = args.epochs if args.epochs is not None else params["epochs"]
     for epoch in range(hl.epoch, n_epochs):
         seed_all(args.seed + epoch)
+        if hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)                     # a different shuffle every epoch
         hl.on_epoch_start()
         print("CURRENT learning rate: {:0.08f}".format(hl.get_current_lr()))
         t1 = time.time()

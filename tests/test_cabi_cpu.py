@@ -23,13 +23,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.sb_wgrad_grid(100) == 2
 
 
-def test_struct_layouts_match_header_sizes():
+def test_struct_layouts_match_header(tmp_path):
+    """Every ctypes mirror in _lib.py has the size and the field offsets the C compiler gives the header's struct
+    (gcc on a generated probe; field `inp` is `in` in C)."""
     import ctypes as C
+    import subprocess
     from sound_bubble_amd import _lib
-    # compile-free cross-check: field counts/sizes as laid out by the C rules ctypes follows
-    assert C.sizeof(_lib.LstmFwdArgs) == 5 * 4 + 4 + 3 * 8 + 3 * 8 + 8 * 8 + 4 * 8 + 4 * 8 + 8 + 3 * 8 + 2 * 8 + 8 + 8
-    assert C.sizeof(_lib.LstmBwdArgs) == 4 * 4 + 3 * 8 + 2 * 8 + 4 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 8 + 3 * 8 + 8 + 18 * 8
-    assert C.sizeof(_lib.WgradArgs) % 8 == 0 and C.sizeof(_lib.LinearArgs) % 8 == 0
+    pairs = {"sb_lstm_fwd_args": _lib.LstmFwdArgs, "sb_lstm_bwd_args": _lib.LstmBwdArgs, "sb_linear_args": _lib.LinearArgs,
+             "sb_wgrad_args": _lib.WgradArgs, "sb_lstm_stream_args": _lib.LstmStreamArgs, "sb_ln_bwd_args": _lib.LnBwdArgs,
+             "sb_attn_args": _lib.AttnArgs, "sb_attn_bwd_args": _lib.AttnBwdArgs}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "sound_bubble_hip.h"', "int main(void) {"]
+    want = []
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("%zu\\n", sizeof({cname}));')
+        want.append(C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("%zu\\n", offsetof({cname}, {"in" if fname == "inp" else fname}));')
+            want.append(getattr(cls, fname).offset)
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == want
 
 
 @pytest.mark.parametrize("name,cls", [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"),

@@ -1,0 +1,166 @@
+"""The HIP train step under torch.distributed (run on the MI355X box with -m gpu): 2 ranks share GPU 0 (gloo carries the
+collectives through the host; on an 8-GPU node the same code runs one rank per GPU over RCCL), so the data-parallel
+path of BASELINE configs[3] is exercised with the real kernels:
+
+ (i)  the flat gradient bucket after the all-reduce (/ world) equals the single-process global-batch gradient of
+      mean_b SNRLP -- exact-BPTT arithmetic to 1e-5 (only the summation order differs), default compact arithmetic to
+      the fp16-record tolerance (the dgates scale is derived per shard);
+ (ii) replicas stay bit-identical: after 3 optimiser steps that include a ReduceLROnPlateau decision on val losses that
+      DIFFER per rank (rank 0's shard improves, rank 1's gets worse; only the merged mean shows the plateau), every
+      rank holds the same learning rate and the same parameter bits.
+Reference behaviour matched: nn.DataParallel's global-batch gradient and single-process epoch bookkeeping,
+src/hl_modules/distance_based_hl_module.py:34-35,174-202,430-441.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_state_dict, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _grad_worker(rank, world, port, compact, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd.train import FlatBucket, allreduce_grads
+    ops.COMPACT_BPTT = compact
+    rec, params, _ = load_golden("tiny_small")
+    m = sb.NetOptim(**params)
+    m.load_state_dict(golden_state_dict(rec, torch))
+    m = m.cuda().train()
+    bucket = FlatBucket(m)
+    bucket.zero_grad()
+    sl = slice(rank, rank + 1)                        # shard by utterance; sample 1 has an all-zero target
+    est = m({"mixture": torch.from_numpy(rec["mixture"][sl]).cuda()})["output"]
+    loss, _ = SnrlpLossFn.apply(est, torch.from_numpy(rec["target"][sl]).cuda(), 100.0)
+    loss.backward()
+    w = allreduce_grads(bucket)
+    assert w == world
+    if rank == 0:
+        q.put((bucket.grad / w).cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compact", [False, True], ids=["exact-bptt", "default-compact"])
+def test_two_ranks_on_one_gpu_allreduce_matches_global_batch_gradient(compact):
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, compact, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g_dp = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd.train import FlatBucket
+    old = ops.COMPACT_BPTT
+    ops.COMPACT_BPTT = compact
+    try:
+        rec, params, _ = load_golden("tiny_small")
+        m = sb.NetOptim(**params)
+        m.load_state_dict(golden_state_dict(rec, torch))
+        m = m.cuda().train()
+        bucket = FlatBucket(m)
+        bucket.zero_grad()
+        est = m({"mixture": torch.from_numpy(rec["mixture"]).cuda()})["output"]
+        loss, _ = SnrlpLossFn.apply(est, torch.from_numpy(rec["target"]).cuda(), 100.0)
+        loss.backward()
+        g_ref = bucket.grad.cpu().numpy()
+    finally:
+        ops.COMPACT_BPTT = old
+    err = rel_l2(g_dp, g_ref)
+    assert err < (2e-3 if compact else 1e-5), err
+
+
+def _replica_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sound_bubble_amd.harness import PLModule
+    rec, params, _ = load_golden("tiny_small")
+    torch.manual_seed(100 + rank)                     # DIFFERENT initial weights per rank: the constructor must sync them
+    hl = PLModule(model="src.models.tfgridnet_realtime_clean_optim.net.Net", model_params=params, sr=24000,
+                  optimizer="torch.optim.Adam", optimizer_params={"lr": 2e-3},
+                  scheduler="torch.optim.lr_scheduler.ReduceLROnPlateau",
+                  scheduler_params={"mode": "min", "factor": 0.5, "patience": 0},
+                  loss="src.losses.SNRLP.SNRLPLoss", loss_params={"snr_loss_name": "snr", "neg_weight": 50},
+                  metrics=["si_sdr_i"], grad_clip=1.0)
+    g = torch.Generator().manual_seed(7 + rank)       # each rank trains on its own utterances
+    n = rec["mixture"].shape[-1]
+    lrs = []
+    # per-rank val losses: rank 0 keeps improving, rank 1 gets worse; the merged means are 1.0 -> 1.75 -> 2.5
+    val = {0: [1.0, 0.5, 0.25], 1: [1.0, 3.0, 4.75]}[rank]
+    for epoch in range(3):
+        hl.train()
+        mix = 0.1 * torch.randn(2, 6, n, generator=g)
+        tgt = 0.05 * torch.randn(2, 1, n, generator=g)
+        batch = ({"mixture": mix.cuda()}, {"target": tgt.cuda(), "num_target_speakers": torch.tensor([1, 2]),
+                                           "num_interfering_speakers": torch.tensor([0, 1]), "num_noises": torch.tensor([1, 1])})
+        hl.reset_grad()
+        loss, B = hl.training_step(batch, 0)
+        loss.backward()
+        hl.backprop()
+        hl.log_metric("val/loss", val[epoch], batch_size=4 if rank == 0 else 4)
+        if rank == 1 and epoch == 2:
+            hl.log_metric("val/only_on_rank1", 1.0, 1)          # ragged metric names must merge too
+        hl.on_epoch_end(os.devnull, None)
+        lrs.append(hl.get_current_lr())
+    flat = hl.bucket.flat.detach().cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    merged_val = [hl.get_avg_metric_at_epoch("val/loss", e) for e in range(3)]
+    if rank == 0:
+        q.put((lrs, [t.numpy() for t in gathered], merged_val, "val/only_on_rank1" in hl.metric_values[2]))
+    all_lrs = [None] * world
+    dist.all_gather_object(all_lrs, lrs)
+    assert all_lrs[0] == all_lrs[1], all_lrs
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_stay_bit_identical_through_plateau_scheduler():
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    lrs, flats, merged_val, ragged = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert np.array_equal(flats[0], flats[1])                  # bit-identical replicas after 3 steps
+    assert np.isfinite(flats[0]).all()
+    np.testing.assert_allclose(merged_val, [1.0, 1.75, 2.5])   # every rank sees the merged epoch mean
+    assert lrs == [2e-3, 1e-3, 5e-4], lrs                      # plateau seen on the MERGED loss (rank 0 alone improves)
+    assert ragged

@@ -1,0 +1,110 @@
+"""Full-size parity (run on the MI355X box with -m gpu): the two BASELINE training configurations at the geometry the
+benchmark runs -- 5 s clips, the config's per-GPU batch -- so that the kernels bench.py times are the kernels compared
+with the oracle, through the DEFAULT dispatch:
+
+  small (configs[1], B = 32): 290 inter-frame tiles on 256 CUs -> fused inter-frame BPTT (Linear-wgrad and LayerNorm
+        backward riders) under the time-segmented schedule, fused bidirectional conv-LSTM backward, 29-step intra walks;
+  big   (configs[2], B = 16): 145 inter-frame tiles -> recurrence -> stream kernel pair, one workgroup per tile; fused
+        bidirectional intra-frame backward with persistent workgroups over 625 tiles per direction, 145-step walks.
+
+Checker: the CPU oracle (oracle/tfgridnet_oracle.py, pinned to the reference goldens) on the same seeded weights and
+inputs, one utterance at a time (1.7 GB of autograd state each; the batch-mean SNRLP loss is the mean of the
+per-utterance losses evaluated alone -- the shared negative term is shard-invariant), gradients
+accumulated.  Forward rel-L2 against the north-star bar 1e-3 (held to 2e-4), every parameter gradient (the six stages
+named in the assertion message) to TOL_GRAD.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD_FULL = 2e-4
+TOL_GRAD_FULL = 3e-3
+
+# one representative parameter per stage (front conv, intra W_hh, inter W_ih, inter Linear, a LayerNorm gamma, deconv)
+STAGES = {
+    "small": ["tfgridnet.conv.0.weight", "tfgridnet.blocks.1.intra_rnn.weight_hh_l0", "tfgridnet.blocks.1.inter_rnn.weight_ih_l0",
+              "tfgridnet.blocks.2.inter_linear.weight", "tfgridnet.blocks.0.inter_norm.norm.weight", "tfgridnet.deconv.weight",
+              "tfgridnet.blocks.0.conv.weight", "tfgridnet.blocks.2.deconv.weight"],
+    "big": ["tfgridnet.conv.0.weight", "tfgridnet.blocks.3.intra_rnn.weight_hh_l0_reverse",
+            "tfgridnet.blocks.2.inter_rnn.weight_ih_l0", "tfgridnet.blocks.5.inter_linear.weight",
+            "tfgridnet.blocks.0.intra_norm.norm.weight", "tfgridnet.deconv.weight", "tfgridnet.embeds.2.weight.weight",
+            "tfgridnet.embed_net.dis_embedding.0.weight"],
+}
+
+
+@pytest.mark.parametrize("wl", ["small", "big"])
+def test_full_size_default_dispatch_matches_oracle(wl):
+    import torch
+    import bench
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd.train import FlatBucket
+    from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
+    assert torch.cuda.is_available()
+    assert ops.COMPACT_BPTT and ops.LSTM_MMA == 1 and ops.SCHED_OVERRIDE is None, "default arithmetic / dispatch only"
+    assert os.environ.get("SB_FORCE_FUSED_BPTT", "0") != "1"
+    cls, params, B, negw, _, _ = bench.WORKLOADS[wl]
+    flavour = "optim" if cls == "NetOptim" else "dis_embd3"
+    torch.manual_seed(0)
+    ref = OracleNet(flavour, **params).train()
+    m = getattr(sb, cls)(**params)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda().train()
+    bucket = FlatBucket(m)                      # the bench's gradient path: reductions accumulate into the flat bucket
+    inputs, target = bench.synth_batch(torch, B, 1234, "cuda", flavour == "dis_embd3")
+
+    # the geometry takes the dispatch this test is about
+    tiles = (B * 145 + 15) // 16
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if wl == "small":
+        assert 4 * tiles >= 3 * cus and cus < tiles <= 2 * cus, (tiles, cus)     # fused + time-segmented
+    else:
+        assert 4 * tiles < 3 * cus, (tiles, cus)                                 # two-kernel inter-frame backward
+
+    bucket.zero_grad()
+    est = m(inputs)["output"]
+    loss, lv = SnrlpLossFn.apply(est, target, negw)
+    loss.backward()
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    est_h = est.detach().cpu()
+    lv_h = lv.detach().cpu().numpy()
+
+    # ---- checker: oracle, one utterance at a time ----
+    torch.set_num_threads(bench.host_cores())
+    t0 = time.time()
+    outs, lvs = [], []
+    cpu_in = {k: v.cpu() for k, v in inputs.items()}
+    tgt = target.cpu()
+    for b in range(B):
+        o = ref({k: v[b:b + 1] for k, v in cpu_in.items()})["output"]
+        l = snrlp_loss(o, tgt[b:b + 1], negw)
+        (l.mean() / B).backward()
+        outs.append(o.detach())
+        lvs.append(float(l))
+    want = torch.cat(outs, 0)
+    print(f"[{wl}] oracle: {B} utterances in {time.time() - t0:.1f} s")
+
+    e_fwd = rel_l2(est_h.numpy(), want.numpy())
+    np.testing.assert_allclose(lv_h, np.array(lvs), rtol=2e-3, atol=2e-3)
+    refg = dict(ref.named_parameters())
+    errs = {}
+    for k, p in m.named_parameters():
+        g = refg[k].grad.numpy()
+        errs[k] = rel_l2(p.grad.cpu().numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max())
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    stage = {k: f"{errs[k]:.2e}" for k in STAGES[wl]}
+    print(f"[{wl}] forward rel-L2 {e_fwd:.2e}; worst gradient {worst[0]} {worst[1]:.2e}; stages {stage}")
+    assert e_fwd < TOL_FWD_FULL, e_fwd
+    for k in STAGES[wl]:
+        assert errs[k] < TOL_GRAD_FULL, (k, errs[k], stage)
+    # scalar parameters (PReLU slopes) are sums with heavy cancellation: 10x looser
+    bad = {k: e for k, e in errs.items() if e >= TOL_GRAD_FULL * (10 if refg[k].numel() == 1 else 1)}
+    assert not bad, bad

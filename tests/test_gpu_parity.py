@@ -171,13 +171,34 @@ def test_streaming_matches_reference(torch_gpu, name, cls):
         assert rel_l2(v, rec["stream::state::" + k]) < TOL_FWD, k
 
 
-@pytest.mark.parametrize("compact", [True, False], ids=["bptt-fp16-records", "bptt-fp32-records"])
+# Backward dispatch variants, all held to the REFERENCE goldens:
+#   default          -- what ops.can_fuse_stream picks at this (tiny) geometry: recurrence -> stream kernel pair for the
+#                       inter-frame pass (fewer tiles than 3/4 of the CUs), fused bidirectional intra-frame pass;
+#   fused            -- SB_FORCE_FUSED_BPTT=1: the fused inter-frame BPTT with its Linear-wgrad / LayerNorm-backward riders,
+#                       i.e. the kernel the BASELINE small config runs at B = 32 (290 tiles);
+#   fused-segmented  -- the same under the time-segmented schedule (forward and backward recurrences cut into
+#                       (tile, segment) items handed from workgroup to workgroup), forced through sched_workers/segments;
+#   exact            -- SB_EXACT_BPTT=1 arithmetic (fp32 records, fp32 dgates).
+DISPATCH = ["default", "fused", "fused-segmented", "exact"]
+
+
+def _set_dispatch(monkeypatch, ops, mode):
+    monkeypatch.setattr(ops, "COMPACT_BPTT", mode != "exact")
+    monkeypatch.setattr(ops, "SCHED_OVERRIDE", (4, 2) if mode == "fused-segmented" else None)
+    if mode in ("fused", "fused-segmented"):
+        monkeypatch.setenv("SB_FORCE_FUSED_BPTT", "1")
+    else:
+        monkeypatch.delenv("SB_FORCE_FUSED_BPTT", raising=False)
+
+
+@pytest.mark.parametrize("mode", DISPATCH)
 @pytest.mark.parametrize("name,cls", CASES + ATTN_CASES)
-def test_loss_and_gradients_match_reference(torch_gpu, name, cls, compact, monkeypatch):
+def test_loss_and_gradients_match_reference(torch_gpu, name, cls, mode, monkeypatch):
     torch = torch_gpu
     from sound_bubble_amd.functional import SnrlpLossFn
     from sound_bubble_amd import ops
-    monkeypatch.setattr(ops, "COMPACT_BPTT", compact)
+    compact = mode != "exact"
+    _set_dispatch(monkeypatch, ops, mode)
     rec, params, m = _build(torch, name, cls)
     m.train()
     est = m(_inputs(torch, rec))["output"]
@@ -191,6 +212,7 @@ def test_loss_and_gradients_match_reference(torch_gpu, name, cls, compact, monke
         e = rel_l2(p.grad.cpu().numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max())
         if e > worst[1]:
             worst = (k, e)
+    ops.check_sched_status()
     assert worst[1] < (TOL_GRAD if compact else 2e-4), worst
 
 
@@ -298,16 +320,19 @@ def test_direct_grad_accumulation_equals_autograd_path(torch_gpu, name, cls, mon
         assert rel_l2(p.grad.cpu().numpy(), 2 * want[k].cpu().numpy()) < 1e-4 or float(want[k].abs().max()) == 0, k
 
 
+@pytest.mark.parametrize("mode", ["exact", "fused", "fused-segmented"])
 @pytest.mark.parametrize("N", [1, 100, 192, 193, 1000])
 @pytest.mark.parametrize("flavour", ["optim", "dis_embd3"])
-def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, monkeypatch):
+def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, mode, monkeypatch):
     """mod_pad (net.py:8-18) edge cases: clips shorter than one hop, exactly one hop, one sample more, ragged --
-    a single STFT frame makes every recurrence a one-step walk.  Forward and parameter gradients vs the oracle
-    (fp32 BPTT records: this is a logic test; scalar gradients such as PReLU slopes are cancellation-prone)."""
+    a single STFT frame makes every recurrence a one-step walk.  Forward and parameter gradients vs the oracle, with
+    fp32 BPTT records (the logic test) and through the fused / fused + time-segmented inter-frame BPTT of the default
+    training path (compact fp16 records; scalar gradients such as PReLU slopes are cancellation-prone and are held
+    to a looser bar there)."""
     torch = torch_gpu
     import sound_bubble_amd as sb
     from sound_bubble_amd import ops
-    monkeypatch.setattr(ops, "COMPACT_BPTT", False)
+    _set_dispatch(monkeypatch, ops, mode)
     from oracle.tfgridnet_oracle import OracleNet
     params = dict(stft_chunk_size=192, stft_pad_size=96, num_ch=6, L=4, I=1, J=1, H=64, E=2, use_attn=False,
                   lookahead=True, chunk_causal=True, use_first_ln=True, merge_method="early_cat", B=2,
@@ -340,8 +365,11 @@ def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, monkeypatch):
         if g is None or float(g.abs().max()) == 0:
             continue
         e = rel_l2(p.grad.cpu().numpy(), g.numpy())
+        if mode != "exact" and g.numel() == 1:
+            e *= 0.1                      # scalar (PReLU slope) gradients: sums with heavy cancellation, bar 2e-2
         if e > worst[1]:
             worst = (k, e)
+    ops.check_sched_status()
     assert worst[1] < TOL_GRAD, worst
 
 
@@ -440,7 +468,8 @@ def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, mo
     """Single-direction passes with more tiles than CUs are cut into (tile, time-segment) work items that hand the
     recurrent state from workgroup to workgroup (sb_lstm_fwd_args.seg_state).  The arithmetic is unchanged, so the
     forward outputs, the fused Linear output, the final state and the backward dgates must be bit-identical to the
-    one-workgroup-per-tile schedule (forced here on a small problem through the SB_LSTM_SEG_TEST hook)."""
+    one-workgroup-per-tile schedule (forced here on a small problem through sb_lstm_fwd_args.sched_workers /
+    sched_segments = ops.SCHED_OVERRIDE)."""
     torch = torch_gpu
     from sound_bubble_amd import ops
     if ops.LSTM_MMA != 1 or not ops.COMPACT_BPTT or not ops.DGATES_FP16:
@@ -472,17 +501,18 @@ def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, mo
             rc[-1, :, :, :, jv:] = 0
         return [hs, y, hN, cN, rg, rc, u, dg.data]
 
-    monkeypatch.delenv("SB_LSTM_SEG_TEST", raising=False)
+    monkeypatch.setattr(ops, "SCHED_OVERRIDE", None)
     ref = run()
-    monkeypatch.setenv("SB_LSTM_SEG_TEST", f"{workers},{segments}")
+    monkeypatch.setattr(ops, "SCHED_OVERRIDE", (workers, segments))
     got = run()
+    ops.check_sched_status()
     names = ["hs", "y", "hN", "cN", "gate records", "c_prev records", "u", "dgates"]
     for name, a_, b_ in zip(names, ref, got):
         assert torch.equal(a_, b_), (name, float((a_.float() - b_.float()).abs().max()))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C_,hook", [(16, None), (32, None), (16, "2,3"), (32, "3,2")])
+@pytest.mark.parametrize("C_,hook", [(16, None), (32, None), (16, (2, 3)), (32, (3, 2))])
 def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch):
     """Single-direction passes run the streaming part of the backward (dW_ih, dW_hh, db, dU) inside the recurrence
     kernel, from dgates that stay in LDS (sb_lstm_bwd_args.wpart).  Same arithmetic on the same fp16 dgates as the
@@ -501,10 +531,7 @@ def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch
     dirs = [(wi, wh, torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)]
     lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
     dy = torch.randn(geom.P, C_, device="cuda") * 0.01
-    if hook:
-        monkeypatch.setenv("SB_LSTM_SEG_TEST", hook)
-    else:
-        monkeypatch.delenv("SB_LSTM_SEG_TEST", raising=False)
+    monkeypatch.setattr(ops, "SCHED_OVERRIDE", hook)
     y = torch.empty(geom.P, C_, device="cuda")
     hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, y))
     assert ops.can_fuse_stream(u, hs)
