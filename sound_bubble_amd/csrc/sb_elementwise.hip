@@ -269,12 +269,30 @@ __global__ __launch_bounds__(256) void signal_stats_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
-  float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    s += g[i] * g[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+// Gradient norm for clip_grad_norm_.  DETERMINISTIC (one workgroup, fixed summation tree, no atomics): every
+// data-parallel rank must derive bit-identical clip factors from the bit-identical all-reduced bucket, or the replicas
+// drift apart in the last bit (found by tests/test_gpu_distributed.py with the atomicAdd version).  The bucket is
+// 1-2 MB: one CU reads it in ~10 us.
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int64_t n4 = n / 4;
+  int64_t i = threadIdx.x;
+  for (; i < n4; i += 1024) {
+    const f32x4 v = ld4(g + 4 * i);
+    s0 = __builtin_fmaf(v[0], v[0], s0); s1 = __builtin_fmaf(v[1], v[1], s1);
+    s2 = __builtin_fmaf(v[2], v[2], s2); s3 = __builtin_fmaf(v[3], v[3], s3);
+  }
+  for (int64_t k = 4 * n4 + threadIdx.x; k < n; k += 1024) s0 = __builtin_fmaf(g[k], g[k], s0);
+  float s = wave_sum((s0 + s1) + (s2 + s3));
+  __shared__ float ws[16];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += ws[k];
+    out[0] += t;
+  }
 }
 
 // max |x| (bit pattern of a non-negative float orders like an unsigned integer)
@@ -400,9 +418,8 @@ extern "C" int sb_signal_stats(const float* est, const float* gt, const float* m
 }
 
 extern "C" int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
-  unsigned gx = nblk(n, 256 * 4);
-  if (gx > 512) gx = 512;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
+  if (n <= 0 || (reinterpret_cast<uintptr_t>(g) & 15)) return -1002;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, sumsq);
   SB_CHECK_LAUNCH();
   return 0;
 }

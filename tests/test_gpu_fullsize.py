@@ -10,7 +10,7 @@ with the oracle, through the DEFAULT dispatch:
 Checker: the CPU oracle (oracle/tfgridnet_oracle.py, pinned to the reference goldens) on the same seeded weights and
 inputs, one utterance at a time (1.7 GB of autograd state each; the batch-mean SNRLP loss is the mean of the
 per-utterance losses evaluated alone -- the shared negative term is shard-invariant), gradients
-accumulated.  Forward rel-L2 against the north-star bar 1e-3 (held to 2e-4), every parameter gradient (the six stages
+accumulated.  Forward rel-L2 against the north-star bar 1e-3 (held to 2e-5), every parameter gradient (the six stages
 named in the assertion message) to TOL_GRAD.
 """
 import os
@@ -23,8 +23,8 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL_FWD_FULL = 2e-4
-TOL_GRAD_FULL = 3e-3
+TOL_FWD_FULL = 2e-5      # measured 2.9e-6 (small) / 5.7e-7 (big); north-star bar 1e-3
+TOL_GRAD_FULL = 1.5e-3    # measured worst 3.6e-4 (small, a PReLU slope) / 1.8e-5 (big)
 
 # one representative parameter per stage (front conv, intra W_hh, inter W_ih, inter Linear, a LayerNorm gamma, deconv)
 STAGES = {
@@ -88,12 +88,18 @@ def test_full_size_default_dispatch_matches_oracle(wl):
         l = snrlp_loss(o, tgt[b:b + 1], negw)
         (l.mean() / B).backward()
         outs.append(o.detach())
-        lvs.append(float(l))
+        lvs.append(float(l.detach()))
     want = torch.cat(outs, 0)
     print(f"[{wl}] oracle: {B} utterances in {time.time() - t0:.1f} s")
 
     e_fwd = rel_l2(est_h.numpy(), want.numpy())
-    np.testing.assert_allclose(lv_h, np.array(lvs), rtol=2e-3, atol=2e-3)
+    # per-utterance losses: positives one by one; the silent-target utterances share ONE scalar in the batch (the L1 mean
+    # over all negatives, SNRLP.py:29-32) whose sum equals the sum of their stand-alone values
+    lvs = np.array(lvs)
+    neg = (tgt.abs().amax(dim=(1, 2)) == 0).numpy()
+    assert neg.any() and (~neg).any()
+    np.testing.assert_allclose(lv_h[~neg], lvs[~neg], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lv_h[neg].sum(), lvs[neg].sum(), rtol=1e-4)
     refg = dict(ref.named_parameters())
     errs = {}
     for k, p in m.named_parameters():
