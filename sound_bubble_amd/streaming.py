@@ -21,6 +21,38 @@ def flatten_state(d, prefix=""):
     return out
 
 
+DELIMITER = "::"
+
+
+def flatten_state_buffers(state_buffers_dict, prefix=""):
+    """edge/flatbuf.py:10-25: (names, buffers) of a nested state dict, keys sorted at every level, names joined with
+    '::', every buffer cloned -- the chunk-level I/O order of the exported edge model (to_onnx.py:94-101)."""
+    flat = flatten_state(state_buffers_dict, prefix)
+    for k, v in flat.items():
+        if not torch.is_tensor(v):
+            raise TypeError(f"{k}: expected torch.Tensor, found {type(v).__name__}")
+    return list(flat.keys()), [v.clone() for v in flat.values()]
+
+
+def unflatten_state_buffers(state_names, state_buffers):
+    """edge/flatbuf.py:27-70: rebuild the nested state dict from '::'-joined names (buffers cloned)."""
+    if len(state_names) != len(state_buffers):
+        raise ValueError(f"{len(state_names)} names for {len(state_buffers)} buffers")
+    root = {}
+    for name, buf in zip(state_names, state_buffers):
+        path = name.split(DELIMITER)
+        node = root
+        for part in path[:-1]:
+            nxt = node.setdefault(part, {})
+            if not isinstance(nxt, dict):
+                raise ValueError(f"{name}: '{part}' is both a buffer and a group")
+            node = nxt
+        if isinstance(node.get(path[-1]), dict):
+            raise ValueError(f"{name}: both a buffer and a group")
+        node[path[-1]] = buf.clone()
+    return root
+
+
 def _clone_tree(d):
     return {k: _clone_tree(v) if isinstance(v, dict) else v for k, v in d.items()}
 

@@ -288,6 +288,76 @@ def make_samples(torch, NetBig, out_dir, n_keep=36000):
     np.savez_compressed(os.path.join(out_dir, "samples_syn_1m.npz"), **rec)
 
 
+def make_state_io(torch, nets, out_dir):
+    """edge/flatbuf.py:8-25 name order: the reference's own flatten_state_buffers over init_buffers of each family
+    (+ attention buffers), and the reference's named_parameters() order (= torch.optim.Adam state indices)."""
+    import json
+    sys.path.insert(0, os.path.join(REF, "edge"))
+    flatbuf = importlib.import_module("flatbuf")                   # reference edge/flatbuf.py
+    rec = {}
+    for name, (Net, params) in nets.items():
+        model = Net(**params).eval()
+        names, bufs = flatbuf.flatten_state_buffers(model.init_buffers(1, "cpu"))
+        back = flatbuf.unflatten_state_buffers(names, bufs)
+        n2, _ = flatbuf.flatten_state_buffers(back)
+        assert n2 == names
+        rec[name] = {"params": repr(sorted(params.items())), "state_names": names,
+                     "state_shapes": [list(b.shape) for b in bufs],
+                     "parameter_order": [k for k, _ in model.named_parameters()]}
+    with open(os.path.join(out_dir, "state_io.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("state_io.json:", {k: len(v["state_names"]) for k, v in rec.items()})
+
+
+def make_ckpt(torch, NetSmall, out_dir):
+    """A checkpoint in the REFERENCE's format (PLModule.dump_state, hl_module:141-156: {'model', 'optimizer' =
+    torch.optim.Adam.state_dict(), 'current_epoch', 'metric_values', 'statistics', 'scheduler'}) written after two
+    optimiser steps / scheduler epochs of the reference Net (tiny_small weights and batch, raspberrypi_model_pretrain.json's
+    Adam + sequential scheduler + grad_clip 1), and the parameters the reference reaches with a THIRD step from it.
+    (PLModule itself cannot be imported here -- wandb / torchmetrics / asteroid -- so its dump_state dict is restated.)"""
+    z = np.load(os.path.join(out_dir, "tiny_small.npz"))
+    params = dict(eval(str(z["meta::params"])))
+    model = NetSmall(**params).train()
+    sd = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param::")}
+    filt = torch.from_numpy(np.load(os.path.join(out_dir, "stft_filters.npz"))["filters"])
+    sd["tfgridnet.enc.filterbank._filters"] = filt
+    sd["tfgridnet.dec.filterbank._filters"] = filt.clone()
+    model.load_state_dict(sd)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    L = torch.optim.lr_scheduler
+    sched = L.SequentialLR(opt, [L.LinearLR(opt, start_factor=0.1, total_iters=10), L.ConstantLR(opt, factor=1),
+                                 L.StepLR(opt, step_size=2, gamma=0.95)], [10, 30])     # hl_module:460-481
+    mix, tgt = torch.from_numpy(z["mixture"]), torch.from_numpy(z["target"])
+
+    def step():
+        opt.zero_grad()
+        loss = snrlp_loss(torch, model({"mixture": mix})["output"], tgt, 50.0).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return float(loss.detach())
+
+    losses = []
+    for epoch in range(2):
+        losses.append(step())
+        sched.step()
+    state = dict(model=model.state_dict(), optimizer=opt.state_dict(), current_epoch=2,
+                 metric_values={0: {"val/loss": {"step": None, "epoch": 3.0, "num_elements": 2}},
+                                1: {"val/loss": {"step": None, "epoch": 2.5, "num_elements": 2}}},
+                 statistics={}, scheduler=sched.state_dict())
+    torch.save(state, os.path.join(out_dir, "ref_format_last_tiny_small.pt"))
+    lr3 = opt.param_groups[0]["lr"]
+    losses.append(step())
+    rec = {"loss": np.array(losses, np.float64), "lr_at_step3": np.float64(lr3)}
+    for k, p in model.named_parameters():
+        rec["param_after3::" + k] = p.detach().numpy().copy()
+    for i, (k, p) in enumerate(model.named_parameters()):
+        if k.endswith("inter_rnn.weight_hh_l0"):
+            rec["exp_avg_after3::" + k] = opt.state[p]["exp_avg"].numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, "ckpt_resume_tiny_small.npz"), **rec)
+    print("ref_format_last_tiny_small.pt + ckpt_resume_tiny_small.npz: losses", losses, "lr", lr3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.dirname(os.path.abspath(__file__)))
@@ -344,6 +414,12 @@ def main():
               with_grads=False, with_stream=False, with_stages=False)
     if not only or "samples" in only:
         make_samples(torch, NetBig, args.out)
+    if not only or "state_io" in only:
+        make_state_io(torch, {"small": (NetSmall, small), "big": (NetBig, big), "orange": (NetSmall, orange),
+                              "big_attn": (NetBig, dict(big, use_attn=True)),
+                              "tiny_small": (NetSmall, dict(small, B=2))}, args.out)
+    if not only or "ckpt" in only:
+        make_ckpt(torch, NetSmall, args.out)
 
 
 if __name__ == "__main__":

@@ -232,16 +232,22 @@ def test_oracle_agrees_at_full_size_property(torch_gpu):
 
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
-def test_streaming_separator_equals_offline(torch_gpu, use_graph):
-    """edge/causal_infer.py:49-86 self-check: chunked output == one-shot output (atol 1e-3 there)."""
+@pytest.mark.parametrize("name,cls", [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"), ("small_1s", "NetOptim")],
+                         ids=["big-family", "edge-family-tiny", "edge-config-0.3M"])
+def test_streaming_separator_equals_offline(torch_gpu, use_graph, name, cls):
+    """edge/causal_infer.py:49-86 self-check: chunked output == one-shot output (atol 1e-3 there) -- for the big family
+    and for the edge (small / optim, conv-LSTM) family incl. the shipped 0.3 M configuration that causal_infer.py runs."""
     torch = torch_gpu
     from sound_bubble_amd.streaming import StreamingSeparator, streaming_inference
-    rec, params, m = _build(torch, "tiny_big", "NetDisEmbd3")
-    dis = torch.from_numpy(rec["dis_embed"][:1]).cuda()
+    rec, params, m = _build(torch, name, cls)
+    dis = torch.from_numpy(rec["dis_embed"][:1]).cuda() if "dis_embed" in rec else None
     torch.manual_seed(1)
     X = (0.1 * torch.randn(1, 6, 192 * 12 + 96)).cuda()
     with torch.no_grad():
-        Y = m({"mixture": X, "dis_embed": dis}, pad=False)["output"]
+        inp = {"mixture": X}
+        if dis is not None:
+            inp["dis_embed"] = dis
+        Y = m(inp, pad=False)["output"]
     sep = StreamingSeparator(m, 1, dis_embed=dis, use_graph=use_graph)
     Z = streaming_inference(sep, X)
     assert Z.shape == Y.shape == (1, 1, 192 * 12)
