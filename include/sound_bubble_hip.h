@@ -134,6 +134,31 @@ int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
  * of 16 (N <= 128 per call).  n_valid <= N features are stored.
  * Replaces nn.Linear / Conv1d(k=s) / ConvTranspose1d(k=s) / Conv2d(3x3) /
  * asteroid Encoder+Decoder GEMMs: tfgridnet_causal.py:475,507,520,537,803-824,845. */
+/* A logical [N, K] weight matrix laid over a parameter tensor in its NATIVE (torch) layout, so that no transposed /
+ * permuted / zero-padded copy of a weight is ever made on the host side of a training step:
+ *   element (n, k) = base[off + (n % nmod) * sn_lo + (n / nmod) * sn_hi + (k % kmod) * sk_lo + (k / kmod) * sk_hi]
+ * and elements with (k % kmod) >= kvalid or n >= nvalid are zero when read (sb_linear_fwd) / dropped when written
+ * (sb_wgrad).  nmod == 0 means "no view": a dense row-major [N, K] matrix.  Examples (C channels):
+ *   Conv1d weight [co, ci, j] as W[co][j*C + ci]              : nmod 1<<30, sn_lo C*s, kmod C, sk_lo s, sk_hi 1
+ *   ConvTranspose1d weight [h, c, j] as W[j*C + c][h]         : nmod C, sn_lo s, sn_hi 1, kmod 1<<30, sk_lo C*s
+ *   Conv2d weight [co, 27, 3, 3] as W[co][(a*3+d)*32 + ci]    : sn_lo 243, kmod 32, sk_lo 9, sk_hi 1, kvalid 27
+ *   ConvTranspose2d weight [c, 2, 3, 3] as W[o][(a*3+d)*C + c] (flipped taps): off 8, sn_lo 9, kmod C, sk_lo 18, sk_hi -1,
+ *                                                                nvalid 2
+ *   a transposed Linear weight [K, N] as W[n][k]              : sn_lo 1, sk_lo N                                     */
+typedef struct {
+  int64_t off;
+  int nmod; int64_t sn_lo, sn_hi;
+  int kmod; int64_t sk_lo, sk_hi;
+  int kvalid, nvalid;
+} sb_wview;
+/* Kernel-layout weight forms.  The GEMM kernels stage dense row-major [N, K] weights with 16-byte loads; the forms of
+ * ALL layers of a model (transposes, tap-major conv weights, zero-padded rows, biases repeated over taps) are refreshed
+ * from the parameters by ONE launch per forward pass: jobs[i] (a DEVICE array, built once by the caller) copies the
+ * logical matrix of view v over src into dst [N, K].  max_elems = max N*K over the jobs.  (Staging through the view inside
+ * every GEMM launch was measured slower: 10-20 us of index arithmetic per launch, four waves per SIMD each.) */
+typedef struct { const float* src; float* dst; sb_wview v; int N, K; } sb_wview_job;
+int sb_wview_gather(const sb_wview_job* jobs, int njobs, int max_elems, void* stream);
+
 enum {
   SB_EPI_NONE = 0,   /* + bias                                              */
   SB_EPI_RES = 1,    /* + bias + res[p]  (res addressed like out: rs_*)     */
@@ -184,6 +209,10 @@ typedef struct {
      n = j*c + i as i*(N/c) + j (Conv1d / ConvTranspose1d weights [out, in, k] addressed as [out][k*in + i]);
      bias_mod = c > 0 folds the bias gradient: dbias[n % c] += ... */
   int perm_k, perm_n, bias_mod;
+  /* general form of the above (wv.nmod != 0; perm_k / perm_n / transpose_out must then be 0): dW[n, k] is ADDED at
+     dW[wv-address(n, k)] of the parameter's gradient in its native layout (see sb_wview), and dbias[n % bias_mod] only
+     for n < wv.nvalid. */
+  sb_wview wv;
 } sb_wgrad_args;
 int sb_wgrad(const sb_wgrad_args* a, void* stream);
 int sb_wgrad_grid(int64_t positions);

@@ -39,6 +39,22 @@ class LstmBwdArgs(C.Structure):
                 ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp)]
 
 
+class WView(C.Structure):
+    """sb_wview: a logical [N, K] matrix over a parameter's native layout (see the header)"""
+    _fields_ = [("off", i64), ("nmod", C.c_int), ("sn_lo", i64), ("sn_hi", i64),
+                ("kmod", C.c_int), ("sk_lo", i64), ("sk_hi", i64), ("kvalid", C.c_int), ("nvalid", C.c_int)]
+
+    BIG = 1 << 30
+
+    @classmethod
+    def make(cls, sn_lo, sk_lo, *, off=0, nmod=None, sn_hi=0, kmod=None, sk_hi=0, kvalid=None, nvalid=None):
+        v = cls()
+        v.off, v.nmod, v.sn_lo, v.sn_hi = off, nmod or cls.BIG, sn_lo, sn_hi
+        v.kmod, v.sk_lo, v.sk_hi = kmod or cls.BIG, sk_lo, sk_hi
+        v.kvalid, v.nvalid = kvalid if kvalid is not None else cls.BIG, nvalid if nvalid is not None else cls.BIG
+        return v
+
+
 class LinearArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("F", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("n_valid", C.c_int), ("kseg", C.c_int), ("epi", C.c_int),
@@ -51,6 +67,10 @@ class LinearArgs(C.Structure):
                 ("absmax_out", c_fp)]
 
 
+class WViewJob(C.Structure):
+    _fields_ = [("src", c_fp), ("dst", c_fp), ("v", WView), ("N", C.c_int), ("K", C.c_int)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("F", C.c_int), ("N", C.c_int), ("K", C.c_int), ("kseg", C.c_int),
                 ("g", c_fp), ("ldg", i64),
@@ -58,7 +78,7 @@ class WgradArgs(C.Structure):
                 ("in2", c_fp), ("ld2", i64), ("shift2", i64), ("K2", C.c_int),
                 ("seg_len", C.c_int), ("skip_first", C.c_int), ("skip_last", C.c_int),
                 ("transpose_out", C.c_int), ("dW", c_fp), ("dW2", c_fp), ("dbias", c_fp), ("dbias2", c_fp),
-                ("scratch", c_fp), ("in_f16", C.c_int), ("perm_k", C.c_int), ("perm_n", C.c_int), ("bias_mod", C.c_int)]
+                ("scratch", c_fp), ("in_f16", C.c_int), ("perm_k", C.c_int), ("perm_n", C.c_int), ("bias_mod", C.c_int), ("wv", WView)]
 
 
 class LstmStreamArgs(C.Structure):
@@ -99,6 +119,7 @@ SYMBOLS = {
     "sb_lstm_bwd_rec": (_ci, [C.POINTER(LstmBwdArgs), _vp]),
     "sb_linear_fwd": (_ci, [C.POINTER(LinearArgs), _vp]),
     "sb_linear_grid": (_ci, [i64]),
+    "sb_wview_gather": (_ci, [c_fp, _ci, _ci, _vp]),
     "sb_wgrad": (_ci, [C.POINTER(WgradArgs), _vp]),
     "sb_wgrad_grid": (_ci, [i64]),
     "sb_lstm_bwd_stream": (_ci, [C.POINTER(LstmStreamArgs), _vp]),

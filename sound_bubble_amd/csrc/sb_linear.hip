@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(sb_wgrad_args a, int64_
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int rows, int N, int K1,
                                                            int K2, float* __restrict__ dW1, float* __restrict__ dW2,
                                                            float* __restrict__ db1, float* __restrict__ db2,
-                                                           int transpose_out, int perm_k, int perm_n, int bias_mod) {
+                                                           int transpose_out, int perm_k, int perm_n, int bias_mod,
+                                                           sb_wview wv) {
   const int Ktot = K1 + K2;
   const int total = N * Ktot + N;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -495,7 +496,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   s += sa + sb + sc;
   if (i < N * Ktot) {
     const int n = i / Ktot, k = i - n * Ktot;
-    if (k < K1) {
+    if (k < K1 && wv.nmod != 0) {
+      // destination through a weight view over the parameter's native layout (sb_wview)
+      const int kl = k % wv.kmod, kh = k / wv.kmod;
+      if (kl < wv.kvalid && n < wv.nvalid)
+        atomicAdd(dW1 + wv.off + (int64_t)(n % wv.nmod) * wv.sn_lo + (int64_t)(n / wv.nmod) * wv.sn_hi +
+                  (int64_t)kl * wv.sk_lo + (int64_t)kh * wv.sk_hi, s);
+    } else if (k < K1) {
       // destination in the parameter's native layout (sb_wgrad_args.perm_k / perm_n)
       const int kd = perm_k > 0 ? (k % perm_k) * (K1 / perm_k) + k / perm_k : k;
       const int nd = perm_n > 0 ? (n % perm_n) * (N / perm_n) + n / perm_n : n;
@@ -504,6 +511,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   } else {
     const int n = i - N * Ktot;
     const int nb = bias_mod > 0 ? n % bias_mod : n;
+    if (wv.nmod != 0 && n >= wv.nvalid) return;
     if (db1) atomicAdd(db1 + nb, s);
     if (db2) atomicAdd(db2 + nb, s);
   }
@@ -548,6 +556,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
   __syncthreads();
   if (rr == 0 && c < N)
     scratch[(size_t)blockIdx.x * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// Weight forms: every job copies the logical [N, K] matrix a view describes over a parameter's native layout into a
+// dense row-major buffer (zeros where the view says so).  One launch refreshes all forms of a model (a few hundred KB).
+__global__ __launch_bounds__(256) void wview_gather_kernel(const sb_wview_job* __restrict__ jobs) {
+  const sb_wview_job j = jobs[blockIdx.y];
+  const int total = j.N * j.K;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int n = idx / j.K, k = idx - n * j.K;
+    const int kl = k % j.v.kmod, kh = k / j.v.kmod;
+    const bool ok = kl < j.v.kvalid && n < j.v.nvalid;
+    const int64_t ad = j.v.off + (int64_t)(n % j.v.nmod) * j.v.sn_lo + (int64_t)(n / j.v.nmod) * j.v.sn_hi +
+                       (int64_t)kl * j.v.sk_lo + (int64_t)kh * j.v.sk_hi;
+    j.dst[idx] = ok ? j.src[ad] : 0.f;
+  }
 }
 
 template <int NT, int EPI>
@@ -615,6 +638,15 @@ extern "C" int sb_linear_fwd(const sb_linear_args* ap, void* stream) {
   return 0;
 }
 
+extern "C" int sb_wview_gather(const sb_wview_job* jobs, int njobs, int max_elems, void* stream) {
+  if (!jobs || njobs <= 0 || max_elems <= 0) return -1001;
+  int gx = (max_elems + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(wview_gather_kernel, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (!ap) return -1001;
   const sb_wgrad_args& a = *ap;
@@ -624,6 +656,7 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (a.K2 % 16 || (a.K2 && a.K % 16)) return -1002;
   if ((a.perm_k > 0 && a.K % a.perm_k) || (a.perm_n > 0 && a.N % a.perm_n) || a.perm_k < 0 || a.perm_n < 0 || a.bias_mod < 0)
     return -1002;
+  if (a.wv.nmod != 0 && (a.wv.nmod < 0 || a.wv.kmod <= 0 || a.perm_k || a.perm_n || a.transpose_out)) return -1002;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(sb_wgrad_grid(P)), block(256);
   // wide-load kernel: single source, whole tiles, whole segments, rows aligned for 16-byte (fp16: 8-byte) loads
@@ -659,7 +692,7 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   const int total = a.N * (a.K + a.K2) + a.N;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, grid.x >= 64 ? 16 : 1), dim3(256), 0, st, a.scratch,
                      (int)grid.x * 4, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out, a.perm_k, a.perm_n,
-                     a.bias_mod);
+                     a.bias_mod, a.wv);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -19,6 +19,14 @@
 #ifndef SB_EXP_SKIP
 #define SB_EXP_SKIP 0
 #endif
+// Developer experiment (scripts/exp_gate_recompute.py; 0 in the shipped library): cost model of RECOMPUTING the four
+// gates in the backward recurrence from (u, h_prev) instead of loading the forward's gate records -- bit 0: issue the
+// recompute's instruction mix per step (12 fp16 MFMAs 16x16x32 = W[4 gates][3 K-chunks] . [u | h_prev], 16 gate
+// activations = 16 v_exp + 16 v_rcp, results folded into the gates at 1e-30 so nothing is eliminated); bit 1: do not
+// load the gate records (their bytes are what a recompute would save; the c_prev record stays).
+#ifndef SB_EXP_RECOMPUTE
+#define SB_EXP_RECOMPUTE 0
+#endif
 #include "../../include/sound_bubble_hip.h"
 
 // Phase timing (developer tool): build with -DSB_PHASE_TIMING and pass a scratch buffer (fwd: save_u with
@@ -889,7 +897,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         // blocked lane-order layout of the forward kernel: one contiguous KB per load instruction
         const int64_t blk = (rec_tile + st) * ndir + dir;
         const float* rec = a.save_gates + blk * (16 * 4 * H / 2) + (w * 128 + lane) * 4;
-        r.r0 = ld4(rec); r.r1 = ld4(rec + 256);
+        if (SB_EXP_RECOMPUTE & 2) { const float cv = __builtin_bit_cast(float, (unsigned)(0x38003800u + (s & 1))); r.r0 = r.r1 = f32x4{cv, cv, cv, cv}; }
+        else { r.r0 = ld4(rec); r.r1 = ld4(rec + 256); }
         r.r2 = r.r3 = r.cp = zero4();
         r.cp16 = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(a.save_c) + blk * (16 * H) + (w * 64 + lane) * 4);
       } else {
@@ -940,6 +949,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     } else {
       gi = raw.r0; gf = raw.r1; gg = raw.r2; go = raw.r3;
     }
+#if SB_EXP_RECOMPUTE & 1
+    {
+      // operands that depend on loaded data (so nothing is hoisted out of the time loop)
+      const h16x8 xb = __builtin_bit_cast(h16x8, raw.dh), wa = __builtin_bit_cast(h16x8, f32x4{gi[0], gf[1], gg[2], go[3]});
+      f32x4 z[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, z[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x7F6);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[r] = __builtin_fmaf(1e-30f, sigmoid_pre(z[0][r]), gi[r]);
+        gf[r] = __builtin_fmaf(1e-30f, sigmoid_pre(z[1][r]), gf[r]);
+        gg[r] = __builtin_fmaf(1e-30f, tanh_pre(z[2][r]), gg[r]);
+        go[r] = __builtin_fmaf(1e-30f, sigmoid_pre(z[3][r]), go[r]);
+      }
+    }
+#endif
     f32x4 dhext = raw.dh;
     if constexpr (DG16 && FUSE_C == 0) dhext *= gS;
     if constexpr (FUSE_C > 0) {

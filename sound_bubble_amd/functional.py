@@ -30,8 +30,10 @@ class _GradTargets:
 
     def __call__(self, name, p):
         g = p.grad
-        if (DIRECT_GRADS and g is not None and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous()
-                and g.device == p.device):
+        # direct accumulation only into gradient buffers train.FlatBucket set up (it tags the parameter): an ordinary
+        # .grad left over from autograd, a frozen parameter or torch.autograd.grad() calls go through autograd as usual
+        if (DIRECT_GRADS and g is not None and getattr(p, "_sb_flat_grad", False) and p.requires_grad
+                and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous() and g.device == p.device):
             self.ret[name] = None
             return g
         z = torch.zeros_like(p, dtype=torch.float32)
@@ -179,7 +181,7 @@ class IntraConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, act_a, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, dec_w, dec_b,
-                down, bias_tail):
+                down, bias_tail, wc, wd, bd, wdT, wcT):
         B, T, F, Cc = x.shape
         x = x.contiguous()
         Kd = F // down
@@ -187,7 +189,8 @@ class IntraConvFn(torch.autograd.Function):
         P2 = B * T * Kd
         train = GRAD_MODE and any(ctx.needs_input_grad)
         dev = x.device
-        wc = conv_w.permute(0, 2, 1).reshape(Cc, down * Cc).contiguous()          # [co][j*C+ci]
+        # kernel-layout forms of the two conv weights (forms.WeightForms, refreshed once per optimiser step):
+        # wc [co][j*C + ci], wd [j*C + c][h], bd = bias repeated over the taps, wdT / wcT their transposes (backward)
         v_pre = torch.empty(P2, Cc, device=dev, dtype=torch.float32) if train else None
         a = torch.empty(P2, Cc, device=dev, dtype=torch.float32)
         grid = (B * T, 1, Kd)
@@ -197,23 +200,21 @@ class IntraConvFn(torch.autograd.Function):
         geom = Geom.intra(B * T, Kd)
         dirs = [(wif, whf, bif, bhf), (wir, whr, bir, bhr)]
         hs, _, gates, u = ops.lstm_fwd(a, ln_g, ln_b, dirs, geom, save=train)
-        wd = dec_w.permute(2, 1, 0).reshape(down * Cc, 2 * H).contiguous()        # [j*C+c][h]
-        bd = dec_b.repeat(down).contiguous()
         y = torch.empty_like(x)
         s_h = (Kd * 2 * H, 0, 2 * H)
         ops.linear(hs, wd, bd, y, grid, s_h, s_x, 2 * H, down * Cc, epi=L.EPI_RES, res=x)
         if Fm < F:      # tail frequencies: residual (+ bias when ConvTranspose1d has output_padding)
             y[:, :, Fm:, :] = x[:, :, Fm:, :] + (dec_b if bias_tail else 0.0)
         if train:
-            ctx.save_for_backward(x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, ln_b, bif, bhf, bir, bhr,
-                                  conv_w, conv_b, dec_w, dec_b, *[t for t in gates if t is not None])
+            ctx.save_for_backward(x, act_a, ln_g, wif, whf, wir, whr, hs, u, v_pre, ln_b, bif, bhf, bir, bhr,
+                                  conv_w, conv_b, dec_w, dec_b, wdT, wcT, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc, down, Kd, bool(bias_tail))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, wc, act_a, ln_g, wif, whf, wir, whr, wd, hs, u, v_pre, ln_b, bif, bhf, bir, bhr, conv_w, conv_b, dec_w, dec_b,
-         *g_) = ctx.saved_tensors
+        (x, act_a, ln_g, wif, whf, wir, whr, hs, u, v_pre, ln_b, bif, bhf, bir, bhr, conv_w, conv_b, dec_w, dec_b,
+         wdT, wcT, *g_) = ctx.saved_tensors
         gates = (g_[0], g_[1] if len(g_) > 1 else None)
         gt = _GradTargets()
         B, T, F, Cc, down, Kd, bias_tail = ctx.dims
@@ -229,8 +230,8 @@ class IntraConvFn(torch.autograd.Function):
         _, sC = dense(P2, Cc)
         # ConvTranspose1d backward
         dhs = torch.empty(P2, 2 * H, device=dev, dtype=torch.float32)
-        gm_dhs = torch.zeros(1, device=dev, dtype=torch.float32) if ops.ABSMAX_HINTS else None   # max |dhs| on the fly
-        ops.linear(dym, wd.t().contiguous(), None, dhs, gP2, sNC, s2H, NC, 2 * H, absmax_out=gm_dhs)
+        gm_dhs = ops.zero_scalar(dev) if ops.ABSMAX_HINTS else None   # max |dhs| on the fly
+        ops.linear(dym, wdT, None, dhs, gP2, sNC, s2H, NC, 2 * H, absmax_out=gm_dhs)
         # dW[n = j*C + c][k = h] and its bias sums land in the parameters' native layout: dec_w [2H, C, down] (transposed,
         # rows n -> c*down + j), dec_b [C] (rows folded mod C) -- straight into the .grad buffers when they exist
         t_dec_w, t_dec_b = gt("dec_w", dec_w), gt("dec_b", dec_b)
@@ -254,8 +255,8 @@ class IntraConvFn(torch.autograd.Function):
         s_x = (F * Cc, 0, NC)
         s_v = (Kd * Cc, 0, Cc)
         # dx is the dy of the inter-frame backward of the previous block: its max |.| is measured here
-        gm_dx = torch.zeros(1, device=dev, dtype=torch.float32) if (ops.ABSMAX_HINTS and Fm == F) else None
-        ops.linear(dv, wc.t().contiguous(), None, dx, grid, s_v, s_x, Cc, NC, epi=L.EPI_RES, res=dy, absmax_out=gm_dx)
+        gm_dx = ops.zero_scalar(dev) if (ops.ABSMAX_HINTS and Fm == F) else None
+        ops.linear(dv, wcT, None, dx, grid, s_v, s_x, Cc, NC, epi=L.EPI_RES, res=dy, absmax_out=gm_dx)
         if Fm < F:
             dx[:, :, Fm:, :] = dy[:, :, Fm:, :]
         if gm_dx is not None:
@@ -263,7 +264,8 @@ class IntraConvFn(torch.autograd.Function):
         # dW[co][k = j*C + ci] -> conv_w [co, ci, j]
         ops.wgrad(dv, Cc, Cc, x, s_x, grid, NC, gt("conv_w", conv_w), dbias=gt("conv_b", conv_b), perm_k=Cc)
         return (dx, gt["conv_w"], gt["conv_b"], gt["act_a"], gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"],
-                gt["bhf"], gt["wir"], gt["whr"], gt["bir"], gt["bhr"], gt["dec_w"], gt["dec_b"], None, None)
+                gt["bhf"], gt["wir"], gt["whr"], gt["bir"], gt["bhr"], gt["dec_w"], gt["dec_b"], None, None,
+                None, None, None, None, None)
 
 
 class AttentionFn(torch.autograd.Function):
@@ -422,7 +424,7 @@ class FrontEndFn(torch.autograd.Function):
     2-frame context.  Returns x0 [B,T,F,C] channels-last and the new conv_buf."""
 
     @staticmethod
-    def forward(ctx, mix, enc_filters, conv_w, conv_b, ln_g, ln_b, conv_buf, use_ln, hop):
+    def forward(ctx, mix, enc_filters, conv_w, conv_b, ln_g, ln_b, conv_buf, use_ln, hop, wk):
         B, M, Np = mix.shape
         win = enc_filters.shape[-1]
         F = enc_filters.shape[0] // 2
@@ -443,9 +445,7 @@ class FrontEndFn(torch.autograd.Function):
         ops.features(spec, NSPEC, zp, B, M, T, F)
         new_buf = zp[:, T:T + 2, 1:F + 1, :nfeat].permute(0, 3, 1, 2).contiguous()
         # 3. 3x3 conv as 3 K-segments of 96 contiguous floats (+ fused LayerNorm)
-        wk = torch.zeros(Cc, 3, 3, ZC, device=dev, dtype=torch.float32)
-        wk[..., :nfeat] = conv_w.permute(0, 2, 3, 1)
-        wk = wk.view(Cc, 9 * ZC)
+        # wk: kernel-layout form of the Conv2d weight, [co][(a*3 + d)*32 + ci] with channels 27..31 zero (forms.WeightForms)
         x0 = torch.empty(B, T, F, Cc, device=dev, dtype=torch.float32)
         pre = torch.empty(B * T * F, Cc, device=dev, dtype=torch.float32) if (train and use_ln) else None
         s_in = ((T + 2) * (F + 2) * ZC, (F + 2) * ZC, ZC)
@@ -454,30 +454,28 @@ class FrontEndFn(torch.autograd.Function):
                    epi=L.EPI_LN if use_ln else L.EPI_NONE, ln_g=ln_g if use_ln else None,
                    ln_b=ln_b if use_ln else None, aux_out=pre)
         if train:
-            ctx.save_for_backward(zp, pre, ln_g)
+            ctx.save_for_backward(zp, pre, ln_g, conv_w, conv_b, ln_b)
             ctx.dims = (B, T, F, Cc, nfeat, bool(use_ln))
         ctx.mark_non_differentiable(new_buf)
         return x0, new_buf
 
     @staticmethod
     def backward(ctx, dx0, _dbuf):
-        zp, pre, ln_g = ctx.saved_tensors
+        zp, pre, ln_g, conv_w, conv_b, ln_b = ctx.saved_tensors
         B, T, F, Cc, nfeat, use_ln = ctx.dims
         P = B * T * F
-        dev = dx0.device
         dx0 = dx0.contiguous()
-        gP, sC = dense(P, Cc)
-        d_g = d_b = None
+        gt = _GradTargets()
         if use_ln:
-            dpre, d_g, d_b, _ = ops.ln_bwd(dx0.view(P, 1, Cc), pre, ln_g)
+            dpre, _, _, _ = ops.ln_bwd(dx0.view(P, 1, Cc), pre, ln_g, d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b))
         else:
             dpre = dx0.view(P, Cc)
-        d_wk = torch.zeros(Cc, 9 * ZC, device=dev, dtype=torch.float32)
+            gt.ret["ln_g"] = gt.ret["ln_b"] = None
         s_in = ((T + 2) * (F + 2) * ZC, (F + 2) * ZC, ZC)
-        d_conv_b = torch.zeros(Cc, device=dev, dtype=torch.float32)
-        ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, d_wk, kseg=3 * ZC, is_seg=(F + 2) * ZC, dbias=d_conv_b)
-        d_conv_w = d_wk.view(Cc, 3, 3, ZC)[..., :nfeat].permute(0, 3, 1, 2).contiguous()
-        return None, None, d_conv_w, d_conv_b, d_g, d_b, None, None, None
+        # dW[co][(a*3 + d)*32 + ci] lands in conv_w's own [co, ci, a, d] layout (and in the flat bucket when it exists)
+        ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, gt("conv_w", conv_w), kseg=3 * ZC, is_seg=(F + 2) * ZC,
+                  dbias=gt("conv_b", conv_b), wview=L.WView.make(nfeat * 9, 9, kmod=ZC, sk_hi=1, kvalid=nfeat))
+        return None, None, gt["conv_w"], gt["conv_b"], gt["ln_g"], gt["ln_b"], None, None, None, None
 
 
 def _istft_weights(dec_filters):
@@ -499,7 +497,7 @@ class BackEndFn(torch.autograd.Function):
     new istft_buf [B,1,2F,1]."""
 
     @staticmethod
-    def forward(ctx, y, dec_filters, dw, db, deconv_buf, istft_buf, hop):
+    def forward(ctx, y, dec_filters, dw, db, deconv_buf, istft_buf, hop, wk, bk):
         B, T, F, Cc = y.shape
         dev = y.device
         win = dec_filters.shape[-1]
@@ -515,11 +513,7 @@ class BackEndFn(torch.autograd.Function):
         rows = torch.zeros(B, T + 1, NSPEC, device=dev, dtype=torch.float32)
         ib = istft_buf.reshape(B, 2, F)                                           # [re | im]
         rows[:, 0, : 2 * F] = ib.permute(0, 2, 1).reshape(B, 2 * F)
-        wk = torch.zeros(16, 3, 3, Cc, device=dev, dtype=torch.float32)          # [o][a][d][c] = W[c,o,2-a,2-d]
-        wk[:2] = dw.flip(2, 3).permute(1, 2, 3, 0)
-        wk = wk.view(16, 9 * Cc)
-        bk = torch.zeros(16, device=dev, dtype=torch.float32)
-        bk[:2] = db
+        # wk [16][(a*3 + d)*C + c] = dw[c, o, 2-a, 2-d] (rows 2..15 zero), bk [16]: kernel-layout forms (forms.WeightForms)
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
         ops.linear(yp, wk, bk, rows, (B, T, F), s_in, ((T + 1) * NSPEC, NSPEC, 2), 9 * Cc, 16, kseg=3 * Cc,
                    is_seg=(F + 2) * Cc, n_valid=2, out_off=NSPEC)
@@ -532,14 +526,14 @@ class BackEndFn(torch.autograd.Function):
         last = rows[:, T, : 2 * F].reshape(B, F, 2).permute(0, 2, 1)              # [B, 2, F]
         new_ibuf = last.reshape(B, 1, 2 * F, 1).contiguous()
         if train:
-            ctx.save_for_backward(yp, dw, w_ana)
+            ctx.save_for_backward(yp, dw, w_ana, db)
             ctx.dims = (B, T, F, Cc, win, hop)
         ctx.mark_non_differentiable(new_dbuf, new_ibuf)
         return wave.view(B, 1, hop * T), new_dbuf, new_ibuf
 
     @staticmethod
     def backward(ctx, dwave, _d1, _d2):
-        yp, dw, w_ana = ctx.saved_tensors
+        yp, dw, w_ana, db = ctx.saved_tensors
         B, T, F, Cc, win, hop = ctx.dims
         dev = dwave.device
         dframes = ops.overlap_add_bwd(dwave.contiguous().view(B, hop * T), B, T, win, hop)
@@ -548,14 +542,13 @@ class BackEndFn(torch.autograd.Function):
         _, s_r = dense(B * (T + 1), NSPEC)
         ops.linear(dframes, w_ana, None, drows, g, s_f, s_r, win, NSPEC)
         dspec = drows[:, 1:, : 2 * F].contiguous()                                # [B,T,F,2]
-        dy = ops.deconv_bwd_data(dspec, dw.contiguous(), B, T, F, Cc)
-        P = B * T * F
-        d_wk = torch.zeros(2, 9 * Cc, device=dev, dtype=torch.float32)
+        dy = ops.deconv_bwd_data(dspec, dw, B, T, F, Cc)
+        gt = _GradTargets()
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
-        d_db = torch.zeros(2, device=dev, dtype=torch.float32)
-        ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, d_wk, kseg=3 * Cc, is_seg=(F + 2) * Cc, dbias=d_db)
-        d_dw = d_wk.view(2, 3, 3, Cc).permute(3, 0, 1, 2).flip(2, 3).contiguous()
-        return dy, None, d_dw, d_db, None, None, None
+        # dW[o][(a*3 + d)*C + c] lands in the parameter's own [c, o, 2-a, 2-d] layout
+        ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, gt("dw", dw), kseg=3 * Cc, is_seg=(F + 2) * Cc,
+                  dbias=gt("db", db), wview=L.WView.make(9, 18, off=8, kmod=Cc, sk_hi=-1, nvalid=2))
+        return dy, None, gt["dw"], gt["db"], None, None, None, None, None
 
 
 class SnrlpLossFn(torch.autograd.Function):
@@ -563,6 +556,8 @@ class SnrlpLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, est, gt, neg_weight):
+        if est.shape != gt.shape:
+            raise ValueError(f"SNRLP: estimate {tuple(est.shape)} and target {tuple(gt.shape)} differ in shape")
         B = est.shape[0]
         e = est.reshape(B, -1).contiguous()
         t = gt.reshape(B, -1).contiguous()

@@ -18,6 +18,8 @@ import torch.nn as nn
 import torch.nn.functional as tF
 
 from . import functional as Fn
+from . import _lib as L
+from .forms import WeightForms
 
 
 def stft_filter_bank(n_fft, stride):
@@ -158,6 +160,27 @@ class _NetBase(nn.Module):
         if self.nfft % 16 or (self.nfft // 2 + 1) * 2 > Fn.NSPEC:
             raise NotImplementedError("n_fft must be a multiple of 16 and <= 302")
 
+    # ---- kernel-layout weight forms (one arena, one refresh launch per optimiser step: forms.py) ----
+    def _weight_forms(self):
+        wf = getattr(self, "_wforms", None)
+        if wf is not None:
+            return wf
+        wf = WeightForms()
+        tg, C, V = self.tfgridnet, self.embed_dim, L.WView.make
+        wf.add("front_w", tg.conv[0].weight, V(self.n_feat * 9, 9, kmod=Fn.ZC, sk_hi=1, kvalid=self.n_feat), C, 9 * Fn.ZC)
+        wf.add("back_w", tg.deconv.weight, V(9, 18, off=8, kmod=C, sk_hi=-1, nvalid=2), 16, 9 * C)
+        wf.add("back_b", tg.deconv.bias, V(1, 0, nvalid=2), 16, 1)
+        if self.conv_lstm:
+            d = self.lstm_down
+            for i, blk in enumerate(tg.blocks):
+                wf.add(f"wc{i}", blk.conv.weight, V(C * d, d, kmod=C, sk_hi=1), C, d * C)            # [co][j*C + ci]
+                wf.add(f"wd{i}", blk.deconv.weight, V(d, C * d, nmod=C, sn_hi=1), d * C, 2 * self.H)   # [j*C + c][h]
+                wf.add(f"bd{i}", blk.deconv.bias, V(1, 0, nmod=C, sn_hi=0), d * C, 1)                  # bias[n % C]
+                wf.add(f"wdT{i}", blk.deconv.weight, V(C * d, d, kmod=C, sk_hi=1), 2 * self.H, d * C)  # [h][j*C + c]
+                wf.add(f"wcT{i}", blk.conv.weight, V(d, C * d, nmod=C, sn_hi=1), d * C, C)             # [j*C + ci][co]
+        object.__setattr__(self, "_wforms", wf)
+        return wf
+
     # ---- state (reference layout) ----
     def init_buffers(self, batch_size, device):
         F_, C = self.n_freqs, self.embed_dim
@@ -194,11 +217,12 @@ class _NetBase(nn.Module):
         st = input_state
         Fn.GRAD_MODE = torch.is_grad_enabled()      # BPTT records are written only when a backward pass can follow
         e = self._embed(inputs.get("dis_embed"))
+        wf = self._weight_forms().refresh()
         ln = tg.conv[1] if self.use_first_ln else None
         y, st["conv_buf"] = Fn.FrontEndFn.apply(
             x.float(), tg.enc.filterbank._filters, tg.conv[0].weight, tg.conv[0].bias,
             ln.weight if ln is not None else None, ln.bias if ln is not None else None, st["conv_buf"],
-            self.use_first_ln, self.stft_chunk_size)
+            self.use_first_ln, self.stft_chunk_size, wf["front_w"])
         gb = st["gridnet_bufs"]
         for i, blk in enumerate(tg.blocks):
             y = self._film(y, e, i)
@@ -207,7 +231,8 @@ class _NetBase(nn.Module):
                 y = Fn.IntraConvFn.apply(y, blk.conv.weight, blk.conv.bias, blk.act.weight, blk.norm.norm.weight,
                                          blk.norm.norm.bias, *_lstm_dir(rnn, False), *_lstm_dir(rnn, True),
                                          blk.deconv.weight, blk.deconv.bias, self.lstm_down,
-                                         self.flavour == "optim")
+                                         self.flavour == "optim", wf[f"wc{i}"], wf[f"wd{i}"], wf[f"bd{i}"],
+                                         wf[f"wdT{i}"], wf[f"wcT{i}"])
             else:
                 y = Fn.IntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
                                           *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
@@ -226,7 +251,7 @@ class _NetBase(nn.Module):
                                                                  self.local_atten_len)
         out, st["deconv_buf"], st["istft_buf"] = Fn.BackEndFn.apply(
             y, tg.dec.filterbank._filters, tg.deconv.weight, tg.deconv.bias, st["deconv_buf"], st["istft_buf"],
-            self.stft_chunk_size)
+            self.stft_chunk_size, wf["back_w"], wf["back_b"])
         if mod:
             out = out[..., :-mod]
         return {"output": out, "next_state": st}

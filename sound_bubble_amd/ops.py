@@ -235,6 +235,39 @@ _ABSMAX_HINTS = {}
 ABSMAX_HINTS = os.environ.get("SB_NO_ABSMAX_HINTS", "0") != "1"
 
 
+class _ScalarSlots:
+    """Zeroed one-float device scalars (absmax_out targets) cut from one buffer that is re-zeroed with ONE fill per train
+    step, instead of a torch.zeros(1) launch per use (40-80 fills per step)."""
+    N = 256
+
+    def __init__(self):
+        self.buf, self.i = {}, {}
+
+    def get(self, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        b = self.buf.get(key)
+        if b is None or self.i[key] >= self.N or torch.cuda.is_current_stream_capturing():
+            b = self.buf[key] = torch.zeros(self.N, device=dev, dtype=torch.float32)
+            self.i[key] = 0
+        k = self.i[key]
+        self.i[key] = k + 1
+        return b[k:k + 1]
+
+    def new_step(self):
+        """every slot handed out so far is dead (the hints table is cleared with it): start over on fresh zeros"""
+        for key, b in self.buf.items():
+            if self.i[key]:
+                self.buf[key] = torch.zeros_like(b)       # a new buffer: slots still referenced by saved tensors stay valid
+                self.i[key] = 0
+
+
+_SLOTS = _ScalarSlots()
+
+
+def zero_scalar(dev):
+    return _SLOTS.get(dev)
+
+
 def absmax_hint_put(t, gmax):
     if ABSMAX_HINTS:
         if len(_ABSMAX_HINTS) > 64:
@@ -244,6 +277,7 @@ def absmax_hint_put(t, gmax):
 
 def absmax_hints_clear():
     _ABSMAX_HINTS.clear()
+    _SLOTS.new_step()
 
 
 def absmax_or_hint(x):
@@ -470,7 +504,7 @@ def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=N
     a.out, a.partials = _p(out), _p(partials)
     gm = None
     if hint and ABSMAX_HINTS:          # out is the dy of the next backward recurrence: measure max |out| on the way
-        gm = torch.zeros(1, device=dev, dtype=torch.float32)
+        gm = zero_scalar(dev)
         a.absmax_out = _p(gm)
     L.check(lib.sb_ln_bwd(C.byref(a), _stream()), "sb_ln_bwd")
     if gm is not None:
@@ -542,7 +576,7 @@ def dense(P, ld):
 
 def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=None, is_seg=0, in2=None, ld2=0,
           in2_off=0, shift2=0, K2=0, dW2=None, seg_len=None, skip_first=0, skip_last=0, dbias=None, dbias2=None,
-          transpose_out=False, perm_k=0, perm_n=0, bias_mod=0):
+          transpose_out=False, perm_k=0, perm_n=0, bias_mod=0, wview=None):
     """dW[N,K] += sum_p g[p,:N]^T in(p,:K);  dW2[N,K2] += sum_p g^T in2[p*ld2+shift2 : +K2] (segment-masked);
     dbias (+dbias2) += column sums of g.  One pass over g."""
     lib = L.load()
@@ -567,6 +601,8 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     a.skip_first, a.skip_last = skip_first, skip_last
     a.transpose_out = 1 if transpose_out else 0
     a.perm_k, a.perm_n, a.bias_mod = perm_k, perm_n, bias_mod     # native-layout destinations (see the header)
+    if wview is not None:                                         # ... general form: a weight view over dW's tensor
+        a.wv = wview
     a.dW, a.dW2, a.dbias, a.dbias2, a.scratch = _p(dW, "dW"), _p(dW2), _p(dbias), _p(dbias2), _p(scratch)
     L.check(lib.sb_wgrad(C.byref(a), _stream()), "sb_wgrad")
 
@@ -601,7 +637,7 @@ def film_bwd(x, w, dy):
     dx = torch.empty_like(x)
     dw = torch.zeros(B_, F_, Cc, device=x.device, dtype=torch.float32)
     db = torch.zeros_like(dw)
-    gm = torch.zeros(1, device=x.device, dtype=torch.float32) if ABSMAX_HINTS else None   # dx is a next dy
+    gm = zero_scalar(x.device) if ABSMAX_HINTS else None   # dx is a next dy
     L.check(L.load().sb_film_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), B_, T_, F_, Cc, _p(gm), _stream()),
             "sb_film_bwd")
     if gm is not None:

@@ -9,6 +9,7 @@ one process per GPU, identical replicas, ONE all-reduce over a single flat fp32 
 import torch
 
 from . import ops
+from .forms import bump_weight_epoch
 
 
 class FlatBucket:
@@ -30,6 +31,7 @@ class FlatBucket:
             self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + p.numel()].view(p.shape)
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            p._sb_flat_grad = True          # functional._GradTargets: the HIP reductions may accumulate into .grad directly
         self.offsets = offs
         self.n_params = n
 
@@ -62,6 +64,7 @@ class FusedAdam:
             ops.sumsq(b.grad, self.sumsq)
         ops.adam_step(b.flat, b.grad, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.step_count,
                       gscale=1.0 / world_size, clip=clip, sumsq_buf=self.sumsq)
+        bump_weight_epoch()       # the kernel wrote the parameters behind torch's version counters: weight forms are stale
 
     def state_dict(self):
         """torch.optim.Adam.state_dict() layout (what the reference's dump_state stores under 'optimizer',
@@ -141,6 +144,7 @@ def broadcast_replica(bucket, optim=None, src=0):
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
     _broadcast(bucket.flat, src)
+    bump_weight_epoch()
     if optim is not None:
         _broadcast(optim.m, src)
         _broadcast(optim.v, src)
