@@ -179,6 +179,9 @@ typedef struct {
   int accumulate;                           /* out += instead of out = (EPI_NONE/RES only) */
   float* absmax_out;                        /* optional (EPI_NONE/RES): *absmax_out = max(*absmax_out, max |out|), the
                                                scalar sb_lstm_bwd_rec wants as gmax; zero it before the call */
+  int mma;   /* 0: fp32-input MFMA (exact fma chain); 1: fp16 matrix pipe with hi+lo split operands, 3 products per MAC
+                (fp32-class, dropped term <= 2^-22) -- for the long-K narrow layers: N <= 32, K = 288 or 144, EPI_NONE /
+                EPI_RES / EPI_LN (the 3x3 front-end convolution, the output transposed convolution) */
 } sb_linear_args;
 int sb_linear_fwd(const sb_linear_args* a, void* stream);
 /* number of workgroups sb_linear_fwd launches for P positions (size of `partials`) */
@@ -213,6 +216,12 @@ typedef struct {
      dW[wv-address(n, k)] of the parameter's gradient in its native layout (see sb_wview), and dbias[n % bias_mod] only
      for n < wv.nvalid. */
   sb_wview wv;
+  const float* gmax;
+  int mma;   /* 0: fp32-input MFMA; 1: fp16 matrix pipe, both operands fp16 hi + lo, 3 products per MAC (fp32-class) --
+                gmax (nullable; a device scalar max |g|, e.g. from sb_absmax) makes the kernel scale g by the power of two
+                2^-ceil(log2 *gmax) before the fp16 split and the sums back afterwards: gradients of 1e-7 would otherwise
+                underflow fp16.  Single fp32 source, N <= 32 padded to whole 16-row tiles in g (ldg >= 16 * ceil(N/16)), K = 3 segments of
+                96 or 48 columns (the 3x3 convolutions) */
 } sb_wgrad_args;
 int sb_wgrad(const sb_wgrad_args* a, void* stream);
 int sb_wgrad_grid(int64_t positions);

@@ -64,7 +64,7 @@ class LinearArgs(C.Structure):
                 ("res", c_fp), ("rs_b", i64), ("rs_t", i64), ("rs_f", i64),
                 ("prelu_a", c_fp), ("ln_g", c_fp), ("ln_b", c_fp),
                 ("aux_in", c_fp), ("aux_out", c_fp), ("partials", c_fp), ("accumulate", C.c_int),
-                ("absmax_out", c_fp)]
+                ("absmax_out", c_fp), ("mma", C.c_int)]
 
 
 class WViewJob(C.Structure):
@@ -78,7 +78,7 @@ class WgradArgs(C.Structure):
                 ("in2", c_fp), ("ld2", i64), ("shift2", i64), ("K2", C.c_int),
                 ("seg_len", C.c_int), ("skip_first", C.c_int), ("skip_last", C.c_int),
                 ("transpose_out", C.c_int), ("dW", c_fp), ("dW2", c_fp), ("dbias", c_fp), ("dbias2", c_fp),
-                ("scratch", c_fp), ("in_f16", C.c_int), ("perm_k", C.c_int), ("perm_n", C.c_int), ("bias_mod", C.c_int), ("wv", WView)]
+                ("scratch", c_fp), ("in_f16", C.c_int), ("perm_k", C.c_int), ("perm_n", C.c_int), ("bias_mod", C.c_int), ("wv", WView), ("gmax", c_fp), ("mma", C.c_int)]
 
 
 class LstmStreamArgs(C.Structure):

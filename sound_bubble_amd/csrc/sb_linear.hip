@@ -253,6 +253,179 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp16x3 form of the position-wise GEMM for the long-K, narrow-N layers (the 3x3 front-end convolution K = 9*32, the
+// output transposed convolution K = 9*C; sb_linear_args.mma == 1).  On the fp32-input MFMA these ran at 36-46 % matrix
+// pipe busy and 0.4 of the fp32 peak (profiles/r02_pmc_sq_*.json); here every fp32 operand is split into fp16 hi + lo
+// (11 + 11 bits) and the product evaluated as lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16 -- the same fp32-class
+// arithmetic as the recurrent kernels (dropped term <= 2^-22), one sixth of the matrix-pipe time.  Weights are
+// register-resident (A operand, split once); the activations of a whole 16-position tile are fetched up front
+// (KC * 32 bytes per lane in flight) and split as they arrive.
+typedef _Float16 lh16x8 __attribute__((ext_vector_type(8)));
+struct LSplitH { lh16x8 hi, lo; };
+SB_DEVINL LSplitH lsplit8(const f32x4 lo4, const f32x4 hi4) {
+  LSplitH s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const _Float16 h0 = (_Float16)lo4[k], h1 = (_Float16)hi4[k];
+    s.hi[k] = h0; s.hi[4 + k] = h1;
+    s.lo[k] = (_Float16)(lo4[k] - (float)h0); s.lo[4 + k] = (_Float16)(hi4[k] - (float)h1);
+  }
+  return s;
+}
+
+template <int NT, int KC, int EPI>
+__global__ __launch_bounds__(256) void linear16_kernel(sb_linear_args a, int64_t P) {
+  static_assert(EPI == SB_EPI_NONE || EPI == SB_EPI_RES || EPI == SB_EPI_LN, "fp16x3 form: bias / residual / LayerNorm");
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
+  constexpr int N = NT * 16;
+  const int K = a.K;
+  // this lane's K offsets: chunk m covers k = 32 m + 8 q .. + 7 (kseg is a multiple of 8, so the 8 values share a segment)
+  int64_t koff[KC];
+  bool kval[KC];
+#pragma unroll
+  for (int m = 0; m < KC; ++m) {
+    const int k0 = 32 * m + 8 * q;
+    kval[m] = k0 < K;
+    const int seg = kval[m] ? k0 / a.kseg : 0;
+    koff[m] = kval[m] ? (int64_t)seg * a.is_seg + (k0 - seg * a.kseg) : 0;
+  }
+  // A[i = feature 16 nt + j][k = 32 m + 8 q + kk], split once.  Register-resident while it fits (NT * KC <= 9: 72 VGPRs);
+  // beyond that (C = 32, K = 288: 144 VGPRs, one wave per SIMD) it lives in LDS in lane order -- every lane re-reads its
+  // own 16 bytes per term and chunk, conflict-free.
+  constexpr bool ALDS = NT * KC > 9;
+  __shared__ __attribute__((aligned(16))) lh16x8 Al[ALDS ? 2 * NT * KC * 64 : 1];
+  LSplitH A[ALDS ? 1 : NT][ALDS ? 1 : KC];
+  if constexpr (ALDS) {
+    for (int e = tid; e < NT * KC * 64; e += 256) {
+      const int ln = e & 63, mm = (e >> 6) % KC, nt = (e >> 6) / KC;
+      const int k0 = 32 * mm + 8 * (ln >> 4);
+      const float* wr = a.w + (size_t)(16 * nt + (ln & 15)) * K + k0;
+      const f32x4 z = zero4();
+      const LSplitH t = lsplit8(k0 < K ? ld4(wr) : z, k0 < K ? ld4(wr + 4) : z);
+      Al[(nt * KC + mm) * 64 + ln] = t.hi;
+      Al[((NT + nt) * KC + mm) * 64 + ln] = t.lo;
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < KC; ++m) {
+        const float* wr = a.w + (size_t)(16 * nt + j) * K + 32 * m + 8 * q;
+        const f32x4 z = zero4();
+        A[nt][m] = lsplit8(kval[m] ? ld4(wr) : z, kval[m] ? ld4(wr + 4) : z);
+      }
+  }
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = a.bias ? ld4(a.bias + 16 * nt + 4 * q) : zero4();
+
+  float amax = 0.f;
+  const int64_t ntiles = (P + 63) / 64;
+  const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
+  const bool out_dense = dense_strides(a.T, a.F, a.os_b, a.os_t, a.os_f);
+  const bool res_dense = !a.res || dense_strides(a.T, a.F, a.rs_b, a.rs_t, a.rs_f);
+  const bool all_dense = in_dense && out_dense && res_dense;
+  // XCD-aware tile order: a 3x3 window re-reads the rows of its neighbours in t, and workgroup i runs on XCD i % 8, each
+  // with its own L2 -- so every XCD walks a CONTIGUOUS eighth of the position range (its workgroups on adjacent tiles)
+  // instead of every eighth tile (which made all eight L2s fetch every row: 3x the compulsory reads in the PMC counters).
+  const int xcd = blockIdx.x & 7, xl = blockIdx.x >> 3, nxl = (gridDim.x + 7 - xcd) >> 3;
+  const int64_t tpx = (ntiles + 7) / 8;
+  for (int64_t tl = xl; tl < tpx; tl += nxl) {
+    const int64_t tile = (int64_t)xcd * tpx + tl;
+    if (tile >= ntiles) break;
+    const int64_t p_raw = tile * 64 + 16 * w + j;
+    const bool valid = p_raw < P;
+    const int64_t p = valid ? p_raw : P - 1;          // out-of-range lanes recompute the last position and skip the store
+    Pos3 ps = {0, 0, 0};
+    if (!all_dense) ps = split_pos((unsigned)p, a.T, a.F);
+    const float* src = a.in + (in_dense ? p * a.is_f : off3(ps, a.is_b, a.is_t, a.is_f));
+    f32x4 b0[KC], b1[KC];
+#pragma unroll
+    for (int m = 0; m < KC; ++m) { b0[m] = ld4(src + koff[m]); b1[m] = ld4(src + koff[m] + 4); }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = bias[nt];
+    int alane = lane;
+    if constexpr (ALDS) asm volatile("" : "+v"(alane));      // keeps the (tile-invariant) LDS reads inside the tile loop
+#pragma unroll
+    for (int m = 0; m < KC; ++m) {
+      const f32x4 z = zero4();
+      const LSplitH B = lsplit8(kval[m] ? b0[m] : z, kval[m] ? b1[m] : z);
+      lh16x8 ah[NT], al[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (ALDS) { ah[nt] = Al[(nt * KC + m) * 64 + alane]; al[nt] = Al[((NT + nt) * KC + m) * 64 + alane]; }
+        else { ah[nt] = A[nt][m].hi; al[nt] = A[nt][m].lo; }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nt], B.hi, acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt], B.lo, acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt], B.hi, acc[nt], 0, 0, 0);
+    }
+    // ---------------- epilogue: lane holds features 16nt+4q..+3 of position p (as in linear_kernel) ----------------
+    const int64_t ooff = out_dense ? p * a.os_f : off3(ps, a.os_b, a.os_t, a.os_f);
+    if constexpr (EPI == SB_EPI_RES) {
+      const int64_t roff = res_dense ? p * a.rs_f : off3(ps, a.rs_b, a.rs_t, a.rs_f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] += ld4(a.res + roff + 16 * nt + 4 * q);
+    } else if constexpr (EPI == SB_EPI_LN) {
+      if (valid && a.aux_out)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) st4(a.aux_out + p * N + 16 * nt + 4 * q, acc[nt]);
+      float sm = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) sm += acc[nt][0] + acc[nt][1] + acc[nt][2] + acc[nt][3];
+      const float mean = quad_sum(sm) * (1.0f / N);
+      float sq = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc[nt][r] - mean; sq += d * d; }
+      const float rstd = 1.0f / sqrtf(quad_sum(sq) * (1.0f / N) + 1e-5f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 g4 = ld4(a.ln_g + 16 * nt + 4 * q), b4 = ld4(a.ln_b + 16 * nt + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nt][r] = (acc[nt][r] - mean) * rstd * g4[r] + b4[r];
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = 16 * nt + 4 * q;
+        float* o = a.out + ooff + n0;
+        if (n0 + 4 <= a.n_valid) {
+          if (a.accumulate) { acc[nt] += ld4(o); st4(o, acc[nt]); } else st4(o, acc[nt]);
+          if constexpr (EPI != SB_EPI_LN)
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[nt][0]), fabsf(acc[nt][1]))), fmaxf(fabsf(acc[nt][2]), fabsf(acc[nt][3])));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < a.n_valid) {
+              const float v = a.accumulate ? o[r] + acc[nt][r] : acc[nt][r];
+              o[r] = v;
+              amax = fmaxf(amax, fabsf(v));
+            }
+        }
+      }
+    }
+  }
+  if constexpr (EPI != SB_EPI_LN) {
+    if (a.absmax_out) {
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      __shared__ float wm[4];
+      if (lane == 0) wm[w] = amax;
+      __syncthreads();
+      if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out),
+                              __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // dW[n, k] = sum_p g(p, n) * [in1(p, :K1) | in2(p, :K2)][k]  (+ column sums of g = bias gradients).
 // Used for the narrow layers (N <= 80: Linear / Conv1d / ConvTranspose1d / 3x3 convs); the 256-row LSTM
 // gradients have their own kernel (sb_lstm_stream.hip).  Every wave holds ALL n-blocks and walks its own
@@ -471,6 +644,132 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(sb_wgrad_args a, int64_
   }
 }
 
+// fp16x3 form of the wide-load weight-gradient kernel (sb_wgrad_args.mma == 1): 32 positions per MFMA
+// (v_mfma_f32_16x16x32_f16), both operands split into fp16 hi + lo, products lo*hi + hi*lo + hi*hi (fp32-class, dropped
+// term <= 2^-22).  (One fp16 term for the activations was measured first: 2e-4 on random data but 2e-3 on the real
+// front-end convolution gradient at full size -- a weight gradient is a heavily cancelling sum, which amplifies the
+// 2^-12 per-product rounding.)  On the fp32-input MFMA the K = 288 convolutions' weight gradients ran at 42-52 %
+// matrix-pipe busy (issue-stalled on the 8-pass fp32 MFMA); this form issues 3 x 4-pass MFMAs per 32 positions and tile
+// instead of 8 x 8-pass ones.
+template <int NTW, int NSEG, int TS>
+SB_DEVINL void wgrad16_body(const sb_wgrad_args& a, int64_t P) {
+  constexpr int KT = NSEG * TS;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
+  f32x4 acc[NTW][KT];
+  float csum[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    csum[nt] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = zero4();
+  }
+  const int64_t ntiles = (P + 31) / 32, tstride = (int64_t)gridDim.x * 4;
+  const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
+  // Gradients are tiny (1e-6 .. 1e-9 here) and fp16 underflows below 6e-8: g is scaled by S = 2^-ceil(log2 max|g|) before
+  // the split (exact) and the sums by 1/S at the end -- the scaled-fp16 device of the LSTM backward (sb_lstm_bwd_args.gmax).
+  float gS = 1.0f;
+  if (a.gmax) { const float m = a.gmax[0]; if (m > 0.f && m < 3.0e38f) gS = exp2f(-ceilf(log2f(m))); }
+  const float invS = 1.0f / gS;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += tstride) {
+    Pos3 base = {0, 0, 0};
+    if (!in_dense) base = split_pos((unsigned)(tile * 32), a.T, a.F);          // wave-uniform: once per tile
+    int64_t ioff[8];
+    bool ok[8];
+    float gv[NTW][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t p_raw = tile * 32 + 8 * q + r;
+      ok[r] = p_raw < P;
+      const int64_t p = ok[r] ? p_raw : P - 1;                                 // clamped address + select
+      ioff[r] = in_dense ? p * a.is_f : off3_delta(base, (unsigned)(p - tile * 32), a.T, a.F, a.is_b, a.is_t, a.is_f);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const TileGroup tg = tile_group(nt, NTW);
+        if (tg.e == 0) {
+          float v[4];
+          if (tg.G == 4) load_group<false, 4>(a.g, p * a.ldg + 16 * tg.gs + 4 * j, v);
+          else if (tg.G == 2) load_group<false, 2>(a.g, p * a.ldg + 16 * tg.gs + 2 * j, v);
+          else load_group<false, 1>(a.g, p * a.ldg + (16 * tg.gs + j < a.N ? 16 * tg.gs + j : 0), v);   // N < 16: masked
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < tg.G) gv[tg.gs + e][r] = (ok[r] && 16 * tg.gs + tg.G * j + e < a.N) ? v[e] * gS : 0.f;
+        }
+      }
+    }
+    lh16x8 ghi[NTW], glo[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        csum[nt] += gv[nt][r];
+        const _Float16 h = (_Float16)gv[nt][r];
+        ghi[nt][r] = h;
+        glo[nt][r] = (_Float16)(gv[nt][r] - (float)h);
+      }
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+      lh16x8 bh[TS], bl[TS];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+          const TileGroup tg = tile_group(t, TS);
+          if (tg.e == 0) {
+            float v[4];
+            const int64_t o = ioff[r] + (int64_t)sg * a.is_seg + 16 * tg.gs;
+            if (tg.G == 4) load_group<false, 4>(a.in, o + 4 * j, v);
+            else if (tg.G == 2) load_group<false, 2>(a.in, o + 2 * j, v);
+            else load_group<false, 1>(a.in, o + j, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < tg.G) {
+                const float x = ok[r] ? v[e] : 0.f;
+                const _Float16 h = (_Float16)x;
+                bh[tg.gs + e][r] = h;
+                bl[tg.gs + e][r] = (_Float16)(x - (float)h);
+              }
+          }
+        }
+#pragma unroll
+      for (int t = 0; t < TS; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          acc[nt][sg * TS + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(glo[nt], bh[t], acc[nt][sg * TS + t], 0, 0, 0);
+          acc[nt][sg * TS + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ghi[nt], bl[t], acc[nt][sg * TS + t], 0, 0, 0);
+          acc[nt][sg * TS + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ghi[nt], bh[t], acc[nt][sg * TS + t], 0, 0, 0);
+        }
+    }
+  }
+  const int Ktot = a.K;
+  float* part = a.scratch + ((size_t)blockIdx.x * 4 + w) * ((size_t)a.N * Ktot + a.N);
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const TileGroup ng = tile_group(nt, NTW);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const TileGroup kg = tile_group(kt % TS, TS);
+      const int k = (kt / TS) * a.kseg + 16 * kg.gs + kg.G * j + kg.e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * ng.gs + ng.G * (4 * q + r) + ng.e;
+        if (n < a.N) part[(size_t)n * Ktot + k] = acc[nt][kt][r] * invS;
+      }
+    }
+    const float cs = quad_sum(csum[nt]);
+    const int nb = 16 * ng.gs + ng.G * j + ng.e;
+    if (q == 0 && nb < a.N) part[(size_t)a.N * Ktot + nb] = cs * invS;
+  }
+}
+
+template <int NTW, int NSEG, int TS>
+__global__ __launch_bounds__(256) void wgrad16_kernel(sb_wgrad_args a, int64_t P) { wgrad16_body<NTW, NSEG, TS>(a, P); }
+// N = 32 (144 accumulator registers): capped at 256 registers so that two waves share a SIMD (uncapped it took 292 and
+// ran alone: 645 us against 313 us for the fp32 kernel it replaces)
+template <int NSEG, int TS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad16_n32_kernel(sb_wgrad_args a, int64_t P) {
+  wgrad16_body<2, NSEG, TS>(a, P);
+}
+
 // out (+)= sum over partial rows; 2-D grid (columns x row-chunks) + atomics so that the reduction of
 // 512 x 24 K partials is itself a wide, short kernel.  Columns route to dW1 / dW2 / the bias gradients.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int rows, int N, int K1,
@@ -623,6 +922,20 @@ extern "C" int sb_linear_fwd(const sb_linear_args* ap, void* stream) {
   if (a.epi == SB_EPI_LNBWD && a.partials)
     (void)hipMemsetAsync(a.partials, 0, (size_t)grid * (2 * a.N + 1) * sizeof(float), st);
   int rc;
+  if (a.mma == 1) {
+    // fp16x3 form: N <= 32, K = 9 * 32 or 9 * 16 (padded to 160), kseg | 8, bias / residual / LayerNorm epilogues
+    const int kc = (a.K + 31) / 32;
+    if (a.N > 32 || (kc != 9 && kc != 5) || a.kseg % 8 || a.K % 16 || a.epi > SB_EPI_LN || a.epi == SB_EPI_PRELU) return -1004;
+#define SB_L16(NT_, KC_, EP_) hipLaunchKernelGGL((linear16_kernel<NT_, KC_, EP_>), dim3(grid), dim3(256), 0, st, a, P)
+#define SB_L16E(NT_, KC_) do { if (a.epi == SB_EPI_LN) SB_L16(NT_, KC_, SB_EPI_LN); else if (a.epi == SB_EPI_RES) SB_L16(NT_, KC_, SB_EPI_RES); \
+                              else SB_L16(NT_, KC_, SB_EPI_NONE); } while (0)
+    if (a.N == 16) { if (kc == 9) SB_L16E(1, 9); else SB_L16E(1, 5); }
+    else { if (kc == 9) SB_L16E(2, 9); else SB_L16E(2, 5); }
+#undef SB_L16E
+#undef SB_L16
+    SB_CHECK_LAUNCH();
+    return 0;
+  }
   switch (a.N / 16) {
     case 1: rc = launch_linear<1>(a, P, st); break;
     case 2: rc = launch_linear<2>(a, P, st); break;
@@ -666,6 +979,21 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
                     a.is_t % 4 == 0 && a.is_f % 4 == 0 && a.is_seg % 4 == 0 && a.ldg % 4 == 0 &&
                     (reinterpret_cast<uintptr_t>(a.in) % (4 * es)) == 0 && (reinterpret_cast<uintptr_t>(a.g) % 16) == 0;
   bool launched = false;
+  // fp16 matrix-pipe form for the K = 288 / 144 convolutions (mma == 1): single source, whole segments of 6 or 3 tiles
+  if (a.mma == 1) {
+    const bool ok16 = kt2 == 0 && a.K % 16 == 0 && ts > 0 && kt1 % ts == 0 && a.is_b % 4 == 0 && a.is_t % 4 == 0 &&
+                      a.is_f % 4 == 0 && a.is_seg % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) % 16) == 0 &&
+                      ((a.N % 16 == 0 && a.ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(a.g) % 16) == 0) || ntw == 1);
+    if (!ok16 || a.in_f16 || ntw > 2) return -1004;
+#define SB_W16(NTW_, NSEG_, TS_) \
+    if (!launched && ntw == NTW_ && kt1 == NSEG_ * TS_ && ts == TS_) { \
+      hipLaunchKernelGGL((wgrad16_kernel<NTW_, NSEG_, TS_>), grid, block, 0, st, a, P); launched = true; }
+    SB_W16(1, 3, 6) SB_W16(1, 3, 3)
+#undef SB_W16
+    if (!launched && ntw == 2 && kt1 == 18 && ts == 6) {
+      hipLaunchKernelGGL((wgrad16_n32_kernel<3, 6>), grid, block, 0, st, a, P); launched = true; }
+    if (!launched) return -1004;
+  }
 #define SB_WW(NTW_, KT1_, TS_, H16_) \
   if (!launched && wide && ntw == NTW_ && kt1 == KT1_ && ts == TS_ && (a.in_f16 != 0) == H16_) { \
     hipLaunchKernelGGL((wgrad_wide_kernel<NTW_, KT1_, TS_, H16_>), grid, block, 0, st, a, P); launched = true; }

@@ -452,7 +452,7 @@ class FrontEndFn(torch.autograd.Function):
         s_out = (T * F * Cc, F * Cc, Cc)
         ops.linear(zp, wk, conv_b, x0, (B, T, F), s_in, s_out, 9 * ZC, Cc, kseg=3 * ZC, is_seg=(F + 2) * ZC,
                    epi=L.EPI_LN if use_ln else L.EPI_NONE, ln_g=ln_g if use_ln else None,
-                   ln_b=ln_b if use_ln else None, aux_out=pre)
+                   ln_b=ln_b if use_ln else None, aux_out=pre, f16x3=True)
         if train:
             ctx.save_for_backward(zp, pre, ln_g, conv_w, conv_b, ln_b)
             ctx.dims = (B, T, F, Cc, nfeat, bool(use_ln))
@@ -467,14 +467,15 @@ class FrontEndFn(torch.autograd.Function):
         dx0 = dx0.contiguous()
         gt = _GradTargets()
         if use_ln:
-            dpre, _, _, _ = ops.ln_bwd(dx0.view(P, 1, Cc), pre, ln_g, d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b))
+            dpre, _, _, _ = ops.ln_bwd(dx0.view(P, 1, Cc), pre, ln_g, d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
+                                       hint=True)          # max |dpre| measured on the way (the weight gradient's fp16 scale)
         else:
             dpre = dx0.view(P, Cc)
             gt.ret["ln_g"] = gt.ret["ln_b"] = None
         s_in = ((T + 2) * (F + 2) * ZC, (F + 2) * ZC, ZC)
         # dW[co][(a*3 + d)*32 + ci] lands in conv_w's own [co, ci, a, d] layout (and in the flat bucket when it exists)
         ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, gt("conv_w", conv_w), kseg=3 * ZC, is_seg=(F + 2) * ZC,
-                  dbias=gt("conv_b", conv_b), wview=L.WView.make(nfeat * 9, 9, kmod=ZC, sk_hi=1, kvalid=nfeat))
+                  dbias=gt("conv_b", conv_b), wview=L.WView.make(nfeat * 9, 9, kmod=ZC, sk_hi=1, kvalid=nfeat), f16=True)
         return None, None, gt["conv_w"], gt["conv_b"], gt["ln_g"], gt["ln_b"], None, None, None, None
 
 
@@ -516,7 +517,7 @@ class BackEndFn(torch.autograd.Function):
         # wk [16][(a*3 + d)*C + c] = dw[c, o, 2-a, 2-d] (rows 2..15 zero), bk [16]: kernel-layout forms (forms.WeightForms)
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
         ops.linear(yp, wk, bk, rows, (B, T, F), s_in, ((T + 1) * NSPEC, NSPEC, 2), 9 * Cc, 16, kseg=3 * Cc,
-                   is_seg=(F + 2) * Cc, n_valid=2, out_off=NSPEC)
+                   is_seg=(F + 2) * Cc, n_valid=2, out_off=NSPEC, f16x3=True)
         w_syn, w_ana = _istft_weights(dec_filters)
         frames = torch.empty(B, T + 1, win, device=dev, dtype=torch.float32)
         g, s_r = dense(B * (T + 1), NSPEC)
@@ -547,7 +548,7 @@ class BackEndFn(torch.autograd.Function):
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
         # dW[o][(a*3 + d)*C + c] lands in the parameter's own [c, o, 2-a, 2-d] layout
         ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, gt("dw", dw), kseg=3 * Cc, is_seg=(F + 2) * Cc,
-                  dbias=gt("db", db), wview=L.WView.make(9, 18, off=8, kmod=Cc, sk_hi=-1, nvalid=2))
+                  dbias=gt("db", db), wview=L.WView.make(9, 18, off=8, kmod=Cc, sk_hi=-1, nvalid=2), f16=True)
         return dy, None, gt["dw"], gt["db"], None, None, None, None, None
 
 

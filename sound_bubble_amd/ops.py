@@ -129,6 +129,10 @@ def _seg_scratch(a, geom, dev):
     return scratch
 
 
+# the 3x3 front-end convolution and the output transposed convolution on the fp16 matrix pipe with hi+lo split operands
+# (SB_LINEAR_FP32=1: the fp32-input MFMA as everywhere else in sb_linear.hip)
+LINEAR_F16X3 = os.environ.get("SB_LINEAR_FP32", "0") != "1"
+
 PHASE_TIMING_BUF = None   # developer hook: scratch for a -DSB_PHASE_TIMING build (scripts/phase_timing.py)
 
 
@@ -223,7 +227,14 @@ class DGates:
 
 def absmax(x):
     out = torch.empty(1, device=x.device, dtype=torch.float32)
-    L.check(L.load().sb_absmax(_p(x), x.numel(), _p(out), _stream()), "sb_absmax")
+    n = x.numel()
+    if n % 4:                       # the kernel reads 16-byte groups: the (rare) ragged tail goes through torch
+        flat = x.reshape(-1)
+        if n >= 4:
+            L.check(L.load().sb_absmax(_p(flat), n - n % 4, _p(out), _stream()), "sb_absmax")
+            return torch.maximum(out, flat[n - n % 4:].abs().max().reshape(1))
+        return flat.abs().max().reshape(1)
+    L.check(L.load().sb_absmax(_p(x), n, _p(out), _stream()), "sb_absmax")
     return out
 
 
@@ -523,7 +534,8 @@ def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=N
 
 def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None, is_seg=0, n_valid=None,
            epi=L.EPI_NONE, res=None, res_strides=None, prelu_a=None, ln_g=None, ln_b=None, aux_in=None,
-           aux_out=None, want_partials=False, accumulate=False, in_off=0, out_off=0, res_off=0, absmax_out=None):
+           aux_out=None, want_partials=False, accumulate=False, in_off=0, out_off=0, res_off=0, absmax_out=None,
+           f16x3=False):
     """out[p, :N] = epi(W[N,K] . in(p, :K) + bias).  grid = (B, T, F); strides in floats.
     N is chunked into <=128-wide launches when needed (not for LN epilogues).
     absmax_out (EPI_NONE / EPI_RES): zeroed [1] tensor that receives max |out| (the gmax of a following lstm_bwd_rec)."""
@@ -563,6 +575,7 @@ def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None,
             partials = torch.empty(g, 2 * N + 1, device=out.device, dtype=torch.float32)
             a.partials = _p(partials)
         a.accumulate = 1 if accumulate else 0
+        a.mma = 1 if (f16x3 and LINEAR_F16X3) else 0      # long-K narrow convolutions on the fp16 pipe (fp32-class split)
         if a.n_valid > 0:
             L.check(lib.sb_linear_fwd(C.byref(a), _stream()), "sb_linear_fwd")
         n0 += nc
@@ -576,7 +589,7 @@ def dense(P, ld):
 
 def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=None, is_seg=0, in2=None, ld2=0,
           in2_off=0, shift2=0, K2=0, dW2=None, seg_len=None, skip_first=0, skip_last=0, dbias=None, dbias2=None,
-          transpose_out=False, perm_k=0, perm_n=0, bias_mod=0, wview=None):
+          transpose_out=False, perm_k=0, perm_n=0, bias_mod=0, wview=None, f16=False, gmax=None):
     """dW[N,K] += sum_p g[p,:N]^T in(p,:K);  dW2[N,K2] += sum_p g^T in2[p*ld2+shift2 : +K2] (segment-masked);
     dbias (+dbias2) += column sums of g.  One pass over g."""
     lib = L.load()
@@ -603,6 +616,9 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     a.perm_k, a.perm_n, a.bias_mod = perm_k, perm_n, bias_mod     # native-layout destinations (see the header)
     if wview is not None:                                         # ... general form: a weight view over dW's tensor
         a.wv = wview
+    a.mma = 1 if (f16 and LINEAR_F16X3) else 0                    # 3x3 convolutions' dW on the fp16 pipe, hi+lo operands
+    if a.mma:
+        a.gmax = _p(gmax if gmax is not None else absmax_or_hint(g))   # power-of-two scale against fp16 underflow
     a.dW, a.dW2, a.dbias, a.dbias2, a.scratch = _p(dW, "dW"), _p(dW2), _p(dbias), _p(dbias2), _p(scratch)
     L.check(lib.sb_wgrad(C.byref(a), _stream()), "sb_wgrad")
 

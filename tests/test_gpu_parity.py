@@ -639,3 +639,50 @@ def test_fused_bptt_bidirectional_matches_two_kernel_backward(torch_gpu, C_, fus
     if fuse_lin:           # the Linear's weight gradient rides along (dy as a scaled fp16 term, h as fp16)
         assert rel_l2(ltg[0].cpu().numpy(), (dy.double().t() @ hs.double()).cpu().numpy()) < 1e-3
         assert rel_l2(ltg[1].cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("C_,kind", [(16, "front"), (32, "front"), (16, "back"), (32, "back")])
+def test_conv3x3_fp16x3_matrix_pipe_matches_fp32_mfma(torch_gpu, C_, kind, monkeypatch):
+    """sb_linear_args.mma = 1 / sb_wgrad_args.mma = 1: the 3x3 front-end convolution (K = 9*32, LayerNorm epilogue) and the
+    output transposed convolution (K = 9*C, 2 valid output rows) on the fp16 matrix pipe with hi+lo split operands, against
+    the fp32-input MFMA kernels and a float64 reference -- forward and weight gradient to fp32 rounding (the split drops
+    <= 2^-22)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops, _lib as L
+    torch.manual_seed(C_)
+    B, T, F = 2, 9, 145
+    Kc = 32 if kind == "front" else C_
+    N = C_ if kind == "front" else 16
+    nv = N if kind == "front" else 2
+    zp = torch.randn(B, T + 2, F + 2, Kc, device="cuda")
+    w = torch.randn(N, 9 * Kc, device="cuda") * 0.1
+    if kind == "back":
+        w[2:] = 0
+    bias = torch.randn(N, device="cuda")
+    g_, b_ = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda") * 0.1
+    s_in = ((T + 2) * (F + 2) * Kc, (F + 2) * Kc, Kc)
+    epi = L.EPI_LN if kind == "front" else L.EPI_NONE
+    outs = []
+    for f16 in (False, True):
+        out = torch.zeros(B, T, F, N, device="cuda")
+        ops.linear(zp, w, bias, out, (B, T, F), s_in, (T * F * N, F * N, N), 9 * Kc, N, kseg=3 * Kc, is_seg=(F + 2) * Kc,
+                   epi=epi, ln_g=g_ if kind == "front" else None, ln_b=b_ if kind == "front" else None, n_valid=nv, f16x3=f16)
+        outs.append(out)
+    # float64 reference: rows (t, f) see the 3 x 3 x Kc window starting at padded (t, f)
+    win = torch.stack([zp[:, a:a + T, d:d + F] for a in range(3) for d in range(3)], 3).reshape(B, T, F, 9 * Kc).double()
+    ref = win @ w.double().t() + bias.double()
+    if kind == "front":
+        ref = torch.nn.functional.layer_norm(ref, (N,), g_.double(), b_.double(), 1e-5)
+    assert rel_l2(outs[0][..., :nv].cpu().numpy(), ref[..., :nv].cpu().numpy()) < 2e-6
+    assert rel_l2(outs[1][..., :nv].cpu().numpy(), ref[..., :nv].cpu().numpy()) < 2e-6
+    # weight gradient
+    Ng = nv
+    gr = torch.randn(B * T * F, Ng if kind == "back" else N, device="cuda") * 0.01
+    want = gr.double().t() @ win.reshape(-1, 9 * Kc)
+    for f16 in (False, True):
+        monkeypatch.setattr(ops, "LINEAR_F16X3", f16)
+        dW = torch.zeros(Ng, 9 * Kc, device="cuda")
+        db = torch.zeros(Ng, device="cuda")
+        ops.wgrad(gr, gr.shape[1], Ng, zp, s_in, (B, T, F), 9 * Kc, dW, kseg=3 * Kc, is_seg=(F + 2) * Kc, dbias=db, f16=True)
+        assert rel_l2(dW.cpu().numpy(), want.cpu().numpy()) < 5e-6, f16
+        assert rel_l2(db.cpu().numpy(), gr.double().sum(0).cpu().numpy()) < 5e-6
