@@ -16,6 +16,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {"fwdnogates": "-DSB_EXP_SKIP=1", "rc1": "-DSB_EXP_RECOMPUTE=1", "rc3": "-DSB_EXP_RECOMPUTE=3"}
+if os.environ.get("SB_EXP_VARIANTS"):       # e.g. SB_EXP_VARIANTS="noagpr=-DSB_AGPR_OPERANDS=0": other A/B builds of sb_lstm_bf.hip
+    VARIANTS = dict(v.split("=", 1) for v in os.environ["SB_EXP_VARIANTS"].split(";"))
 
 
 def build():
