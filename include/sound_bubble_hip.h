@@ -254,6 +254,11 @@ typedef struct {
                          fp16 matrix pipe is used (dgates exact, the fp32 operands as fp16 hi + lo) and every output
                          is multiplied by 1/S */
   int u_f16, hs_f16;  /* gmax != NULL only: u / hs are the fp16 tensors written by sb_lstm_fwd with aux_f16 */
+  /* optional fusion of the LayerNorm backward that follows (single direction, gmax != NULL, u_f16 and hs_f16): when
+     dx != NULL, du_part is not written; dx [P, C] = LN-backward(du; ln_x, ln_g) + ln_res (ln_x the pre-LayerNorm
+     input, ln_res the residual branch's gradient), d_ln_g / d_ln_b [C] += the parameter gradients (the scratch rows
+     grow by 2C floats), *absmax_out = max(*absmax_out, max |dx|) when non-NULL (zero it before the call). */
+  const float* ln_x; const float* ln_g; const float* ln_res; float* dx; float* d_ln_g; float* d_ln_b; float* absmax_out;
 } sb_lstm_stream_args;
 int sb_lstm_bwd_stream(const sb_lstm_stream_args* a, void* stream);
 int sb_lstm_stream_grid(int64_t positions);

@@ -88,7 +88,9 @@ class LstmStreamArgs(C.Structure):
                 ("w_ih", c_fp * 2),
                 ("dW_ih", c_fp * 2), ("dW_hh", c_fp * 2), ("db_ih", c_fp * 2), ("db_hh", c_fp * 2),
                 ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int), ("gmax", c_fp),
-                ("u_f16", C.c_int), ("hs_f16", C.c_int)]
+                ("u_f16", C.c_int), ("hs_f16", C.c_int),
+                ("ln_x", c_fp), ("ln_g", c_fp), ("ln_res", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
+                ("absmax_out", c_fp)]
 
 
 class LnBwdArgs(C.Structure):

@@ -351,7 +351,12 @@ SB_DEVINL SplitH splith8(const float (&x)[8]) {
 SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // U16 / HS16: u / hs arrive as the fp16 tensors the forward kernel wrote for this purpose (sb_lstm_fwd_args.aux_f16)
-template <int C, bool SMALLSEG, bool U16, bool HS16>
+// LNB (single direction): the LayerNorm backward that follows (sb_ln_bwd) rides in the flush of the du rows:
+// dx[p] = LN-backward(du[p]; ln_x[p], ln_g) + ln_res[p] is stored instead of du, d(ln_g) / d(ln_b) join the workgroup's
+// partial row, max |dx| goes to absmax_out.  After the barrier wave w takes sub-tile w >> 1, positions 8 (w & 1) + (lane & 7)
+// and channel quad lane >> 3, so the 4 CK lanes that hold one position's channels differ in lane bits 3.. and the
+// LayerNorm sums are three (two for C = 16) xor-shuffles.  Saves the du round trip (2 x 4C bytes per position) and a launch.
+template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
@@ -395,6 +400,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   struct Chunk {                                                                   // raw operands of 32 positions
     h16x4 a4[8]; f32x4 h4[HS16 ? 1 : 8]; h16x4 hh4[HS16 ? 8 : 1]; h16x8 d8[2][2];
     float uv[U16 ? 1 : CK][8]; _Float16 uh[U16 ? CK : 1][8];
+    f32x4 xq, rq;                                                                  // LNB: x and residual of the flush position
+  };
+  // LNB flush role of this lane
+  const int fsb = w >> 1, fjj = 8 * (w & 1) + (lane & 7), fqq = lane >> 3;
+  const int fct = CK == 2 ? fqq >> 2 : 0, fqr = fqq & 3;
+  const bool fact = CK == 2 || fqq < 4;
+  const int fcol = 16 * fct + 4 * fqr;
+  f32x4 lgam = zero4(), dgam = zero4(), dbet = zero4();
+  float amax = 0.f;
+  if constexpr (LNB) lgam = ld4(a.ln_g + fcol);
+  auto grp_sum = [&](float v) {                      // over the lanes holding one position's channels
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    if constexpr (CK == 2) v += __shfl_xor(v, 32, 64);
+    return v;
   };
   const int nchunks = (Pi + 31) / 32;
   const h16x4 hz4 = {0, 0, 0, 0};
@@ -439,6 +459,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       const int pjc = min(p0 + 16 * sb + j, Pi - 1);      // dU of positions beyond P is computed but never stored
 #pragma unroll
       for (int m = 0; m < 2; ++m) t.d8[sb][m] = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 32 * m + 8 * q);
+    }
+    if constexpr (LNB) {
+      const int64_t pf = min(p0 + 16 * fsb + fjj, Pi - 1);
+      t.xq = ld4(a.ln_x + pf * C + fcol);
+      t.rq = ld4(a.ln_res + pf * C + fcol);
     }
   };
 
@@ -495,6 +520,41 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
     }
     __syncthreads();
+    if constexpr (LNB) {
+      const int rl = fqr * 16 + fjj;
+      const int pj = ch * 32 + 16 * fsb + fjj;
+      const bool valid = fact && pj < Pi;
+      const f32x4 du4 = (ld4(&R[buf][0][fsb][fct][rl][0]) + ld4(&R[buf][1][fsb][fct][rl][0]) + ld4(&R[buf][2][fsb][fct][rl][0]) +
+                         ld4(&R[buf][3][fsb][fct][rl][0])) * invS;
+      const f32x4 x4 = cur.xq;
+      const float mean = grp_sum(fact ? x4[0] + x4[1] + x4[2] + x4[3] : 0.f) * (1.0f / C);
+      f32x4 xh;
+      float sq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { xh[r] = x4[r] - mean; sq += xh[r] * xh[r]; }
+      const float rstd = 1.0f / sqrtf(grp_sum(fact ? sq : 0.f) * (1.0f / C) + 1e-5f);
+      float m1 = 0.f, m2 = 0.f;
+      f32x4 gg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xh[r] *= rstd;
+        const float g = valid ? du4[r] : 0.f;
+        dgam[r] += g * xh[r];
+        dbet[r] += g;
+        gg[r] = g * lgam[r];
+        m1 += gg[r];
+        m2 += gg[r] * xh[r];
+      }
+      m1 = grp_sum(m1) * (1.0f / C);
+      m2 = grp_sum(m2) * (1.0f / C);
+      f32x4 dx4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dx4[r] = rstd * (gg[r] - m1 - xh[r] * m2) + cur.rq[r];
+        if (valid) amax = fmaxf(amax, fabsf(dx4[r]));
+      }
+      if (valid) st4(a.dx + (int64_t)pj * C + fcol, dx4);
+    } else
     {   // 2 sub-tiles x CK channel tiles = 2*CK (<= 4) reductions: one per wave
       const int sb = w / CK, ct = w % CK;
       const int pj = ch * 32 + 16 * sb + j;
@@ -508,7 +568,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   }
 
   constexpr int Ktot = C + H;
-  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) * ((size_t)4 * H * Ktot + 4 * H);
+  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) * ((size_t)4 * H * Ktot + 4 * H + (LNB ? 2 * C : 0));
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -521,6 +581,32 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     }
     const float cs = quad_sum(csum[nt]);
     if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
+  }
+  if constexpr (LNB) {
+    // d(ln_g), d(ln_b): lanes with the same channel quad (lane >> 3) differ in lane bits 0..2 and in the wave
+    __syncthreads();
+    float* red = &R[0][0][0][0][0][0];                // [wave][2][C]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float g = dgam[r], b = dbet[r];
+      g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64); g += __shfl_xor(g, 4, 64);
+      b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64);
+      if ((lane & 7) == 0 && fact) { red[(w * 2 + 0) * C + fcol + r] = g; red[(w * 2 + 1) * C + fcol + r] = b; }
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+      const int which = tid / C, c = tid % C;
+      part[(size_t)4 * H * Ktot + 4 * H + tid] = red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c] +
+                                                  red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c];
+    }
+    if (a.absmax_out) {                              // one atomic per workgroup
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      __shared__ float wm[4];
+      if (lane == 0) wm[w] = amax;
+      __syncthreads();
+      if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out),
+                              __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    }
   }
 }
 
@@ -660,6 +746,10 @@ extern "C" int sb_lstm_stream_grid(int64_t positions) {
   return (int)(t < STREAM_MAX_WG ? (t < 1 ? 1 : t) : STREAM_MAX_WG);
 }
 
+int sb_launch_stream_reduce(const float* partials, int rows, int64_t ld, int C, float* dW_ih, float* dW_hh, float* db_ih,
+                            float* db_hh, hipStream_t st, int n_extra, const int* ex_off, const int* ex_n,
+                            float* const* ex_out);
+
 extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   if (!ap || ap->P <= 0 || (ap->ndir != 1 && ap->ndir != 2)) return -1001;
   if (ap->C != 16 && ap->C != 32) return -1002;
@@ -674,6 +764,22 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
 #define SB_SHC(CC) do { if (ap->u_f16 && ap->hs_f16) SB_SH(CC, true, true); else if (ap->u_f16) SB_SH(CC, true, false); \
                         else SB_SH(CC, false, false); } while (0)
   if ((ap->u_f16 || ap->hs_f16) && (!ap->gmax || !ap->u_f16)) return -1003;      // fp16 hs comes with fp16 u
+  const bool lnb = ap->dx != nullptr;
+  if (lnb) {                                         // fused LayerNorm backward: single direction, fp16 side outputs
+    if (ap->ndir != 1 || !ap->gmax || !ap->u_f16 || !ap->hs_f16 || !ap->ln_x || !ap->ln_g || !ap->ln_res || !ap->d_ln_g ||
+        !ap->d_ln_b)
+      return -1003;
+#define SB_SL(CC) do { if (sm) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, true, true, true, true>), grid, block, 0, st, *ap); \
+                       else hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true>), grid, block, 0, st, *ap); } while (0)
+    if (ap->C == 32) SB_SL(32); else SB_SL(16);
+#undef SB_SL
+    SB_CHECK_LAUNCH();
+    const int tot = 4 * H * (ap->C + H) + 4 * H;
+    const int ex_off[2] = {tot, tot + ap->C}, ex_n[2] = {ap->C, ap->C};
+    float* const ex_out[2] = {ap->d_ln_g, ap->d_ln_b};
+    return sb_launch_stream_reduce(ap->scratch, gx, (int64_t)tot + 2 * ap->C, ap->C, ap->dW_ih[0], ap->dW_hh[0], ap->db_ih[0],
+                                   ap->db_hh[0], st, 2, ex_off, ex_n, ex_out);
+  }
   if (ap->gmax) { if (ap->C == 32) SB_SHC(32); else SB_SHC(16); }
   else if (ap->split_bf16) { if (ap->C == 32) SB_S(lstm_bwd_stream_bf16_kernel, 32); else SB_S(lstm_bwd_stream_bf16_kernel, 16); }
   else { if (ap->C == 32) SB_S(lstm_bwd_stream_kernel, 32); else SB_S(lstm_bwd_stream_kernel, 16); }

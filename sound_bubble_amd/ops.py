@@ -462,9 +462,17 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     return du
 
 
-def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None):
+def can_fuse_stream_ln(dg, u, hs):
+    """the streaming kernel can carry the LayerNorm backward (single direction, scaled fp16 dgates, fp16 u / hs)"""
+    return (FUSED_LN_BWD and isinstance(dg, DGates) and dg.gmax is not None and dg.data.shape[1] == 1
+            and u.dtype == torch.float16 and hs.dtype == torch.float16)
+
+
+def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None, ln=None):
     """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C].
-    targets (optional): per direction 4 buffers the gradients are ACCUMULATED into (instead of fresh zero tensors)."""
+    targets (optional): per direction 4 buffers the gradients are ACCUMULATED into (instead of fresh zero tensors).
+    ln = (x [P, C] pre-LayerNorm input, ln_g, res [P, C], d_ln_g, d_ln_b) (see can_fuse_stream_ln): the LayerNorm backward
+    runs in the kernel and dx [P, C] = LN-backward(du) + res is returned instead of du_part (max |dx| left as a hint)."""
     lib = L.load()
     if not isinstance(dg, DGates):
         dg = DGates(dg)
@@ -486,15 +494,28 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None
         grads.append(g)
         a.w_ih[d] = _p(w_ih_list[d])
         a.dW_ih[d], a.dW_hh[d], a.db_ih[d], a.db_hh[d] = _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3])
-    du = torch.empty(P, ndir, Cc, device=dev, dtype=torch.float32)
+    du = torch.empty(P, ndir, Cc, device=dev, dtype=torch.float32) if ln is None else torch.empty(P, Cc, device=dev,
+                                                                                                  dtype=torch.float32)
     ng = lib.sb_lstm_stream_grid(P)
-    scratch = torch.empty(ndir * ng * (4 * H * (Cc + H) + 4 * H), device=dev, dtype=torch.float32)
-    a.du_part, a.scratch = _p(du), _p(scratch)
+    scratch = torch.empty(ndir * ng * (4 * H * (Cc + H) + 4 * H + (2 * Cc if ln is not None else 0)), device=dev,
+                          dtype=torch.float32)
+    a.scratch = _p(scratch)
+    gm = None
+    if ln is not None:
+        assert ndir == 1 and gmax is not None
+        a.ln_x, a.ln_g, a.ln_res, a.dx, a.d_ln_g, a.d_ln_b = _p(ln[0]), _p(ln[1]), _p(ln[2]), _p(du), _p(ln[3]), _p(ln[4])
+        if ABSMAX_HINTS:
+            gm = zero_scalar(dev)
+            a.absmax_out = _p(gm)
+    else:
+        a.du_part = _p(du)
     a.split_bf16 = 1 if COMPACT_BPTT else 0       # exact mode (SB_EXACT_BPTT=1) keeps the fp32 matrix path
     by = P * ndir * (dg.element_size() * 4.0 * H + hs.element_size() * H + 4.0 * Cc) + u.element_size() * Cc * P
     with _Prof(f"lstm_bwd_stream kernel C={Cc} ndir={ndir}", (2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P * ndir,
                8.0 * Cc * P, by):
         L.check(lib.sb_lstm_bwd_stream(C.byref(a), _stream()), "sb_lstm_bwd_stream")
+    if gm is not None:
+        absmax_hint_put(du, gm)
     return grads, du
 
 

@@ -686,3 +686,43 @@ def test_conv3x3_fp16x3_matrix_pipe_matches_fp32_mfma(torch_gpu, C_, kind, monke
         ops.wgrad(gr, gr.shape[1], Ng, zp, s_in, (B, T, F), 9 * Kc, dW, kseg=3 * Kc, is_seg=(F + 2) * Kc, dbias=db, f16=True)
         assert rel_l2(dW.cpu().numpy(), want.cpu().numpy()) < 5e-6, f16
         assert rel_l2(db.cpu().numpy(), gr.double().sum(0).cpu().numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("C_", [16, 32])
+def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(torch_gpu, C_):
+    """sb_lstm_stream_args.dx: the LayerNorm backward + residual of a single-direction pass computed in the flush of the
+    streaming kernel (big config's inter-frame backward) against the streaming kernel followed by sb_ln_bwd: dx, d(ln_g),
+    d(ln_b), the LSTM weight gradients and the max |dx| hint.  Odd position count (a partial last chunk)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.can_fuse_linear_fwd()):
+        pytest.skip("default compact fp16 path only")
+    torch.manual_seed(21)
+    B_, T_, F_ = 2, 23, 21
+    geom = ops.Geom.inter(B_, T_, F_)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    wi, wh = torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2
+    dirs = [(wi, wh, torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)]
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    y = torch.empty(geom.P, C_, device="cuda")
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, y))
+    dy = torch.randn(geom.P, C_, device="cuda") * 0.01
+    dg = ops.lstm_bwd_rec([wh], gates, None, geom, dy=dy, w_lin=lin_w)
+    assert ops.can_fuse_stream_ln(dg, u, hs)
+    ref, du = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_)
+    dgr, dbr = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    dx_ref, _, _, _ = ops.ln_bwd(du, x, g, res=dy, d_g=dgr, d_b=dbr)
+    tg = [torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+          torch.zeros(256, device="cuda")]
+    dgf, dbf = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    ops.absmax_hints_clear()
+    _, dx = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_, targets=[tg], ln=(x, g, dy, dgf, dbf))
+    torch.cuda.synchronize()
+    assert rel_l2(dx.cpu().numpy(), dx_ref.cpu().numpy()) < 2e-6
+    assert rel_l2(dgf.cpu().numpy(), dgr.cpu().numpy()) < 2e-5
+    assert rel_l2(dbf.cpu().numpy(), dbr.cpu().numpy()) < 2e-5
+    for a_, b_ in zip(tg, ref[0]):
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-6
+    if ops.ABSMAX_HINTS:
+        assert float(ops.absmax_or_hint(dx)) == float(dx.abs().max())
