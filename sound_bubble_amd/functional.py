@@ -381,18 +381,106 @@ class AttentionFn(torch.autograd.Function):
 
 
 class FilmFn(torch.autograd.Function):
-    """y = x * w[b,f,c] + bias[b,f,c]  -- FilmLayer.forward, dis_embd3/tfgridnet_causal.py:59-68."""
+    """y = x * w[b,f,c] + bias[b,f,c]  -- FilmLayer.forward, dis_embd3/tfgridnet_causal.py:59-68.
+    bank (optional): the FilmBankFn bookkeeping dict and this layer's index k -- the gradients of w and bias are then
+    accumulated into slices of ONE zeroed buffer shared by all layers (a single fill per backward pass)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, bank=None, k=0):
         x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
         ctx.save_for_backward(x, w)
+        ctx.bank, ctx.k = bank, k
         return ops.film_fwd(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        return ops.film_bwd(x, w, dy.contiguous())
+        out = None
+        if ctx.bank is not None:
+            if ctx.bank.get("G") is None:
+                ctx.bank["G"] = torch.zeros(ctx.bank["n"], 2, *w.shape, device=w.device, dtype=torch.float32)
+            out = (ctx.bank["G"][ctx.k, 0], ctx.bank["G"][ctx.k, 1])
+        dx, dw, db = ops.film_bwd(x, w, dy.contiguous(), out=out)
+        return dx, dw, db, None, None
+
+
+class FilmBankFn(torch.autograd.Function):
+    """All FiLM scale / shift planes of a forward pass in one autograd node (dis_embd3/tfgridnet_causal.py:150-173,
+    51-68, 509-513): e = LN_4(view(W_e . dis_embed, [B, F, 4])), plane[k, which] = e . W[k, which]^T + b[k, which] for
+    the n = n_layers - 1 FiLM layers (which = 0 scale, 1 shift).  A few hundred KB of arithmetic, done with a handful of
+    batched torch ops instead of 2 Linear calls per layer forward and ~16 tiny launches per layer backward; the
+    parameter gradients are added into the flat gradient bucket with ONE add when the 4n Conv1d(4 -> C, k = 1)
+    parameters sit back to back in it (train.FlatBucket), through autograd otherwise.
+    forward(dis_embed [B, 3], W_e [4F, 3], ln_w [4], ln_b [4], bank, *[w.weight, w.bias, b.weight, b.bias] * n)
+      -> 2n tensors [B, F, C]: (scale_0, shift_0, scale_1, ...), slices of one buffer."""
+
+    @staticmethod
+    def forward(ctx, dis, W_e, ln_w, ln_b, bank, *conv):
+        n = len(conv) // 4
+        B = dis.shape[0]
+        d_in = ln_w.shape[0]
+        F_ = W_e.shape[0] // d_in
+        Cc = conv[0].shape[0]
+        E0 = torch.mm(dis.float(), W_e.t()).view(B * F_, d_in)
+        e = torch.nn.functional.layer_norm(E0, (d_in,), ln_w, ln_b, 1e-5)
+        Wall = torch.stack([conv[4 * k + 2 * wh].reshape(Cc, d_in) for k in range(n) for wh in range(2)])      # [2n, C, 4]
+        ball = torch.stack([conv[4 * k + 2 * wh + 1] for k in range(n) for wh in range(2)])                    # [2n, C]
+        planes = torch.baddbmm(ball[:, None, :], e.unsqueeze(0).expand(2 * n, -1, -1), Wall.transpose(1, 2))   # [2n, BF, C]
+        ctx.save_for_backward(dis, W_e, ln_w, ln_b, E0, e, Wall, *conv)
+        ctx.dims = (n, B, F_, Cc, d_in)
+        ctx.bank = bank
+        planes = planes.view(2 * n, B, F_, Cc)
+        return tuple(planes[i] for i in range(2 * n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        dis, W_e, ln_w, ln_b, E0, e, Wall, *conv = ctx.saved_tensors
+        n, B, F_, Cc, d_in = ctx.dims
+        G = ctx.bank.get("G") if ctx.bank is not None else None
+        nb = B * F_ * Cc * 4
+        if G is None or any(g is None or g.data_ptr() != G.data_ptr() + i * nb for i, g in enumerate(gs)):
+            G = torch.stack([g if g is not None else torch.zeros(B, F_, Cc, device=e.device) for g in gs])
+        if ctx.bank is not None:
+            ctx.bank["G"] = None
+        G = G.reshape(2 * n, B * F_, Cc)
+        dball = G.sum(1)                                                        # [2n, C]
+        dWall = torch.bmm(G.transpose(1, 2), e.unsqueeze(0).expand(2 * n, -1, -1))      # [2n, C, 4]
+        de = torch.bmm(G, Wall).sum(0)                                          # [BF, 4]
+        dE0, dlw, dlb = torch.ops.aten.native_layer_norm_backward(
+            de, E0, [d_in], *_ln_stats(E0, d_in), ln_w, ln_b, [True, True, True])
+        dW_e = torch.mm(dE0.view(B, F_ * d_in).t(), dis.float())               # [4F, 3]
+        # parameter gradients: one add into the flat bucket when the conv parameters are adjacent there
+        region = _adjacent_grad_region(conv)
+        if region is not None:
+            region.add_(torch.cat([dWall.reshape(2 * n, Cc * d_in), dball], 1).reshape(-1))
+            cg = [None] * (4 * n)
+        else:
+            cg = []
+            for k in range(n):
+                for wh in range(2):
+                    cg += [dWall[2 * k + wh].reshape(conv[4 * k + 2 * wh].shape), dball[2 * k + wh]]
+        return (None, dW_e, dlw, dlb, None, *cg)
+
+
+def _ln_stats(x, d):
+    mean = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    return mean, rstd
+
+
+def _adjacent_grad_region(params):
+    """flat view over the .grad buffers of `params` when they are FlatBucket views lying back to back (in this order)"""
+    if not params or not all(getattr(p, "_sb_flat_grad", False) and p.grad is not None and p.requires_grad for p in params):
+        return None
+    g0 = params[0].grad
+    off, total = g0.data_ptr(), 0
+    for p in params:
+        g = p.grad
+        if g.data_ptr() != off or not g.is_contiguous() or g.dtype != torch.float32:
+            return None
+        off += g.numel() * 4
+        total += g.numel()
+    return torch.as_strided(g0, (total,), (1,), g0.storage_offset())
 
 
 # GEMM forms of the fixed STFT / iSTFT filter banks (module buffers, never trained): built once per (tensor, version)

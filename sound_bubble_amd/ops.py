@@ -669,11 +669,15 @@ def film_fwd(x, w, b):
     return y
 
 
-def film_bwd(x, w, dy):
+def film_bwd(x, w, dy, out=None):
+    """out = (dw, db): pre-zeroed [B, F, C] buffers the T-reductions are accumulated into (default: fresh zeros)"""
     B_, T_, F_, Cc = x.shape
     dx = torch.empty_like(x)
-    dw = torch.zeros(B_, F_, Cc, device=x.device, dtype=torch.float32)
-    db = torch.zeros_like(dw)
+    if out is not None:
+        dw, db = out
+    else:
+        dw = torch.zeros(B_, F_, Cc, device=x.device, dtype=torch.float32)
+        db = torch.zeros_like(dw)
     gm = zero_scalar(x.device) if ABSMAX_HINTS else None   # dx is a next dy
     L.check(L.load().sb_film_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), B_, T_, F_, Cc, _p(gm), _stream()),
             "sb_film_bwd")
