@@ -53,7 +53,10 @@ typedef struct {
                 (dropped terms <= 2^-24) */
   /* optional fusion of the Linear(64 -> C) + residual that follows a single-direction LSTM (mma == 1, ndir == 1):
      when lin_w != NULL, y[p, :] = x[p, :] + lin_w[C, 64] . hs[p, :] + lin_b is written as well, and hs may be NULL
-     (inference).  tfgridnet_causal.py:843-849. */
+     (inference).  tfgridnet_causal.py:843-849.
+     With ndir == 2 (intra-frame pass, lin_w [C, 128]; :824-827) the kernel works in PARTIAL mode: y is [P, 2, C] and
+     y[p, d, :] = lin_w[:, 64 d .. 64 d + 63] . h_d[p] (+ lin_b for d == 0), without the residual -- the caller finishes
+     with sb_add3 (x + y[:, 0] + y[:, 1]); hs [P, 128] is then only needed by the backward kernels (fp16 with aux_f16). */
   const float* lin_w; const float* lin_b; float* y;
   /* optional scratch for time-segmented scheduling of single-direction passes with more 16-sequence tiles than the
      chip has CUs (mma == 1): seg_state [ceil(nseq/16) * 2 * 16 * 64] floats, seg_flags [ceil(nseq/16)] ints (zeroed by
@@ -122,6 +125,8 @@ typedef struct {
      du [P, 2, C] per direction, no Linear / LayerNorm riders; direction 1 takes w_ih1 and accumulates into the *1
      targets.  wpart: 2 * min(ceil(nseq/16), CUs/2) rows of 256*(C+64)+256 floats (persistent workgroups). */
   const float* w_ih1; float* dW_ih1; float* dW_hh1; float* db_ih1; float* db_hh1;
+  int hs_f16;   /* bidirectional fused form only: hs is the fp16 [P, 128] tensor written by sb_lstm_fwd in its partial-Linear
+                   mode (lin_w != NULL with ndir == 2); C == 32 with the fused Linear backward (dy form) */
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 
@@ -330,6 +335,10 @@ int sb_film_fwd(const float* x, const float* w, const float* bias, float* y, int
 int sb_film_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias,
                 int B, int T, int F, int C, float* absmax_out /* optional: max |dx|, as sb_linear_args.absmax_out */,
                 void* stream);
+
+/* y[p, :] = x[p, :] + part[p, 0, :] + part[p, 1, :]  (x, y [P, C]; part [P, 2, C]): the residual + the two directions'
+ * partial products of the intra-frame Linear written by sb_lstm_fwd in partial mode (tfgridnet_causal.py:824-827). */
+int sb_add3(const float* x, const float* part, float* y, int64_t P, int C, void* stream);
 
 /* ---- iSTFT overlap-add ---------------------------------------------------
  * frames [B, T+1, 288] (row 0 = carried istft_buf frame) -> wave [B, hop*T]:

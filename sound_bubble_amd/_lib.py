@@ -36,7 +36,8 @@ class LstmBwdArgs(C.Structure):
                 ("u", c_fp), ("hs", c_fp), ("w_ih", c_fp), ("C", C.c_int), ("du", c_fp), ("wpart", c_fp),
                 ("dW_ih", c_fp), ("dW_hh", c_fp), ("db_ih", c_fp), ("db_hh", c_fp), ("dW_lin", c_fp), ("db_lin", c_fp),
                 ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
-                ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp)]
+                ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp),
+                ("hs_f16", C.c_int)]
 
 
 class WView(C.Structure):
@@ -138,6 +139,7 @@ SYMBOLS = {
     "sb_features": (_ci, [c_fp, i64, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_film_fwd": (_ci, [c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_film_bwd": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, c_fp, _vp]),
+    "sb_add3": (_ci, [c_fp, c_fp, c_fp, i64, _ci, _vp]),
     "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),

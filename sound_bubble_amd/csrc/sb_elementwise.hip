@@ -339,6 +339,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// y = x + part[:, 0] + part[:, 1]: thread = 4 channels of one position
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                   float* __restrict__ y, int64_t n4, int c4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c4, c = i - p * c4;
+    const f32x4 a = ld4(x + 4 * i), b0 = ld4(part + 4 * ((2 * p) * c4 + c)), b1 = ld4(part + 4 * ((2 * p + 1) * c4 + c));
+    st4(y + 4 * i, (a + b0) + b1);
+  }
+}
+
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -367,6 +377,16 @@ extern "C" int sb_film_bwd(const float* x, const float* w, const float* dy, floa
   const int tchunk = 25;
   dim3 grid(nblk(n), (T + tchunk - 1) / tchunk);
   hipLaunchKernelGGL(film_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, dy, dx, dw, dbias, B, T, F, C, tchunk, absmax_out);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_add3(const float* x, const float* part, float* y, int64_t P, int C, void* stream) {
+  if (P <= 0 || C <= 0 || C % 4) return -1002;
+  const int64_t n4 = P * (C / 4);
+  unsigned gx = nblk(n4);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(add3_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, x, part, y, n4, C / 4);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -203,17 +203,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   }
   if (tid < 4 * H) Bias[tid >> 6][tid & 63] = ((tid >> 6) == 2 ? 2.0f : 1.0f) * SB_NLOG2E * (a.b_ih[dir][tid] + a.b_hh[dir][tid]);
   const bool linw = LIN && w < C / 16;                  // this wave owns output channels 16w .. 16w+15 of y
+  // bidirectional passes (a.ndir == 2): PARTIAL mode -- each direction writes its half of the Linear(128 -> C),
+  // y[p, dir, :] = W_lin[:, dir*64 .. +63] . h_dir[p] (+ b_lin in direction 0), no residual: the two directions visit a
+  // position at different times in different workgroups, so the sum x + y[p,0] + y[p,1] is a cheap elementwise pass
+  // (sb_add3) instead of a pass over hs [P, 128] fp32 -- and hs itself only travels as the fp16 side output.
+  const bool lin_part = LIN && a.ndir == 2;
   SplitN<F16> Wl[2];
   f32x4 lbias = zero4(), yacc = zero4(), xres = zero4();
   if constexpr (LIN) {
+    const int ldl = a.ndir * H;
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
       float t[8];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) t[kk] = linw ? a.lin_w[(size_t)(16 * w + j) * H + 32 * ck + 8 * q + kk] : 0.f;
+      for (int kk = 0; kk < 8; ++kk) t[kk] = linw ? a.lin_w[(size_t)(16 * w + j) * ldl + dir * H + 32 * ck + 8 * q + kk] : 0.f;
       Wl[ck] = splitn8<F16>(t);
     }
-    if (linw) lbias = ld4(a.lin_b + 16 * w + 4 * q);
+    if (linw && dir == 0) lbias = ld4(a.lin_b + 16 * w + 4 * q);
   }
   // zero the padded channels of the input tiles once (C = 16: channels 16..31 stay zero)
   for (int i = tid; i < 2 * NT * 16 * UP; i += 256) (&U16[0][0][0][0])[i] = (elem)0.f;
@@ -343,11 +349,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     if (linw && cvalid && !(SB_EXP_SKIP & 16)) {
       const int st = rev ? S - 1 - sy : sy;
       const int64_t pos = cbase + (int64_t)st * a.p_step;
-      st4(a.y + pos * C + 16 * w + 4 * q, yacc + lbias + xres);
+      st4(a.y + (lin_part ? pos * 2 + dir : pos) * C + 16 * w + 4 * q, yacc + lbias + xres);
     }
   };
   auto load_res = [&](int sy) {
-    if (linw && cvalid && !(SB_EXP_SKIP & 32)) {
+    if (linw && cvalid && !lin_part && !(SB_EXP_SKIP & 32)) {
       const int st = rev ? S - 1 - sy : sy;
       const int64_t pos = cbase + (int64_t)st * a.p_step;
       xres = ld4(a.x + pos * C + 16 * w + 4 * q);
@@ -585,7 +591,9 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 // of its 16 positions), dx = LN-backward(du) + dy goes out instead of du.
 // BI (FST > 0, two directions): hs is the fp32 [P, 128] tensor, du goes to [P, 2, C], no Linear / LayerNorm riders;
 // persistent workgroups (gridDim.x <= tiles) walk several tiles.
-template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false>
+// HS16B (BI): hs is the fp16 [P, 128] side output of the forward kernel's partial-Linear mode (sb_lstm_bwd_args.hs_f16)
+template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
+          bool HS16B = false>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -686,7 +694,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // loop body (the select of the first version did, and doubled the kernel time once the dy loads joined)
   static_assert(!BI || (!LNB && !SEG), "bidirectional fused form: no LayerNorm rider, no time segments");
   constexpr bool LINW = !BI || FUSE_C > 0;        // the fused Linear's weight gradient rides along (needs dy)
-  struct PairOps { h16x4 hh4[BI ? 1 : 8]; f32x4 hh32[BI ? 8 : 1]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8];
+  constexpr bool H32 = BI && !HS16B;              // hs as fp32 rows (bidirectional passes whose Linear is a separate kernel)
+  struct PairOps { h16x4 hh4[H32 ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8];
                    float dyv[CK][LINW ? 8 : 1];
                    float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
   static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
@@ -718,7 +727,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     for (int kk = 0; kk < 8; ++kk) {
       const int64_t pos = (int64_t)posb[kk] + (int64_t)st * a.p_step;
       const int64_t posh = (int64_t)posb[kk] + (int64_t)sth * a.p_step;
-      if constexpr (BI) o.hh32[kk] = ld4(hs32 + posh * (2 * H) + 4 * j);
+      if constexpr (H32) o.hh32[kk] = ld4(hs32 + posh * (2 * H) + 4 * j);
+      else if constexpr (BI) o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * (2 * H) + dir * H + 4 * j);
       else o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * H + 4 * j);
       if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
       else o.uh1[kk] = u16[pos * FST + j];
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      if constexpr (BI) {
+      if constexpr (H32) {
         const f32x4 hm = hp ? o.hh32[kk] : zero4();
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = (_Float16)hm[kt];
@@ -825,10 +835,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     for (int kk = 0; kk < 8; ++kk) {
       const int64_t pos = (int64_t)posb[kk] + (int64_t)st_of(S - 1) * a.p_step;       // walk index S - 1
       h16x4 hv;
-      if constexpr (BI) {
+      if constexpr (H32) {
         const f32x4 h32 = ld4(hs32 + pos * (2 * H) + 4 * j);
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[r] = (_Float16)h32[r];
+      } else if constexpr (BI) {
+        hv = *reinterpret_cast<const h16x4*>(hs16 + pos * (2 * H) + dir * H + 4 * j);
       } else {
         hv = *reinterpret_cast<const h16x4*>(hs16 + pos * H + 4 * j);
       }
@@ -1270,7 +1282,7 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   const int save = a.save_gates == nullptr ? 0 : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
   dim3 grid(ntiles, a.ndir);
   const bool lin = a.lin_w != nullptr;
-  if (lin && (!f16 || a.ndir != 1 || !a.lin_b || !a.y)) return -1003;
+  if (lin && (!f16 || !a.lin_b || !a.y)) return -1003;         // ndir == 2: per-direction partial products (see the kernel)
   if (!lin && !a.hs) return -1003;
   // time-segmented scheduling (see the kernel): single direction, scratch provided, more tiles than CUs
   const int cus = device_cu_count();
@@ -1344,9 +1356,10 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     dim3 g2(gx, 2);
-#define SB_FB(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true>), g2, block, 0, st, a)
-    if (a.C == 16 && fc == 0) { if (full) SB_FB(true, 0, 16); else SB_FB(false, 0, 16); }
-    else if (a.C == 32 && fc == 32) { if (full) SB_FB(true, 32, 32); else SB_FB(false, 32, 32); }
+#define SB_FB(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_>), g2, block, 0, st, a)
+    if (a.C == 16 && fc == 0 && !a.hs_f16) { if (full) SB_FB(true, 0, 16, false); else SB_FB(false, 0, 16, false); }
+    else if (a.C == 32 && fc == 32 && !a.hs_f16) { if (full) SB_FB(true, 32, 32, false); else SB_FB(false, 32, 32, false); }
+    else if (a.C == 32 && fc == 32) { if (full) SB_FB(true, 32, 32, true); else SB_FB(false, 32, 32, true); }
     else return -1003;
 #undef SB_FB
     const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + (fc > 0 ? a.C * 2 * H + a.C : 0);

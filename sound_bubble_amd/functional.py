@@ -58,11 +58,19 @@ class IntraPlainFn(torch.autograd.Function):
         train = GRAD_MODE and any(ctx.needs_input_grad)
         geom = Geom.intra(B * T, F)
         dirs = [(wif, whf, bif, bhf), (wir, whr, bir, bhr)]
-        hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train)
-        y = torch.empty_like(x)
-        g, s_in = dense(P, 2 * H)
-        _, s_out = dense(P, Cc)
-        ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, 2 * H, Cc, epi=L.EPI_RES, res=x)
+        if ops.intra_lin_fusion_ok(train, Cc):
+            # the Linear inside the recurrence: two per-direction partial products + one elementwise pass; hs is then
+            # only a (fp16) side output for the backward kernels, and none at all in inference
+            part = torch.empty(P, 2, Cc, device=x.device, dtype=torch.float32)
+            hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train,
+                                           lin=(lin_w.contiguous(), lin_b, part), want_hs=train)
+            y = ops.add3(x.view(P, Cc), part).view(B, T, F, Cc)
+        else:
+            hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train)
+            y = torch.empty_like(x)
+            g, s_in = dense(P, 2 * H)
+            _, s_out = dense(P, Cc)
+            ops.linear(hs, lin_w, lin_b, y, g, s_in, s_out, 2 * H, Cc, epi=L.EPI_RES, res=x)
         if train:
             ctx.save_for_backward(x, ln_g, wif, whf, wir, whr, lin_w, hs, u, ln_b, bif, bhf, bir, bhr, lin_b,
                                   *[t for t in gates if t is not None])

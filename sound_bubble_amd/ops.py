@@ -180,8 +180,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     a.aux_f16 = 1 if aux16 else 0
     a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.mma = LSTM_MMA
-    if lin is not None:
-        assert can_fuse_linear_fwd() and ndir == 1 and lin[0].shape == (Cc, H)
+    if lin is not None:       # ndir == 2: partial mode, y is [P, 2, C] (see the header)
+        assert can_fuse_linear_fwd() and lin[0].shape == (Cc, ndir * H) and lin[2].numel() == geom.P * ndir * Cc
         a.lin_w, a.lin_b, a.y = _p(lin[0]), _p(lin[1]), _p(lin[2])
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
     seg_scratch = None
@@ -411,9 +411,31 @@ FUSED_BPTT_BI = os.environ.get("SB_NO_FUSED_BPTT_BI", "0") != "1"
 
 
 def can_fuse_stream_bi(u, hs):
-    """bidirectional passes: fused form with fp32 hs (see lstm_bwd_fused_bi)"""
+    """bidirectional passes: fused form with fp32 hs, or (C == 32, partial-Linear forward) fp16 hs (see lstm_bwd_fused_bi)"""
     return (FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and COMPACT_BPTT and LSTM_MMA in (1, 2) and u is not None
-            and u.dtype == torch.float16 and hs.dtype == torch.float32 and u.shape[-1] in (16, 32))
+            and u.dtype == torch.float16 and u.shape[-1] in (16, 32)
+            and (hs.dtype == torch.float32 or (hs.dtype == torch.float16 and u.shape[-1] == 32)))
+
+
+# bidirectional (intra-frame) passes: the Linear(128 -> C) is applied inside the forward recurrence as two per-direction
+# partial products + one elementwise pass, and hs travels as fp16 (SB_NO_INTRA_LIN_FUSION=1: hs fp32 + a Linear kernel)
+INTRA_LIN_FUSION = os.environ.get("SB_NO_INTRA_LIN_FUSION", "0") != "1"
+
+
+def intra_lin_fusion_ok(train, Cc):
+    """inference: any time the fp16x3 forward is on; training: only with the fused bidirectional backward (the one kernel
+    that takes hs as fp16 [P, 128])"""
+    if not (INTRA_LIN_FUSION and can_fuse_linear_fwd() and Cc == 32):
+        return False
+    return (not train) or (can_fuse_linear_bwd() and FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and AUX_FP16)
+
+
+def add3(x, part):
+    """x [P, C] + part[:, 0] + part[:, 1]  (part [P, 2, C])"""
+    y = torch.empty_like(x)
+    Cc = x.shape[-1]
+    L.check(L.load().sb_add3(_p(x), _p(part), _p(y), x.numel() // Cc, Cc, _stream()), "sb_add3")
+    return y
 
 
 def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=None, dy=None, w_lin=None, gmax=None,
@@ -448,12 +470,14 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     if lin_targets is not None:          # (dW_lin [C, 128], db_lin [C]) of the fused Linear (dy form only)
         assert dy is not None and lin_targets[0].shape == (Cc, 2 * H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
-    a.u, a.hs, a.C = _ph(u), _p(hs), Cc
+    a.u, a.hs, a.C = _ph(u), _ph(hs), Cc
+    a.hs_f16 = int(hs.dtype == torch.float16)
+    assert not a.hs_f16 or (dy is not None and Cc == 32)
     a.w_ih, a.w_ih1 = _p(w_ih_list[0]), _p(w_ih_list[1])
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
     a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
-    by = geom.P * (2 * 640.0 + (4.0 * Cc if dy is not None else 8.0 * H) + 8.0 * H + 2.0 * Cc + 8.0 * Cc)
+    by = geom.P * (2 * 640.0 + (4.0 * Cc if dy is not None else 8.0 * H) + 2.0 * H * hs.element_size() + 2.0 * Cc + 8.0 * Cc)
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)", fl,
