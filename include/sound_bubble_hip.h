@@ -56,7 +56,9 @@ typedef struct {
      (inference).  tfgridnet_causal.py:843-849.
      With ndir == 2 (intra-frame pass, lin_w [C, 128]; :824-827) the kernel works in PARTIAL mode: y is [P, 2, C] and
      y[p, d, :] = lin_w[:, 64 d .. 64 d + 63] . h_d[p] (+ lin_b for d == 0), without the residual -- the caller finishes
-     with sb_add3 (x + y[:, 0] + y[:, 1]); hs [P, 128] is then only needed by the backward kernels (fp16 with aux_f16). */
+     with sb_add3 (x + y[:, 0] + y[:, 1]); hs [P, 128] is then only needed by the backward kernels (fp16 with aux_f16).
+     Records without gates: save_c != NULL with save_gates == NULL (aux_f16 only) stores c_prev, u and hs but not the four
+     gates -- for a backward that recomputes them (sb_lstm_bwd_args.recompute). */
   const float* lin_w; const float* lin_b; float* y;
   /* optional scratch for time-segmented scheduling of single-direction passes with more 16-sequence tiles than the
      chip has CUs (mma == 1): seg_state [ceil(nseq/16) * 2 * 16 * 64] floats, seg_flags [ceil(nseq/16)] ints (zeroed by
@@ -127,6 +129,10 @@ typedef struct {
   const float* w_ih1; float* dW_ih1; float* dW_hh1; float* db_ih1; float* db_hh1;
   int hs_f16;   /* bidirectional fused form only: hs is the fp16 [P, 128] tensor written by sb_lstm_fwd in its partial-Linear
                    mode (lin_w != NULL with ndir == 2); C == 32 with the fused Linear backward (dy form) */
+  /* ... and, with hs_f16: recompute != 0 says the forward wrote NO gate records (sb_lstm_fwd with save_gates == NULL,
+     save_c != NULL, aux_f16): save_gates is ignored and the four gates of every step are recomputed from u, the fp16
+     hs and the forward weights w_ih / w_ih1, w_hh[2], b_ih[2], b_hh[2] (single fp16 terms on the matrix pipe). */
+  int recompute; const float* b_ih[2]; const float* b_hh[2];
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

@@ -37,7 +37,7 @@ class LstmBwdArgs(C.Structure):
                 ("dW_ih", c_fp), ("dW_hh", c_fp), ("db_ih", c_fp), ("db_hh", c_fp), ("dW_lin", c_fp), ("db_lin", c_fp),
                 ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
                 ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp),
-                ("hs_f16", C.c_int)]
+                ("hs_f16", C.c_int), ("recompute", C.c_int), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2)]
 
 
 class WView(C.Structure):

@@ -423,6 +423,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
           st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
         } else if (SAVE >= 2) {
+          const int64_t blk = (rec_tile + st) * ndir + dir;
+          if (SAVE != 3 || a.save_gates) {   // SAVE == 3 with save_gates == NULL: the backward recomputes the gates (c_prev only)
           h16x8 lo, hi;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -435,11 +437,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           // contiguous KB (512 B for c_prev).  In the position-major layout adjacent lanes (sequences j, j+1) hit
           // different rows and the L1 splits each instruction into 64 sixteen-byte writes: measured 19 % of the
           // inter-frame forward, 27 % of the intra-frame one.
-          const int64_t blk = (rec_tile + st) * ndir + dir;
           _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + blk * (16 * 4 * H) + (w * 128 + lane) * 8;
           if (!(SB_EXP_SKIP & 1)) {
           *reinterpret_cast<h16x8*>(rec) = lo;
           *reinterpret_cast<h16x8*>(rec + 512) = hi;
+          }
           }
           h16x4 c16;
 #pragma unroll
@@ -592,8 +594,12 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 // BI (FST > 0, two directions): hs is the fp32 [P, 128] tensor, du goes to [P, 2, C], no Linear / LayerNorm riders;
 // persistent workgroups (gridDim.x <= tiles) walk several tiles.
 // HS16B (BI): hs is the fp16 [P, 128] side output of the forward kernel's partial-Linear mode (sb_lstm_bwd_args.hs_f16)
+// RECOMP (BI + HS16B): the forward kept no gate records; the four gates of a step are recomputed here as
+// act(W_ih u_s + W_hh h_{s-1} + b) -- 12 MFMAs per step on the matrix pipe (13 % busy in this kernel) with the weights as
+// single fp16 terms in LDS (48 KB, lane order) and u_s / h_{s-1} fetched as fp16 B operands with the other records.
+// Halves the bytes the intra-frame forward writes (it is store-bound) and the record bytes read here.
 template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
-          bool HS16B = false>
+          bool HS16B = false, bool RECOMP = false>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -604,7 +610,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
   __shared__ __attribute__((aligned(16))) float R[FST > 0 ? 2 : 1][4][2][CK][FST > 0 ? 64 : 1][4];
   static_assert(FST == 0 || (DG16 && REC16), "fused streaming part: compact fp16 path only");
-
+  static_assert(!RECOMP || (BI && HS16B && FST == 32), "gate recomputation: bidirectional C = 32 form with fp16 hs");
+  // forward weights of this direction as MFMA A operands: WR[gate][chunk][wave][lane] = rows gate*64 + 16 wave + (lane & 15),
+  // k = 8 (lane >> 4) .. + 7 of chunk 0 (W_ih) / 1, 2 (W_hh), scaled like the forward kernel's (activations as rcp(1 + 2^z));
+  // BR[gate][unit]: the scaled bias sums
+  __shared__ __attribute__((aligned(16))) h16x8 WR[RECOMP ? 4 : 1][RECOMP ? 3 : 1][RECOMP ? 4 : 1][RECOMP ? 64 : 1];
+  __shared__ __attribute__((aligned(16))) float BR[RECOMP ? 4 : 1][RECOMP ? H : 1];
   const float* __restrict__ whh = a.w_hh[dir];
   // [out tile ot][chunk]: A[i = out unit 16ot + j][k] = W_hh[gate row(k)][16ot + j].  DG16: the dgates enter the
   // product as the fp16 values that are stored (one term), W_hh as fp16 hi + lo -> 2 MFMAs per tile and chunk
@@ -621,6 +632,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         t[kk] = whh[(size_t)((2 * c + (kk >> 2)) * H + 16 * w + 4 * q + (kk & 3)) * H + 16 * ot + j];
       if constexpr (DG16) Ah[ot][c] = splith8(t); else At[ot][c] = split8(t);
     }
+
+  if constexpr (RECOMP) {
+    const float* __restrict__ wih = dir == 0 ? a.w_ih : a.w_ih1;
+    for (int e = tid; e < 4 * 3 * 4 * 64; e += 256) {
+      const int ln = e & 63, wv = (e >> 6) & 3, ck = (e >> 8) % 3, g = (e >> 8) / 3;
+      const int row = g * H + 16 * wv + (ln & 15), k0 = 8 * (ln >> 4);
+      const float gsc = (g == 2 ? 2.0f : 1.0f) * SB_NLOG2E;
+      h16x8 v;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+        v[kk] = (_Float16)(gsc * (ck == 0 ? wih[(size_t)row * FST + k0 + kk] : whh[(size_t)row * H + 32 * (ck - 1) + k0 + kk]));
+      WR[g][ck][wv][ln] = v;
+    }
+    if (tid < 4 * H) BR[tid >> 6][tid & 63] = ((tid >> 6) == 2 ? 2.0f : 1.0f) * SB_NLOG2E * (a.b_ih[dir][tid] + a.b_hh[dir][tid]);
+    __syncthreads();
+  }
 
   bool valid = false;                            // per work item (tile): set_tile()
   int64_t base = 0, rec_tile = 0;
@@ -899,7 +926,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
   };
 
-  struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; h16x4 cp16; };
+  struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; h16x4 cp16; h16x8 ub, hb0, hb1; };   // RECOMP: u_s, h_{s-1} as B operands
   auto load_raw = [&](int s) {
     Raw r;
     const int st = rev ? S - 1 - s : s;
@@ -909,6 +936,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         // blocked lane-order layout of the forward kernel: one contiguous KB per load instruction
         const int64_t blk = (rec_tile + st) * ndir + dir;
         const float* rec = a.save_gates + blk * (16 * 4 * H / 2) + (w * 128 + lane) * 4;
+        if constexpr (RECOMP) {
+          // B operands of the gate recomputation: lane (q, j) = sequence j, k = 8q .. 8q+7 of the chunk
+          r.r0 = r.r1 = zero4();
+          r.ub = *reinterpret_cast<const h16x8*>(u16 + pos * FST + 8 * q);
+          const int sp = s > 0 ? s - 1 : 0;                              // walk index of the previous step (masked at s == 0)
+          const int64_t posp = base + (int64_t)(rev ? S - 1 - sp : sp) * a.p_step;
+          const _Float16* hp = hs16 + posp * (2 * H) + dir * H + 8 * q;
+          const h16x8 h0v = *reinterpret_cast<const h16x8*>(hp), h1v = *reinterpret_cast<const h16x8*>(hp + 32);
+          const h16x8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+          r.hb0 = s > 0 ? h0v : hz;
+          r.hb1 = s > 0 ? h1v : hz;
+        } else
         if (SB_EXP_RECOMPUTE & 2) { const float cv = __builtin_bit_cast(float, (unsigned)(0x38003800u + (s & 1))); r.r0 = r.r1 = f32x4{cv, cv, cv, cv}; }
         else { r.r0 = ld4(rec); r.r1 = ld4(rec + 256); }
         r.r2 = r.r3 = r.cp = zero4();
@@ -930,6 +969,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     } else {
       r.r0 = r.r1 = r.r2 = r.r3 = r.cp = r.dh = r.dy1 = zero4();
       r.cp16 = h16x4{0, 0, 0, 0};
+      r.ub = r.hb0 = r.hb1 = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
     return r;
   };
@@ -944,7 +984,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // the body (loop-carried values) only touch loads that are two steps old.  (Four steps ahead with a 4-step body:
   // -4 % on the small inter-frame pass, +2..6 % on the others -- the big intra-frame variant crosses 256 VGPRs.)
   auto consume = [&](Raw& raw) {      // pins the s_waitcnt of this record here
-    asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.dh));
+    if constexpr (RECOMP) asm volatile("" : "+v"(raw.ub), "+v"(raw.hb0), "+v"(raw.hb1), "+v"(raw.dh));
+    else asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.dh));
     if constexpr (REC16) asm volatile("" : "+v"(raw.cp16)); else asm volatile("" : "+v"(raw.cp));
     if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
@@ -954,7 +995,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     SB_TICK(c0);
     SB_TICK(c1);
     f32x4 gi, gf, gg, go;
-    if constexpr (REC16) {
+    if constexpr (RECOMP) {
+      f32x4 z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = ld4(&BR[g][uoff]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WR[g][0][w][lane], raw.ub, z[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WR[g][1][w][lane], raw.hb0, z[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WR[g][2][w][lane], raw.hb1, z[g], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[r] = sigmoid_pre(z[0][r]);
+        gf[r] = sigmoid_pre(z[1][r]);
+        gg[r] = tanh_pre(z[2][r]);
+        go[r] = sigmoid_pre(z[3][r]);
+      }
+    } else if constexpr (REC16) {
       const h16x8 lo = __builtin_bit_cast(h16x8, raw.r0), hi = __builtin_bit_cast(h16x8, raw.r1);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { gi[k] = (float)lo[k]; gf[k] = (float)lo[4 + k]; gg[k] = (float)hi[k]; go[k] = (float)hi[4 + k]; }
@@ -1278,8 +1336,9 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   const int ntiles = (a.nseq + 15) / 16;
   const bool full = a.nseq % 16 == 0;
   const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
-  if (a.aux_f16 && (!a.save_gates || !a.save_c)) return -1003;
-  const int save = a.save_gates == nullptr ? 0 : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
+  if (a.aux_f16 && !a.save_c) return -1003;
+  // aux_f16 with save_gates == NULL: records without the gates (the backward recomputes them: sb_lstm_bwd_args.recompute)
+  const int save = a.save_gates == nullptr ? (a.save_c && a.aux_f16 ? 3 : 0) : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
   dim3 grid(ntiles, a.ndir);
   const bool lin = a.lin_w != nullptr;
   if (lin && (!f16 || !a.lin_b || !a.y)) return -1003;         // ndir == 2: per-direction partial products (see the kernel)
@@ -1359,7 +1418,12 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
 #define SB_FB(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_>), g2, block, 0, st, a)
     if (a.C == 16 && fc == 0 && !a.hs_f16) { if (full) SB_FB(true, 0, 16, false); else SB_FB(false, 0, 16, false); }
     else if (a.C == 32 && fc == 32 && !a.hs_f16) { if (full) SB_FB(true, 32, 32, false); else SB_FB(false, 32, 32, false); }
-    else if (a.C == 32 && fc == 32) { if (full) SB_FB(true, 32, 32, true); else SB_FB(false, 32, 32, true); }
+    else if (a.C == 32 && fc == 32 && !a.recompute) { if (full) SB_FB(true, 32, 32, true); else SB_FB(false, 32, 32, true); }
+    else if (a.C == 32 && fc == 32) {               // gate recomputation: no gate records, forward weights + biases needed
+      if (!a.b_ih[0] || !a.b_hh[0] || !a.b_ih[1] || !a.b_hh[1]) return -1003;
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, true, 32, true, false, 32, false, true, true, true>), g2, block, 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, true, 32, true, false, 32, false, true, true, true>), g2, block, 0, st, a);
+    }
     else return -1003;
 #undef SB_FB
     const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + (fc > 0 ? a.C * 2 * H + a.C : 0);

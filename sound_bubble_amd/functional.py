@@ -63,7 +63,8 @@ class IntraPlainFn(torch.autograd.Function):
             # only a (fp16) side output for the backward kernels, and none at all in inference
             part = torch.empty(P, 2, Cc, device=x.device, dtype=torch.float32)
             hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train,
-                                           lin=(lin_w.contiguous(), lin_b, part), want_hs=train)
+                                           lin=(lin_w.contiguous(), lin_b, part), want_hs=train,
+                                           no_gates=train and ops.GATE_RECOMPUTE)
             y = ops.add3(x.view(P, Cc), part).view(B, T, F, Cc)
         else:
             hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train)
@@ -75,12 +76,13 @@ class IntraPlainFn(torch.autograd.Function):
             ctx.save_for_backward(x, ln_g, wif, whf, wir, whr, lin_w, hs, u, ln_b, bif, bhf, bir, bhr, lin_b,
                                   *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
+            ctx.no_gates = gates[0] is None          # records without gates: the fused backward recomputes them
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, ln_g, wif, whf, wir, whr, lin_w, hs, u, ln_b, bif, bhf, bir, bhr, lin_b, *g_ = ctx.saved_tensors
-        gates = (g_[0], g_[1] if len(g_) > 1 else None)
+        gates = (None, g_[0]) if ctx.no_gates else (g_[0], g_[1] if len(g_) > 1 else None)
         gt = _GradTargets()
         B, T, F, Cc = ctx.dims
         P = B * T * F
@@ -100,7 +102,8 @@ class IntraPlainFn(torch.autograd.Function):
         if fuse and Cc == 32 and ops.can_fuse_stream_bi(u, hs):
             # recurrence + streaming part + the Linear's weight gradient in one launch (dgates stay in LDS)
             du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w,
-                                       lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)))
+                                       lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)),
+                                       biases=[(bif, bhf), (bir, bhr)])
         else:
             ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
             dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,

@@ -141,7 +141,16 @@ def can_fuse_linear_fwd():
     return LSTM_MMA == 1
 
 
-def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True):
+# SB_GATE_RECOMPUTE=1 (opt-in): bidirectional C = 32 passes with the fused Linear keep no gate records in the forward and
+# the fused backward recomputes the gates on the matrix pipe.  Measured (big, B = 16, same box): forward intra-frame
+# recurrence 780 -> 613 us, fused backward 1393 -> 1886 us, train step 539 -> 510 utt/s -- the backward is bound by
+# instruction issue and LDS traffic, not by the record bytes, so this is a MEMORY-saving mode (BPTT records of the
+# intra-frame passes 640 -> 128 B per position and direction), not a speed-up.  Gradients stay inside the test bars.
+GATE_RECOMPUTE = os.environ.get("SB_GATE_RECOMPUTE", "0") == "1"
+
+
+def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True,
+             no_gates=False):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
     lin = (lin_w [C, 64], lin_b [C], y [P, C]): fused  y = x + lin_w . hs + lin_b  (single direction,
     can_fuse_linear_fwd()); with want_hs=False hs is then not materialised.
@@ -161,7 +170,10 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         # opaque to the host: on the 16-bit matrix path the records are blocked per (16-sequence tile, step, direction)
         # in the kernels' lane order (include/sound_bubble_hip.h), hence the rows padded to whole tiles
         Pr = (geom.nseq + 15) // 16 * 16 * geom.nsteps if LSTM_MMA else geom.P
-        gates = torch.empty(Pr, ndir, 4 * H, device=dev, dtype=torch.float16)
+        if no_gates:          # records without gates (the backward recomputes them): fp16 side outputs required
+            assert aux16 and lin is not None and ndir == 2
+        else:
+            gates = torch.empty(Pr, ndir, 4 * H, device=dev, dtype=torch.float16)
         cprev = torch.empty(Pr, ndir, H, device=dev, dtype=torch.float16 if LSTM_MMA else torch.float32)
     elif save:
         gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32)
@@ -190,8 +202,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     # design bytes of this launch
     by = 4.0 * Cc * geom.P                                               # x rows (both directions share them)
     by += geom.P * ndir * (hs.element_size() * H if hs is not None else 0.0)    # hidden sequence out
-    if gates is not None:                                                # BPTT records + saved LayerNorm output
-        by += geom.P * ndir * (gates.element_size() * gates[0, 0].numel()
+    if gates is not None or cprev is not None:                           # BPTT records + saved LayerNorm output
+        by += geom.P * ndir * ((gates.element_size() * gates[0, 0].numel() if gates is not None else 0)
                                + (cprev.element_size() * H if cprev is not None else 0)) + u.element_size() * Cc * geom.P
     if lin is not None:
         by += 2 * 4.0 * Cc * geom.P                                      # residual rows in, y out
@@ -439,7 +451,7 @@ def add3(x, part):
 
 
 def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=None, dy=None, w_lin=None, gmax=None,
-                      lin_targets=None):
+                      lin_targets=None, biases=None):
     """Backward of a bidirectional LSTM pass, recurrence + streaming part in one launch (persistent workgroups, dgates in
     LDS).  Incoming gradient: dhs [P, 128], or dy [P, C] with w_lin [C, 128] (fused Linear backward, C == 32).
     u [P, C] fp16, hs [P, 128] fp32; targets[d] = (dW_ih, dW_hh, db_ih, db_hh) accumulated into.  -> du [P, 2, C]"""
@@ -454,7 +466,13 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 2
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
     a.w_hh[0], a.w_hh[1] = _p(w_hh_list[0]), _p(w_hh_list[1])
-    a.save_gates = C.c_void_p(rec.data_ptr())
+    if rec is None:           # the forward kept no gate records: recompute them (needs the forward biases)
+        assert biases is not None and hs.dtype == torch.float16 and dy is not None
+        a.recompute = 1
+        for d in range(2):
+            a.b_ih[d], a.b_hh[d] = _p(biases[d][0]), _p(biases[d][1])
+    else:
+        a.save_gates = C.c_void_p(rec.data_ptr())
     a.save_c = C.c_void_p(cprev.data_ptr())
     a.gmax, a.mma = _p(gmax), LSTM_MMA
     if dy is not None:
@@ -477,7 +495,8 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
     a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
-    by = geom.P * (2 * 640.0 + (4.0 * Cc if dy is not None else 8.0 * H) + 2.0 * H * hs.element_size() + 2.0 * Cc + 8.0 * Cc)
+    by = geom.P * (2 * (640.0 if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
+                   + 2.0 * H * hs.element_size() + 2.0 * Cc + 8.0 * Cc)
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)", fl,
