@@ -56,15 +56,17 @@ class WeightForms:
         self.max_elems = max(N * K for _, _, _, N, K in self.specs)
         self._key = None
 
-    def refresh(self):
-        """-> dict key -> dense form.  Launches the gather only when a source parameter may have changed."""
+    def refresh(self, force=False):
+        """-> dict key -> dense form.  Launches the gather only when a source parameter may have changed (always with
+        `force`: a training forward refreshes unconditionally -- one 5 us launch -- so that an in-place update that
+        bypasses torch's version counters, e.g. through `.data`, can never leave stale forms behind)."""
         if not self.specs:
             return self.views
         ptrs = tuple(p.data_ptr() for _, p, _, _, _ in self.specs)
         if self.arena is None or ptrs != self._ptrs:                 # first use / parameters moved (FlatBucket, .to())
             self._build()
         key = (WEIGHT_EPOCH, tuple(p._version for _, p, _, _, _ in self.specs))
-        if key != self._key:
+        if force or key != self._key:
             if not (self.arena.is_cuda and self._table.is_cuda):
                 raise L.SoundBubbleHipError("weight forms: parameters must live on the GPU")
             L.check(L.load().sb_wview_gather(C.c_void_p(self._table.data_ptr()), len(self.specs), self.max_elems,

@@ -245,7 +245,7 @@ class _NetBase(nn.Module):
         st = input_state
         Fn.GRAD_MODE = torch.is_grad_enabled()      # BPTT records are written only when a backward pass can follow
         e = self._embed(inputs.get("dis_embed"))
-        wf = self._weight_forms().refresh()
+        wf = self._weight_forms().refresh(force=self.training and torch.is_grad_enabled())
         ln = tg.conv[1] if self.use_first_ln else None
         y, st["conv_buf"] = Fn.FrontEndFn.apply(
             x.float(), tg.enc.filterbank._filters, tg.conv[0].weight, tg.conv[0].bias,

@@ -190,3 +190,40 @@ def test_resume_from_reference_format_checkpoint_takes_the_reference_third_step(
             p, o = hl.bucket.params[i], hl.bucket.offsets[i]
             got = hl.optimizer.m[o:o + p.numel()].view(p.shape).cpu().numpy()
             assert rel_l2(got, gold[k]) < (2e-4 if exact else 2e-3), k
+
+
+def test_weight_forms_follow_parameter_updates(torch_gpu):
+    """forms.WeightForms: the kernel-layout copies of the conv weights are refreshed when a parameter changes -- through
+    torch (version counters), through the fused Adam kernel (weight epoch), after FlatBucket re-points the parameters --
+    and NOT re-gathered in an inference loop."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import forms
+    from sound_bubble_amd.train import FlatBucket, FusedAdam
+    rec, params, _ = load_golden("tiny_small")
+    m = sb.NetOptim(**params)
+    m.load_state_dict(golden_state_dict(rec, torch))
+    m = m.cuda().eval()
+    x = {"mixture": torch.from_numpy(rec["mixture"]).cuda()}
+    with torch.no_grad():
+        y0 = m(x)["output"].clone()
+        wf = m._weight_forms()
+        key0 = wf._key
+        y1 = m(x)["output"]
+        assert wf._key == key0 and torch.equal(y0, y1)                 # nothing changed: no re-gather, same result
+        m.tfgridnet.blocks[0].conv.weight.mul_(1.5)                    # torch in-place update: version counter
+        y2 = m(x)["output"].clone()
+        assert wf._key != key0 and not torch.equal(y2, y0)
+        bucket = FlatBucket(m)                                         # parameters move into the flat bucket
+        y3 = m(x)["output"]
+        assert torch.equal(y3, y2)
+        opt = FusedAdam(bucket, lr=1e-2)
+        bucket.grad.fill_(1e-3)
+        e0 = forms.WEIGHT_EPOCH
+        opt.step()                                                     # the HIP kernel writes behind torch's back
+        assert forms.WEIGHT_EPOCH == e0 + 1
+        y4 = m(x)["output"]
+        assert not torch.equal(y4, y2)
+        ref = sb.NetOptim(**params).cuda().eval()                      # a fresh model with the updated weights agrees
+        ref.load_state_dict(m.state_dict())
+        assert torch.equal(ref(x)["output"], y4)

@@ -179,11 +179,14 @@ def test_streaming_matches_reference(torch_gpu, name, cls):
 #   fused-segmented  -- the same under the time-segmented schedule (forward and backward recurrences cut into
 #                       (tile, segment) items handed from workgroup to workgroup), forced through sched_workers/segments;
 #   exact            -- SB_EXACT_BPTT=1 arithmetic (fp32 records, fp32 dgates).
-DISPATCH = ["default", "fused", "fused-segmented", "exact"]
+#   recompute        -- SB_GATE_RECOMPUTE=1: no gate records in the C = 32 intra-frame passes, the fused bidirectional
+#                       backward recomputes the gates on the matrix pipe (memory-saving mode).
+DISPATCH = ["default", "fused", "fused-segmented", "exact", "recompute"]
 
 
 def _set_dispatch(monkeypatch, ops, mode):
     monkeypatch.setattr(ops, "COMPACT_BPTT", mode != "exact")
+    monkeypatch.setattr(ops, "GATE_RECOMPUTE", mode == "recompute")
     monkeypatch.setattr(ops, "SCHED_OVERRIDE", (4, 2) if mode == "fused-segmented" else None)
     if mode in ("fused", "fused-segmented"):
         monkeypatch.setenv("SB_FORCE_FUSED_BPTT", "1")
