@@ -164,3 +164,25 @@ def test_two_ranks_on_one_gpu_stay_bit_identical_through_plateau_scheduler():
     np.testing.assert_allclose(merged_val, [1.0, 1.75, 2.5])   # every rank sees the merged epoch mean
     assert lrs == [2e-3, 1e-3, 5e-4], lrs                      # plateau seen on the MERGED loss (rank 0 alone improves)
     assert ragged
+
+
+def test_bench_contract_under_torchrun_two_ranks_one_gpu():
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`)
+    with 2 ranks on GPU 0 (SB_FORCE_DEVICE / SB_DIST_BACKEND=gloo hooks): rank 0 prints ONE JSON line, whole-job value,
+    weak scaling, max-over-ranks timing, the all-reduce inside the timed step."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SB_FORCE_DEVICE="0", SB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "small", "--batch", "4", "--no-exact"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["kernel"]
