@@ -208,14 +208,16 @@ DTYPE_TRAIN = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+
 DTYPE_EXACT = "f32 storage/accumulate; forward products fp16 hi+lo split (fp32-class); BPTT state fp32 (SB_EXACT_BPTT=1)"
 DTYPE_FWD = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo split operands (3 products per MAC, fp32-class)"
 
-# rocprof kernel-name patterns of the labels ops.PROFILE uses (for the committed PMC traffic JSONs)
+# rocprof kernel-name patterns of the labels ops.PROFILE uses (for the committed PMC traffic JSONs, whose keys are
+# "<kernel name> grid=<threads>").  The two forward recurrences share one instantiation since the intra-frame pass applies
+# its Linear in the kernel too: they are told apart by the grid (bidirectional = twice the workgroups of more tiles).
 PMC_PATTERNS = [
-    ("intra-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, false, \d+, false, true>"),
-    ("inter-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, (16|32), \w+, false>"),
-    ("recurrence only", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, 0, false, false>"),
-    ("lstm_bwd_stream", r"lstm_bwd_stream_f16_kernel"),
-    ("intra-frame (bidirectional)", r"lstm_fwd_bf_kernel<\d+, \d, \w+, true, false, false>"),
-    ("inter-frame (Linear fused)", r"lstm_fwd_bf_kernel<\d+, \d, \w+, true, true, \w+>"),
+    ("intra-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, false, \d+, false, true", None),
+    ("inter-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, (16|32), \w+, false", None),
+    ("recurrence only", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, 0, false, false", None),
+    ("lstm_bwd_stream", r"lstm_bwd_stream_f16_kernel", None),
+    ("intra-frame (bidirectional)", r"lstm_fwd_bf_kernel<", "max-grid"),
+    ("inter-frame (Linear fused)", r"lstm_fwd_bf_kernel<", "min-grid"),
 ]
 
 
@@ -225,10 +227,16 @@ def pmc_traffic(workload, label):
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}.json")))
-    pat = next((p for key, p in PMC_PATTERNS if key in label), None)
-    if not files or pat is None:
+    ent = next(((p, sel) for key, p, sel in PMC_PATTERNS if key in label), None)
+    if not files or ent is None:
         return None, None
-    ks = [v for k, v in json.load(open(files[-1]))["kernels"].items() if re.search(pat, k)]
+    pat, sel = ent
+    ks = [(k, v) for k, v in json.load(open(files[-1]))["kernels"].items() if re.search(pat, k)]
+    if sel and ks:
+        grid = lambda k: int(re.search(r"grid=(\d+)", k).group(1))
+        pick = (max if sel == "max-grid" else min)(grid(k) for k, _ in ks)
+        ks = [(k, v) for k, v in ks if grid(k) == pick]
+    ks = [v for _, v in ks]
     if not ks:
         return None, None
     return (sum(v["hbm_bytes"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks),
