@@ -60,6 +60,10 @@ typedef struct {
      Records without gates: save_c != NULL with save_gates == NULL (aux_f16 only) stores c_prev, u and hs but not the four
      gates -- for a backward that recomputes them (sb_lstm_bwd_args.recompute). */
   const float* lin_w; const float* lin_b; float* y;
+  /* ... and the consumer side of the partial mode (ndir == 1, lin_w != NULL, C == 32): when x_part != NULL ([P, 2, C], the
+     y of a preceding bidirectional call) the input row of position p is x[p] + x_part[p, 0] + x_part[p, 1] (summed as
+     sb_add3 does); x_sum (nullable, [P, C]) receives that sum -- the backward kernels' pre-LayerNorm input. */
+  const float* x_part; float* x_sum;
   /* optional scratch for time-segmented scheduling of single-direction passes with more 16-sequence tiles than the
      chip has CUs (mma == 1): seg_state [ceil(nseq/16) * 2 * 16 * 64] floats, seg_flags [ceil(nseq/16)] ints (zeroed by
      the call).  seg_count / seg_len are filled in by the library; pass 0. */

@@ -162,7 +162,12 @@ struct XVec { float v[C / 16]; };
 // run 1.8 T with most CUs idle half the time; cut into k segments the makespan is ceil(290 k / 256) / k ~ 1.14 T.
 // Item i = segment * ntiles + tile goes to workgroup i mod W in increasing order; its predecessor i - ntiles lies in an
 // earlier round (ntiles >= W), so every wait is on an item some resident workgroup is already past or working on.
-template <int C, int SAVE, bool FULL, bool F16, bool LIN, bool SEG>
+// SUM3 (single-direction passes that follow a bidirectional pass in partial-Linear mode): the input row is
+// x[p] + x_part[p, 0, :] + x_part[p, 1, :] -- the residual and the two directions' halves of the intra-frame Linear --
+// summed by the loader as it fetches the row (the separate elementwise pass, 16 C bytes per position, is gone); the sum
+// is written once to x_sum for the backward kernels (training) and handed to the fused Linear's residual through a
+// four-row LDS ring (the residual is needed two barriers after the row was normalised).
+template <int C, int SAVE, bool FULL, bool F16, bool LIN, bool SEG, bool SUM3 = false>
 __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   typedef Prec<F16> PR;
   typedef typename PR::elem elem;
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   __shared__ __attribute__((aligned(16))) elem U16[2][NT][16][UP];      // [buf][term][seq][channel]
   __shared__ __attribute__((aligned(16))) elem H16[2][NT][16][HP16];    // [buf][term][seq][unit]
   __shared__ __attribute__((aligned(16))) float Bias[4][H];
+  __shared__ __attribute__((aligned(16))) float XS[SUM3 ? 4 : 1][SUM3 ? 16 : 1][SUM3 ? C + 4 : 1];   // summed input rows (ring)
 
   // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
   const float* __restrict__ wih = a.w_ih[dir];
@@ -250,6 +256,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     const float* p = a.x + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) r.v[v] = (SB_EXP_SKIP & 64) ? (float)((s + v + lane) & 7) * 0.25f : (lvalid ? p[v] : 0.f);
+    if constexpr (SUM3) {
+      const float* p0 = a.x_part + (lbase + (int64_t)st * a.p_step) * (2 * C) + cpart * VPT;
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) r.v[v] = lvalid ? (r.v[v] + p0[v]) + p0[C + v] : 0.f;      // (x + part0) + part1, as sb_add3
+    }
     return r;
   };
   auto ln_store = [&](const XVec<C>& xv, int buf, int s) {
@@ -269,6 +280,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       splitn1<F16>(u[v], e);
 #pragma unroll
       for (int n = 0; n < NT; ++n) U16[buf][n][ls][cpart * VPT + v] = e[n];
+    }
+    if constexpr (SUM3) {
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) XS[s & 3][ls][cpart * VPT + v] = xv.v[v];
+      if (a.x_sum && lvalid) {
+        const int st = rev ? S - 1 - s : s;
+        float* p = a.x_sum + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) p[v] = xv.v[v];
+      }
     }
     if (SAVE && lvalid && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
       const int st = rev ? S - 1 - s : s;
@@ -356,7 +377,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     if (linw && cvalid && !lin_part && !(SB_EXP_SKIP & 32)) {
       const int st = rev ? S - 1 - sy : sy;
       const int64_t pos = cbase + (int64_t)st * a.p_step;
-      xres = ld4(a.x + pos * C + 16 * w + 4 * q);
+      if constexpr (SUM3) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);
+      else xres = ld4(a.x + pos * C + 16 * w + 4 * q);
     }
   };
 
@@ -1366,6 +1388,18 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
 #define SB_L(CC, SV, FL, HF, LN, SG) do { \
     if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>>()) return -1008; \
     hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>), grid, dim3(256), 0, st, a); } while (0)
+  if (a.x_part) {        // summed-input mode: single direction, fused Linear, C = 32, inference or fp16 side outputs
+    if (!lin || a.ndir != 1 || a.C != 32 || (save != 0 && save != 3)) return -1003;
+#define SB_L3(SV, FL, SG) do { \
+    if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<32, SV, FL, true, true, SG, true>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, SG, true>), grid, dim3(256), 0, st, a); } while (0)
+#define SB_L3F(SV) do { if (full) { if (seg) SB_L3(SV, true, true); else SB_L3(SV, true, false); } \
+                        else { if (seg) SB_L3(SV, false, true); else SB_L3(SV, false, false); } } while (0)
+    if (save == 0) SB_L3F(0); else SB_L3F(3);
+#undef SB_L3F
+#undef SB_L3
+    return 0;
+  }
 #define SB_LT(CC, SV, FL) do { \
     if (seg) { if (lin) SB_L(CC, SV, FL, true, true, true); else SB_L(CC, SV, FL, true, false, true); } \
     else if (lin) SB_L(CC, SV, FL, true, true, false); else if (f16) SB_L(CC, SV, FL, true, false, false); \

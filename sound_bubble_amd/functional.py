@@ -51,7 +51,10 @@ class IntraPlainFn(torch.autograd.Function):
     optim/tfgridnet_causal.py:699-707."""
 
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, lin_w, lin_b):
+    def forward(ctx, x, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, lin_w, lin_b, defer_sum=False):
+        """defer_sum: return the two per-direction partial products `part` [B, T, F, 2, C] instead of
+        y = x + part[..., 0, :] + part[..., 1, :]; the InterFn that follows forms the sum in its loader (and owns the
+        residual's forward); the gradient that comes back for `part` is the gradient of that sum, broadcast."""
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
@@ -65,8 +68,9 @@ class IntraPlainFn(torch.autograd.Function):
             hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train,
                                            lin=(lin_w.contiguous(), lin_b, part), want_hs=train,
                                            no_gates=train and ops.GATE_RECOMPUTE)
-            y = ops.add3(x.view(P, Cc), part).view(B, T, F, Cc)
+            y = part.view(B, T, F, 2, Cc) if defer_sum else ops.add3(x.view(P, Cc), part).view(B, T, F, Cc)
         else:
+            assert not defer_sum
             hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train)
             y = torch.empty_like(x)
             g, s_in = dense(P, 2 * H)
@@ -77,6 +81,7 @@ class IntraPlainFn(torch.autograd.Function):
                                   *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
             ctx.no_gates = gates[0] is None          # records without gates: the fused backward recomputes them
+            ctx.defer_sum = bool(defer_sum)
         return y
 
     @staticmethod
@@ -86,6 +91,8 @@ class IntraPlainFn(torch.autograd.Function):
         gt = _GradTargets()
         B, T, F, Cc = ctx.dims
         P = B * T * F
+        if ctx.defer_sum:                      # [B, T, F, 2, C], both halves equal (a stride-0 broadcast): take one
+            dy = dy[..., 0, :]
         dy = dy.contiguous()
         geom = Geom.intra(B * T, F)
         gP, sC = dense(P, Cc)
@@ -114,7 +121,7 @@ class IntraPlainFn(torch.autograd.Function):
                                  hint=True)
         dx = dx.view(B, T, F, Cc)
         return (dx, gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"], gt["wir"], gt["whr"], gt["bir"],
-                gt["bhr"], gt["lin_w"], gt["lin_b"])
+                gt["bhr"], gt["lin_w"], gt["lin_b"], None)
 
 
 class InterFn(torch.autograd.Function):
@@ -122,7 +129,10 @@ class InterFn(torch.autograd.Function):
     optim :709-728.  Returns (y, hN, cN); the state rows are b*F+f as in the reference."""
 
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0):
+    def forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0, part=None):
+        """part (optional, [B, T, F, 2, C]): the deferred halves of the preceding IntraPlainFn -- the block input is then
+        x + part[..., 0, :] + part[..., 1, :], summed by the kernel's loader; x is the intra-frame block's own input and
+        gets NO gradient from here (the residual's gradient is applied by IntraPlainFn.backward, as before)."""
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
@@ -132,10 +142,17 @@ class InterFn(torch.autograd.Function):
         c0c = c0.reshape(B * F, H).contiguous() if c0 is not None else None
         y = torch.empty_like(x)
         fuse = ops.can_fuse_linear_fwd()            # Linear + residual applied inside the recurrent kernel
+        x_sum = None
+        if part is not None:
+            assert fuse and Cc == 32
+            x_sum = torch.empty_like(x) if train else None
         hs, (hN, cN), gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, [(wi, wh, bi, bh)], geom, h0=h0c, c0=c0c,
                                               save=train, want_state=True,
                                               lin=(lin_w.contiguous(), lin_b, y) if fuse else None,
-                                              want_hs=train or not fuse)
+                                              want_hs=train or not fuse,
+                                              x_part=part.contiguous() if part is not None else None, x_sum=x_sum)
+        if part is not None and train:
+            x = x_sum                               # the block's real input: what the backward's LayerNorm needs
         if not fuse:
             g, s_in = dense(P, H)
             _, s_out = dense(P, Cc)
@@ -143,6 +160,7 @@ class InterFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
+            ctx.deferred = part is not None
         hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
         ctx.mark_non_differentiable(hN, cN)
         return y, hN, cN
@@ -156,6 +174,17 @@ class InterFn(torch.autograd.Function):
         P = B * T * F
         dy = dy.contiguous()
         geom = Geom.inter(B, T, F)
+
+        def ret(dx):
+            # deferred sum: the gradient of x + part0 + part1 goes to `part` (broadcast over the two halves, no copy) and
+            # NOT to x -- IntraPlainFn.backward applies the residual's share itself
+            if ctx.deferred:
+                dpart = dx.view(B, T, F, 1, Cc).expand(B, T, F, 2, Cc)
+                return (None, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
+                        None, None, dpart)
+            return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
+                    None, None, None)
+
         gP, sC = dense(P, Cc)
         _, sH = dense(P, H)
         fuse = ops.can_fuse_linear_bwd()
@@ -172,8 +201,7 @@ class InterFn(torch.autograd.Function):
                                     lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)), ln=ln).view(P, 1, Cc)
             if ln is not None:                         # ... and the LayerNorm backward + residual: du is dx already
                 dx = du.view(B, T, F, Cc)
-                return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
-                        None, None)
+                return ret(dx)
         else:
             ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
             dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
@@ -181,13 +209,12 @@ class InterFn(torch.autograd.Function):
             if ops.can_fuse_stream_ln(dg, u, hs):          # ... and the LayerNorm backward + residual in the same pass
                 _, dx = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F, targets=tg,
                                             ln=(x.view(P, Cc), ln_g, dy.view(P, Cc), gt("ln_g", ln_g), gt("ln_b", ln_b)))
-                return (dx.view(B, T, F, Cc), gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"],
-                        gt["lin_b"], None, None)
+                return ret(dx.view(B, T, F, Cc))
             _, du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F, targets=tg)
         dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
                                  hint=True)
         dx = dx.view(B, T, F, Cc)
-        return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"], None, None)
+        return ret(dx)
 
 
 class IntraConvFn(torch.autograd.Function):

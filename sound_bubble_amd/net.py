@@ -255,6 +255,7 @@ class _NetBase(nn.Module):
         for i, blk in enumerate(tg.blocks):
             y = self._film(y, e, i)
             rnn = blk.intra_rnn
+            part = None
             if self.conv_lstm:
                 y = Fn.IntraConvFn.apply(y, blk.conv.weight, blk.conv.bias, blk.act.weight, blk.norm.norm.weight,
                                          blk.norm.norm.bias, *_lstm_dir(rnn, False), *_lstm_dir(rnn, True),
@@ -262,13 +263,18 @@ class _NetBase(nn.Module):
                                          self.flavour == "optim", wf[f"wc{i}"], wf[f"wd{i}"], wf[f"bd{i}"],
                                          wf[f"wdT{i}"], wf[f"wcT{i}"])
             else:
-                y = Fn.IntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
-                                          *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
-                                          blk.intra_linear.bias)
+                # the sum x + part0 + part1 that finishes the intra-frame Linear is formed by the inter-frame kernel's loader
+                defer = (Fn.ops.INTER_SUM3 and y.shape[-1] == 32 and
+                         Fn.ops.intra_lin_fusion_ok(torch.is_grad_enabled(), y.shape[-1]))
+                part = Fn.IntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
+                                             *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
+                                             blk.intra_linear.bias, defer)
+                if not defer:
+                    y, part = part, None
             b = gb[f"buf{i}"]
             y, b["h0"], b["c0"] = Fn.InterFn.apply(y, blk.inter_norm.norm.weight, blk.inter_norm.norm.bias,
                                                    *_lstm_dir(blk.inter_rnn, False), blk.inter_linear.weight,
-                                                   blk.inter_linear.bias, b["h0"], b["c0"])
+                                                   blk.inter_linear.bias, b["h0"], b["c0"], part)
             if self.use_attn:
                 args = []
                 for name in ("attn_conv_Q", "attn_conv_K", "attn_conv_V", "attn_concat_proj"):

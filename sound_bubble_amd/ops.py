@@ -150,7 +150,7 @@ GATE_RECOMPUTE = os.environ.get("SB_GATE_RECOMPUTE", "0") == "1"
 
 
 def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True,
-             no_gates=False):
+             no_gates=False, x_part=None, x_sum=None):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
     lin = (lin_w [C, 64], lin_b [C], y [P, C]): fused  y = x + lin_w . hs + lin_b  (single direction,
     can_fuse_linear_fwd()); with want_hs=False hs is then not materialised.
@@ -196,6 +196,9 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         assert can_fuse_linear_fwd() and lin[0].shape == (Cc, ndir * H) and lin[2].numel() == geom.P * ndir * Cc
         a.lin_w, a.lin_b, a.y = _p(lin[0]), _p(lin[1]), _p(lin[2])
     a.save_gates = C.c_void_p(gates.data_ptr()) if gates is not None else None
+    if x_part is not None:    # summed-input mode: x + x_part[:, 0] + x_part[:, 1] formed by the loader (see the header)
+        assert ndir == 1 and lin is not None and Cc == 32 and x_part.numel() == geom.P * 2 * Cc
+        a.x_part, a.x_sum = _p(x_part), _p(x_sum)
     seg_scratch = None
     if ndir == 1 and LSTM_MMA == 1 and TIME_SEGMENTS:       # scratch for time-segmented scheduling (used when it pays)
         seg_scratch = _seg_scratch(a, geom, dev)
@@ -207,6 +210,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
                                + (cprev.element_size() * H if cprev is not None else 0)) + u.element_size() * Cc * geom.P
     if lin is not None:
         by += 2 * 4.0 * Cc * geom.P                                      # residual rows in, y out
+    if x_part is not None:
+        by += (2 + (1 if x_sum is not None else 0)) * 4.0 * Cc * geom.P - 4.0 * Cc * geom.P   # two halves in, sum out; no second read of x
     label = f"lstm_fwd_bf_kernel C={Cc} " + ("intra-frame (bidirectional)" if ndir == 2 else "inter-frame (Linear fused)"
                                              if lin is not None else "inter-frame")
     with _Prof(label, 2.0 * 4 * H * (Cc + H) * geom.P * ndir + (2.0 * H * Cc * geom.P if lin is not None else 0.0),
@@ -440,6 +445,11 @@ def intra_lin_fusion_ok(train, Cc):
     if not (INTRA_LIN_FUSION and can_fuse_linear_fwd() and Cc == 32):
         return False
     return (not train) or (can_fuse_linear_bwd() and FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and AUX_FP16)
+
+
+# ... and the elementwise pass that finishes it (x + part0 + part1) is done by the loader of the inter-frame forward
+# recurrence that follows (SB_NO_INTER_SUM3=1: sb_add3 as a separate pass)
+INTER_SUM3 = os.environ.get("SB_NO_INTER_SUM3", "0") != "1"
 
 
 def add3(x, part):

@@ -729,3 +729,40 @@ def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(
         assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-6
     if ops.ABSMAX_HINTS:
         assert float(ops.absmax_or_hint(dx)) == float(dx.abs().max())
+
+
+@pytest.mark.parametrize("sched", [None, (4, 3)], ids=["plain", "time-segmented"])
+@pytest.mark.parametrize("save", [False, True], ids=["inference", "training"])
+def test_inter_forward_with_summed_input_is_bit_identical_to_add3(torch_gpu, sched, save, monkeypatch):
+    """sb_lstm_fwd_args.x_part: the single-direction forward recurrence whose loader forms x + part[:, 0] + part[:, 1]
+    itself (the deferred halves of the intra-frame Linear) against sb_add3 followed by the plain call -- same summation
+    order, so y, the final state, hs, the LayerNorm output and the side output x_sum must be bit-identical; also under
+    the time-segmented schedule (the residual travels through the LDS ring across segment hand-offs)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    if not ops.can_fuse_linear_fwd():
+        pytest.skip("fp16x3 forward only")
+    monkeypatch.setattr(ops, "SCHED_OVERRIDE", sched)
+    torch.manual_seed(31)
+    C_, B_, T_, F_ = 32, 2, 23, 145
+    geom = ops.Geom.inter(B_, T_, F_)
+    x = torch.randn(geom.P, C_, device="cuda")
+    part = torch.randn(geom.P, 2, C_, device="cuda") * 0.3
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    dirs = [tuple(t.cuda() for t in (torch.randn(256, C_) * 0.2, torch.randn(256, 64) * 0.2, torch.randn(256) * 0.1,
+                                     torch.randn(256) * 0.1))]
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    h0, c0 = torch.randn(geom.nseq, 64, device="cuda") * 0.3, torch.randn(geom.nseq, 64, device="cuda") * 0.3
+    xs = ops.add3(x, part)
+    y0 = torch.empty(geom.P, C_, device="cuda")
+    hs0, (hN0, cN0), _, u0 = ops.lstm_fwd(xs, g, b, dirs, geom, h0=h0, c0=c0, save=save, want_state=True,
+                                          lin=(lin_w, lin_b, y0), want_hs=save)
+    y1 = torch.empty(geom.P, C_, device="cuda")
+    x_sum = torch.empty(geom.P, C_, device="cuda") if save else None
+    hs1, (hN1, cN1), _, u1 = ops.lstm_fwd(x, g, b, dirs, geom, h0=h0, c0=c0, save=save, want_state=True,
+                                          lin=(lin_w, lin_b, y1), want_hs=save, x_part=part, x_sum=x_sum)
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    assert torch.equal(y0, y1) and torch.equal(hN0, hN1) and torch.equal(cN0, cN1)
+    if save:
+        assert torch.equal(hs0, hs1) and torch.equal(u0, u1) and torch.equal(x_sum, xs)
