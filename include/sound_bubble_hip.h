@@ -64,6 +64,11 @@ typedef struct {
      y of a preceding bidirectional call) the input row of position p is x[p] + x_part[p, 0] + x_part[p, 1] (summed as
      sb_add3 does); x_sum (nullable, [P, C]) receives that sum -- the backward kernels' pre-LayerNorm input. */
   const float* x_part; float* x_sum;
+  /* ... and FiLM in the same epilogue (ndir == 1, lin_w != NULL): when film_w != NULL, film_w / film_b [nseq, C] (the scale /
+     shift planes of the FilmLayer that follows, tfgridnet_causal.py:59-68,509-513; constant along the time walk) are applied
+     to y before it is stored, y = (x + lin_w . hs + lin_b) * film_w[n] + film_b[n]; y_pre (nullable, [P, C]) receives the
+     pre-FiLM value the FiLM backward needs. */
+  const float* film_w; const float* film_b; float* y_pre;
   /* optional scratch for time-segmented scheduling of single-direction passes with more 16-sequence tiles than the
      chip has CUs (mma == 1): seg_state [ceil(nseq/16) * 2 * 16 * 64] floats, seg_flags [ceil(nseq/16)] ints (zeroed by
      the call).  seg_count / seg_len are filled in by the library; pass 0. */

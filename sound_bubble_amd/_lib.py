@@ -21,6 +21,7 @@ class LstmFwdArgs(C.Structure):
                 ("h0", c_fp), ("c0", c_fp), ("hN", c_fp), ("cN", c_fp),
                 ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp), ("save_c", c_fp), ("mma", C.c_int),
                 ("lin_w", c_fp), ("lin_b", c_fp), ("y", c_fp), ("x_part", c_fp), ("x_sum", c_fp),
+                ("film_w", c_fp), ("film_b", c_fp), ("y_pre", c_fp),
                 ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int),
                 ("sched_status", c_fp), ("sched_workers", C.c_int), ("sched_segments", C.c_int),
                 ("aux_f16", C.c_int)]

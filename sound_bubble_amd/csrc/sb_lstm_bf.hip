@@ -237,6 +237,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   int64_t lbase = 0, cbase = 0;
   int nc = 0;
   int64_t rec_tile = 0;                         // tile * S: compact records are blocked per (tile, step, direction)
+  // FiLM of the NEXT block (dis_embd3 :509-513) in the y epilogue: y <- y * film_w[n] + film_b[n] with the planes of
+  // sequence n = (b, f) -- constant along this kernel's time walk, so eight registers per lane, loaded once per tile.
+  // The pre-FiLM value goes to y_pre when the backward needs it (training).  Replaces a pass over [B, T, F, C].
+  const bool film = LIN && a.film_w != nullptr;
+  f32x4 fw = {1.f, 1.f, 1.f, 1.f}, fb = zero4();
   auto set_tile = [&](int tile) {
     rec_tile = (int64_t)tile * S;
     const int nl = tile * 16 + ls;
@@ -245,6 +250,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     nc = tile * 16 + j;
     cvalid = FULL || nc < a.nseq;
     cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    if (film && linw && cvalid) {
+      fw = ld4(a.film_w + (size_t)nc * C + 16 * w + 4 * q);
+      fb = ld4(a.film_b + (size_t)nc * C + 16 * w + 4 * q);
+    }
   };
   float gam[VPT], bet[VPT];
 #pragma unroll
@@ -370,7 +379,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     if (linw && cvalid && !(SB_EXP_SKIP & 16)) {
       const int st = rev ? S - 1 - sy : sy;
       const int64_t pos = cbase + (int64_t)st * a.p_step;
-      st4(a.y + (lin_part ? pos * 2 + dir : pos) * C + 16 * w + 4 * q, yacc + lbias + xres);
+      f32x4 v = yacc + lbias + xres;
+      if (film) {
+        if (a.y_pre) st4(a.y_pre + pos * C + 16 * w + 4 * q, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], fw[r], fb[r]);
+      }
+      st4(a.y + (lin_part ? pos * 2 + dir : pos) * C + 16 * w + 4 * q, v);
     }
   };
   auto load_res = [&](int sy) {
@@ -1364,6 +1379,7 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   dim3 grid(ntiles, a.ndir);
   const bool lin = a.lin_w != nullptr;
   if (lin && (!f16 || !a.lin_b || !a.y)) return -1003;         // ndir == 2: per-direction partial products (see the kernel)
+  if (a.film_w && (!lin || a.ndir != 1 || !a.film_b)) return -1003;
   if (!lin && !a.hs) return -1003;
   // time-segmented scheduling (see the kernel): single direction, scratch provided, more tiles than CUs
   const int cus = device_cu_count();

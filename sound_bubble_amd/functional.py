@@ -129,10 +129,13 @@ class InterFn(torch.autograd.Function):
     optim :709-728.  Returns (y, hN, cN); the state rows are b*F+f as in the reference."""
 
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0, part=None):
+    def forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0, part=None, film_w=None, film_b=None, bank=None,
+                film_k=0):
         """part (optional, [B, T, F, 2, C]): the deferred halves of the preceding IntraPlainFn -- the block input is then
         x + part[..., 0, :] + part[..., 1, :], summed by the kernel's loader; x is the intra-frame block's own input and
-        gets NO gradient from here (the residual's gradient is applied by IntraPlainFn.backward, as before)."""
+        gets NO gradient from here (the residual's gradient is applied by IntraPlainFn.backward, as before).
+        film_w / film_b (optional, [B, F, C]): the FiLM planes of the NEXT block, applied to y in the kernel's epilogue
+        (the returned y is post-FiLM); bank / film_k as in FilmFn."""
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
@@ -146,11 +149,16 @@ class InterFn(torch.autograd.Function):
         if part is not None:
             assert fuse and Cc == 32
             x_sum = torch.empty_like(x) if train else None
+        film = None
+        if film_w is not None:
+            assert fuse
+            film = (film_w.contiguous(), film_b.contiguous(), torch.empty_like(x) if train else None)
         hs, (hN, cN), gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, [(wi, wh, bi, bh)], geom, h0=h0c, c0=c0c,
                                               save=train, want_state=True,
                                               lin=(lin_w.contiguous(), lin_b, y) if fuse else None,
                                               want_hs=train or not fuse,
-                                              x_part=part.contiguous() if part is not None else None, x_sum=x_sum)
+                                              x_part=part.contiguous() if part is not None else None, x_sum=x_sum,
+                                              film=film)
         if part is not None and train:
             x = x_sum                               # the block's real input: what the backward's LayerNorm needs
         if not fuse:
@@ -161,6 +169,7 @@ class InterFn(torch.autograd.Function):
             ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
             ctx.deferred = part is not None
+            ctx.film = (film[0], film[2], bank, film_k) if film is not None else None
         hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
         ctx.mark_non_differentiable(hN, cN)
         return y, hN, cN
@@ -174,6 +183,15 @@ class InterFn(torch.autograd.Function):
         P = B * T * F
         dy = dy.contiguous()
         geom = Geom.inter(B, T, F)
+        d_fw = d_fb = None
+        if ctx.film is not None:               # FiLM applied in the forward kernel's epilogue: its backward comes first
+            f_w, y_pre, bank, k = ctx.film
+            out = None
+            if bank is not None:
+                if bank.get("G") is None:
+                    bank["G"] = torch.zeros(bank["n"], 2, *f_w.shape, device=f_w.device, dtype=torch.float32)
+                out = (bank["G"][k, 0], bank["G"][k, 1])
+            dy, d_fw, d_fb = ops.film_bwd(y_pre, f_w, dy, out=out)
 
         def ret(dx):
             # deferred sum: the gradient of x + part0 + part1 goes to `part` (broadcast over the two halves, no copy) and
@@ -181,9 +199,9 @@ class InterFn(torch.autograd.Function):
             if ctx.deferred:
                 dpart = dx.view(B, T, F, 1, Cc).expand(B, T, F, 2, Cc)
                 return (None, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
-                        None, None, dpart)
+                        None, None, dpart, d_fw, d_fb, None, None)
             return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
-                    None, None, None)
+                    None, None, None, d_fw, d_fb, None, None)
 
         gP, sC = dense(P, Cc)
         _, sH = dense(P, H)

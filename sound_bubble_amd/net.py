@@ -252,8 +252,11 @@ class _NetBase(nn.Module):
             ln.weight if ln is not None else None, ln.bias if ln is not None else None, st["conv_buf"],
             self.use_first_ln, self.stft_chunk_size, wf["front_w"])
         gb = st["gridnet_bufs"]
+        film_done = False          # FiLM of block i already applied in block i-1's inter-frame kernel epilogue
         for i, blk in enumerate(tg.blocks):
-            y = self._film(y, e, i)
+            if not film_done:
+                y = self._film(y, e, i)
+            film_done = False
             rnn = blk.intra_rnn
             part = None
             if self.conv_lstm:
@@ -272,9 +275,15 @@ class _NetBase(nn.Module):
                 if not defer:
                     y, part = part, None
             b = gb[f"buf{i}"]
+            nf = (None, None, None, 0)
+            if (e is not None and i + 1 < len(tg.blocks) and not self.use_attn and Fn.ops.INTER_FILM
+                    and Fn.ops.can_fuse_linear_fwd()):
+                bank, planes = e                # the next block's FiLM rides in this kernel's y epilogue
+                nf = (planes[2 * i], planes[2 * i + 1], bank, i)
+                film_done = True
             y, b["h0"], b["c0"] = Fn.InterFn.apply(y, blk.inter_norm.norm.weight, blk.inter_norm.norm.bias,
                                                    *_lstm_dir(blk.inter_rnn, False), blk.inter_linear.weight,
-                                                   blk.inter_linear.bias, b["h0"], b["c0"], part)
+                                                   blk.inter_linear.bias, b["h0"], b["c0"], part, *nf)
             if self.use_attn:
                 args = []
                 for name in ("attn_conv_Q", "attn_conv_K", "attn_conv_V", "attn_concat_proj"):

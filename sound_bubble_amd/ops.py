@@ -150,7 +150,7 @@ GATE_RECOMPUTE = os.environ.get("SB_GATE_RECOMPUTE", "0") == "1"
 
 
 def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True,
-             no_gates=False, x_part=None, x_sum=None):
+             no_gates=False, x_part=None, x_sum=None, film=None):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
     lin = (lin_w [C, 64], lin_b [C], y [P, C]): fused  y = x + lin_w . hs + lin_b  (single direction,
     can_fuse_linear_fwd()); with want_hs=False hs is then not materialised.
@@ -199,6 +199,9 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     if x_part is not None:    # summed-input mode: x + x_part[:, 0] + x_part[:, 1] formed by the loader (see the header)
         assert ndir == 1 and lin is not None and Cc == 32 and x_part.numel() == geom.P * 2 * Cc
         a.x_part, a.x_sum = _p(x_part), _p(x_sum)
+    if film is not None:      # (film_w [nseq, C], film_b [nseq, C], y_pre [P, C] or None): FiLM applied to y in the kernel
+        assert ndir == 1 and lin is not None and film[0].numel() == geom.nseq * Cc
+        a.film_w, a.film_b, a.y_pre = _p(film[0]), _p(film[1]), _p(film[2])
     seg_scratch = None
     if ndir == 1 and LSTM_MMA == 1 and TIME_SEGMENTS:       # scratch for time-segmented scheduling (used when it pays)
         seg_scratch = _seg_scratch(a, geom, dev)
@@ -450,6 +453,8 @@ def intra_lin_fusion_ok(train, Cc):
 # ... and the elementwise pass that finishes it (x + part0 + part1) is done by the loader of the inter-frame forward
 # recurrence that follows (SB_NO_INTER_SUM3=1: sb_add3 as a separate pass)
 INTER_SUM3 = os.environ.get("SB_NO_INTER_SUM3", "0") != "1"
+# FiLM of the next block applied in the inter-frame forward kernel's y epilogue (SB_NO_INTER_FILM=1: sb_film_fwd pass)
+INTER_FILM = os.environ.get("SB_NO_INTER_FILM", "0") != "1"
 
 
 def add3(x, part):
