@@ -279,6 +279,10 @@ typedef struct {
      input, ln_res the residual branch's gradient), d_ln_g / d_ln_b [C] += the parameter gradients (the scratch rows
      grow by 2C floats), *absmax_out = max(*absmax_out, max |dx|) when non-NULL (zero it before the call). */
   const float* ln_x; const float* ln_g; const float* ln_res; float* dx; float* d_ln_g; float* d_ln_b; float* absmax_out;
+  /* ... and of the weight gradient of the Linear in front of that residual (tfgridnet_causal.py:844-845), whose output
+     gradient is ln_res: when d_lin_w != NULL (dx != NULL required), d_lin_w [C, 64] += ln_res^T hs and d_lin_b [C] +=
+     column sums of ln_res (the scratch rows grow by another 64C + C floats; gmax must be max |ln_res| or above). */
+  float* d_lin_w; float* d_lin_b;
 } sb_lstm_stream_args;
 int sb_lstm_bwd_stream(const sb_lstm_stream_args* a, void* stream);
 int sb_lstm_stream_grid(int64_t positions);

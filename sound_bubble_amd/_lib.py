@@ -92,7 +92,7 @@ class LstmStreamArgs(C.Structure):
                 ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int), ("gmax", c_fp),
                 ("u_f16", C.c_int), ("hs_f16", C.c_int),
                 ("ln_x", c_fp), ("ln_g", c_fp), ("ln_res", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
-                ("absmax_out", c_fp)]
+                ("absmax_out", c_fp), ("d_lin_w", c_fp), ("d_lin_b", c_fp)]
 
 
 class LnBwdArgs(C.Structure):

@@ -356,13 +356,17 @@ SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma
 // partial row, max |dx| goes to absmax_out.  After the barrier wave w takes sub-tile w >> 1, positions 8 (w & 1) + (lane & 7)
 // and channel quad lane >> 3, so the 4 CK lanes that hold one position's channels differ in lane bits 3.. and the
 // LayerNorm sums are three (two for C = 16) xor-shuffles.  Saves the du round trip (2 x 4C bytes per position) and a launch.
-template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false>
+// LINW (with LNB): the weight gradient of the Linear in front of the residual rides along as well -- its output gradient IS
+// ln_res, which the flush lanes hold; they drop it (scaled fp16) into a [channel][position] LDS tile, wave w multiplies
+// it with the UNSHIFTED hs rows of the chunk (h columns 4j + w): d_lin_w [C, 64] += dy^T hs, d_lin_b [C] += sum dy.
+template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false, bool LINW = false>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y, ndir = a.ndir;
   const int Pi = (int)a.P;
   __shared__ __attribute__((aligned(16))) float R[2][4][2][CK][64][4];
+  __shared__ __attribute__((aligned(16))) _Float16 DY[LINW ? 2 : 1][LINW ? C : 1][40];
   float invS = 1.0f;
   {
     const float m = a.gmax[0];
@@ -401,13 +405,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     h16x4 a4[8]; f32x4 h4[HS16 ? 1 : 8]; h16x4 hh4[HS16 ? 8 : 1]; h16x8 d8[2][2];
     float uv[U16 ? 1 : CK][8]; _Float16 uh[U16 ? CK : 1][8];
     f32x4 xq, rq;                                                                  // LNB: x and residual of the flush position
+    h16x4 hu[LINW ? 8 : 1];                                                        // LINW: hs of the chunk's own positions
   };
   // LNB flush role of this lane
   const int fsb = w >> 1, fjj = 8 * (w & 1) + (lane & 7), fqq = lane >> 3;
   const int fct = CK == 2 ? fqq >> 2 : 0, fqr = fqq & 3;
   const bool fact = CK == 2 || fqq < 4;
   const int fcol = 16 * fct + 4 * fqr;
-  f32x4 lgam = zero4(), dgam = zero4(), dbet = zero4();
+  f32x4 lgam = zero4(), dgam = zero4(), dbet = zero4(), dlb = zero4();
+  f32x4 lacc[CK];
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct) lacc[ct] = zero4();
+  const float gS = 1.0f / invS;                      // exact: invS is a power of two
   float amax = 0.f;
   if constexpr (LNB) lgam = ld4(a.ln_g + fcol);
   auto grp_sum = [&](float v) {                      // over the lanes holding one position's channels
@@ -436,6 +445,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       if constexpr (HS16) {
         const h16x4 hv = *reinterpret_cast<const h16x4*>(hs16 + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
         t.hh4[kk] = ok2 ? hv : hz4;
+        if constexpr (LINW) {
+          const h16x4 hu = *reinterpret_cast<const h16x4*>(hs16 + (int64_t)pc * ldh + 4 * j);
+          t.hu[kk] = ok ? hu : hz4;
+        }
       } else {
         const f32x4 hv = ld4(hs + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 4 * j);
         t.h4[kk] = ok2 ? hv : zero4();
@@ -519,7 +532,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
 #pragma unroll
       for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
     }
+    if constexpr (LINW) {
+      const bool valid = fact && ch * 32 + 16 * fsb + fjj < Pi;
+      if (fact) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = valid ? cur.rq[r] : 0.f;
+          dlb[r] += v;
+          DY[buf][fcol + r][16 * fsb + fjj] = (_Float16)(v * gS);
+        }
+      }
+    }
     __syncthreads();
+    if constexpr (LINW) {
+      h16x8 Bu;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) Bu[kk] = cur.hu[kk][w];
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct)
+        lacc[ct] = mfma_h(*reinterpret_cast<const h16x8*>(&DY[buf][16 * ct + j][8 * q]), Bu, lacc[ct]);
+    }
     if constexpr (LNB) {
       const int rl = fqr * 16 + fjj;
       const int pj = ch * 32 + 16 * fsb + fjj;
@@ -568,7 +600,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   }
 
   constexpr int Ktot = C + H;
-  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) * ((size_t)4 * H * Ktot + 4 * H + (LNB ? 2 * C : 0));
+  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) *
+                                ((size_t)4 * H * Ktot + 4 * H + (LNB ? 2 * C : 0) + (LINW ? C * H + C : 0));
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -591,13 +624,27 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       float g = dgam[r], b = dbet[r];
       g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64); g += __shfl_xor(g, 4, 64);
       b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64);
-      if ((lane & 7) == 0 && fact) { red[(w * 2 + 0) * C + fcol + r] = g; red[(w * 2 + 1) * C + fcol + r] = b; }
+      if ((lane & 7) == 0 && fact) { red[(w * 3 + 0) * C + fcol + r] = g; red[(w * 3 + 1) * C + fcol + r] = b; }
+      if constexpr (LINW) {
+        float l = dlb[r];
+        l += __shfl_xor(l, 1, 64); l += __shfl_xor(l, 2, 64); l += __shfl_xor(l, 4, 64);
+        if ((lane & 7) == 0 && fact) red[(w * 3 + 2) * C + fcol + r] = l;
+      }
     }
     __syncthreads();
-    if (tid < 2 * C) {
+    if (tid < (LINW ? 3 : 2) * C) {
       const int which = tid / C, c = tid % C;
-      part[(size_t)4 * H * Ktot + 4 * H + tid] = red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c] +
-                                                  red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c];
+      const float v = red[(0 * 3 + which) * C + c] + red[(1 * 3 + which) * C + c] + red[(2 * 3 + which) * C + c] +
+                      red[(3 * 3 + which) * C + c];
+      // layout of the extras: d(ln_g) [C], d(ln_b) [C], d(lin_w) [C, 64], d(lin_b) [C]
+      part[(size_t)4 * H * Ktot + 4 * H + (which < 2 ? tid : 2 * C + C * H + c)] = v;
+    }
+    if constexpr (LINW) {
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          part[(size_t)4 * H * Ktot + 4 * H + 2 * C + (size_t)(16 * ct + 4 * q + r) * H + 4 * j + w] = lacc[ct][r] * invS;
     }
     if (a.absmax_out) {                              // one atomic per workgroup
       for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
@@ -769,16 +816,19 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
     if (ap->ndir != 1 || !ap->gmax || !ap->u_f16 || !ap->hs_f16 || !ap->ln_x || !ap->ln_g || !ap->ln_res || !ap->d_ln_g ||
         !ap->d_ln_b)
       return -1003;
-#define SB_SL(CC) do { if (sm) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, true, true, true, true>), grid, block, 0, st, *ap); \
-                       else hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true>), grid, block, 0, st, *ap); } while (0)
-    if (ap->C == 32) SB_SL(32); else SB_SL(16);
+    const bool linw = ap->d_lin_w != nullptr;
+    if (linw && !ap->d_lin_b) return -1003;
+#define SB_SL(CC, LW) do { if (sm) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, true, true, true, true, LW>), grid, block, 0, st, *ap); \
+                           else hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, LW>), grid, block, 0, st, *ap); } while (0)
+    if (linw) { if (ap->C == 32) SB_SL(32, true); else SB_SL(16, true); }
+    else { if (ap->C == 32) SB_SL(32, false); else SB_SL(16, false); }
 #undef SB_SL
     SB_CHECK_LAUNCH();
-    const int tot = 4 * H * (ap->C + H) + 4 * H;
-    const int ex_off[2] = {tot, tot + ap->C}, ex_n[2] = {ap->C, ap->C};
-    float* const ex_out[2] = {ap->d_ln_g, ap->d_ln_b};
-    return sb_launch_stream_reduce(ap->scratch, gx, (int64_t)tot + 2 * ap->C, ap->C, ap->dW_ih[0], ap->dW_hh[0], ap->db_ih[0],
-                                   ap->db_hh[0], st, 2, ex_off, ex_n, ex_out);
+    const int tot = 4 * H * (ap->C + H) + 4 * H, Cc = ap->C;
+    const int ex_off[4] = {tot, tot + Cc, tot + 2 * Cc, tot + 2 * Cc + Cc * H}, ex_n[4] = {Cc, Cc, Cc * H, Cc};
+    float* const ex_out[4] = {ap->d_ln_g, ap->d_ln_b, ap->d_lin_w, ap->d_lin_b};
+    return sb_launch_stream_reduce(ap->scratch, gx, (int64_t)tot + 2 * Cc + (linw ? Cc * H + Cc : 0), Cc, ap->dW_ih[0],
+                                   ap->dW_hh[0], ap->db_ih[0], ap->db_hh[0], st, linw ? 4 : 2, ex_off, ex_n, ex_out);
   }
   if (ap->gmax) { if (ap->C == 32) SB_SHC(32); else SB_SHC(16); }
   else if (ap->split_bf16) { if (ap->C == 32) SB_S(lstm_bwd_stream_bf16_kernel, 32); else SB_S(lstm_bwd_stream_bf16_kernel, 16); }

@@ -221,13 +221,18 @@ class InterFn(torch.autograd.Function):
                 dx = du.view(B, T, F, Cc)
                 return ret(dx)
         else:
-            ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
             dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
                                   w_lin=lin_w if fuse else None)
-            if ops.can_fuse_stream_ln(dg, u, hs):          # ... and the LayerNorm backward + residual in the same pass
+            lin_t = (gt("lin_w", lin_w), gt("lin_b", lin_b))
+            if ops.can_fuse_stream_ln(dg, u, hs):          # ... and the LayerNorm backward + residual in the same pass,
+                ride = fuse and ops.STREAM_LIN_WGRAD       # ... and the Linear's weight gradient (its dy is that residual)
+                if not ride:
+                    ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, lin_t[0], dbias=lin_t[1])
                 _, dx = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F, targets=tg,
-                                            ln=(x.view(P, Cc), ln_g, dy.view(P, Cc), gt("ln_g", ln_g), gt("ln_b", ln_b)))
+                                            ln=(x.view(P, Cc), ln_g, dy.view(P, Cc), gt("ln_g", ln_g), gt("ln_b", ln_b)),
+                                            lin_targets=lin_t if ride else None)
                 return ret(dx.view(B, T, F, Cc))
+            ops.wgrad(dy, Cc, Cc, hs, sH, gP, H, lin_t[0], dbias=lin_t[1])
             _, du = ops.lstm_bwd_stream(dg, u, hs, [wi], F, T * F, F, targets=tg)
         dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
                                  hint=True)

@@ -455,6 +455,9 @@ def intra_lin_fusion_ok(train, Cc):
 INTER_SUM3 = os.environ.get("SB_NO_INTER_SUM3", "0") != "1"
 # FiLM of the next block applied in the inter-frame forward kernel's y epilogue (SB_NO_INTER_FILM=1: sb_film_fwd pass)
 INTER_FILM = os.environ.get("SB_NO_INTER_FILM", "0") != "1"
+# the inter-frame Linear's weight gradient rides in the stream kernel next to the LayerNorm backward
+# (SB_NO_STREAM_LIN_WGRAD=1: its own sb_wgrad launch)
+STREAM_LIN_WGRAD = os.environ.get("SB_NO_STREAM_LIN_WGRAD", "0") != "1"
 
 
 def add3(x, part):
@@ -526,11 +529,12 @@ def can_fuse_stream_ln(dg, u, hs):
             and u.dtype == torch.float16 and hs.dtype == torch.float16)
 
 
-def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None, ln=None):
+def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None, ln=None, lin_targets=None):
     """One pass over dgates [P, ndir, 4, 64]: -> [(dW_ih, dW_hh, db_ih, db_hh)] per direction, du_part [P, ndir, C].
     targets (optional): per direction 4 buffers the gradients are ACCUMULATED into (instead of fresh zero tensors).
     ln = (x [P, C] pre-LayerNorm input, ln_g, res [P, C], d_ln_g, d_ln_b) (see can_fuse_stream_ln): the LayerNorm backward
-    runs in the kernel and dx [P, C] = LN-backward(du) + res is returned instead of du_part (max |dx| left as a hint)."""
+    runs in the kernel and dx [P, C] = LN-backward(du) + res is returned instead of du_part (max |dx| left as a hint).
+    lin_targets = (d_lin_w [C, 64], d_lin_b [C]) (with ln): += the gradients of the Linear whose output gradient res is."""
     lib = L.load()
     if not isinstance(dg, DGates):
         dg = DGates(dg)
@@ -555,17 +559,20 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None
     du = torch.empty(P, ndir, Cc, device=dev, dtype=torch.float32) if ln is None else torch.empty(P, Cc, device=dev,
                                                                                                   dtype=torch.float32)
     ng = lib.sb_lstm_stream_grid(P)
-    scratch = torch.empty(ndir * ng * (4 * H * (Cc + H) + 4 * H + (2 * Cc if ln is not None else 0)), device=dev,
-                          dtype=torch.float32)
+    extras = (2 * Cc if ln is not None else 0) + (Cc * H + Cc if lin_targets is not None else 0)
+    scratch = torch.empty(ndir * ng * (4 * H * (Cc + H) + 4 * H + extras), device=dev, dtype=torch.float32)
     a.scratch = _p(scratch)
     gm = None
     if ln is not None:
         assert ndir == 1 and gmax is not None
         a.ln_x, a.ln_g, a.ln_res, a.dx, a.d_ln_g, a.d_ln_b = _p(ln[0]), _p(ln[1]), _p(ln[2]), _p(du), _p(ln[3]), _p(ln[4])
+        if lin_targets is not None:
+            a.d_lin_w, a.d_lin_b = _p(lin_targets[0]), _p(lin_targets[1])
         if ABSMAX_HINTS:
             gm = zero_scalar(dev)
             a.absmax_out = _p(gm)
     else:
+        assert lin_targets is None
         a.du_part = _p(du)
     a.split_bf16 = 1 if COMPACT_BPTT else 0       # exact mode (SB_EXACT_BPTT=1) keeps the fp32 matrix path
     by = P * ndir * (dg.element_size() * 4.0 * H + hs.element_size() * H + 4.0 * Cc) + u.element_size() * Cc * P

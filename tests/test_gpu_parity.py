@@ -720,8 +720,18 @@ def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(
           torch.zeros(256, device="cuda")]
     dgf, dbf = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
     ops.absmax_hints_clear()
-    _, dx = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_, targets=[tg], ln=(x, g, dy, dgf, dbf))
+    # ... and the Linear's weight gradient riding along (sb_lstm_stream_args.d_lin_w) against its own sb_wgrad launch
+    gP, sH = ops.dense(geom.P, 64)
+    lw_ref, lb_ref = torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")
+    ops.wgrad(dy, C_, C_, hs, sH, gP, 64, lw_ref, dbias=lb_ref)
+    lwf, lbf = torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")
+    _, dx = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_, targets=[tg], ln=(x, g, dy, dgf, dbf),
+                                lin_targets=(lwf, lbf))
     torch.cuda.synchronize()
+    exact = dy.t().double() @ hs.double()           # hs: the fp16 side output both kernels read
+    assert rel_l2(lwf.cpu().numpy(), exact.cpu().numpy()) < 5e-4          # dy as one scaled fp16 term (2^-12 noise)
+    assert rel_l2(lw_ref.cpu().numpy(), exact.cpu().numpy()) < 5e-4
+    assert rel_l2(lbf.cpu().numpy(), dy.sum(0).cpu().numpy()) < 1e-5
     assert rel_l2(dx.cpu().numpy(), dx_ref.cpu().numpy()) < 2e-6
     assert rel_l2(dgf.cpu().numpy(), dgr.cpu().numpy()) < 2e-5
     assert rel_l2(dbf.cpu().numpy(), dbr.cpu().numpy()) < 2e-5
