@@ -38,7 +38,8 @@ class LstmBwdArgs(C.Structure):
                 ("dW_ih", c_fp), ("dW_hh", c_fp), ("db_ih", c_fp), ("db_hh", c_fp), ("dW_lin", c_fp), ("db_lin", c_fp),
                 ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
                 ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp),
-                ("hs_f16", C.c_int), ("recompute", C.c_int), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2)]
+                ("hs_f16", C.c_int), ("recompute", C.c_int), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
+                ("slab_flags", C.c_void_p), ("slab_len", C.c_int)]
 
 
 class WView(C.Structure):
@@ -92,7 +93,10 @@ class LstmStreamArgs(C.Structure):
                 ("du_part", c_fp), ("scratch", c_fp), ("split_bf16", C.c_int), ("gmax", c_fp),
                 ("u_f16", C.c_int), ("hs_f16", C.c_int),
                 ("ln_x", c_fp), ("ln_g", c_fp), ("ln_res", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
-                ("absmax_out", c_fp), ("d_lin_w", c_fp), ("d_lin_b", c_fp)]
+                ("absmax_out", c_fp), ("d_lin_w", c_fp), ("d_lin_b", c_fp),
+                ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_need", C.c_int),
+                ("chunk_begin", C.c_int), ("chunk_end", C.c_int), ("row_base", C.c_int), ("sched_status", C.c_void_p),
+                ("chunk_reverse", C.c_int)]
 
 
 class LnBwdArgs(C.Structure):
@@ -128,6 +132,8 @@ SYMBOLS = {
     "sb_wgrad_grid": (_ci, [i64]),
     "sb_lstm_bwd_stream": (_ci, [C.POINTER(LstmStreamArgs), _vp]),
     "sb_lstm_stream_grid": (_ci, [i64]),
+    "sb_lstm_bwd_inter_overlapped": (_ci, [C.POINTER(LstmBwdArgs), C.POINTER(LstmStreamArgs), _vp, _ci, C.c_double, _vp]),
+    "sb_lstm_overlap_rows": (_ci, [i64, _ci]),
     "sb_ln_bwd": (_ci, [C.POINTER(LnBwdArgs), _vp]),
     "sb_ln_bwd_grid": (_ci, [i64]),
     "sb_head_ln": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, c_fp, _vp]),

@@ -635,8 +635,13 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 // act(W_ih u_s + W_hh h_{s-1} + b) -- 12 MFMAs per step on the matrix pipe (13 % busy in this kernel) with the weights as
 // single fp16 terms in LDS (48 KB, lane order) and u_s / h_{s-1} fetched as fp16 B operands with the other records.
 // Halves the bytes the intra-frame forward writes (it is store-bound) and the record bytes read here.
+// SLAB (DG16, no FST / SEG, single direction): producer side of the overlapped inter-frame backward
+// (sb_lstm_bwd_inter_overlapped).  The dgates rows are stored write-through at agent scope (sc1) and after every
+// slab_len steps the workgroup counts itself into slab_flags[k]; the stream kernel, running at the same time on the CUs
+// this launch leaves idle, starts on slab k when all tiles have.  Same protocol as the segment hand-off: sc1 accesses
+// ordered by s_waitcnt + barrier, no L2-wide release fences.
 template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
-          bool HS16B = false, bool RECOMP = false>
+          bool HS16B = false, bool RECOMP = false, bool SLAB = false>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -646,6 +651,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   constexpr int CK = FST > 0 ? FST / 16 : 1, KT = CK + 4;
   __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
   __shared__ __attribute__((aligned(16))) float R[FST > 0 ? 2 : 1][4][2][CK][FST > 0 ? 64 : 1][4];
+  // SLAB: the step's 16 dgates rows are assembled here so that they leave as whole 512-byte rows (write-through stores of
+  // the 32-byte pieces each lane holds would reach HBM as partial lines)
+  __shared__ __attribute__((aligned(16))) _Float16 DS[SLAB ? 2 : 1][SLAB ? 16 : 1][SLAB ? 4 * H + 8 : 8];
   static_assert(FST == 0 || (DG16 && REC16), "fused streaming part: compact fp16 path only");
   static_assert(!RECOMP || (BI && HS16B && FST == 32), "gate recomputation: bidirectional C = 32 form with fp16 hs");
   // forward weights of this direction as MFMA A operands: WR[gate][chunk][wave][lane] = rows gate*64 + 16 wave + (lane & 15),
@@ -692,11 +700,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   unsigned slotv = 0;                             // ... and whether that sequence exists (bit kk)
   int posq[2] = {0, 0};                           // LNB: step-0 position of this lane's two flush sequences
   bool fvalid[2] = {false, false};
+  int64_t sbase[4] = {0, 0, 0, 0};                // SLAB: step-0 position of row 4w + i (uniform; -1: no such sequence)
   auto set_tile = [&](int tile) {
     rec_tile = (int64_t)tile * S;
     const int nc = tile * 16 + j;
     valid = FULL || nc < a.nseq;
     base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    if constexpr (SLAB) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n4 = tile * 16 + 4 * w + i;
+        sbase[i] = (FULL || n4 < a.nseq) ? (int64_t)(n4 / a.n_inner) * a.p_outer + (int64_t)(n4 % a.n_inner) * a.p_inner : -1;
+      }
+    }
     if constexpr (LNB) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -1027,6 +1043,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
   };
+  // SLAB: a step's dgates rows leave one step late -- whole rows (one instruction = 64 lanes x 8 bytes = one row),
+  // write-through (sc1), issued where the LDS reads that fetched them have long returned
+  unsigned long long prow[4] = {0, 0, 0, 0};
+  int prow_st = -1;
+  auto rows_out = [&]() {
+    if (prow_st >= 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (sbase[i] >= 0)
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(reinterpret_cast<_Float16*>(a.dgates) +
+                                                                    (sbase[i] + (int64_t)prow_st * a.p_step) * (4 * H) + 4 * lane),
+                             prow[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      prow_st = -1;
+    }
+  };
   auto step = [&](int s, const Raw& raw, int slot = 0) {    // slot: LDS dgates tile of this step (FST)
     const int cur = s & 1;
     SB_TICK(c0);
@@ -1132,6 +1163,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         for (int r = 0; r < 4; ++r) t[r] = Bh[g >> 1][4 * (g & 1) + r];
         *reinterpret_cast<h16x4*>(&DG[slot][j][g * H + uoff]) = t;
       }
+    } else if constexpr (SLAB) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h16x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = Bh[g >> 1][4 * (g & 1) + r];
+        *reinterpret_cast<h16x4*>(&DS[cur][j][g * H + uoff]) = t;
+      }
     } else
     if (valid && !(SB_EXP_SKIP & 256)) {
       const int st = rev ? S - 1 - s : s;
@@ -1177,12 +1216,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       for (int ot = 0; ot < 4; ++ot) part[ot] = mma(At[ot][c].h, Bop[c].h, part[ot]);
     }
     SB_TICK(c3);
+    if constexpr (SLAB) rows_out();                    // the previous step's rows, in the shadow of the MFMAs above
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) st4(&P[cur][w][ot][lane][0], part[ot]);
     SB_TICK(c4);
     __syncthreads();
     dhrec = ld4(&P[cur][0][w][lane][0]) + ld4(&P[cur][1][w][lane][0]) + ld4(&P[cur][2][w][lane][0]) +
             ld4(&P[cur][3][w][lane][0]);
+    if constexpr (SLAB) {                              // rows 4w .. 4w + 3 of the step: picked up now, stored by rows_out()
+#pragma unroll
+      for (int i = 0; i < 4; ++i) prow[i] = *reinterpret_cast<const unsigned long long*>(&DS[cur][4 * w + i][4 * lane]);
+      prow_st = rev ? S - 1 - s : s;
+    }
 #ifdef SB_PHASE_TIMING
     asm volatile("" : "+v"(dhrec));
     SB_TICK(c5);
@@ -1252,6 +1297,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       __syncthreads();                                   // R of the last chunk complete
       if (pend_n) flush(pend_s, pend_n, pk ^ 1, pend_x, pend_r);
     } else {
+    auto slab_signal = [&](int k) {                    // every dgates row of slab k of this tile is on its way: count in
+      rows_out();
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(a.slab_flags + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     for (; s >= s_lo + 1; s -= 2) {
       Raw curA = rA, curB = rB;
       consume(curA);
@@ -1262,8 +1313,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       step(s, curA);
       consume(curB);
       step(s - 1, curB);
+      if constexpr (SLAB) {                            // slab_len is even: slabs end on pair boundaries
+        const int done = S - (s - 1);
+        if (done % a.slab_len == 0) slab_signal(done / a.slab_len - 1);
+      }
     }
     if (s == s_lo) { consume(rA); step(s_lo, rA); }
+    if constexpr (SLAB) { if (S % a.slab_len != 0) slab_signal(S / a.slab_len); }
     }
     if constexpr (SEG) {
       if (s_lo > 0) {
@@ -1509,6 +1565,15 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     float* const ex_out[4] = {a.dW_lin, a.db_lin, lnb ? a.d_ln_g : nullptr, lnb ? a.d_ln_b : nullptr};
     return sb_launch_stream_reduce(a.wpart, (int)grid.x, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st, 4, ex_off, ex_n,
                                    ex_out);
+  }
+  if (a.slab_flags) {                               // overlapped form: see sb_lstm_bwd_inter_overlapped
+    if (seg || !dg16 || a.ndir != 1 || a.slab_len < 2 || (a.slab_len & 1) || (fc != 16 && fc != 32)) return -1003;
+#define SB_SLB(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC, true, false, 0, false, false, false, false, true>), grid, block, 0, st, a)
+    if (fc == 32) { if (full) SB_SLB(true, 32); else SB_SLB(false, 32); }
+    else { if (full) SB_SLB(true, 16); else SB_SLB(false, 16); }
+#undef SB_SLB
+    SB_CHECK_LAUNCH();
+    return 0;
   }
 #define SB_B(FL, R16, FC, D16, SG) do { \
     if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>>()) return -1008; \

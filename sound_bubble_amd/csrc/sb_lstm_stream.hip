@@ -359,7 +359,13 @@ SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma
 // LINW (with LNB): the weight gradient of the Linear in front of the residual rides along as well -- its output gradient IS
 // ln_res, which the flush lanes hold; they drop it (scaled fp16) into a [channel][position] LDS tile, wave w multiplies
 // it with the UNSHIFTED hs rows of the chunk (h columns 4j + w): d_lin_w [C, 64] += dy^T hs, d_lin_b [C] += sum dy.
-template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false, bool LINW = false>
+// SLAB: consumer side of the overlapped inter-frame backward (sb_lstm_bwd_inter_overlapped): chunk ch of this launch is
+// chunk i of batch b of time slab k (slab_len steps, latest first -- the order the recurrence produces them in) and is
+// started once slab_flags[k] has reached slab_need (every tile of the recurrence has stored that slab's dgates,
+// write-through).  A chunk never reads a dgates row outside its own (b, slab) range, so no line of an unfinished slab is
+// ever brought into this XCD's L2.  The launch covers chunks [chunk_begin, chunk_end) and writes partial rows from
+// row_base on.
+template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false, bool LINW = false, bool SLAB = false>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
@@ -407,6 +413,79 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     f32x4 xq, rq;                                                                  // LNB: x and residual of the flush position
     h16x4 hu[LINW ? 8 : 1];                                                        // LINW: hs of the chunk's own positions
   };
+  // SLAB geometry: B sequences-of-slabs x nslabs, cpb chunks per (batch, slab)
+  const int sF = (int)a.shift_pos, sT = SLAB ? a.seg_len / sF : 0;
+  // every slab but the last (shorter) one has cpb chunks per batch entry
+  const int cpb = SLAB ? (a.slab_len * sF + 31) / 32 : 1, cps = SLAB ? (Pi / a.seg_len) * cpb : 1;
+  const int nsl = SLAB ? (sT + a.slab_len - 1) / a.slab_len : 1;
+  const int cpl = SLAB ? ((sT - (nsl - 1) * a.slab_len) * sF + 31) / 32 : 1;
+  // A workgroup's chunks are ch, ch + G, ch + 2G ...: the (slab, batch entry, chunk-in-range) coordinates are decoded
+  // once and then advanced by carries -- no integer division per chunk (uniform, scalar unit)
+  const int nbat = SLAB ? Pi / a.seg_len : 1;
+  struct Span { int k, b, i, cpk, p0, pe, idx0; };
+  auto span_fill = [&](Span& c) {
+    const int t1 = sT - c.k * a.slab_len, t0 = max(0, t1 - a.slab_len);
+    c.idx0 = t0 * sF + 32 * c.i;
+    c.p0 = c.b * a.seg_len + c.idx0;
+    c.pe = c.b * a.seg_len + t1 * sF;
+  };
+  auto span_at = [&](int ch) -> Span {
+    Span c;
+    if constexpr (SLAB) {
+      c.k = min(ch / cps, nsl - 1);
+      const int r = ch - c.k * cps;
+      c.cpk = c.k == nsl - 1 ? cpl : cpb;
+      c.b = r / c.cpk;
+      c.i = r - c.b * c.cpk;
+      span_fill(c);
+    } else {
+      c.k = c.b = c.i = c.cpk = 0;
+      c.p0 = ch * 32; c.pe = Pi; c.idx0 = c.p0 % a.seg_len;
+    }
+    return c;
+  };
+  auto span_next = [&](const Span& o, int ch_next) -> Span {     // coordinates of chunk ch_next = o's chunk + gridDim.x
+    Span c = o;
+    if constexpr (SLAB) {
+      if (a.chunk_reverse) {                          // walking down from chunk_end - 1 (see load order below)
+        c.i -= gridDim.x;
+        while (c.i < 0 && c.k >= 0) {
+          if (--c.b < 0) { c.b = nbat - 1; --c.k; c.cpk = c.k >= nsl - 1 ? cpl : cpb; }
+          c.i += c.cpk;
+        }
+      } else {
+        c.i += gridDim.x;
+        while (c.i >= c.cpk) {
+          c.i -= c.cpk;
+          if (++c.b == nbat) { c.b = 0; ++c.k; c.cpk = c.k >= nsl - 1 ? cpl : cpb; }
+        }
+      }
+      span_fill(c);
+    } else {
+      c.p0 = ch_next * 32; c.idx0 = c.p0 % a.seg_len;
+    }
+    return c;
+  };
+  // Thread 0 polls (bounded, like the segment hand-off) and leaves the verdict in LDS; the workgroup reads it after its
+  // next barrier -- inside the chunk loop that is the barrier the loop has anyway, one chunk ahead of the loads.
+  __shared__ int slab_abort;
+  int ready_k = -1;                                        // thread 0 only
+  auto slab_poll = [&](int k) {
+    if (tid == 0 && k > ready_k) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(a.slab_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.slab_need) {
+        ++spins;
+        if ((spins & 63u) == 0 &&
+            (spins > (1u << 22) || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          __hip_atomic_store(a.sched_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          slab_abort = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      ready_k = k;
+    }
+  };
   // LNB flush role of this lane
   const int fsb = w >> 1, fjj = 8 * (w & 1) + (lane & 7), fqq = lane >> 3;
   const int fct = CK == 2 ? fqq >> 2 : 0, fqr = fqq & 3;
@@ -425,17 +504,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     if constexpr (CK == 2) v += __shfl_xor(v, 32, 64);
     return v;
   };
-  const int nchunks = (Pi + 31) / 32;
+  const int ch_begin = SLAB ? a.chunk_begin : 0, nchunks = SLAB ? a.chunk_end : (Pi + 31) / 32;
   const h16x4 hz4 = {0, 0, 0, 0};
   const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto load_chunk = [&](int ch, Chunk& t) {          // branch-free (clamped address + select)
-    const int p0 = ch * 32;
-    const int idx0 = p0 % a.seg_len;
+  auto load_chunk = [&](const Span& sp, Chunk& t) {  // branch-free (clamped address + select)
+    const int p0 = sp.p0, pe = sp.pe, idx0 = sp.idx0;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int p = p0 + 8 * q + kk;
-      const bool ok = p < Pi;
-      const int pc = min(p, Pi - 1);
+      const bool ok = p < pe;
+      const int pc = min(p, pe - 1);
       // positions beyond P are cancelled through their (zeroed) dgates alone; u / h_prev of the clamped row are finite
       const h16x4 av = *reinterpret_cast<const h16x4*>(dg + (int64_t)pc * ldg + 4 * j);
       t.a4[kk] = ok ? av : hz4;
@@ -469,12 +547,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {          // dU operand: position p0 + 16 sb + j, gates 32m + 8q .. +7 (one 16-byte load)
-      const int pjc = min(p0 + 16 * sb + j, Pi - 1);      // dU of positions beyond P is computed but never stored
+      const int pjc = min(p0 + 16 * sb + j, pe - 1);      // dU of positions beyond the range is computed but never stored
 #pragma unroll
       for (int m = 0; m < 2; ++m) t.d8[sb][m] = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 32 * m + 8 * q);
     }
     if constexpr (LNB) {
-      const int64_t pf = min(p0 + 16 * fsb + fjj, Pi - 1);
+      const int64_t pf = min(p0 + 16 * fsb + fjj, pe - 1);
       t.xq = ld4(a.ln_x + pf * C + fcol);
       t.rq = ld4(a.ln_res + pf * C + fcol);
     }
@@ -482,12 +560,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
 
   const h16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
   Chunk cur;
-  if ((int)blockIdx.x < nchunks) load_chunk(blockIdx.x, cur);
+  int ch = ch_begin + blockIdx.x;
+  // chunk_reverse (the launch that runs after the recurrence): the same chunks from the last one down -- the slabs written
+  // last are still in the memory-side cache
+  Span sc = span_at(SLAB && a.chunk_reverse ? a.chunk_end - 1 - (int)blockIdx.x : ch);
+  Span sn = span_next(sc, ch + gridDim.x);           // chunk in hand, the one being loaded
+  if constexpr (SLAB) {                              // the first two chunks of this workgroup
+    if (tid == 0) slab_abort = 0;
+    if (ch < nchunks) slab_poll(ch + (int)gridDim.x < nchunks ? sn.k : sc.k);
+    __syncthreads();
+    if (slab_abort) return;
+  }
+  if (ch < nchunks) load_chunk(sc, cur);             // (a workgroup without chunks still writes its zero partial row)
   int it = 0;
-  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x, ++it) {
+  for (; ch < nchunks; ++it) {
     Chunk nxt;
     const int cn = ch + gridDim.x;
-    load_chunk(cn < nchunks ? cn : ch, nxt);
+    load_chunk(cn < nchunks ? sn : sc, nxt);
+    const int cp0 = sc.p0, cpe = sc.pe;              // positions [cp0, cpe) of the chunk in hand (uniform)
+    const Span s2 = span_next(sn, cn + gridDim.x);   // ... and of the chunk the NEXT iteration loads
     // ---- weight gradients: 4 gate tiles x (CK + 4) column tiles, K = 32 positions ----
     // u (LayerNorm output) and h_prev enter as single fp16 terms: like the dgates they multiply, they carry 2^-12
     // relative rounding noise, unbiased and averaged over millions of positions in these sums
@@ -533,7 +624,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
     }
     if constexpr (LINW) {
-      const bool valid = fact && ch * 32 + 16 * fsb + fjj < Pi;
+      const bool valid = fact && cp0 + 16 * fsb + fjj < cpe;
       if (fact) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -543,7 +634,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
         }
       }
     }
+    if constexpr (SLAB) { if (cn + (int)gridDim.x < nchunks) slab_poll(s2.k); }
     __syncthreads();
+    if constexpr (SLAB) { if (slab_abort) break; }
     if constexpr (LINW) {
       h16x8 Bu;
 #pragma unroll
@@ -554,8 +647,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     }
     if constexpr (LNB) {
       const int rl = fqr * 16 + fjj;
-      const int pj = ch * 32 + 16 * fsb + fjj;
-      const bool valid = fact && pj < Pi;
+      const int pj = cp0 + 16 * fsb + fjj;
+      const bool valid = fact && pj < cpe;
       const f32x4 du4 = (ld4(&R[buf][0][fsb][fct][rl][0]) + ld4(&R[buf][1][fsb][fct][rl][0]) + ld4(&R[buf][2][fsb][fct][rl][0]) +
                          ld4(&R[buf][3][fsb][fct][rl][0])) * invS;
       const f32x4 x4 = cur.xq;
@@ -589,18 +682,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     } else
     {   // 2 sub-tiles x CK channel tiles = 2*CK (<= 4) reductions: one per wave
       const int sb = w / CK, ct = w % CK;
-      const int pj = ch * 32 + 16 * sb + j;
-      if (w < 2 * CK && pj < Pi) {
+      const int pj = cp0 + 16 * sb + j;
+      if (w < 2 * CK && pj < cpe) {
         const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
                          ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
         st4(a.du_part + ((int64_t)pj * ndir + dir) * C + 16 * ct + 4 * q, s4 * invS);
       }
     }
     cur = nxt;
+    ch = cn;
+    sc = sn; sn = s2;
   }
 
   constexpr int Ktot = C + H;
-  float* part = a.scratch + ((size_t)dir * gridDim.x + blockIdx.x) *
+  float* part = a.scratch + (SLAB ? (size_t)a.row_base + blockIdx.x : (size_t)dir * gridDim.x + blockIdx.x) *
                                 ((size_t)4 * H * Ktot + 4 * H + (LNB ? 2 * C : 0) + (LINW ? C * H + C : 0));
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -845,6 +940,87 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   }
   SB_CHECK_LAUNCH();
   return 0;
+}
+
+// ---- overlapped inter-frame backward (see the header) ----
+namespace {
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideStream* side_stream() {
+  static SideStream tab[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& t = tab[dev];
+  if (!t.s) {
+    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &t;
+}
+int device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return n;
+}
+}  // namespace
+
+extern "C" int sb_lstm_overlap_rows(int64_t positions, int nseq) {
+  const int idle = device_cus() - (nseq + 15) / 16;
+  return (idle > 0 ? idle : 0) + sb_lstm_stream_grid(positions);
+}
+
+extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args* st_in, int* flags,
+                                            int slab_len, double frac, void* stream) {
+  if (!rec_in || !st_in || !flags) return -1001;
+  sb_lstm_bwd_args rec = *rec_in;
+  sb_lstm_stream_args sa = *st_in;
+  hipStream_t main_st = (hipStream_t)stream;
+  const int T = rec.nsteps, ntiles = (rec.nseq + 15) / 16, C = sa.C;
+  if (rec.ndir != 1 || sa.ndir != 1 || !sa.dx || !sa.d_lin_w || !sa.d_lin_b || !sa.gmax || !sa.u_f16 || !sa.hs_f16 ||
+      !sa.ln_x || !sa.ln_g || !sa.ln_res || !sa.d_ln_g || !sa.d_ln_b || !sa.sched_status || (C != 16 && C != 32) ||
+      slab_len < 2 || (slab_len & 1) || sa.shift_pos <= 0 || sa.seg_len != T * sa.shift_pos || sa.P % sa.seg_len != 0 ||
+      sa.seg_len < 32 || !(frac > 0.0 && frac < 1.0))
+    return -1003;
+  const int idle = device_cus() - ntiles;
+  if (idle < 16) return -1003;
+  SideStream* ss = side_stream();
+  if (!ss) return -1009;
+  const int nslabs = (T + slab_len - 1) / slab_len;
+  const int nb = (int)(sa.P / sa.seg_len);
+  const int cpb = (int)((slab_len * sa.shift_pos + 31) / 32), cps = nb * cpb;
+  const int cpl = (int)(((T - (nslabs - 1) * slab_len) * sa.shift_pos + 31) / 32);     // the last slab is shorter
+  const int nch = (nslabs - 1) * cps + nb * cpl;
+  int split = (int)(frac * nch);
+  if (split < 1) split = 1;
+  if (split > nch - 1) split = nch - 1;
+  const int g1 = idle < split ? idle : split;
+  int g2 = device_cus();                             // one workgroup per CU is all that is resident (register budget)
+  if (g2 > sb_lstm_stream_grid(sa.P)) g2 = sb_lstm_stream_grid(sa.P);
+  if (g2 > nch - split) g2 = nch - split;
+
+  if (hipMemsetAsync(flags, 0, (size_t)nslabs * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;
+  rec.slab_flags = flags; rec.slab_len = slab_len;
+  int rc = sb_lstm_bwd_rec(&rec, stream);
+  if (rc) return rc;
+  sa.slab_flags = flags; sa.slab_len = slab_len; sa.slab_need = ntiles;
+#define SB_SO(CC, ST, G) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, true, true>), dim3(G), dim3(256), 0, ST, sa)
+  if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
+  sa.chunk_begin = 0; sa.chunk_end = split; sa.row_base = 0; sa.chunk_reverse = 0;
+  if (C == 32) SB_SO(32, ss->s, g1); else SB_SO(16, ss->s, g1);
+  SB_CHECK_LAUNCH();
+  if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
+  if (hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
+  sa.chunk_begin = split; sa.chunk_end = nch; sa.row_base = g1; sa.chunk_reverse = 1;
+  if (C == 32) SB_SO(32, main_st, g2); else SB_SO(16, main_st, g2);
+#undef SB_SO
+  SB_CHECK_LAUNCH();
+  const int tot = 4 * H * (C + H) + 4 * H;
+  const int ex_off[4] = {tot, tot + C, tot + 2 * C, tot + 2 * C + C * H}, ex_n[4] = {C, C, C * H, C};
+  float* const ex_out[4] = {sa.d_ln_g, sa.d_ln_b, sa.d_lin_w, sa.d_lin_b};
+  return sb_launch_stream_reduce(sa.scratch, g1 + g2, (int64_t)tot + 2 * C + C * H + C, C, sa.dW_ih[0], sa.dW_hh[0],
+                                 sa.db_ih[0], sa.db_hh[0], main_st, 4, ex_off, ex_n, ex_out);
 }
 
 // shared with the fused backward recurrence (sb_lstm_bf.hip), which emits the same partial rows

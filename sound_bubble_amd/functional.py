@@ -221,9 +221,15 @@ class InterFn(torch.autograd.Function):
                 dx = du.view(B, T, F, Cc)
                 return ret(dx)
         else:
+            lin_t = (gt("lin_w", lin_w), gt("lin_b", lin_b))
+            if fuse and ops.can_overlap_inter_bwd(geom, u, hs):
+                # fewer tiles than CUs: the stream kernel (with its LayerNorm / Linear riders) starts on the idle CUs while
+                # the recurrence runs
+                dx = ops.lstm_bwd_inter_overlapped(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0], lin_t,
+                                                   (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)))
+                return ret(dx.view(B, T, F, Cc))
             dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
                                   w_lin=lin_w if fuse else None)
-            lin_t = (gt("lin_w", lin_w), gt("lin_b", lin_b))
             if ops.can_fuse_stream_ln(dg, u, hs):          # ... and the LayerNorm backward + residual in the same pass,
                 ride = fuse and ops.STREAM_LIN_WGRAD       # ... and the Linear's weight gradient (its dy is that residual)
                 if not ride:

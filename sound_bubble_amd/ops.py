@@ -353,6 +353,75 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
     return DGates(dg, gmax)
 
 
+# Inter-frame backward with fewer tiles than CUs: the streaming part starts on the idle CUs while the recurrence is still
+# running (sb_lstm_bwd_inter_overlapped).  SB_NO_BWD_OVERLAP=1: the two launches one after the other.
+BWD_OVERLAP = os.environ.get("SB_NO_BWD_OVERLAP", "0") != "1"
+BWD_OVERLAP_FRAC = float(os.environ.get("SB_BWD_OVERLAP_FRAC", "0.5"))
+BWD_OVERLAP_SLAB = int(os.environ.get("SB_BWD_OVERLAP_SLAB", "32"))
+
+
+def can_overlap_inter_bwd(geom, u, hs):
+    """the overlapped form pays when the recurrence leaves a good part of the chip idle and has enough slabs to pipeline"""
+    if not (BWD_OVERLAP and STREAM_LIN_WGRAD and FUSED_LN_BWD and DGATES_FP16 and COMPACT_BPTT and LSTM_MMA in (1, 2)
+            and can_fuse_linear_bwd() and u is not None and hs is not None and u.dtype == torch.float16
+            and hs.dtype == torch.float16 and u.shape[-1] in (16, 32)):
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    ntiles = (geom.nseq + 15) // 16
+    cus = _cu_count(u.device)
+    return 4 * ntiles <= 3 * cus and geom.nsteps >= 4 * BWD_OVERLAP_SLAB and geom.n_inner * geom.nsteps >= 32
+
+
+def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets, ln):
+    """Inter-frame backward of one block, recurrence and streaming part overlapped (see can_overlap_inter_bwd):
+    dy [P, C]; u / hs the fp16 side outputs; targets = (dW_ih, dW_hh, db_ih, db_hh), lin_targets = (dW_lin, db_lin),
+    ln = (x [P, C], ln_g, d_ln_g, d_ln_b).  -> dx [P, C] = LN-backward(du) + dy (max |dx| left as a hint)."""
+    lib = L.load()
+    rec, cprev = gates
+    dev = dy.device
+    Cc = dy.shape[-1]
+    P = geom.P
+    F_ = geom.n_inner
+    gmax = absmax_or_hint(dy)
+    dg = torch.empty(P, 1, 4, H, device=dev, dtype=torch.float16)
+    a = L.LstmBwdArgs()
+    a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 1
+    a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
+    a.w_hh[0] = _p(w_hh)
+    a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), C.c_void_p(cprev.data_ptr())
+    a.dgates, a.gmax, a.mma = C.c_void_p(dg.data_ptr()), _p(gmax), LSTM_MMA
+    a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
+    s = L.LstmStreamArgs()
+    s.P, s.ndir, s.C = P, 1, Cc
+    s.shift_pos, s.seg_len, s.skip = F_, geom.nsteps * F_, F_
+    s.dgates, s.u, s.hs = C.c_void_p(dg.data_ptr()), _ph(u), _ph(hs)
+    s.gmax, s.u_f16, s.hs_f16, s.split_bf16 = _p(gmax), 1, 1, 1
+    s.w_ih[0] = _p(w_ih)
+    s.dW_ih[0], s.dW_hh[0], s.db_ih[0], s.db_hh[0] = (_p(t) for t in targets)
+    dx = torch.empty(P, Cc, device=dev, dtype=torch.float32)
+    s.ln_x, s.ln_g, s.ln_res, s.dx, s.d_ln_g, s.d_ln_b = _p(ln[0]), _p(ln[1]), _p(dy), _p(dx), _p(ln[2]), _p(ln[3])
+    s.d_lin_w, s.d_lin_b = _p(lin_targets[0]), _p(lin_targets[1])
+    rows = lib.sb_lstm_overlap_rows(P, geom.nseq)
+    scratch = torch.empty(rows * (4 * H * (Cc + H) + 4 * H + 2 * Cc + Cc * H + Cc), device=dev, dtype=torch.float32)
+    s.scratch = _p(scratch)
+    s.sched_status = C.c_void_p(sched_status(dev).data_ptr())
+    gm = None
+    if ABSMAX_HINTS:
+        gm = zero_scalar(dev)
+        s.absmax_out = _p(gm)
+    slab = BWD_OVERLAP_SLAB
+    flags = torch.empty((geom.nsteps + slab - 1) // slab, device=dev, dtype=torch.int32)
+    by = P * (640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc + 4 * 4.0 * Cc)
+    with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)",
+               (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P, 8.0 * Cc * P, by):
+        L.check(lib.sb_lstm_bwd_inter_overlapped(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab,
+                                                 BWD_OVERLAP_FRAC, _stream()), "sb_lstm_bwd_inter_overlapped")
+    if gm is not None:
+        absmax_hint_put(dx, gm)
+    return dx
+
+
 # single-direction passes on the default path: the streaming part runs inside the backward recurrence (the dgates stay in
 # LDS); SB_NO_FUSED_BPTT=1 keeps the two-kernel form
 FUSED_BPTT = os.environ.get("SB_NO_FUSED_BPTT", "0") != "1"

@@ -741,6 +741,51 @@ def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(
         assert float(ops.absmax_or_hint(dx)) == float(dx.abs().max())
 
 
+@pytest.mark.parametrize("C_,slab,frac", [(32, 32, 0.55), (32, 6, 0.3), (16, 10, 0.8)])
+def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab, frac, monkeypatch):
+    """sb_lstm_bwd_inter_overlapped (recurrence on the main stream publishing its dgates slab by slab, the first part of the
+    stream kernel behind it on the library's side stream, the rest after the join) against sb_lstm_bwd_rec followed by
+    sb_lstm_bwd_stream: dx, every weight / bias gradient, the LayerNorm and Linear riders, the max |dx| hint.  Ragged
+    geometry: 3 tiles (the last one partial), a short last slab, chunk ranges that do not end on 32 positions."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.can_fuse_linear_fwd() and ops.STREAM_LIN_WGRAD):
+        pytest.skip("default compact fp16 path only")
+    monkeypatch.setattr(ops, "BWD_OVERLAP_SLAB", slab)
+    monkeypatch.setattr(ops, "BWD_OVERLAP_FRAC", frac)
+    torch.manual_seed(23)
+    B_, T_, F_ = 2, 150, 21
+    geom = ops.Geom.inter(B_, T_, F_)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    wi, wh = torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2
+    dirs = [(wi, wh, torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)]
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    y = torch.empty(geom.P, C_, device="cuda")
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, y))
+    dy = torch.randn(geom.P, C_, device="cuda") * 0.01
+
+    def targets():
+        return ([torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+                 torch.zeros(256, device="cuda")], (torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")),
+                (torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")))
+
+    tg0, lin0, ln0 = targets()
+    dg = ops.lstm_bwd_rec([wh], gates, None, geom, dy=dy, w_lin=lin_w)
+    _, dx0 = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_, targets=[tg0], ln=(x, g, dy, ln0[0], ln0[1]),
+                                 lin_targets=lin0)
+    tg1, lin1, ln1 = targets()
+    ops.absmax_hints_clear()
+    dx1 = ops.lstm_bwd_inter_overlapped(wh, gates, geom, dy, lin_w, u, hs, wi, tg1, lin1, (x, g, ln1[0], ln1[1]))
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    assert torch.equal(dx1, dx0)                       # per-position arithmetic does not depend on the chunking
+    for a_, b_ in zip(tg1 + list(lin1) + list(ln1), tg0 + list(lin0) + list(ln0)):
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6       # sums over positions: other grouping
+    if ops.ABSMAX_HINTS:
+        assert float(ops.absmax_or_hint(dx1)) == float(dx1.abs().max())
+
+
 @pytest.mark.parametrize("sched", [None, (4, 3)], ids=["plain", "time-segmented"])
 @pytest.mark.parametrize("save", [False, True], ids=["inference", "training"])
 def test_inter_forward_with_summed_input_is_bit_identical_to_add3(torch_gpu, sched, save, monkeypatch):
