@@ -88,8 +88,31 @@ typedef struct {
      NULL; y carries the fp32 result forward).  sb_lstm_bwd_stream consumes them as single fp16 terms anyway (u_f16 /
      hs_f16 there), sb_wgrad takes the fp16 hs through in_f16. */
   int aux_f16;
+  /* overlapped forward (set by sb_lstm_fwd_produce / sb_lstm_fwd_consume; leave NULL / 0 otherwise) */
+  int* slab_flags; int slab_len, slab_need;
+  const int* tile_order; const int* tile_need; int item_begin, item_end, ord_grid;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
+
+/* ---- inter-frame forward of block k OVERLAPPED with the intra-frame forward of block k + 1 ------------------------
+ * The inter-frame pass of the BASELINE big configuration has 145 serial chains on 256 CUs; the bidirectional intra-frame
+ * pass that follows it needs, for a tile of 16 frames (b, t .. t + 15), only the y rows of those frames.  Two calls:
+ *   sb_lstm_fwd_produce(a, flags, slab_len, stream): sb_lstm_fwd of a single-direction pass with the fused Linear (y
+ *     written; fewer tiles than CUs, no time segments) on `stream`; y rows are stored write-through and after every
+ *     slab_len steps (multiple of 4) each tile counts itself into flags[k] ([ceil(nsteps / slab_len)] ints, zeroed by the
+ *     call).
+ *   sb_lstm_fwd_consume(a, flags, slab_len, producer_tiles, order, need, frac, stream): sb_lstm_fwd of the
+ *     bidirectional partial-Linear pass (ndir == 2, lin_w != NULL, C == 32; a->x is the producer's y) whose tiles are
+ *     taken in the order order[ntiles] (a permutation sorted by need[], need[i] = time slab of the producer that
+ *     completes the frames of tile order[i]); the first frac of the 2 * ntiles (tile, direction) items run as persistent
+ *     workgroups on a side stream of the library -- at most two per CU the producer leaves idle -- each item waiting
+ *     (bounded; a->sched_status required) for flags[need] == producer_tiles; the rest follows on `stream` after the join.
+ * The consume call must be the next library call after its produce call on that device.  Memory the producer reads or
+ * writes must stay allocated until the consume call has returned (the side stream is not ordered after `stream`).
+ * -1003 when fewer than 16 CUs stay idle. */
+int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a, int* flags, int slab_len, void* stream);
+int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
+                        const int* need, double frac, void* stream);
 
 /* ---- recurrent LSTM (backward through time, recurrent part) --------------
  * Autograd of the nn.LSTM calls above (loss.backward(), tain_val.py:75).

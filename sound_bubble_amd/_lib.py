@@ -24,7 +24,10 @@ class LstmFwdArgs(C.Structure):
                 ("film_w", c_fp), ("film_b", c_fp), ("y_pre", c_fp),
                 ("seg_state", c_fp), ("seg_flags", c_fp), ("seg_count", C.c_int), ("seg_len", C.c_int),
                 ("sched_status", c_fp), ("sched_workers", C.c_int), ("sched_segments", C.c_int),
-                ("aux_f16", C.c_int)]
+                ("aux_f16", C.c_int),
+                ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_need", C.c_int),
+                ("tile_order", C.c_void_p), ("tile_need", C.c_void_p), ("item_begin", C.c_int), ("item_end", C.c_int),
+                ("ord_grid", C.c_int)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -124,6 +127,8 @@ EPI_NONE, EPI_RES, EPI_PRELU, EPI_LN, EPI_LNBWD = range(5)
 _vp, _ci, _cf = C.c_void_p, C.c_int, C.c_float
 SYMBOLS = {
     "sb_lstm_fwd": (_ci, [C.POINTER(LstmFwdArgs), _vp]),
+    "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
+    "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, C.c_double, _vp]),
     "sb_lstm_bwd_rec": (_ci, [C.POINTER(LstmBwdArgs), _vp]),
     "sb_linear_fwd": (_ci, [C.POINTER(LinearArgs), _vp]),
     "sb_linear_grid": (_ci, [i64]),

@@ -167,7 +167,16 @@ struct XVec { float v[C / 16]; };
 // summed by the loader as it fetches the row (the separate elementwise pass, 16 C bytes per position, is gone); the sum
 // is written once to x_sum for the backward kernels (training) and handed to the fused Linear's residual through a
 // four-row LDS ring (the residual is needed two barriers after the row was normalised).
-template <int C, int SAVE, bool FULL, bool F16, bool LIN, bool SEG, bool SUM3 = false>
+// Overlapped forward (sb_lstm_fwd_produce / sb_lstm_fwd_consume): an inter-frame pass with fewer tiles than CUs publishes
+// its y rows (write-through, sc1) and counts itself into slab_flags[k] after every slab_len time steps (runtime flag:
+// a.slab_flags on a single-direction LIN launch); the NEXT block's intra-frame pass (ORD: 1-D grid, item i = direction i & 1
+// of tile tile_order[i >> 1], tiles ordered by the latest time slab their 16 frames need) starts on the idle CUs and each
+// item waits for slab_flags[tile_need[i >> 1]] to reach slab_need.  An input row is one 128-byte line that only its frame's
+// items ever read, so no line of an unfinished slab enters the reader's L2.
+SB_DEVINL void st4_sc1(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+template <int C, int SAVE, bool FULL, bool F16, bool LIN, bool SEG, bool SUM3 = false, bool ORD = false>
 __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   typedef Prec<F16> PR;
   typedef typename PR::elem elem;
@@ -176,9 +185,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   constexpr int NT = PR::NT;
   constexpr int VPT = C / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
-  const int dir = blockIdx.y;
+  const int dir = ORD ? (a.item_begin + (int)blockIdx.x) & 1 : (int)blockIdx.y;
   const int S = a.nsteps;
   const bool rev = dir == 1;
+  const bool prod = LIN && !ORD && !SEG && a.slab_flags != nullptr;      // producer side of the overlapped forward
 
   __shared__ __attribute__((aligned(16))) elem U16[2][NT][16][UP];      // [buf][term][seq][channel]
   __shared__ __attribute__((aligned(16))) elem H16[2][NT][16][HP16];    // [buf][term][seq][unit]
@@ -385,7 +395,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], fw[r], fb[r]);
       }
-      st4(a.y + (lin_part ? pos * 2 + dir : pos) * C + 16 * w + 4 * q, v);
+      float* yp = a.y + (lin_part ? pos * 2 + dir : pos) * C + 16 * w + 4 * q;
+      if (prod) st4_sc1(yp, v); else st4(yp, v);
     }
   };
   auto load_res = [&](int sy) {
@@ -502,11 +513,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   const int ntiles = (a.nseq + 15) / 16;
   const int nitems = SEG ? ntiles * a.seg_count : ntiles;          // !SEG: gridDim.x == ntiles, one item each
   float* const seg_hc = SEG ? a.seg_state : nullptr;               // [ntiles][2][16][64]: c, h
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  int next_slab = 0;                                               // producer: first slab not yet counted in
+  auto slab_signal = [&](int k) {                                  // every y row of slab k of this tile is on its way
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.slab_flags + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  const int item0 = ORD ? a.item_begin + (int)blockIdx.x : (int)blockIdx.x, item1 = ORD ? a.item_end : nitems;
+  for (int item = item0; item < item1; item += gridDim.x) {       // ORD: gridDim.x is even (the direction is fixed per workgroup)
     const int seg = SEG ? item / ntiles : 0;
-    const int tile = SEG ? item - seg * ntiles : item;
+    const int tile = ORD ? a.tile_order[item >> 1] : SEG ? item - seg * ntiles : item;
     s_begin = SEG ? seg * a.seg_len : 0;
     const int s_end = SEG ? min(S, s_begin + a.seg_len) : S;
+    if constexpr (ORD) { if (!seg_wait(a.slab_flags, a.tile_need[item >> 1], a.slab_need, a.sched_status)) return; }
     set_tile(tile);
     // ---- initial state of this item ----
     c = zero4();
@@ -554,6 +573,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       step(s + 1, cb);
       step(s + 2, cc);
       step(s + 3, cd);
+      if (prod) {                                      // y of steps .. s + 2 has been issued
+        while ((next_slab + 1) * a.slab_len <= s + 3) slab_signal(next_slab++);
+      }
     }
     if (s < s_end) step(s, xa);
     if (s + 1 < s_end) step(s + 1, xb);
@@ -574,6 +596,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         }
       }
       store_y(s_end - 1);
+      if (prod) { while (next_slab * a.slab_len < S) slab_signal(next_slab++); }
     }
     // ---- final state: to the caller after the last step, to the next segment otherwise ----
     if (s_end == S) {
@@ -592,7 +615,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       __syncthreads();                                 // ... by every wave, before the flag goes up
       if (tid == 0) __hip_atomic_store(a.seg_flags + tile, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if constexpr (SEG) __syncthreads();                // LDS tiles are reused by the next item
+    if constexpr (SEG || ORD) __syncthreads();         // LDS tiles are reused by the next item
   }
 #ifdef SB_PHASE_TIMING
   if (SAVE == 0 && a.save_u && lane == 0 && blockIdx.x < 4) {
@@ -1456,6 +1479,19 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
       grid.x = W;
       (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
     }
+  }
+  if (a.slab_flags && (seg || !lin || !f16 || a.slab_len < 4 || (a.slab_len & 3))) return -1003;
+  if (a.tile_order) {    // consumer side of the overlapped forward: bidirectional partial-Linear pass, ordered 1-D grid
+    if (!a.slab_flags || !a.tile_need || !a.sched_status || a.ndir != 2 || a.C != 32 || (save != 0 && save != 3) ||
+        a.item_begin < 0 || a.item_end > 2 * ntiles || a.item_begin >= a.item_end || a.ord_grid < 1 ||
+        (a.ord_grid > 1 && (a.ord_grid & 1)))
+      return -1003;
+    dim3 g1(a.ord_grid);
+#define SB_LO(SV, FL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, false, false, true>), g1, dim3(256), 0, st, a)
+    if (save == 0) { if (full) SB_LO(0, true); else SB_LO(0, false); }
+    else { if (full) SB_LO(3, true); else SB_LO(3, false); }
+#undef SB_LO
+    return 0;
   }
 #define SB_L(CC, SV, FL, HF, LN, SG) do { \
     if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>>()) return -1008; \

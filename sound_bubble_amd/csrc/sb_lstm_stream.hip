@@ -1011,16 +1011,63 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
   if (C == 32) SB_SO(32, ss->s, g1); else SB_SO(16, ss->s, g1);
   SB_CHECK_LAUNCH();
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
-  if (hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
+  // the rest on `stream` (ordered after the recurrence: all flags are up), from the last chunk down; then the join
   sa.chunk_begin = split; sa.chunk_end = nch; sa.row_base = g1; sa.chunk_reverse = 1;
   if (C == 32) SB_SO(32, main_st, g2); else SB_SO(16, main_st, g2);
 #undef SB_SO
   SB_CHECK_LAUNCH();
+  if (hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
   const int tot = 4 * H * (C + H) + 4 * H;
   const int ex_off[4] = {tot, tot + C, tot + 2 * C, tot + 2 * C + C * H}, ex_n[4] = {C, C, C * H, C};
   float* const ex_out[4] = {sa.d_ln_g, sa.d_ln_b, sa.d_lin_w, sa.d_lin_b};
   return sb_launch_stream_reduce(sa.scratch, g1 + g2, (int64_t)tot + 2 * C + C * H + C, C, sa.dW_ih[0], sa.dW_hh[0],
                                  sa.db_ih[0], sa.db_hh[0], main_st, 4, ex_off, ex_n, ex_out);
+}
+
+// ---- overlapped forward (see the header) ----
+extern "C" int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, void* stream) {
+  if (!a_in || !flags) return -1001;
+  sb_lstm_fwd_args a = *a_in;
+  hipStream_t main_st = (hipStream_t)stream;
+  const int ntiles = (a.nseq + 15) / 16;
+  if (a.ndir != 1 || !a.lin_w || slab_len < 4 || (slab_len & 3) || device_cus() - ntiles < 16) return -1003;
+  SideStream* ss = side_stream();
+  if (!ss) return -1009;
+  const int nslabs = (a.nsteps + slab_len - 1) / slab_len;
+  if (hipMemsetAsync(flags, 0, (size_t)nslabs * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
+  a.slab_flags = flags; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
+  return sb_lstm_fwd(&a, stream);
+}
+
+extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, int producer_tiles,
+                                   const int* order, const int* need, double frac, void* stream) {
+  if (!a_in || !flags || !order || !need) return -1001;
+  sb_lstm_fwd_args a = *a_in;
+  hipStream_t main_st = (hipStream_t)stream;
+  const int ntiles = (a.nseq + 15) / 16, nitems = 2 * ntiles;
+  const int idle = device_cus() - producer_tiles;
+  if (a.ndir != 2 || !a.lin_w || !a.sched_status || idle < 16 || !(frac > 0.0 && frac < 1.0)) return -1003;
+  SideStream* ss = side_stream();
+  if (!ss) return -1009;
+  int split = ((int)(frac * nitems)) & ~1;             // both directions of a tile stay in the same launch
+  if (split < 2) split = 2;
+  if (split > nitems - 2) split = nitems - 2;
+  if (split < 2) return -1003;
+  int g1 = 2 * idle;                                    // two workgroups per CU are resident (254 registers each)
+  if (g1 > split) g1 = split;
+  a.slab_flags = flags; a.slab_len = slab_len; a.slab_need = producer_tiles;
+  a.tile_order = order; a.tile_need = need;
+  if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
+  a.item_begin = 0; a.item_end = split; a.ord_grid = g1;
+  int rc = sb_lstm_fwd(&a, ss->s);
+  if (rc) return rc;
+  if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
+  // the rest on `stream` (ordered after the producer: all flags are up), one item per workgroup; then the join
+  a.item_begin = split; a.item_end = nitems; a.ord_grid = nitems - split;
+  rc = sb_lstm_fwd(&a, stream);
+  if (hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
+  return rc;
 }
 
 // shared with the fused backward recurrence (sb_lstm_bf.hip), which emits the same partial rows

@@ -51,10 +51,12 @@ class IntraPlainFn(torch.autograd.Function):
     optim/tfgridnet_causal.py:699-707."""
 
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, lin_w, lin_b, defer_sum=False):
+    def forward(ctx, x, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, lin_w, lin_b, defer_sum=False, ovl=None):
         """defer_sum: return the two per-direction partial products `part` [B, T, F, 2, C] instead of
         y = x + part[..., 0, :] + part[..., 1, :]; the InterFn that follows forms the sum in its loader (and owns the
-        residual's forward); the gradient that comes back for `part` is the gradient of that sum, broadcast."""
+        residual's forward); the gradient that comes back for `part` is the gradient of that sum, broadcast.
+        ovl (ops.FwdOverlap): x is being produced by the preceding InterFn's kernel right now -- this pass starts behind it
+        on the idle CUs (overlapped forward)."""
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
@@ -67,7 +69,7 @@ class IntraPlainFn(torch.autograd.Function):
             part = torch.empty(P, 2, Cc, device=x.device, dtype=torch.float32)
             hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train,
                                            lin=(lin_w.contiguous(), lin_b, part), want_hs=train,
-                                           no_gates=train and ops.GATE_RECOMPUTE)
+                                           no_gates=train and ops.GATE_RECOMPUTE, consume=ovl)
             y = part.view(B, T, F, 2, Cc) if defer_sum else ops.add3(x.view(P, Cc), part).view(B, T, F, Cc)
         else:
             assert not defer_sum
@@ -121,7 +123,7 @@ class IntraPlainFn(torch.autograd.Function):
                                  hint=True)
         dx = dx.view(B, T, F, Cc)
         return (dx, gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"], gt["wir"], gt["whr"], gt["bir"],
-                gt["bhr"], gt["lin_w"], gt["lin_b"], None)
+                gt["bhr"], gt["lin_w"], gt["lin_b"], None, None)
 
 
 class InterFn(torch.autograd.Function):
@@ -130,12 +132,13 @@ class InterFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0, part=None, film_w=None, film_b=None, bank=None,
-                film_k=0):
+                film_k=0, ovl=None):
         """part (optional, [B, T, F, 2, C]): the deferred halves of the preceding IntraPlainFn -- the block input is then
         x + part[..., 0, :] + part[..., 1, :], summed by the kernel's loader; x is the intra-frame block's own input and
         gets NO gradient from here (the residual's gradient is applied by IntraPlainFn.backward, as before).
         film_w / film_b (optional, [B, F, C]): the FiLM planes of the NEXT block, applied to y in the kernel's epilogue
-        (the returned y is post-FiLM); bank / film_k as in FilmFn."""
+        (the returned y is post-FiLM); bank / film_k as in FilmFn.
+        ovl (ops.FwdOverlap): the kernel publishes y slab by slab for the next block's IntraPlainFn (overlapped forward)."""
         B, T, F, Cc = x.shape
         x = x.contiguous()
         P = B * T * F
@@ -158,7 +161,7 @@ class InterFn(torch.autograd.Function):
                                               lin=(lin_w.contiguous(), lin_b, y) if fuse else None,
                                               want_hs=train or not fuse,
                                               x_part=part.contiguous() if part is not None else None, x_sum=x_sum,
-                                              film=film)
+                                              film=film, produce=ovl if fuse else None)
         if part is not None and train:
             x = x_sum                               # the block's real input: what the backward's LayerNorm needs
         if not fuse:
@@ -199,9 +202,9 @@ class InterFn(torch.autograd.Function):
             if ctx.deferred:
                 dpart = dx.view(B, T, F, 1, Cc).expand(B, T, F, 2, Cc)
                 return (None, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
-                        None, None, dpart, d_fw, d_fb, None, None)
+                        None, None, dpart, d_fw, d_fb, None, None, None)
             return (dx, gt["ln_g"], gt["ln_b"], gt["wi"], gt["wh"], gt["bi"], gt["bh"], gt["lin_w"], gt["lin_b"],
-                    None, None, None, d_fw, d_fb, None, None)
+                    None, None, None, d_fw, d_fb, None, None, None)
 
         gP, sC = dense(P, Cc)
         _, sH = dense(P, H)

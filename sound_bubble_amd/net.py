@@ -253,6 +253,7 @@ class _NetBase(nn.Module):
             self.use_first_ln, self.stft_chunk_size, wf["front_w"])
         gb = st["gridnet_bufs"]
         film_done = False          # FiLM of block i already applied in block i-1's inter-frame kernel epilogue
+        ovl = None                 # overlapped forward: block i-1's inter-frame kernel is still producing y
         for i, blk in enumerate(tg.blocks):
             if not film_done:
                 y = self._film(y, e, i)
@@ -271,7 +272,7 @@ class _NetBase(nn.Module):
                          Fn.ops.intra_lin_fusion_ok(torch.is_grad_enabled(), y.shape[-1]))
                 part = Fn.IntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
                                              *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
-                                             blk.intra_linear.bias, defer)
+                                             blk.intra_linear.bias, defer, ovl)
                 if not defer:
                     y, part = part, None
             b = gb[f"buf{i}"]
@@ -281,9 +282,17 @@ class _NetBase(nn.Module):
                 bank, planes = e                # the next block's FiLM rides in this kernel's y epilogue
                 nf = (planes[2 * i], planes[2 * i + 1], bank, i)
                 film_done = True
+            # nothing runs between this block's inter-frame kernel and the next block's intra-frame kernel (FiLM rides in
+            # the epilogue, no attention): with fewer inter-frame tiles than CUs the two overlap
+            ovl = None
+            Bq, Tq, Fq, Cq = y.shape
+            if (part is not None and i + 1 < len(tg.blocks) and not self.conv_lstm and not self.use_attn
+                    and (e is None or film_done)
+                    and Fn.ops.can_overlap_fwd(Bq, Tq, Fq, Cq, torch.is_grad_enabled(), y.device)):
+                ovl = Fn.ops.FwdOverlap(Bq, Tq, Fq, y.device)
             y, b["h0"], b["c0"] = Fn.InterFn.apply(y, blk.inter_norm.norm.weight, blk.inter_norm.norm.bias,
                                                    *_lstm_dir(blk.inter_rnn, False), blk.inter_linear.weight,
-                                                   blk.inter_linear.bias, b["h0"], b["c0"], part, *nf)
+                                                   blk.inter_linear.bias, b["h0"], b["c0"], part, *nf, ovl)
             if self.use_attn:
                 args = []
                 for name in ("attn_conv_Q", "attn_conv_K", "attn_conv_V", "attn_concat_proj"):

@@ -149,8 +149,53 @@ def can_fuse_linear_fwd():
 GATE_RECOMPUTE = os.environ.get("SB_GATE_RECOMPUTE", "0") == "1"
 
 
+# Forward with fewer inter-frame tiles than CUs: the NEXT block's intra-frame pass starts on the idle CUs while the
+# inter-frame recurrence is still running (sb_lstm_fwd_produce / sb_lstm_fwd_consume).  SB_NO_FWD_OVERLAP=1: one after
+# the other.
+FWD_OVERLAP = os.environ.get("SB_NO_FWD_OVERLAP", "0") != "1"
+FWD_OVERLAP_FRAC = float(os.environ.get("SB_FWD_OVERLAP_FRAC", "0.5"))
+FWD_OVERLAP_SLAB = int(os.environ.get("SB_FWD_OVERLAP_SLAB", "32"))
+_TILE_ORDER = {}
+
+
+def _tile_order(B, T, slab, dev):
+    """intra-frame tiles (16 consecutive frames n = b T + t) sorted by the inter-frame time slab that completes them"""
+    key = (B, T, slab, dev.index if dev.index is not None else torch.cuda.current_device())
+    r = _TILE_ORDER.get(key)
+    if r is None:
+        import numpy as np
+        n = np.arange((B * T + 15) // 16 * 16).reshape(-1, 16)
+        need = np.where(n < B * T, (n % T) // slab, 0).max(axis=1)
+        order = np.argsort(need, kind="stable")
+        r = _TILE_ORDER[key] = (torch.from_numpy(order.astype(np.int32)).to(dev),
+                                torch.from_numpy(need[order].astype(np.int32)).to(dev))
+    return r
+
+
+class FwdOverlap:
+    """One inter-frame (block k) -> intra-frame (block k + 1) boundary of the overlapped forward: created by the model,
+    handed to lstm_fwd(produce=...) of the former and lstm_fwd(consume=...) of the latter."""
+
+    def __init__(self, B, T, F_, dev):
+        self.slab = FWD_OVERLAP_SLAB
+        self.flags = torch.empty((T + self.slab - 1) // self.slab, device=dev, dtype=torch.int32)
+        self.producer_tiles = (B * F_ + 15) // 16
+        self.order, self.need = _tile_order(B, T, self.slab, dev)
+        self.keep = []            # everything the producer touches stays allocated until the consumer has been launched
+        self.produced = False
+
+
+def can_overlap_fwd(B, T, F_, Cc, train, dev):
+    if not (FWD_OVERLAP and LSTM_MMA == 1 and Cc == 32 and can_fuse_linear_fwd() and INTER_SUM3
+            and intra_lin_fusion_ok(train, Cc) and SCHED_OVERRIDE is None):
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    return 4 * ((B * F_ + 15) // 16) <= 3 * _cu_count(dev) and T >= 4 * FWD_OVERLAP_SLAB and B * T >= 64
+
+
 def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True,
-             no_gates=False, x_part=None, x_sum=None, film=None):
+             no_gates=False, x_part=None, x_sum=None, film=None, produce=None, consume=None):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
     lin = (lin_w [C, 64], lin_b [C], y [P, C]): fused  y = x + lin_w . hs + lin_b  (single direction,
     can_fuse_linear_fwd()); with want_hs=False hs is then not materialised.
@@ -217,9 +262,29 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         by += (2 + (1 if x_sum is not None else 0)) * 4.0 * Cc * geom.P - 4.0 * Cc * geom.P   # two halves in, sum out; no second read of x
     label = f"lstm_fwd_bf_kernel C={Cc} " + ("intra-frame (bidirectional)" if ndir == 2 else "inter-frame (Linear fused)"
                                              if lin is not None else "inter-frame")
-    with _Prof(label, 2.0 * 4 * H * (Cc + H) * geom.P * ndir + (2.0 * H * Cc * geom.P if lin is not None else 0.0),
+    if consume is not None and not consume.produced:
+        consume = None
+    if consume is not None:
+        a.sched_status = C.c_void_p(sched_status(dev).data_ptr())
+    with _Prof(label + (" [producer]" if produce is not None else " [consumer, overlapped]" if consume is not None else ""),
+               2.0 * 4 * H * (Cc + H) * geom.P * ndir + (2.0 * H * Cc * geom.P if lin is not None else 0.0),
                8.0 * Cc * geom.P, by):
-        L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
+        if produce is not None:
+            assert ndir == 1 and lin is not None
+            L.check(lib.sb_lstm_fwd_produce(C.byref(a), C.c_void_p(produce.flags.data_ptr()), produce.slab, _stream()),
+                    "sb_lstm_fwd_produce")
+            produce.keep += [x, ln_g, ln_b, h0, c0, hs, gates, cprev, u, hN, cN, x_part, x_sum, seg_scratch, lin, film, dirs]
+            produce.produced = True
+        elif consume is not None:
+            assert ndir == 2 and lin is not None
+            L.check(lib.sb_lstm_fwd_consume(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
+                                            consume.producer_tiles, C.c_void_p(consume.order.data_ptr()),
+                                            C.c_void_p(consume.need.data_ptr()), FWD_OVERLAP_FRAC, _stream()),
+                    "sb_lstm_fwd_consume")
+            consume.keep.clear()
+            consume.produced = False
+        else:
+            L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
     return hs, ((hN, cN) if want_state else None), (gates, cprev), u
 
 

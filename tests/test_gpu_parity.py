@@ -786,6 +786,56 @@ def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab,
         assert float(ops.absmax_or_hint(dx1)) == float(dx1.abs().max())
 
 
+@pytest.mark.parametrize("train", [False, True], ids=["inference", "training"])
+def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train, monkeypatch):
+    """sb_lstm_fwd_produce / sb_lstm_fwd_consume: block k's inter-frame kernel publishing y slab by slab while block k+1's
+    intra-frame pass (ordered items, persistent workgroups on the library's side stream, the rest after the producer)
+    already consumes it -- against the plain launch order on the big-family model at 150 frames: the separated output
+    and the final streaming state must be bit-identical (same per-sequence arithmetic, only the schedule differs), in
+    training also the loss and every parameter gradient (overlapped backward on in both runs)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    rec, params, m = _build(torch, "tiny_big", "NetDisEmbd3")
+    torch.manual_seed(5)
+    B_ = 2
+    x = (0.1 * torch.randn(B_, rec["mixture"].shape[1], 192 * 150 + 96)).cuda()
+    dis = torch.from_numpy(rec["dis_embed"][:1]).cuda().expand(B_, -1).contiguous()
+    tgt = (0.05 * torch.randn(B_, 1, 192 * 150)).cuda()
+    monkeypatch.setattr(ops, "FWD_OVERLAP_FRAC", 0.6)
+
+    def run(overlap):
+        monkeypatch.setattr(ops, "FWD_OVERLAP", overlap)
+        used = []
+        orig = ops.FwdOverlap.__init__
+        monkeypatch.setattr(ops.FwdOverlap, "__init__", lambda self, *a: (used.append(1), orig(self, *a))[1])
+        m.train(train)
+        for p_ in m.parameters():
+            p_.grad = None
+        with torch.set_grad_enabled(train):
+            res = m({"mixture": x, "dis_embed": dis}, pad=False)
+            grads = None
+            if train:
+                loss, _ = SnrlpLossFn.apply(res["output"], tgt, 100.0)
+                loss.backward()
+                grads = {k: p_.grad.clone() for k, p_ in m.named_parameters()}
+        torch.cuda.synchronize()
+        ops.check_sched_status()
+        monkeypatch.setattr(ops.FwdOverlap, "__init__", orig)
+        return res, grads, len(used)
+
+    r0, g0, n0 = run(False)
+    r1, g1, n1 = run(True)
+    nblocks = len(m.tfgridnet.blocks)
+    assert n0 == 0 and n1 == nblocks - 1, (n0, n1)         # every inter -> intra boundary took the overlapped path
+    assert torch.equal(r0["output"], r1["output"])
+    for (k, a_), (_, b_) in zip(flatten_state(r0["next_state"]).items(), flatten_state(r1["next_state"]).items()):
+        assert np.array_equal(a_, b_), k
+    if train:
+        for k in g0:
+            assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-5, k      # atomic accumulation order
+
+
 @pytest.mark.parametrize("sched", [None, (4, 3)], ids=["plain", "time-segmented"])
 @pytest.mark.parametrize("save", [False, True], ids=["inference", "training"])
 def test_inter_forward_with_summed_input_is_bit_identical_to_add3(torch_gpu, sched, save, monkeypatch):
