@@ -328,6 +328,11 @@ int sb_lstm_stream_grid(int64_t positions);
 int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec, const sb_lstm_stream_args* st, int* flags, int slab_len,
                                  double frac, void* stream);
 int sb_lstm_overlap_rows(int64_t positions, int nseq);
+/* The overlapped calls need a side stream whose kernels really run at the same time as those of `stream` (the runtime
+ * multiplexes streams over a few hardware queues; two streams on one queue serialise).  Returns 1 when the library has
+ * found one for `stream` -- probed on first use with a pair of tiny kernels, synchronising `stream` once -- and 0 when the
+ * overlapped entry points would return -1009 (use the plain calls).  Not to be called while `stream` is capturing. */
+int sb_overlap_available(void* stream);
 
 /* ---- LayerNorm (+PReLU) backward over C channels ---------------------------
  * g = sum_d du_part[p, d, :];  x = xin[p] (PReLU(xin[p]) with slope *prelu_a when prelu_a != NULL);

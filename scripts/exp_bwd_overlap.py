@@ -8,6 +8,35 @@ if os.environ.get("SB_LIB_VARIANT"):
     _L.LIB_PATH = os.path.join(os.path.dirname(_L.LIB_PATH), "exp", f"lib_{os.environ['SB_LIB_VARIANT']}.so")
 from sound_bubble_amd import ops
 
+PRE = os.environ.get("PRE", "")
+if "streams" in PRE:                      # torch's stream pool (32 streams) before the library's side stream exists
+    _s = [torch.cuda.Stream() for _ in range(4)]
+    with torch.cuda.stream(_s[0]):
+        torch.zeros(8, device="cuda")
+    torch.cuda.synchronize()
+if "graph" in PRE:
+    _g = torch.cuda.CUDAGraph()
+    _x = torch.zeros(1024, device="cuda")
+    with torch.cuda.graph(_g):
+        _x += 1
+    if "noreplay" not in PRE:
+        _g.replay()
+    torch.cuda.synchronize()
+    if "del" in PRE:
+        del _g
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+if "capture" in PRE:                      # raw stream capture without instantiating a graph exec
+    _cs = torch.cuda.Stream()
+    _x = torch.zeros(1024, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(_cs):
+        _x += 1
+    torch.cuda.synchronize()
+if "mem" in PRE:                          # a fragmented caching-allocator pool
+    _t = [torch.empty(int(n), device="cuda") for n in (3e8, 1e8, 2e8, 5e7, 1.5e8, 7e7)]
+    del _t
 B_, T_, F_, C_ = 16, 625, 145, 32
 geom = ops.Geom.inter(B_, T_, F_)
 torch.manual_seed(0)

@@ -8,6 +8,8 @@
 // "position on the k-lanes".  Instead of 4-byte loads, gate columns / hidden units are assigned to MFMA tiles
 // as  gate = 64*w + 4*i + tile  (unit = 4*i + tile), so ONE 16-byte load per lane per position yields the
 // operand of four tiles at once (4 x 256 B contiguous per wave-instruction instead of 16 x 64 B).
+#include <cstdio>
+#include <cstdlib>
 #include "sb_common.h"
 #include "../../include/sound_bubble_hip.h"
 
@@ -942,20 +944,83 @@ extern "C" int sb_lstm_bwd_stream(const sb_lstm_stream_args* ap, void* stream) {
   return 0;
 }
 
-// ---- overlapped inter-frame backward (see the header) ----
+// ---- overlapped schedules: the side stream (see the header) ----
 namespace {
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-SideStream* side_stream() {
+// The runtime multiplexes HIP streams over a few hardware queues, and not every pair of queues gives real concurrency:
+// measured on MI355X / ROCm 7.2, a side stream created after torch had used another stream of its pool (graph capture is
+// enough) landed on a queue whose kernels made no progress until the main stream's kernel had drained -- the "overlapped"
+// step ran at 434-552 instead of 560 (plain) / 590 (overlapped, fresh process) utterances/s, although spin-wait probe
+// kernels on the same pair of streams did see each other.  So a candidate side stream is TIMED against the caller's
+// stream with the shape of the real thing and the choreography of the real calls (fork event, main launch, side launch,
+// join): a fixed amount of dependent arithmetic in 9/16 of the CUs' worth of one-per-CU workgroups (96 KB of LDS each) on
+// the caller's stream and in 3/8 of the CUs' worth on the candidate; the pair must take less than 0.7 of the two solo
+// times added up.  Up to 8 candidates, each created while the rejected ones are still alive so that it lands on the next
+// queue; none passing = no overlap on this stream (sb_overlap_available() == 0, the overlapped calls return -1009).
+__global__ __launch_bounds__(256) void probe_busy_kernel(float* sink, int iters) {
+  __shared__ float pad[24 * 1024];
+  pad[threadIdx.x] = (float)threadIdx.x;
+  __syncthreads();
+  float x = pad[(threadIdx.x * 7) & 255] * 1e-3f + 1.0f;
+  for (int i = 0; i < iters; ++i) x = __builtin_fmaf(x, 0.999999f, 1e-7f);
+  if (x == 123.456f) sink[0] = x + pad[3];       // never true: keeps the chain
+}
+
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; hipStream_t main = nullptr;
+                    bool probed = false; };
+SideStream* side_stream(hipStream_t main_st) {
   static SideStream tab[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideStream& t = tab[dev];
-  if (!t.s) {
-    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (t.probed && t.main == main_st) return t.s ? &t : nullptr;
+  // (re)probe for this caller stream
+  if (t.s) { (void)hipStreamDestroy(t.s); t.s = nullptr; }
+  t.probed = true; t.main = main_st;
+  if (!t.fork && (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess))
+    return nullptr;
+  float* buf = nullptr;
+  if (hipMalloc(&buf, 4 * sizeof(float)) != hipSuccess) return nullptr;
+  int cus = 0;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (cus < 32 || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(buf); return nullptr; }
+  const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 40000;          // ~0.2-0.3 ms each
+  auto timed = [&](hipStream_t side, bool a, bool b) -> float {         // ms; < 0 on error
+    if (hipEventRecord(e0, main_st) != hipSuccess) return -1.f;
+    if (side && hipEventRecord(t.fork, main_st) != hipSuccess) return -1.f;
+    if (a) hipLaunchKernelGGL(probe_busy_kernel, dim3(ga), dim3(256), 0, main_st, buf, iters);
+    if (b) {
+      if (side) {
+        if (hipStreamWaitEvent(side, t.fork, 0) != hipSuccess) return -1.f;
+        hipLaunchKernelGGL(probe_busy_kernel, dim3(gb), dim3(256), 0, side, buf, iters);
+        if (hipEventRecord(t.join, side) != hipSuccess || hipStreamWaitEvent(main_st, t.join, 0) != hipSuccess) return -1.f;
+      } else {
+        hipLaunchKernelGGL(probe_busy_kernel, dim3(gb), dim3(256), 0, main_st, buf, iters);
+      }
+    }
+    float ms = -1.f;
+    if (hipEventRecord(e1, main_st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+        hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+      return -1.f;
+    return ms;
+  };
+  (void)timed(nullptr, true, true);                                      // warm-up (code object load)
+  const float solo = timed(nullptr, true, true);                         // both on the caller's stream: one after the other
+  hipStream_t rejected[8];
+  int nrej = 0;
+  for (int c = 0; c < 8 && !t.s && solo > 0.f; ++c) {
+    hipStream_t cand = nullptr;
+    if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+    (void)timed(cand, true, true);
+    const float pair = timed(cand, true, true);
+    if (getenv("SB_OVERLAP_DEBUG")) fprintf(stderr, "[sb] side-stream probe %d: back to back %.3f ms, pair %.3f ms\n", c, solo, pair);
+    if (pair > 0.f && pair < 0.7f * solo) t.s = cand; else rejected[nrej++] = cand;
   }
-  return &t;
+  for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  return t.s ? &t : nullptr;
 }
 int device_cus() {
   int dev = 0, n = 0;
@@ -963,11 +1028,24 @@ int device_cus() {
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   return n;
 }
+// Workgroups a side launch may have next to a `tiles`-workgroup launch when neither can share a CU with the other: the
+// dispatcher deals the workgroups of a launch round-robin over the XCDs (8 x 32 CUs on MI355X), so what counts is the room
+// left in the FULLEST XCD, not the chip-wide CU count.  (First version: CUs - tiles = 111 next to 145 tiles, i.e. 19 + 14
+// workgroups for the 32 CUs of one XCD whenever the two round-robins did not happen to interleave -- the one workgroup
+// left over started after the producer had drained and ran its share alone: 1154 instead of 650 us.)
+int idle_slots(int tiles) {
+  const int cus = device_cus();
+  const int nx = cus >= 64 ? cus / 32 : 1, per = cus / nx;
+  const int room = per - (tiles + nx - 1) / nx;
+  return room > 0 ? room * nx : 0;
+}
 }  // namespace
 
+// 1 when kernels on the library's side stream run concurrently with kernels on `stream` (probed once per stream)
+extern "C" int sb_overlap_available(void* stream) { return side_stream((hipStream_t)stream) != nullptr ? 1 : 0; }
+
 extern "C" int sb_lstm_overlap_rows(int64_t positions, int nseq) {
-  const int idle = device_cus() - (nseq + 15) / 16;
-  return (idle > 0 ? idle : 0) + sb_lstm_stream_grid(positions);
+  return idle_slots((nseq + 15) / 16) + sb_lstm_stream_grid(positions);
 }
 
 extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args* st_in, int* flags,
@@ -982,9 +1060,9 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
       slab_len < 2 || (slab_len & 1) || sa.shift_pos <= 0 || sa.seg_len != T * sa.shift_pos || sa.P % sa.seg_len != 0 ||
       sa.seg_len < 32 || !(frac > 0.0 && frac < 1.0))
     return -1003;
-  const int idle = device_cus() - ntiles;
+  const int idle = idle_slots(ntiles);
   if (idle < 16) return -1003;
-  SideStream* ss = side_stream();
+  SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
   const int nslabs = (T + slab_len - 1) / slab_len;
   const int nb = (int)(sa.P / sa.seg_len);
@@ -1030,8 +1108,8 @@ extern "C" int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a_in, int* flags, int
   sb_lstm_fwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
   const int ntiles = (a.nseq + 15) / 16;
-  if (a.ndir != 1 || !a.lin_w || slab_len < 4 || (slab_len & 3) || device_cus() - ntiles < 16) return -1003;
-  SideStream* ss = side_stream();
+  if (a.ndir != 1 || !a.lin_w || slab_len < 4 || (slab_len & 3) || idle_slots(ntiles) < 16) return -1003;
+  SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
   const int nslabs = (a.nsteps + slab_len - 1) / slab_len;
   if (hipMemsetAsync(flags, 0, (size_t)nslabs * sizeof(int), main_st) != hipSuccess) return -1009;
@@ -1046,15 +1124,17 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
   sb_lstm_fwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
   const int ntiles = (a.nseq + 15) / 16, nitems = 2 * ntiles;
-  const int idle = device_cus() - producer_tiles;
+  const int idle = idle_slots(producer_tiles);
   if (a.ndir != 2 || !a.lin_w || !a.sched_status || idle < 16 || !(frac > 0.0 && frac < 1.0)) return -1003;
-  SideStream* ss = side_stream();
+  SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
   int split = ((int)(frac * nitems)) & ~1;             // both directions of a tile stay in the same launch
   if (split < 2) split = 2;
   if (split > nitems - 2) split = nitems - 2;
   if (split < 2) return -1003;
-  int g1 = 2 * idle;                                    // two workgroups per CU are resident (254 registers each)
+  // one workgroup per idle CU: should the dispatcher place the side launch first and spread it one per CU, the producer
+  // still finds its CUs free (a producer workgroup cannot share a CU with one of these: 274 + 254 registers per lane)
+  int g1 = idle & ~1;
   if (g1 > split) g1 = split;
   a.slab_flags = flags; a.slab_len = slab_len; a.slab_need = producer_tiles;
   a.tile_order = order; a.tile_need = need;

@@ -153,7 +153,7 @@ GATE_RECOMPUTE = os.environ.get("SB_GATE_RECOMPUTE", "0") == "1"
 # inter-frame recurrence is still running (sb_lstm_fwd_produce / sb_lstm_fwd_consume).  SB_NO_FWD_OVERLAP=1: one after
 # the other.
 FWD_OVERLAP = os.environ.get("SB_NO_FWD_OVERLAP", "0") != "1"
-FWD_OVERLAP_FRAC = float(os.environ.get("SB_FWD_OVERLAP_FRAC", "0.5"))
+FWD_OVERLAP_FRAC = float(os.environ.get("SB_FWD_OVERLAP_FRAC", "0.4"))
 FWD_OVERLAP_SLAB = int(os.environ.get("SB_FWD_OVERLAP_SLAB", "32"))
 _TILE_ORDER = {}
 
@@ -170,6 +170,20 @@ def _tile_order(B, T, slab, dev):
         r = _TILE_ORDER[key] = (torch.from_numpy(order.astype(np.int32)).to(dev),
                                 torch.from_numpy(need[order].astype(np.int32)).to(dev))
     return r
+
+
+_OVERLAP_OK = {}
+
+
+def overlap_available():
+    """kernels on the library's side stream really run next to those of the current stream (sb_overlap_available: probed
+    once per stream -- a side stream that shares the hardware queue of the main stream would serialise the two launches)"""
+    st = _stream()
+    key = (torch.cuda.current_device(), st.value)
+    ok = _OVERLAP_OK.get(key)
+    if ok is None:
+        ok = _OVERLAP_OK[key] = bool(L.load().sb_overlap_available(st))
+    return ok
 
 
 class FwdOverlap:
@@ -191,7 +205,8 @@ def can_overlap_fwd(B, T, F_, Cc, train, dev):
         return False
     if torch.cuda.is_current_stream_capturing():
         return False
-    return 4 * ((B * F_ + 15) // 16) <= 3 * _cu_count(dev) and T >= 4 * FWD_OVERLAP_SLAB and B * T >= 64
+    return (4 * ((B * F_ + 15) // 16) <= 3 * _cu_count(dev) and T >= 4 * FWD_OVERLAP_SLAB and B * T >= 64
+            and overlap_available())
 
 
 def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True,
@@ -421,7 +436,7 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
 # Inter-frame backward with fewer tiles than CUs: the streaming part starts on the idle CUs while the recurrence is still
 # running (sb_lstm_bwd_inter_overlapped).  SB_NO_BWD_OVERLAP=1: the two launches one after the other.
 BWD_OVERLAP = os.environ.get("SB_NO_BWD_OVERLAP", "0") != "1"
-BWD_OVERLAP_FRAC = float(os.environ.get("SB_BWD_OVERLAP_FRAC", "0.5"))
+BWD_OVERLAP_FRAC = float(os.environ.get("SB_BWD_OVERLAP_FRAC", "0.45"))
 BWD_OVERLAP_SLAB = int(os.environ.get("SB_BWD_OVERLAP_SLAB", "32"))
 
 
@@ -435,7 +450,8 @@ def can_overlap_inter_bwd(geom, u, hs):
         return False
     ntiles = (geom.nseq + 15) // 16
     cus = _cu_count(u.device)
-    return 4 * ntiles <= 3 * cus and geom.nsteps >= 4 * BWD_OVERLAP_SLAB and geom.n_inner * geom.nsteps >= 32
+    return (4 * ntiles <= 3 * cus and geom.nsteps >= 4 * BWD_OVERLAP_SLAB and geom.n_inner * geom.nsteps >= 32
+            and overlap_available())
 
 
 def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets, ln):
