@@ -985,7 +985,7 @@ SideStream* side_stream(hipStream_t main_st) {
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (cus < 32 || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(buf); return nullptr; }
-  const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 40000;          // ~0.2-0.3 ms each
+  const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 12000;          // ~0.2 ms each
   auto timed = [&](hipStream_t side, bool a, bool b) -> float {         // ms; < 0 on error
     if (hipEventRecord(e0, main_st) != hipSuccess) return -1.f;
     if (side && hipEventRecord(t.fork, main_st) != hipSuccess) return -1.f;

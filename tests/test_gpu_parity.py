@@ -751,6 +751,8 @@ def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab,
     from sound_bubble_amd import ops
     if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.can_fuse_linear_fwd() and ops.STREAM_LIN_WGRAD):
         pytest.skip("default compact fp16 path only")
+    if not ops.overlap_available():
+        pytest.skip("no side stream that runs concurrently with the main stream on this box")
     monkeypatch.setattr(ops, "BWD_OVERLAP_SLAB", slab)
     monkeypatch.setattr(ops, "BWD_OVERLAP_FRAC", frac)
     torch.manual_seed(23)
@@ -803,6 +805,9 @@ def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train
     dis = torch.from_numpy(rec["dis_embed"][:1]).cuda().expand(B_, -1).contiguous()
     tgt = (0.05 * torch.randn(B_, 1, 192 * 150)).cuda()
     monkeypatch.setattr(ops, "FWD_OVERLAP_FRAC", 0.6)
+    monkeypatch.setattr(ops, "FWD_OVERLAP_INFERENCE", True)      # off by default (it only pays in training)
+    if not ops.overlap_available():
+        pytest.skip("no side stream that runs concurrently with the main stream on this box")
 
     def run(overlap):
         monkeypatch.setattr(ops, "FWD_OVERLAP", overlap)
