@@ -90,7 +90,7 @@ typedef struct {
   int aux_f16;
   /* overlapped forward (set by sb_lstm_fwd_produce / sb_lstm_fwd_consume; leave NULL / 0 otherwise) */
   int* slab_flags; int slab_len, slab_need;
-  const int* tile_order; const int* tile_need; int item_begin, item_end, ord_grid;
+  const int* tile_order; const int* tile_need; int* ord_counter; int* ord_started; int ord_guard, ord_grid;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 
@@ -99,20 +99,21 @@ int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
  * pass that follows it needs, for a tile of 16 frames (b, t .. t + 15), only the y rows of those frames.  Two calls:
  *   sb_lstm_fwd_produce(a, flags, slab_len, stream): sb_lstm_fwd of a single-direction pass with the fused Linear (y
  *     written; fewer tiles than CUs, no time segments) on `stream`; y rows are stored write-through and after every
- *     slab_len steps (multiple of 4) each tile counts itself into flags[k] ([ceil(nsteps / slab_len)] ints, zeroed by the
- *     call).
- *   sb_lstm_fwd_consume(a, flags, slab_len, producer_tiles, order, need, frac, stream): sb_lstm_fwd of the
- *     bidirectional partial-Linear pass (ndir == 2, lin_w != NULL, C == 32; a->x is the producer's y) whose tiles are
- *     taken in the order order[ntiles] (a permutation sorted by need[], need[i] = time slab of the producer that
- *     completes the frames of tile order[i]); the first frac of the 2 * ntiles (tile, direction) items run as persistent
- *     workgroups on a side stream of the library -- at most two per CU the producer leaves idle -- each item waiting
- *     (bounded; a->sched_status required) for flags[need] == producer_tiles; the rest follows on `stream` after the join.
+ *     slab_len steps (multiple of 4) each tile counts itself into flags[4 + k].  flags: [4 + ceil(nsteps / slab_len)]
+ *     ints, zeroed by the call ([0] producer workgroups started, [1], [2] the consumer's item counters, [3] spare).
+ *   sb_lstm_fwd_consume(a, flags, slab_len, producer_tiles, order, need, stream): sb_lstm_fwd of the bidirectional
+ *     partial-Linear pass (ndir == 2, lin_w != NULL, C == 32; a->x is the producer's y) whose tiles are taken in the
+ *     order order[ntiles] (a permutation sorted by need[], need[i] = time slab of the producer that completes the frames
+ *     of tile order[i]) as (tile, direction) items drawn from one atomic counter per direction by TWO launches: persistent
+ *     workgroups on a side stream of the library (two per CU the producer leaves idle; guarded: a workgroup that does not
+ *     see all producer workgroups started within ~50 us leaves), each item waiting (bounded; a->sched_status required) for
+ *     flags[4 + need] == producer_tiles, and one workgroup per item on `stream` behind the producer, taking what is left.
  * The consume call must be the next library call after its produce call on that device.  Memory the producer reads or
  * writes must stay allocated until the consume call has returned (the side stream is not ordered after `stream`).
- * -1003 when fewer than 16 CUs stay idle. */
+ * -1003 when fewer than 16 CUs stay idle, -1009 without a concurrent side stream (sb_overlap_available). */
 int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a, int* flags, int slab_len, void* stream);
 int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
-                        const int* need, double frac, void* stream);
+                        const int* need, void* stream);
 
 /* ---- recurrent LSTM (backward through time, recurrent part) --------------
  * Autograd of the nn.LSTM calls above (loss.backward(), tain_val.py:75).

@@ -26,8 +26,8 @@ class LstmFwdArgs(C.Structure):
                 ("sched_status", c_fp), ("sched_workers", C.c_int), ("sched_segments", C.c_int),
                 ("aux_f16", C.c_int),
                 ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_need", C.c_int),
-                ("tile_order", C.c_void_p), ("tile_need", C.c_void_p), ("item_begin", C.c_int), ("item_end", C.c_int),
-                ("ord_grid", C.c_int)]
+                ("tile_order", C.c_void_p), ("tile_need", C.c_void_p), ("ord_counter", C.c_void_p),
+                ("ord_started", C.c_void_p), ("ord_guard", C.c_int), ("ord_grid", C.c_int)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -128,7 +128,7 @@ _vp, _ci, _cf = C.c_void_p, C.c_int, C.c_float
 SYMBOLS = {
     "sb_lstm_fwd": (_ci, [C.POINTER(LstmFwdArgs), _vp]),
     "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
-    "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, C.c_double, _vp]),
+    "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),
     "sb_lstm_bwd_rec": (_ci, [C.POINTER(LstmBwdArgs), _vp]),
     "sb_linear_fwd": (_ci, [C.POINTER(LinearArgs), _vp]),
     "sb_linear_grid": (_ci, [i64]),

@@ -169,10 +169,13 @@ struct XVec { float v[C / 16]; };
 // four-row LDS ring (the residual is needed two barriers after the row was normalised).
 // Overlapped forward (sb_lstm_fwd_produce / sb_lstm_fwd_consume): an inter-frame pass with fewer tiles than CUs publishes
 // its y rows (write-through, sc1) and counts itself into slab_flags[k] after every slab_len time steps (runtime flag:
-// a.slab_flags on a single-direction LIN launch); the NEXT block's intra-frame pass (ORD: 1-D grid, item i = direction i & 1
-// of tile tile_order[i >> 1], tiles ordered by the latest time slab their 16 frames need) starts on the idle CUs and each
-// item waits for slab_flags[tile_need[i >> 1]] to reach slab_need.  An input row is one 128-byte line that only its frame's
-// items ever read, so no line of an unfinished slab enters the reader's L2.
+// a.slab_flags on a single-direction LIN launch); the NEXT block's intra-frame pass (ORD: 1-D grid, direction = workgroup
+// parity, tiles tile_order[0 .. ntiles) sorted by the latest time slab their 16 frames need, drawn by the workgroups of BOTH
+// launches of the pass from one atomic counter per direction) starts on the idle CUs and each item waits for
+// slab_flags[tile_need[i]] to reach slab_need.  An input row is one 128-byte line that only its frame's items ever read,
+// so no line of an unfinished slab enters the reader's L2.  Guarded launch (ord_guard, the one that runs NEXT to the
+// producer): a workgroup that does not find every producer workgroup started within ~50 us leaves at once -- should the
+// dispatcher have placed this launch first, it must not sit on the CUs the producer needs.
 SB_DEVINL void st4_sc1(float* p, const f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
@@ -185,10 +188,35 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   constexpr int NT = PR::NT;
   constexpr int VPT = C / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
-  const int dir = ORD ? (a.item_begin + (int)blockIdx.x) & 1 : (int)blockIdx.y;
+  const int dir = ORD ? (int)blockIdx.x & 1 : (int)blockIdx.y;
   const int S = a.nsteps;
   const bool rev = dir == 1;
   const bool prod = LIN && !ORD && !SEG && a.slab_flags != nullptr;      // producer side of the overlapped forward
+  if (prod && tid == 0) __hip_atomic_fetch_add(a.ord_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __shared__ int ord_item;
+  auto ord_next = [&]() -> int {                     // next (tile, this direction) item; uniform over the workgroup
+    if (tid == 0) ord_item = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return ord_item;
+  };
+  int ord_first = 0;
+  if constexpr (ORD) {
+    if (a.ord_guard) {
+      if (tid == 0) {
+        int ok = 0;
+        for (int i = 0; i < 200 && !ok; ++i) {
+          ok = __hip_atomic_load(a.ord_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.slab_need;
+          if (!ok) __builtin_amdgcn_s_sleep(8);
+        }
+        ord_item = ok;
+      }
+      __syncthreads();
+      if (!ord_item) return;
+      __syncthreads();
+    }
+    ord_first = ord_next();                           // before the weights are fetched: most late workgroups find nothing
+    if (ord_first >= (a.nseq + 15) / 16) return;
+  }
 
   __shared__ __attribute__((aligned(16))) elem U16[2][NT][16][UP];      // [buf][term][seq][channel]
   __shared__ __attribute__((aligned(16))) elem H16[2][NT][16][HP16];    // [buf][term][seq][unit]
@@ -519,13 +547,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(a.slab_flags + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  const int item0 = ORD ? a.item_begin + (int)blockIdx.x : (int)blockIdx.x, item1 = ORD ? a.item_end : nitems;
-  for (int item = item0; item < item1; item += gridDim.x) {       // ORD: gridDim.x is even (the direction is fixed per workgroup)
+  const int item1 = ORD ? ntiles : nitems;
+  for (int item = ORD ? ord_first : (int)blockIdx.x; item < item1; item = ORD ? ord_next() : item + (int)gridDim.x) {
     const int seg = SEG ? item / ntiles : 0;
-    const int tile = ORD ? a.tile_order[item >> 1] : SEG ? item - seg * ntiles : item;
+    const int tile = ORD ? a.tile_order[item] : SEG ? item - seg * ntiles : item;
     s_begin = SEG ? seg * a.seg_len : 0;
     const int s_end = SEG ? min(S, s_begin + a.seg_len) : S;
-    if constexpr (ORD) { if (!seg_wait(a.slab_flags, a.tile_need[item >> 1], a.slab_need, a.sched_status)) return; }
+    if constexpr (ORD) { if (!seg_wait(a.slab_flags, a.tile_need[item], a.slab_need, a.sched_status)) return; }
     set_tile(tile);
     // ---- initial state of this item ----
     c = zero4();
@@ -1480,11 +1508,10 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
       (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
     }
   }
-  if (a.slab_flags && (seg || !lin || !f16 || a.slab_len < 4 || (a.slab_len & 3))) return -1003;
+  if (a.slab_flags && (seg || !lin || !f16 || a.slab_len < 4 || (a.slab_len & 3) || !a.ord_started)) return -1003;
   if (a.tile_order) {    // consumer side of the overlapped forward: bidirectional partial-Linear pass, ordered 1-D grid
-    if (!a.slab_flags || !a.tile_need || !a.sched_status || a.ndir != 2 || a.C != 32 || (save != 0 && save != 3) ||
-        a.item_begin < 0 || a.item_end > 2 * ntiles || a.item_begin >= a.item_end || a.ord_grid < 1 ||
-        (a.ord_grid > 1 && (a.ord_grid & 1)))
+    if (!a.slab_flags || !a.tile_need || !a.sched_status || !a.ord_counter || !a.ord_started || a.ndir != 2 || a.C != 32 ||
+        (save != 0 && save != 3) || a.ord_grid < 2 || (a.ord_grid & 1))
       return -1003;
     dim3 g1(a.ord_grid);
 #define SB_LO(SV, FL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, false, false, true>), g1, dim3(256), 0, st, a)

@@ -1103,48 +1103,48 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
 }
 
 // ---- overlapped forward (see the header) ----
+// flags layout: [0] producer workgroups started, [1], [2] the consumer's item counters (one per direction), [3] spare,
+// [4 ..] the slab flags
 extern "C" int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, void* stream) {
   if (!a_in || !flags) return -1001;
   sb_lstm_fwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
   const int ntiles = (a.nseq + 15) / 16;
-  if (a.ndir != 1 || !a.lin_w || slab_len < 4 || (slab_len & 3) || idle_slots(ntiles) < 16) return -1003;
+  if (a.ndir != 1 || !a.lin_w || slab_len < 4 || (slab_len & 3) || device_cus() - ntiles < 16) return -1003;
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
   const int nslabs = (a.nsteps + slab_len - 1) / slab_len;
-  if (hipMemsetAsync(flags, 0, (size_t)nslabs * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (hipMemsetAsync(flags, 0, (size_t)(nslabs + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
-  a.slab_flags = flags; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
+  a.slab_flags = flags + 4; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
+  a.ord_started = flags;
   return sb_lstm_fwd(&a, stream);
 }
 
 extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, int producer_tiles,
-                                   const int* order, const int* need, double frac, void* stream) {
+                                   const int* order, const int* need, void* stream) {
   if (!a_in || !flags || !order || !need) return -1001;
   sb_lstm_fwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
-  const int ntiles = (a.nseq + 15) / 16, nitems = 2 * ntiles;
-  const int idle = idle_slots(producer_tiles);
-  if (a.ndir != 2 || !a.lin_w || !a.sched_status || idle < 16 || !(frac > 0.0 && frac < 1.0)) return -1003;
+  const int ntiles = (a.nseq + 15) / 16;
+  const int idle = device_cus() - producer_tiles;
+  if (a.ndir != 2 || !a.lin_w || !a.sched_status || idle < 16 || slab_len < 4) return -1003;
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
-  int split = ((int)(frac * nitems)) & ~1;             // both directions of a tile stay in the same launch
-  if (split < 2) split = 2;
-  if (split > nitems - 2) split = nitems - 2;
-  if (split < 2) return -1003;
-  // one workgroup per idle CU: should the dispatcher place the side launch first and spread it one per CU, the producer
-  // still finds its CUs free (a producer workgroup cannot share a CU with one of these: 274 + 254 registers per lane)
-  int g1 = idle & ~1;
-  if (g1 > split) g1 = split;
-  a.slab_flags = flags; a.slab_len = slab_len; a.slab_need = producer_tiles;
+  a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_need = producer_tiles;
   a.tile_order = order; a.tile_need = need;
+  a.ord_started = flags; a.ord_counter = flags + 1;
+  // next to the producer: two persistent workgroups per idle CU (254 registers each; none fits on a producer's CU); one
+  // that cannot be placed at once simply starts later and draws fewer items
+  int g1 = 2 * idle;
+  if (g1 > 2 * ntiles) g1 = 2 * ntiles;
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
-  a.item_begin = 0; a.item_end = split; a.ord_grid = g1;
+  a.ord_guard = 1; a.ord_grid = g1;
   int rc = sb_lstm_fwd(&a, ss->s);
   if (rc) return rc;
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
-  // the rest on `stream` (ordered after the producer: all flags are up), one item per workgroup; then the join
-  a.item_begin = split; a.item_end = nitems; a.ord_grid = nitems - split;
+  // behind the producer on `stream` (all flags up): one workgroup per item, each taking what is left; then the join
+  a.ord_guard = 0; a.ord_grid = 2 * ntiles;
   rc = sb_lstm_fwd(&a, stream);
   if (hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
   return rc;

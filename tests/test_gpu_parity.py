@@ -804,8 +804,6 @@ def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train
     x = (0.1 * torch.randn(B_, rec["mixture"].shape[1], 192 * 150 + 96)).cuda()
     dis = torch.from_numpy(rec["dis_embed"][:1]).cuda().expand(B_, -1).contiguous()
     tgt = (0.05 * torch.randn(B_, 1, 192 * 150)).cuda()
-    monkeypatch.setattr(ops, "FWD_OVERLAP_FRAC", 0.6)
-    monkeypatch.setattr(ops, "FWD_OVERLAP_INFERENCE", True)      # off by default (it only pays in training)
     if not ops.overlap_available():
         pytest.skip("no side stream that runs concurrently with the main stream on this box")
 

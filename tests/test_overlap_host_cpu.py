@@ -23,3 +23,4 @@ def test_tile_order_is_a_permutation_sorted_by_the_slab_that_completes_the_tile(
     if B > 1 and T % 16:
         straddle = [i for i, tile in enumerate(order) if (16 * tile) // T != min(16 * tile + 15, B * T - 1) // T]
         assert straddle and all(need[i] == nslabs - 1 for i in straddle)
+
