@@ -167,7 +167,7 @@ typedef struct {
      hs and the forward weights w_ih / w_ih1, w_hh[2], b_ih[2], b_hh[2] (single fp16 terms on the matrix pipe). */
   int recompute; const float* b_ih[2]; const float* b_hh[2];
   /* producer side of sb_lstm_bwd_inter_overlapped (set by that call; leave NULL / 0 otherwise) */
-  int* slab_flags; int slab_len;
+  int* slab_flags; int slab_len; int* slab_started;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 
@@ -310,7 +310,8 @@ typedef struct {
      column sums of ln_res (the scratch rows grow by another 64C + C floats; gmax must be max |ln_res| or above). */
   float* d_lin_w; float* d_lin_b;
   /* consumer side of sb_lstm_bwd_inter_overlapped (set by that call; leave NULL / 0 otherwise) */
-  int* slab_flags; int slab_len, slab_need; int chunk_begin, chunk_end, row_base; int* sched_status; int chunk_reverse;
+  int* slab_flags; int slab_len, slab_need; int* chunk_counter; int* started; int nchunks, guard, row_base;
+  int* sched_status;
 } sb_lstm_stream_args;
 int sb_lstm_bwd_stream(const sb_lstm_stream_args* a, void* stream);
 int sb_lstm_stream_grid(int64_t positions);
@@ -318,16 +319,19 @@ int sb_lstm_stream_grid(int64_t positions);
 /* ---- inter-frame LSTM backward, recurrence and streaming part OVERLAPPED ---------------------------------------
  * The inter-frame recurrence has nseq/16 serial chains (145 at the BASELINE big configuration) -- fewer than the chip has
  * CUs -- and the streaming part that follows is throughput work.  This call runs both at once: `rec` (dy form, compact
- * fp16 dgates, single direction) on `stream`, publishing the dgates per slab of `slab_len` time steps, and the first
- * `frac` of the streaming part (fused LayerNorm backward + Linear weight gradient form: st->dx and st->d_lin_w set) on a
- * side stream of the library with a grid of (CUs - tiles) workgroups, slab by slab behind the recurrence; the rest of the
- * streaming part follows on `stream` with the full grid.  Both kernels poll bounded (st->sched_status: watchdog word as
- * in sb_lstm_fwd_args, required).
- *   flags [ceil(nsteps / slab_len)] ints (zeroed by the call); slab_len even, >= 2
+ * fp16 dgates, single direction) on `stream`, publishing the dgates per slab of `slab_len` time steps, and the streaming
+ * part (fused LayerNorm backward + Linear weight gradient form: st->dx and st->d_lin_w set) as TWO launches whose
+ * workgroups draw units of 16 consecutive 32-position chunks from one atomic counter in production order: one on a side
+ * stream of the library with a workgroup per CU the recurrence leaves idle (guarded: a workgroup that does not see every
+ * recurrence workgroup started within ~50 us draws nothing), each unit waiting (bounded) for its slab, and one on
+ * `stream` behind the recurrence with a workgroup per CU, taking what is left.  st->sched_status: watchdog word as in
+ * sb_lstm_fwd_args, required.
+ *   flags [4 + ceil(nsteps / slab_len)] ints (zeroed by the call); slab_len even, >= 2
  *   st->scratch: sb_lstm_overlap_rows(P, nseq) partial rows of 256*(C+64) + 256 + 2C + 64C + C floats
- * returns -1003 when the geometry leaves fewer than 16 idle CUs (use the two plain calls). */
+ * returns -1003 when the geometry leaves fewer than 16 idle CUs, -1009 without a concurrent side stream
+ * (sb_overlap_available): use the two plain calls. */
 int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec, const sb_lstm_stream_args* st, int* flags, int slab_len,
-                                 double frac, void* stream);
+                                 void* stream);
 int sb_lstm_overlap_rows(int64_t positions, int nseq);
 /* The overlapped calls need a side stream whose kernels really run at the same time as those of `stream` (the runtime
  * multiplexes streams over a few hardware queues; two streams on one queue serialise).  Returns 1 when the library has

@@ -1,5 +1,5 @@
 """Experiment: overlapped inter-frame backward (recurrence || stream kernel on the idle CUs) at the BASELINE big geometry:
-time of the pair of plain launches vs sb_lstm_bwd_inter_overlapped over the split fraction and the slab length."""
+time of the pair of plain launches vs sb_lstm_bwd_inter_overlapped over the slab length."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -78,7 +78,6 @@ def timeit(fn, n=10):
 
 print(f"plain pair: {timeit(plain):.0f} us")
 for slab in [int(v) for v in os.environ.get("SLABS", "16,32,64").split(",")]:
-    for frac in [float(v) for v in os.environ.get("FRACS", "0.35,0.45,0.55,0.65,0.75").split(",")]:
-        ops.BWD_OVERLAP_SLAB, ops.BWD_OVERLAP_FRAC = slab, frac
-        print(f"overlapped slab={slab} frac={frac}: {timeit(over):.0f} us", flush=True)
+    ops.BWD_OVERLAP_SLAB = slab
+    print(f"overlapped slab={slab}: {timeit(over):.0f} us", flush=True)
 ops.check_sched_status()

@@ -42,7 +42,7 @@ class LstmBwdArgs(C.Structure):
                 ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
                 ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp),
                 ("hs_f16", C.c_int), ("recompute", C.c_int), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
-                ("slab_flags", C.c_void_p), ("slab_len", C.c_int)]
+                ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_started", C.c_void_p)]
 
 
 class WView(C.Structure):
@@ -98,8 +98,8 @@ class LstmStreamArgs(C.Structure):
                 ("ln_x", c_fp), ("ln_g", c_fp), ("ln_res", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
                 ("absmax_out", c_fp), ("d_lin_w", c_fp), ("d_lin_b", c_fp),
                 ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_need", C.c_int),
-                ("chunk_begin", C.c_int), ("chunk_end", C.c_int), ("row_base", C.c_int), ("sched_status", C.c_void_p),
-                ("chunk_reverse", C.c_int)]
+                ("chunk_counter", C.c_void_p), ("started", C.c_void_p), ("nchunks", C.c_int), ("guard", C.c_int),
+                ("row_base", C.c_int), ("sched_status", C.c_void_p)]
 
 
 class LnBwdArgs(C.Structure):
@@ -137,7 +137,7 @@ SYMBOLS = {
     "sb_wgrad_grid": (_ci, [i64]),
     "sb_lstm_bwd_stream": (_ci, [C.POINTER(LstmStreamArgs), _vp]),
     "sb_lstm_stream_grid": (_ci, [i64]),
-    "sb_lstm_bwd_inter_overlapped": (_ci, [C.POINTER(LstmBwdArgs), C.POINTER(LstmStreamArgs), _vp, _ci, C.c_double, _vp]),
+    "sb_lstm_bwd_inter_overlapped": (_ci, [C.POINTER(LstmBwdArgs), C.POINTER(LstmStreamArgs), _vp, _ci, _vp]),
     "sb_lstm_overlap_rows": (_ci, [i64, _ci]),
     "sb_overlap_available": (_ci, [_vp]),
     "sb_ln_bwd": (_ci, [C.POINTER(LnBwdArgs), _vp]),

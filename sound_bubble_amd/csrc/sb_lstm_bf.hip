@@ -698,6 +698,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   const int dir = blockIdx.y;
   const int S = a.nsteps, ndir = a.ndir;
   const bool rev = dir == 1;
+  if constexpr (SLAB) { if (tid == 0) __hip_atomic_fetch_add(a.slab_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
   constexpr int CK = FST > 0 ? FST / 16 : 1, KT = CK + 4;
   __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
@@ -1630,7 +1631,8 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
                                    ex_out);
   }
   if (a.slab_flags) {                               // overlapped form: see sb_lstm_bwd_inter_overlapped
-    if (seg || !dg16 || a.ndir != 1 || a.slab_len < 2 || (a.slab_len & 1) || (fc != 16 && fc != 32)) return -1003;
+    if (seg || !dg16 || a.ndir != 1 || a.slab_len < 2 || (a.slab_len & 1) || (fc != 16 && fc != 32) || !a.slab_started)
+      return -1003;
 #define SB_SLB(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC, true, false, 0, false, false, false, false, true>), grid, block, 0, st, a)
     if (fc == 32) { if (full) SB_SLB(true, 32); else SB_SLB(false, 32); }
     else { if (full) SB_SLB(true, 16); else SB_SLB(false, 16); }

@@ -361,12 +361,17 @@ SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma
 // LINW (with LNB): the weight gradient of the Linear in front of the residual rides along as well -- its output gradient IS
 // ln_res, which the flush lanes hold; they drop it (scaled fp16) into a [channel][position] LDS tile, wave w multiplies
 // it with the UNSHIFTED hs rows of the chunk (h columns 4j + w): d_lin_w [C, 64] += dy^T hs, d_lin_b [C] += sum dy.
-// SLAB: consumer side of the overlapped inter-frame backward (sb_lstm_bwd_inter_overlapped): chunk ch of this launch is
-// chunk i of batch b of time slab k (slab_len steps, latest first -- the order the recurrence produces them in) and is
-// started once slab_flags[k] has reached slab_need (every tile of the recurrence has stored that slab's dgates,
-// write-through).  A chunk never reads a dgates row outside its own (b, slab) range, so no line of an unfinished slab is
-// ever brought into this XCD's L2.  The launch covers chunks [chunk_begin, chunk_end) and writes partial rows from
-// row_base on.
+// SLAB: consumer side of the overlapped inter-frame backward (sb_lstm_bwd_inter_overlapped).  Chunk c is chunk i of batch
+// entry b of time slab k (slab_len steps, latest first -- the order the recurrence produces them in).  The workgroups of
+// BOTH launches of the pass draw UNITS of kUnit consecutive chunks from one atomic counter (a draw per chunk was tried:
+// device-scope atomics on one address retire at a few tens per microsecond, and whatever thread 0 does per chunk in front
+// of the barrier is time the other three waves spend waiting there); inside a unit the chunk coordinates advance by
+// carries and the next chunk is prefetched as in the plain kernel.  A unit is started once slab_flags[k] of its LAST chunk
+// has reached slab_need (every tile of the recurrence has stored that slab's dgates, write-through).  A chunk never reads
+// a dgates row outside its own (b, slab) range, so no line of an unfinished slab is ever brought into this XCD's L2.
+// Guarded launch (the one that runs NEXT to the recurrence): a workgroup that does not find every recurrence workgroup
+// started within ~50 us draws nothing -- should the dispatcher have placed this launch first, it must not sit on the CUs
+// the recurrence needs.  Partial rows from row_base on.
 template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false, bool LINW = false, bool SLAB = false>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
   constexpr int CK = C / 16, KT = CK + 4;
@@ -446,21 +451,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     }
     return c;
   };
-  auto span_next = [&](const Span& o, int ch_next) -> Span {     // coordinates of chunk ch_next = o's chunk + gridDim.x
+  auto span_next = [&](const Span& o, int ch_next) -> Span {     // coordinates of chunk ch_next = o's chunk + cstride
     Span c = o;
     if constexpr (SLAB) {
-      if (a.chunk_reverse) {                          // walking down from chunk_end - 1 (see load order below)
-        c.i -= gridDim.x;
-        while (c.i < 0 && c.k >= 0) {
-          if (--c.b < 0) { c.b = nbat - 1; --c.k; c.cpk = c.k >= nsl - 1 ? cpl : cpb; }
-          c.i += c.cpk;
-        }
-      } else {
-        c.i += gridDim.x;
-        while (c.i >= c.cpk) {
-          c.i -= c.cpk;
-          if (++c.b == nbat) { c.b = 0; ++c.k; c.cpk = c.k >= nsl - 1 ? cpl : cpb; }
-        }
+      c.i += 1;
+      if (c.i >= c.cpk) {
+        c.i = 0;
+        if (++c.b == nbat) { c.b = 0; ++c.k; c.cpk = c.k >= nsl - 1 ? cpl : cpb; }
       }
       span_fill(c);
     } else {
@@ -506,7 +503,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     if constexpr (CK == 2) v += __shfl_xor(v, 32, 64);
     return v;
   };
-  const int ch_begin = SLAB ? a.chunk_begin : 0, nchunks = SLAB ? a.chunk_end : (Pi + 31) / 32;
+  const int nchunks = SLAB ? a.nchunks : (Pi + 31) / 32;
+  constexpr int kUnit = 16;                              // chunks per draw (SLAB; 8: +8 %, 32: +6 % on the pass)
+  const int cstride = SLAB ? 1 : (int)gridDim.x;
   const h16x4 hz4 = {0, 0, 0, 0};
   const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto load_chunk = [&](const Span& sp, Chunk& t) {  // branch-free (clamped address + select)
@@ -562,25 +561,46 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
 
   const h16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
   Chunk cur;
-  int ch = ch_begin + blockIdx.x;
-  // chunk_reverse (the launch that runs after the recurrence): the same chunks from the last one down -- the slabs written
-  // last are still in the memory-side cache
-  Span sc = span_at(SLAB && a.chunk_reverse ? a.chunk_end - 1 - (int)blockIdx.x : ch);
-  Span sn = span_next(sc, ch + gridDim.x);           // chunk in hand, the one being loaded
-  if constexpr (SLAB) {                              // the first two chunks of this workgroup
-    if (tid == 0) slab_abort = 0;
-    if (ch < nchunks) slab_poll(ch + (int)gridDim.x < nchunks ? sn.k : sc.k);
-    __syncthreads();
-    if (slab_abort) return;
-  }
-  if (ch < nchunks) load_chunk(sc, cur);             // (a workgroup without chunks still writes its zero partial row)
+  __shared__ int unit_box;
+  bool gok = true;                                   // thread 0: the guard's verdict
   int it = 0;
-  for (; ch < nchunks; ++it) {
+  for (int round = 0;; ++round) {                    // SLAB: one unit per round; plain launches: one round
+  int ch, ch_hi;
+  if constexpr (SLAB) {
+    if (tid == 0) {
+      if (round == 0) {
+        slab_abort = 0;
+        if (a.guard) {                               // every recurrence workgroup started?
+          gok = false;
+          for (int i = 0; i < 200 && !gok; ++i) {
+            gok = __hip_atomic_load(a.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.slab_need;
+            if (!gok) __builtin_amdgcn_s_sleep(8);
+          }
+        }
+      }
+      unit_box = gok ? __hip_atomic_fetch_add(a.chunk_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1 << 26);
+    }
+    __syncthreads();
+    const int u = __builtin_amdgcn_readfirstlane(unit_box);
+    if (u >= (nchunks + kUnit - 1) / kUnit) break;
+    ch = u * kUnit;
+    ch_hi = min(ch + kUnit, nchunks);
+    slab_poll(span_at(ch_hi - 1).k);                 // thread 0; the slabs only grow along a unit
+    __syncthreads();
+    if (slab_abort) break;
+  } else {
+    if (round) break;
+    ch = blockIdx.x;
+    ch_hi = nchunks;
+  }
+  Span sc = span_at(ch), sn = span_next(sc, ch + cstride);          // chunk in hand, the one being loaded
+  if (ch < ch_hi) load_chunk(sc, cur);               // (a workgroup without chunks still writes its zero partial row)
+  for (; ch < ch_hi; ++it) {
     Chunk nxt;
-    const int cn = ch + gridDim.x;
-    load_chunk(cn < nchunks ? sn : sc, nxt);
+    const int cn = ch + cstride;
+    load_chunk(cn < ch_hi ? sn : sc, nxt);
     const int cp0 = sc.p0, cpe = sc.pe;              // positions [cp0, cpe) of the chunk in hand (uniform)
-    const Span s2 = span_next(sn, cn + gridDim.x);   // ... and of the chunk the NEXT iteration loads
+    const Span s2 = span_next(sn, cn + cstride);     // ... and of the chunk the NEXT iteration loads
     // ---- weight gradients: 4 gate tiles x (CK + 4) column tiles, K = 32 positions ----
     // u (LayerNorm output) and h_prev enter as single fp16 terms: like the dgates they multiply, they carry 2^-12
     // relative rounding noise, unbiased and averaged over millions of positions in these sums
@@ -636,9 +656,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
         }
       }
     }
-    if constexpr (SLAB) { if (cn + (int)gridDim.x < nchunks) slab_poll(s2.k); }
     __syncthreads();
-    if constexpr (SLAB) { if (slab_abort) break; }
     if constexpr (LINW) {
       h16x8 Bu;
 #pragma unroll
@@ -694,6 +712,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     cur = nxt;
     ch = cn;
     sc = sn; sn = s2;
+  }
   }
 
   constexpr int Ktot = C + H;
@@ -1028,28 +1047,20 @@ int device_cus() {
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   return n;
 }
-// Workgroups a side launch may have next to a `tiles`-workgroup launch when neither can share a CU with the other: the
-// dispatcher deals the workgroups of a launch round-robin over the XCDs (8 x 32 CUs on MI355X), so what counts is the room
-// left in the FULLEST XCD, not the chip-wide CU count.  (First version: CUs - tiles = 111 next to 145 tiles, i.e. 19 + 14
-// workgroups for the 32 CUs of one XCD whenever the two round-robins did not happen to interleave -- the one workgroup
-// left over started after the producer had drained and ran its share alone: 1154 instead of 650 us.)
-int idle_slots(int tiles) {
-  const int cus = device_cus();
-  const int nx = cus >= 64 ? cus / 32 : 1, per = cus / nx;
-  const int room = per - (tiles + nx - 1) / nx;
-  return room > 0 ? room * nx : 0;
-}
 }  // namespace
 
 // 1 when kernels on the library's side stream run concurrently with kernels on `stream` (probed once per stream)
 extern "C" int sb_overlap_available(void* stream) { return side_stream((hipStream_t)stream) != nullptr ? 1 : 0; }
 
 extern "C" int sb_lstm_overlap_rows(int64_t positions, int nseq) {
-  return idle_slots((nseq + 15) / 16) + sb_lstm_stream_grid(positions);
+  (void)positions;
+  const int cus = device_cus(), idle = cus - (nseq + 15) / 16;
+  return (idle > 0 ? idle : 0) + cus;
 }
 
+// flags layout: [0] recurrence workgroups started, [1] the unit counter, [2], [3] spare, [4 ..] the slab flags
 extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args* st_in, int* flags,
-                                            int slab_len, double frac, void* stream) {
+                                            int slab_len, void* stream) {
   if (!rec_in || !st_in || !flags) return -1001;
   sb_lstm_bwd_args rec = *rec_in;
   sb_lstm_stream_args sa = *st_in;
@@ -1058,9 +1069,9 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
   if (rec.ndir != 1 || sa.ndir != 1 || !sa.dx || !sa.d_lin_w || !sa.d_lin_b || !sa.gmax || !sa.u_f16 || !sa.hs_f16 ||
       !sa.ln_x || !sa.ln_g || !sa.ln_res || !sa.d_ln_g || !sa.d_ln_b || !sa.sched_status || (C != 16 && C != 32) ||
       slab_len < 2 || (slab_len & 1) || sa.shift_pos <= 0 || sa.seg_len != T * sa.shift_pos || sa.P % sa.seg_len != 0 ||
-      sa.seg_len < 32 || !(frac > 0.0 && frac < 1.0))
+      sa.seg_len < 32)
     return -1003;
-  const int idle = idle_slots(ntiles);
+  const int cus = device_cus(), idle = cus - ntiles;
   if (idle < 16) return -1003;
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
@@ -1069,28 +1080,25 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
   const int cpb = (int)((slab_len * sa.shift_pos + 31) / 32), cps = nb * cpb;
   const int cpl = (int)(((T - (nslabs - 1) * slab_len) * sa.shift_pos + 31) / 32);     // the last slab is shorter
   const int nch = (nslabs - 1) * cps + nb * cpl;
-  int split = (int)(frac * nch);
-  if (split < 1) split = 1;
-  if (split > nch - 1) split = nch - 1;
-  const int g1 = idle < split ? idle : split;
-  int g2 = device_cus();                             // one workgroup per CU is all that is resident (register budget)
-  if (g2 > sb_lstm_stream_grid(sa.P)) g2 = sb_lstm_stream_grid(sa.P);
-  if (g2 > nch - split) g2 = nch - split;
+  // next to the recurrence: one workgroup per idle CU (register budget: none fits on a recurrence CU; one that cannot be
+  // placed at once starts later and draws fewer units); behind it: one per CU
+  const int g1 = idle, g2 = cus;
 
-  if (hipMemsetAsync(flags, 0, (size_t)nslabs * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (hipMemsetAsync(flags, 0, (size_t)(nslabs + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;
-  rec.slab_flags = flags; rec.slab_len = slab_len;
+  rec.slab_flags = flags + 4; rec.slab_len = slab_len; rec.slab_started = flags;
   int rc = sb_lstm_bwd_rec(&rec, stream);
   if (rc) return rc;
-  sa.slab_flags = flags; sa.slab_len = slab_len; sa.slab_need = ntiles;
+  sa.slab_flags = flags + 4; sa.slab_len = slab_len; sa.slab_need = ntiles;
+  sa.started = flags; sa.chunk_counter = flags + 1; sa.nchunks = nch;
 #define SB_SO(CC, ST, G) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, true, true>), dim3(G), dim3(256), 0, ST, sa)
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
-  sa.chunk_begin = 0; sa.chunk_end = split; sa.row_base = 0; sa.chunk_reverse = 0;
+  sa.guard = 1; sa.row_base = 0;
   if (C == 32) SB_SO(32, ss->s, g1); else SB_SO(16, ss->s, g1);
   SB_CHECK_LAUNCH();
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
-  // the rest on `stream` (ordered after the recurrence: all flags are up), from the last chunk down; then the join
-  sa.chunk_begin = split; sa.chunk_end = nch; sa.row_base = g1; sa.chunk_reverse = 1;
+  // behind the recurrence on `stream` (all flags up): the same kernel drawing what is left; then the join
+  sa.guard = 0; sa.row_base = g1;
   if (C == 32) SB_SO(32, main_st, g2); else SB_SO(16, main_st, g2);
 #undef SB_SO
   SB_CHECK_LAUNCH();

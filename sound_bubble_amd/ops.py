@@ -442,7 +442,6 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
 # Inter-frame backward with fewer tiles than CUs: the streaming part starts on the idle CUs while the recurrence is still
 # running (sb_lstm_bwd_inter_overlapped).  SB_NO_BWD_OVERLAP=1: the two launches one after the other.
 BWD_OVERLAP = os.environ.get("SB_NO_BWD_OVERLAP", "0") != "1"
-BWD_OVERLAP_FRAC = float(os.environ.get("SB_BWD_OVERLAP_FRAC", "0.45"))
 BWD_OVERLAP_SLAB = int(os.environ.get("SB_BWD_OVERLAP_SLAB", "32"))
 
 
@@ -498,12 +497,12 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
         gm = zero_scalar(dev)
         s.absmax_out = _p(gm)
     slab = BWD_OVERLAP_SLAB
-    flags = torch.empty((geom.nsteps + slab - 1) // slab, device=dev, dtype=torch.int32)
+    flags = torch.empty((geom.nsteps + slab - 1) // slab + 4, device=dev, dtype=torch.int32)      # + 4 control words
     by = P * (640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc + 4 * 4.0 * Cc)
     with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)",
                (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P, 8.0 * Cc * P, by):
-        L.check(lib.sb_lstm_bwd_inter_overlapped(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab,
-                                                 BWD_OVERLAP_FRAC, _stream()), "sb_lstm_bwd_inter_overlapped")
+        L.check(lib.sb_lstm_bwd_inter_overlapped(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab, _stream()),
+                "sb_lstm_bwd_inter_overlapped")
     if gm is not None:
         absmax_hint_put(dx, gm)
     return dx

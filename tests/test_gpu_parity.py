@@ -741,10 +741,11 @@ def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(
         assert float(ops.absmax_or_hint(dx)) == float(dx.abs().max())
 
 
-@pytest.mark.parametrize("C_,slab,frac", [(32, 32, 0.55), (32, 6, 0.3), (16, 10, 0.8)])
-def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab, frac, monkeypatch):
-    """sb_lstm_bwd_inter_overlapped (recurrence on the main stream publishing its dgates slab by slab, the first part of the
-    stream kernel behind it on the library's side stream, the rest after the join) against sb_lstm_bwd_rec followed by
+@pytest.mark.parametrize("C_,slab", [(32, 32), (32, 6), (16, 10)])
+def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab, monkeypatch):
+    """sb_lstm_bwd_inter_overlapped (recurrence on the main stream publishing its dgates slab by slab, the stream kernel as
+    two launches drawing units of chunks from one counter: next to it on the library's side stream, and behind it) against
+    sb_lstm_bwd_rec followed by
     sb_lstm_bwd_stream: dx, every weight / bias gradient, the LayerNorm and Linear riders, the max |dx| hint.  Ragged
     geometry: 3 tiles (the last one partial), a short last slab, chunk ranges that do not end on 32 positions."""
     torch = torch_gpu
@@ -754,7 +755,6 @@ def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab,
     if not ops.overlap_available():
         pytest.skip("no side stream that runs concurrently with the main stream on this box")
     monkeypatch.setattr(ops, "BWD_OVERLAP_SLAB", slab)
-    monkeypatch.setattr(ops, "BWD_OVERLAP_FRAC", frac)
     torch.manual_seed(23)
     B_, T_, F_ = 2, 150, 21
     geom = ops.Geom.inter(B_, T_, F_)
