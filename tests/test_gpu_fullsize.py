@@ -4,8 +4,10 @@ with the oracle, through the DEFAULT dispatch:
 
   small (configs[1], B = 32): 290 inter-frame tiles on 256 CUs -> fused inter-frame BPTT (Linear-wgrad and LayerNorm
         backward riders) under the time-segmented schedule, fused bidirectional conv-LSTM backward, 29-step intra walks;
-  big   (configs[2], B = 16): 145 inter-frame tiles -> recurrence -> stream kernel pair, one workgroup per tile; fused
-        bidirectional intra-frame backward with persistent workgroups over 625 tiles per direction, 145-step walks.
+  big   (configs[2], B = 16): 145 inter-frame tiles -> the overlapped schedules (next block's intra-frame forward and the
+        backward's stream kernel on the CUs the recurrence leaves idle, when the box offers a concurrent side stream;
+        recurrence -> stream kernel pair otherwise); fused bidirectional intra-frame backward with persistent
+        workgroups over 625 tiles per direction, 145-step walks.
 
 Checker: the CPU oracle (oracle/tfgridnet_oracle.py, pinned to the reference goldens) on the same seeded weights and
 inputs, one utterance at a time (1.7 GB of autograd state each; the batch-mean SNRLP loss is the mean of the
