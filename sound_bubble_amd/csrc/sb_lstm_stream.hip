@@ -1144,7 +1144,7 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
   a.ord_started = flags; a.ord_counter = flags + 1;
   // next to the producer: two persistent workgroups per idle CU (254 registers each; none fits on a producer's CU); one
   // that cannot be placed at once simply starts later and draws fewer items
-  int g1 = 2 * idle;
+  int g1 = 2 * idle;                                   // (1 per CU: -10 % forward-only, 3: no better)
   if (g1 > 2 * ntiles) g1 = 2 * ntiles;
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
   a.ord_guard = 1; a.ord_grid = g1;
