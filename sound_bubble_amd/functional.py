@@ -174,6 +174,7 @@ class InterFn(torch.autograd.Function):
             ctx.deferred = part is not None
             ctx.film = (film[0], film[2], bank, film_k) if film is not None else None
         hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
+        ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
         ctx.mark_non_differentiable(hN, cN)
         return y, hN, cN
 
@@ -397,6 +398,7 @@ class AttentionFn(torch.autograd.Function):
         ops.head_ln(pp, gp, ep, y, B, T, F, 1, Cc, T, 0, F * Cc, res=x, prelu_a=ap_)
         nK = Kc[:, rows - (Lw - 1):, : F * E].contiguous()
         nV = Vc[:, rows - (Lw - 1):, : F * Cv].contiguous()
+        ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
         ctx.mark_non_differentiable(nK, nV)
         if train:
             ctx.save_for_backward(x, pq, pk, pv, Qn, Kc, Vc, lse, O, pp, wq, aq, gq, wk, ak, gk, wv, av, gv, wp, ap_, gp)
@@ -619,6 +621,7 @@ class FrontEndFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(zp, pre, ln_g, conv_w, conv_b, ln_b)
             ctx.dims = (B, T, F, Cc, nfeat, bool(use_ln))
+        ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
         ctx.mark_non_differentiable(new_buf)
         return x0, new_buf
 
@@ -692,6 +695,7 @@ class BackEndFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(yp, dw, w_ana, db)
             ctx.dims = (B, T, F, Cc, win, hop)
+        ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
         ctx.mark_non_differentiable(new_dbuf, new_ibuf)
         return wave.view(B, 1, hop * T), new_dbuf, new_ibuf
 
@@ -728,6 +732,7 @@ class SnrlpLossFn(torch.autograd.Function):
         lv, dest = ops.snrlp_loss(e, t, neg_weight, want_grad=ctx.needs_input_grad[0])
         ctx.save_for_backward(dest)
         ctx.shape = est.shape
+        ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
         ctx.mark_non_differentiable(lv)
         return lv.mean(), lv
 
