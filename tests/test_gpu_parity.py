@@ -806,6 +806,9 @@ def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train
     tgt = (0.05 * torch.randn(B_, 1, 192 * 150)).cuda()
     if not ops.overlap_available():
         pytest.skip("no side stream that runs concurrently with the main stream on this box")
+    if not (ops.INTER_SUM3 and ops.INTER_FILM and ops.FWD_OVERLAP):
+        pytest.skip("the overlapped forward needs the summed-input loader and the FiLM epilogue (nothing between the kernels)")
+    monkeypatch.setattr(ops, "FWD_OVERLAP_INFERENCE", True)
 
     def run(overlap):
         monkeypatch.setattr(ops, "FWD_OVERLAP", overlap)
