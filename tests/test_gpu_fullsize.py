@@ -50,8 +50,9 @@ def test_full_size_default_dispatch_matches_oracle(wl):
     from sound_bubble_amd.train import FlatBucket
     from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
     assert torch.cuda.is_available()
-    assert ops.COMPACT_BPTT and ops.LSTM_MMA == 1 and ops.SCHED_OVERRIDE is None, "default arithmetic / dispatch only"
-    assert os.environ.get("SB_FORCE_FUSED_BPTT", "0") != "1"
+    if not (ops.COMPACT_BPTT and ops.LSTM_MMA == 1 and ops.SCHED_OVERRIDE is None) or \
+            os.environ.get("SB_FORCE_FUSED_BPTT", "0") == "1":
+        pytest.skip("this test pins the DEFAULT arithmetic / dispatch (the tolerances are those of the compact fp16 path)")
     cls, params, B, negw, _, _ = bench.WORKLOADS[wl]
     flavour = "optim" if cls == "NetOptim" else "dis_embd3"
     torch.manual_seed(0)

@@ -712,7 +712,8 @@ def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(
     hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, y))
     dy = torch.randn(geom.P, C_, device="cuda") * 0.01
     dg = ops.lstm_bwd_rec([wh], gates, None, geom, dy=dy, w_lin=lin_w)
-    assert ops.can_fuse_stream_ln(dg, u, hs)
+    if not ops.can_fuse_stream_ln(dg, u, hs):
+        pytest.skip("LayerNorm-backward fusion switched off (SB_NO_FUSED_LN)")
     ref, du = ops.lstm_bwd_stream(dg, u, hs, [wi], F_, T_ * F_, F_)
     dgr, dbr = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
     dx_ref, _, _, _ = ops.ln_bwd(du, x, g, res=dy, d_g=dgr, d_b=dbr)
@@ -809,6 +810,8 @@ def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train
     if not (ops.INTER_SUM3 and ops.INTER_FILM and ops.FWD_OVERLAP):
         pytest.skip("the overlapped forward needs the summed-input loader and the FiLM epilogue (nothing between the kernels)")
     monkeypatch.setattr(ops, "FWD_OVERLAP_INFERENCE", True)
+    if not ops.can_overlap_fwd(B_, 150, 145, 32, train, x.device):
+        pytest.skip("the overlapped forward is not available under the kernel-path switches in effect")
 
     def run(overlap):
         monkeypatch.setattr(ops, "FWD_OVERLAP", overlap)
@@ -853,6 +856,8 @@ def test_inter_forward_with_summed_input_is_bit_identical_to_add3(torch_gpu, sch
     from sound_bubble_amd import ops
     if not ops.can_fuse_linear_fwd():
         pytest.skip("fp16x3 forward only")
+    if save and not (ops.AUX_FP16 and ops.COMPACT_BPTT and ops.DGATES_FP16):
+        pytest.skip("the summed-input mode writes the fp16 side outputs of the default compact-BPTT path in training")
     monkeypatch.setattr(ops, "SCHED_OVERRIDE", sched)
     torch.manual_seed(31)
     C_, B_, T_, F_ = 32, 2, 23, 145
