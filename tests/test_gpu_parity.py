@@ -434,6 +434,19 @@ def test_cabi_rejects_bad_arguments_with_status_codes(torch_gpu):
     lin = L.LinearArgs()
     lin.B, lin.T, lin.F, lin.N, lin.K, lin.kseg = 1, 1, 16, 24, 16, 16     # N not a multiple of 16
     assert lib.sb_linear_fwd(C.byref(lin), None) < 0
+    # the overlapped entry points: null pointers, wrong direction counts, geometries without idle CUs
+    flags = torch.zeros(64, device="cuda", dtype=torch.int32)
+    fp = C.c_void_p(flags.data_ptr())
+    st = L.LstmStreamArgs()
+    assert lib.sb_lstm_bwd_inter_overlapped(None, None, None, 32, None) < 0
+    assert lib.sb_lstm_bwd_inter_overlapped(C.byref(b), C.byref(st), fp, 32, None) < 0      # all-zero argument blocks
+    assert lib.sb_lstm_fwd_produce(None, fp, 32, None) < 0
+    a2 = L.LstmFwdArgs()
+    a2.nseq, a2.nsteps, a2.n_inner, a2.ndir, a2.C = 32, 256, 32, 2, 32                      # producer must be single-direction
+    assert lib.sb_lstm_fwd_produce(C.byref(a2), fp, 32, None) < 0
+    a2.ndir, a2.nseq = 1, 16 * 4096                                                         # ... and leave CUs idle
+    assert lib.sb_lstm_fwd_produce(C.byref(a2), fp, 32, None) < 0
+    assert lib.sb_lstm_fwd_consume(C.byref(a2), fp, 32, 16, None, None, None) < 0           # no tile order
     with pytest.raises(L.SoundBubbleHipError):                             # host tensors are refused by the wrappers
         ops.absmax(torch.zeros(8))
     with pytest.raises(L.SoundBubbleHipError):                             # as are non-fp32 ones
