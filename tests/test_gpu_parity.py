@@ -823,6 +823,7 @@ def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train
     if not (ops.INTER_SUM3 and ops.INTER_FILM and ops.FWD_OVERLAP):
         pytest.skip("the overlapped forward needs the summed-input loader and the FiLM epilogue (nothing between the kernels)")
     monkeypatch.setattr(ops, "FWD_OVERLAP_INFERENCE", True)
+    monkeypatch.setattr(ops, "OVERLAP_MIN_FILL", 0.0)           # 19 inter-frame tiles here
     if not ops.can_overlap_fwd(B_, 150, 145, 32, train, x.device):
         pytest.skip("the overlapped forward is not available under the kernel-path switches in effect")
 
