@@ -156,6 +156,7 @@ FWD_OVERLAP = os.environ.get("SB_NO_FWD_OVERLAP", "0") != "1"
 # both overlapped schedules: the under-filled pass must have between OVERLAP_MIN_FILL and 3/4 of the CUs' worth of tiles
 # (big config, train step: -2 % at 37 tiles, +4 % at 73, +4 % at 145, +3.6 % at 182; the tests set 0 to run tiny grids)
 OVERLAP_MIN_FILL = 0.25
+OVERLAP_MAX_FILL = float(os.environ.get("SB_OVERLAP_MAX_FILL", "0.75"))
 FWD_OVERLAP_SLAB = int(os.environ.get("SB_FWD_OVERLAP_SLAB", "32"))
 # ... also in inference (forward-only +9 %: 2160 -> 2353 utterances/s; SB_NO_FWD_OVERLAP_INFERENCE=1: training only)
 FWD_OVERLAP_INFERENCE = os.environ.get("SB_NO_FWD_OVERLAP_INFERENCE", "0") != "1"
@@ -215,7 +216,7 @@ def can_overlap_fwd(B, T, F_, Cc, train, dev):
     if torch.cuda.is_current_stream_capturing() or not (train or FWD_OVERLAP_INFERENCE):
         return False
     tiles, cus = (B * F_ + 15) // 16, _cu_count(dev)
-    return (OVERLAP_MIN_FILL * cus <= tiles <= 0.75 * cus and T >= 4 * FWD_OVERLAP_SLAB and B * T >= 64
+    return (OVERLAP_MIN_FILL * cus <= tiles <= OVERLAP_MAX_FILL * cus and T >= 4 * FWD_OVERLAP_SLAB and B * T >= 64
             and overlap_available())
 
 
@@ -459,7 +460,7 @@ def can_overlap_inter_bwd(geom, u, hs):
         return False
     ntiles = (geom.nseq + 15) // 16
     cus = _cu_count(u.device)
-    return (OVERLAP_MIN_FILL * cus <= ntiles <= 0.75 * cus and geom.nsteps >= 4 * BWD_OVERLAP_SLAB
+    return (OVERLAP_MIN_FILL * cus <= ntiles <= OVERLAP_MAX_FILL * cus and geom.nsteps >= 4 * BWD_OVERLAP_SLAB
             and geom.n_inner * geom.nsteps >= 32 and overlap_available())
 
 
