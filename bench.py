@@ -203,9 +203,16 @@ def stream_bench(torch, sb, args, wl, cls, params, dev):
         "chunk_mflop": fpu / 1e6}), flush=True)
 
 
-DTYPE_TRAIN = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo split operands (3 products per MAC, " \
-              "fp32-class); BPTT state (gate / c_prev records, dgates, LayerNorm-output and hs side outputs) fp16"
-DTYPE_EXACT = "f32 storage/accumulate; forward products fp16 hi+lo split (fp32-class); BPTT state fp32 (SB_EXACT_BPTT=1)"
+DTYPE_BY_MODE = {
+    "wide": "f32 storage/accumulate incl. the BPTT state (fp32 gate / c_prev records, fp32 side outputs); every matrix product "
+            "on the fp16 pipe with TWO-term split operands (3 products per MAC, 22 mantissa bits: fp32-class) in forward "
+            "AND backward",
+    "compact": "f32 storage/accumulate; forward products fp16 hi+lo split (fp32-class); BPTT state (gate / c_prev records, "
+               "dgates, LayerNorm-output and hs side outputs) fp16, single-term gradient products (SB_BPTT=compact, opt-in)",
+    "legacy": "f32 storage/accumulate; forward products fp16 hi+lo split; BPTT state fp32, unfused round-1 kernels "
+              "(SB_BPTT=legacy)",
+}
+SIBLING = {"wide": "compact", "compact": "wide", "legacy": "wide"}
 DTYPE_FWD = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo split operands (3 products per MAC, fp32-class)"
 
 # rocprof kernel-name patterns of the labels ops.PROFILE uses (for the committed PMC traffic JSONs, whose keys are
@@ -243,7 +250,7 @@ def pmc_traffic(workload, label):
             os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc passes of `bench.py --workload " + workload + "`, committed)")
 
 
-def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only=False, exact=False, steps=None,
+def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only=False, mode=None, steps=None,
                  warmup=None, profile=True):
     """W warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks.
     -> (seconds per step, per-kernel profile dict, batch per GPU, params, class name)"""
@@ -252,8 +259,8 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
     B = args.batch or B
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
-    old_compact = ops.COMPACT_BPTT
-    ops.COMPACT_BPTT = not exact
+    mode = mode or args.bptt or ops.BPTT                     # BPTT-state precision: wide (default) | compact | legacy
+    old_mode, ops.BPTT = ops.BPTT, mode
     torch.manual_seed(0)                                     # identical replicas
     model = getattr(sb, cls)(**params).to(dev).train()
     bucket = FlatBucket(model)
@@ -286,7 +293,7 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
         ops.check_sched_status()                             # a time-segmented launch that bailed out voids the run
     finally:
         ops.PROFILE = None
-        ops.COMPACT_BPTT = old_compact
+        ops.BPTT = old_mode
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -353,17 +360,18 @@ def roofline_of(table, wl, step_s, steps, forward_only, utt_s_per_gpu, params):
 
 def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only=False, with_exact=True, with_cpu=True):
     step_s, table, B, params, cls = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, forward_only=forward_only)
+    main_mode = args.bptt or ops.BPTT
     if rank != 0:
         if with_exact and not forward_only:                  # every rank runs the sibling (collectives inside)
-            run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, exact=True, steps=max(3, args.steps // 2),
-                         warmup=min(2, args.warmup), profile=False)
+            run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, mode=SIBLING[main_mode],
+                         steps=max(3, args.steps // 2), warmup=min(2, args.warmup), profile=False)
         return None
     utt_s = world * B / step_s
     out = {
         "metric": "utterances/sec (6-ch, 24 kHz, 5 s) " + ("forward" if forward_only else "train-step"),
         "value": utt_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": DTYPE_FWD if forward_only else DTYPE_TRAIN, "data": "synthetic",
+        "dtype": DTYPE_FWD if forward_only else DTYPE_BY_MODE[main_mode], "data": "synthetic",
         "config": {"workload": f"{wl}: {cls} D={params['D']} B={params['B']} H=64 conv_lstm={params['conv_lstm']}, "
                                f"6ch x 120000 samples, {'forward only' if forward_only else 'fwd+SNRLP+bwd+clip+Adam'}"
                                + (" (BASELINE configs[2]; per-GPU workload of configs[3])" if wl == "big" else
@@ -386,11 +394,13 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
                    "loop; the cell update (40 quarter-rate transcendentals + ~100 VALU ops per step) and the LDS hidden-"
                    "state exchange, not the MFMA issue, set the step time (profiles/: SQ_VALU_MFMA_BUSY vs SQ_BUSY)"}
     if with_exact and not forward_only:
-        es, _, _, _, _ = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, exact=True,
+        sib = SIBLING[main_mode]
+        es, _, _, _, _ = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, mode=sib,
                                       steps=max(3, args.steps // 2), warmup=min(2, args.warmup), profile=False)
-        out["exact_bptt"] = {"value": world * B / es, "unit": "utterances/s", "ms_per_step": es * 1e3,
-                             "steps": max(3, args.steps // 2), "dtype": DTYPE_EXACT,
-                             "ratio_to_default": (world * B / es) / utt_s}
+        out["bptt_mode"] = main_mode
+        out[sib + "_bptt"] = {"value": world * B / es, "unit": "utterances/s", "ms_per_step": es * 1e3,
+                              "steps": max(3, args.steps // 2), "dtype": DTYPE_BY_MODE[sib],
+                              "ratio_to_headline": (world * B / es) / utt_s}
     if with_cpu and world == 1:                               # reported baseline: rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(torch, wl)
         out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
@@ -407,7 +417,9 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="with --workload all: only the headline line")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact", action="store_true", help="skip the SB_EXACT_BPTT=1 sibling measurement")
+    ap.add_argument("--no-exact", action="store_true", help="skip the sibling measurement in the other BPTT-state precision")
+    ap.add_argument("--bptt", default=None, choices=["wide", "compact", "legacy"],
+                    help="BPTT-state precision of the main line (default: SB_BPTT or wide)")
     ap.add_argument("--vendor-gpu-baseline", action="store_true",
                     help="extra leg: time the oracle restatement on the GPU through stock torch ops (MIOpen RNN)")
     ap.add_argument("--forward-only", action="store_true", help="single-workload mode: inference forward utt/s")

@@ -91,6 +91,12 @@ typedef struct {
   /* overlapped forward (set by sb_lstm_fwd_produce / sb_lstm_fwd_consume; leave NULL / 0 otherwise) */
   int* slab_flags; int slab_len, slab_need;
   const int* tile_order; const int* tile_need; int* ord_counter; int* ord_started; int ord_guard, ord_grid;
+  /* WIDE BPTT state (mma == 1, save_gates and save_c given, aux_f16 == 0): rec_f32 != 0 keeps the reference's own
+     precision in everything the backward reads -- the gate records are fp32 (save_gates [R, ndir, 4, 64] floats, save_c
+     [R, ndir, 64] floats, R as for the compact records and blocked per (16-sequence tile, step, direction) in the
+     kernels' lane order like them: 1280 B per step and direction, one contiguous KB per store instruction), save_u and
+     hs stay fp32.  To be handed to sb_lstm_bwd_rec with `wide` set. */
+  int rec_f32;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 
@@ -168,6 +174,14 @@ typedef struct {
   int recompute; const float* b_ih[2]; const float* b_hh[2];
   /* producer side of sb_lstm_bwd_inter_overlapped (set by that call; leave NULL / 0 otherwise) */
   int* slab_flags; int slab_len; int* slab_started;
+  /* WIDE BPTT state: the fused forms above (wpart != NULL; single direction or bidirectional) at the reference's own
+     precision.  wide != 0: save_gates / save_c are the blocked fp32 records of sb_lstm_fwd_args.rec_f32, u [P, C] and hs
+     [P, ndir * 64] are fp32; gmax is still required (the recurrence runs on gradients scaled by the power of two S so
+     that 16-bit terms cannot overflow) and every gradient quantity that meets the fp16 matrix pipe does so as TWO fp16
+     terms x = hi + 2^-11 lo' (lo' = fp16((x - hi) * 2^11): 22 mantissa bits with no underflow of the low term), against
+     fp16 hi + lo splits of u / h_prev / the weights -- three products per MAC, as in the forward kernels.  hs_f16 and
+     recompute must be 0. */
+  int wide;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

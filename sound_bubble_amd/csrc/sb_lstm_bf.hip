@@ -498,6 +498,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         if (SAVE == 1) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
           st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
+        } else if (SAVE == 4) {
+          // wide records (sb_lstm_fwd_args.rec_f32): fp32, blocked per (tile, step, direction) in lane order like the
+          // compact ones -- [wave][gate][lane][4 floats] and [wave][lane][4 floats], one contiguous KB per store
+          const int64_t blk = (rec_tile + st) * ndir + dir;
+          float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
+          st4(rec, gi); st4(rec + 256, gf); st4(rec + 512, gg); st4(rec + 768, go);
+          st4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, cprev);
         } else if (SAVE >= 2) {
           const int64_t blk = (rec_tile + st) * ndir + dir;
           if (SAVE != 3 || a.save_gates) {   // SAVE == 3 with save_gates == NULL: the backward recomputes the gates (c_prev only)
@@ -691,8 +698,15 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 // slab_len steps the workgroup counts itself into slab_flags[k]; the stream kernel, running at the same time on the CUs
 // this launch leaves idle, starts on slab k when all tiles have.  Same protocol as the segment hand-off: sc1 accesses
 // ordered by s_waitcnt + barrier, no L2-wide release fences.
+// XP (FST > 0, DG16, !REC16): WIDE BPTT state (sb_lstm_bwd_args.wide) -- the fused forms at the reference's own precision.
+// Records are the blocked fp32 ones of the forward kernel's SAVE == 4, u and hs are fp32, and every gradient quantity that
+// meets the fp16 matrix pipe is TWO fp16 terms x = hi + 2^-11 lo', lo' = fp16((x - hi) * 2^11): the low term is scaled
+// up so that it cannot underflow however small x is against the power-of-two scale S (which is derived from the LARGEST
+// incoming gradient), and its products are accumulated apart and folded in with the factor 2^-11 (recurrence, du) or
+// meet an operand that carries the factor (dW: the hi terms of u / h_prev times 2^-11).  u, h_prev and the weights are
+// fp16 hi + lo.  Three products per MAC instead of one, dgates tile in LDS twice the size, records twice the bytes.
 template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
-          bool HS16B = false, bool RECOMP = false, bool SLAB = false>
+          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false>
 __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
@@ -702,11 +716,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
   constexpr int CK = FST > 0 ? FST / 16 : 1, KT = CK + 4;
   __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
+  __shared__ __attribute__((aligned(16))) _Float16 DGL[XP ? 4 : 1][XP ? 16 : 1][XP ? DGP : 8];      // XP: the scaled low terms
   __shared__ __attribute__((aligned(16))) float R[FST > 0 ? 2 : 1][4][2][CK][FST > 0 ? 64 : 1][4];
   // SLAB: the step's 16 dgates rows are assembled here so that they leave as whole 512-byte rows (write-through stores of
   // the 32-byte pieces each lane holds would reach HBM as partial lines)
   __shared__ __attribute__((aligned(16))) _Float16 DS[SLAB ? 2 : 1][SLAB ? 16 : 1][SLAB ? 4 * H + 8 : 8];
-  static_assert(FST == 0 || (DG16 && REC16), "fused streaming part: compact fp16 path only");
+  static_assert(FST == 0 || (DG16 && (REC16 || XP)), "fused streaming part: compact fp16 records or the wide form");
+  static_assert(!XP || (FST > 0 && DG16 && !REC16 && !HS16B && !RECOMP && !SLAB), "wide form: fused kernels, fp32 records / hs");
+  constexpr float kLoUp = 2048.0f, kLoDn = 1.0f / 2048.0f;      // scale of the low fp16 term (XP)
   static_assert(!RECOMP || (BI && HS16B && FST == 32), "gate recomputation: bidirectional C = 32 form with fp16 hs");
   // forward weights of this direction as MFMA A operands: WR[gate][chunk][wave][lane] = rows gate*64 + 16 wave + (lane & 15),
   // k = 8 (lane >> 4) .. + 7 of chunk 0 (W_ih) / 1, 2 (W_hh), scaled like the forward kernel's (activations as rcp(1 + 2^z));
@@ -789,15 +806,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   const float gS = DG16 ? grad_scale(a.gmax) : 1.0f;
   // W_lin^T tile of this wave's units (FUSE): A[i = unit 16w + j][k = channel 8q + kk], 2-term split
   bf16x8 Lh, Ll;
+  h16x8 Lxh, Lxl;                                   // XP: fp16 hi + lo of the UNSCALED weights (dy carries the scale)
   if constexpr (FUSE_C > 0) {
     const int ldw = a.ndir * H;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int ch = 8 * q + kk;
-      const float v = ch < FUSE_C ? gS * a.w_lin[(size_t)ch * ldw + dir * H + 16 * w + j] : 0.f;
-      const __bf16 hh = (__bf16)v;
-      Lh[kk] = hh;
-      Ll[kk] = (__bf16)(v - (float)hh);
+      if constexpr (XP) {
+        const float v = ch < FUSE_C ? a.w_lin[(size_t)ch * ldw + dir * H + 16 * w + j] : 0.f;
+        const _Float16 hh = (_Float16)v;
+        Lxh[kk] = hh;
+        Lxl[kk] = (_Float16)(v - (float)hh);
+      } else {
+        const float v = ch < FUSE_C ? gS * a.w_lin[(size_t)ch * ldw + dir * H + 16 * w + j] : 0.f;
+        const __bf16 hh = (__bf16)v;
+        Lh[kk] = hh;
+        Ll[kk] = (__bf16)(v - (float)hh);
+      }
     }
   }
 
@@ -805,6 +830,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   SplitH Awt[CK][2];                               // W_ih^T: A[i = channel 16ct + j][k = gate 64w + 32m + 8q + kk]
   f32x4 wacc[4][KT];                               // dW rows of gate type w: [nt][u tiles | h_prev tiles]
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  float csumx[4] = {0.f, 0.f, 0.f, 0.f};           // XP: sums of the scaled low terms
   if constexpr (FST > 0) {
 #pragma unroll
     for (int ct = 0; ct < CK; ++ct)
@@ -826,8 +852,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // loop body (the select of the first version did, and doubled the kernel time once the dy loads joined)
   static_assert(!BI || (!LNB && !SEG), "bidirectional fused form: no LayerNorm rider, no time segments");
   constexpr bool LINW = !BI || FUSE_C > 0;        // the fused Linear's weight gradient rides along (needs dy)
-  constexpr bool H32 = BI && !HS16B;              // hs as fp32 rows (bidirectional passes whose Linear is a separate kernel)
-  struct PairOps { h16x4 hh4[H32 ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 ? 8 : 1]; _Float16 uh1[CK == 2 ? 1 : 8];
+  constexpr bool H32 = XP || (BI && !HS16B);      // hs as fp32 rows (wide form; bidirectional passes whose Linear is a separate kernel)
+  struct PairOps { h16x4 hh4[H32 ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 && !XP ? 8 : 1]; _Float16 uh1[CK == 2 || XP ? 1 : 8];
+                   float uf[XP ? CK : 1][XP ? 8 : 1];         // XP: u as fp32
                    float dyv[CK][LINW ? 8 : 1];
                    float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
   static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
@@ -844,10 +871,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   for (int ct = 0; ct < CK; ++ct) { lacc[ct] = zero4(); lbs[ct] = 0.f; }
   const float* __restrict__ dyj = a.dy + j;
   const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs);
-  const float* __restrict__ hs32 = reinterpret_cast<const float*>(a.hs) + dir * H;
+  const float* __restrict__ hs32 = reinterpret_cast<const float*>(a.hs) + (BI ? dir * H : 0);
+  constexpr int LDH = BI ? 2 * H : H;               // row length of hs
   // walk index s of this direction <-> time step; the step before walk index s (its h is h_prev) is walk index s - 1
   auto st_of = [&](int s) { return rev ? S - 1 - s : s; };
   const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
+  const float* __restrict__ u32 = reinterpret_cast<const float*>(a.u);
   // slot 8q + kk of the chunk of steps (sa, sa - 1): step sa - (q >> 1), sequence 8 (q & 1) + kk.  `two` = false: the
   // second step does not exist (its dgates rows are zero; addresses clamped to the first)
   auto pair_loads = [&](int sa, bool two) {
@@ -859,10 +888,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     for (int kk = 0; kk < 8; ++kk) {
       const int64_t pos = (int64_t)posb[kk] + (int64_t)st * a.p_step;
       const int64_t posh = (int64_t)posb[kk] + (int64_t)sth * a.p_step;
-      if constexpr (H32) o.hh32[kk] = ld4(hs32 + posh * (2 * H) + 4 * j);
+      if constexpr (H32) o.hh32[kk] = ld4(hs32 + posh * LDH + 4 * j);
       else if constexpr (BI) o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * (2 * H) + dir * H + 4 * j);
       else o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * H + 4 * j);
-      if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
+      if constexpr (XP) {
+        if constexpr (CK == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(u32 + pos * FST + 2 * j);
+          o.uf[0][kk] = v.x; o.uf[1][kk] = v.y;
+        } else {
+          o.uf[0][kk] = u32[pos * FST + j];
+        }
+      } else if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
       else o.uh1[kk] = u16[pos * FST + j];
       // the Linear's weight gradient pairs h of a position with dy of the SAME position (the h_prev row's)
       if constexpr (LINW) {
@@ -887,6 +923,114 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
     const bool hp = sw > 0;
     const h16x4 hz4 = {0, 0, 0, 0};
+    if constexpr (XP) {
+      const h16x8 dn8 = {(_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn,
+                         (_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn};
+      auto split3 = [&](const float (&v)[8], h16x8& bh, h16x8& bl, h16x8& bs) {   // v = bh + bl; bs = 2^-11 bh
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const _Float16 hh = (_Float16)v[kk];
+          bh[kk] = hh;
+          bl[kk] = (_Float16)(v[kk] - (float)hh);
+        }
+        bs = bh * dn8;
+      };
+      auto split2x = [&](const float (&v)[8], h16x8& ah, h16x8& al) {              // v = ah + 2^-11 al
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const _Float16 hh = (_Float16)v[kk];
+          ah[kk] = hh;
+          al[kk] = (_Float16)((v[kk] - (float)hh) * kLoUp);
+        }
+      };
+      if constexpr (LINW) {                          // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
+        float hw[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const f32x4 hm = hp ? o.hh32[kk] : zero4();
+          hw[kk] = w == 0 ? hm[0] : (w == 1 ? hm[1] : (w == 2 ? hm[2] : hm[3]));
+        }
+        h16x8 bwh, bwl, bws;
+        split3(hw, bwh, bwl, bws);
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) {
+          float dv8[8];
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const bool dv = hp && (two || q < 2) && ((slotv >> kk) & 1u);
+            dv8[kk] = dv ? o.dyv[ct][kk] * gS : 0.f;
+            lbs[ct] += dv8[kk];
+          }
+          h16x8 adh, adl;
+          split2x(dv8, adh, adl);
+          lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adl, bws, lacc[ct], 0, 0, 0);
+          lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adh, bwl, lacc[ct], 0, 0, 0);
+          lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adh, bwh, lacc[ct], 0, 0, 0);
+        }
+      }
+      // dgates of this lane's 8 k-slots, gate columns 64w + 4j .. + 3: hi and scaled low terms
+      h16x8 Aoh[4], Aol[4];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const h16x4 th = *reinterpret_cast<const h16x4*>(&DG[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
+        const h16x4 tl = *reinterpret_cast<const h16x4*>(&DGL[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { Aoh[nt][kk] = th[nt]; Aol[nt][kk] = tl[nt]; }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          csum[nt] = __builtin_amdgcn_fdot2(h16x2{Aoh[nt][2 * pr], Aoh[nt][2 * pr + 1]}, ones2, csum[nt], false);
+          csumx[nt] = __builtin_amdgcn_fdot2(h16x2{Aol[nt][2 * pr], Aol[nt][2 * pr + 1]}, ones2, csumx[nt], false);
+        }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {              // column tiles: u, then h_prev
+        float v[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          if (kt < CK) v[kk] = o.uf[kt < CK ? kt : 0][kk];
+          else v[kk] = hp ? o.hh32[kk][kt >= CK ? kt - CK : 0] : 0.f;
+        }
+        h16x8 bh, bl, bs;
+        split3(v, bh, bl, bs);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aol[nt], bs, wacc[nt][kt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bl, wacc[nt][kt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bh, wacc[nt][kt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        f32x4 du[CK], dux[CK];
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) { du[ct] = zero4(); dux[ct] = zero4(); }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const h16x8 d8 = *reinterpret_cast<const h16x8*>(&DG[sl + sb][j][64 * w + 32 * m + 8 * q]);
+          const h16x8 d8l = *reinterpret_cast<const h16x8*>(&DGL[sl + sb][j][64 * w + 32 * m + 8 * q]);
+#pragma unroll
+          for (int ct = 0; ct < CK; ++ct) {
+            if constexpr (LNB) {                     // du^T: rows = positions, columns = channels
+              dux[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8l, Awt[ct][m].hi, dux[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].lo, du[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].hi, du[ct], 0, 0, 0);
+            } else {
+              dux[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8l, dux[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].lo, d8, du[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8, du[ct], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) du[ct][r] = __builtin_fmaf(dux[ct][r], kLoDn, du[ct][r]);
+          st4(&R[buf][w][sb][ct][lane][0], du[ct]);
+        }
+      }
+    } else {
     h16x8 Bop[KT];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -957,9 +1101,47 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
       for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
     }
+    }
   };
   // the chunks pair dy with h at steps 0 .. S-2 (the h_prev rows); the last step of a tile is added here
   auto lin_top = [&]() {
+    if constexpr (XP) {
+      float hw[8], dv8[CK][8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int64_t pos = (int64_t)posb[kk] + (int64_t)st_of(S - 1) * a.p_step;       // walk index S - 1
+        const f32x4 h32 = ld4(hs32 + pos * LDH + 4 * j);
+        const float hv = w == 0 ? h32[0] : (w == 1 ? h32[1] : (w == 2 ? h32[2] : h32[3]));
+        hw[kk] = q < 2 ? hv : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) {
+          const float v = dyj[pos * FST + 16 * ct];
+          dv8[ct][kk] = (q < 2 && ((slotv >> kk) & 1u)) ? v * gS : 0.f;
+        }
+      }
+      h16x8 bwh, bwl, bws;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const _Float16 hh = (_Float16)hw[kk];
+        bwh[kk] = hh;
+        bwl[kk] = (_Float16)(hw[kk] - (float)hh);
+        bws[kk] = hh * (_Float16)kLoDn;
+      }
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) {
+        h16x8 adh, adl;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const _Float16 hh = (_Float16)dv8[ct][kk];
+          adh[kk] = hh;
+          adl[kk] = (_Float16)((dv8[ct][kk] - (float)hh) * kLoUp);
+          lbs[ct] += dv8[ct][kk];
+        }
+        lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adl, bws, lacc[ct], 0, 0, 0);
+        lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adh, bwl, lacc[ct], 0, 0, 0);
+        lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adh, bwh, lacc[ct], 0, 0, 0);
+      }
+    } else {
     h16x8 Bw;
     float lin_top_dy[CK][8];
     const h16x4 hz4 = {0, 0, 0, 0};
@@ -968,7 +1150,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       const int64_t pos = (int64_t)posb[kk] + (int64_t)st_of(S - 1) * a.p_step;       // walk index S - 1
       h16x4 hv;
       if constexpr (H32) {
-        const f32x4 h32 = ld4(hs32 + pos * (2 * H) + 4 * j);
+        const f32x4 h32 = ld4(hs32 + pos * LDH + 4 * j);
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[r] = (_Float16)h32[r];
       } else if constexpr (BI) {
@@ -990,6 +1172,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) { Ad[kk] = (_Float16)lin_top_dy[ct][kk]; lbs[ct] += lin_top_dy[ct][kk]; }
       lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ad, Bw, lacc[ct], 0, 0, 0);
+    }
     }
   };
   const float invS = 1.0f / gS;                    // gS is a power of two
@@ -1057,6 +1240,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         else { r.r0 = ld4(rec); r.r1 = ld4(rec + 256); }
         r.r2 = r.r3 = r.cp = zero4();
         r.cp16 = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(a.save_c) + blk * (16 * H) + (w * 64 + lane) * 4);
+      } else if constexpr (XP) {           // blocked fp32 records of the forward kernel's SAVE == 4
+        const int64_t blk = (rec_tile + st) * ndir + dir;
+        const float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
+        r.r0 = ld4(rec); r.r1 = ld4(rec + 256); r.r2 = ld4(rec + 512); r.r3 = ld4(rec + 768);
+        r.cp = ld4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4);
       } else {
         const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
         r.r0 = ld4(rec); r.r1 = ld4(rec + H); r.r2 = ld4(rec + 2 * H); r.r3 = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
@@ -1161,7 +1349,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #endif
     f32x4 dhext = raw.dh;
     if constexpr (DG16 && FUSE_C == 0) dhext *= gS;
-    if constexpr (FUSE_C > 0) {
+    if constexpr (FUSE_C > 0 && XP) {
+      h16x8 bh, bl;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const float v = (kk < 4 ? raw.dh[kk] : raw.dy1[kk - 4]) * gS;
+        const _Float16 hh = (_Float16)v;
+        bh[kk] = hh;
+        bl[kk] = (_Float16)((v - (float)hh) * kLoUp);
+      }
+      const f32x4 dxl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxh, bl, zero4(), 0, 0, 0);
+      dhext = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxl, bh, zero4(), 0, 0, 0);
+      dhext = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxh, bh, dhext, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dhext[r] = __builtin_fmaf(dxl[r], kLoDn, dhext[r]);
+    } else if constexpr (FUSE_C > 0) {
       bf16x8 bh, bl;
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
@@ -1191,7 +1393,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
     // the 16 dgates of this lane are the two K-chunks of the B operand (3-way bf16 split, or the fp16 values)
     Split3 Bop[2];
-    h16x8 Bh[2];
+    h16x8 Bh[2], Bl[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       float t[8];
@@ -1199,7 +1401,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       for (int kk = 0; kk < 8; ++kk) t[kk] = dG[2 * c + (kk >> 2)][kk & 3];
       if constexpr (DG16) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) Bh[c][kk] = (_Float16)t[kk];
+        for (int kk = 0; kk < 8; ++kk) {
+          Bh[c][kk] = (_Float16)t[kk];
+          if constexpr (XP) Bl[c][kk] = (_Float16)((t[kk] - (float)Bh[c][kk]) * kLoUp);
+        }
       } else {
         Bop[c] = split8(t);
       }
@@ -1214,6 +1419,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = Bh[g >> 1][4 * (g & 1) + r];
         *reinterpret_cast<h16x4*>(&DG[slot][j][g * H + uoff]) = t;
+        if constexpr (XP) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = Bl[g >> 1][4 * (g & 1) + r];
+          *reinterpret_cast<h16x4*>(&DGL[slot][j][g * H + uoff]) = t;
+        }
       }
     } else if constexpr (SLAB) {
 #pragma unroll
@@ -1250,6 +1460,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         for (int ot = 0; ot < 4; ++ot) part[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ot][c].lo, Bh[c], part[ot], 0, 0, 0);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) part[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ot][c].hi, Bh[c], part[ot], 0, 0, 0);
+      }
+      if constexpr (XP) {                              // the scaled low terms of the dgates: accumulated apart, folded in
+        f32x4 partx[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int ot = 0; ot < 4; ++ot) partx[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ot][c].hi, Bl[c], partx[ot], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[ot][r] = __builtin_fmaf(partx[ot][r], kLoDn, part[ot][r]);
       }
     } else
 #pragma unroll
@@ -1339,7 +1560,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         if (pend_n) flush(pend_s, pend_n, pk ^ 1, pend_x, pend_r);
         const h16x4 hz = {0, 0, 0, 0};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<h16x4*>(&DG[2 * pk + 1][j][g * H + uoff]) = hz;
+        for (int g = 0; g < 4; ++g) {
+          *reinterpret_cast<h16x4*>(&DG[2 * pk + 1][j][g * H + uoff]) = hz;
+          if constexpr (XP) *reinterpret_cast<h16x4*>(&DGL[2 * pk + 1][j][g * H + uoff]) = hz;
+        }
         __syncthreads();
         chunk(2 * pk, pk, ops1, s_lo, false);
         pend_s = s_lo; pend_n = 1;
@@ -1405,7 +1629,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) part[(size_t)gate * Ktot + FST + 4 * j + kt] = wacc[nt][CK + kt][r] * invS;
       }
-      const float cs = quad_sum(csum[nt]);
+      const float cs = quad_sum(XP ? __builtin_fmaf(csumx[nt], kLoDn, csum[nt]) : csum[nt]);
       if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
     }
     float* plin = part + (size_t)4 * H * Ktot + 4 * H;           // [C][64] dW_lin, then [C] db_lin
@@ -1483,7 +1707,9 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
   if (a.aux_f16 && !a.save_c) return -1003;
   // aux_f16 with save_gates == NULL: records without the gates (the backward recomputes them: sb_lstm_bwd_args.recompute)
-  const int save = a.save_gates == nullptr ? (a.save_c && a.aux_f16 ? 3 : 0) : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
+  if (a.rec_f32 && (!a.save_gates || !a.save_c || a.aux_f16 || !f16)) return -1003;
+  const int save = a.save_gates == nullptr ? (a.save_c && a.aux_f16 ? 3 : 0)
+                                           : (a.save_c ? (a.rec_f32 ? 4 : (a.aux_f16 ? 3 : 2)) : 1);
   dim3 grid(ntiles, a.ndir);
   const bool lin = a.lin_w != nullptr;
   if (lin && (!f16 || !a.lin_b || !a.y)) return -1003;         // ndir == 2: per-direction partial products (see the kernel)
@@ -1512,11 +1738,12 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   if (a.slab_flags && (seg || !lin || !f16 || a.slab_len < 4 || (a.slab_len & 3) || !a.ord_started)) return -1003;
   if (a.tile_order) {    // consumer side of the overlapped forward: bidirectional partial-Linear pass, ordered 1-D grid
     if (!a.slab_flags || !a.tile_need || !a.sched_status || !a.ord_counter || !a.ord_started || a.ndir != 2 || a.C != 32 ||
-        (save != 0 && save != 3) || a.ord_grid < 2 || (a.ord_grid & 1))
+        (save != 0 && save != 3 && save != 4) || a.ord_grid < 2 || (a.ord_grid & 1))
       return -1003;
     dim3 g1(a.ord_grid);
 #define SB_LO(SV, FL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, false, false, true>), g1, dim3(256), 0, st, a)
     if (save == 0) { if (full) SB_LO(0, true); else SB_LO(0, false); }
+    else if (save == 4) { if (full) SB_LO(4, true); else SB_LO(4, false); }
     else { if (full) SB_LO(3, true); else SB_LO(3, false); }
 #undef SB_LO
     return 0;
@@ -1525,13 +1752,13 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
     if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>>()) return -1008; \
     hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>), grid, dim3(256), 0, st, a); } while (0)
   if (a.x_part) {        // summed-input mode: single direction, fused Linear, C = 32, inference or fp16 side outputs
-    if (!lin || a.ndir != 1 || a.C != 32 || (save != 0 && save != 3)) return -1003;
+    if (!lin || a.ndir != 1 || a.C != 32 || (save != 0 && save != 3 && save != 4)) return -1003;
 #define SB_L3(SV, FL, SG) do { \
     if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<32, SV, FL, true, true, SG, true>>()) return -1008; \
     hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, SG, true>), grid, dim3(256), 0, st, a); } while (0)
 #define SB_L3F(SV) do { if (full) { if (seg) SB_L3(SV, true, true); else SB_L3(SV, true, false); } \
                         else { if (seg) SB_L3(SV, false, true); else SB_L3(SV, false, false); } } while (0)
-    if (save == 0) SB_L3F(0); else SB_L3F(3);
+    if (save == 0) SB_L3F(0); else if (save == 4) SB_L3F(4); else SB_L3F(3);
 #undef SB_L3F
 #undef SB_L3
     return 0;
@@ -1544,6 +1771,7 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
     if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
     else if (save == 1) { if (full) SB_LT(CC, 1, true); else SB_LT(CC, 1, false); } \
     else if (save == 2) { if (full) SB_LT(CC, 2, true); else SB_LT(CC, 2, false); } \
+    else if (save == 4) { if (full) SB_LT(CC, 4, true); else SB_LT(CC, 4, false); } \
     else { if (full) SB_LT(CC, 3, true); else SB_LT(CC, 3, false); } } while (0)
   if (a.C == 32) SB_LC(32); else SB_LC(16);
 #undef SB_LC
@@ -1577,6 +1805,8 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   }
   // fused streaming part (see the kernel): single direction, fused Linear backward with the same channel count
   const bool fst = a.wpart != nullptr;
+  const bool wide = a.wide != 0;                    // fp32 records / u / hs, two-term gradients (see the kernel: XP)
+  if (wide && (!fst || !dg16 || a.hs_f16 || a.recompute)) return -1003;
   if (fst && a.ndir == 2) {                          // bidirectional fused form: persistent workgroups, one per CU
     if (!dg16 || !a.u || !a.hs || !a.w_ih || !a.w_ih1 || !a.du || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
         !a.dW_ih1 || !a.dW_hh1 || !a.db_ih1 || !a.db_hh1 || (int64_t)a.nseq * a.nsteps * H >= (1ll << 31))
@@ -1586,6 +1816,12 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     if (gx > ntiles) gx = ntiles;
     dim3 g2(gx, 2);
 #define SB_FB(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_>), g2, block, 0, st, a)
+#define SB_FBX(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC_, true, false, CC, false, true, false, false, false, true>), g2, block, 0, st, a)
+    if (wide) {
+      if (a.C == 16 && fc == 0) { if (full) SB_FBX(true, 0, 16); else SB_FBX(false, 0, 16); }
+      else if (a.C == 32 && fc == 32) { if (full) SB_FBX(true, 32, 32); else SB_FBX(false, 32, 32); }
+      else return -1003;
+    } else
     if (a.C == 16 && fc == 0 && !a.hs_f16) { if (full) SB_FB(true, 0, 16, false); else SB_FB(false, 0, 16, false); }
     else if (a.C == 32 && fc == 32 && !a.hs_f16) { if (full) SB_FB(true, 32, 32, false); else SB_FB(false, 32, 32, false); }
     else if (a.C == 32 && fc == 32 && !a.recompute) { if (full) SB_FB(true, 32, 32, true); else SB_FB(false, 32, 32, true); }
@@ -1595,6 +1831,7 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
       else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, true, 32, true, false, 32, false, true, true, true>), g2, block, 0, st, a);
     }
     else return -1003;
+#undef SB_FBX
 #undef SB_FB
     const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + (fc > 0 ? a.C * 2 * H + a.C : 0);
     int rc = sb_launch_stream_reduce(a.wpart, gx, ld, a.C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, st);
@@ -1618,7 +1855,16 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC, LB>), grid, block, 0, st, a); } while (0)
 #define SB_FC(CC, LB) do { if (full) { if (seg) SB_F(true, CC, true, LB); else SB_F(true, CC, false, LB); } \
                            else { if (seg) SB_F(false, CC, true, LB); else SB_F(false, CC, false, LB); } } while (0)
+#define SB_FX(FL, CC, SG, LB) do { \
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, false, CC, true, SG, CC, LB, false, false, false, false, true>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, CC, true, SG, CC, LB, false, false, false, false, true>), grid, block, 0, st, a); } while (0)
+#define SB_FXC(CC, LB) do { if (full) { if (seg) SB_FX(true, CC, true, LB); else SB_FX(true, CC, false, LB); } \
+                            else { if (seg) SB_FX(false, CC, true, LB); else SB_FX(false, CC, false, LB); } } while (0)
+    if (wide) { if (a.C == 16) { if (lnb) SB_FXC(16, true); else SB_FXC(16, false); } else SB_FXC(32, false); }
+    else
     if (a.C == 16) { if (lnb) SB_FC(16, true); else SB_FC(16, false); } else SB_FC(32, false);
+#undef SB_FXC
+#undef SB_FX
 #undef SB_FC
 #undef SB_F
     const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + a.C * H + a.C + (lnb ? 2 * a.C : 0);

@@ -63,6 +63,15 @@ class IntraPlainFn(torch.autograd.Function):
         train = GRAD_MODE and any(ctx.needs_input_grad)
         geom = Geom.intra(B * T, F)
         dirs = [(wif, whf, bif, bhf), (wir, whr, bir, bhr)]
+        ctx.bptt = ops.layer_mode("intra-plain", Cc)      # BPTT-state precision this node records (and backpropagates) under
+        with ops.bptt_mode(ctx.bptt):
+            return IntraPlainFn._forward(ctx, x, ln_g, ln_b, dirs, lin_w, lin_b, defer_sum, ovl, geom, train)
+
+    @staticmethod
+    def _forward(ctx, x, ln_g, ln_b, dirs, lin_w, lin_b, defer_sum, ovl, geom, train):
+        B, T, F, Cc = x.shape
+        P = B * T * F
+        (wif, whf, bif, bhf), (wir, whr, bir, bhr) = dirs
         if ops.intra_lin_fusion_ok(train, Cc):
             # the Linear inside the recurrence: two per-direction partial products + one elementwise pass; hs is then
             # only a (fp16) side output for the backward kernels, and none at all in inference
@@ -88,6 +97,11 @@ class IntraPlainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with ops.bptt_mode(ctx.bptt):
+            return IntraPlainFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, ln_g, wif, whf, wir, whr, lin_w, hs, u, ln_b, bif, bhf, bir, bhr, lin_b, *g_ = ctx.saved_tensors
         gates = (None, g_[0]) if ctx.no_gates else (g_[0], g_[1] if len(g_) > 1 else None)
         gt = _GradTargets()
@@ -144,6 +158,16 @@ class InterFn(torch.autograd.Function):
         P = B * T * F
         train = GRAD_MODE and any(ctx.needs_input_grad)
         geom = Geom.inter(B, T, F)
+        ctx.bptt = ops.layer_mode("inter", Cc) if ops.can_fuse_linear_fwd() else ("legacy" if ops.BPTT == "wide" else ops.BPTT)
+        with ops.bptt_mode(ctx.bptt):
+            return InterFn._forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0, part, film_w, film_b, bank,
+                                    film_k, ovl, geom, train)
+
+    @staticmethod
+    def _forward(ctx, x, ln_g, ln_b, wi, wh, bi, bh, lin_w, lin_b, h0, c0, part, film_w, film_b, bank, film_k, ovl, geom,
+                 train):
+        B, T, F, Cc = x.shape
+        P = B * T * F
         h0c = h0.reshape(B * F, H).contiguous() if h0 is not None else None
         c0c = c0.reshape(B * F, H).contiguous() if c0 is not None else None
         y = torch.empty_like(x)
@@ -180,6 +204,11 @@ class InterFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dh, _dc):
+        with ops.bptt_mode(ctx.bptt):
+            return InterFn._backward(ctx, dy, _dh, _dc)
+
+    @staticmethod
+    def _backward(ctx, dy, _dh, _dc):
         x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *g_ = ctx.saved_tensors
         gates = (g_[0], g_[1] if len(g_) > 1 else None)
         gt = _GradTargets()
@@ -265,6 +294,19 @@ class IntraConvFn(torch.autograd.Function):
         P2 = B * T * Kd
         train = GRAD_MODE and any(ctx.needs_input_grad)
         dev = x.device
+        ctx.bptt = ops.layer_mode("intra-conv", Cc)
+        with ops.bptt_mode(ctx.bptt):
+            return IntraConvFn._forward(ctx, x, conv_w, conv_b, act_a, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr,
+                                        dec_w, dec_b, down, bias_tail, wc, wd, bd, wdT, wcT, train)
+
+    @staticmethod
+    def _forward(ctx, x, conv_w, conv_b, act_a, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, dec_w, dec_b,
+                 down, bias_tail, wc, wd, bd, wdT, wcT, train):
+        B, T, F, Cc = x.shape
+        Kd = F // down
+        Fm = Kd * down
+        P2 = B * T * Kd
+        dev = x.device
         # kernel-layout forms of the two conv weights (forms.WeightForms, refreshed once per optimiser step):
         # wc [co][j*C + ci], wd [j*C + c][h], bd = bias repeated over the taps, wdT / wcT their transposes (backward)
         v_pre = torch.empty(P2, Cc, device=dev, dtype=torch.float32) if train else None
@@ -289,6 +331,11 @@ class IntraConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with ops.bptt_mode(ctx.bptt):
+            return IntraConvFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         (x, act_a, ln_g, wif, whf, wir, whr, hs, u, v_pre, ln_b, bif, bhf, bir, bhr, conv_w, conv_b, dec_w, dec_b,
          wdT, wcT, *g_) = ctx.saved_tensors
         gates = (g_[0], g_[1] if len(g_) > 1 else None)

@@ -12,8 +12,69 @@ import torch
 from . import _lib as L
 
 H = 64
-# BPTT record format: compact (fp16 gates + fp32 c_prev, 768 B/step) unless SB_EXACT_BPTT=1 (fp32, 1280 B/step)
-COMPACT_BPTT = os.environ.get("SB_EXACT_BPTT", "0") != "1"
+# Precision of the BPTT state (what the forward pass keeps for the backward pass, and what travels between the backward
+# kernels):
+#   "wide"    (default) -- the reference's own precision: fp32 gate / c_prev records (blocked in the kernels' lane order),
+#             fp32 LayerNorm-output and hs side outputs, gradients on the fp16 matrix pipe as two terms (hi + 2^-11 lo',
+#             22 mantissa bits) against hi + lo splits of activations and weights -- through the SAME fused launch
+#             structure as the compact mode (lstm_bwd_rec_bf_kernel<..., XP>).
+#   "compact" (SB_BPTT=compact, opt-in) -- fp16 gate / c_prev records, fp16 side outputs, single-term scaled fp16 dgates:
+#             half the record bytes, a third of the gradient MFMAs, overlapped inter-frame backward; gradient error against
+#             the reference up to 1.3e-3 (tiny goldens) / 4e-4 (full size) instead of <= 2e-4 / 2e-5.
+#   "legacy"  (SB_BPTT=legacy or SB_EXACT_BPTT=1) -- round-1 form of the wide arithmetic: position-major fp32 records,
+#             unfused kernels, fp32-input MFMA in the streaming part.  Kept as the fallback of "wide" for the layer shapes
+#             the fused kernels do not cover, and as an A/B yardstick.
+BPTT = os.environ.get("SB_BPTT", "legacy" if os.environ.get("SB_EXACT_BPTT", "0") == "1" else "wide")
+assert BPTT in ("wide", "compact", "legacy"), BPTT
+
+
+class bptt_mode:
+    """context manager: run a block under another BPTT-state precision (the backward of an autograd node runs under the
+    mode its forward chose; bench.py / the tests switch modes)"""
+
+    def __init__(self, mode):
+        assert mode in ("wide", "compact", "legacy"), mode
+        self.mode = mode
+
+    def __enter__(self):
+        global BPTT
+        self.old, BPTT = BPTT, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global BPTT
+        BPTT = self.old
+        return False
+
+
+def _compact():
+    return BPTT == "compact"
+
+
+def _wide():
+    return BPTT == "wide"
+
+
+def wide_supported(kind, Cc):
+    """layer shapes the wide fused backward kernels cover: kind 'inter' (single direction, fused Linear, C in {16, 32}),
+    'intra-plain' (bidirectional with the fused Linear backward, C == 32), 'intra-conv' (bidirectional, gradient of hs
+    given, C == 16).  Anything else runs in "legacy" form under the wide mode."""
+    if LSTM_MMA != 1 or not FUSED_BPTT:
+        return False
+    if kind == "inter":
+        return Cc in (16, 32)
+    if kind == "intra-plain":
+        return Cc == 32 and FUSED_BPTT_BI
+    if kind == "intra-conv":
+        return Cc == 16 and FUSED_BPTT_BI
+    return False
+
+
+def layer_mode(kind, Cc):
+    """the BPTT-state precision a layer's forward should record under"""
+    if BPTT == "wide" and not wide_supported(kind, Cc):
+        return "legacy"
+    return BPTT
 # recurrent GEMMs: bf16 matrix pipe with exact 3-way split / 6 products (fp32-class) unless SB_LSTM_FP32=1
 # forward operand split: fp16 hi+lo, 3 products (default, 2^-22) or SB_LSTM_BF16X6=1: bf16 3-way, 6 products (2^-24)
 LSTM_MMA = 0 if os.environ.get("SB_LSTM_FP32", "0") == "1" else (2 if os.environ.get("SB_LSTM_BF16X6", "0") == "1" else 1)
@@ -233,11 +294,17 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     assert want_hs or lin is not None
     # training on the default path: the tensors only the backward kernels read (LayerNorm output u; hs when the Linear
     # is fused here) are written as fp16 -- the streaming backward takes them as single fp16 terms anyway
-    aux16 = bool(save and AUX_FP16 and COMPACT_BPTT and DGATES_FP16 and LSTM_MMA in (1, 2))
+    aux16 = bool(save and AUX_FP16 and _compact() and DGATES_FP16 and LSTM_MMA in (1, 2))
     hs16 = aux16 and lin is not None
     hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float16 if hs16 else torch.float32) if want_hs else None
     gates = cprev = None
-    if save and COMPACT_BPTT:
+    wide = bool(save and _wide())
+    if wide:                  # fp32 records, blocked like the compact ones (see the header: rec_f32)
+        assert LSTM_MMA == 1 and not no_gates
+        Pr = (geom.nseq + 15) // 16 * 16 * geom.nsteps
+        gates = torch.empty(Pr, ndir, 4 * H, device=dev, dtype=torch.float32)
+        cprev = torch.empty(Pr, ndir, H, device=dev, dtype=torch.float32)
+    elif save and _compact():
         # opaque to the host: on the 16-bit matrix path the records are blocked per (16-sequence tile, step, direction)
         # in the kernels' lane order (include/sound_bubble_hip.h), hence the rows padded to whole tiles
         Pr = (geom.nseq + 15) // 16 * 16 * geom.nsteps if LSTM_MMA else geom.P
@@ -261,6 +328,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
     a.hs, a.save_u = _ph(hs), _ph(u if u is not None else PHASE_TIMING_BUF)
     a.aux_f16 = 1 if aux16 else 0
+    a.rec_f32 = 1 if wide else 0
     a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.mma = LSTM_MMA
     if lin is not None:       # ndir == 2: partial mode, y is [P, 2, C] (see the header)
@@ -316,7 +384,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
 
 def can_fuse_linear_bwd():
     """the recurrent backward can form d(hs) = dy . W_lin on the fly (bf16 split path, compact-BPTT mode)"""
-    return LSTM_MMA in (1, 2) and COMPACT_BPTT
+    return (LSTM_MMA in (1, 2) and _compact()) or (LSTM_MMA == 1 and _wide())
 
 
 # compact-BPTT mode on the bf16 path: dgates travel between the two backward kernels as fp16, scaled by a power of
@@ -416,7 +484,7 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
     ndir = len(w_hh_list)
     dev = dhs.device if dhs is not None else dy.device
     rec, cprev = gates
-    dg16 = DGATES_FP16 and LSTM_MMA in (1, 2) and cprev is not None
+    dg16 = DGATES_FP16 and LSTM_MMA in (1, 2) and cprev is not None and cprev.dtype == torch.float16 and _compact()
     gmax = (gmax if gmax is not None else absmax_or_hint(dy if dy is not None else dhs)) if dg16 else None
     dg = torch.empty(geom.P, ndir, 4, H, device=dev, dtype=torch.float16 if dg16 else torch.float32)
     a = L.LstmBwdArgs()
@@ -452,7 +520,7 @@ BWD_OVERLAP_SLAB = int(os.environ.get("SB_BWD_OVERLAP_SLAB", "32"))
 
 def can_overlap_inter_bwd(geom, u, hs):
     """the overlapped form pays when the recurrence leaves a good part of the chip idle and has enough slabs to pipeline"""
-    if not (BWD_OVERLAP and STREAM_LIN_WGRAD and FUSED_LN_BWD and DGATES_FP16 and COMPACT_BPTT and LSTM_MMA in (1, 2)
+    if not (BWD_OVERLAP and STREAM_LIN_WGRAD and FUSED_LN_BWD and DGATES_FP16 and _compact() and LSTM_MMA in (1, 2)
             and can_fuse_linear_bwd() and u is not None and hs is not None and u.dtype == torch.float16
             and hs.dtype == torch.float16 and u.shape[-1] in (16, 32)):
         return False
@@ -533,7 +601,10 @@ def can_fuse_stream(u, hs, geom=None):
     """fp16 side outputs present (default training path).  With a geometry: also whether fusing pays -- the extra chunk
     arithmetic lengthens the serial chain of every tile, which only wins where the pass is memory-bound, i.e. the tiles
     fill the chip (measured: 290 tiles on 256 CUs +7.5 % train step, 145 tiles -1.2 %)."""
-    ok = (FUSED_BPTT and DGATES_FP16 and COMPACT_BPTT and LSTM_MMA in (1, 2) and u is not None and hs is not None
+    if _wide():               # wide form: the fused kernel is the only one that reads the blocked fp32 records
+        return (FUSED_BPTT and LSTM_MMA == 1 and u is not None and hs is not None and u.dtype == torch.float32
+                and hs.dtype == torch.float32 and u.shape[-1] in (16, 32))
+    ok = (FUSED_BPTT and DGATES_FP16 and _compact() and LSTM_MMA in (1, 2) and u is not None and hs is not None
           and u.dtype == torch.float16 and hs.dtype == torch.float16 and u.shape[-1] in (16, 32))
     if ok and geom is not None and os.environ.get("SB_FORCE_FUSED_BPTT", "0") != "1":
         ok = 4 * ((geom.nseq + 15) // 16) >= 3 * _cu_count(u.device)
@@ -560,6 +631,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     a.save_gates = C.c_void_p(rec.data_ptr())
     a.save_c = C.c_void_p(cprev.data_ptr())
     a.gmax, a.mma = _p(gmax), LSTM_MMA
+    a.wide = 1 if rec.dtype == torch.float32 else 0
     a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
     ntiles = (geom.nseq + 15) // 16
     seg_scratch = None
@@ -579,9 +651,11 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     if lin_targets is not None:
         assert lin_targets[0].shape == (Cc, H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
-    by = geom.P * (640.0 + 4.0 * Cc + 2.0 * H + 2.0 * Cc + 4.0 * Cc + (8.0 * Cc if ln is not None else 0.0))
+    by = geom.P * ((1280.0 if a.wide else 640.0) + 4.0 * Cc + hs.element_size() * H + u.element_size() * Cc + 4.0 * Cc
+                   + (8.0 * Cc if ln is not None else 0.0))
     fl = (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc + 2.0 * H * Cc) * geom.P
-    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else ""),
+    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else "")
+               + (" [wide]" if a.wide else ""),
                fl, 8.0 * Cc * geom.P, by):
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
     return du
@@ -592,7 +666,10 @@ FUSED_BPTT_BI = os.environ.get("SB_NO_FUSED_BPTT_BI", "0") != "1"
 
 def can_fuse_stream_bi(u, hs):
     """bidirectional passes: fused form with fp32 hs, or (C == 32, partial-Linear forward) fp16 hs (see lstm_bwd_fused_bi)"""
-    return (FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and COMPACT_BPTT and LSTM_MMA in (1, 2) and u is not None
+    if _wide():
+        return (FUSED_BPTT and FUSED_BPTT_BI and LSTM_MMA == 1 and u is not None and u.dtype == torch.float32
+                and hs.dtype == torch.float32 and u.shape[-1] in (16, 32))
+    return (FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and _compact() and LSTM_MMA in (1, 2) and u is not None
             and u.dtype == torch.float16 and u.shape[-1] in (16, 32)
             and (hs.dtype == torch.float32 or (hs.dtype == torch.float16 and u.shape[-1] == 32)))
 
@@ -607,6 +684,8 @@ def intra_lin_fusion_ok(train, Cc):
     that takes hs as fp16 [P, 128])"""
     if not (INTRA_LIN_FUSION and can_fuse_linear_fwd() and Cc == 32):
         return False
+    if train and _wide():
+        return can_fuse_linear_bwd() and FUSED_BPTT and FUSED_BPTT_BI
     return (not train) or (can_fuse_linear_bwd() and FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and AUX_FP16)
 
 
@@ -653,6 +732,7 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
         a.save_gates = C.c_void_p(rec.data_ptr())
     a.save_c = C.c_void_p(cprev.data_ptr())
     a.gmax, a.mma = _p(gmax), LSTM_MMA
+    a.wide = 1 if cprev.dtype == torch.float32 else 0
     if dy is not None:
         assert w_lin.shape == (Cc, 2 * H) and dy.shape[-1] == Cc
         a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
@@ -673,11 +753,11 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
     a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
-    by = geom.P * (2 * (640.0 if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
-                   + 2.0 * H * hs.element_size() + 2.0 * Cc + 8.0 * Cc)
+    by = geom.P * (2 * ((1280.0 if a.wide else 640.0) if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
+                   + 2.0 * H * hs.element_size() + u.element_size() * Cc + 8.0 * Cc)
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
-    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)", fl,
+    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)" + (" [wide]" if a.wide else ""), fl,
                8.0 * Cc * geom.P, by):
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused, bidirectional)")
     return du
@@ -734,7 +814,7 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None
     else:
         assert lin_targets is None
         a.du_part = _p(du)
-    a.split_bf16 = 1 if COMPACT_BPTT else 0       # exact mode (SB_EXACT_BPTT=1) keeps the fp32 matrix path
+    a.split_bf16 = 1 if _compact() else 0         # legacy mode keeps the fp32 matrix path
     by = P * ndir * (dg.element_size() * 4.0 * H + hs.element_size() * H + 4.0 * Cc) + u.element_size() * Cc * P
     with _Prof(f"lstm_bwd_stream kernel C={Cc} ndir={ndir}", (2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P * ndir,
                8.0 * Cc * P, by):

@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _grad_worker(rank, world, port, compact, q):
+def _grad_worker(rank, world, port, mode, q):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -40,7 +40,7 @@ def _grad_worker(rank, world, port, compact, q):
     from sound_bubble_amd import ops
     from sound_bubble_amd.functional import SnrlpLossFn
     from sound_bubble_amd.train import FlatBucket, allreduce_grads
-    ops.COMPACT_BPTT = compact
+    ops.BPTT = mode
     rec, params, _ = load_golden("tiny_small")
     m = sb.NetOptim(**params)
     m.load_state_dict(golden_state_dict(rec, torch))
@@ -59,15 +59,15 @@ def _grad_worker(rank, world, port, compact, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compact", [False, True], ids=["exact-bptt", "default-compact"])
-def test_two_ranks_on_one_gpu_allreduce_matches_global_batch_gradient(compact):
+@pytest.mark.parametrize("mode", ["wide", "legacy", "compact"])
+def test_two_ranks_on_one_gpu_allreduce_matches_global_batch_gradient(mode):
     import torch
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, compact, q)) for r in range(2)]
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     g_dp = q.get()
@@ -78,8 +78,8 @@ def test_two_ranks_on_one_gpu_allreduce_matches_global_batch_gradient(compact):
     from sound_bubble_amd import ops
     from sound_bubble_amd.functional import SnrlpLossFn
     from sound_bubble_amd.train import FlatBucket
-    old = ops.COMPACT_BPTT
-    ops.COMPACT_BPTT = compact
+    old = ops.BPTT
+    ops.BPTT = mode
     try:
         rec, params, _ = load_golden("tiny_small")
         m = sb.NetOptim(**params)
@@ -92,9 +92,9 @@ def test_two_ranks_on_one_gpu_allreduce_matches_global_batch_gradient(compact):
         loss.backward()
         g_ref = bucket.grad.cpu().numpy()
     finally:
-        ops.COMPACT_BPTT = old
+        ops.BPTT = old
     err = rel_l2(g_dp, g_ref)
-    assert err < (2e-3 if compact else 1e-5), err
+    assert err < (2e-3 if mode == "compact" else 1e-5), err
 
 
 def _replica_worker(rank, world, port, q):

@@ -26,7 +26,7 @@ def test_two_train_steps_match_oracle_adam(torch_gpu, clip, monkeypatch):
     torch = torch_gpu
     import sound_bubble_amd as sb
     from sound_bubble_amd import ops
-    monkeypatch.setattr(ops, "COMPACT_BPTT", False)
+    monkeypatch.setattr(ops, "BPTT", "wide")
     from sound_bubble_amd.train import FlatBucket, FusedAdam, train_step
     from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
     rec, params, flavour = load_golden("tiny_small")
@@ -143,7 +143,7 @@ def test_plmodule_protocol_and_checkpoint(torch_gpu, tmp_path):
     assert hl2.optimizer.step_count == hl.optimizer.step_count
 
 
-@pytest.mark.parametrize("exact", [True, False], ids=["exact-bptt", "default-compact"])
+@pytest.mark.parametrize("exact", [True, False], ids=["wide-bptt", "compact-bptt"])
 def test_resume_from_reference_format_checkpoint_takes_the_reference_third_step(torch_gpu, exact, monkeypatch):
     """Row f2: a last.pt in the REFERENCE's layout (torch.optim.Adam state_dict under 'optimizer', SequentialLR state
     under 'scheduler'; written by the reference Net + torch Adam after two steps, tests/golden/make_goldens.py) is
@@ -153,7 +153,7 @@ def test_resume_from_reference_format_checkpoint_takes_the_reference_third_step(
     from sound_bubble_amd import ops
     from sound_bubble_amd.harness import PLModule
     from conftest import GOLDEN
-    monkeypatch.setattr(ops, "COMPACT_BPTT", not exact)
+    monkeypatch.setattr(ops, "BPTT", "wide" if exact else "compact")
     rec, params, _ = load_golden("tiny_small")
     gold = np.load(os.path.join(GOLDEN, "ckpt_resume_tiny_small.npz"))
     path = os.path.join(GOLDEN, "ref_format_last_tiny_small.pt")

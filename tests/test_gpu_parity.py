@@ -11,6 +11,13 @@ TOL_FWD = 2e-5        # measured ~1e-6; the north-star bar is 1e-3 relative L2
 TOL_GRAD = 2e-3
 
 
+@pytest.fixture
+def compact_bptt(monkeypatch):
+    """kernel-level tests of the compact-BPTT (fp16 state) kernels: opt-in mode since round 3 (default: wide)"""
+    from sound_bubble_amd import ops
+    monkeypatch.setattr(ops, "BPTT", "compact")
+
+
 @pytest.fixture(scope="module")
 def torch_gpu():
     import torch
@@ -178,16 +185,20 @@ def test_streaming_matches_reference(torch_gpu, name, cls):
 #                       i.e. the kernel the BASELINE small config runs at B = 32 (290 tiles);
 #   fused-segmented  -- the same under the time-segmented schedule (forward and backward recurrences cut into
 #                       (tile, segment) items handed from workgroup to workgroup), forced through sched_workers/segments;
-#   exact            -- SB_EXACT_BPTT=1 arithmetic (fp32 records, fp32 dgates).
+#   exact            -- SB_BPTT=legacy arithmetic (position-major fp32 records, unfused kernels, fp32 dgates).
 #   recompute        -- SB_GATE_RECOMPUTE=1: no gate records in the C = 32 intra-frame passes, the fused bidirectional
 #                       backward recomputes the gates on the matrix pipe (memory-saving mode).
-DISPATCH = ["default", "fused", "fused-segmented", "exact", "recompute"]
+# The four above run under SB_BPTT=compact (fp16 BPTT state, opt-in since round 3).  The DEFAULT mode is "wide":
+#   wide             -- fp32 records / side outputs, two-term gradients, the fused kernels (lstm_bwd_rec_bf_kernel<.., XP>);
+#   wide-segmented   -- the same under the time-segmented schedule.
+DISPATCH = ["wide", "wide-segmented", "default", "fused", "fused-segmented", "exact", "recompute"]
+COMPACT_MODES = ("default", "fused", "fused-segmented", "recompute")
 
 
 def _set_dispatch(monkeypatch, ops, mode):
-    monkeypatch.setattr(ops, "COMPACT_BPTT", mode != "exact")
+    monkeypatch.setattr(ops, "BPTT", "legacy" if mode == "exact" else "wide" if mode.startswith("wide") else "compact")
     monkeypatch.setattr(ops, "GATE_RECOMPUTE", mode == "recompute")
-    monkeypatch.setattr(ops, "SCHED_OVERRIDE", (4, 2) if mode == "fused-segmented" else None)
+    monkeypatch.setattr(ops, "SCHED_OVERRIDE", (4, 2) if mode.endswith("-segmented") else None)
     if mode in ("fused", "fused-segmented"):
         monkeypatch.setenv("SB_FORCE_FUSED_BPTT", "1")
     else:
@@ -200,7 +211,7 @@ def test_loss_and_gradients_match_reference(torch_gpu, name, cls, mode, monkeypa
     torch = torch_gpu
     from sound_bubble_amd.functional import SnrlpLossFn
     from sound_bubble_amd import ops
-    compact = mode != "exact"
+    compact = mode in COMPACT_MODES
     _set_dispatch(monkeypatch, ops, mode)
     rec, params, m = _build(torch, name, cls)
     m.train()
@@ -329,7 +340,7 @@ def test_direct_grad_accumulation_equals_autograd_path(torch_gpu, name, cls, mon
         assert rel_l2(p.grad.cpu().numpy(), 2 * want[k].cpu().numpy()) < 1e-4 or float(want[k].abs().max()) == 0, k
 
 
-@pytest.mark.parametrize("mode", ["exact", "fused", "fused-segmented"])
+@pytest.mark.parametrize("mode", ["wide", "wide-segmented", "exact", "fused", "fused-segmented"])
 @pytest.mark.parametrize("N", [1, 100, 192, 193, 1000])
 @pytest.mark.parametrize("flavour", ["optim", "dis_embd3"])
 def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, mode, monkeypatch):
@@ -374,21 +385,21 @@ def test_ragged_lengths_match_oracle(torch_gpu, N, flavour, mode, monkeypatch):
         if g is None or float(g.abs().max()) == 0:
             continue
         e = rel_l2(p.grad.cpu().numpy(), g.numpy())
-        if mode != "exact" and g.numel() == 1:
+        if mode in COMPACT_MODES and g.numel() == 1:
             e *= 0.1                      # scalar (PReLU slope) gradients: sums with heavy cancellation, bar 2e-2
         if e > worst[1]:
             worst = (k, e)
     ops.check_sched_status()
-    assert worst[1] < TOL_GRAD, worst
+    assert worst[1] < (TOL_GRAD if mode in COMPACT_MODES else 2e-4), worst
 
 
-def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu, monkeypatch):
+def test_absmax_and_scaled_fp16_dgates_roundtrip(torch_gpu, monkeypatch, compact_bptt):
     """sb_absmax feeds the power-of-two scale of the compact (fp16) dgates: exact max |x|, and the backward pair
     (recurrence -> stream) gives the same weight gradients / dU as the fp32-dgates pair within fp16 rounding,
     also for gradients far outside the fp16 range (1e-9 and 1e+6 magnitudes)."""
     torch = torch_gpu
     from sound_bubble_amd import ops
-    if ops.LSTM_MMA == 0 or not ops.COMPACT_BPTT:
+    if ops.LSTM_MMA == 0:
         pytest.skip("compact fp16 dgates exist only on the 16-bit matrix path in compact-BPTT mode")
     torch.manual_seed(5)
     x = torch.randn(4 * 1237, device="cuda") * 3
@@ -486,7 +497,7 @@ def test_full_size_train_step_properties(torch_gpu):
 
 
 @pytest.mark.parametrize("workers,segments", [(4, 3), (7, 2), (16, 5)])
-def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, monkeypatch):
+def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, monkeypatch, compact_bptt):
     """Single-direction passes with more tiles than CUs are cut into (tile, time-segment) work items that hand the
     recurrent state from workgroup to workgroup (sb_lstm_fwd_args.seg_state).  The arithmetic is unchanged, so the
     forward outputs, the fused Linear output, the final state and the backward dgates must be bit-identical to the
@@ -494,7 +505,7 @@ def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, mo
     sched_segments = ops.SCHED_OVERRIDE)."""
     torch = torch_gpu
     from sound_bubble_amd import ops
-    if ops.LSTM_MMA != 1 or not ops.COMPACT_BPTT or not ops.DGATES_FP16:
+    if ops.LSTM_MMA != 1 or not ops.DGATES_FP16:
         pytest.skip("time-segmented scheduling exists on the default fp16 path only")
     torch.manual_seed(9)
     C_, F_, T_, B_ = 32, 145, 47, 2
@@ -535,15 +546,15 @@ def test_time_segmented_scheduling_is_bit_exact(torch_gpu, workers, segments, mo
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("C_,hook", [(16, None), (32, None), (16, (2, 3)), (32, (3, 2))])
-def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch):
+def test_fused_bptt_matches_two_kernel_backward(torch_gpu, C_, hook, monkeypatch, compact_bptt):
     """Single-direction passes run the streaming part of the backward (dW_ih, dW_hh, db, dU) inside the recurrence
     kernel, from dgates that stay in LDS (sb_lstm_bwd_args.wpart).  Same arithmetic on the same fp16 dgates as the
     recurrence -> stream kernel pair, only the summation order differs: weight gradients and dU must agree to fp32
     rounding.  Odd step count, a partial last tile, and the time-segmented schedule are covered."""
     torch = torch_gpu
     from sound_bubble_amd import ops
-    if not (ops.FUSED_BPTT and ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.can_fuse_linear_fwd()):
-        pytest.skip("fused BPTT exists on the default compact fp16 path only (it needs the fused forward Linear)")
+    if not (ops.FUSED_BPTT and ops.AUX_FP16 and ops.DGATES_FP16 and ops.can_fuse_linear_fwd()):
+        pytest.skip("fused BPTT needs the fused forward Linear and the fp16 side outputs")
     torch.manual_seed(11)
     B_, T_, F_ = 2, 47, 21                                   # 42 sequences = 3 tiles, the last one partial
     geom = ops.Geom.inter(B_, T_, F_)
@@ -617,12 +628,12 @@ def test_linear_reports_absmax_of_its_output(torch_gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("C_,fuse_lin", [(16, False), (32, True)])
-def test_fused_bptt_bidirectional_matches_two_kernel_backward(torch_gpu, C_, fuse_lin):
+def test_fused_bptt_bidirectional_matches_two_kernel_backward(torch_gpu, C_, fuse_lin, compact_bptt):
     """The bidirectional (intra-frame) form of the fused backward: fp32 hs, two directions, persistent workgroups that
     walk several tiles, odd step count and a partial last tile -- against the recurrence -> stream kernel pair."""
     torch = torch_gpu
     from sound_bubble_amd import ops
-    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.LSTM_MMA in (1, 2) and ops.FUSED_BPTT
+    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.LSTM_MMA in (1, 2) and ops.FUSED_BPTT
             and ops.FUSED_BPTT_BI and (not fuse_lin or ops.can_fuse_linear_bwd())):
         pytest.skip("fused BPTT exists on the default compact fp16 path only")
     torch.manual_seed(12)
@@ -705,14 +716,14 @@ def test_conv3x3_fp16x3_matrix_pipe_matches_fp32_mfma(torch_gpu, C_, kind, monke
 
 
 @pytest.mark.parametrize("C_", [16, 32])
-def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(torch_gpu, C_):
+def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(torch_gpu, C_, compact_bptt):
     """sb_lstm_stream_args.dx: the LayerNorm backward + residual of a single-direction pass computed in the flush of the
     streaming kernel (big config's inter-frame backward) against the streaming kernel followed by sb_ln_bwd: dx, d(ln_g),
     d(ln_b), the LSTM weight gradients and the max |dx| hint.  Odd position count (a partial last chunk)."""
     torch = torch_gpu
     from sound_bubble_amd import ops
-    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.can_fuse_linear_fwd()):
-        pytest.skip("default compact fp16 path only")
+    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.can_fuse_linear_fwd()):
+        pytest.skip("compact fp16 path switched off")
     torch.manual_seed(21)
     B_, T_, F_ = 2, 23, 21
     geom = ops.Geom.inter(B_, T_, F_)
@@ -756,7 +767,7 @@ def test_stream_kernel_with_fused_layernorm_backward_matches_stream_then_ln_bwd(
 
 
 @pytest.mark.parametrize("C_,slab", [(32, 32), (32, 6), (16, 10)])
-def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab, monkeypatch):
+def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab, monkeypatch, compact_bptt):
     """sb_lstm_bwd_inter_overlapped (recurrence on the main stream publishing its dgates slab by slab, the stream kernel as
     two launches drawing units of chunks from one counter: next to it on the library's side stream, and behind it) against
     sb_lstm_bwd_rec followed by
@@ -764,8 +775,8 @@ def test_overlapped_inter_backward_matches_the_two_launches(torch_gpu, C_, slab,
     geometry: 3 tiles (the last one partial), a short last slab, chunk ranges that do not end on 32 positions."""
     torch = torch_gpu
     from sound_bubble_amd import ops
-    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.COMPACT_BPTT and ops.can_fuse_linear_fwd() and ops.STREAM_LIN_WGRAD):
-        pytest.skip("default compact fp16 path only")
+    if not (ops.AUX_FP16 and ops.DGATES_FP16 and ops.can_fuse_linear_fwd() and ops.STREAM_LIN_WGRAD):
+        pytest.skip("compact fp16 path switched off")
     if not ops.overlap_available():
         pytest.skip("no side stream that runs concurrently with the main stream on this box")
     monkeypatch.setattr(ops, "BWD_OVERLAP_SLAB", slab)
@@ -870,8 +881,8 @@ def test_inter_forward_with_summed_input_is_bit_identical_to_add3(torch_gpu, sch
     from sound_bubble_amd import ops
     if not ops.can_fuse_linear_fwd():
         pytest.skip("fp16x3 forward only")
-    if save and not (ops.AUX_FP16 and ops.COMPACT_BPTT and ops.DGATES_FP16):
-        pytest.skip("the summed-input mode writes the fp16 side outputs of the default compact-BPTT path in training")
+    if save and not (ops.AUX_FP16 and ops.DGATES_FP16) and ops.BPTT == "compact":
+        pytest.skip("the summed-input mode writes the fp16 side outputs of the compact-BPTT path in training")
     monkeypatch.setattr(ops, "SCHED_OVERRIDE", sched)
     torch.manual_seed(31)
     C_, B_, T_, F_ = 32, 2, 23, 145
@@ -896,3 +907,135 @@ def test_inter_forward_with_summed_input_is_bit_identical_to_add3(torch_gpu, sch
     assert torch.equal(y0, y1) and torch.equal(hN0, hN1) and torch.equal(cN0, cN1)
     if save:
         assert torch.equal(hs0, hs1) and torch.equal(u0, u1) and torch.equal(x_sum, xs)
+
+
+# ---- wide BPTT state (round 3): the fused backward kernels at the reference's precision, against float64 autograd ----
+def _f64_lstm(torch, C_, wi, wh, bi, bh, rev=False):
+    l = torch.nn.LSTM(C_, 64, batch_first=True).double()
+    with torch.no_grad():
+        l.weight_ih_l0.copy_(wi.double().cpu()); l.weight_hh_l0.copy_(wh.double().cpu())
+        l.bias_ih_l0.copy_(bi.double().cpu()); l.bias_hh_l0.copy_(bh.double().cpu())
+    return l
+
+
+@pytest.mark.parametrize("C_,hook", [(16, None), (32, None), (16, (2, 3)), (32, (3, 2))])
+def test_wide_fused_bptt_single_direction_matches_float64_autograd(torch_gpu, C_, hook, monkeypatch):
+    """lstm_bwd_rec_bf_kernel<..., XP> (single direction: the inter-frame pass): forward with blocked fp32 records, fp32
+    u / hs, then recurrence + streaming part + Linear weight gradient (+ LayerNorm backward for C = 16) in one launch, two-
+    term gradients.  Checker: torch.nn.LSTM in float64 with autograd on the same tensors.  Odd step count, a partial
+    last tile, and the time-segmented schedule are covered."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    monkeypatch.setattr(ops, "BPTT", "wide")
+    if not ops.wide_supported("inter", C_):
+        pytest.skip("wide fused kernels switched off")
+    torch.manual_seed(11)
+    B_, T_, F_ = 2, 47, 21                                   # 42 sequences = 3 tiles, the last one partial
+    geom = ops.Geom.inter(B_, T_, F_)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    wi, wh = torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2
+    bi, bh = torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    # gradient magnitudes spread over five decades, the largest an outlier: what the power-of-two scale has to survive
+    dy = torch.randn(geom.P, C_, device="cuda") * 1e-4 * torch.logspace(-3, 0, geom.P, device="cuda")[:, None]
+    dy[7, 3] = 0.5
+    monkeypatch.setattr(ops, "SCHED_OVERRIDE", hook)
+    y = torch.empty(geom.P, C_, device="cuda")
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, [(wi, wh, bi, bh)], geom, save=True, lin=(lin_w, lin_b, y))
+    assert gates[0].dtype == torch.float32 and u.dtype == torch.float32 and hs.dtype == torch.float32
+    assert ops.can_fuse_stream(u, hs)
+    tg = [torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+          torch.zeros(256, device="cuda")]
+    ltg = [torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")]
+    du = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg, lin_targets=ltg)
+    dx = dgf = dbf = None
+    if C_ == 16:
+        tg2 = [torch.zeros_like(t) for t in tg]
+        dgf, dbf = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+        dx = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg2, ln=(x, g, dgf, dbf))
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    # ---- float64 reference ----
+    X = x.double().cpu().view(B_, T_, F_, C_).requires_grad_(True)
+    G, Bt = g.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    U = torch.nn.functional.layer_norm(X, (C_,), G, Bt, 1e-5)
+    U.retain_grad()
+    l = _f64_lstm(torch, C_, wi, wh, bi, bh)
+    Hs, _ = l(U.permute(0, 2, 1, 3).reshape(B_ * F_, T_, C_))
+    Hs = Hs.view(B_, F_, T_, 64).permute(0, 2, 1, 3)
+    LW, LB = lin_w.double().cpu().requires_grad_(True), lin_b.double().cpu().requires_grad_(True)
+    Y = X + Hs @ LW.t() + LB
+    assert rel_l2(y.cpu().numpy(), Y.detach().reshape(-1, C_).numpy()) < 2e-6
+    (Y * dy.double().cpu().view(B_, T_, F_, C_)).sum().backward()
+    tol = 2e-5
+    assert rel_l2(du.cpu().numpy(), U.grad.reshape(-1, C_).numpy()) < tol
+    for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh"), tg,
+                            (l.weight_ih_l0.grad, l.weight_hh_l0.grad, l.bias_ih_l0.grad, l.bias_hh_l0.grad)):
+        assert rel_l2(a_.cpu().numpy(), b_.numpy()) < tol, name
+    assert rel_l2(ltg[0].cpu().numpy(), LW.grad.numpy()) < tol
+    assert rel_l2(ltg[1].cpu().numpy(), LB.grad.numpy()) < tol
+    if C_ == 16:
+        assert rel_l2(dx.cpu().numpy(), X.grad.reshape(-1, C_).numpy()) < tol
+        assert rel_l2(dgf.cpu().numpy(), G.grad.numpy()) < tol
+        assert rel_l2(dbf.cpu().numpy(), Bt.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("C_,fuse_lin", [(16, False), (32, True)])
+def test_wide_fused_bptt_bidirectional_matches_float64_autograd(torch_gpu, C_, fuse_lin, monkeypatch):
+    """The bidirectional (intra-frame) wide form: persistent workgroups over several tiles, odd step count, a partial last
+    tile; incoming gradient as d(hs) (conv-LSTM flavour, C = 16) or as dy through the fused Linear backward (C = 32)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    monkeypatch.setattr(ops, "BPTT", "wide")
+    if not ops.wide_supported("intra-plain" if fuse_lin else "intra-conv", C_):
+        pytest.skip("wide fused kernels switched off")
+    torch.manual_seed(12)
+    nseq, S = 16 * 300 + 5, 29                              # more tiles than persistent workgroups, partial last tile
+    geom = ops.Geom.intra(nseq, S)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    mk = lambda: (torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2,
+                  torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)
+    dirs = [mk(), mk()]
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True)
+    assert gates[0].dtype == torch.float32 and ops.can_fuse_stream_bi(u, hs)
+    lin_w = torch.randn(C_, 128, device="cuda") * 0.2
+    scale = 1e-3 * torch.logspace(-3, 0, geom.P, device="cuda")[:, None]
+    dy = torch.randn(geom.P, C_, device="cuda") * scale
+    dhs = torch.randn(geom.P, 128, device="cuda") * scale
+    dy[11, 2] = 0.25
+    dhs[11, 2] = 0.25
+    kw = dict(dy=dy, w_lin=lin_w) if fuse_lin else dict(dhs=dhs)
+    tg = [[torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+           torch.zeros(256, device="cuda")] for _ in range(2)]
+    ltg = [torch.zeros(C_, 128, device="cuda"), torch.zeros(C_, device="cuda")] if fuse_lin else None
+    du = ops.lstm_bwd_fused_bi([dirs[0][1], dirs[1][1]], gates, geom, u, hs, [dirs[0][0], dirs[1][0]], tg,
+                               lin_targets=ltg, **kw)
+    torch.cuda.synchronize()
+    # ---- float64 reference ----
+    U = torch.nn.functional.layer_norm(x.double().cpu().view(nseq, S, C_), (C_,), g.double().cpu(), b.double().cpu(), 1e-5)
+    U.requires_grad_(True)
+    l = torch.nn.LSTM(C_, 64, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for d, sfx in enumerate(("", "_reverse")):
+            getattr(l, "weight_ih_l0" + sfx).copy_(dirs[d][0].double().cpu())
+            getattr(l, "weight_hh_l0" + sfx).copy_(dirs[d][1].double().cpu())
+            getattr(l, "bias_ih_l0" + sfx).copy_(dirs[d][2].double().cpu())
+            getattr(l, "bias_hh_l0" + sfx).copy_(dirs[d][3].double().cpu())
+    Hs, _ = l(U)
+    assert rel_l2(hs.cpu().numpy(), Hs.detach().reshape(-1, 128).numpy()) < 2e-6
+    LW = lin_w.double().cpu().requires_grad_(True)
+    if fuse_lin:
+        ((Hs.reshape(-1, 128) @ LW.t()) * dy.double().cpu()).sum().backward()
+    else:
+        (Hs.reshape(-1, 128) * dhs.double().cpu()).sum().backward()
+    tol = 2e-5
+    # du [P, 2, C]: the two directions' shares of the gradient w.r.t. the LayerNorm output
+    assert rel_l2(du.sum(1).cpu().numpy(), U.grad.reshape(-1, C_).numpy()) < tol
+    for d, sfx in enumerate(("", "_reverse")):
+        for name, a_ in zip(("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"), tg[d]):
+            assert rel_l2(a_.cpu().numpy(), getattr(l, name + sfx).grad.numpy()) < tol, (d, name)
+    if fuse_lin:
+        assert rel_l2(ltg[0].cpu().numpy(), LW.grad.numpy()) < tol
+        assert rel_l2(ltg[1].cpu().numpy(), dy.double().sum(0).cpu().numpy()) < tol
