@@ -15,6 +15,7 @@
 // C/D as in sb_common.h.  K is walked in chunks of 32: chunk 0 = the (LayerNormed) input u (zero-padded to 32),
 // chunks 1,2 = the hidden state.  Step pipeline: A: hidden part (MFMA) with the LayerNorm of row s+2 in its issue
 // gaps; B: input part of step s+1 (MFMA) || cell update; C: h -> LDS, stores, barrier.
+#include <type_traits>
 #include "sb_common.h"
 #ifndef SB_EXP_SKIP
 #define SB_EXP_SKIP 0
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq = __builtin_fmaf(d, d, sq); }
     const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(row16_sum(sq), 1.0f / C, 1e-5f));   // v_rsq_f32, 1 ulp
     float u[VPT];
+    elem uterm[2][VPT];                            // the two leading terms (SAVE == 4 stores them)
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       u[v] = __builtin_fmaf((xv.v[v] - mean) * rstd, gam[v], bet[v]);
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       splitn1<F16>(u[v], e);
 #pragma unroll
       for (int n = 0; n < NT; ++n) U16[buf][n][ls][cpart * VPT + v] = e[n];
+      uterm[0][v] = e[0]; uterm[1][v] = e[1];
     }
     if constexpr (SUM3) {
 #pragma unroll
@@ -345,6 +348,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + uo;
         if constexpr (VPT == 2) *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)u[0], (_Float16)u[1]};
         else p[0] = (_Float16)u[0];
+      } else if constexpr (SAVE == 4 && F16) {
+        // wide form: u travels as the fp16 hi + lo terms this kernel's own products use (same bytes as fp32, and the
+        // backward kernels take them as matrix operands without a split): [P][C/2][hi0, hi1, lo0, lo1] resp. [P][C][hi, lo]
+        _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + 2 * uo;
+        if constexpr (VPT == 2) *reinterpret_cast<h16x4*>(p) = h16x4{(_Float16)uterm[0][0], (_Float16)uterm[0][1], (_Float16)uterm[1][0], (_Float16)uterm[1][1]};
+        else *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)uterm[0][0], (_Float16)uterm[1][0]};
       } else {
         float* p = a.save_u + uo;
 #pragma unroll
@@ -356,8 +365,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // ---- compute role ----
   const int uoff = 16 * w + 4 * q;
   f32x4 c = zero4(), h = zero4();
+  vec4 htv[NT];                                   // terms of the hidden state this lane stored last (SAVE == 4 writes them out)
   auto store_h = [&](int buf, const f32x4& hv) {   // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
-    vec4 tv[NT];
+    vec4 (&tv)[NT] = htv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       elem e[NT];
@@ -492,6 +502,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) h16[r] = (_Float16)h[r];
           if (a.hs && !(SB_EXP_SKIP & 4)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.hs) + (pos * ndir + dir) * H + uoff) = h16;
+        } else if constexpr (LIN && SAVE == 4 && F16) {
+          // wide form with the Linear applied here: hs only feeds the backward kernels' matrix products -- it travels as the
+          // fp16 hi + lo terms just stored to LDS: [P][ndir][16 unit quads][hi x 4, lo x 4], same bytes as fp32
+          h16x8 hp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { hp[r] = (_Float16)htv[0][r]; hp[4 + r] = (_Float16)htv[1][r]; }
+          if (a.hs) *reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ((pos * ndir + dir) * H + uoff) * 2) = hp;
         } else {
           if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + (pos * ndir + dir) * H + uoff, h);
         }
@@ -852,9 +869,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // loop body (the select of the first version did, and doubled the kernel time once the dy loads joined)
   static_assert(!BI || (!LNB && !SEG), "bidirectional fused form: no LayerNorm rider, no time segments");
   constexpr bool LINW = !BI || FUSE_C > 0;        // the fused Linear's weight gradient rides along (needs dy)
-  constexpr bool H32 = XP || (BI && !HS16B);      // hs as fp32 rows (wide form; bidirectional passes whose Linear is a separate kernel)
-  struct PairOps { h16x4 hh4[H32 ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 && !XP ? 8 : 1]; _Float16 uh1[CK == 2 || XP ? 1 : 8];
-                   float uf[XP ? CK : 1][XP ? 8 : 1];         // XP: u as fp32
+  // XP: u is the forward kernel's fp16 (hi, lo) pair tensor; so is hs when the Linear was applied in the forward kernel
+  // (HSP: every form with the fused Linear backward), else hs is fp32 (the conv-LSTM flavour, whose ConvTranspose reads it)
+  constexpr bool HSP = XP && FUSE_C > 0;
+  constexpr bool H32 = (XP && !HSP) || (BI && !HS16B && !XP);   // hs as fp32 rows
+  struct PairOps { h16x4 hh4[H32 || HSP ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 && !XP ? 8 : 1]; _Float16 uh1[CK == 2 || XP ? 1 : 8];
+                   h16x8 hp8[HSP ? 8 : 1];                    // XP + HSP: h_prev units 4j .. 4j + 3 as (hi x 4, lo x 4)
+                   h16x4 up4[XP && CK == 2 ? 8 : 1]; h16x2 up2[XP && CK == 1 ? 8 : 1];   // XP: u channels (2j, 2j + 1) / j as (hi.., lo..)
                    float dyv[CK][LINW ? 8 : 1];
                    float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
   static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
@@ -888,16 +909,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     for (int kk = 0; kk < 8; ++kk) {
       const int64_t pos = (int64_t)posb[kk] + (int64_t)st * a.p_step;
       const int64_t posh = (int64_t)posb[kk] + (int64_t)sth * a.p_step;
-      if constexpr (H32) o.hh32[kk] = ld4(hs32 + posh * LDH + 4 * j);
+      if constexpr (HSP) o.hp8[kk] = *reinterpret_cast<const h16x8*>(hs16 + (posh * LDH + (BI ? dir * H : 0) + 4 * j) * 2);
+      else if constexpr (H32) o.hh32[kk] = ld4(hs32 + posh * LDH + 4 * j);
       else if constexpr (BI) o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * (2 * H) + dir * H + 4 * j);
       else o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * H + 4 * j);
       if constexpr (XP) {
-        if constexpr (CK == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(u32 + pos * FST + 2 * j);
-          o.uf[0][kk] = v.x; o.uf[1][kk] = v.y;
-        } else {
-          o.uf[0][kk] = u32[pos * FST + j];
-        }
+        if constexpr (CK == 2) o.up4[kk] = *reinterpret_cast<const h16x4*>(u16 + (pos * FST + 2 * j) * 2);
+        else o.up2[kk] = *reinterpret_cast<const h16x2*>(u16 + (pos * FST + j) * 2);
       } else if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
       else o.uh1[kk] = u16[pos * FST + j];
       // the Linear's weight gradient pairs h of a position with dy of the SAME position (the h_prev row's)
@@ -919,7 +937,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   };
   const h16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
   // chunk arithmetic on the dgates rows in LDS slots (sl, sl + 1); du partial sums -> R[buf]
+  // steady (uniform): a full pair of steps away from walk index 0 -- every h_prev row exists, and the per-lane masks
+  // (~50-90 v_cndmask per chunk) sit in blocks behind a uniform branch (the empty asm keeps hipcc from turning the branch
+  // back into selects)
   auto chunk = [&](int sl, int buf, const PairOps& o, int sa, bool two) {
+    const bool steady = two && sa >= 2;
     const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
     const bool hp = sw > 0;
     const h16x4 hz4 = {0, 0, 0, 0};
@@ -940,27 +962,56 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         for (int kk = 0; kk < 8; ++kk) {
           const _Float16 hh = (_Float16)v[kk];
           ah[kk] = hh;
-          al[kk] = (_Float16)((v[kk] - (float)hh) * kLoUp);
+          al[kk] = (_Float16)__builtin_fmaf((float)hh, -kLoUp, v[kk] * kLoUp);
         }
       };
-      if constexpr (LINW) {                          // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
-        float hw[8];
+      // h_prev tiles kt = 0..3 (units 4j + kt of the 8 k-slots) as matrix operands: hi, lo, 2^-11 hi
+      h16x8 hBh[4], hBl[4], hBs[4];
+      if constexpr (HSP) {
+        const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        h16x8 hpm[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) hpm[kk] = o.hp8[kk];
+        if (!steady) {
+          asm volatile("");
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) hpm[kk] = hp ? hpm[kk] : hz8;
+        }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-          const f32x4 hm = hp ? o.hh32[kk] : zero4();
-          hw[kk] = w == 0 ? hm[0] : (w == 1 ? hm[1] : (w == 2 ? hm[2] : hm[3]));
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) { hBh[kt][kk] = hpm[kk][kt]; hBl[kt][kk] = hpm[kk][4 + kt]; }
         }
-        h16x8 bwh, bwl, bws;
-        split3(hw, bwh, bwl, bws);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) hBs[kt] = hBh[kt] * dn8;
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          float v[8];
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) v[kk] = hp ? o.hh32[kk][kt] : 0.f;
+          split3(v, hBh[kt], hBl[kt], hBs[kt]);
+        }
+      }
+      if constexpr (LINW) {                          // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
+        const h16x8 bwh = w == 0 ? hBh[0] : (w == 1 ? hBh[1] : (w == 2 ? hBh[2] : hBh[3]));
+        const h16x8 bwl = w == 0 ? hBl[0] : (w == 1 ? hBl[1] : (w == 2 ? hBl[2] : hBl[3]));
+        const h16x8 bws = w == 0 ? hBs[0] : (w == 1 ? hBs[1] : (w == 2 ? hBs[2] : hBs[3]));
 #pragma unroll
         for (int ct = 0; ct < CK; ++ct) {
           float dv8[8];
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            const bool dv = hp && (two || q < 2) && ((slotv >> kk) & 1u);
-            dv8[kk] = dv ? o.dyv[ct][kk] * gS : 0.f;
-            lbs[ct] += dv8[kk];
+          for (int kk = 0; kk < 8; ++kk) dv8[kk] = o.dyv[ct][kk] * gS;
+          if (!FULL || !steady) {                    // slots of a missing second step / of sequences beyond nseq must not count
+            asm volatile("");
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              const bool dv = hp && (two || q < 2) && ((slotv >> kk) & 1u);
+              dv8[kk] = dv ? dv8[kk] : 0.f;
+            }
           }
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) lbs[ct] += dv8[kk];
           h16x8 adh, adl;
           split2x(dv8, adh, adl);
           lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adl, bws, lacc[ct], 0, 0, 0);
@@ -986,14 +1037,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {              // column tiles: u, then h_prev
-        float v[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          if (kt < CK) v[kk] = o.uf[kt < CK ? kt : 0][kk];
-          else v[kk] = hp ? o.hh32[kk][kt >= CK ? kt - CK : 0] : 0.f;
-        }
         h16x8 bh, bl, bs;
-        split3(v, bh, bl, bs);
+        if (kt < CK) {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            if constexpr (CK == 2) { bh[kk] = o.up4[kk][kt < CK ? kt : 0]; bl[kk] = o.up4[kk][2 + (kt < CK ? kt : 0)]; }
+            else { bh[kk] = o.up2[kk][0]; bl[kk] = o.up2[kk][1]; }
+          }
+          bs = bh * dn8;
+        } else {
+          bh = hBh[kt >= CK ? kt - CK : 0]; bl = hBl[kt >= CK ? kt - CK : 0]; bs = hBs[kt >= CK ? kt - CK : 0];
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aol[nt], bs, wacc[nt][kt], 0, 0, 0);
 #pragma unroll
@@ -1044,22 +1098,39 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = (_Float16)hm[kt];
       } else {
-        const h16x4 hm = hp ? o.hh4[kk] : hz4;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = hm[kt];
+        for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = o.hh4[kk][kt];
+      }
+    }
+    if constexpr (!H32) {
+      if (!steady) {                               // h_prev of walk index 0 is the (zero) initial state
+        asm volatile("");
+        const _Float16 z = (_Float16)0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) Bop[CK + kt][kk] = hp ? Bop[CK + kt][kk] : z;
       }
     }
     if constexpr (LINW)
 #pragma unroll
     for (int ct = 0; ct < CK; ++ct) {              // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
       h16x8 Ad;
+      float dv8[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) dv8[kk] = o.dyv[ct][kk] * gS;
+      if (!FULL || !steady) {                      // slots of a missing second step and of sequences beyond nseq must not count
+        asm volatile("");
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const bool dv = hp && (two || q < 2) && ((slotv >> kk) & 1u);
+          dv8[kk] = dv ? dv8[kk] : 0.f;
+        }
+      }
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        // slots of a missing second step and of sequences beyond nseq must not count
-        const bool dv = hp && (two || q < 2) && ((slotv >> kk) & 1u);
-        const float v = dv ? o.dyv[ct][kk] * gS : 0.f;
-        Ad[kk] = (_Float16)v;
-        lbs[ct] += v;
+        Ad[kk] = (_Float16)dv8[kk];
+        lbs[ct] += dv8[kk];
       }
       const h16x8 Bw = w == 0 ? Bop[CK] : (w == 1 ? Bop[CK + 1] : (w == 2 ? Bop[CK + 2] : Bop[CK + 3]));
       lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ad, Bw, lacc[ct], 0, 0, 0);
@@ -1110,8 +1181,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const int64_t pos = (int64_t)posb[kk] + (int64_t)st_of(S - 1) * a.p_step;       // walk index S - 1
-        const f32x4 h32 = ld4(hs32 + pos * LDH + 4 * j);
-        const float hv = w == 0 ? h32[0] : (w == 1 ? h32[1] : (w == 2 ? h32[2] : h32[3]));
+        float hv;
+        if constexpr (HSP) {
+          const h16x8 hp8 = *reinterpret_cast<const h16x8*>(hs16 + (pos * LDH + (BI ? dir * H : 0) + 4 * j) * 2);
+          hv = w == 0 ? (float)hp8[0] + (float)hp8[4] : (w == 1 ? (float)hp8[1] + (float)hp8[5]
+               : (w == 2 ? (float)hp8[2] + (float)hp8[6] : (float)hp8[3] + (float)hp8[7]));
+        } else {
+          const f32x4 h32 = ld4(hs32 + pos * LDH + 4 * j);
+          hv = w == 0 ? h32[0] : (w == 1 ? h32[1] : (w == 2 ? h32[2] : h32[3]));
+        }
         hw[kk] = q < 2 ? hv : 0.f;
 #pragma unroll
         for (int ct = 0; ct < CK; ++ct) {
@@ -1356,7 +1434,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         const float v = (kk < 4 ? raw.dh[kk] : raw.dy1[kk - 4]) * gS;
         const _Float16 hh = (_Float16)v;
         bh[kk] = hh;
-        bl[kk] = (_Float16)((v - (float)hh) * kLoUp);
+        bl[kk] = (_Float16)__builtin_fmaf((float)hh, -kLoUp, v * kLoUp);
       }
       const f32x4 dxl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxh, bl, zero4(), 0, 0, 0);
       dhext = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxl, bh, zero4(), 0, 0, 0);
@@ -1403,7 +1481,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           Bh[c][kk] = (_Float16)t[kk];
-          if constexpr (XP) Bl[c][kk] = (_Float16)((t[kk] - (float)Bh[c][kk]) * kLoUp);
+          if constexpr (XP) Bl[c][kk] = (_Float16)__builtin_fmaf((float)Bh[c][kk], -kLoUp, t[kk] * kLoUp);
         }
       } else {
         Bop[c] = split8(t);

@@ -296,9 +296,14 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     # is fused here) are written as fp16 -- the streaming backward takes them as single fp16 terms anyway
     aux16 = bool(save and AUX_FP16 and _compact() and DGATES_FP16 and LSTM_MMA in (1, 2))
     hs16 = aux16 and lin is not None
-    hs = torch.empty(geom.P, ndir * H, device=dev, dtype=torch.float16 if hs16 else torch.float32) if want_hs else None
-    gates = cprev = None
     wide = bool(save and _wide())
+    # wide form: the tensors that only the backward kernels' matrix products read travel as the fp16 (hi, lo) term pairs
+    # the forward kernel itself multiplies with -- same bytes as fp32, no split in the backward: u always ([P, 2C] halves),
+    # hs when the Linear is applied inside this kernel ([P, ndir * 128] halves); kernel-private layouts (see the header)
+    hsp = wide and lin is not None
+    hs = (torch.empty(geom.P, ndir * H * (2 if hsp else 1), device=dev,
+                      dtype=torch.float16 if (hs16 or hsp) else torch.float32) if want_hs else None)
+    gates = cprev = None
     if wide:                  # fp32 records, blocked like the compact ones (see the header: rec_f32)
         assert LSTM_MMA == 1 and not no_gates
         Pr = (geom.nseq + 15) // 16 * 16 * geom.nsteps
@@ -315,7 +320,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         cprev = torch.empty(Pr, ndir, H, device=dev, dtype=torch.float16 if LSTM_MMA else torch.float32)
     elif save:
         gates = torch.empty(geom.P, ndir, 5, H, device=dev, dtype=torch.float32)
-    u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float16 if aux16 else torch.float32) if save else None
+    u = (torch.empty(geom.P, Cc * (2 if wide else 1), device=dev, dtype=torch.float16 if (aux16 or wide) else torch.float32)
+         if save else None)
     hN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
     cN = torch.empty(geom.nseq, H, device=dev, dtype=torch.float32) if want_state else None
     a = L.LstmFwdArgs()
@@ -346,10 +352,10 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         seg_scratch = _seg_scratch(a, geom, dev)
     # design bytes of this launch
     by = 4.0 * Cc * geom.P                                               # x rows (both directions share them)
-    by += geom.P * ndir * (hs.element_size() * H if hs is not None else 0.0)    # hidden sequence out
+    by += hs.numel() * hs.element_size() if hs is not None else 0.0             # hidden sequence out
     if gates is not None or cprev is not None:                           # BPTT records + saved LayerNorm output
         by += geom.P * ndir * ((gates.element_size() * gates[0, 0].numel() if gates is not None else 0)
-                               + (cprev.element_size() * H if cprev is not None else 0)) + u.element_size() * Cc * geom.P
+                               + (cprev.element_size() * H if cprev is not None else 0)) + u.numel() * u.element_size()
     if lin is not None:
         by += 2 * 4.0 * Cc * geom.P                                      # residual rows in, y out
     if x_part is not None:
@@ -602,8 +608,8 @@ def can_fuse_stream(u, hs, geom=None):
     arithmetic lengthens the serial chain of every tile, which only wins where the pass is memory-bound, i.e. the tiles
     fill the chip (measured: 290 tiles on 256 CUs +7.5 % train step, 145 tiles -1.2 %)."""
     if _wide():               # wide form: the fused kernel is the only one that reads the blocked fp32 records
-        return (FUSED_BPTT and LSTM_MMA == 1 and u is not None and hs is not None and u.dtype == torch.float32
-                and hs.dtype == torch.float32 and u.shape[-1] in (16, 32))
+        return (FUSED_BPTT and LSTM_MMA == 1 and u is not None and hs is not None and u.dtype == torch.float16
+                and hs.dtype == torch.float16 and u.shape[-1] in (32, 64) and hs.shape[-1] == 2 * H)
     ok = (FUSED_BPTT and DGATES_FP16 and _compact() and LSTM_MMA in (1, 2) and u is not None and hs is not None
           and u.dtype == torch.float16 and hs.dtype == torch.float16 and u.shape[-1] in (16, 32))
     if ok and geom is not None and os.environ.get("SB_FORCE_FUSED_BPTT", "0") != "1":
@@ -622,7 +628,8 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     rec, cprev = gates
     dev = dy.device
     Cc = dy.shape[-1]
-    assert can_fuse_stream(u, hs) and cprev is not None and w_lin.shape == (Cc, H) and u.shape[-1] == Cc
+    assert can_fuse_stream(u, hs) and cprev is not None and w_lin.shape == (Cc, H) and u.numel() * u.element_size() in (
+        2 * geom.P * Cc, 4 * geom.P * Cc)
     gmax = absmax_or_hint(dy)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 1
@@ -651,8 +658,8 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     if lin_targets is not None:
         assert lin_targets[0].shape == (Cc, H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
-    by = geom.P * ((1280.0 if a.wide else 640.0) + 4.0 * Cc + hs.element_size() * H + u.element_size() * Cc + 4.0 * Cc
-                   + (8.0 * Cc if ln is not None else 0.0))
+    by = (geom.P * ((1280.0 if a.wide else 640.0) + 4.0 * Cc + 4.0 * Cc + (8.0 * Cc if ln is not None else 0.0))
+          + hs.numel() * hs.element_size() + u.numel() * u.element_size())
     fl = (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc + 2.0 * H * Cc) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else "")
                + (" [wide]" if a.wide else ""),
@@ -666,9 +673,10 @@ FUSED_BPTT_BI = os.environ.get("SB_NO_FUSED_BPTT_BI", "0") != "1"
 
 def can_fuse_stream_bi(u, hs):
     """bidirectional passes: fused form with fp32 hs, or (C == 32, partial-Linear forward) fp16 hs (see lstm_bwd_fused_bi)"""
-    if _wide():
-        return (FUSED_BPTT and FUSED_BPTT_BI and LSTM_MMA == 1 and u is not None and u.dtype == torch.float32
-                and hs.dtype == torch.float32 and u.shape[-1] in (16, 32))
+    if _wide():               # u as (hi, lo) pairs; hs as pairs (C = 32, Linear applied in the forward kernel) or fp32 (C = 16)
+        return (FUSED_BPTT and FUSED_BPTT_BI and LSTM_MMA == 1 and u is not None and u.dtype == torch.float16
+                and ((u.shape[-1] == 64 and hs.dtype == torch.float16 and hs.shape[-1] == 4 * H)
+                     or (u.shape[-1] == 32 and hs.dtype == torch.float32)))
     return (FUSED_BPTT and FUSED_BPTT_BI and DGATES_FP16 and _compact() and LSTM_MMA in (1, 2) and u is not None
             and u.dtype == torch.float16 and u.shape[-1] in (16, 32)
             and (hs.dtype == torch.float32 or (hs.dtype == torch.float16 and u.shape[-1] == 32)))
@@ -715,7 +723,7 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     lib = L.load()
     rec, cprev = gates
     dev = u.device
-    Cc = u.shape[-1]
+    Cc = w_ih_list[0].shape[1]
     assert can_fuse_stream_bi(u, hs) and cprev is not None and len(w_hh_list) == 2
     if gmax is None:
         gmax = absmax_or_hint(dy if dy is not None else dhs)
@@ -747,14 +755,14 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
         assert dy is not None and lin_targets[0].shape == (Cc, 2 * H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
     a.u, a.hs, a.C = _ph(u), _ph(hs), Cc
-    a.hs_f16 = int(hs.dtype == torch.float16)
-    assert not a.hs_f16 or (dy is not None and Cc == 32)
+    a.hs_f16 = int(hs.dtype == torch.float16 and not a.wide)
+    assert not (a.hs_f16 or (a.wide and hs.dtype == torch.float16)) or (dy is not None and Cc == 32)
     a.w_ih, a.w_ih1 = _p(w_ih_list[0]), _p(w_ih_list[1])
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
     a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
-    by = geom.P * (2 * ((1280.0 if a.wide else 640.0) if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
-                   + 2.0 * H * hs.element_size() + u.element_size() * Cc + 8.0 * Cc)
+    by = (geom.P * (2 * ((1280.0 if a.wide else 640.0) if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
+                    + 8.0 * Cc) + hs.numel() * hs.element_size() + u.numel() * u.element_size())
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)" + (" [wide]" if a.wide else ""), fl,

@@ -51,8 +51,14 @@ def test_lstm_fwd_intra_bidirectional(torch_gpu, C):
     hs, _, gates, u = ops.lstm_fwd(d(x).view(-1, C), d(g), d(b), dirs, ops.Geom.intra(nseq, S), save=True)
     assert rel_l2(hs.cpu().view(nseq, S, 128).numpy(), ref.detach().numpy()) < 5e-6
     uref = torch.nn.functional.layer_norm(x, (C,), g, b, 1e-5)
-    # u is a backward-only side output: fp16 on the default training path (sb_lstm_fwd_args.aux_f16)
-    assert rel_l2(u.float().cpu().view(nseq, S, C).numpy(), uref.numpy()) < (5e-4 if u.dtype == torch.float16 else 2e-6)
+    # u is a backward-only side output: fp16 (hi, lo) term pairs in the wide mode (kernel-private layout: [P][C/2][hi0, hi1,
+    # lo0, lo1] resp. [P][C][hi, lo]), a single fp16 term in the compact mode (sb_lstm_fwd_args.aux_f16)
+    if ops.BPTT == "wide":
+        v = u.float().cpu().view(nseq * S, 16, -1)
+        uv = (v[..., :v.shape[-1] // 2] + v[..., v.shape[-1] // 2:]).reshape(nseq, S, C)
+        assert rel_l2(uv.numpy(), uref.numpy()) < 2e-6
+    else:
+        assert rel_l2(u.float().cpu().view(nseq, S, C).numpy(), uref.numpy()) < (5e-4 if u.dtype == torch.float16 else 2e-6)
     assert gates[0] is not None          # opaque BPTT records (blocked per tile; checked through the backward tests)
 
 
@@ -943,7 +949,7 @@ def test_wide_fused_bptt_single_direction_matches_float64_autograd(torch_gpu, C_
     monkeypatch.setattr(ops, "SCHED_OVERRIDE", hook)
     y = torch.empty(geom.P, C_, device="cuda")
     hs, _, gates, u = ops.lstm_fwd(x, g, b, [(wi, wh, bi, bh)], geom, save=True, lin=(lin_w, lin_b, y))
-    assert gates[0].dtype == torch.float32 and u.dtype == torch.float32 and hs.dtype == torch.float32
+    assert gates[0].dtype == torch.float32 and u.dtype == torch.float16 and hs.dtype == torch.float16   # (hi, lo) pairs
     assert ops.can_fuse_stream(u, hs)
     tg = [torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
           torch.zeros(256, device="cuda")]
@@ -998,9 +1004,11 @@ def test_wide_fused_bptt_bidirectional_matches_float64_autograd(torch_gpu, C_, f
     mk = lambda: (torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2,
                   torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)
     dirs = [mk(), mk()]
-    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True)
+    lin_w, lin_b = torch.randn(C_, 128, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    # the dy form goes with the forward's partial-Linear mode (hs then travels as fp16 (hi, lo) pairs)
+    part = torch.empty(geom.P, 2, C_, device="cuda") if fuse_lin else None
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, part) if fuse_lin else None)
     assert gates[0].dtype == torch.float32 and ops.can_fuse_stream_bi(u, hs)
-    lin_w = torch.randn(C_, 128, device="cuda") * 0.2
     scale = 1e-3 * torch.logspace(-3, 0, geom.P, device="cuda")[:, None]
     dy = torch.randn(geom.P, C_, device="cuda") * scale
     dhs = torch.randn(geom.P, 128, device="cuda") * scale
@@ -1024,8 +1032,12 @@ def test_wide_fused_bptt_bidirectional_matches_float64_autograd(torch_gpu, C_, f
             getattr(l, "bias_ih_l0" + sfx).copy_(dirs[d][2].double().cpu())
             getattr(l, "bias_hh_l0" + sfx).copy_(dirs[d][3].double().cpu())
     Hs, _ = l(U)
-    assert rel_l2(hs.cpu().numpy(), Hs.detach().reshape(-1, 128).numpy()) < 2e-6
     LW = lin_w.double().cpu().requires_grad_(True)
+    if fuse_lin:
+        want = Hs.detach().reshape(-1, 128) @ LW.detach().t() + lin_b.double().cpu()
+        assert rel_l2(part.sum(1).cpu().numpy(), want.numpy()) < 2e-6
+    else:
+        assert rel_l2(hs.cpu().numpy(), Hs.detach().reshape(-1, 128).numpy()) < 2e-6
     if fuse_lin:
         ((Hs.reshape(-1, 128) @ LW.t()) * dy.double().cpu()).sum().backward()
     else:
