@@ -457,6 +457,32 @@ int sb_signal_stats(const float* est, const float* gt, const float* mix, int B, 
  * sumsq[0] += sum g^2 (grad-norm for clip_grad_norm_, hl_module:437-441). */
 /* max |x| over n (multiple of 4) floats -> out[0] (device scalar, set by the call) */
 int sb_absmax(const float* x, int64_t n, float* out, void* stream);
+/* ---- fine-tune loss: multi-resolution STFT magnitude L1 + waveform L1 -------------------------------------------
+ * src/losses/MultiResoLoss.py:6-31 = auraloss.freq.MultiResolutionSTFTLoss(perceptual_weighting, w_lin_mag) +
+ * l1_ratio * nn.L1Loss (selected by syn_experiments/finetune_stage.json:34, real_experiments/<x>_finetune.json).  The STFTs
+ * themselves are sb_linear_fwd GEMMs over overlapping rows of the reflect-padded signal (frame t = samples
+ * [t * hop + off, t * hop + off + K) of the padded row, K = window support); these calls are the rest of the chain.
+ *   sb_fir: y[b, n] = sum_k taps[k] x[b, n + k - ntaps/2], zero padded (torch conv1d; auraloss FIRFilter "aw", 101 taps).
+ *     Its input gradient is the same call with the taps reversed.  ntaps odd, <= 257.
+ *   sb_reflect_pad: xp[b, i] = x[b, reflect(i - pad)], i < N + 2 pad (torch.stft center=True, pad_mode="reflect"); the
+ *     rest of the row (ldp >= N + 2 pad floats) is zeroed.
+ *   sb_stft_mag_l1: spectra rows [rows, ld] of interleaved (re, im) pairs, bins k < nbins.  |X| = sqrt(max(re^2 + im^2,
+ *     eps)) (auraloss STFTLoss.stft); *loss (+)= loss_scale * sum | |X| - |Y| | (fixed summation tree);
+ *     dspec_x (nullable) [rows, ld] = gscale * sign(|X| - |Y|) * X / |X| (zero on the clamp, zero in the padding columns).
+ *     partial: sb_stft_mag_l1_grid(rows, ld) floats of scratch.
+ *   sb_frames_fold: backward of framing + reflect padding: dx[b, m] (+)= sum of dframes[b, t, k] over all (t, k) whose
+ *     padded sample t * hop + off + k maps onto m; dframes [B, nframes, ldk], k < K.
+ *   sb_l1_grad: *loss (+)= loss_scale * sum |x - y|, dx (nullable) (+)= gscale * sign(x - y); partial: ceil(n / 256) floats. */
+int sb_fir(const float* x, const float* taps, float* y, int B, int64_t N, int ntaps, void* stream);
+int sb_reflect_pad(const float* x, float* xp, int B, int64_t N, int pad, int64_t ldp, void* stream);
+int sb_stft_mag_l1_grid(int64_t rows, int ld);
+int sb_stft_mag_l1(const float* spec_x, const float* spec_y, int64_t rows, int nbins, int ld, float eps, float gscale,
+                   float* dspec_x, float* partial, float loss_scale, float* loss, int accumulate, void* stream);
+int sb_frames_fold(const float* dframes, float* dx, int B, int64_t N, int nframes, int K, int ldk, int hop, int off,
+                   int pad, int accumulate, void* stream);
+int sb_l1_grad(const float* x, const float* y, int64_t n, float gscale, float* dx, int accumulate, float* partial,
+               float loss_scale, float* loss, int accumulate_loss, void* stream);
+
 int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
 /* Adam step (torch.optim.Adam, no weight decay / amsgrad) over a flat bucket.
  * grad is first scaled by gscale * min(1, clip / (sqrt(sumsq[0]) * gscale + 1e-6))

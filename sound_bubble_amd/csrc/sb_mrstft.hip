@@ -1,0 +1,217 @@
+// Fine-tune loss of the reference (src/losses/MultiResoLoss.py:6-31): auraloss MultiResolutionSTFTLoss with
+// perceptual (A-) weighting and the linear-magnitude L1 term, plus l1_ratio * L1(est, gt).
+//
+// The STFTs are GEMMs over overlapping rows (sb_linear_fwd: frames of the reflect-padded signal times the windowed DFT
+// basis restricted to the window's support), so what lives here is the streaming rest of the chain:
+//   sb_fir          the 101-tap A-weighting FIR (conv1d, zero padded) -- also its backward (flipped taps)
+//   sb_reflect_pad  torch.stft(center=True, pad_mode="reflect") framing input
+//   sb_stft_mag_l1  |X|, |Y| from interleaved (re, im) spectra, sum |(|X| - |Y|)|, d(loss)/d(spectrum of X)
+//   sb_frames_fold  backward of framing + reflect padding: frame gradients -> signal gradient
+//   sb_l1_grad      sum |x - y| and its gradient
+// All HBM-bound single passes.
+#include "sb_common.h"
+#include "../../include/sound_bubble_hip.h"
+
+namespace {
+
+inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+constexpr int FIR_TILE = 1024;        // outputs per workgroup
+constexpr int FIR_MAX_TAPS = 257;
+
+// y[b, n] = sum_k taps[k] * x[b, n + k - ntaps / 2]   (torch conv1d = cross-correlation, zero padding ntaps / 2)
+__global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, const float* __restrict__ taps,
+                                                  float* __restrict__ y, int64_t N, int ntaps) {
+  __shared__ float xs[FIR_TILE + FIR_MAX_TAPS + 3];
+  __shared__ float ts[FIR_MAX_TAPS];
+  const int b = blockIdx.y, tid = threadIdx.x, half = ntaps / 2;
+  const int64_t n0 = (int64_t)blockIdx.x * FIR_TILE;
+  const float* xb = x + (int64_t)b * N;
+  for (int i = tid; i < FIR_TILE + ntaps - 1; i += 256) {
+    const int64_t n = n0 + i - half;
+    xs[i] = (n >= 0 && n < N) ? xb[n] : 0.f;
+  }
+  for (int i = tid; i < ntaps; i += 256) ts[i] = taps[i];
+  __syncthreads();
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < ntaps; ++k) {
+    const float t = ts[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(t, xs[tid + 256 * r + k], acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t n = n0 + tid + 256 * r;
+    if (n < N) y[(int64_t)b * N + n] = acc[r];
+  }
+}
+
+// xp[b, i] = x[b, refl(i - pad)] for i < N + 2 pad (refl(j) = -j below 0, 2 (N - 1) - j from N on), zero up to ldp
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ xp, int64_t N,
+                                                          int pad, int64_t ldp) {
+  const int b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ldp) return;
+  float v = 0.f;
+  if (i < N + 2 * pad) {
+    int64_t j = i - pad;
+    if (j < 0) j = -j;
+    else if (j >= N) j = 2 * (N - 1) - j;
+    v = x[(int64_t)b * N + j];
+  }
+  xp[(int64_t)b * ldp + i] = v;
+}
+
+// spectra: rows of ld floats, interleaved (re_k, im_k), k < nbins.  One thread per (row, k).
+// partial[blockIdx] = sum over the block of | |X| - |Y| | ; dsx = gscale * sign(|X| - |Y|) * X / |X|  (0 where the
+// squared magnitude sits on the clamp eps, as torch.clamp's gradient; columns k >= nbins are written as zeros)
+__global__ __launch_bounds__(256) void stft_mag_l1_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                          int64_t rows, int nbins, int ld, float eps, float gscale,
+                                                          float* __restrict__ dsx, float* __restrict__ partial) {
+  const int half = ld / 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = rows * half;
+  float d = 0.f;
+  if (idx < total) {
+    const int64_t row = idx / half;
+    const int k = (int)(idx - row * half);
+    const int64_t o = row * ld + 2 * k;
+    float2 g = {0.f, 0.f};
+    if (k < nbins) {
+      const float2 a = *reinterpret_cast<const float2*>(sx + o), c = *reinterpret_cast<const float2*>(sy + o);
+      const float px = a.x * a.x + a.y * a.y, py = c.x * c.x + c.y * c.y;
+      const float mx = sqrtf(fmaxf(px, eps)), my = sqrtf(fmaxf(py, eps));
+      const float e = mx - my;
+      d = fabsf(e);
+      if (px > eps && e != 0.f) {
+        const float s = (e > 0.f ? gscale : -gscale) / mx;
+        g.x = s * a.x;
+        g.y = s * a.y;
+      }
+    }
+    if (dsx) *reinterpret_cast<float2*>(dsx + o) = g;
+  }
+  d = wave_sum(d);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// out[0] (+)= scale * sum partial[0 .. n)  -- one workgroup, fixed summation tree (bit-identical on every replica)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int64_t n, float scale,
+                                                           float* __restrict__ out, int accumulate) {
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)(red[0] * (double)scale);
+}
+
+// dx[b, m] (+)= sum over the padded indices i that map onto m (i = m + pad, the left mirror pad - m, the right mirror
+// pad + 2 (N - 1) - m) of  sum_t dframes[b, t, i - off - t * hop]  (0 <= i - off - t hop < K)
+__global__ __launch_bounds__(256) void frames_fold_kernel(const float* __restrict__ df, float* __restrict__ dx, int64_t N,
+                                                          int nframes, int K, int ldk, int hop, int off, int pad,
+                                                          int accumulate) {
+  const int b = blockIdx.y;
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= N) return;
+  const float* dfb = df + (int64_t)b * nframes * ldk;
+  int64_t src[3] = {m + pad, (m >= 1 && m <= pad) ? pad - m : -1,
+                    (m >= N - 1 - pad && m <= N - 2) ? pad + 2 * (N - 1) - m : -1};
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int64_t i = src[c] - off;                  // position inside the window-support grid
+    if (src[c] < 0 || i < 0) continue;
+    int64_t t1 = i / hop;                            // last frame that can cover i
+    if (t1 > nframes - 1) t1 = nframes - 1;
+    for (int64_t t = t1; t >= 0; --t) {
+      const int64_t k = i - t * hop;
+      if (k >= K) break;
+      acc += dfb[t * ldk + k];
+    }
+  }
+  float* o = dx + (int64_t)b * N + m;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// partial[blockIdx] = sum |x - y| ; dx (+)= gscale * sign(x - y)
+__global__ __launch_bounds__(256) void l1_grad_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t n,
+                                                      float gscale, float* __restrict__ dx, int accumulate,
+                                                      float* __restrict__ partial) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float d = 0.f;
+  if (i < n) {
+    const float e = x[i] - y[i];
+    d = fabsf(e);
+    if (dx) {
+      const float g = e > 0.f ? gscale : (e < 0.f ? -gscale : 0.f);
+      dx[i] = accumulate ? dx[i] + g : g;
+    }
+  }
+  d = wave_sum(d);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+}  // namespace
+
+extern "C" int sb_fir(const float* x, const float* taps, float* y, int B, int64_t N, int ntaps, void* stream) {
+  if (!x || !taps || !y || B <= 0 || N <= 0 || ntaps < 1 || ntaps > FIR_MAX_TAPS || !(ntaps & 1)) return -1001;
+  hipLaunchKernelGGL(fir_kernel, dim3(nblk(N, FIR_TILE), B), dim3(256), 0, (hipStream_t)stream, x, taps, y, N, ntaps);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_reflect_pad(const float* x, float* xp, int B, int64_t N, int pad, int64_t ldp, void* stream) {
+  if (!x || !xp || B <= 0 || pad < 0 || N <= pad || ldp < N + 2 * pad) return -1001;
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(nblk(ldp), B), dim3(256), 0, (hipStream_t)stream, x, xp, N, pad, ldp);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_stft_mag_l1_grid(int64_t rows, int ld) { return (int)nblk(rows * (ld / 2)); }
+
+extern "C" int sb_stft_mag_l1(const float* spec_x, const float* spec_y, int64_t rows, int nbins, int ld, float eps,
+                              float gscale, float* dspec_x, float* partial, float loss_scale, float* loss,
+                              int accumulate, void* stream) {
+  if (!spec_x || !spec_y || !partial || !loss || rows <= 0 || nbins <= 0 || ld < 2 * nbins || (ld & 1)) return -1001;
+  const int64_t blocks = nblk(rows * (ld / 2));
+  if (blocks >= (1ll << 31)) return -1002;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(stft_mag_l1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, spec_x, spec_y, rows, nbins, ld, eps,
+                     gscale, dspec_x, partial);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, blocks, loss_scale, loss, accumulate);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_frames_fold(const float* dframes, float* dx, int B, int64_t N, int nframes, int K, int ldk, int hop,
+                              int off, int pad, int accumulate, void* stream) {
+  if (!dframes || !dx || B <= 0 || N <= pad || nframes <= 0 || K <= 0 || ldk < K || hop <= 0 || off < 0 || pad < 0)
+    return -1001;
+  hipLaunchKernelGGL(frames_fold_kernel, dim3(nblk(N), B), dim3(256), 0, (hipStream_t)stream, dframes, dx, N, nframes, K,
+                     ldk, hop, off, pad, accumulate);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_l1_grad(const float* x, const float* y, int64_t n, float gscale, float* dx, int accumulate,
+                          float* partial, float loss_scale, float* loss, int accumulate_loss, void* stream) {
+  if (!x || !y || !partial || !loss || n <= 0) return -1001;
+  const int64_t blocks = nblk(n);
+  if (blocks >= (1ll << 31)) return -1002;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, n, gscale, dx, accumulate, partial);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, blocks, loss_scale, loss, accumulate_loss);
+  SB_CHECK_LAUNCH();
+  return 0;
+}

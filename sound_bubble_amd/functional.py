@@ -787,3 +787,58 @@ class SnrlpLossFn(torch.autograd.Function):
     def backward(ctx, gout, _glv):
         (dest,) = ctx.saved_tensors
         return (dest * gout).view(ctx.shape), None, None
+
+
+class MultiResoFuseLossFn(torch.autograd.Function):
+    """auraloss MultiResolutionSTFTLoss (perceptual weighting, linear-magnitude L1) + l1_ratio * L1(est, gt)
+    -- src/losses/MultiResoLoss.py:6-31.  cfg: the MultiResoFuseLoss module (sound_bubble_amd.losses), which holds the
+    A-weighting taps and, per resolution, the windowed DFT basis restricted to the window's support as GEMM weights
+    (w [Npad, K] interleaved (re, im) rows and its transpose).  The STFTs run as sb_linear_fwd GEMMs over overlapping rows
+    of the reflect-padded signals; the gradient w.r.t. est is formed in the forward pass (as SnrlpLossFn does) and scaled
+    by the incoming gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, est, gt, cfg):
+        if est.shape != gt.shape:
+            raise ValueError(f"MultiResoFuseLoss: estimate {tuple(est.shape)} and target {tuple(gt.shape)} differ in shape")
+        shape = est.shape
+        T = shape[-1]
+        e = est.reshape(-1, T).contiguous().float()
+        g = gt.reshape(-1, T).contiguous().float()
+        R = e.shape[0]
+        dev = e.device
+        want_grad = ctx.needs_input_grad[0]
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        both = torch.cat([e, g], 0)                                   # [2R, T]: one set of launches for both signals
+        xw = ops.fir(both, cfg.taps) if cfg.taps is not None else both
+        dxw = torch.empty(R, T, device=dev, dtype=torch.float32) if want_grad else None
+        nres = len(cfg.res)
+        for i, r in enumerate(cfg.res):
+            pad, K, Npad, nbins, hop, off = r["pad"], r["K"], r["Npad"], r["nbins"], r["hop"], r["off"]
+            nfr = 1 + T // hop
+            ldp = T + 2 * pad + 32
+            xp = ops.reflect_pad(xw, pad, ldp)
+            spec = torch.empty(2 * R * nfr, Npad, device=dev, dtype=torch.float32)
+            ops.linear(xp, r["w"], None, spec, (2 * R, nfr, 1), (ldp, hop, 0), (nfr * Npad, Npad, 0), K, Npad, in_off=off)
+            cnt = float(R * nfr * nbins)
+            dsx = ops.stft_mag_l1(spec[: R * nfr], spec[R * nfr:], R * nfr, nbins, Npad, cfg.eps,
+                                  cfg.w_lin_mag / (nres * cnt), loss, cfg.w_lin_mag / (nres * cnt), want_grad)
+            if want_grad:
+                dfr = torch.empty(R * nfr, K, device=dev, dtype=torch.float32)
+                gP, s_in = dense(R * nfr, Npad)
+                _, s_out = dense(R * nfr, K)
+                ops.linear(dsx, r["wT"], None, dfr, gP, s_in, s_out, Npad, K)
+                ops.frames_fold(dfr, dxw, nfr, K, K, hop, off, pad, accumulate=i > 0)
+        dest = None
+        if want_grad:
+            dest = ops.fir(dxw, cfg.taps_rev) if cfg.taps is not None else dxw
+        if cfg.l1_ratio > 0:
+            ops.l1_grad(e, g, cfg.l1_ratio / e.numel(), dest, True, loss, cfg.l1_ratio / e.numel())
+        ctx.save_for_backward(dest)
+        ctx.shape = shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dest,) = ctx.saved_tensors
+        return (dest * gout).view(ctx.shape), None, None

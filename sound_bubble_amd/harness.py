@@ -26,6 +26,7 @@ ALIASES = {
     "src.models.tfgridnet_realtime_clean_dis_embd3.net.Net": "sound_bubble_amd.net.NetDisEmbd3",
     "src.models.tfgridnet_realtime_clean_optim.net.Net": "sound_bubble_amd.net.NetOptim",
     "src.losses.SNRLP.SNRLPLoss": "sound_bubble_amd.losses.SNRLPLoss",
+    "src.losses.MultiResoLoss.MultiResoFuseLoss": "sound_bubble_amd.losses.MultiResoFuseLoss",
     "src.hl_modules.distance_based_hl_module.PLModule": "sound_bubble_amd.harness.PLModule",
 }
 

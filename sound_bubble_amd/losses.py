@@ -1,7 +1,10 @@
 """Loss modules with the reference's constructor surface (JSON: "loss": "src.losses.SNRLP.SNRLPLoss")."""
 import torch.nn as nn
 
-from .functional import SnrlpLossFn
+import numpy as np
+import torch
+
+from .functional import MultiResoFuseLossFn, SnrlpLossFn
 
 
 class SNRLPLoss(nn.Module):
@@ -20,3 +23,74 @@ class SNRLPLoss(nn.Module):
 
     def forward(self, est, gt, **kwargs):
         return self.mean_loss(est, gt)[1]
+
+
+def _aweight_fir_taps(fs, ntaps=101):
+    """auraloss.perceptual.FIRFilter(filter_type="aw"): the analog A-weighting filter (IEC/CD 1672) -> bilinear transform ->
+    magnitude response on 512 points -> 101-tap least-squares FIR.  Third-party algorithm restated (auraloss is not in the
+    reference tree); scipy.signal does the filter design, as it does inside auraloss."""
+    import scipy.signal
+    f1, f2, f3, f4, a1000 = 20.598997, 107.65265, 737.86223, 12194.217, 1.9997
+    nums = [(2 * np.pi * f4) ** 2 * (10 ** (a1000 / 20)), 0, 0, 0, 0]
+    dens = np.polymul([1, 4 * np.pi * f4, (2 * np.pi * f4) ** 2], [1, 4 * np.pi * f1, (2 * np.pi * f1) ** 2])
+    dens = np.polymul(np.polymul(dens, [1, 2 * np.pi * f3]), [1, 2 * np.pi * f2])
+    b, a = scipy.signal.bilinear(nums, dens, fs=fs)
+    w_iir, h_iir = scipy.signal.freqz(b, a, worN=512, fs=fs)
+    return scipy.signal.firls(ntaps, w_iir, abs(h_iir), fs=fs).astype("float32")
+
+
+class MultiResoFuseLoss(nn.Module):
+    """src/losses/MultiResoLoss.py:6-31: auraloss.freq.MultiResolutionSTFTLoss(**kwargs)(est, gt) + l1_ratio * L1(est, gt).
+    JSON: "loss": "src.losses.MultiResoLoss.MultiResoFuseLoss" with loss_params {l1_ratio, sample_rate, perceptual_weighting,
+    w_sc, w_log_mag, w_lin_mag} (syn_experiments/finetune_stage.json:34-41, real_experiments/*_finetune.json).
+    Built: the linear-magnitude term (w_lin_mag) with optional perceptual weighting -- what every shipped fine-tune JSON
+    selects (w_sc = w_log_mag = 0); the other auraloss terms raise.  forward(est, gt) -> scalar, as the reference's."""
+
+    def __init__(self, l1_ratio=0, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240),
+                 window="hann_window", w_sc=1.0, w_log_mag=1.0, w_lin_mag=0.0, w_phs=0.0, sample_rate=None, scale=None,
+                 n_bins=None, perceptual_weighting=False, scale_invariance=False, eps=1e-8, **kwargs):
+        super().__init__()
+        if w_sc or w_log_mag or w_phs or scale is not None or scale_invariance or window != "hann_window":
+            raise NotImplementedError("MultiResoFuseLoss: only the linear-magnitude term with a hann window is built "
+                                      "(w_sc = w_log_mag = w_phs = 0, scale = None: every shipped fine-tune config)")
+        if not (len(fft_sizes) == len(hop_sizes) == len(win_lengths)):
+            raise ValueError("fft_sizes, hop_sizes and win_lengths must have the same length")
+        if perceptual_weighting and sample_rate is None:
+            raise ValueError("perceptual_weighting needs sample_rate")
+        self.l1_ratio, self.w_lin_mag, self.eps = float(l1_ratio), float(w_lin_mag), float(eps)
+        if perceptual_weighting:
+            taps = torch.from_numpy(_aweight_fir_taps(sample_rate))
+            self.register_buffer("taps", taps, persistent=False)
+            self.register_buffer("taps_rev", taps.flip(0).contiguous(), persistent=False)
+        else:
+            self.taps = self.taps_rev = None
+        self.res = []
+        for i, (n_fft, hop, wl) in enumerate(zip(fft_sizes, hop_sizes, win_lengths)):
+            nbins = n_fft // 2 + 1
+            K = (wl + 15) // 16 * 16                      # window support, padded (zero weights) to the GEMM's K granule
+            Npad = (2 * nbins + 15) // 16 * 16
+            off = (n_fft - wl) // 2                       # torch.stft centres the window in the n_fft frame
+            n = np.arange(K, dtype=np.float64)
+            win = np.where(n < wl, 0.5 - 0.5 * np.cos(2 * np.pi * n / wl), 0.0)          # torch.hann_window (periodic)
+            ang = 2 * np.pi * np.outer(np.arange(nbins), n + off) / n_fft
+            w = np.zeros((Npad, K), np.float64)
+            w[0:2 * nbins:2] = win * np.cos(ang)
+            w[1:2 * nbins:2] = -win * np.sin(ang)
+            self.register_buffer(f"w{i}", torch.from_numpy(w.astype(np.float32)), persistent=False)
+            self.register_buffer(f"wT{i}", torch.from_numpy(np.ascontiguousarray(w.T).astype(np.float32)), persistent=False)
+            self.res.append(dict(pad=n_fft // 2, K=K, Npad=Npad, nbins=nbins, hop=int(hop), off=off, i=i))
+
+    def _cfg(self, dev):
+        if self.w0.device != dev:
+            self.to(dev)
+        for r in self.res:
+            r["w"], r["wT"] = getattr(self, f"w{r['i']}"), getattr(self, f"wT{r['i']}")
+        return self
+
+    def mean_loss(self, est, gt):
+        """(differentiable scalar, per-sample view of it) -- the harness protocol of SNRLPLoss.mean_loss"""
+        loss = MultiResoFuseLossFn.apply(est, gt, self._cfg(est.device))
+        return loss, loss.detach().expand(est.shape[0])
+
+    def forward(self, est, gt, **kwargs):
+        return self.mean_loss(est, gt)[0]

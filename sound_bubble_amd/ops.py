@@ -879,8 +879,11 @@ def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None,
     assert w.shape == (N, K) and w.is_contiguous()
     partials = None
     n0 = 0
+    # the kernel stages its [nc, K] weight slice in LDS (160 KB): long-K layers (the loss STFTs) get narrower slices
+    cap = max(16, min(128, (160 * 1024 // (4 * (K + 4))) // 16 * 16))
+    cap = max(c for c in (16, 32, 48, 64, 80, 96, 128) if c <= cap)
     while n0 < N:
-        nc = min(128, N - n0)
+        nc = min(cap, N - n0)
         if nc not in (16, 32, 48, 64, 80, 96, 128):       # NT in {1,2,3,4,5,6,8}
             nc = 96 if nc > 96 else 64
         a = L.LinearArgs()
@@ -1093,3 +1096,40 @@ def sumsq(g, out):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gscale=1.0, clip=0.0, sumsq_buf=None):
     L.check(L.load().sb_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step),
                                   float(gscale), float(clip), _p(sumsq_buf), _stream()), "sb_adam_step")
+
+
+# ---- fine-tune loss (include/sound_bubble_hip.h: multi-resolution STFT magnitude L1 + waveform L1) ----
+def fir(x, taps):
+    """y[b, n] = sum_k taps[k] x[b, n + k - ntaps // 2] (zero padded); x [B, N]"""
+    y = torch.empty_like(x)
+    L.check(L.load().sb_fir(_p(x), _p(taps), _p(y), x.shape[0], x.shape[1], taps.numel(), _stream()), "sb_fir")
+    return y
+
+
+def reflect_pad(x, pad, ldp):
+    xp = torch.empty(x.shape[0], ldp, device=x.device, dtype=torch.float32)
+    L.check(L.load().sb_reflect_pad(_p(x), _p(xp), x.shape[0], x.shape[1], pad, ldp, _stream()), "sb_reflect_pad")
+    return xp
+
+
+def stft_mag_l1(spec_x, spec_y, rows, nbins, ld, eps, gscale, loss, loss_scale, want_grad):
+    """loss[0] += loss_scale * sum | |X| - |Y| |; -> d(loss)/d spec_x * (gscale / loss_scale) or None"""
+    lib = L.load()
+    dsx = torch.empty(rows, ld, device=spec_x.device, dtype=torch.float32) if want_grad else None
+    part = torch.empty(lib.sb_stft_mag_l1_grid(rows, ld), device=spec_x.device, dtype=torch.float32)
+    L.check(lib.sb_stft_mag_l1(_p(spec_x), _p(spec_y), rows, nbins, ld, eps, gscale, _p(dsx), _p(part), loss_scale, _p(loss),
+                               1, _stream()), "sb_stft_mag_l1")
+    return dsx
+
+
+def frames_fold(dframes, dx, nframes, K, ldk, hop, off, pad, accumulate):
+    B_, N = dx.shape
+    L.check(L.load().sb_frames_fold(_p(dframes), _p(dx), B_, N, nframes, K, ldk, hop, off, pad, 1 if accumulate else 0,
+                                    _stream()), "sb_frames_fold")
+
+
+def l1_grad(x, y, gscale, dx, accumulate, loss, loss_scale):
+    n = x.numel()
+    part = torch.empty((n + 255) // 256, device=x.device, dtype=torch.float32)
+    L.check(L.load().sb_l1_grad(_p(x), _p(y), n, gscale, _p(dx), 1 if accumulate else 0, _p(part), loss_scale, _p(loss), 1,
+                                _stream()), "sb_l1_grad")
