@@ -11,13 +11,17 @@ Launch: `python bench.py --gpus 1` or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
  bench.py --gpus N --steps K --warmup W`.
 
-At N = 1 the default run first prints the secondary lines (one JSON object each, all driver-observable):
-streaming chunk loop (configs[4], both model sizes), forward-only utt/s (both), the small config's train step
-(configs[1], B = 32) -- then the headline.  `--workload small|big|big-attn` prints that single train line only;
-`--headline-only` skips the secondary lines.  Every train line carries `roofline` (the kernel with the largest total
-time of the timed region, HIP events on the launch stream, per-kernel table alongside), `exact_bptt` (the same step with
-SB_EXACT_BPTT=1 arithmetic: fp32 BPTT records and dgates) and, at N = 1, `cpu_baseline` (the oracle -- a CPU port of
-the reference's algorithm -- timed on the host cores on a bounded sample).
+At N = 1 the default run first measures the secondary numbers -- streaming chunk loop (configs[4], both model sizes),
+forward-only utt/s (both), the small config's train step (configs[1], B = 32) -- printing one JSON line each, then the
+headline, whose `secondary` object carries all of them again (so the LAST line alone holds every number of the run).
+`--workload small|big|big-attn` prints that single train line only; `--headline-only` skips the secondary measurements.
+
+The timed region is event-free; the per-kernel table behind `roofline` (the recurrent kernel with the largest total time,
+HIP events on the launch stream) comes from a separate, untimed pass of the same step.  Every train line names its
+BPTT-state precision (`bptt_mode`; default "wide": fp32 records, two-term gradient products = the reference's own
+arithmetic) and carries the sibling mode's number (`compact_bptt`: fp16 BPTT state, opt-in) with its own roofline, and, at
+N = 1, `cpu_baseline` (the oracle -- a CPU port of the reference's algorithm -- on the host cores: train B = 1 / 4, eval
+forward B = 1 / 4, bounded).
 """
 import argparse
 import json
@@ -66,7 +70,7 @@ def fwd_bytes_per_utt(p, T=625, F=145, M=6):
     return 4 * (M * (N_SAMPLES + 96) + p["D"] * T * F * (2 + 4 * p["B"]) + N_SAMPLES)
 
 
-def synth_batch(torch, B, seed, device, with_dis):
+def synth_batch(torch, B, seed, device, with_dis, cycle_radii=False):
     g = torch.Generator().manual_seed(seed)
     base = 0.1 * torch.randn(B, 1, N_SAMPLES + 8, generator=g)
     mix = torch.cat([base[..., 4 - min(m, 4): 4 - min(m, 4) + N_SAMPLES] for m in range(6)], 1)
@@ -75,8 +79,8 @@ def synth_batch(torch, B, seed, device, with_dis):
     tgt[7::8] = 0.0                              # every 8th sample: silent target (negative branch)
     inputs = {"mixture": mix.to(device)}
     if with_dis:
-        dis = torch.zeros(B, 3)
-        dis[torch.arange(B), torch.arange(B) % 3] = 1.0
+        dis = torch.zeros(B, 3)                  # configs[2] all [0, 1, 0] (1.5 m); configs[3] cycles the radii
+        dis[torch.arange(B), (torch.arange(B) % 3) if cycle_radii else 1] = 1.0
         inputs["dis_embed"] = dis.to(device)
     return inputs, tgt.to(device)
 
@@ -98,8 +102,20 @@ def host_cores():
     return n
 
 
-def cpu_baseline(torch, wl, budget_s=20.0):
-    """Oracle (CPU port of the reference algorithm, oracle/tfgridnet_oracle.py) train step on host cores."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(torch, wl, budget_s=36.0):
+    """Oracle (CPU port of the reference algorithm, oracle/tfgridnet_oracle.py -- the reference's own .py cannot travel to the
+    GPU box) on the host cores, the four legs of SURVEY.md 8(d): train step at B = 1 (the metric; `value`) and B = 4, eval
+    forward at B = 1 and B = 4, each one warm-up + a bounded number of timed passes within the time budget."""
     from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
     cls, params, _, negw, clip, lr = WORKLOADS[wl]
     cores = host_cores()
@@ -107,27 +123,49 @@ def cpu_baseline(torch, wl, budget_s=20.0):
     torch.manual_seed(0)
     m = OracleNet("optim" if cls == "NetOptim" else "dis_embd3", **params).train()
     opt = torch.optim.Adam(m.parameters(), lr=lr)
-    B = 1
-    inputs, tgt = synth_batch(torch, B, 1234, "cpu", cls != "NetOptim")
+    t_start = time.time()
 
-    def step():
-        opt.zero_grad()
-        est = m(dict(inputs))["output"]
-        snrlp_loss(est, tgt, negw).mean().backward()
-        if clip:
-            torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
-        opt.step()
+    def timed(fn, max_n, share):
+        fn()                                     # warm-up
+        t0, n = time.time(), 0
+        while n < max_n:
+            fn()
+            n += 1
+            if time.time() - t_start > budget_s * share:
+                break
+        return (time.time() - t0) / n, n
 
-    step()                                       # warm-up
-    t0, n = time.time(), 0
-    while True:
-        step()
-        n += 1
-        if time.time() - t0 > budget_s or n >= 8:
-            break
-    dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps of batch {B} ({wl} config, 5 s clips), oracle CPU port, after 1 warm-up"}
+    legs = {}
+    for name, B, train, max_n, share in (("train_b1", 1, True, 3, 0.30), ("eval_fwd_b1", 1, False, 3, 0.42),
+                                         ("eval_fwd_b4", 4, False, 2, 0.62), ("train_b4", 4, True, 1, 1.0)):
+        inputs, tgt = synth_batch(torch, B, 1234, "cpu", cls != "NetOptim")
+        if time.time() - t_start > budget_s * 0.9 and legs:
+            legs[name] = {"dropped": "time budget"}
+            continue
+        if train:
+            m.train()
+
+            def fn():
+                opt.zero_grad()
+                est = m(dict(inputs))["output"]
+                snrlp_loss(est, tgt, negw).mean().backward()
+                if clip:
+                    torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+                opt.step()
+        else:
+            m.eval()
+
+            def fn():
+                with torch.no_grad():
+                    m(dict(inputs))["output"]
+        dt, n = timed(fn, max_n, share)
+        legs[name] = {"utt_s": B / dt, "s_per_pass": dt, "passes": n, "batch": B}
+    main = legs["train_b1"]
+    return {"value": main["utt_s"], "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model_string(),
+            "sample": f"{main['passes']} train steps of batch 1 ({wl} config, 5 s clips), oracle CPU port, after 1 warm-up; "
+                      f"other legs (eval forward B = 1 / 4, train B = 4) under `legs`, {time.time() - t_start:.0f} s in all",
+            "legs": legs}
 
 
 def vendor_gpu_baseline(torch, wl, B, dev, steps=3):
@@ -190,7 +228,7 @@ def stream_bench(torch, sb, args, wl, cls, params, dev):
     dt = time.perf_counter() - t0
     lat = np.array(lat) * 1e3
     fpu = fwd_flops_per_utt(params) / 625.0
-    print(json.dumps({
+    obj = {
         "metric": "streaming chunks/sec (8 ms hop, 6 mics, B=1)", "value": 625 / dt, "unit": "chunks/s", "n_gpus": 1,
         "steps": 625, "warmup": 20, "ms_per_step": dt / 625 * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE_FWD, "data": "synthetic",
@@ -200,7 +238,9 @@ def stream_bench(torch, sb, args, wl, cls, params, dev):
                        "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
         "realtime_factor": 8.0 / float(np.percentile(lat, 50)),
         "reference_claim": "6.36 ms per 8 ms chunk on an embedded CPU (README.md:9)",
-        "chunk_mflop": fpu / 1e6}), flush=True)
+        "chunk_mflop": fpu / 1e6}
+    print(json.dumps(obj), flush=True)
+    return obj
 
 
 DTYPE_BY_MODE = {
@@ -219,8 +259,8 @@ DTYPE_FWD = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo
 # "<kernel name> grid=<threads>").  The two forward recurrences share one instantiation since the intra-frame pass applies
 # its Linear in the kernel too: they are told apart by the grid (bidirectional = twice the workgroups of more tiles).
 PMC_PATTERNS = [
-    ("intra-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, false, \d+, false, true", None),
-    ("inter-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, (16|32), \w+, false", None),
+    ("intra-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, false, \d+, false, true", None),
+    ("inter-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, \w+, (16|32), \w+, false", None),
     ("recurrence only", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, 0, false, false", None),
     ("lstm_bwd_stream", r"lstm_bwd_stream_f16_kernel", None),
     ("intra-frame (bidirectional)", r"lstm_fwd_bf_kernel<", "max-grid"),
@@ -228,12 +268,12 @@ PMC_PATTERNS = [
 ]
 
 
-def pmc_traffic(workload, label):
+def pmc_traffic(workload, label, mode="wide"):
     """HBM bytes per launch of the kernel behind `label` from the newest committed rocprofv3 --pmc summary
     (profiles/r*_pmc_traffic_<workload>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}{'' if mode == 'compact' else '_' + mode}.json")))
     ent = next(((p, sel) for key, p, sel in PMC_PATTERNS if key in label), None)
     if not files or ent is None:
         return None, None
@@ -265,7 +305,7 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
     model = getattr(sb, cls)(**params).to(dev).train()
     bucket = FlatBucket(model)
     optim = FusedAdam(bucket, lr=lr)
-    inputs, target = synth_batch(torch, B, 1234 + rank, dev, cls != "NetOptim")
+    inputs, target = synth_batch(torch, B, 1234 + rank, dev, cls != "NetOptim", cycle_radii=world > 1)
 
     def step():
         if forward_only:
@@ -281,16 +321,22 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
     try:
         for _ in range(warmup):
             step()
-        ops.PROFILE = {} if profile else None                # HIP-event pairs around every recurrent-kernel launch
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps):                               # the timed region carries no profiling events
             step()
         barrier()
         dt = time.perf_counter() - t0
-        prof = ops.PROFILE or {}
-        ops.PROFILE = None
         ops.check_sched_status()                             # a time-segmented launch that bailed out voids the run
+        prof, prof_steps = {}, 0
+        if profile:                                          # separate, untimed pass: HIP-event pairs (on the launch stream)
+            prof_steps = max(2, min(4, steps))               # around every recurrent-kernel launch -> per-kernel table
+            ops.PROFILE = {}
+            for _ in range(prof_steps):
+                step()
+            barrier()
+            prof = ops.PROFILE or {}
+            ops.PROFILE = None
     finally:
         ops.PROFILE = None
         ops.BPTT = old_mode
@@ -303,12 +349,14 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
         ms = sum(e[0].elapsed_time(e[1]) for e in evs)
         table[label] = dict(launches=len(evs), total_ms=ms, flops=sum(e[2] for e in evs),
                             compulsory_bytes=sum(e[3] for e in evs), design_bytes=sum(e[4] for e in evs))
+    for t in table.values():
+        t["steps"] = prof_steps
     del model, bucket, optim, inputs, target
     torch.cuda.empty_cache()
     return dt / steps, table, B, params, cls
 
 
-def roofline_of(table, wl, step_s, steps, forward_only, utt_s_per_gpu, params):
+def roofline_of(table, wl, step_s, steps, forward_only, utt_s_per_gpu, params, mode="wide"):
     """`roofline` object: the recurrent kernel with the largest total time in the timed region."""
     fpu, bpu = fwd_flops_per_utt(params), fwd_bytes_per_utt(params)
     work_mult = 1.0 if forward_only else 3.0
@@ -320,10 +368,10 @@ def roofline_of(table, wl, step_s, steps, forward_only, utt_s_per_gpu, params):
     per = {}
     for label, t in table.items():
         n, sec = t["launches"], t["total_ms"] * 1e-3
-        traffic, src = pmc_traffic(wl, label) if not forward_only else (None, None)
+        traffic, src = pmc_traffic(wl, label, mode) if not forward_only else (None, None)
         per[label] = {
-            "launches_per_step": n / steps, "avg_launch_ms": t["total_ms"] / n,
-            "share_of_step": sec / (step_s * steps),
+            "launches_per_step": n / t["steps"], "avg_launch_ms": t["total_ms"] / n,
+            "share_of_step": sec / (step_s * t["steps"]),
             "compulsory_gbs": t["compulsory_bytes"] / sec / 1e9, "frac_compulsory_bytes": t["compulsory_bytes"] / sec / HBM_PEAK,
             "design_gbs": t["design_bytes"] / sec / 1e9, "frac_design_bytes": t["design_bytes"] / sec / HBM_PEAK,
             "traffic_bytes_per_launch": traffic,
@@ -364,7 +412,7 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
     if rank != 0:
         if with_exact and not forward_only:                  # every rank runs the sibling (collectives inside)
             run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, mode=SIBLING[main_mode],
-                         steps=max(3, args.steps // 2), warmup=min(2, args.warmup), profile=False)
+                         steps=max(3, args.steps // 2), warmup=min(2, args.warmup), profile=True)
         return None
     utt_s = world * B / step_s
     out = {
@@ -377,7 +425,7 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
                                + (" (BASELINE configs[2]; per-GPU workload of configs[3])" if wl == "big" else
                                   " (BASELINE configs[1])" if wl == "small" else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-        "roofline": roofline_of(table, wl, step_s, args.steps, forward_only, utt_s / world, params),
+        "roofline": roofline_of(table, wl, step_s, args.steps, forward_only, utt_s / world, params, main_mode),
     }
     if forward_only:
         # north-star target: >= 30 % of the HBM roofline on the forward.  The forward is 292 (big) / 223 (small) FLOP per
@@ -395,12 +443,18 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
                    "state exchange, not the MFMA issue, set the step time (profiles/: SQ_VALU_MFMA_BUSY vs SQ_BUSY)"}
     if with_exact and not forward_only:
         sib = SIBLING[main_mode]
-        es, _, _, _, _ = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, mode=sib,
-                                      steps=max(3, args.steps // 2), warmup=min(2, args.warmup), profile=False)
+        es, etab, _, _, _ = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, mode=sib,
+                                         steps=max(3, args.steps // 2), warmup=min(2, args.warmup), profile=True)
         out["bptt_mode"] = main_mode
+        sroof = roofline_of(etab, wl, es, max(3, args.steps // 2), False, B / es, params, sib)
         out[sib + "_bptt"] = {"value": world * B / es, "unit": "utterances/s", "ms_per_step": es * 1e3,
                               "steps": max(3, args.steps // 2), "dtype": DTYPE_BY_MODE[sib],
-                              "ratio_to_headline": (world * B / es) / utt_s}
+                              "ratio_to_headline": (world * B / es) / utt_s,
+                              "roofline": {k: sroof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                  "avg_launch_ms", "share_of_step", "frac_design_bytes",
+                                                                  "frac_hbm_counter", "frac_compute_issued") if k in sroof},
+                              "kernels": {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
+                                              "share_of_step": v["share_of_step"]} for k, v in sroof.get("kernels", {}).items()}}
     if with_cpu and world == 1:                               # reported baseline: rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(torch, wl)
         out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
@@ -462,16 +516,33 @@ def main():
         emit(train_line(torch, dist, sb, ops, wl if single else "big", args, dev, world, rank, forward_only=True,
                         with_cpu=False))
     else:
+        secondary = None
         if not single and not args.headline_only and world == 1:
-            # secondary lines (driver-observable): streaming, forward-only, the small config's train step
+            # secondary measurements (BASELINE configs[1] and [4], forward-only): each printed as its own JSON line AND folded,
+            # compactly, into the headline's `secondary` object so that the last line alone carries every number of the run
+            secondary = {}
             for w2 in ("small", "big"):
-                stream_bench(torch, sb, args, w2, WORKLOADS[w2][0], WORKLOADS[w2][1], dev)
+                o = stream_bench(torch, sb, args, w2, WORKLOADS[w2][0], WORKLOADS[w2][1], dev)
+                secondary[f"stream_{w2}"] = {"chunks_s": o["value"], "p50_ms": o["latency_ms"]["p50"], "p99_ms": o["latency_ms"]["p99"],
+                                             "realtime_factor": o["realtime_factor"], "config": "BASELINE configs[4], hipGraph chunk loop, B=1"}
             for w2 in ("small", "big"):
-                emit(train_line(torch, dist, sb, ops, w2, args, dev, world, rank, forward_only=True, with_cpu=False))
-            emit(train_line(torch, dist, sb, ops, "small", args, dev, world, rank, with_exact=not args.no_exact,
-                            with_cpu=False))
+                o = train_line(torch, dist, sb, ops, w2, args, dev, world, rank, forward_only=True, with_cpu=False)
+                emit(o)
+                secondary[f"forward_{w2}"] = {"utt_s": o["value"], "ms_per_step": o["ms_per_step"],
+                                              "hbm_frac": o["forward_roofline"]["hbm_frac"],
+                                              "frac_of_fp16x3_ceiling": o["forward_roofline"]["frac_of_fp16x3_ceiling"],
+                                              "batch": o["config"]["batch_per_gpu"]}
+            o = train_line(torch, dist, sb, ops, "small", args, dev, world, rank, with_exact=not args.no_exact, with_cpu=False)
+            emit(o)
+            sib = SIBLING[o.get("bptt_mode", "wide")] + "_bptt"
+            secondary["train_small"] = {"utt_s": o["value"], "ms_per_step": o["ms_per_step"], "batch": o["config"]["batch_per_gpu"],
+                                        "config": "BASELINE configs[1]", "bptt_mode": o.get("bptt_mode"),
+                                        sib: o.get(sib, {}).get("value"),
+                                        "roofline_kernel": o["roofline"].get("kernel"), "roofline_frac": o["roofline"].get("frac")}
         out = train_line(torch, dist, sb, ops, wl, args, dev, world, rank, with_exact=not args.no_exact,
                          with_cpu=not args.no_cpu_baseline)
+        if rank == 0 and secondary is not None:
+            out["secondary"] = secondary
         if rank == 0 and args.vendor_gpu_baseline:
             B = args.batch or WORKLOADS[wl][2]
             out["vendor_gpu_baseline"] = vendor_gpu_baseline(torch, wl, B, dev)

@@ -5,11 +5,15 @@
  * the reference launches for one stage of that path; the reference line each
  * one stands in for is cited.  Conventions:
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the
- *     library never allocates, frees or synchronises; scratch is passed in;
+ *     library never allocates or frees device memory and the data-path calls
+ *     never synchronise; scratch is passed in.  The one piece of process state
+ *     is the side-stream table of the overlapped schedules, managed by the
+ *     explicit sb_overlap_init / _reprobe / _shutdown calls (mutex-guarded);
  *   - fp32, contiguous unless a stride is given (strides are in floats);
  *   - asynchronous on `stream` (a hipStream_t passed as void*);
  *   - returns 0 on success, -(hipError_t) on a launch error, -1000-x on a
- *     bad argument; never throws; re-entrant (no mutable globals).
+ *     bad argument; never throws; thread-safe and, the side-stream table
+ *     aside, stateless.
  * Activations are channels-last [B, T, F, C]; a "position" p is the dense
  * index over that (b, t, f) grid (or (b, t, k) on the down-sampled intra grid).
  */
@@ -348,10 +352,26 @@ int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec, const sb_lstm_stre
                                  void* stream);
 int sb_lstm_overlap_rows(int64_t positions, int nseq);
 /* The overlapped calls need a side stream whose kernels really run at the same time as those of `stream` (the runtime
- * multiplexes streams over a few hardware queues; two streams on one queue serialise).  Returns 1 when the library has
- * found one for `stream` -- probed on first use with a pair of tiny kernels, synchronising `stream` once -- and 0 when the
- * overlapped entry points would return -1009 (use the plain calls).  Not to be called while `stream` is capturing. */
+ * multiplexes streams over a few hardware queues; two streams on one queue serialise).  These four calls are the ONLY
+ * ones in the library that create / destroy HIP objects or synchronise; the data-path entry points above only look the
+ * side stream up (-1009 when there is none: use the plain calls).
+ *   sb_overlap_init(stream, scratch, timings): finds a side stream for (current device, stream) with a TIMED probe -- a
+ *     0.2 ms pair of one-per-CU arithmetic kernels with the fork / join choreography of the real calls must finish in
+ *     < 0.7 of the back-to-back time; up to 8 candidate streams -- and keeps it, with its own fork / join events, until
+ *     sb_overlap_shutdown.  scratch: 4 floats of device memory owned by the caller (the probe kernels' sink); timings
+ *     (nullable, HOST pointer to 2 floats): back-to-back and best pair time in ms.  Synchronises `stream` several times;
+ *     not to be called while it is capturing.  Returns 1 (found) / 0 (none: overlapped calls unavailable on this stream);
+ *     a second call for the same (device, stream) returns the stored verdict.
+ *   sb_overlap_reprobe: re-times the stored pair (two timed launches) and updates the verdict -- a stream that was
+ *     concurrent at start-up can lose that (another process on the GPU, more streams alive); call it now and then (the
+ *     harness does once per epoch) and fall back to the plain calls when it returns 0.
+ *   sb_overlap_available: the stored verdict, no side effects.
+ *   sb_overlap_shutdown: destroys every side stream and event of the process.
+ * The table behind them is mutex-guarded; everything else in the library is stateless. */
+int sb_overlap_init(void* stream, float* scratch, float* timings_ms);
+int sb_overlap_reprobe(void* stream, float* scratch, float* timings_ms);
 int sb_overlap_available(void* stream);
+int sb_overlap_shutdown(void);
 
 /* ---- LayerNorm (+PReLU) backward over C channels ---------------------------
  * g = sum_d du_part[p, d, :];  x = xin[p] (PReLU(xin[p]) with slope *prelu_a when prelu_a != NULL);

@@ -140,6 +140,9 @@ SYMBOLS = {
     "sb_lstm_bwd_inter_overlapped": (_ci, [C.POINTER(LstmBwdArgs), C.POINTER(LstmStreamArgs), _vp, _ci, _vp]),
     "sb_lstm_overlap_rows": (_ci, [i64, _ci]),
     "sb_overlap_available": (_ci, [_vp]),
+    "sb_overlap_init": (_ci, [_vp, c_fp, C.POINTER(C.c_float)]),
+    "sb_overlap_reprobe": (_ci, [_vp, c_fp, C.POINTER(C.c_float)]),
+    "sb_overlap_shutdown": (_ci, []),
     "sb_ln_bwd": (_ci, [C.POINTER(LnBwdArgs), _vp]),
     "sb_ln_bwd_grid": (_ci, [i64]),
     "sb_head_ln": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, c_fp, _vp]),

@@ -10,6 +10,7 @@
 // operand of four tiles at once (4 x 256 B contiguous per wave-instruction instead of 16 x 64 B).
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include "sb_common.h"
 #include "../../include/sound_bubble_hip.h"
 
@@ -984,62 +985,49 @@ __global__ __launch_bounds__(256) void probe_busy_kernel(float* sink, int iters)
   if (x == 123.456f) sink[0] = x + pad[3];       // never true: keeps the chain
 }
 
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; hipStream_t main = nullptr;
-                    bool probed = false; };
-SideStream* side_stream(hipStream_t main_st) {
-  static SideStream tab[64];
+// One entry per (device, caller stream), created by sb_overlap_init and kept until sb_overlap_shutdown: a side stream that
+// passed the probe is never destroyed or re-created behind the caller's back, every entry owns its fork / join events, and
+// the table is guarded by a mutex (the library is called from one thread per process in this product, but the header
+// promises thread safety).  The overlapped entry points only LOOK UP: no allocation, no synchronisation, no probe inside a
+// data-path call.
+struct SideStream { int dev = -1; hipStream_t main = nullptr, s = nullptr; hipEvent_t fork = nullptr, join = nullptr;
+                    bool ok = false; };
+constexpr int kMaxSide = 64;
+SideStream g_side[kMaxSide];
+int g_nside = 0;
+std::mutex g_side_mu;
+
+SideStream* side_lookup_locked(int dev, hipStream_t main_st) {
+  for (int i = 0; i < g_nside; ++i)
+    if (g_side[i].dev == dev && g_side[i].main == main_st) return &g_side[i];
+  return nullptr;
+}
+SideStream* side_stream(hipStream_t main_st) {       // data path: look-up only
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream& t = tab[dev];
-  if (t.probed && t.main == main_st) return t.s ? &t : nullptr;
-  // (re)probe for this caller stream
-  if (t.s) { (void)hipStreamDestroy(t.s); t.s = nullptr; }
-  t.probed = true; t.main = main_st;
-  if (!t.fork && (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess ||
-                  hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess))
-    return nullptr;
-  float* buf = nullptr;
-  if (hipMalloc(&buf, 4 * sizeof(float)) != hipSuccess) return nullptr;
-  int cus = 0;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (cus < 32 || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(buf); return nullptr; }
-  const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 12000;          // ~0.2 ms each
-  auto timed = [&](hipStream_t side, bool a, bool b) -> float {         // ms; < 0 on error
-    if (hipEventRecord(e0, main_st) != hipSuccess) return -1.f;
-    if (side && hipEventRecord(t.fork, main_st) != hipSuccess) return -1.f;
-    if (a) hipLaunchKernelGGL(probe_busy_kernel, dim3(ga), dim3(256), 0, main_st, buf, iters);
-    if (b) {
-      if (side) {
-        if (hipStreamWaitEvent(side, t.fork, 0) != hipSuccess) return -1.f;
-        hipLaunchKernelGGL(probe_busy_kernel, dim3(gb), dim3(256), 0, side, buf, iters);
-        if (hipEventRecord(t.join, side) != hipSuccess || hipStreamWaitEvent(main_st, t.join, 0) != hipSuccess) return -1.f;
-      } else {
-        hipLaunchKernelGGL(probe_busy_kernel, dim3(gb), dim3(256), 0, main_st, buf, iters);
-      }
-    }
-    float ms = -1.f;
-    if (hipEventRecord(e1, main_st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-        hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-      return -1.f;
-    return ms;
-  };
-  (void)timed(nullptr, true, true);                                      // warm-up (code object load)
-  const float solo = timed(nullptr, true, true);                         // both on the caller's stream: one after the other
-  hipStream_t rejected[8];
-  int nrej = 0;
-  for (int c = 0; c < 8 && !t.s && solo > 0.f; ++c) {
-    hipStream_t cand = nullptr;
-    if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
-    (void)timed(cand, true, true);
-    const float pair = timed(cand, true, true);
-    if (getenv("SB_OVERLAP_DEBUG")) fprintf(stderr, "[sb] side-stream probe %d: back to back %.3f ms, pair %.3f ms\n", c, solo, pair);
-    if (pair > 0.f && pair < 0.7f * solo) t.s = cand; else rejected[nrej++] = cand;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream* t = side_lookup_locked(dev, main_st);
+  return (t && t->ok && t->s) ? t : nullptr;
+}
+// the timed pair: `a` on the caller's stream, `b` on `side` (fork / join choreography of the real calls) or, with
+// side == nullptr, behind `a` on the caller's stream.  ms, or < 0 on error.  Synchronises the caller's stream.
+float probe_timed(hipStream_t main_st, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipEvent_t e0, hipEvent_t e1,
+                  float* buf, int ga, int gb, int iters) {
+  if (hipEventRecord(e0, main_st) != hipSuccess) return -1.f;
+  if (side && hipEventRecord(fork, main_st) != hipSuccess) return -1.f;
+  hipLaunchKernelGGL(probe_busy_kernel, dim3(ga), dim3(256), 0, main_st, buf, iters);
+  if (side) {
+    if (hipStreamWaitEvent(side, fork, 0) != hipSuccess) return -1.f;
+    hipLaunchKernelGGL(probe_busy_kernel, dim3(gb), dim3(256), 0, side, buf, iters);
+    if (hipEventRecord(join, side) != hipSuccess || hipStreamWaitEvent(main_st, join, 0) != hipSuccess) return -1.f;
+  } else {
+    hipLaunchKernelGGL(probe_busy_kernel, dim3(gb), dim3(256), 0, main_st, buf, iters);
   }
-  for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(buf);
-  return t.s ? &t : nullptr;
+  float ms = -1.f;
+  if (hipEventRecord(e1, main_st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+      hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+    return -1.f;
+  return ms;
 }
 int device_cus() {
   int dev = 0, n = 0;
@@ -1049,8 +1037,80 @@ int device_cus() {
 }
 }  // namespace
 
-// 1 when kernels on the library's side stream run concurrently with kernels on `stream` (probed once per stream)
+// 1 when sb_overlap_init found (and sb_overlap_reprobe has not since lost) a concurrent side stream for `stream`
 extern "C" int sb_overlap_available(void* stream) { return side_stream((hipStream_t)stream) != nullptr ? 1 : 0; }
+
+extern "C" int sb_overlap_init(void* stream, float* scratch, float* timings_ms) {
+  hipStream_t main_st = (hipStream_t)stream;
+  if (!scratch) return -1001;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1009;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream* t = side_lookup_locked(dev, main_st);
+  if (t) return t->ok ? 1 : 0;                        // probed before: the verdict stands until sb_overlap_reprobe
+  if (g_nside >= kMaxSide) return 0;
+  t = &g_side[g_nside];
+  *t = SideStream{};
+  t->dev = dev; t->main = main_st;
+  ++g_nside;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (cus < 32 || hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->join, hipEventDisableTiming) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+      hipEventCreate(&e1) != hipSuccess)
+    return 0;
+  const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 12000;          // ~0.2 ms each
+  (void)probe_timed(main_st, nullptr, t->fork, t->join, e0, e1, scratch, ga, gb, iters);      // warm-up (code object load)
+  const float solo = probe_timed(main_st, nullptr, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+  float best_pair = -1.f;
+  hipStream_t rejected[8];
+  int nrej = 0;
+  for (int c = 0; c < 8 && !t->s && solo > 0.f; ++c) {
+    hipStream_t cand = nullptr;
+    if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+    (void)probe_timed(main_st, cand, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+    const float pair = probe_timed(main_st, cand, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+    if (best_pair < 0.f || (pair > 0.f && pair < best_pair)) best_pair = pair;
+    if (pair > 0.f && pair < 0.7f * solo) t->s = cand; else rejected[nrej++] = cand;
+  }
+  for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (timings_ms) { timings_ms[0] = solo; timings_ms[1] = best_pair; }
+  t->ok = t->s != nullptr;
+  return t->ok ? 1 : 0;
+}
+
+extern "C" int sb_overlap_reprobe(void* stream, float* scratch, float* timings_ms) {
+  hipStream_t main_st = (hipStream_t)stream;
+  if (!scratch) return -1001;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1009;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream* t = side_lookup_locked(dev, main_st);
+  if (!t || !t->s) return 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1009;
+  const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 12000;
+  const float solo = probe_timed(main_st, nullptr, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+  const float pair = probe_timed(main_st, t->s, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (timings_ms) { timings_ms[0] = solo; timings_ms[1] = pair; }
+  t->ok = solo > 0.f && pair > 0.f && pair < 0.7f * solo;
+  return t->ok ? 1 : 0;
+}
+
+extern "C" int sb_overlap_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  for (int i = 0; i < g_nside; ++i) {
+    if (g_side[i].s) (void)hipStreamDestroy(g_side[i].s);
+    if (g_side[i].fork) (void)hipEventDestroy(g_side[i].fork);
+    if (g_side[i].join) (void)hipEventDestroy(g_side[i].join);
+    g_side[i] = SideStream{};
+  }
+  g_nside = 0;
+  return 0;
+}
 
 extern "C" int sb_lstm_overlap_rows(int64_t positions, int nseq) {
   (void)positions;

@@ -260,7 +260,8 @@ class InterFn(torch.autograd.Function):
                 # the recurrence runs
                 dx = ops.lstm_bwd_inter_overlapped(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0], lin_t,
                                                    (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)))
-                return ret(dx.view(B, T, F, Cc))
+                if dx is not None:             # None: the side stream was lost since the check -- plain order below
+                    return ret(dx.view(B, T, F, Cc))
             dg = ops.lstm_bwd_rec([wh], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
                                   w_lin=lin_w if fuse else None)
             if ops.can_fuse_stream_ln(dg, u, hs):          # ... and the LayerNorm backward + residual in the same pass,

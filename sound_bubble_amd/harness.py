@@ -102,8 +102,21 @@ class PLModule(object):
         """hl_module:115-139.  Reads the reference's own last.pt / best.pt: `optimizer` in torch.optim.Adam.state_dict()
         layout is converted into the flat moment buffers (FusedAdam.load_state_dict), so a resumed run continues with
         the saved moments, step count and learning rate."""
-        state = torch.load(path, map_location=map_location or "cpu", weights_only=False)
-        self.model.load_state_dict(state["model"])            # in-place copy_: bucket views stay valid
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
+            # only rank 0 needs to see the file (node-local run directories): it reads, the bookkeeping travels as one
+            # object, parameters / moments by broadcast_replica below -- called by EVERY rank, whatever its file system holds
+            box = [None]
+            if dist.get_rank() == 0:
+                st0 = torch.load(path, map_location=map_location or "cpu", weights_only=False)
+                box[0] = {k: st0[k] for k in ("scheduler", "current_epoch", "metric_values", "statistics") if k in st0}
+            dist.broadcast_object_list(box, src=0)
+            state = st0 if dist.get_rank() == 0 else box[0]
+        else:
+            state = torch.load(path, map_location=map_location or "cpu", weights_only=False)
+        if "model" in state:
+            self.model.load_state_dict(state["model"])        # in-place copy_: bucket views stay valid
         opt = state.get("optimizer")
         if isinstance(opt, dict):
             self.optimizer.load_state_dict(opt)
@@ -121,6 +134,8 @@ class PLModule(object):
         if "statistics" in state:
             self.statistics = state["statistics"]
         broadcast_replica(self.bucket, self.optimizer)
+        for g in self._lr_carrier.param_groups:               # (ranks > 0 received the lr just now)
+            g["lr"] = self.optimizer.param_groups[0]["lr"]
 
     def get_current_lr(self):
         return self.optimizer.param_groups[0]["lr"]
@@ -163,7 +178,11 @@ class PLModule(object):
     def on_epoch_end(self, best_path, wandb_run=None):
         self.sync_epoch_metrics()
         from . import ops
-        ops.check_sched_status()              # one sync per epoch: did a time-segmented launch bail out?
+        # one sync per epoch: did a time-segmented / overlapped launch bail out?  (verdict shared by all ranks: a lone
+        # raising rank would leave the others hanging in the next all-reduce); and is the side stream still concurrent?
+        ops.check_sched_status_all_ranks()
+        if ops._OVERLAP_OK:
+            ops.overlap_reprobe()
         last = self.get_avg_metric_at_epoch(self.monitor)
         best = all(not (last > self.get_avg_metric_at_epoch(self.monitor, e)) for e in range(len(self.metric_values) - 1))
         if best:

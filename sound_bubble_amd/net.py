@@ -167,17 +167,17 @@ class _NetBase(nn.Module):
             return wf
         wf = WeightForms()
         tg, C, V = self.tfgridnet, self.embed_dim, L.WView.make
-        wf.add("front_w", tg.conv[0].weight, V(self.n_feat * 9, 9, kmod=Fn.ZC, sk_hi=1, kvalid=self.n_feat), C, 9 * Fn.ZC)
-        wf.add("back_w", tg.deconv.weight, V(9, 18, off=8, kmod=C, sk_hi=-1, nvalid=2), 16, 9 * C)
-        wf.add("back_b", tg.deconv.bias, V(1, 0, nvalid=2), 16, 1)
+        wf.add("front_w", lambda: tg.conv[0].weight, V(self.n_feat * 9, 9, kmod=Fn.ZC, sk_hi=1, kvalid=self.n_feat), C, 9 * Fn.ZC)
+        wf.add("back_w", lambda: tg.deconv.weight, V(9, 18, off=8, kmod=C, sk_hi=-1, nvalid=2), 16, 9 * C)
+        wf.add("back_b", lambda: tg.deconv.bias, V(1, 0, nvalid=2), 16, 1)
         if self.conv_lstm:
             d = self.lstm_down
             for i, blk in enumerate(tg.blocks):
-                wf.add(f"wc{i}", blk.conv.weight, V(C * d, d, kmod=C, sk_hi=1), C, d * C)            # [co][j*C + ci]
-                wf.add(f"wd{i}", blk.deconv.weight, V(d, C * d, nmod=C, sn_hi=1), d * C, 2 * self.H)   # [j*C + c][h]
-                wf.add(f"bd{i}", blk.deconv.bias, V(1, 0, nmod=C, sn_hi=0), d * C, 1)                  # bias[n % C]
-                wf.add(f"wdT{i}", blk.deconv.weight, V(C * d, d, kmod=C, sk_hi=1), 2 * self.H, d * C)  # [h][j*C + c]
-                wf.add(f"wcT{i}", blk.conv.weight, V(d, C * d, nmod=C, sn_hi=1), d * C, C)             # [j*C + ci][co]
+                wf.add(f"wc{i}", lambda blk=blk: blk.conv.weight, V(C * d, d, kmod=C, sk_hi=1), C, d * C)            # [co][j*C + ci]
+                wf.add(f"wd{i}", lambda blk=blk: blk.deconv.weight, V(d, C * d, nmod=C, sn_hi=1), d * C, 2 * self.H)   # [j*C + c][h]
+                wf.add(f"bd{i}", lambda blk=blk: blk.deconv.bias, V(1, 0, nmod=C, sn_hi=0), d * C, 1)                  # bias[n % C]
+                wf.add(f"wdT{i}", lambda blk=blk: blk.deconv.weight, V(C * d, d, kmod=C, sk_hi=1), 2 * self.H, d * C)  # [h][j*C + c]
+                wf.add(f"wcT{i}", lambda blk=blk: blk.conv.weight, V(d, C * d, nmod=C, sn_hi=1), d * C, C)             # [j*C + ci][co]
         object.__setattr__(self, "_wforms", wf)
         return wf
 
@@ -245,7 +245,7 @@ class _NetBase(nn.Module):
         st = input_state
         Fn.GRAD_MODE = torch.is_grad_enabled()      # BPTT records are written only when a backward pass can follow
         e = self._embed(inputs.get("dis_embed"))
-        wf = self._weight_forms().refresh(force=self.training and torch.is_grad_enabled())
+        wf = self._weight_forms().refresh()
         ln = tg.conv[1] if self.use_first_ln else None
         y, st["conv_buf"] = Fn.FrontEndFn.apply(
             x.float(), tg.enc.filterbank._filters, tg.conv[0].weight, tg.conv[0].bias,
@@ -254,6 +254,7 @@ class _NetBase(nn.Module):
         gb = st["gridnet_bufs"]
         film_done = False          # FiLM of block i already applied in block i-1's inter-frame kernel epilogue
         ovl = None                 # overlapped forward: block i-1's inter-frame kernel is still producing y
+        used_overlap = False
         for i, blk in enumerate(tg.blocks):
             if not film_done:
                 y = self._film(y, e, i)
@@ -290,6 +291,7 @@ class _NetBase(nn.Module):
                     and (e is None or film_done)
                     and Fn.ops.can_overlap_fwd(Bq, Tq, Fq, Cq, torch.is_grad_enabled(), y.device)):
                 ovl = Fn.ops.FwdOverlap(Bq, Tq, Fq, y.device)
+                used_overlap = True
             y, b["h0"], b["c0"] = Fn.InterFn.apply(y, blk.inter_norm.norm.weight, blk.inter_norm.norm.bias,
                                                    *_lstm_dir(blk.inter_rnn, False), blk.inter_linear.weight,
                                                    blk.inter_linear.bias, b["h0"], b["c0"], part, *nf, ovl)
@@ -306,6 +308,13 @@ class _NetBase(nn.Module):
             self.stft_chunk_size, wf["back_w"], wf["back_b"])
         if mod:
             out = out[..., :-mod]
+        if used_overlap and not torch.is_grad_enabled():
+            # a plain inference loop never passes a place that reads the watchdog word of the overlapped schedule (training:
+            # the harness, once per epoch): check it every 64th overlapped forward -- one synchronisation, amortised -- so
+            # that an aborted consumer item (GPU shared / CU-masked) surfaces as an error and not as garbage output
+            n = self.__dict__["_ovl_fwd_count"] = self.__dict__.get("_ovl_fwd_count", 0) + 1
+            if n % 64 == 0:
+                Fn.ops.check_sched_status()
         return {"output": out, "next_state": st}
 
 

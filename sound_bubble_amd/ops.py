@@ -166,6 +166,34 @@ def sched_status(dev):
     return t
 
 
+def read_sched_status():
+    """synchronises; -> list of device indices whose watchdog word was set (and clears those words)"""
+    bad = []
+    for i, t in _SCHED_STATUS.items():
+        if int(t.item()) != 0:
+            t.zero_()
+            bad.append(i)
+    return bad
+
+
+def check_sched_status_all_ranks():
+    """check_sched_status for a data-parallel job: the verdict is all-reduced (max) first, so that EVERY rank raises when any
+    rank's launch aborted -- a lone raising rank would leave the others hanging in their next collective"""
+    import torch.distributed as dist
+    bad = read_sched_status()
+    flag = 1 if bad else 0
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([flag], dtype=torch.int32,
+                         device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        flag = int(t.item())
+    if flag:
+        raise L.SoundBubbleHipError(
+            f"a time-segmented / overlapped LSTM launch aborted on {'this rank (cuda:%s)' % bad if bad else 'another rank'} "
+            "(its workgroups were not co-resident -- GPU shared or CU-masked?).  Results since the last check are invalid; set "
+            "SB_NO_TIME_SEGMENTS=1 / SB_NO_FWD_OVERLAP=1 / SB_NO_BWD_OVERLAP=1 or ops.SCHED_OVERRIDE.")
+
+
 def check_sched_status():
     """Synchronises and raises if a segmented launch gave up waiting for a co-resident workgroup (its outputs are then
     garbage).  Called after the timed region by bench.py, once per epoch by the harness, and by the tests."""
@@ -244,17 +272,61 @@ def _tile_order(B, T, slab, dev):
 
 
 _OVERLAP_OK = {}
+_OVERLAP_SCRATCH = {}
+
+
+def _overlap_scratch(dev_index):
+    t = _OVERLAP_SCRATCH.get(dev_index)
+    if t is None:
+        t = _OVERLAP_SCRATCH[dev_index] = torch.zeros(4, device=torch.device("cuda", dev_index), dtype=torch.float32)
+    return t
 
 
 def overlap_available():
-    """kernels on the library's side stream really run next to those of the current stream (sb_overlap_available: probed
-    once per stream -- a side stream that shares the hardware queue of the main stream would serialise the two launches)"""
+    """kernels on the library's side stream really run next to those of the current stream.  First use per (device, stream):
+    sb_overlap_init -- a timed probe, which synchronises the stream (a side stream that shares the hardware queue of the main
+    stream would serialise the two launches); afterwards the stored verdict (sb_overlap_reprobe refreshes it)."""
     st = _stream()
-    key = (torch.cuda.current_device(), st.value)
+    dev = torch.cuda.current_device()
+    key = (dev, st.value)
     ok = _OVERLAP_OK.get(key)
     if ok is None:
-        ok = _OVERLAP_OK[key] = bool(L.load().sb_overlap_available(st))
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        tm = (C.c_float * 2)()
+        rc = L.load().sb_overlap_init(st, _p(_overlap_scratch(dev)), tm)
+        ok = _OVERLAP_OK[key] = rc == 1
+        OVERLAP_LOG.append(("init", key, rc, float(tm[0]), float(tm[1])))
     return ok
+
+
+OVERLAP_LOG = []          # (event, (device, stream), verdict, back-to-back ms, pair ms) -- what SB_OVERLAP_DEBUG used to print
+
+
+def overlap_reprobe():
+    """Re-time the side stream of the current stream (two 0.2 ms launches + a synchronisation): concurrency that was there at
+    start-up can be lost later (another process on the GPU, more streams alive), and the overlapped schedules then cost
+    15-25 % instead of gaining 4 % -- silently.  Called once per epoch by the harness; -> True while still concurrent.  On
+    loss the overlapped paths are switched off for this stream (plain order) and a warning is issued."""
+    st = _stream()
+    dev = torch.cuda.current_device()
+    key = (dev, st.value)
+    if not _OVERLAP_OK.get(key):
+        return False
+    tm = (C.c_float * 2)()
+    rc = L.load().sb_overlap_reprobe(st, _p(_overlap_scratch(dev)), tm)
+    OVERLAP_LOG.append(("reprobe", key, rc, float(tm[0]), float(tm[1])))
+    if rc != 1:
+        import warnings
+        _OVERLAP_OK[key] = False
+        warnings.warn(f"cuda:{dev}: the side stream of the overlapped LSTM schedules no longer runs concurrently with the main "
+                      f"stream (back-to-back {tm[0]:.3f} ms, pair {tm[1]:.3f} ms): falling back to the plain launch order")
+    return rc == 1
+
+
+def overlap_lost():
+    """a data-path call found no side stream (-1009): stop choosing the overlapped paths on this stream"""
+    _OVERLAP_OK[(torch.cuda.current_device(), _stream().value)] = False
 
 
 class FwdOverlap:
@@ -371,10 +443,14 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
                8.0 * Cc * geom.P, by):
         if produce is not None:
             assert ndir == 1 and lin is not None
-            L.check(lib.sb_lstm_fwd_produce(C.byref(a), C.c_void_p(produce.flags.data_ptr()), produce.slab, _stream()),
-                    "sb_lstm_fwd_produce")
-            produce.keep += [x, ln_g, ln_b, h0, c0, hs, gates, cprev, u, hN, cN, x_part, x_sum, seg_scratch, lin, film, dirs]
-            produce.produced = True
+            rc = lib.sb_lstm_fwd_produce(C.byref(a), C.c_void_p(produce.flags.data_ptr()), produce.slab, _stream())
+            if rc == -1009:                # no side stream (any more): the plain call; the consumer then runs in plain order too
+                overlap_lost()
+                L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
+            else:
+                L.check(rc, "sb_lstm_fwd_produce")
+                produce.keep += [x, ln_g, ln_b, h0, c0, hs, gates, cprev, u, hN, cN, x_part, x_sum, seg_scratch, lin, film, dirs]
+                produce.produced = True
         elif consume is not None:
             assert ndir == 2 and lin is not None
             L.check(lib.sb_lstm_fwd_consume(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
@@ -580,8 +656,11 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
     by = P * (640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc + 4 * 4.0 * Cc)
     with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)",
                (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P, 8.0 * Cc * P, by):
-        L.check(lib.sb_lstm_bwd_inter_overlapped(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab, _stream()),
-                "sb_lstm_bwd_inter_overlapped")
+        rc = lib.sb_lstm_bwd_inter_overlapped(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab, _stream())
+        if rc == -1009:                    # no side stream (any more): the caller takes the two plain launches
+            overlap_lost()
+            return None
+        L.check(rc, "sb_lstm_bwd_inter_overlapped")
     if gm is not None:
         absmax_hint_put(dx, gm)
     return dx

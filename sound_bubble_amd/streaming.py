@@ -68,6 +68,7 @@ class StreamingSeparator(torch.nn.Module):
         self.dis_embed = dis_embed.to(dev) if dis_embed is not None else None
         self.out = None
         self.graph = None
+        self._param_key = None
         self.use_graph = use_graph
 
     def _inputs(self):
@@ -109,8 +110,12 @@ class StreamingSeparator(torch.nn.Module):
         self.frame.copy_(frame, non_blocking=True)
         if not self.use_graph:
             return self._step_inplace()
-        if self.graph is None:
+        # the graph holds the addresses of the parameters: re-capture when one was replaced (load_state_dict(assign=True),
+        # module.weight = ...); in-place updates need nothing -- the weight-form refresh is one of the captured launches
+        key = tuple((id(p), p.data_ptr()) for p in self.model.parameters())
+        if self.graph is None or key != self._param_key:
             self._capture()
+            self._param_key = key
         self.graph.replay()
         return self.out
 

@@ -146,7 +146,12 @@ def main(argv=None):
         if not os.path.exists(os.path.join(args.run_dir, "config.json")):
             shutil.copyfile(args.config, os.path.join(args.run_dir, "config.json"))
     best_path, state_path = os.path.join(ckdir, "best.pt"), os.path.join(ckdir, "last.pt")
-    if os.path.exists(state_path):
+    # resume: rank 0 decides (only it writes last.pt, and run directories may be node-local) and every rank follows --
+    # load_state ends in collectives, so a per-rank os.path.exists() could leave ranks waiting for each other
+    resume = [os.path.exists(state_path) if rank == 0 else False]
+    if world > 1:
+        dist.broadcast_object_list(resume, src=0)
+    if resume[0]:
         hl.load_state(state_path)
     wandb_run = None
     if args.wandb and rank == 0:
@@ -158,7 +163,10 @@ def main(argv=None):
             print("[train_cli] wandb unavailable:", e)
     n_epochs = args.epochs if args.epochs is not None else params["epochs"]
     for epoch in range(hl.epoch, n_epochs):
-        seed_all(args.seed + epoch)
+        # data-side RNGs (crop offsets, perturbations drawn by the loader workers) differ per rank, as the reference's single
+        # process draws independently per sample; model-side randomness does not exist (no dropout), and the sampler keeps
+        # its own (seed, epoch) generator, so the sharding is unaffected
+        seed_all(args.seed + epoch + 100003 * rank)
         if hasattr(train_loader.sampler, "set_epoch"):
             train_loader.sampler.set_epoch(epoch)                     # a different shuffle every epoch
         hl.on_epoch_start()

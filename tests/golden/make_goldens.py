@@ -288,6 +288,60 @@ def make_samples(torch, NetBig, out_dir, n_keep=36000):
     np.savez_compressed(os.path.join(out_dir, "samples_syn_1m.npz"), **rec)
 
 
+def make_samples_more(torch, NetBig, out_dir):
+    """The other two radii of test_samples/ (src/test_samples.py:96-104 one-hots: 1.5 m -> [0, 1, 0], 2 m -> [1, 0, 0]):
+    syn_1_5m/00001 trimmed to 1.5 s like the syn_1m scenes, and syn_2m/00002 at its FULL 5 s length (625 frames), both
+    through the REFERENCE model (weights of tiny_big.npz) with the reference's own NumPy metrics."""
+    import json
+    import wave
+    import shutil
+    sys.path.insert(0, os.path.join(REF, "helpers"))
+    import eval_utils                                            # reference helpers/eval_utils.py
+    z = np.load(os.path.join(out_dir, "tiny_big.npz"))
+    params = dict(eval(str(z["meta::params"])))
+    model = NetBig(**params).eval()
+    sd = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param::")}
+    filt = torch.from_numpy(np.load(os.path.join(out_dir, "stft_filters.npz"))["filters"])
+    sd["tfgridnet.enc.filterbank._filters"] = filt
+    sd["tfgridnet.dec.filterbank._filters"] = filt.clone()
+    model.load_state_dict(sd)
+    rec = {}
+    for sset, scene, thr, onehot, n_keep in (("syn_1_5m", "00001", 1.5, [0.0, 1.0, 0.0], 36000),
+                                             ("syn_2m", "00002", 2.0, [1.0, 0.0, 0.0], 120000)):
+        src = os.path.join(REF, "test_samples", sset, scene)
+        dst = os.path.join(out_dir, "test_samples", sset, scene)
+        os.makedirs(dst, exist_ok=True)
+        shutil.copyfile(os.path.join(src, "metadata.json"), os.path.join(dst, "metadata.json"))
+        for fn in sorted(os.listdir(src)):
+            if fn.endswith(".wav"):
+                with wave.open(os.path.join(src, fn), "rb") as w:
+                    par, data = w.getparams(), w.readframes(n_keep)
+                with wave.open(os.path.join(dst, fn), "wb") as w:
+                    w.setparams(par)
+                    w.writeframes(data)
+        meta = json.load(open(os.path.join(dst, "metadata.json")))
+        with wave.open(os.path.join(dst, "mixture.wav"), "rb") as w:
+            mix = np.frombuffer(w.readframes(n_keep), "<i2").reshape(-1, 6).T.astype(np.float32) / 32768.0
+        gt = np.zeros((1, mix.shape[1]), np.float32)
+        ntg = 0
+        for spk in sorted(k for k in meta if k.startswith("voice")):
+            if meta[spk]["dis"] <= thr:
+                ntg += 1
+                with wave.open(os.path.join(dst, f"mic00_{spk}.wav"), "rb") as w:
+                    gt[0] += np.frombuffer(w.readframes(n_keep), "<i2").astype(np.float32) / 32768.0
+        with torch.no_grad():
+            out = model({"mixture": torch.from_numpy(mix)[None], "dis_embed": torch.tensor([onehot])})["output"][0].numpy()
+        key = f"{sset}/{scene}"
+        rec[key + "::output"] = out
+        rec[key + "::gt"] = gt
+        rec[key + "::n_targets"] = np.int64(ntg)
+        rec[key + "::si_sdr"] = np.float64(eval_utils.si_sdr(out[0].astype(np.float64), gt[0].astype(np.float64)))
+        rec[key + "::input_si_sdr"] = np.float64(eval_utils.si_sdr(mix[0].astype(np.float64), gt[0].astype(np.float64)))
+        rec[key + "::snr"] = np.float64(eval_utils.snr(out[0].astype(np.float64), gt[0].astype(np.float64)))
+        print(key, mix.shape, "targets", ntg, "SI-SDR", rec[key + "::si_sdr"], "input", rec[key + "::input_si_sdr"])
+    np.savez_compressed(os.path.join(out_dir, "samples_more.npz"), **rec)
+
+
 def make_state_io(torch, nets, out_dir):
     """edge/flatbuf.py:8-25 name order: the reference's own flatten_state_buffers over init_buffers of each family
     (+ attention buffers), and the reference's named_parameters() order (= torch.optim.Adam state indices)."""
@@ -414,6 +468,8 @@ def main():
               with_grads=False, with_stream=False, with_stages=False)
     if not only or "samples" in only:
         make_samples(torch, NetBig, args.out)
+    if not only or "samples_more" in only:
+        make_samples_more(torch, NetBig, args.out)
     if not only or "state_io" in only:
         make_state_io(torch, {"small": (NetSmall, small), "big": (NetBig, big), "orange": (NetSmall, orange),
                               "big_attn": (NetBig, dict(big, use_attn=True)),

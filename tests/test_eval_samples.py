@@ -73,3 +73,60 @@ def test_hip_model_on_samples_si_sdr_parity():
         assert abs(rows[scene]["si_sdr"] - float(g[scene + "::si_sdr"])) < 0.05
     with pytest.raises(ValueError):
         run_testcase(m, np.zeros((6, 960), np.float32), 1.2)
+
+
+# ---- the other two radii of test_samples/ and one full-length scene (round 3; src/test_samples.py:35-112) ----
+MORE = [("syn_1_5m", "00001", 1.5, 36000, 1), ("syn_2m", "00002", 2.0, 120000, 2)]
+
+
+def _golden_more():
+    z = np.load(os.path.join(GOLDEN, "samples_more.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_reader_and_oracle_on_the_other_radii(torch_mod):
+    torch = torch_mod
+    from oracle.tfgridnet_oracle import OracleNet
+    from sound_bubble_amd.eval_samples import ONE_HOT, load_testcase, si_sdr_np
+    assert ONE_HOT[1.0] == [0.0, 0.0, 1.0] and ONE_HOT[1.5] == [0.0, 1.0, 0.0] and ONE_HOT[2.0] == [1.0, 0.0, 0.0]
+    rec, params, flavour = load_golden("tiny_big")
+    m = OracleNet(flavour, **params).eval()
+    m.load_state_dict(golden_state_dict(rec, torch))
+    g = _golden_more()
+    for sset, scene, thr, n, ntg in MORE:
+        _, mix, gt, tg = load_testcase(os.path.join(GOLDEN, "test_samples", sset, scene), thr)
+        assert mix.shape == (6, n) and len(tg) == ntg == int(g[f"{sset}/{scene}::n_targets"])
+        np.testing.assert_array_equal(gt, g[f"{sset}/{scene}::gt"])
+        with torch.no_grad():
+            out = m({"mixture": torch.from_numpy(mix)[None], "dis_embed": torch.tensor([ONE_HOT[thr]])})["output"][0].numpy()
+        assert rel_l2(out, g[f"{sset}/{scene}::output"]) < 5e-6
+        assert abs(si_sdr_np(out[0], gt[0]) - float(g[f"{sset}/{scene}::si_sdr"])) < 0.05
+        assert abs(si_sdr_np(mix[0], gt[0]) - float(g[f"{sset}/{scene}::input_si_sdr"])) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_model_on_the_other_radii_and_a_full_length_scene():
+    """evaluate_dir with thresholds 1.5 / 2.0 (one-hots [0, 1, 0] / [1, 0, 0]); syn_2m/00002 is a full 5 s scene (625 frames,
+    the BASELINE clip length) -- rel-L2 <= 2e-4 against the REFERENCE model's output, SI-SDR within 0.05 dB."""
+    import torch
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.eval_samples import evaluate_dir
+    rec, params, _ = load_golden("tiny_big")
+    m = sb.NetDisEmbd3(**params)
+    m.load_state_dict(golden_state_dict(rec, torch))
+    m = m.cuda().eval()
+    g = _golden_more()
+    for sset, scene, thr, n, ntg in MORE:
+        out_dir = os.path.join("/tmp", f"sb_eval_{sset}")
+        rows = {r["sample"]: r for r in evaluate_dir(m, os.path.join(GOLDEN, "test_samples", sset), thr, out_dir=out_dir)}
+        row = rows[scene]
+        assert row["n_targets"] == ntg
+        from sound_bubble_amd.eval_samples import read_wav
+        assert abs(row["si_sdr"] - float(g[f"{sset}/{scene}::si_sdr"])) < 0.05
+        assert abs(row["input_si_sdr"] - float(g[f"{sset}/{scene}::input_si_sdr"])) < 1e-4
+        from sound_bubble_amd.eval_samples import load_testcase, run_testcase
+        _, mix, _, _ = load_testcase(os.path.join(GOLDEN, "test_samples", sset, scene), thr)
+        out = run_testcase(m, mix, thr)
+        assert out.shape == (1, n) and rel_l2(out, g[f"{sset}/{scene}::output"]) < 2e-4
+        wav, sr = read_wav(os.path.join(out_dir, f"{scene}_output.wav"))       # the written demo output round-trips
+        assert sr == 24000 and wav.shape[-1] == n

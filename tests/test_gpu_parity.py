@@ -1051,3 +1051,129 @@ def test_wide_fused_bptt_bidirectional_matches_float64_autograd(torch_gpu, C_, f
     if fuse_lin:
         assert rel_l2(ltg[0].cpu().numpy(), LW.grad.numpy()) < tol
         assert rel_l2(ltg[1].cpu().numpy(), dy.double().sum(0).cpu().numpy()) < tol
+
+
+# ---- robustness items of round 3 ----
+def test_weight_forms_follow_in_place_and_replaced_parameters(torch_gpu):
+    """The kernel-layout weight forms (front / back convolutions, conv-LSTM Conv1d / ConvTranspose1d) are refreshed from the
+    LIVE parameters at every forward: an in-place write through `.data` (no version bump), a replaced Parameter object and a
+    load_state_dict between two feeds of a graphed streaming loop must all be seen."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.streaming import StreamingSeparator
+    rec, params, m = _build(torch, "tiny_small", "NetOptim")
+    m.eval()
+    x = _inputs(torch, rec)
+
+    def fresh_output(model):
+        ref = sb.NetOptim(**params)
+        ref.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            return ref.cuda().eval()(x)["output"]
+
+    with torch.no_grad():
+        y0 = m(x)["output"]
+        tg = m.tfgridnet
+        for p in (tg.conv[0].weight, tg.blocks[0].conv.weight, tg.blocks[1].deconv.weight, tg.deconv.weight):
+            v = p._version
+            p.data.mul_(1.5)                       # behind torch's version counter
+            assert p._version == v
+        y1 = m(x)["output"]
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y1, fresh_output(m))
+    tg.deconv.weight = torch.nn.Parameter(tg.deconv.weight.detach().clone() * 0.5)       # a NEW Parameter object
+    tg.blocks[0].conv.weight = torch.nn.Parameter(tg.blocks[0].conv.weight.detach().clone() * 0.5)
+    with torch.no_grad():
+        y2 = m(x)["output"]
+    assert torch.equal(y2, fresh_output(m))
+    # graphed streaming loop: new weights loaded between two feeds (in place: same addresses, the captured refresh sees them)
+    sep = StreamingSeparator(m, 1, use_graph=True)
+    frame = (0.1 * torch.randn(1, 6, 288, generator=torch.Generator().manual_seed(3))).cuda()
+    sep.feed(frame)
+    sd = {k: (v * 0.9 if v.dtype.is_floating_point and "filterbank" not in k else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    sep.reset()
+    z = sep.feed(frame).clone()
+    ref = sb.NetOptim(**params)
+    ref.load_state_dict(sd)
+    ref = ref.cuda().eval()
+    with torch.no_grad():
+        want = ref({"mixture": frame}, ref.init_buffers(1, "cuda"), pad=False)["output"]
+    assert rel_l2(z.cpu().numpy(), want.cpu().numpy()) < 1e-6
+
+
+def test_side_stream_management_api(torch_gpu):
+    """sb_overlap_init / _reprobe / _available / _shutdown (include/sound_bubble_hip.h): explicit, per (device, stream)
+    entries, caller-owned scratch, stored verdicts, bad arguments by status code."""
+    torch = torch_gpu
+    import ctypes as C
+    from sound_bubble_amd import ops, _lib as L
+    lib = L.load()
+    scratch = torch.zeros(4, device="cuda")
+    ptr = C.c_void_p(scratch.data_ptr())
+    try:
+        assert lib.sb_overlap_shutdown() == 0
+        ops._OVERLAP_OK.clear()
+        st = ops._stream()
+        assert lib.sb_overlap_available(st) == 0                       # nothing initialised: look-up only, no probe
+        assert lib.sb_overlap_init(st, None, None) == -1001
+        tm = (C.c_float * 2)()
+        r1 = lib.sb_overlap_init(st, ptr, tm)
+        assert r1 in (0, 1) and tm[0] > 0
+        assert lib.sb_overlap_available(st) == r1
+        assert lib.sb_overlap_init(st, ptr, None) == r1                # the stored verdict
+        s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            st2 = ops._stream()
+            r2 = lib.sb_overlap_init(st2, ptr, None)
+            assert r2 in (0, 1) and lib.sb_overlap_available(st2) == r2
+        assert lib.sb_overlap_available(st) == r1                      # the first entry is untouched
+        rp = lib.sb_overlap_reprobe(st, ptr, tm)
+        assert rp in (0, 1) and lib.sb_overlap_available(st) == rp and (rp == 0 or tm[1] < 0.7 * tm[0])
+        assert lib.sb_overlap_shutdown() == 0
+        assert lib.sb_overlap_available(st) == 0
+    finally:
+        lib.sb_overlap_shutdown()
+        ops._OVERLAP_OK.clear()
+    assert ops.overlap_available() in (True, False) and ops.OVERLAP_LOG[-1][0] == "init"
+
+
+def test_overlapped_paths_fall_back_when_the_side_stream_is_gone(torch_gpu, monkeypatch, compact_bptt):
+    """-1009 from a data-path call (side stream shut down after the check) -> the plain launch order, no exception, same
+    gradients."""
+    torch = torch_gpu
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd import ops, _lib as L
+    rec, params, m = _build(torch, "tiny_big", "NetDisEmbd3")
+    m.train()
+    torch.manual_seed(5)
+    B_ = 2
+    x = (0.1 * torch.randn(B_, rec["mixture"].shape[1], 192 * 150 + 96)).cuda()
+    dis = torch.from_numpy(rec["dis_embed"][:1]).cuda().expand(B_, -1).contiguous()
+    tgt = (0.05 * torch.randn(B_, 1, 192 * 150)).cuda()
+    monkeypatch.setattr(ops, "OVERLAP_MIN_FILL", 0.0)
+
+    def grads():
+        for p_ in m.parameters():
+            p_.grad = None
+        loss, _ = SnrlpLossFn.apply(m({"mixture": x, "dis_embed": dis}, pad=False)["output"], tgt, 100.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        ops.check_sched_status()
+        return {k: p_.grad.clone() for k, p_ in m.named_parameters()}
+
+    monkeypatch.setattr(ops, "FWD_OVERLAP", False)
+    monkeypatch.setattr(ops, "BWD_OVERLAP", False)
+    g0 = grads()
+    monkeypatch.setattr(ops, "FWD_OVERLAP", True)
+    monkeypatch.setattr(ops, "BWD_OVERLAP", True)
+    key = (torch.cuda.current_device(), ops._stream().value)
+    try:
+        L.load().sb_overlap_shutdown()
+        monkeypatch.setitem(ops._OVERLAP_OK, key, True)          # the Python side still believes in the side stream
+        g1 = grads()
+        assert ops._OVERLAP_OK[key] is False                     # ... until the first -1009
+    finally:
+        ops._OVERLAP_OK.clear()
+    for k in g0:
+        assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-5, k
