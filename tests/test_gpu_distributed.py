@@ -201,8 +201,8 @@ def _overlap_worker(rank, world, port, mode, q):
     ops.BPTT = mode
     ops.OVERLAP_MIN_FILL = 0.0                        # 19 inter-frame tiles at this size: force the overlapped schedules
     rec, params, _ = load_golden("tiny_big")
+    torch.manual_seed(3)                              # BEFORE construction: the default initialisers draw too
     m = sb.NetDisEmbd3(**dict(params, B=6))           # the BIG model's depth (six blocks), seeded weights
-    torch.manual_seed(3)
     for p in m.parameters():
         torch.nn.init.uniform_(p, -0.2, 0.2) if p.dim() > 1 else None
     m = m.cuda().train()
@@ -225,7 +225,7 @@ def _overlap_worker(rank, world, port, mode, q):
     out = [None] * world
     dist.all_gather_object(out, (avail, still, [e[2:] for e in ops.OVERLAP_LOG]))
     if rank == 0:
-        q.put(((bucket.grad / w).cpu().numpy(), out, {k: v.detach().cpu() for k, v in m.state_dict().items()}))
+        q.put(((bucket.grad / w).cpu().numpy(), out, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -258,7 +258,7 @@ def test_two_ranks_contending_for_one_gpu_with_overlapped_schedules(mode):
     from sound_bubble_amd.train import FlatBucket
     rec, params, _ = load_golden("tiny_big")
     m = sb.NetDisEmbd3(**dict(params, B=6))
-    m.load_state_dict(sd)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m = m.cuda().train()
     bucket = FlatBucket(m)
     g = torch.Generator().manual_seed(11)
