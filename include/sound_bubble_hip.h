@@ -330,6 +330,10 @@ typedef struct {
   /* consumer side of sb_lstm_bwd_inter_overlapped (set by that call; leave NULL / 0 otherwise) */
   int* slab_flags; int slab_len, slab_need; int* chunk_counter; int* started; int nchunks, guard, row_base;
   int* sched_status;
+  /* WIDE form (sb_lstm_bwd_inter_overlapped only; rec->wide must be set as well): dgates rows are [hi x 256 | lo' x 256]
+     halves, x = hi + 2^-11 lo' (1 KB per position), u [P, 2C] and hs [P, 128] halves are the fp16 (hi, lo) pair tensors of
+     sb_lstm_fwd_args.rec_f32 (u_f16 = hs_f16 = 1): three products per MAC, as in the fused wide kernels. */
+  int wide;
 } sb_lstm_stream_args;
 int sb_lstm_bwd_stream(const sb_lstm_stream_args* a, void* stream);
 int sb_lstm_stream_grid(int64_t positions);

@@ -99,7 +99,7 @@ class LstmStreamArgs(C.Structure):
                 ("absmax_out", c_fp), ("d_lin_w", c_fp), ("d_lin_b", c_fp),
                 ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_need", C.c_int),
                 ("chunk_counter", C.c_void_p), ("started", C.c_void_p), ("nchunks", C.c_int), ("guard", C.c_int),
-                ("row_base", C.c_int), ("sched_status", C.c_void_p)]
+                ("row_base", C.c_int), ("sched_status", C.c_void_p), ("wide", C.c_int)]
 
 
 class LnBwdArgs(C.Structure):

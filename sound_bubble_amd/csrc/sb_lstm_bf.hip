@@ -738,8 +738,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   // SLAB: the step's 16 dgates rows are assembled here so that they leave as whole 512-byte rows (write-through stores of
   // the 32-byte pieces each lane holds would reach HBM as partial lines)
   __shared__ __attribute__((aligned(16))) _Float16 DS[SLAB ? 2 : 1][SLAB ? 16 : 1][SLAB ? 4 * H + 8 : 8];
+  __shared__ __attribute__((aligned(16))) _Float16 DSL[SLAB && XP ? 2 : 1][SLAB && XP ? 16 : 1][SLAB && XP ? 4 * H + 8 : 8];
   static_assert(FST == 0 || (DG16 && (REC16 || XP)), "fused streaming part: compact fp16 records or the wide form");
-  static_assert(!XP || (FST > 0 && DG16 && !REC16 && !HS16B && !RECOMP && !SLAB), "wide form: fused kernels, fp32 records / hs");
+  static_assert(!XP || ((FST > 0 || SLAB) && DG16 && !REC16 && !HS16B && !RECOMP), "wide form: fused or overlapped kernels, fp32 records");
   constexpr float kLoUp = 2048.0f, kLoDn = 1.0f / 2048.0f;      // scale of the low fp16 term (XP)
   static_assert(!RECOMP || (BI && HS16B && FST == 32), "gate recomputation: bidirectional C = 32 form with fp16 hs");
   // forward weights of this direction as MFMA A operands: WR[gate][chunk][wave][lane] = rows gate*64 + 16 wave + (lane & 15),
@@ -1363,16 +1364,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   };
   // SLAB: a step's dgates rows leave one step late -- whole rows (one instruction = 64 lanes x 8 bytes = one row),
   // write-through (sc1), issued where the LDS reads that fetched them have long returned
-  unsigned long long prow[4] = {0, 0, 0, 0};
+  // XP: a dgates row is [hi x 256 | scaled lo x 256] halves (1 KB): two planes, each stored as one whole 512-byte piece
+  unsigned long long prow[4] = {0, 0, 0, 0}, prowl[4] = {0, 0, 0, 0};
   int prow_st = -1;
+  constexpr int DGROW = XP ? 8 * H : 4 * H;         // halves per dgates row in HBM
   auto rows_out = [&]() {
     if (prow_st >= 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (sbase[i] >= 0)
-          __hip_atomic_store(reinterpret_cast<unsigned long long*>(reinterpret_cast<_Float16*>(a.dgates) +
-                                                                    (sbase[i] + (int64_t)prow_st * a.p_step) * (4 * H) + 4 * lane),
-                             prow[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sbase[i] >= 0) {
+          _Float16* row = reinterpret_cast<_Float16*>(a.dgates) + (sbase[i] + (int64_t)prow_st * a.p_step) * DGROW + 4 * lane;
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(row), prow[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if constexpr (XP)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(row + 4 * H), prowl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       prow_st = -1;
     }
   };
@@ -1510,6 +1515,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = Bh[g >> 1][4 * (g & 1) + r];
         *reinterpret_cast<h16x4*>(&DS[cur][j][g * H + uoff]) = t;
+        if constexpr (XP) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = Bl[g >> 1][4 * (g & 1) + r];
+          *reinterpret_cast<h16x4*>(&DSL[cur][j][g * H + uoff]) = t;
+        }
       }
     } else
     if (valid && !(SB_EXP_SKIP & 256)) {
@@ -1576,7 +1586,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
             ld4(&P[cur][3][w][lane][0]);
     if constexpr (SLAB) {                              // rows 4w .. 4w + 3 of the step: picked up now, stored by rows_out()
 #pragma unroll
-      for (int i = 0; i < 4; ++i) prow[i] = *reinterpret_cast<const unsigned long long*>(&DS[cur][4 * w + i][4 * lane]);
+      for (int i = 0; i < 4; ++i) {
+        prow[i] = *reinterpret_cast<const unsigned long long*>(&DS[cur][4 * w + i][4 * lane]);
+        if constexpr (XP) prowl[i] = *reinterpret_cast<const unsigned long long*>(&DSL[cur][4 * w + i][4 * lane]);
+      }
       prow_st = rev ? S - 1 - s : s;
     }
 #ifdef SB_PHASE_TIMING
@@ -1884,7 +1897,7 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   // fused streaming part (see the kernel): single direction, fused Linear backward with the same channel count
   const bool fst = a.wpart != nullptr;
   const bool wide = a.wide != 0;                    // fp32 records / u / hs, two-term gradients (see the kernel: XP)
-  if (wide && (!fst || !dg16 || a.hs_f16 || a.recompute)) return -1003;
+  if (wide && ((!fst && !a.slab_flags) || !dg16 || a.hs_f16 || a.recompute)) return -1003;
   if (fst && a.ndir == 2) {                          // bidirectional fused form: persistent workgroups, one per CU
     if (!dg16 || !a.u || !a.hs || !a.w_ih || !a.w_ih1 || !a.du || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
         !a.dW_ih1 || !a.dW_hh1 || !a.db_ih1 || !a.db_hh1 || (int64_t)a.nseq * a.nsteps * H >= (1ll << 31))
@@ -1958,8 +1971,14 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     if (seg || !dg16 || a.ndir != 1 || a.slab_len < 2 || (a.slab_len & 1) || (fc != 16 && fc != 32) || !a.slab_started)
       return -1003;
 #define SB_SLB(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC, true, false, 0, false, false, false, false, true>), grid, block, 0, st, a)
+#define SB_SLBX(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC, true, false, 0, false, false, false, false, true, true>), grid, block, 0, st, a)
+    if (wide) {
+      if (fc == 32) { if (full) SB_SLBX(true, 32); else SB_SLBX(false, 32); }
+      else { if (full) SB_SLBX(true, 16); else SB_SLBX(false, 16); }
+    } else
     if (fc == 32) { if (full) SB_SLB(true, 32); else SB_SLB(false, 32); }
     else { if (full) SB_SLB(true, 16); else SB_SLB(false, 16); }
+#undef SB_SLBX
 #undef SB_SLB
     SB_CHECK_LAUNCH();
     return 0;

@@ -373,14 +373,23 @@ SB_DEVINL f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma
 // Guarded launch (the one that runs NEXT to the recurrence): a workgroup that does not find every recurrence workgroup
 // started within ~50 us draws nothing -- should the dispatcher have placed this launch first, it must not sit on the CUs
 // the recurrence needs.  Partial rows from row_base on.
-template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false, bool LINW = false, bool SLAB = false>
+// XPS (with U16, HS16, LNB, LINW, SLAB): the WIDE form of the overlapped inter-frame backward (sb_lstm_stream_args.wide).  A
+// dgates row is [hi x 256 | lo' x 256] halves, x = hi + 2^-11 lo' (written by lstm_bwd_rec_bf_kernel<..., SLAB, XP>), u and hs
+// are the forward kernel's fp16 (hi, lo) pair tensors: three products per MAC, the scaled low terms of du and of the bias
+// sums accumulated apart and folded in with 2^-11, the low dgates terms of dW meeting 2^-11 * hi of u / h.  Only the
+// dgates of the next chunk are prefetched (64 registers); u / h / x / residual rows are fetched at the top of the chunk
+// and meet their first use after the 24 MFMAs of du -- this launch fills CUs the recurrence leaves idle, it has time.
+template <int C, bool SMALLSEG, bool U16, bool HS16, bool LNB = false, bool LINW = false, bool SLAB = false, bool XPS = false>
 __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream_args a) {
+  static_assert(!XPS || (U16 && HS16 && LNB && LINW && SLAB), "wide form: the overlapped instantiation only");
   constexpr int CK = C / 16, KT = CK + 4;
+  constexpr float kLoDn = 1.0f / 2048.0f, kLoUp = 2048.0f;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y, ndir = a.ndir;
   const int Pi = (int)a.P;
   __shared__ __attribute__((aligned(16))) float R[2][4][2][CK][64][4];
   __shared__ __attribute__((aligned(16))) _Float16 DY[LINW ? 2 : 1][LINW ? C : 1][40];
+  __shared__ __attribute__((aligned(16))) _Float16 DYL[XPS ? 2 : 1][XPS ? C : 1][40];      // XPS: scaled low terms of dy
   float invS = 1.0f;
   {
     const float m = a.gmax[0];
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
     }
 
   f32x4 acc[4][KT];
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  float csum[4] = {0.f, 0.f, 0.f, 0.f}, csumx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -411,16 +420,28 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   const float* __restrict__ hs = a.hs + (size_t)dir * H;
   const _Float16* __restrict__ hs16 = reinterpret_cast<const _Float16*>(a.hs) + (size_t)dir * H;
   const _Float16* __restrict__ u16 = reinterpret_cast<const _Float16*>(a.u);
-  const int64_t ldg = (int64_t)ndir * 4 * H, ldh = (int64_t)ndir * H;
+  const int64_t ldg = XPS ? (int64_t)8 * H : (int64_t)ndir * 4 * H, ldh = XPS ? (int64_t)2 * H : (int64_t)ndir * H;
   const int64_t hshift = (dir == 0 ? -1 : 1) * a.shift_pos * ldh;
   const int skip_first = dir == 0 ? a.skip : 0, skip_last = dir == 1 ? a.skip : 0;
 
   struct Chunk {                                                                   // raw operands of 32 positions
-    h16x4 a4[8]; f32x4 h4[HS16 ? 1 : 8]; h16x4 hh4[HS16 ? 8 : 1]; h16x8 d8[2][2];
-    float uv[U16 ? 1 : CK][8]; _Float16 uh[U16 ? CK : 1][8];
+    h16x4 a4[8]; f32x4 h4[HS16 ? 1 : 8]; h16x4 hh4[HS16 && !XPS ? 8 : 1]; h16x8 d8[2][2];
+    h16x4 a4l[XPS ? 8 : 1]; h16x8 d8l[XPS ? 2 : 1][2];                            // XPS: the scaled low terms
+    float uv[U16 ? 1 : CK][8]; _Float16 uh[U16 && !XPS ? CK : 1][8];
     f32x4 xq, rq;                                                                  // LNB: x and residual of the flush position
-    h16x4 hu[LINW ? 8 : 1];                                                        // LINW: hs of the chunk's own positions
+    h16x4 hu[LINW && !XPS ? 8 : 1];                                                // LINW: hs of the chunk's own positions
   };
+  // XPS: the u / h_prev / own-hs pair rows and the flush rows (x, residual) of a chunk reach the waves through LDS: every
+  // thread fetches a few 16-byte pieces of the chunk TWO iterations ahead into registers (28 instead of the 120 a private
+  // copy per wave would take -- there is no room to prefetch those), drops them into the other LDS buffer one iteration
+  // later, and all four waves read their operands from there.  One fetch per workgroup instead of one per wave as well.
+  constexpr int HROW = 256 + 16, UROW = 4 * C + 16;            // padded LDS rows (bytes): hs pairs; u pairs / x / residual
+  __shared__ __attribute__((aligned(16))) char SHP[XPS ? 2 : 1][XPS ? 32 * HROW : 16];
+  __shared__ __attribute__((aligned(16))) char SHU[XPS ? 2 : 1][XPS ? 32 * HROW : 16];
+  __shared__ __attribute__((aligned(16))) char SUP[XPS ? 2 : 1][XPS ? 32 * UROW : 16];
+  __shared__ __attribute__((aligned(16))) char SX[XPS ? 2 : 1][XPS ? 32 * UROW : 16];
+  __shared__ __attribute__((aligned(16))) char SR[XPS ? 2 : 1][XPS ? 32 * UROW : 16];
+  struct Stage { f32x4 hp[2], hu[2], up, x, r; };
   // SLAB geometry: B sequences-of-slabs x nslabs, cpb chunks per (batch, slab)
   const int sF = (int)a.shift_pos, sT = SLAB ? a.seg_len / sF : 0;
   // every slab but the last (shorter) one has cpb chunks per batch entry
@@ -519,6 +540,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       // positions beyond P are cancelled through their (zeroed) dgates alone; u / h_prev of the clamped row are finite
       const h16x4 av = *reinterpret_cast<const h16x4*>(dg + (int64_t)pc * ldg + 4 * j);
       t.a4[kk] = ok ? av : hz4;
+      if constexpr (XPS) {
+        const h16x4 avl = *reinterpret_cast<const h16x4*>(dg + (int64_t)pc * ldg + 4 * H + 4 * j);
+        t.a4l[kk] = ok ? avl : hz4;            // everything else of the chunk is fetched late (load_late)
+      } else {
       int idx = idx0 + 8 * q + kk;
       if constexpr (SMALLSEG) idx %= a.seg_len; else idx -= idx >= a.seg_len ? a.seg_len : 0;
       const bool ok2 = ok & (idx >= skip_first) & (idx < a.seg_len - skip_last);
@@ -546,19 +571,64 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       } else {
         t.uv[0][kk] = a.u[(int64_t)pc * C + j];
       }
+      }
     }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {          // dU operand: position p0 + 16 sb + j, gates 32m + 8q .. +7 (one 16-byte load)
       const int pjc = min(p0 + 16 * sb + j, pe - 1);      // dU of positions beyond the range is computed but never stored
 #pragma unroll
-      for (int m = 0; m < 2; ++m) t.d8[sb][m] = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 32 * m + 8 * q);
+      for (int m = 0; m < 2; ++m) {
+        t.d8[sb][m] = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 32 * m + 8 * q);
+        if constexpr (XPS) t.d8l[sb][m] = *reinterpret_cast<const h16x8*>(dg + (int64_t)pjc * ldg + 4 * H + 32 * m + 8 * q);
+      }
     }
-    if constexpr (LNB) {
+    if constexpr (LNB && !XPS) {
       const int64_t pf = min(p0 + 16 * fsb + fjj, pe - 1);
       t.xq = ld4(a.ln_x + pf * C + fcol);
       t.rq = ld4(a.ln_res + pf * C + fcol);
     }
   };
+
+  const int srow = tid >> 4, scol = tid & 15;                    // hs rows: 16 pieces of 16 bytes; this thread: rows srow, 16 + srow
+  constexpr int UPC = C / 4;                                     // 16-byte pieces per u / x / residual row (C = 32: 8)
+  const int urow = tid / UPC, ucol = tid % UPC;                  // (threads < 32 UPC carry one piece each)
+  const f32x4 z4 = zero4();
+  auto stage_load = [&](const Span& sp, Stage& g) {
+    const int p0 = sp.p0, pe = sp.pe, idx0 = sp.idx0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = srow + 16 * i, p = p0 + r;
+      const bool ok = p < pe;
+      const int pc = min(p, pe - 1);
+      int idx = idx0 + r;
+      if constexpr (SMALLSEG) idx %= a.seg_len; else idx -= idx >= a.seg_len ? a.seg_len : 0;
+      const bool ok2 = ok & (idx >= skip_first) & (idx < a.seg_len - skip_last);
+      const f32x4 hv = ld4(reinterpret_cast<const float*>(hs16 + (int64_t)pc * ldh + (ok2 ? hshift : 0) + 8 * scol));
+      g.hp[i] = ok2 ? hv : z4;
+      const f32x4 hu = ld4(reinterpret_cast<const float*>(hs16 + (int64_t)pc * ldh + 8 * scol));
+      g.hu[i] = ok ? hu : z4;
+    }
+    if (tid < 32 * UPC) {
+      const int pc = min(p0 + urow, pe - 1);
+      g.up = ld4(reinterpret_cast<const float*>(u16 + ((int64_t)pc * C) * 2 + 8 * ucol));
+      g.x = ld4(a.ln_x + (int64_t)pc * C + 4 * ucol);
+      g.r = ld4(a.ln_res + (int64_t)pc * C + 4 * ucol);
+    }
+  };
+  auto stage_store = [&](int sb_, const Stage& g) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      st4(reinterpret_cast<float*>(&SHP[sb_][(srow + 16 * i) * HROW + 16 * scol]), g.hp[i]);
+      st4(reinterpret_cast<float*>(&SHU[sb_][(srow + 16 * i) * HROW + 16 * scol]), g.hu[i]);
+    }
+    if (tid < 32 * UPC) {
+      st4(reinterpret_cast<float*>(&SUP[sb_][urow * UROW + 16 * ucol]), g.up);
+      st4(reinterpret_cast<float*>(&SX[sb_][urow * UROW + 16 * ucol]), g.x);
+      st4(reinterpret_cast<float*>(&SR[sb_][urow * UROW + 16 * ucol]), g.r);
+    }
+  };
+  Stage stg;
+  int sbuf = 0;                                                  // LDS buffer of the chunk in hand (XPS)
 
   const h16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
   Chunk cur;
@@ -596,12 +666,107 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   }
   Span sc = span_at(ch), sn = span_next(sc, ch + cstride);          // chunk in hand, the one being loaded
   if (ch < ch_hi) load_chunk(sc, cur);               // (a workgroup without chunks still writes its zero partial row)
+  if constexpr (XPS) {                               // pipeline start of this unit: chunk ch into LDS, chunk ch + 1 in flight
+    if (ch < ch_hi) {
+      sbuf ^= 1;
+      stage_load(sc, stg);
+      stage_store(sbuf, stg);
+      stage_load(ch + cstride < ch_hi ? sn : sc, stg);
+      __syncthreads();
+    }
+  }
   for (; ch < ch_hi; ++it) {
     Chunk nxt;
     const int cn = ch + cstride;
     load_chunk(cn < ch_hi ? sn : sc, nxt);
     const int cp0 = sc.p0, cpe = sc.pe;              // positions [cp0, cpe) of the chunk in hand (uniform)
     const Span s2 = span_next(sn, cn + cstride);     // ... and of the chunk the NEXT iteration loads
+    if constexpr (XPS) {
+      // chunk ch + 1 (fetched one iteration ago) -> the other LDS buffer: every wave has passed the barrier of the previous
+      // iteration, i.e. has finished reading that buffer; then chunk ch + 2 goes in flight
+      stage_store(sbuf ^ 1, stg);
+      stage_load(cn + cstride < ch_hi ? s2 : sc, stg);
+    }
+    const int buf = it & 1;
+    f32x4 fxq, frq;                                  // x and residual of this lane's flush position
+    h16x8 Bu, Bul, Bus;                              // LINW: h tile w of the chunk's own positions (XPS: hi, lo, 2^-11 hi)
+    if constexpr (XPS) {
+      const char* __restrict__ shp = SHP[sbuf];
+      const char* __restrict__ shu = SHU[sbuf];
+      const char* __restrict__ sup = SUP[sbuf];
+      const h16x8 dn8 = {(_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn,
+                         (_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn, (_Float16)kLoDn};
+      // ---- dU first: it needs nothing but the (prefetched) dgates ----
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        f32x4 du[CK], dux[CK];
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) { du[ct] = zero4(); dux[ct] = zero4(); }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int ct = 0; ct < CK; ++ct) {
+            dux[ct] = mfma_h(Awt[ct][m].hi, cur.d8l[sb][m], dux[ct]);
+            du[ct] = mfma_h(Awt[ct][m].lo, cur.d8[sb][m], du[ct]);
+            du[ct] = mfma_h(Awt[ct][m].hi, cur.d8[sb][m], du[ct]);
+          }
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) du[ct][r] = __builtin_fmaf(dux[ct][r], kLoDn, du[ct][r]);
+          st4(&R[buf][w][sb][ct][lane][0], du[ct]);
+        }
+      }
+      // ---- weight gradients: 3 products per MAC ----
+      h16x8 Aoh[4], Aol[4];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { Aoh[nt][kk] = cur.a4[kk][nt]; Aol[nt][kk] = cur.a4l[kk][nt]; }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          csum[nt] = __builtin_amdgcn_fdot2(h16x2{Aoh[nt][2 * pr], Aoh[nt][2 * pr + 1]}, ones, csum[nt], false);
+          csumx[nt] = __builtin_amdgcn_fdot2(h16x2{Aol[nt][2 * pr], Aol[nt][2 * pr + 1]}, ones, csumx[nt], false);
+        }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        h16x8 bh, bl;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          if (kt < CK) {
+            if constexpr (CK == 2) {
+              const h16x4 up = *reinterpret_cast<const h16x4*>(sup + (8 * q + kk) * UROW + 8 * j);      // (hi0, hi1, lo0, lo1)
+              bh[kk] = up[kt < CK ? kt : 0]; bl[kk] = up[2 + (kt < CK ? kt : 0)];
+            } else {
+              const h16x2 up = *reinterpret_cast<const h16x2*>(sup + (8 * q + kk) * UROW + 4 * j);      // (hi, lo)
+              bh[kk] = up[0]; bl[kk] = up[1];
+            }
+          } else {
+            const h16x8 hp = *reinterpret_cast<const h16x8*>(shp + (8 * q + kk) * HROW + 16 * j);       // (hi x 4, lo x 4)
+            bh[kk] = hp[kt >= CK ? kt - CK : 0]; bl[kk] = hp[4 + (kt >= CK ? kt - CK : 0)];
+          }
+        }
+        const h16x8 bs = bh * dn8;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt][kt] = mfma_h(Aol[nt], bs, acc[nt][kt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt][kt] = mfma_h(Aoh[nt], bl, acc[nt][kt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt][kt] = mfma_h(Aoh[nt], bh, acc[nt][kt]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {             // unit 4j + w of the chunk's own positions: (hi, lo) at halves w, 4 + w
+        const _Float16* hu = reinterpret_cast<const _Float16*>(shu + (8 * q + kk) * HROW + 16 * j);
+        Bu[kk] = hu[w];
+        Bul[kk] = hu[4 + w];
+      }
+      Bus = Bu * dn8;
+      fxq = ld4(reinterpret_cast<const float*>(&SX[sbuf][(16 * fsb + fjj) * UROW + 4 * fcol]));
+      frq = ld4(reinterpret_cast<const float*>(&SR[sbuf][(16 * fsb + fjj) * UROW + 4 * fcol]));
+      sbuf ^= 1;                                     // the next iteration's chunk sits in the other buffer
+    } else {
     // ---- weight gradients: 4 gate tiles x (CK + 4) column tiles, K = 32 positions ----
     // u (LayerNorm output) and h_prev enter as single fp16 terms: like the dgates they multiply, they carry 2^-12
     // relative rounding noise, unbiased and averaged over millions of positions in these sums
@@ -630,7 +795,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       for (int kt = 0; kt < KT; ++kt) acc[nt][kt] = mfma_h(Aop, Bop[kt], acc[nt][kt]);
     }
     // ---- dU = W_ih^T dgates for the two 16-position sub-tiles ----
-    const int buf = it & 1;
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       f32x4 du[CK];
@@ -647,24 +811,35 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       for (int ct = 0; ct < CK; ++ct) st4(&R[buf][w][sb][ct][lane][0], du[ct]);
     }
     if constexpr (LINW) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) Bu[kk] = cur.hu[kk][w];
+    }
+    fxq = cur.xq; frq = cur.rq;
+    }
+    if constexpr (LINW) {
       const bool valid = fact && cp0 + 16 * fsb + fjj < cpe;
       if (fact) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = valid ? cur.rq[r] : 0.f;
+          const float v = valid ? frq[r] : 0.f;
           dlb[r] += v;
-          DY[buf][fcol + r][16 * fsb + fjj] = (_Float16)(v * gS);
+          const _Float16 hh = (_Float16)(v * gS);
+          DY[buf][fcol + r][16 * fsb + fjj] = hh;
+          if constexpr (XPS) DYL[buf][fcol + r][16 * fsb + fjj] = (_Float16)__builtin_fmaf((float)hh, -kLoUp, v * gS * kLoUp);
         }
       }
     }
     __syncthreads();
     if constexpr (LINW) {
-      h16x8 Bu;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) Bu[kk] = cur.hu[kk][w];
-#pragma unroll
-      for (int ct = 0; ct < CK; ++ct)
-        lacc[ct] = mfma_h(*reinterpret_cast<const h16x8*>(&DY[buf][16 * ct + j][8 * q]), Bu, lacc[ct]);
+      for (int ct = 0; ct < CK; ++ct) {
+        const h16x8 dyh = *reinterpret_cast<const h16x8*>(&DY[buf][16 * ct + j][8 * q]);
+        if constexpr (XPS) {
+          lacc[ct] = mfma_h(*reinterpret_cast<const h16x8*>(&DYL[buf][16 * ct + j][8 * q]), Bus, lacc[ct]);
+          lacc[ct] = mfma_h(dyh, Bul, lacc[ct]);
+        }
+        lacc[ct] = mfma_h(dyh, Bu, lacc[ct]);
+      }
     }
     if constexpr (LNB) {
       const int rl = fqr * 16 + fjj;
@@ -672,7 +847,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       const bool valid = fact && pj < cpe;
       const f32x4 du4 = (ld4(&R[buf][0][fsb][fct][rl][0]) + ld4(&R[buf][1][fsb][fct][rl][0]) + ld4(&R[buf][2][fsb][fct][rl][0]) +
                          ld4(&R[buf][3][fsb][fct][rl][0])) * invS;
-      const f32x4 x4 = cur.xq;
+      const f32x4 x4 = fxq;
       const float mean = grp_sum(fact ? x4[0] + x4[1] + x4[2] + x4[3] : 0.f) * (1.0f / C);
       f32x4 xh;
       float sq = 0.f;
@@ -696,7 +871,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       f32x4 dx4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        dx4[r] = rstd * (gg[r] - m1 - xh[r] * m2) + cur.rq[r];
+        dx4[r] = rstd * (gg[r] - m1 - xh[r] * m2) + frq[r];
         if (valid) amax = fmaxf(amax, fabsf(dx4[r]));
       }
       if (valid) st4(a.dx + (int64_t)pj * C + fcol, dx4);
@@ -729,7 +904,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) part[(size_t)gate * Ktot + C + 4 * j + kt] = acc[nt][CK + kt][r] * invS;
     }
-    const float cs = quad_sum(csum[nt]);
+    const float cs = quad_sum(XPS ? __builtin_fmaf(csumx[nt], kLoDn, csum[nt]) : csum[nt]);
     if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
   }
   if constexpr (LNB) {
@@ -1129,7 +1304,7 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
   if (rec.ndir != 1 || sa.ndir != 1 || !sa.dx || !sa.d_lin_w || !sa.d_lin_b || !sa.gmax || !sa.u_f16 || !sa.hs_f16 ||
       !sa.ln_x || !sa.ln_g || !sa.ln_res || !sa.d_ln_g || !sa.d_ln_b || !sa.sched_status || (C != 16 && C != 32) ||
       slab_len < 2 || (slab_len & 1) || sa.shift_pos <= 0 || sa.seg_len != T * sa.shift_pos || sa.P % sa.seg_len != 0 ||
-      sa.seg_len < 32)
+      sa.seg_len < 32 || (sa.wide != 0) != (rec.wide != 0))
     return -1003;
   const int cus = device_cus(), idle = cus - ntiles;
   if (idle < 16) return -1003;
@@ -1151,7 +1326,9 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
   if (rc) return rc;
   sa.slab_flags = flags + 4; sa.slab_len = slab_len; sa.slab_need = ntiles;
   sa.started = flags; sa.chunk_counter = flags + 1; sa.nchunks = nch;
-#define SB_SO(CC, ST, G) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, true, true>), dim3(G), dim3(256), 0, ST, sa)
+#define SB_SO(CC, ST, G) do { \
+    if (sa.wide) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, true, true, true>), dim3(G), dim3(256), 0, ST, sa); \
+    else hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, true, true>), dim3(G), dim3(256), 0, ST, sa); } while (0)
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
   sa.guard = 1; sa.row_base = 0;
   if (C == 32) SB_SO(32, ss->s, g1); else SB_SO(16, ss->s, g1);

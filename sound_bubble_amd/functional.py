@@ -245,6 +245,14 @@ class InterFn(torch.autograd.Function):
             ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
         # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
         tg = [(gt("wi", wi), gt("wh", wh), gt("bi", bi), gt("bh", bh))]
+        if fuse and ops.BPTT == "wide" and ops.can_overlap_inter_bwd(geom, u, hs):
+            # wide form with fewer tiles than CUs: recurrence || stream kernel (two-term dgates through L2) instead of the fused
+            # single launch, which would leave the idle CUs idle
+            dx = ops.lstm_bwd_inter_overlapped(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
+                                               (gt("lin_w", lin_w), gt("lin_b", lin_b)),
+                                               (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)))
+            if dx is not None:
+                return ret(dx.view(B, T, F, Cc))
         if fuse and ops.can_fuse_stream(u, hs, geom):
             # recurrence + streaming part + the Linear's weight gradient in one launch (where it pays)
             ln = (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)) if (Cc == 16 and ops.FUSED_LN_BWD) else None

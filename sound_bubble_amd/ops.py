@@ -602,9 +602,14 @@ BWD_OVERLAP_SLAB = int(os.environ.get("SB_BWD_OVERLAP_SLAB", "32"))
 
 def can_overlap_inter_bwd(geom, u, hs):
     """the overlapped form pays when the recurrence leaves a good part of the chip idle and has enough slabs to pipeline"""
-    if not (BWD_OVERLAP and STREAM_LIN_WGRAD and FUSED_LN_BWD and DGATES_FP16 and _compact() and LSTM_MMA in (1, 2)
-            and can_fuse_linear_bwd() and u is not None and hs is not None and u.dtype == torch.float16
-            and hs.dtype == torch.float16 and u.shape[-1] in (16, 32)):
+    if _wide():               # wide form: u / hs are the (hi, lo) pair tensors
+        if not (BWD_OVERLAP and STREAM_LIN_WGRAD and FUSED_LN_BWD and LSTM_MMA == 1 and u is not None and hs is not None
+                and u.dtype == torch.float16 and hs.dtype == torch.float16 and u.shape[-1] in (32, 64)
+                and hs.shape[-1] == 2 * H):
+            return False
+    elif not (BWD_OVERLAP and STREAM_LIN_WGRAD and FUSED_LN_BWD and DGATES_FP16 and _compact() and LSTM_MMA in (1, 2)
+              and can_fuse_linear_bwd() and u is not None and hs is not None and u.dtype == torch.float16
+              and hs.dtype == torch.float16 and u.shape[-1] in (16, 32)):
         return False
     if torch.cuda.is_current_stream_capturing():
         return False
@@ -625,19 +630,22 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
     P = geom.P
     F_ = geom.n_inner
     gmax = absmax_or_hint(dy)
-    dg = torch.empty(P, 1, 4, H, device=dev, dtype=torch.float16)
+    wide = rec.dtype == torch.float32                  # wide form: dgates rows [hi x 256 | scaled lo x 256] halves
+    dg = torch.empty(P, 1, 8 if wide else 4, H, device=dev, dtype=torch.float16)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 1
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
     a.w_hh[0] = _p(w_hh)
     a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), C.c_void_p(cprev.data_ptr())
     a.dgates, a.gmax, a.mma = C.c_void_p(dg.data_ptr()), _p(gmax), LSTM_MMA
+    a.wide = 1 if wide else 0
     a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
     s = L.LstmStreamArgs()
     s.P, s.ndir, s.C = P, 1, Cc
     s.shift_pos, s.seg_len, s.skip = F_, geom.nsteps * F_, F_
     s.dgates, s.u, s.hs = C.c_void_p(dg.data_ptr()), _ph(u), _ph(hs)
     s.gmax, s.u_f16, s.hs_f16, s.split_bf16 = _p(gmax), 1, 1, 1
+    s.wide = 1 if wide else 0
     s.w_ih[0] = _p(w_ih)
     s.dW_ih[0], s.dW_hh[0], s.db_ih[0], s.db_hh[0] = (_p(t) for t in targets)
     dx = torch.empty(P, Cc, device=dev, dtype=torch.float32)
@@ -653,8 +661,8 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
         s.absmax_out = _p(gm)
     slab = BWD_OVERLAP_SLAB
     flags = torch.empty((geom.nsteps + slab - 1) // slab + 4, device=dev, dtype=torch.int32)      # + 4 control words
-    by = P * (640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc + 4 * 4.0 * Cc)
-    with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)",
+    by = P * ((1280.0 + 3 * 1024.0 + 256 * 2 + 4.0 * Cc if wide else 640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc) + 4 * 4.0 * Cc)
+    with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)" + (" [wide]" if wide else ""),
                (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P, 8.0 * Cc * P, by):
         rc = lib.sb_lstm_bwd_inter_overlapped(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab, _stream())
         if rc == -1009:                    # no side stream (any more): the caller takes the two plain launches

@@ -69,7 +69,9 @@ class StreamingSeparator(torch.nn.Module):
         self.out = None
         self.graph = None
         self._param_key = None
+        self._feeds, self._dirty = 0, False
         self.use_graph = use_graph
+        model.register_load_state_dict_post_hook(lambda *_: setattr(self, "_dirty", True))
 
     def _inputs(self):
         d = {"mixture": self.frame}
@@ -111,11 +113,16 @@ class StreamingSeparator(torch.nn.Module):
         if not self.use_graph:
             return self._step_inplace()
         # the graph holds the addresses of the parameters: re-capture when one was replaced (load_state_dict(assign=True),
-        # module.weight = ...); in-place updates need nothing -- the weight-form refresh is one of the captured launches
-        key = tuple((id(p), p.data_ptr()) for p in self.model.parameters())
-        if self.graph is None or key != self._param_key:
-            self._capture()
-            self._param_key = key
+        # module.weight = ...); in-place updates need nothing -- the weight-form refresh is one of the captured launches.
+        # Walking all parameters costs ~50 us of Python, a sixth of a chunk: done after every load_state_dict (hook) and
+        # every 256th feed, not per chunk.
+        self._feeds += 1
+        if self.graph is None or self._dirty or (self._feeds & 255) == 0:
+            key = tuple((id(p), p.data_ptr()) for p in self.model.parameters())
+            if self.graph is None or key != self._param_key:
+                self._capture()
+                self._param_key = key
+            self._dirty = False
         self.graph.replay()
         return self.out
 

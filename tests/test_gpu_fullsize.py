@@ -111,7 +111,12 @@ def test_full_size_default_dispatch_matches_oracle(wl):
         # the dispatch this geometry is meant to take
         if mode == "wide":
             assert any("intra-frame fused BPTT" in k and "[wide]" in k for k in labels), labels
-            assert any("inter-frame fused BPTT" in k and "[wide]" in k for k in labels), labels
+            # small: fused inter-frame BPTT (290 tiles); big: 145 tiles -> recurrence || stream kernel when the box offers
+            # a concurrent side stream, the fused launch otherwise
+            assert any(("inter-frame fused BPTT" in k or "inter overlapped" in k) and "[wide]" in k for k in labels), labels
+            if wl == "big" and ops.overlap_available():
+                assert any("inter overlapped" in k and "[wide]" in k for k in labels), labels
+                assert any("[producer]" in k for k in labels) and any("[consumer, overlapped]" in k for k in labels), labels
         elif wl == "big" and ops.overlap_available():
             assert any("inter overlapped" in k for k in labels), labels          # overlapped backward pair
             assert any("[producer]" in k for k in labels) and any("[consumer, overlapped]" in k for k in labels), labels

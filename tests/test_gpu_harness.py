@@ -208,12 +208,12 @@ def test_weight_forms_follow_parameter_updates(torch_gpu):
     with torch.no_grad():
         y0 = m(x)["output"].clone()
         wf = m._weight_forms()
-        key0 = wf._key
+        src0 = wf.source_key()
         y1 = m(x)["output"]
-        assert wf._key == key0 and torch.equal(y0, y1)                 # nothing changed: no re-gather, same result
-        m.tfgridnet.blocks[0].conv.weight.mul_(1.5)                    # torch in-place update: version counter
+        assert wf.source_key() == src0 and torch.equal(y0, y1)        # nothing changed: same job table, same result
+        m.tfgridnet.blocks[0].conv.weight.mul_(1.5)                    # torch in-place update
         y2 = m(x)["output"].clone()
-        assert wf._key != key0 and not torch.equal(y2, y0)
+        assert wf.source_key() == src0 and not torch.equal(y2, y0)     # same addresses, fresh forms (refresh at every forward)
         bucket = FlatBucket(m)                                         # parameters move into the flat bucket
         y3 = m(x)["output"]
         assert torch.equal(y3, y2)

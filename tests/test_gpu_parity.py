@@ -1170,10 +1170,57 @@ def test_overlapped_paths_fall_back_when_the_side_stream_is_gone(torch_gpu, monk
     key = (torch.cuda.current_device(), ops._stream().value)
     try:
         L.load().sb_overlap_shutdown()
-        monkeypatch.setitem(ops._OVERLAP_OK, key, True)          # the Python side still believes in the side stream
+        ops._OVERLAP_OK[key] = True                              # the Python side still believes in the side stream
         g1 = grads()
         assert ops._OVERLAP_OK[key] is False                     # ... until the first -1009
     finally:
         ops._OVERLAP_OK.clear()
     for k in g0:
         assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-5, k
+
+
+@pytest.mark.parametrize("C_,slab", [(32, 32), (32, 6), (16, 10)])
+def test_wide_overlapped_inter_backward_matches_the_fused_wide_launch(torch_gpu, C_, slab, monkeypatch):
+    """sb_lstm_bwd_inter_overlapped in the WIDE form (lstm_bwd_rec_bf_kernel<.., SLAB, XP> publishing two-term dgates rows,
+    lstm_bwd_stream_f16_kernel<.., XPS> drawing chunk units next to and behind it) against the fused wide launch
+    (sb_lstm_bwd_rec with wpart) followed by sb_ln_bwd: dx, every weight / bias gradient, the LayerNorm and Linear riders.
+    Ragged geometry as in the compact test."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    monkeypatch.setattr(ops, "BPTT", "wide")
+    if not ops.wide_supported("inter", C_):
+        pytest.skip("wide fused kernels switched off")
+    if not ops.overlap_available():
+        pytest.skip("no side stream that runs concurrently with the main stream on this box")
+    monkeypatch.setattr(ops, "BWD_OVERLAP_SLAB", slab)
+    torch.manual_seed(23)
+    B_, T_, F_ = 2, 150, 21
+    geom = ops.Geom.inter(B_, T_, F_)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    wi, wh = torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2
+    dirs = [(wi, wh, torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1)]
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    y = torch.empty(geom.P, C_, device="cuda")
+    hs, _, gates, u = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, y))
+    dy = torch.randn(geom.P, C_, device="cuda") * 0.01 * torch.logspace(-2, 0, geom.P, device="cuda")[:, None]
+
+    def targets():
+        return ([torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+                 torch.zeros(256, device="cuda")], (torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")),
+                (torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")))
+
+    tg0, lin0, ln0 = targets()
+    du = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg0, lin_targets=lin0)
+    dx0, _, _, _ = ops.ln_bwd(du.view(geom.P, 1, C_), x, g, res=dy, d_g=ln0[0], d_b=ln0[1])
+    tg1, lin1, ln1 = targets()
+    ops.absmax_hints_clear()
+    dx1 = ops.lstm_bwd_inter_overlapped(wh, gates, geom, dy, lin_w, u, hs, wi, tg1, lin1, (x, g, ln1[0], ln1[1]))
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    assert dx1 is not None and rel_l2(dx1.cpu().numpy(), dx0.cpu().numpy()) < 2e-6
+    for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh", "dW_lin", "db_lin", "d_ln_g", "d_ln_b"),
+                            tg1 + list(lin1) + list(ln1), tg0 + list(lin0) + list(ln0)):
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 5e-6, name
+    if ops.ABSMAX_HINTS:
+        assert float(ops.absmax_or_hint(dx1)) == float(dx1.abs().max())
