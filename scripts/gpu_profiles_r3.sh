@@ -1,0 +1,21 @@
+#!/bin/bash
+# round-3 evidence: rocprofv3 kernel-trace stats (wide = default mode: big, small; compact: big) and PMC passes (separate
+# passes, never combined with sys/hip/hsa trace domains) of the default-mode train step
+R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
+prof() { # name, bench args
+  cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$1" -o k -- python "$R/bench.py" $2 --no-cpu-baseline --no-exact > "$R/gpurun_out/prof_$1.log" 2>&1
+}
+prof big_wide "--steps 3 --warmup 1 --workload big"
+prof small_wide "--steps 5 --warmup 2 --workload small"
+prof big_compact "--steps 3 --warmup 1 --workload big --bptt compact"
+pmc() { # workload
+  WL=$1; ARGS="--steps 2 --warmup 1 --workload $WL --no-cpu-baseline --no-exact"
+  cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch_$WL" -o f -- python "$R/bench.py" $ARGS > "$R/gpurun_out/pmc_fetch_$WL.log" 2>&1
+  cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write_$WL" -o w -- python "$R/bench.py" $ARGS > "$R/gpurun_out/pmc_write_$WL.log" 2>&1
+  cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d "$R/gpurun_out/pmc_sq_$WL" -o s -- python "$R/bench.py" $ARGS > "$R/gpurun_out/pmc_sq_$WL.log" 2>&1
+  cd "$R"; python scripts/pmc_summary.py $WL "$R/gpurun_out" "$R/gpurun_out/pmc_traffic_${WL}_wide.json" "$R/gpurun_out/pmc_sq_${WL}_wide.json" > "$R/gpurun_out/pmc_summary_$WL.log" 2>&1
+}
+pmc big
+pmc small
+cd "$R"; find gpurun_out -name "*kernel_trace.csv" -size +30M -delete; find gpurun_out -name "*counter_collection.csv" -size +20M -delete; find gpurun_out -name "*.db" -delete
+ls gpurun_out | head -50

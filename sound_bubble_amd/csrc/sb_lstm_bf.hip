@@ -722,10 +722,20 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 // incoming gradient), and its products are accumulated apart and folded in with the factor 2^-11 (recurrence, du) or
 // meet an operand that carries the factor (dW: the hi terms of u / h_prev times 2^-11).  u, h_prev and the weights are
 // fp16 hi + lo.  Three products per MAC instead of one, dgates tile in LDS twice the size, records twice the bytes.
+// SPLIT (FST > 0, no SEG / LNB): ROLE-SPLIT workgroup of 8 waves, two per SIMD.  Waves 0..3 run the recurrence (the serial
+// chain: records in, cell backward, W_hh^T dgates, the partial-sum exchange) and leave the dgates of a step in the LDS
+// tiles; waves 4..7 run the chunk arithmetic of the PREVIOUS pair of steps (dW_ih / dW_hh / db, du, the Linear's weight
+// gradient) from those tiles, u / h_prev from HBM.  Measured on the one-role kernel: the chunk arithmetic is ~70 % of its
+// instructions and none of it is on the serial chain, yet a single wave per SIMD issues it in line (SQ: 40 % VALU-active,
+// 50 % stalled, nothing to hide behind), and its 500+ registers force ~500 AGPR copies per pair.  Split, each role fits
+// 256 registers, the chunk role fills the recurrence role's stalls, and the copies are gone.  Both roles pass the same
+// two workgroup barriers per pair: the recurrence's partial-sum exchange barriers double as the hand-over points.
 template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
-          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false>
-__global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
+          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
+  static_assert(!SPLIT || (FST > 0 && !SEG && !LNB && !RECOMP && !SLAB), "role split: fused forms without segments / LayerNorm rider");
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, q = lane >> 4, j = lane & 15;
+  const bool crole = SPLIT && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;       // chunk role (waves 4..7)
   const int dir = blockIdx.y;
   const int S = a.nsteps, ndir = a.ndir;
   const bool rev = dir == 1;
@@ -734,7 +744,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   constexpr int CK = FST > 0 ? FST / 16 : 1, KT = CK + 4;
   __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
   __shared__ __attribute__((aligned(16))) _Float16 DGL[XP ? 4 : 1][XP ? 16 : 1][XP ? DGP : 8];      // XP: the scaled low terms
-  __shared__ __attribute__((aligned(16))) float R[FST > 0 ? 2 : 1][4][2][CK][FST > 0 ? 64 : 1][4];
+  // AWL (role split, wide form): the chunk role is 40 registers over its 256 -- W_ih^T (hi, lo) moves to LDS (read once per
+  // chunk), dy for the Linear's weight gradient is fetched late (behind the dW products), and the du exchange buffer needs
+  // no double buffering there (its reduction and the next write are two barriers apart), which pays for the LDS
+  constexpr bool AWL = SPLIT && XP;
+  __shared__ __attribute__((aligned(16))) float R[FST > 0 ? (AWL ? 1 : 2) : 1][4][2][CK][FST > 0 ? 64 : 1][4];
+  __shared__ __attribute__((aligned(16))) h16x8 AW[AWL ? 4 : 1][AWL ? CK : 1][2][2][AWL ? 64 : 1];
   // SLAB: the step's 16 dgates rows are assembled here so that they leave as whole 512-byte rows (write-through stores of
   // the 32-byte pieces each lane holds would reach HBM as partial lines)
   __shared__ __attribute__((aligned(16))) _Float16 DS[SLAB ? 2 : 1][SLAB ? 16 : 1][SLAB ? 4 * H + 8 : 8];
@@ -877,7 +892,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   struct PairOps { h16x4 hh4[H32 || HSP ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 && !XP ? 8 : 1]; _Float16 uh1[CK == 2 || XP ? 1 : 8];
                    h16x8 hp8[HSP ? 8 : 1];                    // XP + HSP: h_prev units 4j .. 4j + 3 as (hi x 4, lo x 4)
                    h16x4 up4[XP && CK == 2 ? 8 : 1]; h16x2 up2[XP && CK == 1 ? 8 : 1];   // XP: u channels (2j, 2j + 1) / j as (hi.., lo..)
-                   float dyv[CK][LINW ? 8 : 1];
+                   float dyv[CK][LINW && !AWL ? 8 : 1];
                    float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
   static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
   // LNB: the du tile is formed TRANSPOSED (positions as rows, channels as columns: the two MFMA operands swapped), so a
@@ -920,7 +935,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
       } else if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
       else o.uh1[kk] = u16[pos * FST + j];
       // the Linear's weight gradient pairs h of a position with dy of the SAME position (the h_prev row's)
-      if constexpr (LINW) {
+      if constexpr (LINW && !AWL) {
 #pragma unroll
         for (int ct = 0; ct < CK; ++ct) o.dyv[ct][kk] = dyj[posh * FST + 16 * ct];
       }
@@ -936,12 +951,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
     }
     return o;
   };
+  auto load_dyv = [&](int sa, bool two, float (&dv)[CK][LINW ? 8 : 1]) {      // AWL: dy of the h_prev rows' positions, late
+    if constexpr (LINW) {
+      const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
+      const int sth = st_of(sw > 0 ? sw - 1 : sw);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int64_t posh = (int64_t)posb[kk] + (int64_t)sth * a.p_step;
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) dv[ct][kk] = dyj[posh * FST + 16 * ct];
+      }
+    }
+  };
   const h16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
   // chunk arithmetic on the dgates rows in LDS slots (sl, sl + 1); du partial sums -> R[buf]
   // steady (uniform): a full pair of steps away from walk index 0 -- every h_prev row exists, and the per-lane masks
   // (~50-90 v_cndmask per chunk) sit in blocks behind a uniform branch (the empty asm keeps hipcc from turning the branch
   // back into selects)
-  auto chunk = [&](int sl, int buf, const PairOps& o, int sa, bool two) {
+  // phase: -1 everything (one-role kernel); SPLIT: 0 = du only (before the hand-over barrier), 1 = the rest
+  auto chunk = [&](int sl, int buf, const PairOps& o, int sa, bool two, int phase = -1) {
     const bool steady = two && sa >= 2;
     const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
     const bool hp = sw > 0;
@@ -966,11 +994,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
           al[kk] = (_Float16)__builtin_fmaf((float)hh, -kLoUp, v[kk] * kLoUp);
         }
       };
-      // h_prev tiles kt = 0..3 (units 4j + kt of the 8 k-slots) as matrix operands: hi, lo, 2^-11 hi
-      h16x8 hBh[4], hBl[4], hBs[4];
+      if (phase != 0) {
+      // h_prev tile kt (units 4j + kt of the 8 k-slots) as matrix operands hi, lo, 2^-11 hi -- built on demand from the
+      // (masked) pairs: materialising all four tiles up front costs 48 registers the role-split kernel does not have
+      h16x8 hpm[HSP ? 8 : 1];
       if constexpr (HSP) {
         const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        h16x8 hpm[8];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) hpm[kk] = o.hp8[kk];
         if (!steady) {
@@ -978,31 +1007,41 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) hpm[kk] = hp ? hpm[kk] : hz8;
         }
+      }
+      auto htile = [&](auto kt_tag, h16x8& bh, h16x8& bl, h16x8& bs) {
+        constexpr int kt = decltype(kt_tag)::value;
+        if constexpr (HSP) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) { hBh[kt][kk] = hpm[kk][kt]; hBl[kt][kk] = hpm[kk][4 + kt]; }
-        }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) hBs[kt] = hBh[kt] * dn8;
-      } else {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+          for (int kk = 0; kk < 8; ++kk) { bh[kk] = hpm[kk][kt]; bl[kk] = hpm[kk][4 + kt]; }
+          bs = bh * dn8;
+        } else {
           float v[8];
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) v[kk] = hp ? o.hh32[kk][kt] : 0.f;
-          split3(v, hBh[kt], hBl[kt], hBs[kt]);
+          split3(v, bh, bl, bs);
+        }
+      };
+      float dyl[CK][LINW ? 8 : 1];
+      if constexpr (LINW) {
+        if constexpr (AWL) load_dyv(sa, two, dyl);
+        else {
+#pragma unroll
+          for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) dyl[ct][kk] = o.dyv[ct][kk];
         }
       }
-      if constexpr (LINW) {                          // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
-        const h16x8 bwh = w == 0 ? hBh[0] : (w == 1 ? hBh[1] : (w == 2 ? hBh[2] : hBh[3]));
-        const h16x8 bwl = w == 0 ? hBl[0] : (w == 1 ? hBl[1] : (w == 2 ? hBl[2] : hBl[3]));
-        const h16x8 bws = w == 0 ? hBs[0] : (w == 1 ? hBs[1] : (w == 2 ? hBs[2] : hBs[3]));
+      auto do_linw = [&]() {                         // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
+        h16x8 bwh, bwl, bws;
+        if (w == 0) htile(std::integral_constant<int, 0>{}, bwh, bwl, bws);          // (uniform branches)
+        else if (w == 1) htile(std::integral_constant<int, 1>{}, bwh, bwl, bws);
+        else if (w == 2) htile(std::integral_constant<int, 2>{}, bwh, bwl, bws);
+        else htile(std::integral_constant<int, 3>{}, bwh, bwl, bws);
 #pragma unroll
         for (int ct = 0; ct < CK; ++ct) {
           float dv8[8];
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) dv8[kk] = o.dyv[ct][kk] * gS;
+          for (int kk = 0; kk < 8; ++kk) dv8[kk] = dyl[ct][kk] * gS;
           if (!FULL || !steady) {                    // slots of a missing second step / of sequences beyond nseq must not count
             asm volatile("");
 #pragma unroll
@@ -1019,7 +1058,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
           lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adh, bwl, lacc[ct], 0, 0, 0);
           lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adh, bwh, lacc[ct], 0, 0, 0);
         }
-      }
+      };
+      if constexpr (LINW && !AWL) do_linw();
       // dgates of this lane's 8 k-slots, gate columns 64w + 4j .. + 3: hi and scaled low terms
       h16x8 Aoh[4], Aol[4];
 #pragma unroll
@@ -1047,7 +1087,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
           }
           bs = bh * dn8;
         } else {
-          bh = hBh[kt >= CK ? kt - CK : 0]; bl = hBl[kt >= CK ? kt - CK : 0]; bs = hBs[kt >= CK ? kt - CK : 0];
+          if (kt == CK) htile(std::integral_constant<int, 0>{}, bh, bl, bs);
+          else if (kt == CK + 1) htile(std::integral_constant<int, 1>{}, bh, bl, bs);
+          else if (kt == CK + 2) htile(std::integral_constant<int, 2>{}, bh, bl, bs);
+          else htile(std::integral_constant<int, 3>{}, bh, bl, bs);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aol[nt], bs, wacc[nt][kt], 0, 0, 0);
@@ -1056,6 +1099,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bh, wacc[nt][kt], 0, 0, 0);
       }
+      if constexpr (LINW && AWL) do_linw();
+      }
+      if (phase != 1)
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         f32x4 du[CK], dux[CK];
@@ -1072,9 +1118,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
               du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].lo, du[ct], 0, 0, 0);
               du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].hi, du[ct], 0, 0, 0);
             } else {
-              dux[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8l, dux[ct], 0, 0, 0);
-              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].lo, d8, du[ct], 0, 0, 0);
-              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8, du[ct], 0, 0, 0);
+              const h16x8 awh = AWL ? AW[w][ct][m][0][lane] : Awt[ct][m].hi, awl = AWL ? AW[w][ct][m][1][lane] : Awt[ct][m].lo;
+              dux[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(awh, d8l, dux[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(awl, d8, du[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(awh, d8, du[ct], 0, 0, 0);
             }
           }
         }
@@ -1086,6 +1133,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
         }
       }
     } else {
+    if (phase != 0) {
     h16x8 Bop[KT];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -1151,6 +1199,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aop, Bop[kt], wacc[nt][kt], 0, 0, 0);
     }
+    }
+    if (phase != 1)
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
       f32x4 du[CK];
@@ -1600,6 +1650,78 @@ __global__ __launch_bounds__(256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a
   };
   const int ntiles = (a.nseq + 15) / 16;
   const int nitems = SEG ? ntiles * a.seg_count : ntiles;          // !SEG: gridDim.x == ntiles, one item each
+  if constexpr (SPLIT) {
+    // Periods of two barriers.  Recurrence role, period k: the two steps of pair k (dgates -> LDS slots 2 (k & 1), + 1); after
+    // the last pair one empty period.  Chunk role, period 0: the Linear's top row; period k >= 1: the chunk of pair k - 1
+    // (du before the first barrier, its 4-wave reduction + dW + dW_lin after it).  The slots of pair k - 1 are rewritten in
+    // period k + 1, behind the second barrier of period k.  The role branch sits OUTSIDE the tile loop: inside it the
+    // compiler would keep each role's loop-carried registers (dW sums; weights) alive through the other role's body.
+    const int npairs = (S + 1) / 2;                                // the last pair may be a single step (odd S)
+    if (!crole) {
+      for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        set_tile(item);
+        dc = zero4();
+        dhrec = zero4();
+        // records ONE step ahead (two in the one-role kernel: 56 registers this role does not have; along the intra-frame
+        // walk consecutive steps are adjacent in memory, and a step is ~2 us)
+        Raw nxt = load_raw(S - 1);
+        int s = S - 1;
+        for (int k = 0; k < npairs; ++k, s -= 2) {
+          Raw curA = nxt;
+          consume(curA);
+          __builtin_amdgcn_sched_barrier(0);
+          nxt = load_raw(max(s - 1, 0));
+          __builtin_amdgcn_sched_barrier(0);
+          step(s, curA, 2 * (k & 1));
+          if (s >= 1) {
+            Raw curB = nxt;
+            consume(curB);
+            __builtin_amdgcn_sched_barrier(0);
+            nxt = load_raw(max(s - 2, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            step(s - 1, curB, 2 * (k & 1) + 1);
+          } else {                                                 // odd step count: an empty second half
+            const h16x4 hz = {0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              *reinterpret_cast<h16x4*>(&DG[2 * (k & 1) + 1][j][g * H + uoff]) = hz;
+              if constexpr (XP) *reinterpret_cast<h16x4*>(&DGL[2 * (k & 1) + 1][j][g * H + uoff]) = hz;
+            }
+            __syncthreads();
+          }
+        }
+        __syncthreads();                                           // the chunk role's last period
+        __syncthreads();
+        __syncthreads();                                           // between tiles
+      }
+      return;
+    }
+    if constexpr (AWL) {                                           // (read back by this wave only: no barrier needed)
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { AW[w][ct][m][0][lane] = Awt[ct][m].hi; AW[w][ct][m][1][lane] = Awt[ct][m].lo; }
+    }
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      set_tile(item);
+      if constexpr (LINW) lin_top();
+      __syncthreads();
+      __syncthreads();
+      int s = S - 1;
+      const float nox[2] = {0.f, 0.f};
+      for (int k = 1; k <= npairs; ++k, s -= 2) {                  // chunk of pair k - 1: steps (s, s - 1)
+        const bool two = s >= 1;
+        const int pb = (k - 1) & 1, rb = AWL ? 0 : pb;
+        const PairOps ops2 = pair_loads(s, two);
+        chunk(2 * pb, rb, ops2, s, two, 0);                        // du partial sums -> R[rb]
+        __syncthreads();
+        flush(s, two ? 2 : 1, rb, nox, nox);
+        chunk(2 * pb, rb, ops2, s, two, 1);
+        __syncthreads();
+      }
+      __syncthreads();                                             // between tiles
+    }
+  } else
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int seg = SEG ? item / ntiles : 0;
     const int tile = SEG ? item - seg * ntiles : item;
@@ -1908,9 +2030,21 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     dim3 g2(gx, 2);
 #define SB_FB(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_>), g2, block, 0, st, a)
 #define SB_FBX(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC_, true, false, CC, false, true, false, false, false, true>), g2, block, 0, st, a)
-    if (wide) {
+#define SB_FBXS(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC_, true, false, CC, false, true, false, false, false, true, true>), g2, dim3(512), 0, st, a)
+#define SB_FBS(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_, false, false, false, true>), g2, dim3(512), 0, st, a)
+    if (a.split && a.recompute) return -1003;
+    if (wide && a.split) {                            // role-split workgroups (8 waves): see the kernel
+      if (a.C == 16 && fc == 0) { if (full) SB_FBXS(true, 0, 16); else SB_FBXS(false, 0, 16); }
+      else if (a.C == 32 && fc == 32) { if (full) SB_FBXS(true, 32, 32); else SB_FBXS(false, 32, 32); }
+      else return -1003;
+    } else if (wide) {
       if (a.C == 16 && fc == 0) { if (full) SB_FBX(true, 0, 16); else SB_FBX(false, 0, 16); }
       else if (a.C == 32 && fc == 32) { if (full) SB_FBX(true, 32, 32); else SB_FBX(false, 32, 32); }
+      else return -1003;
+    } else if (a.split) {
+      if (a.C == 16 && fc == 0 && !a.hs_f16) { if (full) SB_FBS(true, 0, 16, false); else SB_FBS(false, 0, 16, false); }
+      else if (a.C == 32 && fc == 32 && !a.hs_f16) { if (full) SB_FBS(true, 32, 32, false); else SB_FBS(false, 32, 32, false); }
+      else if (a.C == 32 && fc == 32) { if (full) SB_FBS(true, 32, 32, true); else SB_FBS(false, 32, 32, true); }
       else return -1003;
     } else
     if (a.C == 16 && fc == 0 && !a.hs_f16) { if (full) SB_FB(true, 0, 16, false); else SB_FB(false, 0, 16, false); }
@@ -1922,6 +2056,8 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
       else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, true, 32, true, false, 32, false, true, true, true>), g2, block, 0, st, a);
     }
     else return -1003;
+#undef SB_FBS
+#undef SB_FBXS
 #undef SB_FBX
 #undef SB_FB
     const int64_t ld = (int64_t)4 * H * (a.C + H) + 4 * H + (fc > 0 ? a.C * 2 * H + a.C : 0);

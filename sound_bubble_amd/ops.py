@@ -756,6 +756,9 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
 
 
 FUSED_BPTT_BI = os.environ.get("SB_NO_FUSED_BPTT_BI", "0") != "1"
+# ... with role-split workgroups: four recurrence waves + four chunk-arithmetic waves per workgroup, two waves per SIMD
+# (SB_NO_ROLE_SPLIT=1: the one-role kernel, 4 waves with 500+ registers each)
+ROLE_SPLIT = os.environ.get("SB_NO_ROLE_SPLIT", "0") != "1"
 
 
 def can_fuse_stream_bi(u, hs):
@@ -828,6 +831,7 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     a.save_c = C.c_void_p(cprev.data_ptr())
     a.gmax, a.mma = _p(gmax), LSTM_MMA
     a.wide = 1 if cprev.dtype == torch.float32 else 0
+    a.split = 1 if (ROLE_SPLIT and rec is not None) else 0
     if dy is not None:
         assert w_lin.shape == (Cc, 2 * H) and dy.shape[-1] == Cc
         a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
@@ -852,7 +856,8 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
                     + 8.0 * Cc) + hs.numel() * hs.element_size() + u.numel() * u.element_size())
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
-    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)" + (" [wide]" if a.wide else ""), fl,
+    with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)" + (" [wide]" if a.wide else "")
+               + (" [role-split]" if a.split else ""), fl,
                8.0 * Cc * geom.P, by):
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused, bidirectional)")
     return du
