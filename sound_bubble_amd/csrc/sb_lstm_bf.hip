@@ -744,12 +744,22 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   constexpr int CK = FST > 0 ? FST / 16 : 1, KT = CK + 4;
   __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
   __shared__ __attribute__((aligned(16))) _Float16 DGL[XP ? 4 : 1][XP ? 16 : 1][XP ? DGP : 8];      // XP: the scaled low terms
-  // AWL (role split, wide form): the chunk role is 40 registers over its 256 -- W_ih^T (hi, lo) moves to LDS (read once per
-  // chunk), dy for the Linear's weight gradient is fetched late (behind the dW products), and the du exchange buffer needs
-  // no double buffering there (its reduction and the next write are two barriers apart), which pays for the LDS
-  constexpr bool AWL = SPLIT && XP;
-  __shared__ __attribute__((aligned(16))) float R[FST > 0 ? (AWL ? 1 : 2) : 1][4][2][CK][FST > 0 ? 64 : 1][4];
-  __shared__ __attribute__((aligned(16))) h16x8 AW[AWL ? 4 : 1][AWL ? CK : 1][2][2][AWL ? 64 : 1];
+  // STG (role split, wide form with hs pairs: C = 32): the chunk role would be 40 registers over its 256 with the u /
+  // h_prev / dy rows of a chunk held in registers across the hand-over barrier (64 of them), and its spill traffic cost more
+  // than the split gained.  There the four chunk waves fetch those rows ONCE, cooperatively, at the top of the period (16
+  // registers per thread, dead before the barrier), park them in LDS and read their operands from there afterwards; rows
+  // that must not count (h_prev / dy of walk index 0, a missing second step, sequences beyond nseq) are zeroed on the way
+  // in, so the mask blocks are gone too.  The du exchange buffer needs no double buffering in the split kernel (its
+  // reduction and the next write are two barriers apart), which pays for the LDS.
+  constexpr bool STG = SPLIT && XP && FUSE_C > 0 && FST == 32;
+  // The rows travel by async global -> LDS copies (global_load_lds_dwordx4: no registers at all; destination = wave-uniform
+  // base + lane x 16 bytes, hence unpadded rows), issued one period ahead into the other buffer and waited for (vmcnt) just
+  // before the hand-over barrier of the period that reads them.
+  constexpr int SHROW = 256, SUROW = 4 * (FST > 0 ? FST : 16);                  // LDS rows (bytes)
+  __shared__ __attribute__((aligned(16))) float R[FST > 0 ? (STG ? 1 : 2) : 1][4][2][CK][FST > 0 ? 64 : 1][4];
+  __shared__ __attribute__((aligned(16))) char SHP[STG ? 2 : 1][STG ? 32 * SHROW : 16];   // h_prev pair rows of the chunk's 32 slots
+  __shared__ __attribute__((aligned(16))) char SUP[STG ? 2 : 1][STG ? 32 * SUROW : 16];   // u pair rows
+  __shared__ __attribute__((aligned(16))) char SDY[STG ? 2 : 1][STG ? 32 * SUROW : 16];   // dy rows of the h_prev positions (fp32)
   // SLAB: the step's 16 dgates rows are assembled here so that they leave as whole 512-byte rows (write-through stores of
   // the 32-byte pieces each lane holds would reach HBM as partial lines)
   __shared__ __attribute__((aligned(16))) _Float16 DS[SLAB ? 2 : 1][SLAB ? 16 : 1][SLAB ? 4 * H + 8 : 8];
@@ -796,6 +806,12 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     __syncthreads();
   }
 
+  // STG: this lane's pieces of a chunk's rows.  Wave w of the chunk role fetches slot rows 8w .. 8w + 7 (step sa - (w >> 1),
+  // sequences 8 (w & 1) ..): h rows 8w + (lane >> 4) and 8w + 4 + (lane >> 4), piece lane & 15; u / dy row 8w + (lane >> 3),
+  // piece lane & 7 -- so that one wave instruction fills one contiguous KB of LDS
+  int64_t stg_b[3] = {0, 0, 0};                   // step-0 positions of those three sequences (set_tile)
+  bool stg_v[3] = {false, false, false};
+  int stg_sel = 0;                                // LDS staging buffer of the chunk in hand
   bool valid = false;                            // per work item (tile): set_tile()
   int64_t base = 0, rec_tile = 0;
   int posb[FST > 0 ? 8 : 1];                      // FST: step-0 position of sequence 8 (q & 1) + kk (chunk slot 8q + kk)
@@ -821,6 +837,15 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         const int n3 = tile * 16 + 8 * (w & 1) + 2 * q + r;
         fvalid[r] = FULL || n3 < a.nseq;
         posq[r] = fvalid[r] ? (int)((int64_t)(n3 / a.n_inner) * a.p_outer + (int64_t)(n3 % a.n_inner) * a.p_inner) : 0;
+      }
+    }
+    if constexpr (STG) {
+      const int sq[3] = {8 * (w & 1) + (lane >> 4), 8 * (w & 1) + 4 + (lane >> 4), 8 * (w & 1) + (lane >> 3)};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int n = tile * 16 + sq[i];
+        stg_v[i] = FULL || n < a.nseq;
+        stg_b[i] = stg_v[i] ? (int64_t)(n / a.n_inner) * a.p_outer + (int64_t)(n % a.n_inner) * a.p_inner : 0;
       }
     }
     if constexpr (FST > 0) {
@@ -892,7 +917,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   struct PairOps { h16x4 hh4[H32 || HSP ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 && !XP ? 8 : 1]; _Float16 uh1[CK == 2 || XP ? 1 : 8];
                    h16x8 hp8[HSP ? 8 : 1];                    // XP + HSP: h_prev units 4j .. 4j + 3 as (hi x 4, lo x 4)
                    h16x4 up4[XP && CK == 2 ? 8 : 1]; h16x2 up2[XP && CK == 1 ? 8 : 1];   // XP: u channels (2j, 2j + 1) / j as (hi.., lo..)
-                   float dyv[CK][LINW && !AWL ? 8 : 1];
+                   float dyv[CK][LINW && !STG ? 8 : 1];
                    float xq[2], rq[2]; };           // LNB: x and dy (channel j) of this lane's two flush positions
   static_assert(!LNB || FST == 16, "fused LayerNorm backward: C = 16");
   // LNB: the du tile is formed TRANSPOSED (positions as rows, channels as columns: the two MFMA operands swapped), so a
@@ -935,7 +960,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       } else if constexpr (CK == 2) o.uh2[kk] = *reinterpret_cast<const h16x2*>(u16 + pos * FST + 2 * j);
       else o.uh1[kk] = u16[pos * FST + j];
       // the Linear's weight gradient pairs h of a position with dy of the SAME position (the h_prev row's)
-      if constexpr (LINW && !AWL) {
+      if constexpr (LINW && !STG) {
 #pragma unroll
         for (int ct = 0; ct < CK; ++ct) o.dyv[ct][kk] = dyj[posh * FST + 16 * ct];
       }
@@ -951,16 +976,34 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     }
     return o;
   };
-  auto load_dyv = [&](int sa, bool two, float (&dv)[CK][LINW ? 8 : 1]) {      // AWL: dy of the h_prev rows' positions, late
-    if constexpr (LINW) {
-      const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
-      const int sth = st_of(sw > 0 ? sw - 1 : sw);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const int64_t posh = (int64_t)posb[kk] + (int64_t)sth * a.p_step;
-#pragma unroll
-        for (int ct = 0; ct < CK; ++ct) dv[ct][kk] = dyj[posh * FST + 16 * ct];
-      }
+  // rows of the chunk of steps (sa, sa - 1) -> staging buffer sel.  Direct (async) copies when every row counts; else -- the
+  // last pair of a tile (h_prev / dy of walk index 0 are zero), a missing second step, a ragged tile -- through registers
+  // with the rows that must not count zeroed (rare: the stall does not matter)
+  auto stage_issue = [&](int sa, bool two, int sel, int tile) {
+    const int i = w >> 1;
+    const int sw = i == 0 ? sa : (two ? sa - 1 : sa);
+    const bool cnt = sw > 0 && (i == 0 || two);                    // uniform over the wave
+    const int64_t sp = (int64_t)st_of(sw) * a.p_step, sph = (int64_t)st_of(sw > 0 ? sw - 1 : sw) * a.p_step;
+    const float* gh0 = reinterpret_cast<const float*>(hs16 + ((stg_b[0] + sph) * LDH + (BI ? dir * H : 0)) * 2 + 8 * (lane & 15));
+    const float* gh1 = reinterpret_cast<const float*>(hs16 + ((stg_b[1] + sph) * LDH + (BI ? dir * H : 0)) * 2 + 8 * (lane & 15));
+    const float* gu = reinterpret_cast<const float*>(u16 + ((stg_b[2] + sp) * FST) * 2 + 8 * (lane & 7));
+    const float* gd = a.dy + (stg_b[2] + sph) * FST + 4 * (lane & 7);
+    char* lh = &SHP[sel][(8 * w) * SHROW];
+    char* lu = &SUP[sel][(8 * w) * SUROW];
+    char* ld = &SDY[sel][(8 * w) * SUROW];
+    const bool whole = FULL || tile * 16 + 16 <= a.nseq;
+    if (cnt && whole) {
+      __builtin_amdgcn_global_load_lds(gh0, (__attribute__((address_space(3))) void*)(lh), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gh1, (__attribute__((address_space(3))) void*)(lh + 4 * SHROW), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gu, (__attribute__((address_space(3))) void*)(lu), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gd, (__attribute__((address_space(3))) void*)(ld), 16, 0, 0);
+    } else {
+      const f32x4 z4 = zero4();
+      const f32x4 h0 = ld4(gh0), h1 = ld4(gh1), uu = ld4(gu), dd = ld4(gd);
+      st4(reinterpret_cast<float*>(lh + 16 * lane), (cnt && stg_v[0]) ? h0 : z4);
+      st4(reinterpret_cast<float*>(lh + 4 * SHROW + 16 * lane), (cnt && stg_v[1]) ? h1 : z4);
+      st4(reinterpret_cast<float*>(lu + 16 * lane), uu);
+      st4(reinterpret_cast<float*>(ld + 16 * lane), (cnt && stg_v[2]) ? dd : z4);
     }
   };
   const h16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
@@ -1000,12 +1043,17 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       h16x8 hpm[HSP ? 8 : 1];
       if constexpr (HSP) {
         const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (STG) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) hpm[kk] = o.hp8[kk];
-        if (!steady) {
-          asm volatile("");
+          for (int kk = 0; kk < 8; ++kk) hpm[kk] = *reinterpret_cast<const h16x8*>(&SHP[stg_sel][(8 * q + kk) * SHROW + 16 * j]);
+        } else {
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) hpm[kk] = hp ? hpm[kk] : hz8;
+          for (int kk = 0; kk < 8; ++kk) hpm[kk] = o.hp8[kk];
+          if (!steady) {
+            asm volatile("");
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) hpm[kk] = hp ? hpm[kk] : hz8;
+          }
         }
       }
       auto htile = [&](auto kt_tag, h16x8& bh, h16x8& bl, h16x8& bs) {
@@ -1023,13 +1071,13 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       };
       float dyl[CK][LINW ? 8 : 1];
       if constexpr (LINW) {
-        if constexpr (AWL) load_dyv(sa, two, dyl);
-        else {
 #pragma unroll
-          for (int ct = 0; ct < CK; ++ct)
+        for (int ct = 0; ct < CK; ++ct)
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) dyl[ct][kk] = o.dyv[ct][kk];
-        }
+          for (int kk = 0; kk < 8; ++kk) {
+            if constexpr (STG) dyl[ct][kk] = *reinterpret_cast<const float*>(&SDY[stg_sel][(8 * q + kk) * SUROW + 4 * (16 * ct + j)]);
+            else dyl[ct][kk] = o.dyv[ct][kk];
+          }
       }
       auto do_linw = [&]() {                         // dW_lin: A = dy^T (channel 16ct + j x 8 positions), B = h tile w
         h16x8 bwh, bwl, bws;
@@ -1042,8 +1090,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
           float dv8[8];
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) dv8[kk] = dyl[ct][kk] * gS;
-          if (!FULL || !steady) {                    // slots of a missing second step / of sequences beyond nseq must not count
-            asm volatile("");
+          if (!STG && (!FULL || !steady)) {          // slots of a missing second step / of sequences beyond nseq must not count
+            asm volatile("");                        // (STG: zeroed on the way into LDS)
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
               const bool dv = hp && (two || q < 2) && ((slotv >> kk) & 1u);
@@ -1059,7 +1107,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
           lacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(adh, bwh, lacc[ct], 0, 0, 0);
         }
       };
-      if constexpr (LINW && !AWL) do_linw();
+      if constexpr (LINW) do_linw();
       // dgates of this lane's 8 k-slots, gate columns 64w + 4j .. + 3: hi and scaled low terms
       h16x8 Aoh[4], Aol[4];
 #pragma unroll
@@ -1082,7 +1130,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         if (kt < CK) {
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) {
-            if constexpr (CK == 2) { bh[kk] = o.up4[kk][kt < CK ? kt : 0]; bl[kk] = o.up4[kk][2 + (kt < CK ? kt : 0)]; }
+            if constexpr (STG) {
+              const h16x4 up = *reinterpret_cast<const h16x4*>(&SUP[stg_sel][(8 * q + kk) * SUROW + 8 * j]);
+              bh[kk] = up[kt < CK ? kt : 0]; bl[kk] = up[2 + (kt < CK ? kt : 0)];
+            } else if constexpr (CK == 2) { bh[kk] = o.up4[kk][kt < CK ? kt : 0]; bl[kk] = o.up4[kk][2 + (kt < CK ? kt : 0)]; }
             else { bh[kk] = o.up2[kk][0]; bl[kk] = o.up2[kk][1]; }
           }
           bs = bh * dn8;
@@ -1099,7 +1150,6 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bh, wacc[nt][kt], 0, 0, 0);
       }
-      if constexpr (LINW && AWL) do_linw();
       }
       if (phase != 1)
 #pragma unroll
@@ -1118,10 +1168,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
               du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].lo, du[ct], 0, 0, 0);
               du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d8, Awt[ct][m].hi, du[ct], 0, 0, 0);
             } else {
-              const h16x8 awh = AWL ? AW[w][ct][m][0][lane] : Awt[ct][m].hi, awl = AWL ? AW[w][ct][m][1][lane] : Awt[ct][m].lo;
-              dux[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(awh, d8l, dux[ct], 0, 0, 0);
-              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(awl, d8, du[ct], 0, 0, 0);
-              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(awh, d8, du[ct], 0, 0, 0);
+              dux[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8l, dux[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].lo, d8, du[ct], 0, 0, 0);
+              du[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Awt[ct][m].hi, d8, du[ct], 0, 0, 0);
             }
           }
         }
@@ -1696,25 +1745,30 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       }
       return;
     }
-    if constexpr (AWL) {                                           // (read back by this wave only: no barrier needed)
-#pragma unroll
-      for (int ct = 0; ct < CK; ++ct)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) { AW[w][ct][m][0][lane] = Awt[ct][m].hi; AW[w][ct][m][1][lane] = Awt[ct][m].lo; }
-    }
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
       set_tile(item);
       if constexpr (LINW) lin_top();
+      if constexpr (STG) stage_issue(S - 1, S >= 2, 1, item);      // the first chunk's rows: read in period 1 (buffer 1)
       __syncthreads();
       __syncthreads();
       int s = S - 1;
       const float nox[2] = {0.f, 0.f};
       for (int k = 1; k <= npairs; ++k, s -= 2) {                  // chunk of pair k - 1: steps (s, s - 1)
         const bool two = s >= 1;
-        const int pb = (k - 1) & 1, rb = AWL ? 0 : pb;
-        const PairOps ops2 = pair_loads(s, two);
-        chunk(2 * pb, rb, ops2, s, two, 0);                        // du partial sums -> R[rb]
+        const int pb = (k - 1) & 1, rb = STG ? 0 : pb;
+        PairOps ops2;
+        if constexpr (STG) {
+          chunk(2 * pb, rb, ops2, s, two, 0);
+          __builtin_amdgcn_s_waitcnt(0);                           // this period's rows (issued a period ago) have landed
+        } else {
+          ops2 = pair_loads(s, two);
+          chunk(2 * pb, rb, ops2, s, two, 0);                      // du partial sums -> R[rb]
+        }
         __syncthreads();
+        if constexpr (STG) {
+          stg_sel = k & 1;
+          if (k < npairs) stage_issue(s - 2, s - 3 >= 0, (k + 1) & 1, item);     // the next period's rows, a period ahead
+        }
         flush(s, two ? 2 : 1, rb, nox, nox);
         chunk(2 * pb, rb, ops2, s, two, 1);
         __syncthreads();
