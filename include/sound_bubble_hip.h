@@ -186,7 +186,7 @@ typedef struct {
      fp16 hi + lo splits of u / h_prev / the weights -- three products per MAC, as in the forward kernels.  hs_f16 and
      recompute must be 0. */
   int wide;
-  /* Bidirectional fused forms (wpart != NULL, ndir == 2), compact or wide: split != 0 launches ROLE-SPLIT workgroups of 8 waves
+  /* Fused forms (wpart != NULL; single direction or bidirectional, compact or wide): split != 0 launches ROLE-SPLIT workgroups of 8 waves
      (two per SIMD): four run the recurrence, four the chunk arithmetic (dW, du, Linear weight gradient) of the previous pair
      of steps from the dgates tiles in LDS.  Same arithmetic, other summation order. */
   int split;

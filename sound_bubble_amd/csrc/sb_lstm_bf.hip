@@ -733,7 +733,7 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
           bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
-  static_assert(!SPLIT || (FST > 0 && !SEG && !LNB && !RECOMP && !SLAB), "role split: fused forms without segments / LayerNorm rider");
+  static_assert(!SPLIT || (FST > 0 && !RECOMP && !SLAB), "role split: fused forms");
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, q = lane >> 4, j = lane & 15;
   const bool crole = SPLIT && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;       // chunk role (waves 4..7)
   const int dir = blockIdx.y;
@@ -1705,16 +1705,32 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     // (du before the first barrier, its 4-wave reduction + dW + dW_lin after it).  The slots of pair k - 1 are rewritten in
     // period k + 1, behind the second barrier of period k.  The role branch sits OUTSIDE the tile loop: inside it the
     // compiler would keep each role's loop-carried registers (dW sums; weights) alive through the other role's body.
-    const int npairs = (S + 1) / 2;                                // the last pair may be a single step (odd S)
+    // Time segments (SEG): an item is (tile, segment) and walks steps s_hi .. s_lo; the hand-off wait and the state publish
+    // carry workgroup barriers of their own, which the chunk role mirrors.
     if (!crole) {
       for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        set_tile(item);
+        const int seg = SEG ? item / ntiles : 0;
+        const int tile = SEG ? item - seg * ntiles : item;
+        const int s_hi = SEG ? S - 1 - seg * a.seg_len : S - 1;
+        const int s_lo = SEG ? max(0, s_hi - a.seg_len + 1) : 0;
+        const int npairs = (s_hi - s_lo + 2) / 2;                  // the last pair may be a single step
+        set_tile(tile);
         dc = zero4();
         dhrec = zero4();
-        // records ONE step ahead (two in the one-role kernel: 56 registers this role does not have; along the intra-frame
-        // walk consecutive steps are adjacent in memory, and a step is ~2 us)
-        Raw nxt = load_raw(S - 1);
-        int s = S - 1;
+        if constexpr (SEG) {
+          if (seg > 0) {
+            if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return;
+            const float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              dc[r] = __hip_atomic_load(st + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              dhrec[r] = __hip_atomic_load(st + 16 * H + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+        // records ONE step ahead (two in the one-role kernel: 56 registers this role does not have)
+        Raw nxt = load_raw(s_hi);
+        int s = s_hi;
         for (int k = 0; k < npairs; ++k, s -= 2) {
           Raw curA = nxt;
           consume(curA);
@@ -1722,7 +1738,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
           nxt = load_raw(max(s - 1, 0));
           __builtin_amdgcn_sched_barrier(0);
           step(s, curA, 2 * (k & 1));
-          if (s >= 1) {
+          if (s - 1 >= s_lo) {
             Raw curB = nxt;
             consume(curB);
             __builtin_amdgcn_sched_barrier(0);
@@ -1741,20 +1757,38 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         }
         __syncthreads();                                           // the chunk role's last period
         __syncthreads();
-        __syncthreads();                                           // between tiles
+        if constexpr (SEG) {
+          if (s_lo > 0) {
+            float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              __hip_atomic_store(st + r, dc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(st + 16 * H + r, dhrec[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.seg_flags + tile, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        __syncthreads();                                           // between items
       }
       return;
     }
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-      set_tile(item);
-      if constexpr (LINW) lin_top();
-      if constexpr (STG) stage_issue(S - 1, S >= 2, 1, item);      // the first chunk's rows: read in period 1 (buffer 1)
+      const int seg = SEG ? item / ntiles : 0;
+      const int tile = SEG ? item - seg * ntiles : item;
+      const int s_hi = SEG ? S - 1 - seg * a.seg_len : S - 1;
+      const int s_lo = SEG ? max(0, s_hi - a.seg_len + 1) : 0;
+      const int npairs = (s_hi - s_lo + 2) / 2;
+      set_tile(tile);
+      if constexpr (SEG) { if (seg > 0) { if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return; } }
+      if constexpr (LINW) { if (s_hi == S - 1) lin_top(); }
+      if constexpr (STG) stage_issue(s_hi, s_hi - 1 >= s_lo, 1, tile);     // the first chunk's rows: read in period 1 (buffer 1)
       __syncthreads();
       __syncthreads();
-      int s = S - 1;
-      const float nox[2] = {0.f, 0.f};
+      int s = s_hi;
       for (int k = 1; k <= npairs; ++k, s -= 2) {                  // chunk of pair k - 1: steps (s, s - 1)
-        const bool two = s >= 1;
+        const bool two = s - 1 >= s_lo;
         const int pb = (k - 1) & 1, rb = STG ? 0 : pb;
         PairOps ops2;
         if constexpr (STG) {
@@ -1767,13 +1801,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         __syncthreads();
         if constexpr (STG) {
           stg_sel = k & 1;
-          if (k < npairs) stage_issue(s - 2, s - 3 >= 0, (k + 1) & 1, item);     // the next period's rows, a period ahead
+          if (k < npairs) stage_issue(s - 2, s - 3 >= s_lo, (k + 1) & 1, tile);  // the next period's rows, a period ahead
         }
-        flush(s, two ? 2 : 1, rb, nox, nox);
+        flush(s, two ? 2 : 1, rb, ops2.xq, ops2.rq);
         chunk(2 * pb, rb, ops2, s, two, 1);
         __syncthreads();
       }
-      __syncthreads();                                             // between tiles
+      if constexpr (SEG) { if (s_lo > 0) __syncthreads(); }        // (the recurrence role publishes its state)
+      __syncthreads();                                             // between items
     }
   } else
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -1917,7 +1952,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       const float g = quad_sum(dgam), b = quad_sum(dbet);      // over the four lane rows
       if (q == 0) { red[w * 32 + j] = g; red[w * 32 + 16 + j] = b; }
       __syncthreads();
-      if (tid < 32) plin[(size_t)FST * H + FST + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+      const int te = SPLIT ? (tid & 255) : tid;
+      if (te < 32) plin[(size_t)FST * H + FST + te] = red[te] + red[32 + te] + red[64 + te] + red[96 + te];
     }
   }
 #ifdef SB_PHASE_TIMING
@@ -1949,11 +1985,11 @@ static int choose_segments(int ntiles, int W, int S, double* cost_out) {
   return best;
 }
 // one resident workgroup per CU is what the segmented schedule relies on: refuse it when the kernel does not fit a CU
-template <auto Kern>
+template <auto Kern, int BS = 256>
 static bool fits_one_per_cu() {
   static const bool ok = [] {
     int n = 0;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, Kern, 256, 0) == hipSuccess && n >= 1;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, Kern, BS, 0) == hipSuccess && n >= 1;
   }();
   return ok;
 }
@@ -2141,9 +2177,19 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, CC, true, SG, CC, LB, false, false, false, false, true>), grid, block, 0, st, a); } while (0)
 #define SB_FXC(CC, LB) do { if (full) { if (seg) SB_FX(true, CC, true, LB); else SB_FX(true, CC, false, LB); } \
                             else { if (seg) SB_FX(false, CC, true, LB); else SB_FX(false, CC, false, LB); } } while (0)
+#define SB_FS(FL, R16_, CC, SG, LB, XP_) do { \
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, R16_, CC, true, SG, CC, LB, false, false, false, false, XP_, true>, 512>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16_, CC, true, SG, CC, LB, false, false, false, false, XP_, true>), grid, dim3(512), 0, st, a); } while (0)
+#define SB_FSC(R16_, CC, LB, XP_) do { if (full) { if (seg) SB_FS(true, R16_, CC, true, LB, XP_); else SB_FS(true, R16_, CC, false, LB, XP_); } \
+                                       else { if (seg) SB_FS(false, R16_, CC, true, LB, XP_); else SB_FS(false, R16_, CC, false, LB, XP_); } } while (0)
+    if (a.split && wide) { if (a.C == 16) { if (lnb) SB_FSC(false, 16, true, true); else SB_FSC(false, 16, false, true); } else SB_FSC(false, 32, false, true); }
+    else if (a.split) { if (a.C == 16) { if (lnb) SB_FSC(true, 16, true, false); else SB_FSC(true, 16, false, false); } else SB_FSC(true, 32, false, false); }
+    else
     if (wide) { if (a.C == 16) { if (lnb) SB_FXC(16, true); else SB_FXC(16, false); } else SB_FXC(32, false); }
     else
     if (a.C == 16) { if (lnb) SB_FC(16, true); else SB_FC(16, false); } else SB_FC(32, false);
+#undef SB_FSC
+#undef SB_FS
 #undef SB_FXC
 #undef SB_FX
 #undef SB_FC

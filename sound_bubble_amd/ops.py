@@ -726,6 +726,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     a.save_c = C.c_void_p(cprev.data_ptr())
     a.gmax, a.mma = _p(gmax), LSTM_MMA
     a.wide = 1 if rec.dtype == torch.float32 else 0
+    a.split = 1 if ROLE_SPLIT else 0
     a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
     ntiles = (geom.nseq + 15) // 16
     seg_scratch = None
@@ -749,7 +750,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
           + hs.numel() * hs.element_size() + u.numel() * u.element_size())
     fl = (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc + 2.0 * H * Cc) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else "")
-               + (" [wide]" if a.wide else ""),
+               + (" [wide]" if a.wide else "") + (" [role-split]" if a.split else ""),
                fl, 8.0 * Cc * geom.P, by):
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
     return du
