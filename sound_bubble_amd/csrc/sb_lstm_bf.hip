@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   const int ls = tid >> 4, cpart = tid & 15;
   bool lvalid = false, cvalid = false;          // per work item (tile): set by set_tile()
   int64_t lbase = 0, cbase = 0;
+  // Per-lane element offsets of the tile, fixed at set_tile(): a per-step address is  pointer + lane offset + (uniform step
+  // term), i.e. one scalar multiply and a 64-bit add.  Formed as (lane base + st * p_step) * row width they cost a
+  // quarter-rate 64-bit multiply chain per address and step -- VALU time, which on this chip adds to the matrix time of
+  // the wave (microbenchmarks in scripts/micro/: a SIMD runs MFMA and VALU instructions back to back, never side by side).
+  int64_t lo_x = 0, lo_xp = 0, co_y = 0, co_h = 0;
+  const int ndir = a.ndir;
   int nc = 0;
   int64_t rec_tile = 0;                         // tile * S: compact records are blocked per (tile, step, direction)
   // FiLM of the NEXT block (dis_embd3 :509-513) in the y epilogue: y <- y * film_w[n] + film_b[n] with the planes of
@@ -289,6 +295,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     nc = tile * 16 + j;
     cvalid = FULL || nc < a.nseq;
     cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    lo_x = lbase * C + cpart * VPT;
+    lo_xp = lbase * (2 * C) + cpart * VPT;
+    co_y = ((LIN && a.ndir == 2) ? cbase * 2 + dir : cbase) * C + 16 * w + 4 * q;
+    co_h = (cbase * ndir + dir) * H + 16 * w + 4 * q;
     if (film && linw && cvalid) {
       fw = ld4(a.film_w + (size_t)nc * C + 16 * w + 4 * q);
       fb = ld4(a.film_b + (size_t)nc * C + 16 * w + 4 * q);
@@ -301,11 +311,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   auto load_x = [&](int s) {
     XVec<C> r;
     const int st = rev ? S - 1 - s : s;
-    const float* p = a.x + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+    const int64_t sp = (int64_t)st * a.p_step;        // uniform
+    const float* p = a.x + sp * C + lo_x;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) r.v[v] = (SB_EXP_SKIP & 64) ? (float)((s + v + lane) & 7) * 0.25f : (lvalid ? p[v] : 0.f);
     if constexpr (SUM3) {
-      const float* p0 = a.x_part + (lbase + (int64_t)st * a.p_step) * (2 * C) + cpart * VPT;
+      const float* p0 = a.x_part + sp * (2 * C) + lo_xp;
 #pragma unroll
       for (int v = 0; v < VPT; ++v) r.v[v] = lvalid ? (r.v[v] + p0[v]) + p0[C + v] : 0.f;      // (x + part0) + part1, as sb_add3
     }
@@ -336,14 +347,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       for (int v = 0; v < VPT; ++v) XS[s & 3][ls][cpart * VPT + v] = xv.v[v];
       if (a.x_sum && lvalid) {
         const int st = rev ? S - 1 - s : s;
-        float* p = a.x_sum + (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+        float* p = a.x_sum + (int64_t)st * a.p_step * C + lo_x;
 #pragma unroll
         for (int v = 0; v < VPT; ++v) p[v] = xv.v[v];
       }
     }
     if (SAVE && lvalid && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
       const int st = rev ? S - 1 - s : s;
-      const int64_t uo = (lbase + (int64_t)st * a.p_step) * C + cpart * VPT;
+      const int64_t uo = (int64_t)st * a.p_step * C + lo_x;
       if constexpr (SAVE == 3) {            // only the streaming backward reads u, as a single fp16 term
         _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + uo;
         if constexpr (VPT == 2) *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)u[0], (_Float16)u[1]};
@@ -426,23 +437,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   auto store_y = [&](int sy) {
     if (linw && cvalid && !(SB_EXP_SKIP & 16)) {
       const int st = rev ? S - 1 - sy : sy;
-      const int64_t pos = cbase + (int64_t)st * a.p_step;
+      const int64_t sp = (int64_t)st * a.p_step;      // uniform
       f32x4 v = yacc + lbias + xres;
       if (film) {
-        if (a.y_pre) st4(a.y_pre + pos * C + 16 * w + 4 * q, v);
+        if (a.y_pre) st4(a.y_pre + sp * C + co_y, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], fw[r], fb[r]);
       }
-      float* yp = a.y + (lin_part ? pos * 2 + dir : pos) * C + 16 * w + 4 * q;
+      float* yp = a.y + sp * (lin_part ? 2 * C : C) + co_y;
       if (prod) st4_sc1(yp, v); else st4(yp, v);
     }
   };
   auto load_res = [&](int sy) {
     if (linw && cvalid && !lin_part && !(SB_EXP_SKIP & 32)) {
       const int st = rev ? S - 1 - sy : sy;
-      const int64_t pos = cbase + (int64_t)st * a.p_step;
       if constexpr (SUM3) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);
-      else xres = ld4(a.x + pos * C + 16 * w + 4 * q);
+      else xres = ld4(a.x + (int64_t)st * a.p_step * C + co_y);
     }
   };
 
@@ -454,7 +464,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   f32x4 accx[4];
   int s_begin = 0;                              // first step of the current work item
 
-  const int ndir = a.ndir;
 #ifdef SB_PHASE_TIMING
   unsigned long long tph[5] = {0, 0, 0, 0, 0};
 #endif
@@ -496,21 +505,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     {
       if (cvalid) {
         const int st = rev ? S - 1 - s : s;
-        const int64_t pos = cbase + (int64_t)st * a.p_step;
+        const int64_t pos = cbase + (int64_t)st * a.p_step;          // (position-major records of SAVE == 1 only)
+        const int64_t ho = (int64_t)st * a.p_step * (ndir * H) + co_h;    // hs element offset: uniform step term + lane offset
         if constexpr (LIN && SAVE == 3) {   // the Linear is applied here: hs only feeds the backward kernels (fp16 terms)
           h16x4 h16;
 #pragma unroll
           for (int r = 0; r < 4; ++r) h16[r] = (_Float16)h[r];
-          if (a.hs && !(SB_EXP_SKIP & 4)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.hs) + (pos * ndir + dir) * H + uoff) = h16;
+          if (a.hs && !(SB_EXP_SKIP & 4)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.hs) + ho) = h16;
         } else if constexpr (LIN && SAVE == 4 && F16) {
           // wide form with the Linear applied here: hs only feeds the backward kernels' matrix products -- it travels as the
           // fp16 hi + lo terms just stored to LDS: [P][ndir][16 unit quads][hi x 4, lo x 4], same bytes as fp32
           h16x8 hp;
 #pragma unroll
           for (int r = 0; r < 4; ++r) { hp[r] = (_Float16)htv[0][r]; hp[4 + r] = (_Float16)htv[1][r]; }
-          if (a.hs) *reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ((pos * ndir + dir) * H + uoff) * 2) = hp;
+          if (a.hs) *reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ho * 2) = hp;
         } else {
-          if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + (pos * ndir + dir) * H + uoff, h);
+          if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + ho, h);
         }
         if (SAVE == 1) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
