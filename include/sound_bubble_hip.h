@@ -188,7 +188,10 @@ typedef struct {
   int wide;
   /* Fused forms (wpart != NULL; single direction or bidirectional, compact or wide): split != 0 launches ROLE-SPLIT workgroups of 8 waves
      (two per SIMD): four run the recurrence, four the chunk arithmetic (dW, du, Linear weight gradient) of the previous pair
-     of steps from the dgates tiles in LDS.  Same arithmetic, other summation order. */
+     of steps from the dgates tiles in LDS.  Same arithmetic, other summation order.  The wide bidirectional form with the
+     fused Linear backward (C = C_lin = 32) does not read hs in this mode (hs may be NULL, and the forward pass need not
+     store it -- sb_lstm_fwd_args.hs == NULL with the Linear fused): its recurrence waves recompute h of a step from the
+     records, bit for bit as the forward kernel formed it, and hand it to the chunk waves through LDS. */
   int split;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);

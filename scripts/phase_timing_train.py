@@ -1,0 +1,29 @@
+"""Per-phase s_memtime ticks of the forward recurrent kernels inside real training steps of the model (wide and compact BPTT
+   state), next to the inference forward.  GPU box; needs a -DSB_PHASE_TIMING build (scripts/gpu_phase.sh)."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from sound_bubble_amd import _lib as L, ops
+lib = ctypes.CDLL(L.LIB_PATH)
+KINDS = ["plain", "fused Linear", "summed input + fused Linear (inter-frame producer)", "ordered consumer (intra-frame)",
+         "bidirectional partial-Linear (intra-frame, first block)"]
+def table(tag):
+    buf = (ctypes.c_float * (5 * 16 * 8))()
+    assert lib.sb_debug_phase_fwd(buf) == 0
+    t = torch.tensor(list(buf)).view(5, 16, 8)[:, :, :5]
+    for k, name in enumerate(KINDS):
+        if float(t[k].abs().sum()) == 0: continue
+        rows = t[k][:4]        # the four waves of tile 0
+        print(f"{tag:28s} {name}")
+        for w in range(4):
+            r = rows[w].tolist()
+            print(f"    wave {w}: A(W_hh h + LN) {r[0]:6.0f}  B(W_ih u + cell) {r[1]:6.0f}  C(store_h) {r[2]:5.0f}  D(records, y) {r[3]:5.0f}  E(barrier) {r[4]:5.0f}   sum {sum(r):6.0f}")
+import argparse
+import sound_bubble_amd as sb
+args = argparse.Namespace(batch=0, steps=2, warmup=1, bptt=None)
+dev = torch.device("cuda:0")
+for wl in ("big", "small"):
+    for mode, fwd in (("wide", True), ("wide", False), ("compact", False)):
+        bench.run_workload(torch, None, sb, ops, wl, args, dev, 1, 0, forward_only=fwd, mode=mode, steps=2, warmup=1, profile=False)
+        torch.cuda.synchronize()
+        table(f"{wl} / {'inference' if fwd else 'train, ' + mode}")

@@ -35,6 +35,16 @@
 // s_memtime cycles per step of each phase.  scripts/phase_timing.py prints them.
 #ifdef SB_PHASE_TIMING
 #define SB_TICK(name) const unsigned long long name = __builtin_readcyclecounter()
+// the last launch of every forward kernel kind also leaves its table here (any SAVE mode: training steps of the whole model);
+// kind 0 plain, 1 fused Linear, 2 summed input + fused Linear (the inter-frame producer), 3 ordered consumer, 4 bidirectional
+// partial-Linear; read with sb_debug_phase_fwd()
+__device__ float g_phase_fwd[5][16][8];
+extern "C" int sb_debug_phase_fwd(float* host_out) {
+  const int rc = -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_fwd), sizeof(g_phase_fwd));
+  static float zeros[5 * 16 * 8];
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_fwd), zeros, sizeof(zeros));      // the next read shows only what ran since
+  return rc;
+}
 #else
 #define SB_TICK(name) do {} while (0)
 #endif
@@ -394,7 +404,81 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // products of a gate back to back on one accumulator, and any VALU instruction that lands between two MFMAs on
   // the SAME accumulator costs ~40 cycles.
   constexpr int kNoMfmaCross = 0x7F6;
-  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const vec8 (&b)[NT]) {
+  constexpr int kNoMfmaVmemCross = 0x786;
+  // Deferred record stores (compact / wide records): the ~6 sixteen-byte-per-lane stores of a step, issued back to back by all
+  // four waves right before the barrier, block the waves while the CU's store path drains (phase table: 700-800 ticks per
+  // step and wave in training against 90 in inference).  They are kept in registers instead and issued one at a time between
+  // the product groups of the NEXT step's W_hh h phase -- ~70 ticks of matrix work apart, no wave ever finds the path busy.
+  constexpr bool DEFER = SAVE >= 2;
+  f32x4 rgi = zero4(), rgf = zero4(), rgg = zero4(), rgo = zero4(), rcp = zero4();     // records of step s_pend
+  int s_pend = -1;
+  auto rec_piece = [&](int k) __attribute__((always_inline)) {
+    if constexpr (DEFER) {
+      if (s_pend >= 0 && cvalid) {
+        const int st = rev ? S - 1 - s_pend : s_pend;
+        const int64_t blk = (rec_tile + st) * ndir + dir;
+        if (k == (SAVE == 4 ? 5 : 3)) {                  // hs of the step (h / htv still hold it: they change in phases B / C)
+          const int64_t ho = (int64_t)st * a.p_step * (ndir * H) + co_h;
+          if constexpr (LIN && SAVE == 3) {   // the Linear is applied here: hs only feeds the backward kernels (fp16 terms)
+            h16x4 h16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h16[r] = (_Float16)h[r];
+            if (a.hs && !(SB_EXP_SKIP & 4)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.hs) + ho) = h16;
+          } else if constexpr (LIN && SAVE == 4 && F16) {
+            // wide form with the Linear applied here: hs only feeds the backward kernels' matrix products -- it travels as the
+            // fp16 hi + lo terms just stored to LDS: [P][ndir][16 unit quads][hi x 4, lo x 4], same bytes as fp32
+            h16x8 hp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { hp[r] = (_Float16)htv[0][r]; hp[4 + r] = (_Float16)htv[1][r]; }
+            if (a.hs) *reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ho * 2) = hp;
+          } else {
+            if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + ho, h);
+          }
+        }
+        if constexpr (SAVE == 4) {
+          // wide records (sb_lstm_fwd_args.rec_f32): fp32, blocked per (tile, step, direction) in lane order like the
+          // compact ones -- [wave][gate][lane][4 floats] and [wave][lane][4 floats], one contiguous KB per store
+          float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
+          if (k == 0) st4(rec, rgi);
+          if (k == 1) st4(rec + 256, rgf);
+          if (k == 2) st4(rec + 512, rgg);
+          if (k == 3) st4(rec + 768, rgo);
+          if (k == 4) st4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, rcp);
+        } else {
+          // Compact records are private to this kernel and the backward recurrence, which walks the same (tile, step)
+          // grid with the same lane ownership, so they are laid out per (tile, step, direction) block in LANE order:
+          // [wave][(i,f) | (g,o)][lane][8 halves] and [wave][lane][4 halves].  Every store instruction then writes one
+          // contiguous KB (512 B for c_prev).  In the position-major layout adjacent lanes (sequences j, j+1) hit
+          // different rows and the L1 splits each instruction into 64 sixteen-byte writes: measured 19 % of the
+          // inter-frame forward, 27 % of the intra-frame one.
+          if ((k == 0 || k == 1) && (SAVE != 3 || a.save_gates) && !(SB_EXP_SKIP & 1)) {   // SAVE == 3, no save_gates: recompute mode
+            _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + blk * (16 * 4 * H) + (w * 128 + lane) * 8;
+            h16x8 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = (_Float16)(k == 0 ? rgi[r] : rgg[r]);
+              v[4 + r] = (_Float16)(k == 0 ? rgf[r] : rgo[r]);
+            }
+            *reinterpret_cast<h16x8*>(rec + 512 * k) = v;
+          }
+          if (k == 2 && !(SB_EXP_SKIP & 2)) {
+            h16x4 c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c16[r] = (_Float16)rcp[r];
+            *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.save_c) + blk * (16 * H) + (w * 64 + lane) * 4) = c16;
+          }
+        }
+      }
+    }
+  };
+  auto rec_flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rec_piece(k);
+    s_pend = -1;
+  };
+  // hook >= 0: after product group pi the pending record store number hook + pi is issued (see rec_piece) and pinned there
+  // (second fence: VMEM may not cross either)
+  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const vec8 (&b)[NT], int hook = -1) {
     // (weight term, operand term) pairs, smallest products first
     constexpr int NP = F16 ? 3 : 6;
     constexpr int WT[6] = {F16 ? 1 : 2, F16 ? 0 : 0, F16 ? 0 : 1, 1, 0, 0};
@@ -404,6 +488,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = PR::mma(Wt[g][chunk].t[WT[pi]], b[XT[pi]], acc[g]);
       __builtin_amdgcn_sched_barrier(kNoMfmaCross);
+      if (hook >= 0) {
+        rec_piece(hook + pi);
+        __builtin_amdgcn_sched_barrier(kNoMfmaVmemCross);
+      }
     }
   };
   auto x_part = [&](f32x4 (&acc)[4], int buf) {
@@ -420,7 +508,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       vec8 b[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[buf][n][j][32 * ck + 8 * q]);
-      mma6(acc, 1 + ck, b);
+      mma6(acc, 1 + ck, b, DEFER ? 3 * ck : -1);
       if constexpr (LIN) {                             // W_lin . h of the step that produced this buffer
         if (linw) {
           if (ck == 0) yacc = zero4();
@@ -502,61 +590,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c3);
     // ---- C ----
-    {
+    if constexpr (DEFER) {            // records of this step: issued in phase A of the next one (or by the flush after the walk)
+      rgi = gi; rgf = gf; rgg = gg; rgo = go; rcp = cprev;
+      s_pend = s;
+    } else {
       if (cvalid) {
         const int st = rev ? S - 1 - s : s;
-        const int64_t pos = cbase + (int64_t)st * a.p_step;          // (position-major records of SAVE == 1 only)
-        const int64_t ho = (int64_t)st * a.p_step * (ndir * H) + co_h;    // hs element offset: uniform step term + lane offset
-        if constexpr (LIN && SAVE == 3) {   // the Linear is applied here: hs only feeds the backward kernels (fp16 terms)
-          h16x4 h16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h16[r] = (_Float16)h[r];
-          if (a.hs && !(SB_EXP_SKIP & 4)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.hs) + ho) = h16;
-        } else if constexpr (LIN && SAVE == 4 && F16) {
-          // wide form with the Linear applied here: hs only feeds the backward kernels' matrix products -- it travels as the
-          // fp16 hi + lo terms just stored to LDS: [P][ndir][16 unit quads][hi x 4, lo x 4], same bytes as fp32
-          h16x8 hp;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { hp[r] = (_Float16)htv[0][r]; hp[4 + r] = (_Float16)htv[1][r]; }
-          if (a.hs) *reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ho * 2) = hp;
-        } else {
-          if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + ho, h);
-        }
+        const int64_t pos = cbase + (int64_t)st * a.p_step;
+        if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + (int64_t)st * a.p_step * (ndir * H) + co_h, h);
         if (SAVE == 1) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
           st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
-        } else if (SAVE == 4) {
-          // wide records (sb_lstm_fwd_args.rec_f32): fp32, blocked per (tile, step, direction) in lane order like the
-          // compact ones -- [wave][gate][lane][4 floats] and [wave][lane][4 floats], one contiguous KB per store
-          const int64_t blk = (rec_tile + st) * ndir + dir;
-          float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
-          st4(rec, gi); st4(rec + 256, gf); st4(rec + 512, gg); st4(rec + 768, go);
-          st4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, cprev);
-        } else if (SAVE >= 2) {
-          const int64_t blk = (rec_tile + st) * ndir + dir;
-          if (SAVE != 3 || a.save_gates) {   // SAVE == 3 with save_gates == NULL: the backward recomputes the gates (c_prev only)
-          h16x8 lo, hi;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            lo[r] = (_Float16)gi[r]; lo[4 + r] = (_Float16)gf[r];
-            hi[r] = (_Float16)gg[r]; hi[4 + r] = (_Float16)go[r];
-          }
-          // Compact records are private to this kernel and the backward recurrence, which walks the same (tile, step)
-          // grid with the same lane ownership, so they are laid out per (tile, step, direction) block in LANE order:
-          // [wave][(i,f) | (g,o)][lane][8 halves] and [wave][lane][4 halves].  Every store instruction then writes one
-          // contiguous KB (512 B for c_prev).  In the position-major layout adjacent lanes (sequences j, j+1) hit
-          // different rows and the L1 splits each instruction into 64 sixteen-byte writes: measured 19 % of the
-          // inter-frame forward, 27 % of the intra-frame one.
-          _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + blk * (16 * 4 * H) + (w * 128 + lane) * 8;
-          if (!(SB_EXP_SKIP & 1)) {
-          *reinterpret_cast<h16x8*>(rec) = lo;
-          *reinterpret_cast<h16x8*>(rec + 512) = hi;
-          }
-          }
-          h16x4 c16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) c16[r] = (_Float16)cprev[r];
-          if (!(SB_EXP_SKIP & 2)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.save_c) + blk * (16 * H) + (w * 64 + lane) * 4) = c16;
         }
       }
     }
@@ -642,6 +686,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     if (s < s_end) step(s, xa);
     if (s + 1 < s_end) step(s + 1, xb);
     if (s + 2 < s_end) step(s + 2, xc);
+    rec_flush();                                       // records of the last step
     if constexpr (LIN) {                               // y of the item's last step from the final hidden-state tiles
       if (linw) {
 #pragma unroll
@@ -683,6 +728,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   if (SAVE == 0 && a.save_u && lane == 0 && blockIdx.x < 4) {
     float* d = a.save_u + (blockIdx.x * 4 + w) * 8;
     for (int i = 0; i < 5; ++i) d[i] = (float)tph[i] / S;
+  }
+  if (lane == 0 && blockIdx.x < 4 && (ORD || blockIdx.y == 0)) {
+    const int kind = ORD ? 3 : (LIN && a.ndir == 2) ? 4 : SUM3 ? 2 : LIN ? 1 : 0;
+    for (int i = 0; i < 5; ++i) g_phase_fwd[kind][blockIdx.x * 4 + w][i] = (float)tph[i] / S;
   }
 #endif
 }
@@ -765,11 +814,25 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   // The rows travel by async global -> LDS copies (global_load_lds_dwordx4: no registers at all; destination = wave-uniform
   // base + lane x 16 bytes, hence unpadded rows), issued one period ahead into the other buffer and waited for (vmcnt) just
   // before the hand-over barrier of the period that reads them.
+  // HREC (STG, bidirectional): the h_prev rows do not come from memory at all.  The recurrence role recomputes h of its step
+  // from the records it holds anyway (h = o tanh(f c_prev + i g): the forward kernel's own expression on the same fp32
+  // values, so the same bits), splits it like the forward kernel and leaves the (hi, lo) row in a four-step ring in LDS
+  // (the SHP buffers); the chunk of steps (s, s - 1) runs one period later and reads h of steps s - 1 (written a period
+  // ago) and s - 2 (written before this period's first barrier; the chunk needs it after that barrier).  The forward pass
+  // then stores no hs for these layers: 512 of its 3456 bytes per position, and 512 fewer read here.
+  constexpr bool HREC = STG && BI;
   constexpr int SHROW = 256, SUROW = 4 * (FST > 0 ? FST : 16);                  // LDS rows (bytes)
   __shared__ __attribute__((aligned(16))) float R[FST > 0 ? (STG ? 1 : 2) : 1][4][2][CK][FST > 0 ? 64 : 1][4];
   __shared__ __attribute__((aligned(16))) char SHP[STG ? 2 : 1][STG ? 32 * SHROW : 16];   // h_prev pair rows of the chunk's 32 slots
   __shared__ __attribute__((aligned(16))) char SUP[STG ? 2 : 1][STG ? 32 * SUROW : 16];   // u pair rows
   __shared__ __attribute__((aligned(16))) char SDY[STG ? 2 : 1][STG ? 32 * SUROW : 16];   // dy rows of the h_prev positions (fp32)
+  auto hring = [&](int step, int seq) -> char* {   // HREC: row of sequence seq of walk index step (two's complement & 3: step -1 is slot 3)
+    return &SHP[0][0] + ((step & 3) * 16 + seq) * SHROW;
+  };
+  if constexpr (HREC) {                            // finite contents from the start: rows of steps that do not exist meet zero dgates
+    for (int i = tid; i < 2 * 32 * SHROW / 16; i += 512) reinterpret_cast<f32x4*>(&SHP[0][0])[i] = zero4();
+    __syncthreads();
+  }
   // SLAB: the step's 16 dgates rows are assembled here so that they leave as whole 512-byte rows (write-through stores of
   // the 32-byte pieces each lane holds would reach HBM as partial lines)
   __shared__ __attribute__((aligned(16))) _Float16 DS[SLAB ? 2 : 1][SLAB ? 16 : 1][SLAB ? 4 * H + 8 : 8];
@@ -1003,15 +1066,20 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     char* ld = &SDY[sel][(8 * w) * SUROW];
     const bool whole = FULL || tile * 16 + 16 <= a.nseq;
     if (cnt && whole) {
-      __builtin_amdgcn_global_load_lds(gh0, (__attribute__((address_space(3))) void*)(lh), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(gh1, (__attribute__((address_space(3))) void*)(lh + 4 * SHROW), 16, 0, 0);
+      if constexpr (!HREC) {
+        __builtin_amdgcn_global_load_lds(gh0, (__attribute__((address_space(3))) void*)(lh), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gh1, (__attribute__((address_space(3))) void*)(lh + 4 * SHROW), 16, 0, 0);
+      }
       __builtin_amdgcn_global_load_lds(gu, (__attribute__((address_space(3))) void*)(lu), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(gd, (__attribute__((address_space(3))) void*)(ld), 16, 0, 0);
     } else {
       const f32x4 z4 = zero4();
-      const f32x4 h0 = ld4(gh0), h1 = ld4(gh1), uu = ld4(gu), dd = ld4(gd);
-      st4(reinterpret_cast<float*>(lh + 16 * lane), (cnt && stg_v[0]) ? h0 : z4);
-      st4(reinterpret_cast<float*>(lh + 4 * SHROW + 16 * lane), (cnt && stg_v[1]) ? h1 : z4);
+      if constexpr (!HREC) {
+        const f32x4 h0 = ld4(gh0), h1 = ld4(gh1);
+        st4(reinterpret_cast<float*>(lh + 16 * lane), (cnt && stg_v[0]) ? h0 : z4);
+        st4(reinterpret_cast<float*>(lh + 4 * SHROW + 16 * lane), (cnt && stg_v[1]) ? h1 : z4);
+      }
+      const f32x4 uu = ld4(gu), dd = ld4(gd);
       st4(reinterpret_cast<float*>(lu + 16 * lane), uu);
       st4(reinterpret_cast<float*>(ld + 16 * lane), (cnt && stg_v[2]) ? dd : z4);
     }
@@ -1053,7 +1121,16 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       h16x8 hpm[HSP ? 8 : 1];
       if constexpr (HSP) {
         const h16x8 hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if constexpr (STG) {
+        if constexpr (HREC) {
+          const char* hr = hring(sw - 1, 8 * (q & 1)) + 16 * j;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) hpm[kk] = *reinterpret_cast<const h16x8*>(hr + kk * SHROW);
+          if (!steady) {                               // walk index 0 has no h_prev
+            asm volatile("");
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) hpm[kk] = hp ? hpm[kk] : hz8;
+          }
+        } else if constexpr (STG) {
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) hpm[kk] = *reinterpret_cast<const h16x8*>(&SHP[stg_sel][(8 * q + kk) * SHROW + 16 * j]);
         } else {
@@ -1293,7 +1370,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         const int64_t pos = (int64_t)posb[kk] + (int64_t)st_of(S - 1) * a.p_step;       // walk index S - 1
         float hv;
         if constexpr (HSP) {
-          const h16x8 hp8 = *reinterpret_cast<const h16x8*>(hs16 + (pos * LDH + (BI ? dir * H : 0) + 4 * j) * 2);
+          const h16x8 hp8 = HREC ? *reinterpret_cast<const h16x8*>(hring(S - 1, 8 * (q & 1) + kk) + 16 * j)
+                                 : *reinterpret_cast<const h16x8*>(hs16 + (pos * LDH + (BI ? dir * H : 0) + 4 * j) * 2);
           hv = w == 0 ? (float)hp8[0] + (float)hp8[4] : (w == 1 ? (float)hp8[1] + (float)hp8[5]
                : (w == 2 ? (float)hp8[2] + (float)hp8[6] : (float)hp8[3] + (float)hp8[7]));
         } else {
@@ -1569,12 +1647,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       dhext = mma(Lh, bh, dhext);
     }
     f32x4 dG[4];
+    float hrow[4];                                   // HREC: h of this step, as the forward kernel formed it
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float dh = dhext[r] + dhrec[r];
       const float cpr = REC16 ? (float)raw.cp16[r] : raw.cp[r];
       const float cc = __builtin_fmaf(gf[r], cpr, gi[r] * gg[r]);
       const float tc = tanhf_fast(cc);
+      hrow[r] = go[r] * tc;
       const float dO = dh * tc;
       const float dct = __builtin_fmaf(dh * go[r], __builtin_fmaf(-tc, tc, 1.0f), dc[r]);
       dG[0][r] = dct * gg[r] * gi[r] * (1.0f - gi[r]);
@@ -1616,6 +1696,16 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
           for (int r = 0; r < 4; ++r) t[r] = Bl[g >> 1][4 * (g & 1) + r];
           *reinterpret_cast<h16x4*>(&DGL[slot][j][g * H + uoff]) = t;
         }
+      }
+      if constexpr (HREC) {                            // (hi x 4, lo x 4) of units 16w + 4q .. + 3: the forward kernel's hs pair
+        h16x8 hp8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const _Float16 hh = (_Float16)hrow[r];
+          hp8[r] = hh;
+          hp8[4 + r] = (_Float16)(hrow[r] - (float)hh);
+        }
+        *reinterpret_cast<h16x8*>(hring(s, j) + 16 * (4 * w + q)) = hp8;
       }
     } else if constexpr (SLAB) {
 #pragma unroll
@@ -1792,9 +1882,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       const int npairs = (s_hi - s_lo + 2) / 2;
       set_tile(tile);
       if constexpr (SEG) { if (seg > 0) { if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return; } }
-      if constexpr (LINW) { if (s_hi == S - 1) lin_top(); }
+      if constexpr (LINW && !HREC) { if (s_hi == S - 1) lin_top(); }
       if constexpr (STG) stage_issue(s_hi, s_hi - 1 >= s_lo, 1, tile);     // the first chunk's rows: read in period 1 (buffer 1)
       __syncthreads();
+      if constexpr (LINW && HREC) lin_top();                               // h of walk index S - 1 is in the ring by now
       __syncthreads();
       int s = s_hi;
       for (int k = 1; k <= npairs; ++k, s -= 2) {                  // chunk of pair k - 1: steps (s, s - 1)
@@ -2121,7 +2212,9 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   const bool wide = a.wide != 0;                    // fp32 records / u / hs, two-term gradients (see the kernel: XP)
   if (wide && ((!fst && !a.slab_flags) || !dg16 || a.hs_f16 || a.recompute)) return -1003;
   if (fst && a.ndir == 2) {                          // bidirectional fused form: persistent workgroups, one per CU
-    if (!dg16 || !a.u || !a.hs || !a.w_ih || !a.w_ih1 || !a.du || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
+    // hs: not read by the wide role-split C = 32 form (its recurrence role recomputes h: see HREC in the kernel)
+    const bool hrec = wide && a.split && a.C == 32 && fc == 32;
+    if (!dg16 || !a.u || (!a.hs && !hrec) || !a.w_ih || !a.w_ih1 || !a.du || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
         !a.dW_ih1 || !a.dW_hh1 || !a.db_ih1 || !a.db_hh1 || (int64_t)a.nseq * a.nsteps * H >= (1ll << 31))
       return -1003;
     int gx = device_cu_count() / 2;

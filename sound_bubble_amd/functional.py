@@ -77,7 +77,8 @@ class IntraPlainFn(torch.autograd.Function):
             # only a (fp16) side output for the backward kernels, and none at all in inference
             part = torch.empty(P, 2, Cc, device=x.device, dtype=torch.float32)
             hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train,
-                                           lin=(lin_w.contiguous(), lin_b, part), want_hs=train,
+                                           lin=(lin_w.contiguous(), lin_b, part),
+                                           want_hs=train and not ops.bi_hs_from_records(Cc),
                                            no_gates=train and ops.GATE_RECOMPUTE, consume=ovl)
             y = part.view(B, T, F, 2, Cc) if defer_sum else ops.add3(x.view(P, Cc), part).view(B, T, F, Cc)
         else:

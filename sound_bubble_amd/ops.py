@@ -762,9 +762,22 @@ FUSED_BPTT_BI = os.environ.get("SB_NO_FUSED_BPTT_BI", "0") != "1"
 ROLE_SPLIT = os.environ.get("SB_NO_ROLE_SPLIT", "0") != "1"
 
 
+# wide bidirectional C = 32 layers (Linear applied inside the forward kernel) under the role-split backward: hs is neither
+# stored by the forward pass nor read by the backward kernel -- its recurrence waves recompute h from the records
+# (SB_NO_HS_RECOMPUTE=1: hs pairs travel through HBM as before)
+HS_FROM_RECORDS = os.environ.get("SB_NO_HS_RECOMPUTE", "0") != "1"
+
+
+def bi_hs_from_records(Cc):
+    return bool(HS_FROM_RECORDS and ROLE_SPLIT and _wide() and Cc == 32 and FUSED_BPTT and FUSED_BPTT_BI and LSTM_MMA == 1
+                and can_fuse_linear_bwd())
+
+
 def can_fuse_stream_bi(u, hs):
     """bidirectional passes: fused form with fp32 hs, or (C == 32, partial-Linear forward) fp16 hs (see lstm_bwd_fused_bi)"""
     if _wide():               # u as (hi, lo) pairs; hs as pairs (C = 32, Linear applied in the forward kernel) or fp32 (C = 16)
+        if hs is None:        # not stored: the role-split kernel recomputes h (bi_hs_from_records)
+            return bool(u is not None and u.dtype == torch.float16 and u.shape[-1] == 64 and bi_hs_from_records(32))
         return (FUSED_BPTT and FUSED_BPTT_BI and LSTM_MMA == 1 and u is not None and u.dtype == torch.float16
                 and ((u.shape[-1] == 64 and hs.dtype == torch.float16 and hs.shape[-1] == 4 * H)
                      or (u.shape[-1] == 32 and hs.dtype == torch.float32)))
@@ -846,15 +859,16 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     if lin_targets is not None:          # (dW_lin [C, 128], db_lin [C]) of the fused Linear (dy form only)
         assert dy is not None and lin_targets[0].shape == (Cc, 2 * H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
-    a.u, a.hs, a.C = _ph(u), _ph(hs), Cc
-    a.hs_f16 = int(hs.dtype == torch.float16 and not a.wide)
-    assert not (a.hs_f16 or (a.wide and hs.dtype == torch.float16)) or (dy is not None and Cc == 32)
+    a.u, a.hs, a.C = _ph(u), (_ph(hs) if hs is not None else None), Cc
+    assert hs is not None or (a.wide and a.split and dy is not None and Cc == 32)
+    a.hs_f16 = int(hs is not None and hs.dtype == torch.float16 and not a.wide)
+    assert hs is None or not (a.hs_f16 or (a.wide and hs.dtype == torch.float16)) or (dy is not None and Cc == 32)
     a.w_ih, a.w_ih1 = _p(w_ih_list[0]), _p(w_ih_list[1])
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
     a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
     by = (geom.P * (2 * ((1280.0 if a.wide else 640.0) if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
-                    + 8.0 * Cc) + hs.numel() * hs.element_size() + u.numel() * u.element_size())
+                    + 8.0 * Cc) + (hs.numel() * hs.element_size() if hs is not None else 0) + u.numel() * u.element_size())
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)" + (" [wide]" if a.wide else "")

@@ -1021,6 +1021,20 @@ def test_wide_fused_bptt_bidirectional_matches_float64_autograd(torch_gpu, C_, f
     du = ops.lstm_bwd_fused_bi([dirs[0][1], dirs[1][1]], gates, geom, u, hs, [dirs[0][0], dirs[1][0]], tg,
                                lin_targets=ltg, **kw)
     torch.cuda.synchronize()
+    if fuse_lin and ops.bi_hs_from_records(C_):
+        # the role-split kernel recomputes h from the records: the forward pass need not store hs at all, and a launch
+        # without it gives the same bits
+        part2 = torch.empty_like(part)
+        hs2, _, gates2, u2 = ops.lstm_fwd(x, g, b, dirs, geom, save=True, lin=(lin_w, lin_b, part2), want_hs=False)
+        assert hs2 is None and torch.equal(part2, part) and ops.can_fuse_stream_bi(u2, None)
+        tg2 = [[torch.zeros_like(t) for t in d] for d in tg]
+        ltg2 = [torch.zeros_like(t) for t in ltg]
+        du2 = ops.lstm_bwd_fused_bi([dirs[0][1], dirs[1][1]], gates2, geom, u2, None, [dirs[0][0], dirs[1][0]], tg2,
+                                    lin_targets=ltg2, **kw)
+        assert torch.equal(du2, du) and torch.equal(ltg2[0], ltg[0]) and torch.equal(ltg2[1], ltg[1])
+        for d2, d1 in zip(tg2, tg):              # (the cross-workgroup reduction of the LSTM weight gradients adds in arrival order)
+            for p_, q_ in zip(d2, d1):
+                assert rel_l2(p_.cpu().numpy(), q_.cpu().numpy()) < 1e-6
     # ---- float64 reference ----
     U = torch.nn.functional.layer_norm(x.double().cpu().view(nseq, S, C_), (C_,), g.double().cpu(), b.double().cpu(), 1e-5)
     U.requires_grad_(True)
