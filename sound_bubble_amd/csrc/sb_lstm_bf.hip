@@ -409,11 +409,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // four waves right before the barrier, block the waves while the CU's store path drains (phase table: 700-800 ticks per
   // step and wave in training against 90 in inference).  They are kept in registers instead and issued one at a time between
   // the product groups of the NEXT step's W_hh h phase -- ~70 ticks of matrix work apart, no wave ever finds the path busy.
-  constexpr bool DEFER = SAVE >= 2;
+  // (not for the C = 16 inter-frame walk: one wave carries its whole y epilogue there and is the pole of every step;
+  // measured 1.11 -> 1.17 ms with the stores moved into its phase A)
+  constexpr bool DEFER = SAVE >= 2 && !(LIN && C == 16);
   f32x4 rgi = zero4(), rgf = zero4(), rgg = zero4(), rgo = zero4(), rcp = zero4();     // records of step s_pend
   int s_pend = -1;
   auto rec_piece = [&](int k) __attribute__((always_inline)) {
-    if constexpr (DEFER) {
+    if constexpr (SAVE >= 2) {
       if (s_pend >= 0 && cvalid) {
         const int st = rev ? S - 1 - s_pend : s_pend;
         const int64_t blk = (rec_tile + st) * ndir + dir;
@@ -590,9 +592,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c3);
     // ---- C ----
-    if constexpr (DEFER) {            // records of this step: issued in phase A of the next one (or by the flush after the walk)
+    if constexpr (SAVE >= 2) {        // records of this step: issued in phase A of the next one (or by the flush after the walk)
       rgi = gi; rgf = gf; rgg = gg; rgo = go; rcp = cprev;
       s_pend = s;
+      if constexpr (!DEFER) rec_flush();              // ... or right here
     } else {
       if (cvalid) {
         const int st = rev ? S - 1 - s : s;
