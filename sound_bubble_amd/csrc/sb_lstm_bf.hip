@@ -290,6 +290,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // the wave (microbenchmarks in scripts/micro/: a SIMD runs MFMA and VALU instructions back to back, never side by side).
   int64_t lo_x = 0, lo_xp = 0, co_y = 0, co_h = 0;
   const int ndir = a.ndir;
+  // ... and the uniform step terms are RUNNING sums: one 64-bit scalar add per step and quantity instead of a 64-bit scalar
+  // multiply chain per address (with one wave per SIMD every instruction, scalar ones included, costs its ~4 issue cycles:
+  // the ~70 scalar instructions of the old epilogue were 290 ticks of a 2 070-tick step).  Row s of the walk:
+  //   run_x = st(s) p_step C (x, x_sum, u, y, y_pre, residual), run_h = st(s) p_step ndir 64 (hs), run_blk = record block;
+  // set by walk_begin(), advanced at the end of every step.
+  int64_t run_x = 0, run_h = 0, run_blk = 0, run_x_last = 0, pend_h = 0, pend_blk = 0;
+  const int64_t d_x = (rev ? -1 : 1) * a.p_step * C, d_h = (rev ? -1 : 1) * a.p_step * (ndir * H), d_blk = rev ? -ndir : ndir;
   int nc = 0;
   int64_t rec_tile = 0;                         // tile * S: compact records are blocked per (tile, step, direction)
   // FiLM of the NEXT block (dis_embd3 :509-513) in the y epilogue: y <- y * film_w[n] + film_b[n] with the planes of
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
     return r;
   };
-  auto ln_store = [&](const XVec<C>& xv, int buf, int s) {
+  auto ln_store = [&](const XVec<C>& xv, int buf, int s, int64_t ex) {      // ex = st(s) p_step C (uniform)
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) sum += xv.v[v];
@@ -356,15 +363,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
       for (int v = 0; v < VPT; ++v) XS[s & 3][ls][cpart * VPT + v] = xv.v[v];
       if (a.x_sum && lvalid) {
-        const int st = rev ? S - 1 - s : s;
-        float* p = a.x_sum + (int64_t)st * a.p_step * C + lo_x;
+        float* p = a.x_sum + ex + lo_x;
 #pragma unroll
         for (int v = 0; v < VPT; ++v) p[v] = xv.v[v];
       }
     }
     if (SAVE && lvalid && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
-      const int st = rev ? S - 1 - s : s;
-      const int64_t uo = (int64_t)st * a.p_step * C + lo_x;
+      const int64_t uo = ex + lo_x;
       if constexpr (SAVE == 3) {            // only the streaming backward reads u, as a single fp16 term
         _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + uo;
         if constexpr (VPT == 2) *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)u[0], (_Float16)u[1]};
@@ -411,16 +416,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // the product groups of the NEXT step's W_hh h phase -- ~70 ticks of matrix work apart, no wave ever finds the path busy.
   // (not for the C = 16 inter-frame walk: one wave carries its whole y epilogue there and is the pole of every step;
   // measured 1.11 -> 1.17 ms with the stores moved into its phase A)
+#ifdef SB_NO_DEFER                                   // A/B switch (developer builds)
+  constexpr bool DEFER = false;
+#else
   constexpr bool DEFER = SAVE >= 2 && !(LIN && C == 16);
+#endif
   f32x4 rgi = zero4(), rgf = zero4(), rgg = zero4(), rgo = zero4(), rcp = zero4();     // records of step s_pend
   int s_pend = -1;
   auto rec_piece = [&](int k) __attribute__((always_inline)) {
     if constexpr (SAVE >= 2) {
       if (s_pend >= 0 && cvalid) {
-        const int st = rev ? S - 1 - s_pend : s_pend;
-        const int64_t blk = (rec_tile + st) * ndir + dir;
+        const int64_t blk = pend_blk;
         if (k == (SAVE == 4 ? 5 : 3)) {                  // hs of the step (h / htv still hold it: they change in phases B / C)
-          const int64_t ho = (int64_t)st * a.p_step * (ndir * H) + co_h;
+          const int64_t ho = pend_h + co_h;
           if constexpr (LIN && SAVE == 3) {   // the Linear is applied here: hs only feeds the backward kernels (fp16 terms)
             h16x4 h16;
 #pragma unroll
@@ -524,25 +532,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
   };
   // y of step sy (its W_lin h is in yacc, its residual row in xres)
-  auto store_y = [&](int sy) {
+  auto store_y = [&](int64_t ey) {                  // ey = st(sy) p_step C of the step sy whose y this is (uniform)
     if (linw && cvalid && !(SB_EXP_SKIP & 16)) {
-      const int st = rev ? S - 1 - sy : sy;
-      const int64_t sp = (int64_t)st * a.p_step;      // uniform
       f32x4 v = yacc + lbias + xres;
       if (film) {
-        if (a.y_pre) st4(a.y_pre + sp * C + co_y, v);
+        if (a.y_pre) st4(a.y_pre + ey + co_y, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], fw[r], fb[r]);
       }
-      float* yp = a.y + sp * (lin_part ? 2 * C : C) + co_y;
+      float* yp = a.y + (lin_part ? 2 * ey : ey) + co_y;
       if (prod) st4_sc1(yp, v); else st4(yp, v);
     }
   };
-  auto load_res = [&](int sy) {
+  auto load_res = [&](int sy, int64_t ey) {
     if (linw && cvalid && !lin_part && !(SB_EXP_SKIP & 32)) {
-      const int st = rev ? S - 1 - sy : sy;
       if constexpr (SUM3) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);
-      else xres = ld4(a.x + (int64_t)st * a.p_step * C + co_y);
+      else xres = ld4(a.x + ey + co_y);
     }
   };
 
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     {
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = accx[g];
-      ln_store(xrow, cur, min(s + 2, S - 1));
+      ln_store(xrow, cur, min(s + 2, S - 1), s + 2 <= S - 1 ? run_x + 2 * d_x : run_x_last);
       h_part(acc, cur);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -595,12 +600,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     if constexpr (SAVE >= 2) {        // records of this step: issued in phase A of the next one (or by the flush after the walk)
       rgi = gi; rgf = gf; rgg = gg; rgo = go; rcp = cprev;
       s_pend = s;
+      pend_blk = run_blk; pend_h = run_h;
       if constexpr (!DEFER) rec_flush();              // ... or right here
     } else {
       if (cvalid) {
         const int st = rev ? S - 1 - s : s;
         const int64_t pos = cbase + (int64_t)st * a.p_step;
-        if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + (int64_t)st * a.p_step * (ndir * H) + co_h, h);
+        if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + run_h + co_h, h);
         if (SAVE == 1) {
           float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
           st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
@@ -608,9 +614,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       }
     }
     if constexpr (LIN) {
-      if (s > s_begin) store_y(s - 1);
-      load_res(s);
+      if (s > s_begin) store_y(run_x - d_x);
+      load_res(s, run_x);
     }
+    run_x += d_x; run_h += d_h; run_blk += d_blk;       // row s + 1
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c4);
     __syncthreads();
@@ -661,8 +668,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       store_h(s_begin & 1, h);
       XVec<C> x0 = load_x(s_begin);
       XVec<C> x1 = load_x(min(s_begin + 1, S - 1));
-      ln_store(x0, s_begin & 1, s_begin);
-      ln_store(x1, (s_begin + 1) & 1, min(s_begin + 1, S - 1));
+      {                                                // running step terms of row s_begin (see their declaration)
+        const int st0 = rev ? S - 1 - s_begin : s_begin;
+        run_x = (int64_t)st0 * a.p_step * C;
+        run_h = (int64_t)st0 * a.p_step * (ndir * H);
+        run_blk = (rec_tile + st0) * ndir + dir;
+        run_x_last = (int64_t)(rev ? 0 : S - 1) * a.p_step * C;
+      }
+      ln_store(x0, s_begin & 1, s_begin, run_x);
+      ln_store(x1, (s_begin + 1) & 1, min(s_begin + 1, S - 1), s_begin + 1 <= S - 1 ? run_x + d_x : run_x_last);
       xa = load_x(min(s_begin + 2, S - 1));
       xb = load_x(min(s_begin + 3, S - 1));
       xc = load_x(min(s_begin + 4, S - 1));
@@ -705,7 +719,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           }
         }
       }
-      store_y(s_end - 1);
+      store_y(run_x - d_x);                            // (run_x stands at row s_end)
       if (prod) { while (next_slab * a.slab_len < S) slab_signal(next_slab++); }
     }
     // ---- final state: to the caller after the last step, to the next segment otherwise ----
