@@ -27,3 +27,8 @@ for wl in ("big", "small"):
         bench.run_workload(torch, None, sb, ops, wl, args, dev, 1, 0, forward_only=fwd, mode=mode, steps=2, warmup=1, profile=False)
         torch.cuda.synchronize()
         table(f"{wl} / {'inference' if fwd else 'train, ' + mode}")
+        if not fwd:
+            b = (ctypes.c_float * 8)()
+            if lib.sb_debug_phase_bwd_split(b) == 0 and sum(b[:4]) > 0:
+                print(f"{wl} / train, {mode}: chunk role of the last role-split backward launch, ticks per period: work before hand-over "
+                      f"{b[0]:.0f}, wait {b[1]:.0f}, work after {b[2]:.0f}, wait at second barrier {b[3]:.0f}  (sum {sum(b[:4]):.0f})")

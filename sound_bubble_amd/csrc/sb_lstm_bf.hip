@@ -39,6 +39,12 @@
 // kind 0 plain, 1 fused Linear, 2 summed input + fused Linear (the inter-frame producer), 3 ordered consumer, 4 bidirectional
 // partial-Linear; read with sb_debug_phase_fwd()
 __device__ float g_phase_fwd[5][16][8];
+// chunk role of the role-split backward (wave 4 of workgroup 0): ticks per period of [work before the hand-over barrier, wait
+// at it, work after it, wait at the second barrier]; read with sb_debug_phase_bwd_split()
+__device__ float g_phase_bwd_split[8];
+extern "C" int sb_debug_phase_bwd_split(float* host_out) {
+  return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_bwd_split), sizeof(g_phase_bwd_split));
+}
 extern "C" int sb_debug_phase_fwd(float* host_out) {
   const int rc = -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_fwd), sizeof(g_phase_fwd));
   static float zeros[5 * 16 * 8];
@@ -1132,6 +1138,53 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
           al[kk] = (_Float16)__builtin_fmaf((float)hh, -kLoUp, v[kk] * kLoUp);
         }
       };
+      // dgates of this lane's 8 k-slots, gate columns 64w + 4j .. + 3: hi and scaled low terms
+      auto build_A = [&](h16x8 (&Aoh)[4], h16x8 (&Aol)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const h16x4 th = *reinterpret_cast<const h16x4*>(&DG[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
+          const h16x4 tl = *reinterpret_cast<const h16x4*>(&DGL[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) { Aoh[nt][kk] = th[nt]; Aol[nt][kk] = tl[nt]; }
+        }
+      };
+      auto col_sums = [&](const h16x8 (&Aoh)[4], const h16x8 (&Aol)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) {
+            csum[nt] = __builtin_amdgcn_fdot2(h16x2{Aoh[nt][2 * pr], Aoh[nt][2 * pr + 1]}, ones2, csum[nt], false);
+            csumx[nt] = __builtin_amdgcn_fdot2(h16x2{Aol[nt][2 * pr], Aol[nt][2 * pr + 1]}, ones2, csumx[nt], false);
+          }
+      };
+      auto w_prod = [&](int kt, const h16x8 (&Aoh)[4], const h16x8 (&Aol)[4], const h16x8& bh, const h16x8& bl, const h16x8& bs)
+          __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aol[nt], bs, wacc[nt][kt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bl, wacc[nt][kt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bh, wacc[nt][kt], 0, 0, 0);
+      };
+      // column tiles of u (dW_ih) and the bias sums: they need no h_prev, so in the role-split kernel they run BEFORE the
+      // hand-over barrier (phase 0), where the chunk role used to wait ~1 350 ticks per period for the recurrence role's step
+      auto u_tiles = [&](const h16x8 (&Aoh)[4], const h16x8 (&Aol)[4]) __attribute__((always_inline)) {
+        col_sums(Aoh, Aol);
+#pragma unroll
+        for (int kt = 0; kt < CK; ++kt) {
+          h16x8 bh, bl, bs;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            if constexpr (STG) {
+              const h16x4 up = *reinterpret_cast<const h16x4*>(&SUP[stg_sel][(8 * q + kk) * SUROW + 8 * j]);
+              bh[kk] = up[kt]; bl[kk] = up[2 + kt];
+            } else if constexpr (CK == 2) { bh[kk] = o.up4[kk][kt]; bl[kk] = o.up4[kk][2 + kt]; }
+            else { bh[kk] = o.up2[kk][0]; bl[kk] = o.up2[kk][1]; }
+          }
+          bs = bh * dn8;
+          w_prod(kt, Aoh, Aol, bh, bl, bs);
+        }
+      };
       if (phase != 0) {
       // h_prev tile kt (units 4j + kt of the 8 k-slots) as matrix operands hi, lo, 2^-11 hi -- built on demand from the
       // (masked) pairs: materialising all four tiles up front costs 48 registers the role-split kernel does not have
@@ -1212,47 +1265,17 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         }
       };
       if constexpr (LINW) do_linw();
-      // dgates of this lane's 8 k-slots, gate columns 64w + 4j .. + 3: hi and scaled low terms
       h16x8 Aoh[4], Aol[4];
+      build_A(Aoh, Aol);
+      if (phase != 1 || !STG) u_tiles(Aoh, Aol);     // (one-role kernel, and the split kernels that hold the rows in registers: here)
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const h16x4 th = *reinterpret_cast<const h16x4*>(&DG[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
-        const h16x4 tl = *reinterpret_cast<const h16x4*>(&DGL[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) { Aoh[nt][kk] = th[nt]; Aol[nt][kk] = tl[nt]; }
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-          csum[nt] = __builtin_amdgcn_fdot2(h16x2{Aoh[nt][2 * pr], Aoh[nt][2 * pr + 1]}, ones2, csum[nt], false);
-          csumx[nt] = __builtin_amdgcn_fdot2(h16x2{Aol[nt][2 * pr], Aol[nt][2 * pr + 1]}, ones2, csumx[nt], false);
-        }
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {              // column tiles: u, then h_prev
+      for (int kt = CK; kt < KT; ++kt) {             // column tiles of h_prev
         h16x8 bh, bl, bs;
-        if (kt < CK) {
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            if constexpr (STG) {
-              const h16x4 up = *reinterpret_cast<const h16x4*>(&SUP[stg_sel][(8 * q + kk) * SUROW + 8 * j]);
-              bh[kk] = up[kt < CK ? kt : 0]; bl[kk] = up[2 + (kt < CK ? kt : 0)];
-            } else if constexpr (CK == 2) { bh[kk] = o.up4[kk][kt < CK ? kt : 0]; bl[kk] = o.up4[kk][2 + (kt < CK ? kt : 0)]; }
-            else { bh[kk] = o.up2[kk][0]; bl[kk] = o.up2[kk][1]; }
-          }
-          bs = bh * dn8;
-        } else {
-          if (kt == CK) htile(std::integral_constant<int, 0>{}, bh, bl, bs);
-          else if (kt == CK + 1) htile(std::integral_constant<int, 1>{}, bh, bl, bs);
-          else if (kt == CK + 2) htile(std::integral_constant<int, 2>{}, bh, bl, bs);
-          else htile(std::integral_constant<int, 3>{}, bh, bl, bs);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aol[nt], bs, wacc[nt][kt], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bl, wacc[nt][kt], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wacc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aoh[nt], bh, wacc[nt][kt], 0, 0, 0);
+        if (kt == CK) htile(std::integral_constant<int, 0>{}, bh, bl, bs);
+        else if (kt == CK + 1) htile(std::integral_constant<int, 1>{}, bh, bl, bs);
+        else if (kt == CK + 2) htile(std::integral_constant<int, 2>{}, bh, bl, bs);
+        else htile(std::integral_constant<int, 3>{}, bh, bl, bs);
+        w_prod(kt, Aoh, Aol, bh, bl, bs);
       }
       }
       if (phase != 1)
@@ -1284,6 +1307,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
           for (int r = 0; r < 4; ++r) du[ct][r] = __builtin_fmaf(dux[ct][r], kLoDn, du[ct][r]);
           st4(&R[buf][w][sb][ct][lane][0], du[ct]);
         }
+      }
+      if (phase == 0 && STG) {                       // (rows in LDS: nothing is held across the barrier for it)
+        h16x8 Aoh[4], Aol[4];
+        build_A(Aoh, Aol);
+        u_tiles(Aoh, Aol);
       }
     } else {
     if (phase != 0) {
@@ -1903,28 +1931,46 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       if constexpr (STG) stage_issue(s_hi, s_hi - 1 >= s_lo, 1, tile);     // the first chunk's rows: read in period 1 (buffer 1)
       __syncthreads();
       if constexpr (LINW && HREC) lin_top();                               // h of walk index S - 1 is in the ring by now
+      if constexpr (STG) __builtin_amdgcn_s_waitcnt(0);                    // the first chunk's rows have landed
       __syncthreads();
       int s = s_hi;
+#ifdef SB_PHASE_TIMING
+      unsigned long long cph[4] = {0, 0, 0, 0};
+#endif
       for (int k = 1; k <= npairs; ++k, s -= 2) {                  // chunk of pair k - 1: steps (s, s - 1)
+        SB_TICK(q0);
         const bool two = s - 1 >= s_lo;
         const int pb = (k - 1) & 1, rb = STG ? 0 : pb;
         PairOps ops2;
         if constexpr (STG) {
+          stg_sel = k & 1;                                         // this period's rows: landed and published before the last barrier
           chunk(2 * pb, rb, ops2, s, two, 0);
-          __builtin_amdgcn_s_waitcnt(0);                           // this period's rows (issued a period ago) have landed
         } else {
           ops2 = pair_loads(s, two);
           chunk(2 * pb, rb, ops2, s, two, 0);                      // du partial sums -> R[rb]
         }
+        __builtin_amdgcn_sched_barrier(0);
+        SB_TICK(q1);
         __syncthreads();
+        SB_TICK(q2);
         if constexpr (STG) {
-          stg_sel = k & 1;
           if (k < npairs) stage_issue(s - 2, s - 3 >= s_lo, (k + 1) & 1, tile);  // the next period's rows, a period ahead
         }
         flush(s, two ? 2 : 1, rb, ops2.xq, ops2.rq);
         chunk(2 * pb, rb, ops2, s, two, 1);
+        if constexpr (STG) __builtin_amdgcn_s_waitcnt(0);          // the next period's rows (issued at the top of this phase) have landed
+        __builtin_amdgcn_sched_barrier(0);
+        SB_TICK(q3);
         __syncthreads();
+#ifdef SB_PHASE_TIMING
+        SB_TICK(q4);
+        cph[0] += q1 - q0; cph[1] += q2 - q1; cph[2] += q3 - q2; cph[3] += q4 - q3;
+#endif
       }
+#ifdef SB_PHASE_TIMING
+      if (blockIdx.x == 0 && blockIdx.y == 0 && w == 0 && lane == 0 && item == (int)blockIdx.x)
+        for (int i = 0; i < 4; ++i) g_phase_bwd_split[i] = (float)cph[i] / npairs;
+#endif
       if constexpr (SEG) { if (s_lo > 0) __syncthreads(); }        // (the recurrence role publishes its state)
       __syncthreads();                                             // between items
     }
