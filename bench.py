@@ -258,6 +258,9 @@ DTYPE_FWD = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo
 # rocprof kernel-name patterns of the labels ops.PROFILE uses (for the committed PMC traffic JSONs, whose keys are
 # "<kernel name> grid=<threads>").  The two forward recurrences share one instantiation since the intra-frame pass applies
 # its Linear in the kernel too: they are told apart by the grid (bidirectional = twice the workgroups of more tiles).
+# the overlapped inter-frame backward: recurrence (dgates to HBM, slab flags) + stream kernel, counted in plain order
+# (SB_BWD_PAIR_SERIAL=1 passes, profiles/r*_pmc_traffic_<wl>_wide_pair.json): the pair's traffic is the SUM of the two
+PMC_PAIR = (r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, false, 0, false, false, false, false, true", r"lstm_bwd_stream_f16_kernel")
 PMC_PATTERNS = [
     ("intra-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, false, \d+, false, true", None),
     ("inter-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, \w+, (16|32), \w+, false", None),
@@ -273,6 +276,19 @@ def pmc_traffic(workload, label, mode="wide"):
     (profiles/r*_pmc_traffic_<workload>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied)."""
     import glob
     import re
+    if "inter overlapped" in label:
+        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}_{mode}_pair.json")))
+        if not pf:
+            return None, None
+        ks = json.load(open(pf[-1]))["kernels"]
+        parts = []
+        for pat in PMC_PAIR:
+            m = [v for k, v in ks.items() if re.search(pat, k)]
+            if not m:
+                return None, None
+            parts.append(sum(v["hbm_bytes"] * v["launches"] for v in m) / sum(v["launches"] for v in m))
+        return sum(parts), (os.path.relpath(pf[-1], ROOT) + " (rocprofv3 --pmc passes with SB_BWD_PAIR_SERIAL=1: the pair's two kernels in "
+                            "plain order, recurrence + stream kernel summed)")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}{'' if mode == 'compact' else '_' + mode}.json")))
     ent = next(((p, sel) for key, p, sel in PMC_PATTERNS if key in label), None)
     if not files or ent is None:

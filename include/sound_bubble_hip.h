@@ -361,6 +361,11 @@ int sb_lstm_stream_grid(int64_t positions);
  * (sb_overlap_available): use the two plain calls. */
 int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec, const sb_lstm_stream_args* st, int* flags, int slab_len,
                                  void* stream);
+/* Measurement aid: the same two kernels in plain order on `stream` (the recurrence, then one stream-kernel launch that
+ * finds every slab flag up), no side stream.  Slower than the fused single launch -- it exists so that profilers that
+ * serialise kernels (rocprofv3 --pmc) can count the HBM traffic of the overlapped pair: the sum of these two launches. */
+int sb_lstm_bwd_inter_pair_serial(const sb_lstm_bwd_args* rec, const sb_lstm_stream_args* st, int* flags, int slab_len,
+                                  void* stream);
 int sb_lstm_overlap_rows(int64_t positions, int nseq);
 /* The overlapped calls need a side stream whose kernels really run at the same time as those of `stream` (the runtime
  * multiplexes streams over a few hardware queues; two streams on one queue serialise).  These four calls are the ONLY

@@ -17,5 +17,11 @@ pmc() { # workload
 }
 pmc big
 pmc small
+# the overlapped inter-frame backward pair cannot be seen by a serialising profiler: its two kernels in plain order
+# (SB_BWD_PAIR_SERIAL=1) -- the pair's HBM traffic is the sum of the two launches
+ARGS="--steps 2 --warmup 1 --workload big --no-cpu-baseline --no-exact"
+cd /tmp && SB_BWD_PAIR_SERIAL=1 timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/pmc_fetch_bigpair" -o f -- python "$R/bench.py" $ARGS > "$R/gpurun_out/pmc_fetch_bigpair.log" 2>&1
+cd /tmp && SB_BWD_PAIR_SERIAL=1 timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/pmc_write_bigpair" -o w -- python "$R/bench.py" $ARGS > "$R/gpurun_out/pmc_write_bigpair.log" 2>&1
+cd "$R"; python scripts/pmc_summary.py bigpair "$R/gpurun_out" "$R/gpurun_out/pmc_traffic_big_wide_pair.json" "$R/gpurun_out/pmc_sq_bigpair_unused.json" > "$R/gpurun_out/pmc_summary_bigpair.log" 2>&1
 cd "$R"; find gpurun_out -name "*kernel_trace.csv" -size +30M -delete; find gpurun_out -name "*counter_collection.csv" -size +20M -delete; find gpurun_out -name "*.db" -delete
 ls gpurun_out | head -50

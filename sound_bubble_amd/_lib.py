@@ -138,6 +138,7 @@ SYMBOLS = {
     "sb_lstm_bwd_stream": (_ci, [C.POINTER(LstmStreamArgs), _vp]),
     "sb_lstm_stream_grid": (_ci, [i64]),
     "sb_lstm_bwd_inter_overlapped": (_ci, [C.POINTER(LstmBwdArgs), C.POINTER(LstmStreamArgs), _vp, _ci, _vp]),
+    "sb_lstm_bwd_inter_pair_serial": (_ci, [C.POINTER(LstmBwdArgs), C.POINTER(LstmStreamArgs), _vp, _ci, _vp]),
     "sb_lstm_overlap_rows": (_ci, [i64, _ci]),
     "sb_overlap_available": (_ci, [_vp]),
     "sb_overlap_init": (_ci, [_vp, c_fp, C.POINTER(C.c_float)]),

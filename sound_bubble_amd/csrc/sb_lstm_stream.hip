@@ -1294,8 +1294,11 @@ extern "C" int sb_lstm_overlap_rows(int64_t positions, int nseq) {
 }
 
 // flags layout: [0] recurrence workgroups started, [1] the unit counter, [2], [3] spare, [4 ..] the slab flags
-extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args* st_in, int* flags,
-                                            int slab_len, void* stream) {
+// serial: the same two kernels in plain order on `stream` (recurrence, then ONE stream-kernel launch that finds every flag
+// up) -- sb_lstm_bwd_inter_pair_serial, a measurement aid: profilers that serialise kernels (rocprofv3 --pmc) cannot see
+// the overlapped pair, and its HBM traffic is the sum of these two launches
+static int inter_pair(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args* st_in, int* flags, int slab_len, void* stream,
+                      bool serial) {
   if (!rec_in || !st_in || !flags) return -1001;
   sb_lstm_bwd_args rec = *rec_in;
   sb_lstm_stream_args sa = *st_in;
@@ -1308,8 +1311,8 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
     return -1003;
   const int cus = device_cus(), idle = cus - ntiles;
   if (idle < 16) return -1003;
-  SideStream* ss = side_stream(main_st);
-  if (!ss) return -1009;
+  SideStream* ss = serial ? nullptr : side_stream(main_st);
+  if (!ss && !serial) return -1009;
   const int nslabs = (T + slab_len - 1) / slab_len;
   const int nb = (int)(sa.P / sa.seg_len);
   const int cpb = (int)((slab_len * sa.shift_pos + 31) / 32), cps = nb * cpb;
@@ -1317,10 +1320,10 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
   const int nch = (nslabs - 1) * cps + nb * cpl;
   // next to the recurrence: one workgroup per idle CU (register budget: none fits on a recurrence CU; one that cannot be
   // placed at once starts later and draws fewer units); behind it: one per CU
-  const int g1 = idle, g2 = cus;
+  const int g1 = serial ? 0 : idle, g2 = cus;
 
   if (hipMemsetAsync(flags, 0, (size_t)(nslabs + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
-  if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;
+  if (!serial && hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;
   rec.slab_flags = flags + 4; rec.slab_len = slab_len; rec.slab_started = flags;
   int rc = sb_lstm_bwd_rec(&rec, stream);
   if (rc) return rc;
@@ -1329,22 +1332,33 @@ extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, cons
 #define SB_SO(CC, ST, G) do { \
     if (sa.wide) hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, true, true, true>), dim3(G), dim3(256), 0, ST, sa); \
     else hipLaunchKernelGGL((lstm_bwd_stream_f16_kernel<CC, false, true, true, true, true, true>), dim3(G), dim3(256), 0, ST, sa); } while (0)
-  if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
-  sa.guard = 1; sa.row_base = 0;
-  if (C == 32) SB_SO(32, ss->s, g1); else SB_SO(16, ss->s, g1);
-  SB_CHECK_LAUNCH();
-  if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
+  if (!serial) {
+    if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
+    sa.guard = 1; sa.row_base = 0;
+    if (C == 32) SB_SO(32, ss->s, g1); else SB_SO(16, ss->s, g1);
+    SB_CHECK_LAUNCH();
+    if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
+  }
   // behind the recurrence on `stream` (all flags up): the same kernel drawing what is left; then the join
   sa.guard = 0; sa.row_base = g1;
   if (C == 32) SB_SO(32, main_st, g2); else SB_SO(16, main_st, g2);
 #undef SB_SO
   SB_CHECK_LAUNCH();
-  if (hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
+  if (!serial && hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
   const int tot = 4 * H * (C + H) + 4 * H;
   const int ex_off[4] = {tot, tot + C, tot + 2 * C, tot + 2 * C + C * H}, ex_n[4] = {C, C, C * H, C};
   float* const ex_out[4] = {sa.d_ln_g, sa.d_ln_b, sa.d_lin_w, sa.d_lin_b};
   return sb_launch_stream_reduce(sa.scratch, g1 + g2, (int64_t)tot + 2 * C + C * H + C, C, sa.dW_ih[0], sa.dW_hh[0],
                                  sa.db_ih[0], sa.db_hh[0], main_st, 4, ex_off, ex_n, ex_out);
+}
+
+extern "C" int sb_lstm_bwd_inter_overlapped(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args* st_in, int* flags,
+                                            int slab_len, void* stream) {
+  return inter_pair(rec_in, st_in, flags, slab_len, stream, false);
+}
+extern "C" int sb_lstm_bwd_inter_pair_serial(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args* st_in, int* flags,
+                                             int slab_len, void* stream) {
+  return inter_pair(rec_in, st_in, flags, slab_len, stream, true);
 }
 
 // ---- overlapped forward (see the header) ----

@@ -600,6 +600,11 @@ BWD_OVERLAP = os.environ.get("SB_NO_BWD_OVERLAP", "0") != "1"
 BWD_OVERLAP_SLAB = int(os.environ.get("SB_BWD_OVERLAP_SLAB", "32"))
 
 
+# measurement aid (scripts/gpu_profiles_r3.sh): the two kernels of the overlapped inter-frame backward in plain order, so that a
+# serialising profiler (rocprofv3 --pmc) can count the pair's HBM traffic
+BWD_PAIR_SERIAL = os.environ.get("SB_BWD_PAIR_SERIAL", "0") == "1"
+
+
 def can_overlap_inter_bwd(geom, u, hs):
     """the overlapped form pays when the recurrence leaves a good part of the chip idle and has enough slabs to pipeline"""
     if _wide():               # wide form: u / hs are the (hi, lo) pair tensors
@@ -616,7 +621,7 @@ def can_overlap_inter_bwd(geom, u, hs):
     ntiles = (geom.nseq + 15) // 16
     cus = _cu_count(u.device)
     return (OVERLAP_MIN_FILL * cus <= ntiles <= OVERLAP_MAX_FILL * cus and geom.nsteps >= 4 * BWD_OVERLAP_SLAB
-            and geom.n_inner * geom.nsteps >= 32 and overlap_available())
+            and geom.n_inner * geom.nsteps >= 32 and (BWD_PAIR_SERIAL or overlap_available()))
 
 
 def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets, ln):
@@ -662,9 +667,11 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
     slab = BWD_OVERLAP_SLAB
     flags = torch.empty((geom.nsteps + slab - 1) // slab + 4, device=dev, dtype=torch.int32)      # + 4 control words
     by = P * ((1280.0 + 3 * 1024.0 + 256 * 2 + 4.0 * Cc if wide else 640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc) + 4 * 4.0 * Cc)
-    with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)" + (" [wide]" if wide else ""),
+    with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)" + (" [wide]" if wide else "")
+               + (" [in plain order: SB_BWD_PAIR_SERIAL]" if BWD_PAIR_SERIAL else ""),
                (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P, 8.0 * Cc * P, by):
-        rc = lib.sb_lstm_bwd_inter_overlapped(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab, _stream())
+        fn = lib.sb_lstm_bwd_inter_pair_serial if BWD_PAIR_SERIAL else lib.sb_lstm_bwd_inter_overlapped
+        rc = fn(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab, _stream())
         if rc == -1009:                    # no side stream (any more): the caller takes the two plain launches
             overlap_lost()
             return None

@@ -1238,3 +1238,13 @@ def test_wide_overlapped_inter_backward_matches_the_fused_wide_launch(torch_gpu,
         assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 5e-6, name
     if ops.ABSMAX_HINTS:
         assert float(ops.absmax_or_hint(dx1)) == float(dx1.abs().max())
+    # the measurement form (the pair's two kernels in plain order, no side stream: SB_BWD_PAIR_SERIAL) is the same arithmetic
+    monkeypatch.setattr(ops, "BWD_PAIR_SERIAL", True)
+    tg2, lin2, ln2 = targets()
+    dx2 = ops.lstm_bwd_inter_overlapped(wh, gates, geom, dy, lin_w, u, hs, wi, tg2, lin2, (x, g, ln2[0], ln2[1]))
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    assert dx2 is not None and torch.equal(dx2, dx1)
+    for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh", "dW_lin", "db_lin", "d_ln_g", "d_ln_b"),
+                            tg2 + list(lin2) + list(ln2), tg1 + list(lin1) + list(ln1)):
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6, name
