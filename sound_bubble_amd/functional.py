@@ -18,6 +18,17 @@ GRAD_MODE = True     # set by the Net wrapper from torch.is_grad_enabled() (Func
 DIRECT_GRADS = True  # accumulate parameter gradients straight into pre-allocated .grad buffers (see _gt)
 
 
+def direct_grad_target(p):
+    """p's flat-bucket gradient buffer when the HIP reductions may add into it directly, else None: only buffers
+    train.FlatBucket set up (it tags the parameter) -- an ordinary .grad left over from autograd or a frozen parameter go
+    through autograd as usual"""
+    g = p.grad
+    if (DIRECT_GRADS and g is not None and getattr(p, "_sb_flat_grad", False) and p.requires_grad
+            and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous() and g.device == p.device):
+        return g
+    return None
+
+
 class _GradTargets:
     """Where the HIP reductions put d(loss)/d(param).  All weight-gradient kernels ACCUMULATE (atomicAdd) into their
     output, so when a parameter already owns a .grad buffer (train.FlatBucket points every .grad into one flat,
@@ -29,11 +40,8 @@ class _GradTargets:
         self.ret = {}
 
     def __call__(self, name, p):
-        g = p.grad
-        # direct accumulation only into gradient buffers train.FlatBucket set up (it tags the parameter): an ordinary
-        # .grad left over from autograd, a frozen parameter or torch.autograd.grad() calls go through autograd as usual
-        if (DIRECT_GRADS and g is not None and getattr(p, "_sb_flat_grad", False) and p.requires_grad
-                and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous() and g.device == p.device):
+        g = direct_grad_target(p)
+        if g is not None:
             self.ret[name] = None
             return g
         z = torch.zeros_like(p, dtype=torch.float32)

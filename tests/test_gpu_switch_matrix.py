@@ -1,0 +1,117 @@
+"""The documented dispatch switches (README "Switches") inside the -m gpu run: one child process per switch
+(tests/switch_probe.py -- the switches are read at import), each held to the REFERENCE goldens at the tiny geometry and to
+the switch-free run at a medium geometry where the schedules the switches steer really engage (73 / 290 inter-frame tiles
+x 200 steps).  A switch that silently changes results, trips the schedule watchdog or stops loading fails here, not only
+in a builder-run sweep."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PROBE = os.path.join(HERE, "switch_probe.py")
+ALL = ["SB_BPTT", "SB_EXACT_BPTT", "SB_NO_ROLE_SPLIT", "SB_NO_HS_RECOMPUTE", "SB_LSTM_BF16X6", "SB_LSTM_FP32",
+       "SB_DGATES_FP32", "SB_NO_TIME_SEGMENTS", "SB_AUX_FP32", "SB_NO_FUSED_BPTT_BI", "SB_NO_FUSED_LN", "SB_NO_ABSMAX_HINTS",
+       "SB_NO_FUSED_BPTT", "SB_FORCE_FUSED_BPTT", "SB_LINEAR_FP32", "SB_NO_FWD_OVERLAP", "SB_NO_BWD_OVERLAP",
+       "SB_NO_FWD_OVERLAP_INFERENCE", "SB_NO_INTER_SUM3", "SB_NO_INTER_FILM", "SB_NO_STREAM_LIN_WGRAD",
+       "SB_NO_INTRA_LIN_FUSION", "SB_GATE_RECOMPUTE", "SB_BWD_PAIR_SERIAL", "SB_FWD_OVERLAP_SLAB", "SB_BWD_OVERLAP_SLAB",
+       "SB_OVERLAP_MAX_FILL"]
+
+# (id, environment, gradient bar): 2e-4 = the wide (default) arithmetic's bar against the goldens, 2e-3 the compact one's
+WIDE, COMPACT = 2e-4, 2e-3
+SWITCHES = [
+    ("bptt-compact", {"SB_BPTT": "compact"}, COMPACT),
+    ("bptt-legacy", {"SB_BPTT": "legacy"}, WIDE),
+    ("exact-bptt", {"SB_EXACT_BPTT": "1"}, WIDE),
+    ("no-role-split", {"SB_NO_ROLE_SPLIT": "1"}, WIDE),
+    ("no-hs-recompute", {"SB_NO_HS_RECOMPUTE": "1"}, WIDE),
+    ("lstm-bf16x6", {"SB_LSTM_BF16X6": "1"}, WIDE),
+    ("lstm-fp32", {"SB_LSTM_FP32": "1"}, WIDE),
+    ("dgates-fp32-compact", {"SB_BPTT": "compact", "SB_DGATES_FP32": "1"}, COMPACT),
+    ("no-time-segments", {"SB_NO_TIME_SEGMENTS": "1"}, WIDE),
+    ("aux-fp32", {"SB_AUX_FP32": "1"}, WIDE),
+    ("no-fused-bptt-bi", {"SB_NO_FUSED_BPTT_BI": "1"}, WIDE),
+    ("no-fused-ln", {"SB_NO_FUSED_LN": "1"}, WIDE),
+    ("no-absmax-hints-compact", {"SB_BPTT": "compact", "SB_NO_ABSMAX_HINTS": "1"}, COMPACT),
+    ("no-fused-bptt", {"SB_NO_FUSED_BPTT": "1"}, WIDE),
+    ("force-fused-bptt", {"SB_FORCE_FUSED_BPTT": "1"}, WIDE),
+    ("linear-fp32", {"SB_LINEAR_FP32": "1"}, WIDE),
+    ("no-fwd-overlap", {"SB_NO_FWD_OVERLAP": "1"}, WIDE),
+    ("no-bwd-overlap", {"SB_NO_BWD_OVERLAP": "1"}, WIDE),
+    ("no-overlap-compact", {"SB_BPTT": "compact", "SB_NO_FWD_OVERLAP": "1", "SB_NO_BWD_OVERLAP": "1"}, COMPACT),
+    ("no-fwd-overlap-inference", {"SB_NO_FWD_OVERLAP_INFERENCE": "1"}, WIDE),
+    ("no-inter-sum3", {"SB_NO_INTER_SUM3": "1"}, WIDE),
+    ("no-inter-film", {"SB_NO_INTER_FILM": "1"}, WIDE),
+    ("no-stream-lin-wgrad", {"SB_NO_STREAM_LIN_WGRAD": "1"}, WIDE),
+    ("no-intra-lin-fusion", {"SB_NO_INTRA_LIN_FUSION": "1"}, WIDE),
+    ("gate-recompute-compact", {"SB_BPTT": "compact", "SB_GATE_RECOMPUTE": "1"}, COMPACT),
+    ("bwd-pair-serial", {"SB_BWD_PAIR_SERIAL": "1"}, WIDE),
+    ("overlap-slabs", {"SB_FWD_OVERLAP_SLAB": "8", "SB_BWD_OVERLAP_SLAB": "12", "SB_OVERLAP_MAX_FILL": "0.6"}, WIDE),
+]
+
+
+def _run(env_extra, *args):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SB_")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, PROBE, *args], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (env_extra, r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("SWITCH_PROBE ")]
+    assert line, r.stdout[-2000:]
+    return json.loads(line[-1][len("SWITCH_PROBE "):])
+
+
+@pytest.fixture(scope="module")
+def baseline(tmp_path_factory):
+    """the switch-free run: held to the goldens itself, keeps the medium-geometry output / gradients for the others"""
+    path = str(tmp_path_factory.mktemp("switch") / "default.npz")
+    out = _run({}, "--save", path)
+    assert out["bptt"] == "wide"
+    for name, g in out["golden"].items():
+        assert g["fwd"] < 2e-5 and g["grad"] < WIDE, (name, g)
+    return path, out
+
+
+def test_every_documented_switch_is_in_the_matrix():
+    """README's switch table, the switches the package reads and this matrix name the same set"""
+    import re
+    root = os.path.dirname(HERE)
+    read = set()
+    for f in ("ops.py", "functional.py", "net.py", "harness.py", "forms.py", "train.py", "streaming.py"):
+        read |= set(re.findall(r"SB_[A-Z0-9_]+", open(os.path.join(root, "sound_bubble_amd", f)).read()))
+    read -= {"SB_PHASE_TIMING", "SB_OVERLAP_DEBUG", "SB_EXTRA_HIPCC_FLAGS", "SB_EPI_LN", "SB_EPI_RES"}
+    covered = set(k for _, env, _ in SWITCHES for k in env)
+    assert covered == set(ALL)
+    assert read <= covered, sorted(read - covered)
+    readme = set(re.findall(r"SB_[A-Z0-9_]+", open(os.path.join(root, "README.md")).read()))
+    assert covered <= readme | {"SB_BWD_PAIR_SERIAL"}, sorted(covered - readme)
+
+
+def test_default_dispatch_takes_the_benched_paths_at_the_medium_geometry(baseline):
+    _, out = baseline
+    big, small = out["medium"]["big"]["labels"], out["medium"]["small"]["labels"]
+    assert any("intra-frame fused BPTT" in k and "[wide]" in k for k in big), big
+    assert any("inter-frame fused BPTT" in k and "[wide]" in k for k in small), small
+    if out["overlap"]:
+        assert any("inter overlapped" in k for k in big), big
+        assert any("[producer]" in k for k in big) and any("[consumer, overlapped]" in k for k in big), big
+
+
+@pytest.mark.parametrize("sid,env,bar", SWITCHES, ids=[s[0] for s in SWITCHES])
+def test_switch_keeps_parity(baseline, sid, env, bar):
+    path, base = baseline
+    out = _run(env, "--compare", path)
+    for name, g in out["golden"].items():                 # against the reference goldens
+        assert g["fwd"] < 2e-5, (sid, name, g)
+        assert g["grad"] < bar, (sid, name, g)
+    for wl, g in out["medium"].items():                   # against the switch-free run where the schedules engage
+        assert g["fwd"] < 2e-5, (sid, wl, g)
+        assert g["grad"] < bar, (sid, wl, g)
+    big = out["medium"]["big"]["labels"]
+    if sid in ("no-fwd-overlap", "no-overlap-compact"):
+        assert not any("[producer]" in k for k in big), big
+    if sid in ("no-bwd-overlap", "no-overlap-compact"):
+        assert not any("inter overlapped" in k for k in big), big
