@@ -64,7 +64,10 @@ def wide_supported(kind, Cc):
     if kind == "inter":
         return Cc in (16, 32)
     if kind == "intra-plain":
-        return Cc == 32 and FUSED_BPTT_BI
+        # the wide bidirectional backward takes hs as the forward's (hi, lo) pairs (or recomputes it): it needs the Linear
+        # applied inside the forward recurrence (found by the switch matrix: SB_NO_INTRA_LIN_FUSION=1 used to reach the
+        # two-kernel backward with pair-form u)
+        return Cc == 32 and FUSED_BPTT_BI and INTRA_LIN_FUSION
     if kind == "intra-conv":
         return Cc == 16 and FUSED_BPTT_BI
     return False

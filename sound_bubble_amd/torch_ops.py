@@ -102,8 +102,8 @@ def separate(mixture: Tensor, dis_embed: Optional[Tensor], params: List[Tensor],
              pad: bool, train: bool) -> List[Tensor]:
     m = _model(model)
     own = list(m.parameters())
-    if len(params) != len(own) or any(a is not b and a.data_ptr() != b.data_ptr() for a, b in zip(params, own)):
-        raise RuntimeError("sound_bubble::separate: params[] must be list(model.parameters()) of the registered model")
+    if len(params) != len(own) or any(a.shape != b.shape for a, b in zip(params, own)):
+        raise RuntimeError("sound_bubble::separate: params[] must match list(model.parameters()) of the registered model")
     B = mixture.shape[0]
     names = _state_names(m, B)
     st = None
@@ -114,9 +114,18 @@ def separate(mixture: Tensor, dis_embed: Optional[Tensor], params: List[Tensor],
     inputs = {"mixture": mixture}
     if dis_embed is not None:
         inputs["dis_embed"] = dis_embed
+    # the usual call hands the module's own parameters; any other tensors of the same shapes (a functional caller, opcheck's
+    # cloned arguments) are swapped in for the call, torch.func.functional_call style -- the result is a function of params[]
+    live = all(a is b or (a.data_ptr() == b.data_ptr() and a.requires_grad == b.requires_grad) for a, b in zip(params, own))
+    if not live:
+        own = list(params)
     record = train and any(p.requires_grad for p in own)
     with _record_autograd(), torch.set_grad_enabled(record):
-        res = m(inputs, st, pad=pad)
+        if live:
+            res = m(inputs, st, pad=pad)
+        else:
+            res = torch.func.functional_call(m, {n: p for (n, _), p in zip(m.named_parameters(), params)}, (inputs, st),
+                                             {"pad": pad})
     out = res["output"]
     nxt = flatten_state(res["next_state"])
     assert list(nxt.keys()) == names
@@ -132,7 +141,8 @@ def separate(mixture: Tensor, dis_embed: Optional[Tensor], params: List[Tensor],
             _PENDING.pop(next(iter(_PENDING)))
     # outputs may not alias inputs: buffers the forward passed through untouched are copied
     ins = {t.data_ptr() for t in state}
-    return [out.detach()] + [(v.detach().clone() if v.data_ptr() in ins else v.detach()) for v in nxt.values()] + [handle]
+    # (the cropped output of a padded call is a view: operators return dense tensors)
+    return [out.detach().contiguous()] + [(v.detach().clone() if v.data_ptr() in ins else v.detach()) for v in nxt.values()] + [handle]
 
 
 @separate.register_fake
@@ -157,6 +167,7 @@ def separate_backward(handle: Tensor, d_output: Tensor, model: int) -> List[Tens
         got = torch.autograd.grad(root, need, d_output.contiguous(), allow_unused=True)
     it = iter(got)
     outs = []
+    seen = {d_output.untyped_storage().data_ptr()}
     for p in own:
         g = next(it) if p.requires_grad else None
         if _grad_in_place(p):
@@ -166,7 +177,17 @@ def separate_backward(handle: Tensor, d_output: Tensor, model: int) -> List[Tens
                 p.grad.add_(g)
             outs.append(p.new_empty(0))
         else:
-            outs.append(torch.zeros_like(p) if g is None else g.contiguous())
+            if g is None:
+                g = torch.zeros_like(p)
+            else:
+                # operator outputs may not share storage (the FiLM planes' gradients are slices of one bank, d_output may come
+                # back as somebody's gradient unchanged)
+                g = g.contiguous()
+                key = g.untyped_storage().data_ptr()
+                if key in seen or g._base is not None:
+                    g = g.clone()
+                seen.add(g.untyped_storage().data_ptr())
+            outs.append(g)
     return outs
 
 
@@ -185,18 +206,18 @@ def _separate_setup(ctx, inputs, output):
     ctx.model = inputs[4]
     ctx.handle = output[-1]
     ctx.n_state = len(inputs[3])
+    ctx.n_params = len(inputs[2])
     ctx.set_materialize_grads(False)
 
 
 def _separate_bwd(ctx, grads):
     d_out = grads[0]
     if d_out is None:
-        return None, None, None, None, None, None, None
+        return None, None, [None] * ctx.n_params, [None] * ctx.n_state, None, None, None
     gs = torch.ops.sound_bubble.separate_backward(ctx.handle, d_out, ctx.model)
     # the state entries are carried values (net.py:88-93: detached between chunks in the reference's streaming use): no
     # gradient flows into them, and none into the waveform
-    return (None, None, [g if g.numel() else None for g in gs], [None] * ctx.n_state if ctx.n_state else None, None, None,
-            None)
+    return None, None, [g if g.numel() else None for g in gs], [None] * ctx.n_state, None, None, None
 
 
 separate.register_autograd(_separate_bwd, setup_context=_separate_setup)

@@ -37,6 +37,16 @@ def test_operator_forward_and_streaming_equal_the_module(name, cls):
     for k in fa:
         assert np.array_equal(fa[k], fb[k]), k
         assert rel_l2(fb[k], rec["next_state::" + k]) < 2e-5, k
+    # the result is a function of params[]: clones give the same output, changed clones a different one, the module untouched
+    ps = [p.detach().clone() for p in m.parameters()]
+    mid = T.register_model(m)
+    with torch.no_grad():
+        o = torch.ops.sound_bubble.separate(inp["mixture"], inp.get("dis_embed"), ps, [], mid, True, False)
+        assert torch.equal(o[0], a["output"])
+        ps[-1].mul_(1.5)                       # the output deconvolution's bias
+        o = torch.ops.sound_bubble.separate(inp["mixture"], inp.get("dis_embed"), ps, [], mid, True, False)
+        assert not torch.equal(o[0], a["output"])
+        assert torch.equal(m(inp)["output"], a["output"])
     # three chunks with the state carried through the operator (edge/causal_infer.py:15-26)
     hop, look = m.stft_chunk_size, m.stft_pad_size
     mix = inp["mixture"]
@@ -73,8 +83,8 @@ def test_operator_gradients_equal_the_module_and_the_goldens(name, cls, bucket):
     w = T.separate_module(m)
     est = w(inp)["output"]
     l2, lv, _ = torch.ops.sound_bubble.snrlp_loss(est, tgt, 100.0)
-    assert float(l2) == float(loss)
-    np.testing.assert_allclose(lv.cpu().numpy(), rec["loss_vec"], rtol=1e-4, atol=1e-4)
+    assert float(l2.detach()) == float(loss.detach())
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), rec["loss_vec"], rtol=1e-4, atol=1e-4)
     l2.backward()
     ops.check_sched_status()
     assert not T._PENDING
