@@ -202,7 +202,10 @@ int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
  * (k / kseg) * is_seg + k % kseg]  (kseg | 16; overlapping rows are allowed,
  * which is how the STFT frames and the 3x3 convolutions are expressed).
  * out row at b*os_b + t*os_t + f*os_f, features contiguous.  N, K multiples
- * of 16 (N <= 128 per call).  n_valid <= N features are stored.
+ * of 16; N <= 128 per call, or any multiple of 16 with the plain / residual
+ * epilogues (served as column slices, one workgroup row per slice -- also what a
+ * call with <= 256 positions gets, so that the streaming chunk step's one-frame
+ * GEMMs read their weights through many CUs).  n_valid <= N features are stored.
  * Replaces nn.Linear / Conv1d(k=s) / ConvTranspose1d(k=s) / Conv2d(3x3) /
  * asteroid Encoder+Decoder GEMMs: tfgridnet_causal.py:475,507,520,537,803-824,845. */
 /* A logical [N, K] weight matrix laid over a parameter tensor in its NATIVE (torch) layout, so that no transposed /
@@ -467,6 +470,20 @@ int sb_add3(const float* x, const float* part, float* y, int64_t P, int C, void*
  * samples (tfgridnet_causal.py:533-542).  bwd: dframes from dwave. */
 int sb_overlap_add(const float* frames, float* wave, int B, int T, int win, int hop, void* stream);
 int sb_overlap_add_bwd(const float* dwave, float* dframes, int B, int T, int win, int hop, void* stream);
+
+/* ---- several small dense copies in one launch ------------------------------
+ * dst[i][0 .. n[i]) = src[i][0 .. n[i]) (floats) for i < njobs <= 16.  The streaming chunk step (edge/causal_infer.py:15-26:
+ * `self.internal_state = next_state`) writes the carried state back into the static buffers its hipGraph reads: one graph
+ * node instead of one copy node per state tensor.  The pointers travel as kernel arguments (no device-side table), so the
+ * call can be stream-captured. */
+#define SB_MULTI_COPY_MAX 16
+typedef struct {
+  const float* src[SB_MULTI_COPY_MAX];
+  float* dst[SB_MULTI_COPY_MAX];
+  int64_t n[SB_MULTI_COPY_MAX];
+  int njobs;
+} sb_multi_copy_args;
+int sb_multi_copy(const sb_multi_copy_args* a, void* stream);
 
 /* ---- output transposed-conv, data gradient --------------------------------
  * dy [B, T, F, C] (gradient w.r.t. the last block's output) from dspec

@@ -125,7 +125,16 @@ EPI_NONE, EPI_RES, EPI_PRELU, EPI_LN, EPI_LNBWD = range(5)
 
 # every symbol include/sound_bubble_hip.h declares: name -> (restype, argtypes)
 _vp, _ci, _cf = C.c_void_p, C.c_int, C.c_float
+MULTI_COPY_MAX = 16
+
+
+class MultiCopyArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p * MULTI_COPY_MAX), ("dst", C.c_void_p * MULTI_COPY_MAX), ("n", C.c_int64 * MULTI_COPY_MAX),
+                ("njobs", C.c_int)]
+
+
 SYMBOLS = {
+    "sb_multi_copy": (_ci, [C.POINTER(MultiCopyArgs), _vp]),
     "sb_lstm_fwd": (_ci, [C.POINTER(LstmFwdArgs), _vp]),
     "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
     "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),

@@ -351,6 +351,19 @@ __global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ x, 
 
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
+// several small dense copies in one launch (workgroup row y = job y): the streaming chunk step's state write-back
+__global__ __launch_bounds__(256) void multi_copy_kernel(sb_multi_copy_args a) {
+  const int jb = blockIdx.y;
+  const float* __restrict__ s = a.src[jb];
+  float* __restrict__ d = a.dst[jb];
+  const int64_t n = a.n[jb];
+  const bool al = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+  const int64_t n4 = al ? n / 4 : 0;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = i0; i < n4; i += stride) st4(d + 4 * i, ld4(s + 4 * i));
+  for (int64_t i = 4 * n4 + i0; i < n; i += stride) d[i] = s[i];
+}
+
 }  // namespace
 
 extern "C" int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int T, int F, void* stream) {
@@ -460,6 +473,21 @@ extern "C" int sb_adam_step(float* p, const float* g, float* m, float* v, int64_
                             void* stream) {
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, gscale, clip, sumsq);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_multi_copy(const sb_multi_copy_args* ap, void* stream) {
+  if (!ap || ap->njobs <= 0 || ap->njobs > SB_MULTI_COPY_MAX) return -1001;
+  int64_t nmax = 0;
+  for (int i = 0; i < ap->njobs; ++i) {
+    if (!ap->src[i] || !ap->dst[i] || ap->n[i] < 0) return -1002;
+    if (ap->n[i] > nmax) nmax = ap->n[i];
+  }
+  if (nmax == 0) return 0;
+  int64_t gx = (nmax / 4 + 255) / 256;
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)gx, ap->njobs), dim3(256), 0, (hipStream_t)stream, *ap);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int LIN_MAX_WG = 1024;   // persistent grid cap (4 WG/CU on 256 CUs)
+constexpr int SB_LINEAR_SLICE_MAX_P = 256;   // at most this many positions: column-sliced launch (see sb_linear_fwd)
 constexpr int WG_MAX_WG = 512;
 
 // Position p = (b*T + t)*F + f  ->  element offset b*sb + t*st + f*sf.  Two 64-bit integer divisions per position and
@@ -52,6 +53,16 @@ __global__ __launch_bounds__(256) void linear_kernel(sb_linear_args a, int64_t P
   extern __shared__ __attribute__((aligned(16))) float Wl[];   // [N][K+4]
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int N = NT * 16, K = a.K, KP = K + 4;
+  if (gridDim.y > 1) {
+    // column slices (sb_linear_fwd: few positions or N > 128): workgroup row y owns output columns [y N, (y + 1) N) -- its
+    // own rows of W in LDS -- so that a call with a handful of positions spreads the weight read over many CUs
+    const int y = blockIdx.y;
+    a.w += (size_t)y * N * K;
+    if (a.bias) a.bias += y * N;
+    a.out += y * N;
+    if (a.res) a.res += y * N;
+    a.n_valid = min(max(a.n_valid - y * N, 0), N);
+  }
   // stage weights
   for (int idx = tid * 4; idx < N * K; idx += 256 * 4) {
     const int n = idx / K, k = idx - n * K;
@@ -873,21 +884,22 @@ __global__ __launch_bounds__(256) void wview_gather_kernel(const sb_wview_job* _
 }
 
 template <int NT, int EPI>
-int launch_linear2(const sb_linear_args& a, int64_t P, hipStream_t st) {
+int launch_linear2(const sb_linear_args& a, int64_t P, hipStream_t st, int ny) {
   const size_t lds = (size_t)NT * 16 * (a.K + 4) * sizeof(float);
   if (lds > 160 * 1024) return -1005;
   (void)hipFuncSetAttribute((const void*)linear_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((linear_kernel<NT, EPI>), dim3(sb_linear_grid(P)), dim3(256), lds, st, a, P);
+  hipLaunchKernelGGL((linear_kernel<NT, EPI>), dim3(sb_linear_grid(P), ny), dim3(256), lds, st, a, P);
   return 0;
 }
 template <int NT>
-int launch_linear(const sb_linear_args& a, int64_t P, hipStream_t st) {
+int launch_linear(const sb_linear_args& a, int64_t P, hipStream_t st, int ny) {
+  if (ny > 1 && a.epi != SB_EPI_NONE && a.epi != SB_EPI_RES) return -1006;      // column slices: plain / residual epilogues
   switch (a.epi) {
-    case SB_EPI_NONE: return launch_linear2<NT, SB_EPI_NONE>(a, P, st);
-    case SB_EPI_RES: return launch_linear2<NT, SB_EPI_RES>(a, P, st);
-    case SB_EPI_PRELU: return launch_linear2<NT, SB_EPI_PRELU>(a, P, st);
-    case SB_EPI_LN: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LN>(a, P, st); else return -1006;
-    case SB_EPI_LNBWD: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LNBWD>(a, P, st); else return -1006;
+    case SB_EPI_NONE: return launch_linear2<NT, SB_EPI_NONE>(a, P, st, ny);
+    case SB_EPI_RES: return launch_linear2<NT, SB_EPI_RES>(a, P, st, ny);
+    case SB_EPI_PRELU: return launch_linear2<NT, SB_EPI_PRELU>(a, P, st, 1);
+    case SB_EPI_LN: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LN>(a, P, st, 1); else return -1006;
+    case SB_EPI_LNBWD: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LNBWD>(a, P, st, 1); else return -1006;
     default: return -1007;
   }
 }
@@ -936,14 +948,29 @@ extern "C" int sb_linear_fwd(const sb_linear_args* ap, void* stream) {
     SB_CHECK_LAUNCH();
     return 0;
   }
+  // Column slices (grid.y): with a handful of positions (the streaming chunk step: one frame) a single workgroup would
+  // stage the whole [N, K] weight block through its LDS -- 17 us for the 304 x 288 STFT basis; N / width workgroups, each
+  // with `width` rows of W, read it in parallel.  Also how N > 128 is served in one launch.
+  int ny = 1;
+  if ((a.epi == SB_EPI_NONE || a.epi == SB_EPI_RES) && (a.N > 128 || (P <= SB_LINEAR_SLICE_MAX_P && a.N >= 64))) {
+    static const int cand[] = {128, 96, 80, 64, 48, 32, 16};
+    int width = 16;
+    for (int c : cand)
+      if (a.N % c == 0 && a.N / c >= (P <= SB_LINEAR_SLICE_MAX_P ? 8 : 1) && (size_t)c * (a.K + 4) * sizeof(float) <= 160 * 1024) {
+        width = c;
+        break;
+      }
+    ny = a.N / width;
+    a.N = width;
+  }
   switch (a.N / 16) {
-    case 1: rc = launch_linear<1>(a, P, st); break;
-    case 2: rc = launch_linear<2>(a, P, st); break;
-    case 3: rc = launch_linear<3>(a, P, st); break;
-    case 4: rc = launch_linear<4>(a, P, st); break;
-    case 5: rc = launch_linear<5>(a, P, st); break;
-    case 6: rc = launch_linear<6>(a, P, st); break;
-    case 8: rc = launch_linear<8>(a, P, st); break;
+    case 1: rc = launch_linear<1>(a, P, st, ny); break;
+    case 2: rc = launch_linear<2>(a, P, st, ny); break;
+    case 3: rc = launch_linear<3>(a, P, st, ny); break;
+    case 4: rc = launch_linear<4>(a, P, st, ny); break;
+    case 5: rc = launch_linear<5>(a, P, st, ny); break;
+    case 6: rc = launch_linear<6>(a, P, st, ny); break;
+    case 8: rc = launch_linear<8>(a, P, st, ny); break;
     default: return -1004;
   }
   if (rc) return rc;

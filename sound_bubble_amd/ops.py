@@ -999,9 +999,13 @@ def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None,
     # the kernel stages its [nc, K] weight slice in LDS (160 KB): long-K layers (the loss STFTs) get narrower slices
     cap = max(16, min(128, (160 * 1024 // (4 * (K + 4))) // 16 * 16))
     cap = max(c for c in (16, 32, 48, 64, 80, 96, 128) if c <= cap)
+    # a handful of positions (the streaming chunk step): ONE launch, column-sliced over grid.y inside the library -- the
+    # 304 x 288 STFT basis is then read by 19 workgroups instead of three launches of one workgroup each
+    one_launch = (B_ * T_ * F_ <= 256 and epi in (L.EPI_NONE, L.EPI_RES) and not want_partials and N >= 64 and N % 16 == 0
+                  and not (f16x3 and LINEAR_F16X3))
     while n0 < N:
-        nc = min(cap, N - n0)
-        if nc not in (16, 32, 48, 64, 80, 96, 128):       # NT in {1,2,3,4,5,6,8}
+        nc = N if one_launch else min(cap, N - n0)
+        if not one_launch and nc not in (16, 32, 48, 64, 80, 96, 128):       # NT in {1,2,3,4,5,6,8}
             nc = 96 if nc > 96 else 64
         a = L.LinearArgs()
         a.B, a.T, a.F, a.N, a.K = B_, T_, F_, nc, K
@@ -1123,6 +1127,22 @@ def overlap_add(frames, B, T, win, hop):
     wave = torch.empty(B, hop * T, device=frames.device, dtype=torch.float32)
     L.check(L.load().sb_overlap_add(_p(frames), _p(wave), B, T, win, hop, _stream()), "sb_overlap_add")
     return wave
+
+
+def multi_copy(pairs):
+    """dst.copy_(src) for every (src, dst) of `pairs` (dense fp32 CUDA tensors of equal numel) in ceil(len / 16) launches
+    (sb_multi_copy): the streaming chunk step's state write-back as one graph node"""
+    lib = L.load()
+    for i in range(0, len(pairs), L.MULTI_COPY_MAX):
+        a = L.MultiCopyArgs()
+        chunk = pairs[i:i + L.MULTI_COPY_MAX]
+        for j, (src, dst) in enumerate(chunk):
+            if not (src.is_cuda and dst.is_cuda and src.dtype == dst.dtype == torch.float32 and src.is_contiguous()
+                    and dst.is_contiguous() and src.numel() == dst.numel()):
+                raise L.SoundBubbleHipError("multi_copy: dense float32 GPU tensors of equal size expected")
+            a.src[j], a.dst[j], a.n[j] = src.data_ptr(), dst.data_ptr(), src.numel()
+        a.njobs = len(chunk)
+        L.check(lib.sb_multi_copy(C.byref(a), _stream()), "sb_multi_copy")
 
 
 def overlap_add_bwd(dwave, B, T, win, hop):

@@ -84,9 +84,17 @@ class StreamingSeparator(torch.nn.Module):
         static = flatten_state(self.state)
         st = _clone_tree(self.state)                               # shallow: same tensors, fresh dicts
         out = self.model(self._inputs(), st, pad=False)["output"]
+        # `self.internal_state = next_state` (edge/causal_infer.py:24) into the static buffers: one launch for all of them
+        pairs, odd = [], []
         for k, v in flatten_state(st).items():
             if v.data_ptr() != static[k].data_ptr():
-                static[k].copy_(v)
+                ok = v.is_contiguous() and v.dtype == torch.float32 and v.numel() == static[k].numel()
+                (pairs if ok else odd).append((v, static[k]))
+        if pairs:
+            from . import ops
+            ops.multi_copy(pairs)
+        for v, dst in odd:
+            dst.copy_(v)
         return out
 
     def _capture(self):

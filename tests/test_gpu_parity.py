@@ -1248,3 +1248,43 @@ def test_wide_overlapped_inter_backward_matches_the_fused_wide_launch(torch_gpu,
     for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh", "dW_lin", "db_lin", "d_ln_g", "d_ln_b"),
                             tg2 + list(lin2) + list(ln2), tg1 + list(lin1) + list(ln1)):
         assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6, name
+
+
+@pytest.mark.parametrize("P,N,K,res", [(6, 304, 288, False), (2, 288, 304, False), (29, 80, 128, True), (200, 64, 32, True),
+                                       (300, 304, 288, False)])
+def test_linear_column_slices_match_torch(torch_gpu, P, N, K, res):
+    """few positions (<= 256: the streaming chunk step) or N > 128: one launch, the output columns sliced over grid.y
+    (sb_linear_fwd); more positions: the <= 128-wide launches as before -- same numbers either way"""
+    torch = torch_gpu
+    from sound_bubble_amd import ops, _lib as L
+    torch.manual_seed(P + N)
+    x, w, b, r = torch.randn(P, K), torch.randn(N, K) * 0.1, torch.randn(N), torch.randn(P, N)
+    nv = N - 14                                            # the STFT basis: 290 valid of 304 columns
+    out = torch.full((P, N), 7.0).cuda()
+    g, si = ops.dense(P, K)
+    _, so = ops.dense(P, N)
+    am = torch.zeros(1).cuda()
+    ops.linear(x.cuda(), w.cuda(), b.cuda(), out, g, si, so, K, N, n_valid=nv, epi=L.EPI_RES if res else L.EPI_NONE,
+               res=r.cuda() if res else None, absmax_out=am)
+    ref = x.double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    assert rel_l2(out.cpu()[:, :nv].numpy(), ref[:, :nv].numpy()) < 2e-6
+    assert (out.cpu()[:, nv:] == 7.0).all()                # columns beyond n_valid are not written
+    assert abs(float(am) - float(ref[:, :nv].abs().max())) < 1e-4 * float(ref.abs().max())
+    # accumulate form
+    ops.linear(x.cuda(), w.cuda(), b.cuda(), out, g, si, so, K, N, n_valid=nv, accumulate=True)
+    assert rel_l2(out.cpu()[:, :nv].numpy(), (ref + (x.double() @ w.double().t() + b.double()))[:, :nv].numpy()) < 2e-6
+
+
+def test_multi_copy(torch_gpu):
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    torch.manual_seed(0)
+    sizes = [1, 3, 4, 64 * 29, 145 * 64, 27 * 2 * 145, 5, 1 << 18] + [17] * 12      # 20 jobs: two launches
+    src = [torch.randn(n).cuda() for n in sizes]
+    dst = [torch.zeros(n + 3).cuda()[3:] if i % 2 else torch.zeros(n).cuda() for i, n in enumerate(sizes)]   # odd: unaligned
+    dst = [d if d.is_contiguous() else d.contiguous() for d in dst]
+    ops.multi_copy(list(zip(src, dst)))
+    for s_, d_ in zip(src, dst):
+        assert torch.equal(s_, d_)
+    with pytest.raises(Exception):
+        ops.multi_copy([(src[0], dst[1])])
