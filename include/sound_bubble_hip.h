@@ -101,6 +101,11 @@ typedef struct {
      kernels' lane order like them: 1280 B per step and direction, one contiguous KB per store instruction), save_u and
      hs stay fp32.  To be handed to sb_lstm_bwd_rec with `wide` set. */
   int rec_f32;
+  /* Calls that ask for hs (+ hN / cN) alone -- no records, no fused Linear / summed input / FiLM -- with at most 256
+     (sequence, direction) chains are served by a one-workgroup-per-chain kernel on the vector ALU (exact fp32 matrix-vector
+     products, weights in registers, one barrier per step; sb_lstm_vec.hip): the streaming chunk step's intra-frame pass is ONE
+     sequence per direction, for which a 16-sequence MFMA tile pays a 4x longer step.  no_vec != 0 keeps the tile kernels. */
+  int no_vec;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 

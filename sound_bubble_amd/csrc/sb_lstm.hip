@@ -21,6 +21,8 @@
 
 // bf16 split-product variants (sb_lstm_bf.hip)
 int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st);
+bool sb_lstm_fwd_vec_ok(const sb_lstm_fwd_args& a);                         // sb_lstm_vec.hip: a handful of sequences, inference
+int sb_launch_lstm_fwd_vec(const sb_lstm_fwd_args& a, hipStream_t st);
 int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a, hipStream_t st);
 
 namespace {
@@ -349,6 +351,12 @@ extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
   if (a->save_gates && !a->save_u) return -1003;
   dim3 grid((a->nseq + 15) / 16, a->ndir);
   if (a->lin_w && a->mma != 1) return -1003;                         // fused Linear: fp16 path only
+  if (sb_lstm_fwd_vec_ok(*a)) {                                      // <= 256 (sequence, direction) chains, hs only: one
+    const int rc = sb_launch_lstm_fwd_vec(*a, (hipStream_t)stream);  // workgroup per chain, fp32 matrix-vector products
+    if (rc) return rc;
+    SB_CHECK_LAUNCH();
+    return 0;
+  }
   if (a->mma == 1 || a->mma == 2) { const int rc = sb_launch_lstm_fwd_bf(*a, (hipStream_t)stream); if (rc) return rc; }
   else if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);
   else launch_fwd<16>(*a, grid, (hipStream_t)stream);

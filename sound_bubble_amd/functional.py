@@ -50,6 +50,31 @@ class _GradTargets:
 
     def __getitem__(self, name):
         return self.ret[name]
+# Inference workspaces (set by the Net wrapper per forward, None in training): the zero-bordered staging tensors of the
+# front end / back end (zp, yp, the spectrum rows) are kept per model and shape, zeroed ONCE -- their borders and padding
+# columns are never written afterwards, the interiors are rewritten by every call -- so a forward launches no fill kernels
+# for them (4 of the streaming chunk step's graph nodes).  Training allocates fresh tensors (they are saved for backward).
+# One forward per model at a time: two streams running the SAME module concurrently would share these.
+WORKSPACE = None
+INFER_WORKSPACE = __import__("os").environ.get("SB_NO_INFER_WORKSPACE", "0") != "1"
+
+
+def _ws_zeros(tag, shape, device):
+    ws = WORKSPACE
+    n = 1
+    for d in shape:
+        n *= d
+    if ws is None or GRAD_MODE or n > (1 << 22):      # small shapes only (chunk / short-clip inference): there a fill launch
+        return None                                   # costs as much as the kernel it feeds; big batches keep fresh tensors
+    key = (tag, tuple(shape), str(device))
+    t = ws.get(key)
+    if t is None:
+        if len(ws) > 12:
+            ws.clear()
+        t = ws[key] = torch.zeros(*shape, device=device, dtype=torch.float32)
+    return t
+
+
 ZC = 32          # padded channel count of the front-end feature tensor
 NSPEC = 304      # 290 STFT bins (re/im) padded to a multiple of 16
 
@@ -80,7 +105,7 @@ class IntraPlainFn(torch.autograd.Function):
         B, T, F, Cc = x.shape
         P = B * T * F
         (wif, whf, bif, bhf), (wir, whr, bir, bhr) = dirs
-        if ops.intra_lin_fusion_ok(train, Cc):
+        if ops.intra_lin_fusion_ok(train, Cc, B * T):
             # the Linear inside the recurrence: two per-direction partial products + one elementwise pass; hs is then
             # only a (fp16) side output for the backward kernels, and none at all in inference
             part = torch.empty(P, 2, Cc, device=x.device, dtype=torch.float32)
@@ -669,8 +694,10 @@ class FrontEndFn(torch.autograd.Function):
         ops.linear(mix, _stft_weight(enc_filters), None, spec, (B * M, T, 1), (Np, hop, 0), (T * NSPEC, NSPEC, 0),
                    win, NSPEC)
         # 2. features into the zero-bordered, channel-padded tensor zp [B, T+2, F+2, 32]
-        zp = torch.empty(B, T + 2, F + 2, ZC, device=dev, dtype=torch.float32)
-        zp[:, :2].zero_()
+        zp = _ws_zeros("zp", (B, T + 2, F + 2, ZC), dev)
+        if zp is None:
+            zp = torch.empty(B, T + 2, F + 2, ZC, device=dev, dtype=torch.float32)
+            zp[:, :2].zero_()
         zp[:, :2, 1:F + 1, :nfeat] = conv_buf.permute(0, 2, 3, 1)
         ops.features(spec, NSPEC, zp, B, M, T, F)
         new_buf = zp[:, T:T + 2, 1:F + 1, :nfeat].permute(0, 3, 1, 2).contiguous()
@@ -735,14 +762,18 @@ class BackEndFn(torch.autograd.Function):
         win = dec_filters.shape[-1]
         train = GRAD_MODE and any(ctx.needs_input_grad)
         assert dw.shape[1] == 2, "num_src=1 only (every shipped config)"
-        yp = torch.empty(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)      # only the frequency borders are zero
-        yp[:, :, 0].zero_()
-        yp[:, :, F + 1].zero_()
+        yp = _ws_zeros("yp", (B, T + 2, F + 2, Cc), dev)
+        if yp is None:
+            yp = torch.empty(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)      # only the frequency borders are zero
+            yp[:, :, 0].zero_()
+            yp[:, :, F + 1].zero_()
         yp[:, :2, 1:F + 1] = deconv_buf.permute(0, 2, 3, 1)
         yp[:, 2:, 1:F + 1] = y
         new_dbuf = yp[:, T:T + 2, 1:F + 1].permute(0, 3, 1, 2).contiguous()
         # spectrum rows [B, T+1, 304], interleaved (re,im) per frequency; row 0 = carried frame
-        rows = torch.zeros(B, T + 1, NSPEC, device=dev, dtype=torch.float32)
+        rows = _ws_zeros("rows", (B, T + 1, NSPEC), dev)        # columns 2F .. NSPEC-1 are padding: never written, stay zero
+        if rows is None:
+            rows = torch.zeros(B, T + 1, NSPEC, device=dev, dtype=torch.float32)
         ib = istft_buf.reshape(B, 2, F)                                           # [re | im]
         rows[:, 0, : 2 * F] = ib.permute(0, 2, 1).reshape(B, 2 * F)
         # wk [16][(a*3 + d)*C + c] = dw[c, o, 2-a, 2-d] (rows 2..15 zero), bk [16]: kernel-layout forms (forms.WeightForms)

@@ -244,6 +244,7 @@ class _NetBase(nn.Module):
         tg = self.tfgridnet
         st = input_state
         Fn.GRAD_MODE = torch.is_grad_enabled()      # BPTT records are written only when a backward pass can follow
+        Fn.WORKSPACE = None if (Fn.GRAD_MODE or not Fn.INFER_WORKSPACE) else self.__dict__.setdefault("_ws", {})      # inference: persistent zero-bordered staging
         e = self._embed(inputs.get("dis_embed"))
         wf = self._weight_forms().refresh()
         ln = tg.conv[1] if self.use_first_ln else None
@@ -270,7 +271,7 @@ class _NetBase(nn.Module):
             else:
                 # the sum x + part0 + part1 that finishes the intra-frame Linear is formed by the inter-frame kernel's loader
                 defer = (Fn.ops.INTER_SUM3 and y.shape[-1] == 32 and
-                         Fn.ops.intra_lin_fusion_ok(torch.is_grad_enabled(), y.shape[-1]))
+                         Fn.ops.intra_lin_fusion_ok(torch.is_grad_enabled(), y.shape[-1], y.shape[0] * y.shape[1]))
                 part = Fn.IntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
                                              *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
                                              blk.intra_linear.bias, defer, ovl)

@@ -410,6 +410,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     a.hs, a.save_u = _ph(hs), _ph(u if u is not None else PHASE_TIMING_BUF)
     a.aux_f16 = 1 if aux16 else 0
     a.rec_f32 = 1 if wide else 0
+    a.no_vec = 0 if VEC_LSTM else 1
     a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.mma = LSTM_MMA
     if lin is not None:       # ndir == 2: partial mode, y is [P, 2, C] (see the header)
@@ -801,10 +802,24 @@ def can_fuse_stream_bi(u, hs):
 INTRA_LIN_FUSION = os.environ.get("SB_NO_INTRA_LIN_FUSION", "0") != "1"
 
 
-def intra_lin_fusion_ok(train, Cc):
+# inference with at most this many (sequence, direction) chains in a recurrent pass: sb_lstm_fwd runs them one workgroup per
+# chain on the vector ALU (sb_lstm_vec.hip: ~4x shorter step than a 16-sequence tile holding one sequence) when the call
+# asks for hs alone -- so the intra-frame Linear is then left to its own kernel (SB_NO_VEC_LSTM=1: tile kernels always)
+VEC_LSTM = os.environ.get("SB_NO_VEC_LSTM", "0") != "1"
+VEC_LSTM_MAX_CHAINS = 256
+
+
+def vec_lstm_ok(train, nseq, ndir):
+    return VEC_LSTM and not train and nseq is not None and nseq * ndir <= VEC_LSTM_MAX_CHAINS
+
+
+def intra_lin_fusion_ok(train, Cc, nseq=None):
     """inference: any time the fp16x3 forward is on; training: only with the fused bidirectional backward (the one kernel
-    that takes hs as fp16 [P, 128])"""
+    that takes hs as fp16 [P, 128]).  nseq (sequences of the pass, when the caller knows them): a handful of sequences in
+    inference go to the vector-ALU kernel, which leaves the Linear to its own launch."""
     if not (INTRA_LIN_FUSION and can_fuse_linear_fwd() and Cc == 32):
+        return False
+    if vec_lstm_ok(train, nseq, 2):
         return False
     if train and _wide():
         return can_fuse_linear_bwd() and FUSED_BPTT and FUSED_BPTT_BI

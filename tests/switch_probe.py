@@ -63,7 +63,10 @@ def main():
         loss.backward()
         ops.check_sched_status()
         k, e = grads_vs(m, lambda k_: rec["grad::" + k_])
-        out["golden"][name] = {"fwd": rel_l2(est.detach().cpu().numpy(), rec["output"]), "grad": e, "worst": k}
+        with torch.no_grad():                            # the inference dispatch (few-sequence vector kernel, workspaces, ...)
+            ev = m(inp)["output"]
+        out["golden"][name] = {"fwd": rel_l2(est.detach().cpu().numpy(), rec["output"]), "grad": e, "worst": k,
+                               "fwd_eval": rel_l2(ev.cpu().numpy(), rec["output"])}
 
     saved = np.load(a.compare) if a.compare else None
     keep = {}

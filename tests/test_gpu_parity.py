@@ -1288,3 +1288,45 @@ def test_multi_copy(torch_gpu):
         assert torch.equal(s_, d_)
     with pytest.raises(Exception):
         ops.multi_copy([(src[0], dst[1])])
+
+
+@pytest.mark.parametrize("C,nseq,S,bi", [(16, 1, 29, True), (32, 1, 145, True), (32, 5, 70, True), (16, 37, 33, False),
+                                         (32, 145, 1, False), (32, 128, 3, True)])
+def test_few_sequence_vector_kernel_matches_float64_lstm(torch_gpu, C, nseq, S, bi):
+    """inference calls with <= 256 (sequence, direction) chains that ask for hs (+ final state) only: the one-workgroup-per-
+    chain vector-ALU kernel (sb_lstm_vec.hip; the streaming chunk step's intra-frame pass) against LayerNorm + nn.LSTM in
+    float64, and against the tile kernel (no_vec) on the same inputs"""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    torch.manual_seed(C + nseq + S)
+    lstm = torch.nn.LSTM(C, 64, 1, batch_first=True, bidirectional=bi).double()
+    g, b = torch.randn(C).double() * 0.5 + 1, torch.randn(C).double() * 0.1
+    x = torch.randn(nseq, S, C).double()
+    nd = 2 if bi else 1
+    h0 = c0 = None
+    if not bi:
+        h0, c0 = torch.randn(1, nseq, 64).double() * 0.3, torch.randn(1, nseq, 64).double() * 0.3
+    u = torch.nn.functional.layer_norm(x, (C,), g, b, 1e-5)
+    ref, (hn, cn) = lstm(u, (h0, c0)) if h0 is not None else lstm(u)
+    d = lambda t: t.detach().float().cuda().contiguous()
+    dirs = [(d(lstm.weight_ih_l0), d(lstm.weight_hh_l0), d(lstm.bias_ih_l0), d(lstm.bias_hh_l0))]
+    if bi:
+        dirs.append((d(lstm.weight_ih_l0_reverse), d(lstm.weight_hh_l0_reverse), d(lstm.bias_ih_l0_reverse),
+                     d(lstm.bias_hh_l0_reverse)))
+    geom = ops.Geom.intra(nseq, S)
+    assert ops.vec_lstm_ok(False, nseq, nd)
+    outs = {}
+    for vec in (True, False):
+        old, ops.VEC_LSTM = ops.VEC_LSTM, vec
+        try:
+            hs, st, _, _ = ops.lstm_fwd(d(x).view(-1, C), d(g), d(b), dirs, geom, h0=d(h0[0]) if h0 is not None else None,
+                                        c0=d(c0[0]) if c0 is not None else None, want_state=not bi)
+        finally:
+            ops.VEC_LSTM = old
+        outs[vec] = hs.cpu().view(nseq, S, nd * 64)
+        assert rel_l2(outs[vec].numpy(), ref.detach().numpy()) < (2e-6 if vec else 5e-6)
+        if not bi:
+            assert rel_l2(st[0].cpu().numpy(), hn[0].detach().numpy()) < 5e-6
+            assert rel_l2(st[1].cpu().numpy(), cn[0].detach().numpy()) < 5e-6
+    assert rel_l2(outs[True].numpy(), outs[False].numpy()) < 5e-6
+    assert not torch.equal(outs[True], outs[False])          # two different kernels did run

@@ -19,7 +19,7 @@ ALL = ["SB_BPTT", "SB_EXACT_BPTT", "SB_NO_ROLE_SPLIT", "SB_NO_HS_RECOMPUTE", "SB
        "SB_NO_FUSED_BPTT", "SB_FORCE_FUSED_BPTT", "SB_LINEAR_FP32", "SB_NO_FWD_OVERLAP", "SB_NO_BWD_OVERLAP",
        "SB_NO_FWD_OVERLAP_INFERENCE", "SB_NO_INTER_SUM3", "SB_NO_INTER_FILM", "SB_NO_STREAM_LIN_WGRAD",
        "SB_NO_INTRA_LIN_FUSION", "SB_GATE_RECOMPUTE", "SB_BWD_PAIR_SERIAL", "SB_FWD_OVERLAP_SLAB", "SB_BWD_OVERLAP_SLAB",
-       "SB_OVERLAP_MAX_FILL"]
+       "SB_OVERLAP_MAX_FILL", "SB_NO_VEC_LSTM", "SB_NO_INFER_WORKSPACE"]
 
 # (id, environment, gradient bar): 2e-4 = the wide (default) arithmetic's bar against the goldens, 2e-3 the compact one's
 WIDE, COMPACT = 2e-4, 2e-3
@@ -50,6 +50,8 @@ SWITCHES = [
     ("no-intra-lin-fusion", {"SB_NO_INTRA_LIN_FUSION": "1"}, WIDE),
     ("gate-recompute-compact", {"SB_BPTT": "compact", "SB_GATE_RECOMPUTE": "1"}, COMPACT),
     ("bwd-pair-serial", {"SB_BWD_PAIR_SERIAL": "1"}, WIDE),
+    ("no-vec-lstm", {"SB_NO_VEC_LSTM": "1"}, WIDE),
+    ("no-infer-workspace", {"SB_NO_INFER_WORKSPACE": "1"}, WIDE),
     ("overlap-slabs", {"SB_FWD_OVERLAP_SLAB": "8", "SB_BWD_OVERLAP_SLAB": "12", "SB_OVERLAP_MAX_FILL": "0.6"}, WIDE),
 ]
 
@@ -71,7 +73,7 @@ def baseline(tmp_path_factory):
     out = _run({}, "--save", path)
     assert out["bptt"] == "wide"
     for name, g in out["golden"].items():
-        assert g["fwd"] < 2e-5 and g["grad"] < WIDE, (name, g)
+        assert g["fwd"] < 2e-5 and g["fwd_eval"] < 2e-5 and g["grad"] < WIDE, (name, g)
     return path, out
 
 
@@ -105,7 +107,7 @@ def test_switch_keeps_parity(baseline, sid, env, bar):
     path, base = baseline
     out = _run(env, "--compare", path)
     for name, g in out["golden"].items():                 # against the reference goldens
-        assert g["fwd"] < 2e-5, (sid, name, g)
+        assert g["fwd"] < 2e-5 and g["fwd_eval"] < 2e-5, (sid, name, g)
         assert g["grad"] < bar, (sid, name, g)
     for wl, g in out["medium"].items():                   # against the switch-free run where the schedules engage
         assert g["fwd"] < 2e-5, (sid, wl, g)
