@@ -9,10 +9,11 @@
 // reference's own arithmetic (tfgridnet_causal.py:818-823 / optim :690-703: nn.LSTM after LayerNorm) -- and one barrier per
 // step.  With <= 256 workgroups every sequence has a CU to itself, so the launch takes nsteps x (one step's latency).
 //
-// Step s of a workgroup (256 threads; wave w owns gate type w of i, f, g, o; lane j = hidden unit j):
+// Step s of a workgroup (256 threads; wave w owns hidden units 16 w .. 16 w + 15, lane = 16 g + u: gate g of i, f, g, o for
+// unit j = 16 w + u, i.e. gate row r = 64 g + j):
 //   z_r   = zin[s][r] + sum_k W_hh[r][k] h[k]        zin = W_ih . LN(x_s) + b_ih + b_hh, precomputed 32 steps at a time
-//   act_r = sigmoid / tanh (z_r)  -> LDS (double-buffered); barrier
-//   every wave redundantly: c_j = f c_j + i g, h_j = o tanh(c_j) -> its own LDS copy of h (no second barrier)
+//   act_r = sigmoid / tanh (z_r); the four gates of a unit sit in ONE wave: lanes u gather f, g, o with three ds_bpermutes
+//   c_j = f c_j + i g, h_j = o tanh(c_j) -> LDS (double-buffered); ONE workgroup barrier; every thread reads all of h
 // No BPTT records (training keeps the tile kernels), no fused Linear / FiLM epilogues: sb_lstm_fwd picks this kernel only for
 // calls that ask for hs (+ final state) alone.
 #include "sb_common.h"
@@ -24,40 +25,48 @@ constexpr int H = 64;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CH = 32;         // steps whose input projections are staged in LDS at a time
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter, i.e. every step
+// would wait for global stores / prefetch loads in flight (a microsecond each)
+SB_DEVINL void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// lane l gets v of lane (l & ~3) + k, k encoded as CTRL = 0x55 k (DPP quad_perm [k, k, k, k])
+template <int CTRL>
+SB_DEVINL float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 template <int CC>
 __global__ __launch_bounds__(256) void lstm_fwd_vec_kernel(sb_lstm_fwd_args a) {
   __shared__ __attribute__((aligned(16))) float zin[CH][4 * H];      // 32 KB
   __shared__ __attribute__((aligned(16))) float u_l[CH][CC];         // LayerNorm output of the chunk's steps
-  __shared__ __attribute__((aligned(16))) float act[2][4 * H];       // double-buffered: one barrier per step
-  __shared__ __attribute__((aligned(16))) float h_l[4][H];           // one copy of h per wave
+  __shared__ __attribute__((aligned(16))) float h_l[2][H];           // double-buffered: one barrier per step
   __shared__ __attribute__((aligned(16))) float hs_l[CH][H];         // the chunk's hidden states: stored in bulk (no global
                                                                      // store -- and no wait for one -- inside the step)
 
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = 16 * w + (lane & 15);
   const int n = blockIdx.x, d = blockIdx.y;
   const int64_t pos0 = (int64_t)(n / a.n_inner) * a.p_outer + (int64_t)(n % a.n_inner) * a.p_inner;
-  const int r = tid;                                                 // gate row: type w, unit lane
+  const int r = g * H + j;                                           // gate row
+  const bool owner = g == 0;                                         // lanes 0..15 of a wave carry c_j / h_j of its 16 units
 
   // weights of this row: registers for the whole launch
-  f32x2 whh2[H / 2];
-  float wih[CC];
+  float wsc[H], wih[CC];
   {
     const float* p = a.w_hh[d] + (size_t)r * H;
 #pragma unroll
-    for (int k = 0; k < H; k += 4) { const f32x4 v = ld4(p + k); whh2[k / 2] = (f32x2){v[0], v[1]}; whh2[k / 2 + 1] = (f32x2){v[2], v[3]}; }
+    for (int k = 0; k < H; k += 4) { const f32x4 v = ld4(p + k); wsc[k] = v[0]; wsc[k + 1] = v[1]; wsc[k + 2] = v[2]; wsc[k + 3] = v[3]; }
     const float* q = a.w_ih[d] + (size_t)r * CC;
 #pragma unroll
     for (int k = 0; k < CC; k += 4) { const f32x4 v = ld4(q + k); wih[k] = v[0]; wih[k + 1] = v[1]; wih[k + 2] = v[2]; wih[k + 3] = v[3]; }
   }
   const float bias = a.b_ih[d][r] + a.b_hh[d][r];
+  // sigmoid(z) = 1 / (1 + 2^(-log2e z)); tanh(z) = 2 sigmoid(2 z) - 1 (gate g = 2, the cell candidate): one exp2 + one rcp per row
+  const float act_scale = g == 2 ? 2.0f * SB_NLOG2E : SB_NLOG2E, act_mul = g == 2 ? 2.0f : 1.0f, act_add = g == 2 ? -1.0f : 0.0f;
 
-  // state: lane j of EVERY wave carries c_j; h lives in LDS (one copy per wave)
-  float c = (d == 0 && a.c0) ? a.c0[(size_t)n * H + lane] : 0.f;
-  float hcur = (d == 0 && a.h0) ? a.h0[(size_t)n * H + lane] : 0.f;
-  h_l[w][lane] = hcur;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float c = (owner && d == 0 && a.c0) ? a.c0[(size_t)n * H + j] : 0.f;
+  float hcur = (owner && d == 0 && a.h0) ? a.h0[(size_t)n * H + j] : 0.f;
+  if (owner) h_l[0][j] = hcur;
 
   // LayerNorm helpers: 8 threads per step of the chunk, CC / 8 channels each
   constexpr int PER = CC / 8;
@@ -66,16 +75,28 @@ __global__ __launch_bounds__(256) void lstm_fwd_vec_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
   for (int i = 0; i < PER; ++i) { lg[i] = a.ln_g[lq * PER + i]; lb[i] = a.ln_b[lq * PER + i]; }
 
+  // x rows of a chunk are fetched one chunk ahead (in flight under the previous chunk's recurrence)
+  float xv[PER];
+  auto fetch = [&](int s0) {
+    const int s = s0 + ls;
+    if (s < a.nsteps) {
+      const int sp = d ? a.nsteps - 1 - s : s;
+      const float* xr = a.x + (pos0 + (int64_t)sp * a.p_step) * CC + lq * PER;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) xv[i] = xr[i];
+    }
+  };
+  fetch(0);
+
+  int hb = 0;                                                        // h buffer the next step reads
   for (int s0 = 0; s0 < a.nsteps; s0 += CH) {
     const int ns = min(CH, a.nsteps - s0);
-    __syncthreads();                                                 // the previous chunk's zin / u are no longer read
+    lds_barrier();                                                   // the previous chunk's zin / u / hs rows are no longer read
     // ---- u = LayerNorm_C(x) for the chunk's steps (two-pass variance, eps 1e-5: torch.nn.LayerNorm) ----
     if (ls < ns) {
-      const int s = s0 + ls, sp = d ? a.nsteps - 1 - s : s;
-      const float* xr = a.x + (pos0 + (int64_t)sp * a.p_step) * CC + lq * PER;
       float v[PER], sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < PER; ++i) { v[i] = xr[i]; sum += v[i]; }
+      for (int i = 0; i < PER; ++i) { v[i] = xv[i]; sum += v[i]; }
       sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
       const float mean = sum * (1.0f / CC);
       float sq = 0.f;
@@ -86,8 +107,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_vec_kernel(sb_lstm_fwd_args a) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) u_l[ls][lq * PER + i] = (v[i] - mean) * rstd * lg[i] + lb[i];
     }
-    __syncthreads();
-    // ---- zin[s][r] = b + W_ih[r] . u_s (off the serial chain) ----
+    fetch(s0 + CH);
+    lds_barrier();
+    // ---- zin[s][tid] = b + W_ih[r] . u_s (off the serial chain; written and read back by the same thread) ----
     for (int s = 0; s < ns; ++s) {
       float acc0 = bias, acc1 = 0.f;
 #pragma unroll
@@ -98,56 +120,56 @@ __global__ __launch_bounds__(256) void lstm_fwd_vec_kernel(sb_lstm_fwd_args a) {
         acc0 = __builtin_fmaf(wih[k + 2], u0[2], acc0); acc1 = __builtin_fmaf(wih[k + 6], u1[2], acc1);
         acc0 = __builtin_fmaf(wih[k + 3], u0[3], acc0); acc1 = __builtin_fmaf(wih[k + 7], u1[3], acc1);
       }
-      zin[s][r] = acc0 + acc1;
+      zin[s][tid] = acc0 + acc1;
     }
-    // (zin[s][r] is read back by thread r only; h_l[w] is wave-private: no barrier needed here)
 
     // ---- the recurrence over the chunk ----
     for (int s = 0; s < ns; ++s) {
-      // packed fp32 fused multiply-adds (v_pk_fma_f32: two per lane and instruction): the 64-term row product is the bulk of
-      // a step's vector-ALU time
-      f32x2 a0 = {zin[s][r], 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
-      const float* hp = h_l[w];
-#pragma unroll
-      for (int k = 0; k < H; k += 16) {
-        const f32x4 h0 = ld4(hp + k), h1 = ld4(hp + k + 4), h2 = ld4(hp + k + 8), h3 = ld4(hp + k + 12);
-        a0 = __builtin_elementwise_fma(whh2[k / 2], (f32x2){h0[0], h0[1]}, a0);
-        a1 = __builtin_elementwise_fma(whh2[k / 2 + 1], (f32x2){h0[2], h0[3]}, a1);
-        a2 = __builtin_elementwise_fma(whh2[k / 2 + 2], (f32x2){h1[0], h1[1]}, a2);
-        a3 = __builtin_elementwise_fma(whh2[k / 2 + 3], (f32x2){h1[2], h1[3]}, a3);
-        a0 = __builtin_elementwise_fma(whh2[k / 2 + 4], (f32x2){h2[0], h2[1]}, a0);
-        a1 = __builtin_elementwise_fma(whh2[k / 2 + 5], (f32x2){h2[2], h2[3]}, a1);
-        a2 = __builtin_elementwise_fma(whh2[k / 2 + 6], (f32x2){h3[0], h3[1]}, a2);
-        a3 = __builtin_elementwise_fma(whh2[k / 2 + 7], (f32x2){h3[2], h3[3]}, a3);
+      // h reaches the lanes through registers, not through 64-lane LDS broadcasts (a broadcast ds_read_b128 still returns
+      // 1 KB per wave: 64 KB per step and workgroup through the 128 B/clk LDS port -- 512 clocks, more than everything else in
+      // the step): lane L fetches the 16 floats h[16 i + 4 (L & 3) + c] (four ds_read_b128: 4 KB per wave) and every product
+      // takes its h operand from the quad neighbour that holds it (DPP quad_perm broadcast folded into the multiply-add)
+      const float* hp = h_l[hb] + 4 * (lane & 3);
+      const f32x4 hq0 = ld4(hp), hq1 = ld4(hp + 16), hq2 = ld4(hp + 32), hq3 = ld4(hp + 48);
+      float a0 = zin[s][tid], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      // v_fmac_f32_dpp: acc += (h of quad lane k) * w -- one instruction per product (hipcc leaves update_dpp + fma as two)
+#define SB_FMAC_Q(ACC, HV, WV, Q)                                                                                  \
+      asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf"      \
+                   : "+v"(ACC) : "v"(HV), "v"(WV))
+#define SB_ROW16(HQ, I)                                                                   \
+      _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) {                                    \
+        const float hv = HQ[cc];                                                           \
+        SB_FMAC_Q(a0, hv, wsc[16 * I + cc], 0);                                            \
+        SB_FMAC_Q(a1, hv, wsc[16 * I + 4 + cc], 1);                                        \
+        SB_FMAC_Q(a2, hv, wsc[16 * I + 8 + cc], 2);                                        \
+        SB_FMAC_Q(a3, hv, wsc[16 * I + 12 + cc], 3);                                       \
       }
-      const f32x2 zz = (a0 + a1) + (a2 + a3);
-      const float z = zz[0] + zz[1];
-      float* ab = act[s & 1];
-      ab[r] = (w == 2) ? tanhf_fast(z) : sigmoidf_fast(z);
-      // one barrier per step: a wave can be at most one step ahead of the slowest one (it waits here), and then it writes
-      // the OTHER act buffer
-      __syncthreads();
-      const float gi = ab[lane], gf = ab[H + lane], gg = ab[2 * H + lane], go = ab[3 * H + lane];
-      c = __builtin_fmaf(gf, c, gi * gg);
+      SB_ROW16(hq0, 0) SB_ROW16(hq1, 1) SB_ROW16(hq2, 2) SB_ROW16(hq3, 3)
+#undef SB_ROW16
+#undef SB_FMAC_Q
+      const float z = (a0 + a1) + (a2 + a3);
+      const float av = __builtin_fmaf(act_mul, sigmoid_pre(act_scale * z), act_add);
+      // the unit's other three gates: lanes u + 16, u + 32, u + 48 of this wave (no workgroup barrier for this exchange)
+      const float gf = __shfl(av, (lane & 15) + 16, 64), gg = __shfl(av, (lane & 15) + 32, 64), go = __shfl(av, (lane & 15) + 48, 64);
+      c = __builtin_fmaf(gf, c, av * gg);                            // (meaningful in the owner lanes, where av = i)
       hcur = go * tanhf_fast(c);
-      h_l[w][lane] = hcur;                                           // this wave's copy: read back by this wave only
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (LDS operations of one wave execute in order)
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (w == 0) hs_l[s][lane] = hcur;
+      hb ^= 1;
+      if (owner) { h_l[hb][j] = hcur; hs_l[s][j] = hcur; }
+      // one barrier per step; h is double-buffered: a wave can run at most one step ahead of the slowest one, and the buffer
+      // it then writes is not the one still being read
+      lds_barrier();
     }
     // ---- the chunk's hs rows -> global, 16 threads x 16 bytes per row ----
     if (a.hs) {
-      __syncthreads();
       for (int s = tid >> 4; s < ns; s += 16) {
         const int sg = s0 + s, sp = d ? a.nsteps - 1 - sg : sg;
         st4(a.hs + (pos0 + (int64_t)sp * a.p_step) * (a.ndir * H) + d * H + 4 * (tid & 15), ld4(&hs_l[s][4 * (tid & 15)]));
       }
     }
   }
-  if (d == 0 && w == 0) {
-    if (a.hN) a.hN[(size_t)n * H + lane] = hcur;
-    if (a.cN) a.cN[(size_t)n * H + lane] = c;
+  if (d == 0 && owner) {
+    if (a.hN) a.hN[(size_t)n * H + j] = hcur;
+    if (a.cN) a.cN[(size_t)n * H + j] = c;
   }
 }
 
