@@ -300,6 +300,11 @@ def overlap_available():
         rc = L.load().sb_overlap_init(st, _p(_overlap_scratch(dev)), tm)
         ok = _OVERLAP_OK[key] = rc == 1
         OVERLAP_LOG.append(("init", key, rc, float(tm[0]), float(tm[1])))
+        # once per (device, stream): nothing of the probe (its candidate streams, their one-per-CU busy kernels) is left in
+        # flight when the first real producer / consumer pair starts -- the first overlapped launch of a fresh process was
+        # the one place a deviating result was ever seen (1 of 176 fresh processes, switch-matrix run; none in 1 000+ later
+        # launches with changing inputs, scripts/stress_overlap.py)
+        torch.cuda.synchronize(dev)
     return ok
 
 

@@ -1330,3 +1330,45 @@ def test_few_sequence_vector_kernel_matches_float64_lstm(torch_gpu, C, nseq, S, 
             assert rel_l2(st[1].cpu().numpy(), cn[0].detach().numpy()) < 5e-6
     assert rel_l2(outs[True].numpy(), outs[False].numpy()) < 5e-6
     assert not torch.equal(outs[True], outs[False])          # two different kernels did run
+
+
+def test_overlapped_schedules_are_deterministic_with_changing_inputs(torch_gpu):
+    """The overlapped forward / backward (producer || consumer, recurrence || stream kernel) at a geometry where they engage,
+    over inputs that CHANGE from step to step: a consumer that read a stale copy of the producer's rows (the previous step's y
+    lives at the same addresses) would reproduce another input's numbers -- identical inputs would hide exactly that."""
+    torch = torch_gpu
+    import bench
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    cls, params = bench.WORKLOADS["big"][0], dict(bench.WORKLOADS["big"][1], B=2)
+    torch.manual_seed(7)
+    m = getattr(sb, cls)(**params).cuda().train()
+    B, N, K = 8, 38400, 3
+    data = []
+    for k in range(K):
+        g = torch.Generator().manual_seed(11 + k)
+        data.append(({"mixture": (torch.randn(B, 6, N, generator=g) * 0.1).cuda(),
+                      "dis_embed": torch.eye(3)[(torch.arange(B) + k) % 3].cuda()}, (torch.randn(B, 1, N, generator=g) * 0.1).cuda()))
+    refs = [None] * K
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    ops.PROFILE = {}
+    try:
+        for it in range(45):
+            inp, tgt = data[it % K]
+            m.zero_grad(set_to_none=True)
+            est = m(inp)["output"]
+            loss, _ = SnrlpLossFn.apply(est, tgt, 100.0)
+            loss.backward()
+            gv = torch.cat([p.grad.flatten() for p in m.parameters()])
+            if refs[it % K] is None:
+                refs[it % K] = (est.detach().clone(), gv.clone())
+            else:
+                assert torch.equal(est, refs[it % K][0]), it                         # the forward is bit-reproducible
+                assert rel(gv, refs[it % K][1]) < 1e-4, it                            # (atomics in the weight-gradient sums)
+        labels = sorted(ops.PROFILE)
+    finally:
+        ops.PROFILE = None
+    ops.check_sched_status()
+    if ops.overlap_available():
+        assert any("[producer]" in k for k in labels) and any("inter overlapped" in k for k in labels), labels
