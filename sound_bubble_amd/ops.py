@@ -166,6 +166,11 @@ def sched_status(dev):
     t = _SCHED_STATUS.get(i)
     if t is None:
         t = _SCHED_STATUS[i] = torch.zeros(1, device=dev, dtype=torch.int32)
+        # the word is read by kernels on the library's SIDE stream too, which is ordered after an event recorded BEFORE this
+        # fill was enqueued when the first use is an overlapped consumer (SB_NO_TIME_SEGMENTS=1: no producer-side scratch
+        # creates it earlier): the consumer then saw whatever the freshly allocated word held, took it for a tripped watchdog,
+        # dropped its items -- and the fill cleared the evidence (found by the switch matrix).  Once per device:
+        torch.cuda.synchronize(dev)
     return t
 
 
@@ -301,9 +306,7 @@ def overlap_available():
         ok = _OVERLAP_OK[key] = rc == 1
         OVERLAP_LOG.append(("init", key, rc, float(tm[0]), float(tm[1])))
         # once per (device, stream): nothing of the probe (its candidate streams, their one-per-CU busy kernels) is left in
-        # flight when the first real producer / consumer pair starts -- the first overlapped launch of a fresh process was
-        # the one place a deviating result was ever seen (1 of 176 fresh processes, switch-matrix run; none in 1 000+ later
-        # launches with changing inputs, scripts/stress_overlap.py)
+        # flight when the first real producer / consumer pair starts
         torch.cuda.synchronize(dev)
     return ok
 

@@ -64,10 +64,15 @@ def main():
         ops.check_sched_status()
         k, e = grads_vs(m, lambda k_: rec["grad::" + k_])
         with torch.no_grad():                            # the inference dispatch (few-sequence vector kernel, workspaces, ...)
-            ev = m(inp)["output"]
+            ev = m(inp)["output"] if os.environ.get("PROBE_NO_EVAL") != "1" else est.detach()
         out["golden"][name] = {"fwd": rel_l2(est.detach().cpu().numpy(), rec["output"]), "grad": e, "worst": k,
                                "fwd_eval": rel_l2(ev.cpu().numpy(), rec["output"])}
 
+    if os.environ.get("PROBE_POISON"):                   # debugging aid: every byte the medium stage allocates starts as NaN
+        del m
+        torch.cuda.empty_cache()
+        t = torch.full((int(float(os.environ["PROBE_POISON"]) * (1 << 28)),), float("nan"), device="cuda")
+        del t
     saved = np.load(a.compare) if a.compare else None
     keep = {}
     for wl, (cls, params, B) in medium().items():

@@ -52,6 +52,11 @@ SWITCHES = [
     ("bwd-pair-serial", {"SB_BWD_PAIR_SERIAL": "1"}, WIDE),
     ("no-vec-lstm", {"SB_NO_VEC_LSTM": "1"}, WIDE),
     ("no-infer-workspace", {"SB_NO_INFER_WORKSPACE": "1"}, WIDE),
+    # every byte the medium stage allocates starts as NaN (debugging aid of the probe): a kernel that reads memory nobody
+    # wrote -- or that a not-yet-ordered launch was going to write -- shows up deterministically instead of once in 176 runs
+    ("poisoned-free-memory", {"PROBE_POISON": "2"}, WIDE),
+    ("poisoned-free-memory-no-time-segments", {"PROBE_POISON": "2", "SB_NO_TIME_SEGMENTS": "1"}, WIDE),
+    ("poisoned-free-memory-compact", {"PROBE_POISON": "2", "SB_BPTT": "compact"}, COMPACT),
     ("overlap-slabs", {"SB_FWD_OVERLAP_SLAB": "8", "SB_BWD_OVERLAP_SLAB": "12", "SB_OVERLAP_MAX_FILL": "0.6"}, WIDE),
 ]
 
@@ -85,7 +90,7 @@ def test_every_documented_switch_is_in_the_matrix():
     for f in ("ops.py", "functional.py", "net.py", "harness.py", "forms.py", "train.py", "streaming.py"):
         read |= set(re.findall(r"SB_[A-Z0-9_]+", open(os.path.join(root, "sound_bubble_amd", f)).read()))
     read -= {"SB_PHASE_TIMING", "SB_OVERLAP_DEBUG", "SB_EXTRA_HIPCC_FLAGS", "SB_EPI_LN", "SB_EPI_RES"}
-    covered = set(k for _, env, _ in SWITCHES for k in env)
+    covered = set(k for _, env, _ in SWITCHES for k in env if k.startswith("SB_"))
     assert covered == set(ALL)
     assert read <= covered, sorted(read - covered)
     readme = set(re.findall(r"SB_[A-Z0-9_]+", open(os.path.join(root, "README.md")).read()))
@@ -102,28 +107,10 @@ def test_default_dispatch_takes_the_benched_paths_at_the_medium_geometry(baselin
         assert any("[producer]" in k for k in big) and any("[consumer, overlapped]" in k for k in big), big
 
 
-def _deviations(out, bar):
-    bad = {}
-    for name, g in out["golden"].items():
-        if not (g["fwd"] < 2e-5 and g["fwd_eval"] < 2e-5 and g["grad"] < bar):
-            bad[name] = g
-    for wl, g in out["medium"].items():
-        if not (g["fwd"] < 2e-5 and g["grad"] < bar):
-            bad[wl] = {k: v for k, v in g.items() if k != "labels"}
-    return bad
-
-
 @pytest.mark.parametrize("sid,env,bar", SWITCHES, ids=[s[0] for s in SWITCHES])
 def test_switch_keeps_parity(baseline, sid, env, bar):
     path, base = baseline
     out = _run(env, "--compare", path)
-    dev = _deviations(out, bar)
-    if dev:
-        # a fresh process's FIRST overlapped launch deviated once in 176 probe runs (never again in 1 000+ in-process launches
-        # with changing inputs: scripts/stress_overlap.py, DESIGN.md "known issues"): one re-run, reported, before failing
-        import warnings
-        warnings.warn(f"switch {sid}: first attempt deviated {dev}; re-running once")
-        out = _run(env, "--compare", path)
     for name, g in out["golden"].items():                 # against the reference goldens
         assert g["fwd"] < 2e-5 and g["fwd_eval"] < 2e-5, (sid, name, g)
         assert g["grad"] < bar, (sid, name, g)
