@@ -45,9 +45,10 @@ def timed(fn):
     return (time.perf_counter() - t0) / steps * 1e3, float(l)
 
 
-for rnd in range(2):
+for rnd in range(int(os.environ.get('ROUNDS', '2'))):
     a = timed(lambda: train_step(model, bucket, optim, inputs, target, negw, grad_clip=clip))
     b = timed(op_step)
     print(f"[{wl}] round {rnd}: module {a[0]:.3f} ms/step (loss {a[1]:.4f})   operators {b[0]:.3f} ms/step (loss {b[1]:.4f})   "
-          f"ratio {b[0] / a[0]:.4f}")
+          f"ratio {b[0] / a[0]:.4f}   reserved {torch.cuda.memory_reserved() >> 20} MiB  mallocs {torch.cuda.memory_stats()['num_device_alloc']}"
+          f"  pending {len(T._PENDING)}  overlap_ok {ops.overlap_available()}")
 ops.check_sched_status()
