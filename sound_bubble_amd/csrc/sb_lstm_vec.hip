@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_vec_kernel(sb_lstm_fwd_args a) {
         SB_FMAC_Q(a2, hv, wsc[16 * I + 8 + cc], 2);                                        \
         SB_FMAC_Q(a3, hv, wsc[16 * I + 12 + cc], 3);                                       \
       }
+      // (a DPP source register written by a VALU instruction needs two wait states; the operands here come straight from
+      // the four LDS reads above -- checked in the ISA -- and the s_nop covers a copy the register allocator might insert)
+      asm volatile("s_nop 1");
       SB_ROW16(hq0, 0) SB_ROW16(hq1, 1) SB_ROW16(hq2, 2) SB_ROW16(hq3, 3)
 #undef SB_ROW16
 #undef SB_FMAC_Q
