@@ -137,7 +137,7 @@ def test_loss_operators_match_the_modules():
         la, lb = op(a), mod(b)
         (3.0 * la).backward()
         (3.0 * lb).backward()
-        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+        assert abs(float(la.detach()) - float(lb.detach())) <= 1e-6 * abs(float(lb.detach()))
         assert rel_l2(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-6
 
 
