@@ -93,15 +93,19 @@ def main():
         labels = sorted(ops.PROFILE)
         ops.PROFILE = None
         ops.check_sched_status()
+        with torch.no_grad():                            # the inference dispatch at this geometry (overlapped forward in inference)
+            ev = m(inp)["output"]
+        ops.check_sched_status()
+        e_eval = rel_l2(ev.cpu().numpy(), est.detach().cpu().numpy())
         if saved is None:
             keep[wl + "::est"] = est.detach().cpu().numpy()
             for k, p in m.named_parameters():
                 keep[wl + "::" + k] = p.grad.cpu().numpy()
-            out["medium"][wl] = {"labels": labels}
+            out["medium"][wl] = {"labels": labels, "fwd_eval": e_eval}
         else:
             k, e = grads_vs(m, lambda k_: saved[wl + "::" + k_])
             out["medium"][wl] = {"fwd": rel_l2(est.detach().cpu().numpy(), saved[wl + "::est"]), "grad": e, "worst": k,
-                                 "labels": labels}
+                                 "labels": labels, "fwd_eval": e_eval}
     if a.save:
         np.savez(a.save, **keep)
     out["overlap"] = bool(ops.overlap_available())

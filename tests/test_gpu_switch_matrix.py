@@ -79,6 +79,8 @@ def baseline(tmp_path_factory):
     assert out["bptt"] == "wide"
     for name, g in out["golden"].items():
         assert g["fwd"] < 2e-5 and g["fwd_eval"] < 2e-5 and g["grad"] < WIDE, (name, g)
+    for wl, g in out["medium"].items():
+        assert g["fwd_eval"] < 2e-5, (wl, g)
     return path, out
 
 
@@ -115,7 +117,7 @@ def test_switch_keeps_parity(baseline, sid, env, bar):
         assert g["fwd"] < 2e-5 and g["fwd_eval"] < 2e-5, (sid, name, g)
         assert g["grad"] < bar, (sid, name, g)
     for wl, g in out["medium"].items():                   # against the switch-free run where the schedules engage
-        assert g["fwd"] < 2e-5, (sid, wl, g)
+        assert g["fwd"] < 2e-5 and g["fwd_eval"] < 2e-5, (sid, wl, g)     # fwd_eval: the inference forward against the training one
         assert g["grad"] < bar, (sid, wl, g)
     big = out["medium"]["big"]["labels"]
     if sid in ("no-fwd-overlap", "no-overlap-compact"):
