@@ -55,3 +55,13 @@ def torch_mod():
     import torch
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     return torch
+
+
+def poison_free_memory(torch, gib):
+    """Every byte the caching allocator hands out next starts as NaN (one block of `gib` GiB filled and freed): a kernel that
+    reads memory nobody wrote -- or that a not-yet-ordered launch was going to write -- shows up as NaN deterministically
+    instead of depending on what the block held before (how the first-use bug of DESIGN.md 9.3 was pinned down)."""
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    t = torch.full((int(gib * (1 << 28)),), float("nan"), device="cuda")
+    del t

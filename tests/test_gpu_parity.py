@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden, golden_state_dict, rel_l2, flatten_state
+from conftest import load_golden, golden_state_dict, rel_l2, flatten_state, poison_free_memory
 
 pytestmark = pytest.mark.gpu
 
@@ -166,6 +166,7 @@ def test_forward_small_config_1s(torch_gpu):
 @pytest.mark.parametrize("name,cls", CASES[:3] + ATTN_CASES)
 def test_streaming_matches_reference(torch_gpu, name, cls):
     torch = torch_gpu
+    poison_free_memory(torch, 2)
     rec, params, m = _build(torch, name, cls)
     x = torch.from_numpy(rec["stream::input"]).cuda()
     st = m.init_buffers(x.shape[0], "cuda")
@@ -258,6 +259,7 @@ def test_streaming_separator_equals_offline(torch_gpu, use_graph, name, cls):
     """edge/causal_infer.py:49-86 self-check: chunked output == one-shot output (atol 1e-3 there) -- for the big family
     and for the edge (small / optim, conv-LSTM) family incl. the shipped 0.3 M configuration that causal_infer.py runs."""
     torch = torch_gpu
+    poison_free_memory(torch, 2)
     from sound_bubble_amd.streaming import StreamingSeparator, streaming_inference
     rec, params, m = _build(torch, name, cls)
     dis = torch.from_numpy(rec["dis_embed"][:1]).cuda() if "dis_embed" in rec else None
@@ -1337,6 +1339,7 @@ def test_overlapped_schedules_are_deterministic_with_changing_inputs(torch_gpu):
     over inputs that CHANGE from step to step: a consumer that read a stale copy of the producer's rows (the previous step's y
     lives at the same addresses) would reproduce another input's numbers -- identical inputs would hide exactly that."""
     torch = torch_gpu
+    poison_free_memory(torch, 8)
     import bench
     import sound_bubble_amd as sb
     from sound_bubble_amd import ops
