@@ -65,3 +65,15 @@ def poison_free_memory(torch, gib):
     torch.cuda.empty_cache()
     t = torch.full((int(gib * (1 << 28)),), float("nan"), device="cuda")
     del t
+
+
+@pytest.fixture(autouse=True)
+def _poison_before_gpu_tests(request):
+    """every -m gpu test starts on NaN-poisoned free memory (1 GiB block; the tests above that need more poison more)"""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        poison_free_memory(torch, 1)
+    yield
