@@ -321,6 +321,7 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
     model = getattr(sb, cls)(**params).to(dev).train()
     bucket = FlatBucket(model)
     optim = FusedAdam(bucket, lr=lr)
+    RUN["bucket_bytes"] = 4 * bucket.numel
     inputs, target = synth_batch(torch, B, 1234 + rank, dev, cls != "NetOptim", cycle_radii=world > 1)
 
     def step():
@@ -338,11 +339,13 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
         for _ in range(warmup):
             step()
         barrier()
+        ops.sched_counts_reset()
         t0 = time.perf_counter()
         for _ in range(steps):                               # the timed region carries no profiling events
             step()
         barrier()
         dt = time.perf_counter() - t0
+        RUN["last_counts"] = dict(ops.SCHED_COUNTS, steps=steps)
         ops.check_sched_status()                             # a time-segmented launch that bailed out voids the run
         prof, prof_steps = {}, 0
         if profile:                                          # separate, untimed pass: HIP-event pairs (on the launch stream)
@@ -357,7 +360,7 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
         ops.PROFILE = None
         ops.BPTT = old_mode
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     table = {}
@@ -432,6 +435,7 @@ def roofline_of(table, wl, step_s, steps, forward_only, utt_s_per_gpu, params, m
 def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only=False, with_exact=True, with_cpu=True):
     step_s, table, B, params, cls = run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, forward_only=forward_only)
     main_mode = args.bptt or ops.BPTT
+    schedules = gather_schedules(dist, world, RUN.get("last_counts"))     # every rank: which inter-frame schedules its timed steps took
     if rank != 0:
         if with_exact and not forward_only:                  # every rank runs the sibling (collectives inside)
             run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, mode=SIBLING[main_mode],
@@ -449,7 +453,15 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
                                   " (BASELINE configs[1])" if wl == "small" else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "roofline": roofline_of(table, wl, step_s, args.steps, forward_only, utt_s / world, params, main_mode),
+        "rccl": RUN.get("rccl"),
+        "schedules": {"per_rank": schedules,
+                      "note": "inter-frame launches of the timed steps per rank: overlapped (producer || consumer, recurrence || "
+                              "stream kernel on the library's side stream) or plain order"},
     }
+    if not forward_only:
+        from sound_bubble_amd import train as _train
+        out["rccl"] = dict(out["rccl"] or {}, allreduce_in_step=bool(world > 1 or _train.FORCE_ALLREDUCE),
+                           allreduce_bytes=RUN.get("bucket_bytes"))
     if forward_only:
         # north-star target: >= 30 % of the HBM roofline on the forward.  The forward is 292 (big) / 223 (small) FLOP per
         # compulsory byte, so an exact-fp32 MFMA implementation tops out at 6.7 % / 8.8 %; on the fp16 pipe
@@ -484,6 +496,64 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
     return out
 
 
+RUN = {}                        # per-process run facts folded into every train line: rccl (process group), schedules
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: re-exec the same command line as N ranks under
+    `torch.distributed.run` on this node (one process per GPU, rendezvous on 127.0.0.1).  Refuses -- non-zero exit, nothing
+    measured -- when the node shows fewer than N GPUs (SB_FORCE_DEVICE, the several-ranks-on-one-GPU test hook, lifts that)."""
+    import subprocess
+    if os.environ.get("SB_FORCE_DEVICE") is None:
+        import torch
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node shows {n}: refusing to measure "
+                  f"fewer ranks than asked for", file=sys.stderr, flush=True)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def dist_info(torch, dist, dev, backend, world):
+    """`rccl` object of the bench lines: what the process group really is (backend, size, one device entry per rank)."""
+    me = {"rank": int(os.environ.get("RANK", "0")), "device": str(dev), "pid": os.getpid()}
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        me.update(name=pr.name, cus=pr.multi_processor_count, pci_bus_id=getattr(pr, "pci_bus_id", None))
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world": 1, "devices": [me], "note": "single process, no process group"}
+    devs = [None] * world
+    dist.all_gather_object(devs, me)
+    info = {"backend": dist.get_backend(), "world": world, "devices": devs}
+    if backend == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    return info
+
+
+def gather_schedules(dist, world, counts):
+    """per-rank schedule counts of the timed region, all-gathered: a side stream lost next to RCCL shows as plain-order counts"""
+    if world > 1 and dist.is_initialized():
+        out = [None] * world
+        dist.all_gather_object(out, counts)
+        return out
+    return [counts]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -503,28 +573,57 @@ def main():
     ap.add_argument("--stream", action="store_true",
                     help="single-workload mode (BASELINE configs[4]): hipGraph-captured 8 ms chunk loop")
     ap.add_argument("--no-graph", action="store_true", help="with --stream: eager launches instead of hipGraph replay")
+    ap.add_argument("--init-dist", action="store_true",
+                    help="initialise the process group (RCCL) even at --gpus 1: the step's all-reduce then really runs")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher / process-group plumbing only: start the ranks, all-gather their devices, print one line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                          # plain `python bench.py --gpus N`: becomes an N-rank run
 
     import torch
     import torch.distributed as dist
-    import sound_bubble_amd as sb
-    from sound_bubble_amd import ops
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if "SB_FORCE_DEVICE" in os.environ:                      # test hook: several ranks on one GPU (with gloo)
-        local = int(os.environ["SB_FORCE_DEVICE"])
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a "
+                 f"{args.gpus}-GPU number from {world} rank(s)")
+    force = os.environ.get("SB_FORCE_DEVICE")               # test hook: several ranks on one GPU (with gloo); "cpu": no GPU at all
+    backend = os.environ.get("SB_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+    if args.launch_check and force == "cpu":
+        dev = torch.device("cpu")
+    else:
+        if force is not None:
+            local = int(force)
+        elif torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node shows {torch.cuda.device_count()}")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    if world > 1 or args.init_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SB_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        world = dist.get_world_size()                        # n_gpus of every line below is the process group's size
+    rccl = dist_info(torch, dist, dev, backend, world)
+    if args.launch_check:                                    # launcher / process-group plumbing only (tests/test_distributed_cpu.py)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rccl": rccl}), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    import sound_bubble_amd as sb
+    from sound_bubble_amd import ops
+    from sound_bubble_amd import train as _train
+    RUN["rccl"] = rccl
+    _train.FORCE_ALLREDUCE = bool(args.init_dist)            # world 1 with a process group: the bucket all-reduce still runs
 
     def emit(obj):
         if rank == 0 and obj is not None:

@@ -311,6 +311,16 @@ def overlap_available():
     return ok
 
 
+# which schedule the inter-frame passes took since the last reset (bench.py: `schedules`, all-gathered over the ranks -- a side
+# stream lost next to RCCL's kernels shows here as plain-order counts)
+SCHED_COUNTS = {"fwd_overlapped": 0, "fwd_plain": 0, "bwd_overlapped": 0, "bwd_plain": 0}
+
+
+def sched_counts_reset():
+    for k in SCHED_COUNTS:
+        SCHED_COUNTS[k] = 0
+
+
 OVERLAP_LOG = []          # (event, (device, stream), verdict, back-to-back ms, pair ms) -- what SB_OVERLAP_DEBUG used to print
 
 
@@ -459,8 +469,10 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
             if rc == -1009:                # no side stream (any more): the plain call; the consumer then runs in plain order too
                 overlap_lost()
                 L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
+                SCHED_COUNTS["fwd_plain"] += 1
             else:
                 L.check(rc, "sb_lstm_fwd_produce")
+                SCHED_COUNTS["fwd_overlapped"] += 1
                 produce.keep += [x, ln_g, ln_b, h0, c0, hs, gates, cprev, u, hN, cN, x_part, x_sum, seg_scratch, lin, film, dirs]
                 produce.produced = True
         elif consume is not None:
@@ -473,6 +485,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
             consume.produced = False
         else:
             L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
+            if ndir == 1 and lin is not None:
+                SCHED_COUNTS["fwd_plain"] += 1
     return hs, ((hN, cN) if want_state else None), (gates, cprev), u
 
 
@@ -603,6 +617,8 @@ def lstm_bwd_rec(w_hh_list, gates, dhs, geom, dy=None, w_lin=None, gmax=None):
     with _Prof(f"lstm_bwd_rec_bf_kernel ndir={ndir} (recurrence only, dgates to HBM)",
                (2.0 * 4 * H * H + 2.0 * H * Cl) * geom.P * ndir, 8.0 * max(Cl, 16) * geom.P, by):
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec")
+    if ndir == 1:
+        SCHED_COUNTS["bwd_plain"] += 1
     return DGates(dg, gmax)
 
 
@@ -688,6 +704,7 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
             overlap_lost()
             return None
         L.check(rc, "sb_lstm_bwd_inter_overlapped")
+        SCHED_COUNTS["bwd_plain" if BWD_PAIR_SERIAL else "bwd_overlapped"] += 1
     if gm is not None:
         absmax_hint_put(dx, gm)
     return dx
@@ -772,6 +789,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
                + (" [wide]" if a.wide else "") + (" [role-split]" if a.split else ""),
                fl, 8.0 * Cc * geom.P, by):
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
+    SCHED_COUNTS["bwd_plain"] += 1
     return du
 
 

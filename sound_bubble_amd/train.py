@@ -154,10 +154,15 @@ def broadcast_replica(bucket, optim=None, src=0):
         optim.step_count, optim.param_groups[0]["lr"] = int(meta[0].item()), float(meta[1].item())
 
 
-def allreduce_grads(bucket):
-    """One RCCL all-reduce (sum) of the whole gradient bucket (no-op without torch.distributed)."""
+FORCE_ALLREDUCE = False     # run the collective in a world of one as well (bench.py --init-dist, the RCCL smoke test)
+
+
+def allreduce_grads(bucket, force=False):
+    """One RCCL all-reduce (sum) of the whole gradient bucket (no-op without torch.distributed).  In a process group of ONE
+    rank the collective is skipped unless `force` / FORCE_ALLREDUCE asks for it (RCCL then runs its kernel on the bucket --
+    a sum over one rank -- in stream order between the backward and the optimiser: what tests/test_gpu_distributed.py checks)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force or FORCE_ALLREDUCE):
         if _via_host(bucket.grad):
             h = bucket.grad.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)

@@ -193,3 +193,44 @@ def test_optimizer_state_roundtrip_in_torch_adam_layout(tmp_path):
     ck = tmp_path / "x.ckpt"
     torch.save({"state_dict": {"model." + k: v for k, v in net.state_dict().items()}}, ck)
     assert set(load_model_weights(str(ck))) == set(net.state_dict())
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_launcher_starts_n_ranks_from_the_plain_command():
+    """`python bench.py --gpus 2` (no torchrun around it) becomes a 2-rank run: the launcher re-execs under
+    torch.distributed.run, the ranks form a process group (gloo here, RCCL on the GPU box) and n_gpus is the group's size --
+    not the flag's value, and never 1 rank reported as 2 (VERDICT r3 #1)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--launch-check"], {"SB_FORCE_DEVICE": "cpu", "SB_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["world"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert sorted(d["rank"] for d in line["rccl"]["devices"]) == [0, 1]
+    assert len({d["pid"] for d in line["rccl"]["devices"]}) == 2
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """no silent single-rank measurement under a multi-GPU flag: with fewer visible GPUs than --gpus the command exits
+    non-zero and prints no bench line"""
+    n = torch.cuda.device_count()
+    r = _run_bench(["--gpus", str(n + 2), "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_refuses_a_world_that_differs_from_the_flag():
+    """started by a launcher with another rank count than --gpus says: exit, do not relabel"""
+    r = _run_bench(["--gpus", "4", "--launch-check"], {"SB_FORCE_DEVICE": "cpu", "SB_DIST_BACKEND": "gloo", "WORLD_SIZE": "1",
+                                                        "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
