@@ -454,11 +454,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         if constexpr (SAVE == 4) {
           // wide records (sb_lstm_fwd_args.rec_f32): fp32, blocked per (tile, step, direction) in lane order like the
           // compact ones -- [wave][gate][lane][4 floats] and [wave][lane][4 floats], one contiguous KB per store
-          float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
-          if (k == 0) st4(rec, rgi);
-          if (k == 1) st4(rec + 256, rgf);
-          if (k == 2) st4(rec + 512, rgg);
-          if (k == 3) st4(rec + 768, rgo);
+          // save_gates == NULL: records WITHOUT the gates (c_prev only) -- for a backward that recomputes them from u and
+          // h_prev with the forward weights (sb_lstm_bwd_args.recompute with `wide`)
+          if (k < 4 && a.save_gates) {
+            float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
+            if (k == 0) st4(rec, rgi);
+            if (k == 1) st4(rec + 256, rgf);
+            if (k == 2) st4(rec + 512, rgg);
+            if (k == 3) st4(rec + 768, rgo);
+          }
           if (k == 4) st4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, rcp);
         } else {
           // Compact records are private to this kernel and the backward recurrence, which walks the same (tile, step)
@@ -2174,9 +2178,11 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
   if (a.aux_f16 && !a.save_c) return -1003;
   // aux_f16 with save_gates == NULL: records without the gates (the backward recomputes them: sb_lstm_bwd_args.recompute)
-  if (a.rec_f32 && (!a.save_gates || !a.save_c || a.aux_f16 || !f16)) return -1003;
-  const int save = a.save_gates == nullptr ? (a.save_c && a.aux_f16 ? 3 : 0)
-                                           : (a.save_c ? (a.rec_f32 ? 4 : (a.aux_f16 ? 3 : 2)) : 1);
+  // rec_f32 with save_gates == NULL: wide records without the gates (c_prev, u and hs pairs only; single direction with the
+  // Linear applied here, so that hs is stored): the backward recomputes the gates
+  if (a.rec_f32 && (!a.save_c || a.aux_f16 || !f16 || (!a.save_gates && (a.ndir != 1 || !a.lin_w || !a.hs)))) return -1003;
+  const int save = a.rec_f32 ? 4 : a.save_gates == nullptr ? (a.save_c && a.aux_f16 ? 3 : 0)
+                                                           : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
   dim3 grid(ntiles, a.ndir);
   const bool lin = a.lin_w != nullptr;
   if (lin && (!f16 || !a.lin_b || !a.y)) return -1003;         // ndir == 2: per-direction partial products (see the kernel)

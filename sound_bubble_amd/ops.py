@@ -374,6 +374,9 @@ def can_overlap_fwd(B, T, F_, Cc, train, dev):
             and overlap_available())
 
 
+EXP_NO_INTER_GATES = False      # scripts/exp_fwd_nogates.py
+
+
 def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True,
              no_gates=False, x_part=None, x_sum=None, film=None, produce=None, consume=None):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
@@ -390,6 +393,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     aux16 = bool(save and AUX_FP16 and _compact() and DGATES_FP16 and LSTM_MMA in (1, 2))
     hs16 = aux16 and lin is not None
     wide = bool(save and _wide())
+    if EXP_NO_INTER_GATES and wide and len(dirs) == 1 and lin is not None:
+        no_gates = True
     # wide form: the tensors that only the backward kernels' matrix products read travel as the fp16 (hi, lo) term pairs
     # the forward kernel itself multiplies with -- same bytes as fp32, no split in the backward: u always ([P, 2C] halves),
     # hs when the Linear is applied inside this kernel ([P, ndir * 128] halves); kernel-private layouts (see the header)
@@ -398,9 +403,10 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
                       dtype=torch.float16 if (hs16 or hsp) else torch.float32) if want_hs else None)
     gates = cprev = None
     if wide:                  # fp32 records, blocked like the compact ones (see the header: rec_f32)
-        assert LSTM_MMA == 1 and not no_gates
+        assert LSTM_MMA == 1 and (not no_gates or (ndir == 1 and hsp))
         Pr = (geom.nseq + 15) // 16 * 16 * geom.nsteps
-        gates = torch.empty(Pr, ndir, 4 * H, device=dev, dtype=torch.float32)
+        if not no_gates:      # no_gates: c_prev + the u / hs pairs only -- the backward recomputes the gates
+            gates = torch.empty(Pr, ndir, 4 * H, device=dev, dtype=torch.float32)
         cprev = torch.empty(Pr, ndir, H, device=dev, dtype=torch.float32)
     elif save and _compact():
         # opaque to the host: on the 16-bit matrix path the records are blocked per (16-sequence tile, step, direction)

@@ -297,35 +297,54 @@ def _rccl_world_of_one(port, q):
     mix = (0.1 * torch.randn(2, 6, 192 * 150, generator=g)).cuda()    # pad=True adds the 96 look-ahead samples: T = 150
     tgt = (0.05 * torch.randn(2, 1, 192 * 150, generator=g)).cuda()
     dis = torch.eye(3)[torch.arange(2) % 3].cuda()
-    res = {}
-    for forced in (False, True):
-        torch.manual_seed(3)
-        m = sb.NetDisEmbd3(**dict(params, B=6)).cuda().train()
-        bucket = FlatBucket(m)
-        optim = FusedAdam(bucket, lr=1e-3)
-        train.FORCE_ALLREDUCE = forced
-        grads = []
-        ops.sched_counts_reset()
-        for it in range(3):
-            # train_step: ... backward -> allreduce_grads (RCCL kernel on the bucket when forced) -> clip + Adam
-            train_step(m, bucket, optim, {"mixture": mix, "dis_embed": dis}, tgt, 100.0, grad_clip=1.0)
-            grads.append(bucket.grad.clone())
-        torch.cuda.synchronize()
-        ops.check_sched_status()
-        res[forced] = (torch.stack(grads).cpu().numpy(), bucket.flat.detach().cpu().numpy(), dict(ops.SCHED_COUNTS))
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd.train import allreduce_grads
+    torch.manual_seed(3)
+    m = sb.NetDisEmbd3(**dict(params, B=6)).cuda().train()
+    bucket = FlatBucket(m)
+    optim = FusedAdam(bucket, lr=1e-3)
+    inputs = {"mixture": mix, "dis_embed": dis}
+    ops.sched_counts_reset()
+    same, adam_err = [], []
+    for it in range(3):
+        # train_step's own sequence with the gradient bucket read back on either side of the collective
+        bucket.zero_grad()
+        loss, _ = SnrlpLossFn.apply(m(inputs)["output"], tgt, 100.0)
+        loss.backward()
+        g0 = bucket.grad.clone()
+        w = allreduce_grads(bucket, force=True)          # RCCL's kernel on the 2 MB bucket: a sum over one rank
+        assert w == 1
+        g1 = bucket.grad.clone()
+        p0, m0, v0 = bucket.flat.clone(), optim.m.clone(), optim.v.clone()
+        optim.step(grad_clip=None, world_size=w)         # reads what the collective left, in stream order
+        t = optim.step_count
+        m1 = 0.9 * m0 + 0.1 * g1
+        v1 = 0.999 * v0 + 0.001 * g1 * g1
+        ref = p0 - 1e-3 * (m1 / (1 - 0.9 ** t)) / ((v1 / (1 - 0.999 ** t)).sqrt() + 1e-8)
+        same.append(bool(torch.equal(g0, g1)) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0)
+        adam_err.append(float((bucket.flat - ref).abs().max() / ref.abs().max()))
+    train.FORCE_ALLREDUCE = True                         # ... and through train_step itself
+    for it in range(2):
+        train_step(m, bucket, optim, inputs, tgt, 100.0, grad_clip=1.0)
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    counts = dict(ops.SCHED_COUNTS)
     still = ops.overlap_reprobe() if ops.overlap_available() else None
     ver = ".".join(str(v) for v in torch.cuda.nccl.version())
-    q.put((res, still, ver, [e[2:] for e in ops.OVERLAP_LOG], dist.get_backend()))
+    q.put((same, adam_err, counts, bool(torch.isfinite(bucket.flat).all()), still, ver, [e[2:] for e in ops.OVERLAP_LOG],
+           dist.get_backend()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_rccl_world_of_one_train_step_with_forced_bucket_allreduce():
-    """RCCL executes (VERDICT r3 #1b): `init_process_group("nccl", world_size=1)` on the one GPU there is, three train steps
-    of the six-block big model with the bucket all-reduce FORCED and the overlapped schedules on.  A sum over one rank is
-    the identity, so the stream ordering RCCL's kernel gets between the backward's last gradient write and `optim.step` is
-    checked to the bit: gradients and parameters after three steps equal the run without the collective.  No watchdog
-    trip; the side stream still runs concurrently afterwards (or the loss is reported: the probe log is printed)."""
+    """RCCL executes (VERDICT r3 #1b): `init_process_group("nccl", world_size=1)` on the one GPU there is, train steps of the
+    six-block big model with the bucket all-reduce FORCED and the overlapped schedules on.  A sum over one rank is the
+    identity, so the stream ordering RCCL's kernel gets between the backward's last gradient write and `optim.step` is checked
+    to the bit: the bucket read back after the collective equals the bucket read back before it, and the parameters after the
+    fused Adam equal Adam applied to that gradient.  No watchdog trip; the side stream still runs concurrently afterwards
+    (the probe log is printed).  (Two RUNS of the step are not bit-comparable: the overlapped schedules deal their work by
+    atomic draws, so the order of the weight-gradient partial sums differs from run to run.)"""
     import torch
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
@@ -333,18 +352,16 @@ def test_rccl_world_of_one_train_step_with_forced_bucket_allreduce():
     q = ctx.SimpleQueue()
     p = ctx.Process(target=_rccl_world_of_one, args=(_free_port(), q))
     p.start()
-    res, still, ver, log, backend = q.get()
+    same, adam_err, counts, finite, still, ver, log, backend = q.get()
     p.join(300)
     assert p.exitcode == 0
     print(f"RCCL {ver} (backend {backend}); side stream concurrent after the run: {still}; probe log: {log}; "
-          f"schedules without / with all-reduce: {res[False][2]} / {res[True][2]}")
+          f"schedules: {counts}; Adam-after-collective error {adam_err}")
     assert backend == "nccl"
-    assert np.isfinite(res[True][0]).all() and np.abs(res[True][0]).max() > 0
-    assert np.array_equal(res[False][0], res[True][0])            # gradients of all three steps, bit for bit
-    assert np.array_equal(res[False][1], res[True][1])            # parameters after three clip + Adam steps
-    assert res[True][2] == res[False][2]                          # same schedules next to RCCL's kernel
+    assert same == [True, True, True]                              # gradient bucket untouched by the one-rank sum, bit for bit
+    assert max(adam_err) < 2e-6 and finite
     if still is not None:
-        assert res[True][2]["fwd_overlapped"] > 0 and res[True][2]["bwd_overlapped"] > 0, res[True][2]
+        assert counts["fwd_overlapped"] > 0 and counts["bwd_overlapped"] > 0, counts
 
 
 def _bench(args, env_extra, timeout=900):
