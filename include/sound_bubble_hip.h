@@ -98,8 +98,15 @@ typedef struct {
   /* WIDE BPTT state (mma == 1, save_gates and save_c given, aux_f16 == 0): rec_f32 != 0 keeps the reference's own
      precision in everything the backward reads -- the gate records are fp32 (save_gates [R, ndir, 4, 64] floats, save_c
      [R, ndir, 64] floats, R as for the compact records and blocked per (16-sequence tile, step, direction) in the
-     kernels' lane order like them: 1280 B per step and direction, one contiguous KB per store instruction), save_u and
-     hs stay fp32.  To be handed to sb_lstm_bwd_rec with `wide` set. */
+     kernels' lane order like them: 1280 B per step and direction, one contiguous KB per store instruction).  The two side
+     outputs only the backward kernels read keep their BYTE SIZE (4 bytes per element) but are OPAQUE pair-form buffers, not
+     fp32 arrays: save_u [P][2 C halves] holds the fp16 (hi, lo) terms the forward kernel multiplies with
+     ([P][C/2][hi0, hi1, lo0, lo1] for C = 32, [P][C][hi, lo] for C = 16), and hs -- when the Linear is applied in the kernel
+     (lin_w != NULL) -- [P][ndir][16 unit quads][hi x 4, lo x 4] halves; with lin_w == NULL hs is plain fp32 [P, ndir*64].
+     An integrator passes both UNCHANGED from sb_lstm_fwd to sb_lstm_bwd_rec / sb_lstm_bwd_stream with `wide` set and never
+     reads them as floats.  hs may be NULL for the bidirectional pass whose backward recomputes h (sb_lstm_bwd_args.split).
+     save_gates == NULL with rec_f32 (single direction, lin_w != NULL, hs given): records WITHOUT the four gates -- c_prev
+     and the u / hs pairs only -- for a backward that recomputes the gates from them (sb_lstm_bwd_args.recompute + wide). */
   int rec_f32;
   /* Calls that ask for hs (+ hN / cN) alone -- no records, no fused Linear / summed input / FiLM -- with at most 256
      (sequence, direction) chains are served by a one-workgroup-per-chain kernel on the vector ALU (exact fp32 matrix-vector
@@ -184,8 +191,9 @@ typedef struct {
   /* producer side of sb_lstm_bwd_inter_overlapped (set by that call; leave NULL / 0 otherwise) */
   int* slab_flags; int slab_len; int* slab_started;
   /* WIDE BPTT state: the fused forms above (wpart != NULL; single direction or bidirectional) at the reference's own
-     precision.  wide != 0: save_gates / save_c are the blocked fp32 records of sb_lstm_fwd_args.rec_f32, u [P, C] and hs
-     [P, ndir * 64] are fp32; gmax is still required (the recurrence runs on gradients scaled by the power of two S so
+     precision.  wide != 0: save_gates / save_c are the blocked fp32 records of sb_lstm_fwd_args.rec_f32, u and hs are the
+     forward call's pair-form side outputs (opaque, 4 bytes per element: see rec_f32; hs plain fp32 [P, ndir * 64] when the
+     forward did not apply the Linear); gmax is still required (the recurrence runs on gradients scaled by the power of two S so
      that 16-bit terms cannot overflow) and every gradient quantity that meets the fp16 matrix pipe does so as TWO fp16
      terms x = hi + 2^-11 lo' (lo' = fp16((x - hi) * 2^11): 22 mantissa bits with no underflow of the low term), against
      fp16 hi + lo splits of u / h_prev / the weights -- three products per MAC, as in the forward kernels.  hs_f16 and
@@ -536,6 +544,16 @@ int sb_reflect_pad(const float* x, float* xp, int B, int64_t N, int pad, int64_t
 int sb_stft_mag_l1_grid(int64_t rows, int ld);
 int sb_stft_mag_l1(const float* spec_x, const float* spec_y, int64_t rows, int nbins, int ld, float eps, float gscale,
                    float* dspec_x, float* partial, float loss_scale, float* loss, int accumulate, void* stream);
+/* All three auraloss STFTLoss terms of one resolution (auraloss/freq.py STFTLoss.forward; reached through the **kwargs of
+ * src/losses/MultiResoLoss.py:12, whose defaults are w_sc = w_log_mag = 1):
+ *   *loss += scale * ( w_lin * mean | |X| - |Y| |  +  w_log * mean | log|X| - log|Y| |  +  w_sc * || |Y| - |X| ||_F / || |Y| ||_F )
+ * (means / norms over the rows x nbins magnitudes; fixed summation trees) and, when dspec_x != NULL, dspec_x [rows, ld] =
+ * d(that) / d spec_x (zero on the clamp and in the padding columns).  Two passes over the spectra: the spectral-convergence
+ * gradient needs the global norms.  partial: 4 * sb_stft_mag_l1_grid(rows, ld) floats of scratch; sums: 4 floats (out:
+ * sum |e|, sum |log ratio|, sum e^2, sum |Y|^2). */
+int sb_stft_mag_terms(const float* spec_x, const float* spec_y, int64_t rows, int nbins, int ld, float eps, float w_lin,
+                      float w_log, float w_sc, float scale, float* dspec_x, float* partial, float* sums, float* loss,
+                      void* stream);
 int sb_frames_fold(const float* dframes, float* dx, int B, int64_t N, int nframes, int K, int ldk, int hop, int off,
                    int pad, int accumulate, void* stream);
 int sb_l1_grad(const float* x, const float* y, int64_t n, float gscale, float* dx, int accumulate, float* partial,

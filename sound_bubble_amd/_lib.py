@@ -179,6 +179,7 @@ SYMBOLS = {
     "sb_reflect_pad": (_ci, [c_fp, c_fp, _ci, i64, _ci, i64, _vp]),
     "sb_stft_mag_l1_grid": (_ci, [i64, _ci]),
     "sb_stft_mag_l1": (_ci, [c_fp, c_fp, i64, _ci, _ci, _cf, _cf, c_fp, c_fp, _cf, c_fp, _ci, _vp]),
+    "sb_stft_mag_terms": (_ci, [c_fp, c_fp, i64, _ci, _ci, _cf, _cf, _cf, _cf, _cf, c_fp, c_fp, c_fp, c_fp, _vp]),
     "sb_frames_fold": (_ci, [c_fp, c_fp, _ci, i64, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
     "sb_l1_grad": (_ci, [c_fp, c_fp, i64, _cf, c_fp, _ci, c_fp, _cf, c_fp, _ci, _vp]),
 }

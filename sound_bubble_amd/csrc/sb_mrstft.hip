@@ -6,6 +6,7 @@
 //   sb_fir          the 101-tap A-weighting FIR (conv1d, zero padded) -- also its backward (flipped taps)
 //   sb_reflect_pad  torch.stft(center=True, pad_mode="reflect") framing input
 //   sb_stft_mag_l1  |X|, |Y| from interleaved (re, im) spectra, sum |(|X| - |Y|)|, d(loss)/d(spectrum of X)
+//   sb_stft_mag_terms  the same with auraloss's other two terms (log-magnitude L1, spectral convergence): two passes
 //   sb_frames_fold  backward of framing + reflect padding: frame gradients -> signal gradient
 //   sb_l1_grad      sum |x - y| and its gradient
 // All HBM-bound single passes.
@@ -96,6 +97,98 @@ __global__ __launch_bounds__(256) void stft_mag_l1_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = d;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// The three auraloss STFT terms together (STFTLoss.forward: w_sc * SC + w_log_mag * L1(log|X|, log|Y|) + w_lin_mag *
+// L1(|X|, |Y|)).  The spectral-convergence term ||  |Y| - |X|  ||_F / || |Y| ||_F is a ratio of GLOBAL norms over the
+// whole [rows, nbins] magnitude array, so its gradient needs both sums first -- two passes:
+//   pass 1 (stft_mag_sums_kernel): per block the four sums  S0 = sum |e|, S1 = sum |log|X| - log|Y||, S2 = sum e^2,
+//           S3 = sum |Y|^2  (e = |X| - |Y|) -> partial[4][blocks]
+//   mag_terms_finish_kernel: fixed-tree totals -> sums[4], *loss (+)= scale * (w_lin S0 / cnt + w_log S1 / cnt + w_sc sqrt(S2 / S3))
+//   pass 2 (stft_mag_grad_kernel): dsx = scale * [ (w_lin / cnt) sign(e) + (w_log / cnt) sign(e) / |X| + w_sc e / (sqrt(S2) sqrt(S3)) ] * X / |X|
+//           (log is monotone: sign(log|X| - log|Y|) = sign(e); zero on the clamp, as torch.clamp's gradient; zero when S2 == 0)
+__global__ __launch_bounds__(256) void stft_mag_sums_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                            int64_t rows, int nbins, int ld, float eps,
+                                                            float* __restrict__ partial, int64_t nblocks) {
+  const int half = ld / 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (idx < rows * half) {
+    const int64_t row = idx / half;
+    const int k = (int)(idx - row * half);
+    if (k < nbins) {
+      const int64_t o = row * ld + 2 * k;
+      const float2 a = *reinterpret_cast<const float2*>(sx + o), c = *reinterpret_cast<const float2*>(sy + o);
+      const float mx = sqrtf(fmaxf(a.x * a.x + a.y * a.y, eps)), my = sqrtf(fmaxf(c.x * c.x + c.y * c.y, eps));
+      const float e = mx - my;
+      v[0] = fabsf(e);
+      v[1] = fabsf(logf(mx) - logf(my));
+      v[2] = e * e;
+      v[3] = my * my;
+    }
+  }
+  __shared__ float ws[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t = wave_sum(v[i]);
+    if ((threadIdx.x & 63) == 0) ws[i][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) partial[threadIdx.x * nblocks + blockIdx.x] = (ws[threadIdx.x][0] + ws[threadIdx.x][1]) + (ws[threadIdx.x][2] + ws[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void mag_terms_finish_kernel(const float* __restrict__ partial, int64_t n, float cnt,
+                                                               float w_lin, float w_log, float w_sc, float scale,
+                                                               float* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double red[256];
+  __shared__ double tot[4];
+  for (int q = 0; q < 4; ++q) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)partial[q * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[q] = red[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 4; ++q) sums[q] = (float)tot[q];
+    double l = (double)w_lin * tot[0] / cnt + (double)w_log * tot[1] / cnt;
+    if (w_sc != 0.f) l += (double)w_sc * sqrt(tot[2] / tot[3]);
+    loss[0] += (float)(l * (double)scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void stft_mag_grad_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                            int64_t rows, int nbins, int ld, float eps, float cnt,
+                                                            float w_lin, float w_log, float w_sc, float scale,
+                                                            const float* __restrict__ sums, float* __restrict__ dsx) {
+  const int half = ld / 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * half) return;
+  const int64_t row = idx / half;
+  const int k = (int)(idx - row * half);
+  const int64_t o = row * ld + 2 * k;
+  float2 g = {0.f, 0.f};
+  if (k < nbins) {
+    const float2 a = *reinterpret_cast<const float2*>(sx + o), c = *reinterpret_cast<const float2*>(sy + o);
+    const float px = a.x * a.x + a.y * a.y;
+    if (px > eps) {
+      const float mx = sqrtf(px), my = sqrtf(fmaxf(c.x * c.x + c.y * c.y, eps));
+      const float e = mx - my;
+      const float sg = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+      float d = sg * (w_lin / cnt) + sg * (w_log / cnt) / mx;
+      const float s2 = sums[2], s3 = sums[3];
+      if (w_sc != 0.f && s2 > 0.f) d += w_sc * e / (sqrtf(s2) * sqrtf(s3));
+      const float f = scale * d / mx;
+      g.x = f * a.x;
+      g.y = f * a.y;
+    }
+  }
+  *reinterpret_cast<float2*>(dsx + o) = g;
 }
 
 // out[0] (+)= scale * sum partial[0 .. n)  -- one workgroup, fixed summation tree (bit-identical on every replica)
@@ -190,6 +283,25 @@ extern "C" int sb_stft_mag_l1(const float* spec_x, const float* spec_y, int64_t 
   hipLaunchKernelGGL(stft_mag_l1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, spec_x, spec_y, rows, nbins, ld, eps,
                      gscale, dspec_x, partial);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, blocks, loss_scale, loss, accumulate);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_stft_mag_terms(const float* spec_x, const float* spec_y, int64_t rows, int nbins, int ld, float eps,
+                                 float w_lin, float w_log, float w_sc, float scale, float* dspec_x, float* partial,
+                                 float* sums, float* loss, void* stream) {
+  if (!spec_x || !spec_y || !partial || !sums || !loss || rows <= 0 || nbins <= 0 || ld < 2 * nbins || (ld & 1)) return -1001;
+  const int64_t blocks = nblk(rows * (ld / 2));
+  if (blocks >= (1ll << 31)) return -1002;
+  hipStream_t st = (hipStream_t)stream;
+  const float cnt = (float)((double)rows * nbins);
+  hipLaunchKernelGGL(stft_mag_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, spec_x, spec_y, rows, nbins, ld, eps,
+                     partial, blocks);
+  hipLaunchKernelGGL(mag_terms_finish_kernel, dim3(1), dim3(256), 0, st, partial, blocks, cnt, w_lin, w_log, w_sc, scale, sums,
+                     loss);
+  if (dspec_x)
+    hipLaunchKernelGGL(stft_mag_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, spec_x, spec_y, rows, nbins, ld, eps,
+                       cnt, w_lin, w_log, w_sc, scale, sums, dspec_x);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -59,6 +59,56 @@ WORKSPACE = None
 INFER_WORKSPACE = __import__("os").environ.get("SB_NO_INFER_WORKSPACE", "0") != "1"
 
 
+class Workspaces:
+    """per-model cache of the zero-bordered inference staging tensors, keyed by (tag, shape, device).  At most `cap` live
+    entries, evicted ONE at a time in least-recently-used order -- never an entry a captured hipGraph refers to: a graph
+    replays against the addresses it was captured with, so StreamingSeparator pins the keys its capture touched (`record` /
+    `pin` / `unpin`) and a pinned tensor stays allocated, with its zero borders intact, for as long as that graph lives."""
+
+    def __init__(self, cap=12):
+        from collections import OrderedDict
+        self.t = OrderedDict()
+        self.pins = {}
+        self.cap = cap
+        self.touched = None                # a list while a capture records the keys it uses
+
+    def get(self, key, make):
+        t = self.t.get(key)
+        if t is None:
+            if len(self.t) >= self.cap:
+                for k in list(self.t):                     # oldest first
+                    if len(self.t) < self.cap:
+                        break
+                    if not self.pins.get(k):
+                        del self.t[k]
+            t = self.t[key] = make()
+        else:
+            self.t.move_to_end(key)
+        if self.touched is not None:
+            self.touched.append(key)
+        return t
+
+    def record(self):
+        self.touched = []
+
+    def pin_recorded(self):
+        keys, self.touched = list(dict.fromkeys(self.touched or [])), None
+        for k in keys:
+            self.pins[k] = self.pins.get(k, 0) + 1
+        return keys
+
+    def unpin(self, keys):
+        for k in keys or []:
+            n = self.pins.get(k, 0) - 1
+            if n > 0:
+                self.pins[k] = n
+            else:
+                self.pins.pop(k, None)
+
+    def __len__(self):
+        return len(self.t)
+
+
 def _ws_zeros(tag, shape, device):
     ws = WORKSPACE
     n = 1
@@ -66,13 +116,7 @@ def _ws_zeros(tag, shape, device):
         n *= d
     if ws is None or GRAD_MODE or n > (1 << 22):      # small shapes only (chunk / short-clip inference): there a fill launch
         return None                                   # costs as much as the kernel it feeds; big batches keep fresh tensors
-    key = (tag, tuple(shape), str(device))
-    t = ws.get(key)
-    if t is None:
-        if len(ws) > 12:
-            ws.clear()
-        t = ws[key] = torch.zeros(*shape, device=device, dtype=torch.float32)
-    return t
+    return ws.get((tag, tuple(shape), str(device)), lambda: torch.zeros(*shape, device=device, dtype=torch.float32))
 
 
 ZC = 32          # padded channel count of the front-end feature tensor
@@ -112,7 +156,7 @@ class IntraPlainFn(torch.autograd.Function):
             hs, _, gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, dirs, geom, save=train,
                                            lin=(lin_w.contiguous(), lin_b, part),
                                            want_hs=train and not ops.bi_hs_from_records(Cc),
-                                           no_gates=train and ops.GATE_RECOMPUTE, consume=ovl)
+                                           no_gates=train and ops.GATE_RECOMPUTE and ops.BPTT == "compact", consume=ovl)   # (compact-mode memory saver)
             y = part.view(B, T, F, 2, Cc) if defer_sum else ops.add3(x.view(P, Cc), part).view(B, T, F, Cc)
         else:
             assert not defer_sum
@@ -870,8 +914,12 @@ class MultiResoFuseLossFn(torch.autograd.Function):
             spec = torch.empty(2 * R * nfr, Npad, device=dev, dtype=torch.float32)
             ops.linear(xp, r["w"], None, spec, (2 * R, nfr, 1), (ldp, hop, 0), (nfr * Npad, Npad, 0), K, Npad, in_off=off)
             cnt = float(R * nfr * nbins)
-            dsx = ops.stft_mag_l1(spec[: R * nfr], spec[R * nfr:], R * nfr, nbins, Npad, cfg.eps,
-                                  cfg.w_lin_mag / (nres * cnt), loss, cfg.w_lin_mag / (nres * cnt), want_grad)
+            if cfg.w_sc or cfg.w_log_mag:     # auraloss's other two terms: two passes (the SC gradient needs the global norms)
+                dsx = ops.stft_mag_terms(spec[: R * nfr], spec[R * nfr:], R * nfr, nbins, Npad, cfg.eps, cfg.w_lin_mag,
+                                         cfg.w_log_mag, cfg.w_sc, 1.0 / nres, loss, want_grad)
+            else:
+                dsx = ops.stft_mag_l1(spec[: R * nfr], spec[R * nfr:], R * nfr, nbins, Npad, cfg.eps,
+                                      cfg.w_lin_mag / (nres * cnt), loss, cfg.w_lin_mag / (nres * cnt), want_grad)
             if want_grad:
                 dfr = torch.empty(R * nfr, K, device=dev, dtype=torch.float32)
                 gP, s_in = dense(R * nfr, Npad)

@@ -43,21 +43,37 @@ class MultiResoFuseLoss(nn.Module):
     """src/losses/MultiResoLoss.py:6-31: auraloss.freq.MultiResolutionSTFTLoss(**kwargs)(est, gt) + l1_ratio * L1(est, gt).
     JSON: "loss": "src.losses.MultiResoLoss.MultiResoFuseLoss" with loss_params {l1_ratio, sample_rate, perceptual_weighting,
     w_sc, w_log_mag, w_lin_mag} (syn_experiments/finetune_stage.json:34-41, real_experiments/*_finetune.json).
-    Built: the linear-magnitude term (w_lin_mag) with optional perceptual weighting -- what every shipped fine-tune JSON
-    selects (w_sc = w_log_mag = 0); the other auraloss terms raise.  forward(est, gt) -> scalar, as the reference's."""
+    Built: all three magnitude terms of auraloss's STFTLoss -- spectral convergence (w_sc), log-magnitude L1 (w_log_mag),
+    linear-magnitude L1 (w_lin_mag) -- with optional perceptual (A-) weighting, so the constructor works with the reference's
+    own defaults (`MultiResoFuseLoss()` = w_sc = w_log_mag = 1, MultiResoLoss.py:12 forwards **kwargs) as well as with every
+    shipped fine-tune JSON (w_sc = w_log_mag = 0, w_lin_mag = 20).  Not built, and raising: the phase term (w_phs), mel /
+    chroma scaling (scale), scale invariance, windows other than hann, and any auraloss option this class does not know --
+    a config must never train on a silently different loss.  forward(est, gt) -> scalar, as the reference's."""
+
+    # auraloss options that are accepted when (and only when) they keep their default, i.e. change nothing
+    _NOOP_DEFAULTS = {"reduction": "mean", "mag_distance": "L1", "output": "loss", "device": None, "n_bins": None}
 
     def __init__(self, l1_ratio=0, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240),
                  window="hann_window", w_sc=1.0, w_log_mag=1.0, w_lin_mag=0.0, w_phs=0.0, sample_rate=None, scale=None,
                  n_bins=None, perceptual_weighting=False, scale_invariance=False, eps=1e-8, **kwargs):
         super().__init__()
-        if w_sc or w_log_mag or w_phs or scale is not None or scale_invariance or window != "hann_window":
-            raise NotImplementedError("MultiResoFuseLoss: only the linear-magnitude term with a hann window is built "
-                                      "(w_sc = w_log_mag = w_phs = 0, scale = None: every shipped fine-tune config)")
+        if w_phs or scale is not None or scale_invariance or window != "hann_window":
+            raise NotImplementedError("MultiResoFuseLoss: the phase term (w_phs), mel / chroma scaling (scale), "
+                                      "scale_invariance and windows other than hann_window are not built")
+        kwargs = dict(kwargs, n_bins=n_bins)
+        for k, v in kwargs.items():
+            if k not in self._NOOP_DEFAULTS:
+                raise TypeError(f"MultiResoFuseLoss: unknown option {k!r} (not an auraloss.freq.MultiResolutionSTFTLoss "
+                                f"argument this implementation knows)")
+            if v != self._NOOP_DEFAULTS[k] and not (k == "device" and v is not None):
+                raise NotImplementedError(f"MultiResoFuseLoss: {k}={v!r} is not built (only the auraloss default "
+                                          f"{self._NOOP_DEFAULTS[k]!r})")
         if not (len(fft_sizes) == len(hop_sizes) == len(win_lengths)):
             raise ValueError("fft_sizes, hop_sizes and win_lengths must have the same length")
         if perceptual_weighting and sample_rate is None:
             raise ValueError("perceptual_weighting needs sample_rate")
         self.l1_ratio, self.w_lin_mag, self.eps = float(l1_ratio), float(w_lin_mag), float(eps)
+        self.w_sc, self.w_log_mag = float(w_sc), float(w_log_mag)
         if perceptual_weighting:
             taps = torch.from_numpy(_aweight_fir_taps(sample_rate))
             self.register_buffer("taps", taps, persistent=False)

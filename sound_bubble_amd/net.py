@@ -244,7 +244,7 @@ class _NetBase(nn.Module):
         tg = self.tfgridnet
         st = input_state
         Fn.GRAD_MODE = torch.is_grad_enabled()      # BPTT records are written only when a backward pass can follow
-        Fn.WORKSPACE = None if (Fn.GRAD_MODE or not Fn.INFER_WORKSPACE) else self.__dict__.setdefault("_ws", {})      # inference: persistent zero-bordered staging
+        Fn.WORKSPACE = None if (Fn.GRAD_MODE or not Fn.INFER_WORKSPACE) else self.__dict__.setdefault("_ws", Fn.Workspaces())      # inference: persistent zero-bordered staging
         e = self._embed(inputs.get("dis_embed"))
         wf = self._weight_forms().refresh()
         ln = tg.conv[1] if self.use_first_ln else None

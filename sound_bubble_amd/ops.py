@@ -1306,6 +1306,19 @@ def stft_mag_l1(spec_x, spec_y, rows, nbins, ld, eps, gscale, loss, loss_scale, 
     return dsx
 
 
+def stft_mag_terms(spec_x, spec_y, rows, nbins, ld, eps, w_lin, w_log, w_sc, scale, loss, want_grad):
+    """all three auraloss STFT terms of one resolution: loss[0] += scale * (w_lin L1 + w_log log-L1 + w_sc SC);
+    -> d(that) / d spec_x or None"""
+    lib = L.load()
+    dev = spec_x.device
+    dsx = torch.empty(rows, ld, device=dev, dtype=torch.float32) if want_grad else None
+    part = torch.empty(4 * lib.sb_stft_mag_l1_grid(rows, ld), device=dev, dtype=torch.float32)
+    sums = torch.empty(4, device=dev, dtype=torch.float32)
+    L.check(lib.sb_stft_mag_terms(_p(spec_x), _p(spec_y), rows, nbins, ld, eps, w_lin, w_log, w_sc, scale, _p(dsx), _p(part),
+                                  _p(sums), _p(loss), _stream()), "sb_stft_mag_terms")
+    return dsx
+
+
 def frames_fold(dframes, dx, nframes, K, ldk, hop, off, pad, accumulate):
     B_, N = dx.shape
     L.check(L.load().sb_frames_fold(_p(dframes), _p(dx), B_, N, nframes, K, ldk, hop, off, pad, 1 if accumulate else 0,

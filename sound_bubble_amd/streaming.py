@@ -57,9 +57,30 @@ def _clone_tree(d):
     return {k: _clone_tree(v) if isinstance(v, dict) else v for k, v in d.items()}
 
 
+# Parameters REPLACED on any module (`module.weight = nn.Parameter(...)`, `load_state_dict(assign=True)` on a sub-module) go
+# through nn.Module.register_parameter: a global registration hook counts them, so that a graphed separator notices on its
+# very next feed (one integer compare per chunk) that the addresses its graph was captured with may be gone.
+_PARAM_REGISTRATIONS = [0]
+
+
+def _count_registration(module, name, param):
+    _PARAM_REGISTRATIONS[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_registration)
+
+
 class StreamingSeparator(torch.nn.Module):
+    """A captured hipGraph replays against fixed ADDRESSES: the parameters, the state buffers and the per-model inference
+    workspaces of the capture.  The separator therefore (i) pins the workspaces its capture used (they are never evicted or
+    re-zeroed while the graph lives: functional.Workspaces), (ii) re-captures when a parameter object was replaced -- noticed
+    on the next feed through the registration counter above and the model's load_state_dict hook -- and (iii) offers
+    `invalidate()` for the one case nothing can observe: re-pointing `p.data` of an existing parameter (FlatBucket does that;
+    build the separator afterwards, or call invalidate())."""
+
     def __init__(self, model, batch_size=1, dis_embed=None, use_graph=True):
         super().__init__()
+        import weakref
         self.model = model.eval()
         dev = next(model.parameters()).device
         self.chunk, self.pad = model.stft_chunk_size, model.stft_pad_size
@@ -69,9 +90,36 @@ class StreamingSeparator(torch.nn.Module):
         self.out = None
         self.graph = None
         self._param_key = None
-        self._feeds, self._dirty = 0, False
+        self._dirty = False
+        self._seen_registrations = -1
+        self._pinned = None                                       # (Workspaces, keys) held by the captured graph
         self.use_graph = use_graph
-        model.register_load_state_dict_post_hook(lambda *_: setattr(self, "_dirty", True))
+        me = weakref.ref(self)                                    # the hook must not keep the separator (and its graph) alive
+
+        def _mark(*_):
+            s = me()
+            if s is not None:
+                s._dirty = True
+        self._hook = model.register_load_state_dict_post_hook(_mark)
+
+    def invalidate(self):
+        """the next feed re-captures the graph (call after re-pointing `p.data` of a parameter of the model)"""
+        self._dirty = True
+        self._param_key = None
+
+    def _release(self):
+        if self._pinned is not None:
+            ws, keys = self._pinned
+            ws.unpin(keys)
+            self._pinned = None
+        self.graph = None
+
+    def __del__(self):
+        try:
+            self._release()
+            self._hook.remove()
+        except Exception:
+            pass
 
     def _inputs(self):
         d = {"mixture": self.frame}
@@ -98,8 +146,12 @@ class StreamingSeparator(torch.nn.Module):
         return out
 
     def _capture(self):
+        from . import functional as Fn
+        self._release()
         static = flatten_state(self.state)
         snap = {k: v.clone() for k, v in static.items()}
+        ws = self.model.__dict__.setdefault("_ws", Fn.Workspaces())
+        ws.record()                                                # every workspace the chunk step touches from here on ...
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():                # warm-up off-graph (allocator, lazy init)
@@ -111,6 +163,7 @@ class StreamingSeparator(torch.nn.Module):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = self._step_inplace()
+        self._pinned = (ws, ws.pin_recorded())                     # ... stays allocated for as long as this graph lives
         for k, v in static.items():
             v.copy_(snap[k])
 
@@ -122,10 +175,10 @@ class StreamingSeparator(torch.nn.Module):
             return self._step_inplace()
         # the graph holds the addresses of the parameters: re-capture when one was replaced (load_state_dict(assign=True),
         # module.weight = ...); in-place updates need nothing -- the weight-form refresh is one of the captured launches.
-        # Walking all parameters costs ~50 us of Python, a sixth of a chunk: done after every load_state_dict (hook) and
-        # every 256th feed, not per chunk.
-        self._feeds += 1
-        if self.graph is None or self._dirty or (self._feeds & 255) == 0:
+        # Walking all parameters costs ~50 us of Python, a sixth of a chunk: done only when a parameter was registered
+        # somewhere since the last look (one integer compare per chunk) or a load_state_dict ran on the model.
+        if self.graph is None or self._dirty or self._seen_registrations != _PARAM_REGISTRATIONS[0]:
+            self._seen_registrations = _PARAM_REGISTRATIONS[0]
             key = tuple((id(p), p.data_ptr()) for p in self.model.parameters())
             if self.graph is None or key != self._param_key:
                 self._capture()

@@ -6,9 +6,10 @@ dotted path in the experiment JSON, `hl_module:22-113`, and the loss classes nex
 implementation, so FakeTensor propagation, `torch.compile(fullgraph=True)` and `torch.export` trace through the
 separator as ONE opaque node per call:
 
-  sound_bubble::separate(mixture, dis_embed?, params[], state[], model, pad, train) -> Tensor[]
+  sound_bubble::separate(mixture, dis_embed?, params[], state[], model, pad, train, grad_bucket?) -> Tensor[]
         [output, *next_state (streaming.flatten_state order), handle] -- `Net.forward` (net.py:70-93 of both reference
-        families).  backward: sound_bubble::separate_backward(handle, d_output, model) -> Tensor[] (one gradient per
+        families).  backward: sound_bubble::separate_backward(handle, d_output, model) -> Tensor[] /
+        sound_bubble::separate_backward_bucket(handle, d_output, model, grad_bucket(mutated)) -> Tensor (one gradient per
         entry of params[]; an EMPTY tensor where the HIP reductions have already accumulated into the parameter's flat
         gradient buffer -- train.FlatBucket -- or the parameter takes none).
   sound_bubble::snrlp_loss(est, gt, neg_weight) -> (loss, loss_vec, d_est)          -- SNRLP.py:17-42
@@ -99,7 +100,9 @@ def _out_len(m, n, pad):
 
 @torch.library.custom_op("sound_bubble::separate", mutates_args=(), device_types="cuda")
 def separate(mixture: Tensor, dis_embed: Optional[Tensor], params: List[Tensor], state: List[Tensor], model: int,
-             pad: bool, train: bool) -> List[Tensor]:
+             pad: bool, train: bool, grad_bucket: Optional[Tensor] = None) -> List[Tensor]:
+    # grad_bucket (flat_grad_bucket(model) or None): not touched here -- carried to separate_backward, which adds the flat-
+    # bucket parameters' gradients into it and declares so; an operator INPUT so that a tracing compiler sees it as a graph input
     m = _model(model)
     own = list(m.parameters())
     if len(params) != len(own) or any(a.shape != b.shape for a, b in zip(params, own)):
@@ -134,11 +137,14 @@ def separate(mixture: Tensor, dis_embed: Optional[Tensor], params: List[Tensor],
         h = _NEXT[0]
         _NEXT[0] += 1
         handle[0] = h
+        # a forward whose backward never runs (an exception, a dropped loss) keeps its autograd graph -- BPTT records and
+        # all -- parked here: at most MAX_PENDING of them, and the next one RAISES instead of silently dropping the oldest
+        # (whose backward would then fail far from the cause); drop_pending() releases them deliberately
+        if len(_PENDING) >= MAX_PENDING:
+            raise RuntimeError(f"sound_bubble::separate: {len(_PENDING)} recorded forwards are waiting for their backward "
+                               f"(MAX_PENDING = {MAX_PENDING}): run or drop them (torch_ops.drop_pending()), or call with "
+                               f"train=False / under torch.no_grad() when no backward will follow")
         _PENDING[h] = (out, own)
-        # a forward whose backward never runs (an exception, a dropped loss) must not keep its graph alive for ever: at most
-        # MAX_PENDING recorded forwards wait for their backward, the oldest is dropped (its backward then raises)
-        while len(_PENDING) > MAX_PENDING:
-            _PENDING.pop(next(iter(_PENDING)))
     # outputs may not alias inputs: buffers the forward passed through untouched are copied
     ins = {t.data_ptr() for t in state}
     # (the cropped output of a padded call is a view: operators return dense tensors)
@@ -146,7 +152,7 @@ def separate(mixture: Tensor, dis_embed: Optional[Tensor], params: List[Tensor],
 
 
 @separate.register_fake
-def _(mixture, dis_embed, params, state, model, pad, train):
+def _(mixture, dis_embed, params, state, model, pad, train, grad_bucket=None):
     m = _model(model)
     B = mixture.shape[0]
     shapes = flatten_state(m._make_buffers(B, lambda *s: tuple(s)))
@@ -155,12 +161,62 @@ def _(mixture, dis_embed, params, state, model, pad, train):
         [torch.empty(1, dtype=torch.int64, device="cpu")]
 
 
-@torch.library.custom_op("sound_bubble::separate_backward", mutates_args=(), device_types="cuda")
-def separate_backward(handle: Tensor, d_output: Tensor, model: int) -> List[Tensor]:
+def drop_pending():
+    """release every recorded forward that is still waiting for its backward (their graphs and BPTT records); -> how many"""
+    n = len(_PENDING)
+    _PENDING.clear()
+    return n
+
+
+def flat_grad_bucket(model):
+    """the ONE flat gradient buffer train.FlatBucket pointed the parameters' .grad views into (None without a bucket):
+    what separate_backward declares as mutated"""
+    base = None
+    for p in model.parameters():
+        g = Fn.direct_grad_target(p)
+        if g is None:
+            continue
+        b = g._base if g._base is not None else g
+        if base is None:
+            base = b
+        elif b.untyped_storage().data_ptr() != base.untyped_storage().data_ptr():
+            raise RuntimeError("sound_bubble::separate_backward: the parameters' gradient views live in more than one flat "
+                               "buffer; build ONE train.FlatBucket per model")
+    return base
+
+
+def _run_backward(handle, d_output, model, grad_bucket):
     ent = _PENDING.pop(int(handle), None)
     if ent is None:
         raise RuntimeError("sound_bubble::separate_backward: this forward recorded no graph (train=False / no parameter "
-                           "requires grad) or its backward has already run")
+                           "requires grad), its backward has already run, or it was dropped (torch_ops.drop_pending)")
+    have = flat_grad_bucket(_model(model))
+    if (have is None) != (grad_bucket is None) or (have is not None and (grad_bucket.numel() != have.numel() or
+                                                                         grad_bucket.dtype != have.dtype or not grad_bucket.is_contiguous())):
+        _PENDING[int(handle)] = ent
+        raise RuntimeError("sound_bubble::separate_backward: grad_bucket must be (a tensor standing in for) "
+                           "torch_ops.flat_grad_bucket(model) -- the buffer the flat-bucket parameters' gradients are added "
+                           "into (separate_backward_bucket); the plain separate_backward is for models WITHOUT a train.FlatBucket")
+    # The gradients go into the tensor that was PASSED: under a functionalising compiler that is a copy of the bucket (the
+    # declared mutation is replayed onto the real one afterwards), so the parameters' .grad views are re-pointed into it for
+    # the duration of the call -- same offsets; the identity when the real bucket was passed.
+    repoint = []
+    if have is not None and grad_bucket.data_ptr() != have.data_ptr():
+        flat = grad_bucket.view(-1)
+        for p in _model(model).parameters():
+            g = Fn.direct_grad_target(p)
+            if g is not None:
+                off = g.storage_offset() - have.storage_offset()
+                repoint.append((p, g))
+                p.grad = flat[off:off + g.numel()].view(g.shape)
+    try:
+        return _backward_into(ent, d_output)
+    finally:
+        for p, g in repoint:
+            p.grad = g
+
+
+def _backward_into(ent, d_output):
     root, own = ent
     need = [p for p in own if p.requires_grad]
     with _record_autograd():
@@ -191,6 +247,35 @@ def separate_backward(handle: Tensor, d_output: Tensor, model: int) -> List[Tens
     return outs
 
 
+# Two backward operators, because a functionalising compiler only takes a MUTATING custom operator whose results are plain
+# tensors (torch/_higher_order_ops/auto_functionalize.py: no Tensor[] returns):
+#   separate_backward(handle, d_output, model) -> Tensor[]: one gradient per parameter, nothing mutated -- for a model whose
+#       parameters own no flat gradient bucket;
+#   separate_backward_bucket(handle, d_output, model, grad_bucket) -> Tensor: for a model under train.FlatBucket.  The HIP
+#       weight-gradient reductions ADD into the per-parameter views of grad_bucket (= flat_grad_bucket(model)) while the
+#       backward runs: declared (mutates_args), so the write is visible to the compiler, which may neither reorder the call
+#       against readers of the bucket (the all-reduce, the optimiser) nor dedupe it.  Returns the number of parameters served.
+@torch.library.custom_op("sound_bubble::separate_backward", mutates_args=(), device_types="cuda")
+def separate_backward(handle: Tensor, d_output: Tensor, model: int) -> List[Tensor]:
+    return _run_backward(handle, d_output, model, None)
+
+
+@torch.library.custom_op("sound_bubble::separate_backward_bucket", mutates_args=("grad_bucket",), device_types="cuda")
+def separate_backward_bucket(handle: Tensor, d_output: Tensor, model: int, grad_bucket: Tensor) -> Tensor:
+    m = _model(model)
+    stray = [n for n, p in m.named_parameters() if p.requires_grad and Fn.direct_grad_target(p) is None]
+    if stray:
+        raise RuntimeError(f"sound_bubble::separate_backward_bucket: parameters outside the flat gradient bucket require "
+                           f"gradients ({stray[:3]} ...): put every trainable parameter into the train.FlatBucket")
+    outs = _run_backward(handle, d_output, model, grad_bucket)
+    return torch.full((1,), len(outs), dtype=torch.int64)
+
+
+@separate_backward_bucket.register_fake
+def _(handle, d_output, model, grad_bucket):
+    return torch.empty(1, dtype=torch.int64, device="cpu")
+
+
 def _grad_in_place(p):
     """the rule both the implementation and its fake follow: no gradient tensor is returned for a frozen parameter or one
     whose gradient lives in train.FlatBucket's flat buffer (accumulated there, as .backward() would)"""
@@ -207,17 +292,24 @@ def _separate_setup(ctx, inputs, output):
     ctx.handle = output[-1]
     ctx.n_state = len(inputs[3])
     ctx.n_params = len(inputs[2])
+    ctx.save_for_backward(inputs[7] if len(inputs) > 7 else None)
     ctx.set_materialize_grads(False)
 
 
 def _separate_bwd(ctx, grads):
+    # (a trailing argument left at its default -- grad_bucket = None -- is not among the inputs autograd shows here)
+    n_in = len(ctx.needs_input_grad)
     d_out = grads[0]
     if d_out is None:
-        return None, None, [None] * ctx.n_params, [None] * ctx.n_state, None, None, None
+        return (None, None, [None] * ctx.n_params, [None] * ctx.n_state, None, None, None, None)[:n_in]
+    (bucket,) = ctx.saved_tensors
+    if bucket is not None:        # every gradient lands in the flat bucket (declared mutated): nothing comes back through autograd
+        torch.ops.sound_bubble.separate_backward_bucket(ctx.handle, d_out, ctx.model, bucket)
+        return (None, None, [None] * ctx.n_params, [None] * ctx.n_state, None, None, None, None)[:n_in]
     gs = torch.ops.sound_bubble.separate_backward(ctx.handle, d_out, ctx.model)
     # the state entries are carried values (net.py:88-93: detached between chunks in the reference's streaming use): no
     # gradient flows into them, and none into the waveform
-    return None, None, [g if g.numel() else None for g in gs], [None] * ctx.n_state, None, None, None
+    return (None, None, [g if g.numel() else None for g in gs], [None] * ctx.n_state, None, None, None, None)[:n_in]
 
 
 separate.register_autograd(_separate_bwd, setup_context=_separate_setup)
@@ -297,7 +389,8 @@ class _SeparateModule(torch.nn.Module):
         B = inputs["mixture"].shape[0]
         state = list(flatten_state(input_state).values()) if input_state is not None else []
         outs = torch.ops.sound_bubble.separate(inputs["mixture"], inputs.get("dis_embed"), list(m.parameters()), state,
-                                               self.model_id, pad, torch.is_grad_enabled())
+                                               self.model_id, pad, torch.is_grad_enabled(),
+                                               flat_grad_bucket(m) if torch.is_grad_enabled() else None)
         names = _state_names(m, B)
         nxt = {}
         for name, buf in zip(names, outs[1:-1]):

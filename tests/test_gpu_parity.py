@@ -1118,6 +1118,57 @@ def test_weight_forms_follow_in_place_and_replaced_parameters(torch_gpu):
     assert rel_l2(z.cpu().numpy(), want.cpu().numpy()) < 1e-6
 
 
+def test_graphed_streaming_survives_workspace_churn_and_parameter_replacement(torch_gpu):
+    """the captured chunk graph holds the addresses of the model's inference workspaces (zp / yp / rows).
+    Twenty no_grad forwards of the SAME model at twenty clip lengths between two feeds used to empty that cache (more than 12
+    keys -> clear()), and the next replay wrote into freed blocks.  The workspaces a graph was captured with are pinned now.
+    ... and a parameter replaced on a sub-module is noticed on the NEXT feed, not on the 256th."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.streaming import StreamingSeparator
+    rec, params, m = _build(torch, "tiny_small", "NetOptim")
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    frames = (0.1 * torch.randn(6, 1, 6, 288, generator=g)).cuda()
+
+    def eager(model, fr):
+        st = model.init_buffers(1, "cuda")
+        outs = []
+        with torch.no_grad():
+            for f in fr:
+                o = model({"mixture": f}, st, pad=False)
+                st = o["next_state"]
+                outs.append(o["output"].clone())
+        return torch.cat(outs, -1)
+
+    ref = sb.NetOptim(**params)
+    ref.load_state_dict(m.state_dict())
+    ref = ref.cuda().eval()
+    want = eager(ref, frames)
+    sep = StreamingSeparator(m, 1, use_graph=True)
+    got = [sep.feed(frames[i]).clone() for i in range(3)]
+    pinned = set(sep._pinned[1])
+    assert pinned and all(k in m._ws.t for k in pinned)
+    with torch.no_grad():                                        # churn: 20 other shapes through the same model's workspaces
+        for k in range(20):
+            m({"mixture": (0.1 * torch.randn(1, 6, 192 * (3 + k), generator=g)).cuda()})
+    assert len(m._ws) <= m._ws.cap + len(pinned) and all(k in m._ws.t for k in pinned)
+    poison_free_memory(torch, 1)                                 # anything that WAS freed now holds NaN
+    got += [sep.feed(frames[i]).clone() for i in range(3, 6)]
+    assert rel_l2(torch.cat(got, -1).cpu().numpy(), want.cpu().numpy()) < 1e-6
+    # a replaced Parameter on a sub-module: re-captured before the very next replay
+    tg = m.tfgridnet
+    tg.blocks[0].inter_linear.weight = torch.nn.Parameter(tg.blocks[0].inter_linear.weight.detach().clone() * 0.5)
+    ref.load_state_dict(m.state_dict())
+    sep.reset()
+    z = sep.feed(frames[0]).clone()
+    assert rel_l2(z.cpu().numpy(), eager(ref, frames[:1]).cpu().numpy()) < 1e-6
+    del sep
+    import gc
+    gc.collect()
+    assert not m._ws.pins                                        # the graph's pins die with the separator
+
+
 def test_side_stream_management_api(torch_gpu):
     """sb_overlap_init / _reprobe / _available / _shutdown (include/sound_bubble_hip.h): explicit, per (device, stream)
     entries, caller-owned scratch, stored verdicts, bad arguments by status code."""

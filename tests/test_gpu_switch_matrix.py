@@ -49,6 +49,7 @@ SWITCHES = [
     ("no-stream-lin-wgrad", {"SB_NO_STREAM_LIN_WGRAD": "1"}, WIDE),
     ("no-intra-lin-fusion", {"SB_NO_INTRA_LIN_FUSION": "1"}, WIDE),
     ("gate-recompute-compact", {"SB_BPTT": "compact", "SB_GATE_RECOMPUTE": "1"}, COMPACT),
+    ("gate-recompute-wide", {"SB_GATE_RECOMPUTE": "1"}, WIDE),     # the compact-mode memory saver must not touch the wide path
     ("bwd-pair-serial", {"SB_BWD_PAIR_SERIAL": "1"}, WIDE),
     ("no-vec-lstm", {"SB_NO_VEC_LSTM": "1"}, WIDE),
     ("no-infer-workspace", {"SB_NO_INFER_WORKSPACE": "1"}, WIDE),

@@ -97,6 +97,46 @@ def test_operator_gradients_equal_the_module_and_the_goldens(name, cls, bucket):
         assert e < 2e-4, (k, e)
 
 
+def test_parked_forwards_raise_at_the_limit_and_backward_declares_its_bucket():
+    """a ninth recorded forward without a backward RAISES (it used to drop the oldest graph silently);
+    drop_pending() releases them; the backward operator takes the flat gradient bucket it adds into as a declared-mutated
+    argument and refuses any other buffer."""
+    import torch
+    from sound_bubble_amd import torch_ops as T
+    from sound_bubble_amd.train import FlatBucket
+    rec, m, inp = _build(torch, "tiny_small", "NetOptim")
+    m.train()
+    fb = FlatBucket(m)
+    mid = T.register_model(m)
+    T.drop_pending()
+    args = (inp["mixture"], None, list(m.parameters()), [], mid, True, True, T.flat_grad_bucket(m))
+    assert T.flat_grad_bucket(m).data_ptr() == fb.grad.data_ptr()
+    outs = [torch.ops.sound_bubble.separate(*args) for _ in range(T.MAX_PENDING)]
+    with pytest.raises(RuntimeError, match="waiting for their backward"):
+        torch.ops.sound_bubble.separate(*args)
+    assert len(T._PENDING) == T.MAX_PENDING
+    o = outs[0]
+    d = torch.ones_like(o[0])
+    with pytest.raises(RuntimeError, match="grad_bucket"):
+        torch.ops.sound_bubble.separate_backward_bucket(o[-1], d, mid, torch.zeros(16, device="cuda"))   # not a bucket of this model
+    with pytest.raises(RuntimeError, match="grad_bucket"):
+        torch.ops.sound_bubble.separate_backward(o[-1], d, mid)                                         # the bucket-free operator
+    fb.zero_grad()
+    n = torch.ops.sound_bubble.separate_backward_bucket(o[-1], d, mid, fb.grad)
+    assert int(n) == len(list(m.parameters())) and float(fb.grad.abs().max()) > 0               # gradients landed in the bucket
+    # the operator writes into the tensor it was HANDED (what a functionalising compiler relies on: it passes a copy and
+    # replays the declared mutation): a stand-in buffer receives the gradients, the model's own bucket stays as it was
+    stand_in, before = torch.zeros_like(fb.grad), fb.grad.clone()
+    torch.ops.sound_bubble.separate_backward_bucket(outs[2][-1], d, mid, stand_in)
+    assert torch.equal(fb.grad, before) and rel_l2(stand_in.cpu().numpy(), before.cpu().numpy()) < 1e-5
+    assert all(p.grad.data_ptr() >= fb.grad.data_ptr() for p in m.parameters())                 # .grad views restored
+    assert T.drop_pending() == T.MAX_PENDING - 2 and not T._PENDING
+    with pytest.raises(RuntimeError, match="dropped"):
+        torch.ops.sound_bubble.separate_backward_bucket(outs[1][-1], d, mid, fb.grad)
+    s = str(torch.ops.sound_bubble.separate_backward_bucket.default._schema)
+    assert "!) grad_bucket" in s, s
+
+
 def test_opcheck():
     import torch
     from sound_bubble_amd import torch_ops as T
@@ -139,6 +179,33 @@ def test_loss_operators_match_the_modules():
         (3.0 * lb).backward()
         assert abs(float(la.detach()) - float(lb.detach())) <= 1e-6 * abs(float(lb.detach()))
         assert rel_l2(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-6
+
+
+def test_train_step_with_flat_bucket_traces_under_torch_compile():
+    """... and with the parameters under train.FlatBucket: the backward operator that ADDS into the bucket is declared
+    mutating, auto-functionalised by AOT autograd, and the compiled step leaves the same gradients in the bucket"""
+    import torch
+    from sound_bubble_amd import torch_ops as T
+    from sound_bubble_amd.train import FlatBucket
+    rec, m, inp = _build(torch, "tiny_small", "NetOptim")
+    m.train()
+    fb = FlatBucket(m)
+    mid = T.register_model(m)
+    tgt = torch.from_numpy(rec["target"]).cuda()
+    params = list(m.parameters())
+
+    def step(mix, tgt, params, bucket):
+        outs = torch.ops.sound_bubble.separate(mix, None, params, [], mid, True, True, bucket)
+        return torch.ops.sound_bubble.snrlp_loss(outs[0], tgt, 100.0)[0]
+
+    fb.zero_grad()
+    step(inp["mixture"], tgt, params, fb.grad).backward()
+    want = fb.grad.clone()
+    fb.zero_grad()
+    cstep = torch.compile(step, fullgraph=True, backend="aot_eager")
+    cstep(inp["mixture"], tgt, params, fb.grad).backward()
+    assert float(want.abs().max()) > 0 and rel_l2(fb.grad.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    assert not T._PENDING
 
 
 def test_train_step_traces_whole_under_torch_compile():

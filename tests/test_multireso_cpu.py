@@ -82,12 +82,40 @@ def test_loss_properties(torch_mod):
     assert abs(full - (float(mrstft_loss(est, gt, **kw)) + 10 * float((est - gt).abs().mean()))) < 1e-12
 
 
-def test_unbuilt_terms_fail_loudly():
+def test_constructor_surface_matches_what_the_reference_can_pass():
+    """MultiResoLoss.py:12 forwards **kwargs to auraloss.freq.MultiResolutionSTFTLoss: the no-argument default (w_sc =
+    w_log_mag = 1) and any weighting of the three magnitude terms construct; what is not built raises, and so does an option
+    this class does not know -- never a silently different loss."""
     from sound_bubble_amd.losses import MultiResoFuseLoss
-    with pytest.raises(NotImplementedError):
-        MultiResoFuseLoss(l1_ratio=1, sample_rate=24000)                      # auraloss defaults: w_sc = w_log_mag = 1
+    m = MultiResoFuseLoss()                                                   # the reference's own defaults
+    assert (m.w_sc, m.w_log_mag, m.w_lin_mag, m.l1_ratio) == (1.0, 1.0, 0.0, 0.0)
+    m = MultiResoFuseLoss(l1_ratio=1, sample_rate=24000, w_sc=0.5, w_log_mag=2, w_lin_mag=3, reduction="mean", output="loss")
+    assert (m.w_sc, m.w_log_mag, m.w_lin_mag) == (0.5, 2.0, 3.0)
     with pytest.raises(ValueError):
         MultiResoFuseLoss(w_sc=0, w_log_mag=0, w_lin_mag=1, perceptual_weighting=True)      # no sample_rate
+    for bad in (dict(w_phs=1.0), dict(scale="mel", n_bins=64), dict(scale_invariance=True), dict(window="hamming_window"),
+                dict(reduction="sum"), dict(mag_distance="L2"), dict(output="full")):
+        with pytest.raises(NotImplementedError):
+            MultiResoFuseLoss(**bad)
+    with pytest.raises(TypeError):
+        MultiResoFuseLoss(w_lin_magnitude=1.0)                                # a typo must not be swallowed
+
+
+def test_oracle_terms_are_what_auraloss_documents(torch_mod):
+    """the spectral-convergence and log-magnitude terms of the oracle against their definitions written out in numpy"""
+    torch = torch_mod
+    from oracle.multireso_oracle import mrstft_loss, stft_mag, FFT_SIZES, HOP_SIZES, WIN_LENGTHS
+    torch.manual_seed(0)
+    gt = 0.05 * torch.randn(2, 1, 6000, dtype=torch.float64)
+    est = gt + 0.03 * torch.randn(2, 1, 6000, dtype=torch.float64)
+    want_sc = want_log = 0.0
+    for n_fft, hop, wl in zip(FFT_SIZES, HOP_SIZES, WIN_LENGTHS):
+        xm, ym = stft_mag(est.reshape(2, -1), n_fft, hop, wl).numpy(), stft_mag(gt.reshape(2, -1), n_fft, hop, wl).numpy()
+        want_sc += np.sqrt(((ym - xm) ** 2).sum()) / np.sqrt((ym ** 2).sum())
+        want_log += np.abs(np.log(xm) - np.log(ym)).mean()
+    assert abs(float(mrstft_loss(est, gt, w_sc=1, w_log_mag=0, w_lin_mag=0)) - want_sc / 3) < 1e-12
+    assert abs(float(mrstft_loss(est, gt, w_sc=0, w_log_mag=1, w_lin_mag=0)) - want_log / 3) < 1e-12
+    assert abs(float(mrstft_loss(est, gt)) - (want_sc + want_log) / 3) < 1e-12          # the auraloss defaults
 
 
 def test_every_shipped_experiment_json_constructs(torch_mod, tmp_path):

@@ -60,6 +60,11 @@ def test_schemas_and_gpu_only_registration(torch_mod):
     m = sb.NetOptim(**params)
     with pytest.raises((NotImplementedError, RuntimeError)):
         T.separate_module(m)({"mixture": torch.zeros(1, 6, 960)})
+    # the backward operator declares the flat gradient bucket it adds into
+    sb_ = str(torch.ops.sound_bubble.separate_backward_bucket.default._schema)
+    assert "!) grad_bucket" in sb_ and sb_.endswith("-> Tensor"), sb_
+    from torch._higher_order_ops.auto_functionalize import can_auto_functionalize
+    assert can_auto_functionalize(torch.ops.sound_bubble.separate_backward_bucket.default)     # a compiler can take the mutation
     # unknown model id
     with pytest.raises(RuntimeError):
         T._model(10 ** 9)
