@@ -168,6 +168,74 @@ def cpu_baseline(torch, wl, budget_s=36.0):
             "legs": legs}
 
 
+def cpu_stream_leg(torch, wl="small", n_chunks=625, budget_s=14.0):
+    """BASELINE.md section 4, last bullet: the CPU side of configs[4] -- the oracle (CPU port of the reference's algorithm)
+    fed 8 ms chunks [1, 6, 288] with carried state, as edge/causal_infer.py:15-26 does; chunks/s and p50 per chunk on the
+    host cores, bounded (all 625 chunks of a 5 s clip when they fit the budget)."""
+    import numpy as np
+    from oracle.tfgridnet_oracle import OracleNet
+    cls, params = WORKLOADS[wl][:2]
+    torch.manual_seed(0)
+    m = OracleNet("optim" if cls == "NetOptim" else "dis_embd3", **params).eval()
+    g = torch.Generator().manual_seed(1234)
+    frames = 0.1 * torch.randn(n_chunks, 1, 6, 288, generator=g)
+    dis = None if cls == "NetOptim" else torch.tensor([[0.0, 1.0, 0.0]])
+    state = m.init_buffers(1, "cpu")
+    lat = []
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n_chunks):
+            inp = {"mixture": frames[i]}
+            if dis is not None:
+                inp["dis_embed"] = dis
+            t1 = time.perf_counter()
+            state = m(inp, state, pad=False)["next_state"]
+            lat.append(time.perf_counter() - t1)
+            if time.perf_counter() - t_start > budget_s and i >= 20:
+                break
+    lat = np.array(lat[5:]) * 1e3                              # the first chunks carry allocator / thread-pool warm-up
+    return {"chunks_s": 1e3 / float(lat.mean()), "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+            "chunks": int(len(lat)), "realtime_factor": 8.0 / float(np.percentile(lat, 50)),
+            "sample": f"{len(lat)} chunks of [1, 6, 288] ({wl} config) through the oracle CPU port with carried state, "
+                      f"{torch.get_num_threads()} threads, after 5 warm-up chunks"}
+
+
+def parity_check(torch, sb, dev):
+    """`parity` object of the headline (BASELINE.json metric: "...; SI-SDRi vs ref"): ONE committed scene -- the reference's
+    test_samples/syn_1m/00001 at its full 5 s -- through the 6-block 0.5 M network of pretrain_stage.json with the weights of
+    tests/golden/samples_6block.npz, against the output the REFERENCE model produced for it (same fixture, generated by
+    tests/golden/make_goldens.py from the imported reference).  Runs outside the timed region; no oracle involved."""
+    import ast
+    import numpy as np
+    from sound_bubble_amd.eval_samples import load_testcase, run_testcase, si_sdr_np
+    gold = os.path.join(ROOT, "tests", "golden")
+    path = os.path.join(gold, "samples_6block.npz")
+    scene = os.path.join(gold, "test_samples_full", "syn_1m", "00001")
+    if not (os.path.exists(path) and os.path.isdir(scene)):
+        return {"skipped": "fixture tests/golden/samples_6block.npz not present"}
+    z = np.load(path)
+    params = dict(ast.literal_eval(str(z["meta::params"])))
+    sd = {k[len("param::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param::")}
+    filt = torch.from_numpy(np.load(os.path.join(gold, "stft_filters.npz"))["filters"])
+    sd["tfgridnet.enc.filterbank._filters"] = filt.clone()
+    sd["tfgridnet.dec.filterbank._filters"] = filt.clone()
+    m = sb.NetDisEmbd3(**params)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    _, mix, gt, tg = load_testcase(scene, 1.0)
+    out = run_testcase(m, mix, 1.0, device=dev)
+    ref = z["output"]
+    rel = float(np.sqrt(((out.astype(np.float64) - ref) ** 2).sum() / (ref.astype(np.float64) ** 2).sum()))
+    ours, theirs = si_sdr_np(out[0], gt[0]), float(z["si_sdr"])
+    inp = si_sdr_np(mix[0], gt[0])
+    return {"scene": "test_samples/syn_1m/00001 (5 s, 1 in-bubble speaker), 6-block model of syn_experiments/pretrain_stage.json, "
+                     "seeded weights (no trained checkpoint offline: SI-SDR values are plumbing-grade)",
+            "fwd_rel_l2": rel, "fwd_rel_l2_bar": 1e-3,
+            "si_sdr_db": ours, "si_sdr_ref_db": theirs, "si_sdr_delta_db": ours - theirs, "si_sdr_delta_bar_db": 0.05,
+            "si_sdr_i_db": ours - inp, "si_sdr_i_ref_db": theirs - float(z["input_si_sdr"]),
+            "reference_output": "tests/golden/samples_6block.npz (the imported reference model's own output)"}
+
+
 def vendor_gpu_baseline(torch, wl, B, dev, steps=3):
     """Second yardstick of SURVEY.md 8(d), measurement only: the same oracle restatement (stock torch.nn ops ->
     MIOpen RNN / rocBLAS / ATen kernels) moved onto the GPU -- i.e. what running the reference unmodified on
@@ -493,6 +561,9 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
     if with_cpu and world == 1:                               # reported baseline: rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(torch, wl)
         out["cpu_baseline"]["gpu_over_cpu"] = utt_s / out["cpu_baseline"]["value"]
+        out["cpu_baseline"]["legs"]["stream_small"] = cpu_stream_leg(torch, "small")     # configs[4] on the CPU
+    if not forward_only and rank == 0 and wl.startswith("big"):
+        out["parity"] = parity_check(torch, sb, dev)
     return out
 
 
@@ -665,6 +736,11 @@ def main():
                          with_cpu=not args.no_cpu_baseline)
         if rank == 0 and secondary is not None:
             out["secondary"] = secondary
+            leg = out.get("cpu_baseline", {}).get("legs", {}).get("stream_small")
+            if leg and "stream_small" in secondary:       # the hipGraph chunk loop beside the CPU chunk loop
+                secondary["stream_small"]["cpu_chunks_s"] = leg["chunks_s"]
+                secondary["stream_small"]["cpu_p50_ms"] = leg["p50_ms"]
+                secondary["stream_small"]["gpu_over_cpu"] = secondary["stream_small"]["chunks_s"] / leg["chunks_s"]
         if rank == 0 and args.vendor_gpu_baseline:
             B = args.batch or WORKLOADS[wl][2]
             out["vendor_gpu_baseline"] = vendor_gpu_baseline(torch, wl, B, dev)

@@ -342,6 +342,49 @@ def make_samples_more(torch, NetBig, out_dir):
     np.savez_compressed(os.path.join(out_dir, "samples_more.npz"), **rec)
 
 
+def make_samples_6block(torch, NetBig, big_params, out_dir):
+    """BASELINE configs[0] at its stated model: test_samples/syn_1m/00001 at its FULL 5 s (120 000 samples, 625 frames)
+    through the REFERENCE 6-block 0.5 M-parameter network of syn_experiments/pretrain_stage.json:8-27 -- seeded default-init
+    weights (no trained checkpoint exists offline), stored with the fixture -- as src/test_samples.py:90-112 runs it (one-hot
+    [0, 0, 1] for the 1 m bubble, GT = sum of the mic00 voices within 1 m), with the reference's own NumPy metrics."""
+    import json
+    import wave
+    import shutil
+    sys.path.insert(0, os.path.join(REF, "helpers"))
+    import eval_utils                                            # reference helpers/eval_utils.py
+    torch.manual_seed(20260930)
+    model = NetBig(**big_params).eval()
+    assert sum(p.numel() for p in model.parameters()) == 501398
+    src = os.path.join(REF, "test_samples", "syn_1m", "00001")
+    dst = os.path.join(out_dir, "test_samples_full", "syn_1m", "00001")
+    os.makedirs(dst, exist_ok=True)
+    for fn in sorted(os.listdir(src)):                           # the scene's own files (MIT-licensed fixtures), untrimmed
+        shutil.copyfile(os.path.join(src, fn), os.path.join(dst, fn))
+    meta = json.load(open(os.path.join(dst, "metadata.json")))
+    with wave.open(os.path.join(dst, "mixture.wav"), "rb") as w:
+        mix = np.frombuffer(w.readframes(w.getnframes()), "<i2").reshape(-1, 6).T.astype(np.float32) / 32768.0
+    gt = np.zeros((1, mix.shape[1]), np.float32)
+    ntg = 0
+    for spk in sorted(k for k in meta if k.startswith("voice")):
+        if meta[spk]["dis"] <= 1.0:
+            ntg += 1
+            with wave.open(os.path.join(dst, f"mic00_{spk}.wav"), "rb") as w:
+                gt[0] += np.frombuffer(w.readframes(w.getnframes()), "<i2").astype(np.float32) / 32768.0
+    with torch.no_grad():
+        out = model({"mixture": torch.from_numpy(mix)[None], "dis_embed": torch.tensor([[0.0, 0.0, 1.0]])})["output"][0].numpy()
+    rec = {"meta::params": np.array(repr(sorted(big_params.items()))), "output": out, "gt": gt, "n_targets": np.int64(ntg),
+           "si_sdr": np.float64(eval_utils.si_sdr(out[0].astype(np.float64), gt[0].astype(np.float64))),
+           "input_si_sdr": np.float64(eval_utils.si_sdr(mix[0].astype(np.float64), gt[0].astype(np.float64))),
+           "snr": np.float64(eval_utils.snr(out[0].astype(np.float64), gt[0].astype(np.float64)))}
+    for k, p in model.state_dict().items():                       # as make_case: everything but the (shared) STFT filters
+        if not k.endswith("_filters"):
+            rec["param::" + k] = p.detach().numpy().copy()
+    path = os.path.join(out_dir, "samples_6block.npz")
+    np.savez_compressed(path, **rec)
+    print("samples_6block:", mix.shape, "targets", ntg, "SI-SDR", rec["si_sdr"], "input", rec["input_si_sdr"],
+          f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def make_state_io(torch, nets, out_dir):
     """edge/flatbuf.py:8-25 name order: the reference's own flatten_state_buffers over init_buffers of each family
     (+ attention buffers), and the reference's named_parameters() order (= torch.optim.Adam state indices)."""
@@ -470,6 +513,8 @@ def main():
         make_samples(torch, NetBig, args.out)
     if not only or "samples_more" in only:
         make_samples_more(torch, NetBig, args.out)
+    if not only or "samples_6block" in only:
+        make_samples_6block(torch, NetBig, big, args.out)
     if not only or "state_io" in only:
         make_state_io(torch, {"small": (NetSmall, small), "big": (NetBig, big), "orange": (NetSmall, orange),
                               "big_attn": (NetBig, dict(big, use_attn=True)),

@@ -130,3 +130,52 @@ def test_hip_model_on_the_other_radii_and_a_full_length_scene():
         assert out.shape == (1, n) and rel_l2(out, g[f"{sset}/{scene}::output"]) < 2e-4
         wav, sr = read_wav(os.path.join(out_dir, f"{scene}_output.wav"))       # the written demo output round-trips
         assert sr == 24000 and wav.shape[-1] == n
+
+
+# ---- BASELINE configs[0] at its OWN size (round 4): the 6-block 0.5 M network of
+# syn_experiments/pretrain_stage.json:8-27 on syn_1m/00001 at its full 5 s, as src/test_samples.py:90-112 runs it ----
+FULL = os.path.join(GOLDEN, "test_samples_full", "syn_1m")
+
+
+def _golden_6block():
+    rec, params, flavour = load_golden("samples_6block")
+    assert params["B"] == 6 and params["D"] == 32 and flavour == "dis_embd3"
+    return rec, params, flavour
+
+
+def test_oracle_on_the_full_scene_through_the_six_block_model(torch_mod):
+    torch = torch_mod
+    from oracle.tfgridnet_oracle import OracleNet
+    from sound_bubble_amd.eval_samples import load_testcase, si_sdr_np
+    rec, params, flavour = _golden_6block()
+    m = OracleNet(flavour, **params).eval()
+    m.load_state_dict(golden_state_dict(rec, torch))
+    assert sum(p.numel() for p in m.parameters()) == 501398
+    _, mix, gt, tg = load_testcase(os.path.join(FULL, "00001"), 1.0)
+    assert mix.shape == (6, 120000) and len(tg) == int(rec["n_targets"]) == 1
+    np.testing.assert_array_equal(gt, rec["gt"])
+    with torch.no_grad():
+        out = m({"mixture": torch.from_numpy(mix)[None], "dis_embed": torch.tensor([[0.0, 0.0, 1.0]])})["output"][0].numpy()
+    assert rel_l2(out, rec["output"]) < 5e-6
+    assert abs(si_sdr_np(out[0], gt[0]) - float(rec["si_sdr"])) < 0.05
+    assert abs(si_sdr_np(mix[0], gt[0]) - float(rec["input_si_sdr"])) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_six_block_model_on_the_full_scene():
+    """evaluate_dir over the untrimmed scene with the 6-block model: rel-L2 <= 2e-4 against the REFERENCE model's output
+    (north-star bar 1e-3), SI-SDR within 0.05 dB of the reference's value"""
+    import torch
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.eval_samples import evaluate_dir, load_testcase, run_testcase
+    rec, params, _ = _golden_6block()
+    m = sb.NetDisEmbd3(**params)
+    m.load_state_dict(golden_state_dict(rec, torch))
+    m = m.cuda().eval()
+    rows = {r["sample"]: r for r in evaluate_dir(m, FULL, 1.0)}
+    row = rows["00001"]
+    assert row["n_targets"] == 1
+    assert abs(row["si_sdr"] - float(rec["si_sdr"])) < 0.05 and abs(row["input_si_sdr"] - float(rec["input_si_sdr"])) < 1e-4
+    _, mix, _, _ = load_testcase(os.path.join(FULL, "00001"), 1.0)
+    out = run_testcase(m, mix, 1.0)
+    assert out.shape == (1, 120000) and rel_l2(out, rec["output"]) < 2e-4
