@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {"fwdnogates": "-DSB_EXP_SKIP=1", "rc1": "-DSB_EXP_RECOMPUTE=1", "rc3": "-DSB_EXP_RECOMPUTE=3"}
-if os.environ.get("SB_EXP_VARIANTS"):       # e.g. SB_EXP_VARIANTS="noagpr=-DSB_AGPR_OPERANDS=0": other A/B builds of sb_lstm_bf.hip
+if os.environ.get("SB_EXP_VARIANTS"):       # e.g. SB_EXP_VARIANTS="noagpr=-DSB_AGPR_OPERANDS=0": other A/B builds of sb_lstm_bf_{fwd,bwd}.hip
     VARIANTS = dict(v.split("=", 1) for v in os.environ["SB_EXP_VARIANTS"].split(";"))
 
 
@@ -24,16 +24,20 @@ def build():
     from sound_bubble_amd import build as B
     exp = os.path.join(B.LIBDIR, "exp")
     os.makedirs(exp, exist_ok=True)
+    BF = ("sb_lstm_bf_fwd.hip", "sb_lstm_bf_bwd.hip")          # the two translation units of the recurrent kernels
     procs = []
     for name, flag in VARIANTS.items():
-        obj = os.path.join(exp, f"sb_lstm_bf_{name}.o")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *B.PER_FILE_FLAGS["sb_lstm_bf.hip"], flag, "-O3", "-std=c++17",
-               "-fPIC", "-Wno-unused-value", "-c", os.path.join(B.CSRC, "sb_lstm_bf.hip"), "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd)))
+        for src in BF:
+            obj = os.path.join(exp, src.replace(".hip", f"_{name}.o"))
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *B.PER_FILE_FLAGS[src], flag, "-O3", "-std=c++17",
+                   "-fPIC", "-Wno-unused-value", "-c", os.path.join(B.CSRC, src), "-o", obj]
+            procs.append((name, src, obj, subprocess.Popen(cmd)))
     B.build()
-    for name, obj, p in procs:
-        assert p.wait() == 0, name
-        objs = [obj if s == "sb_lstm_bf.hip" else os.path.join(B.LIBDIR, s.replace(".hip", ".o")) for s in B.SOURCES]
+    for name, src, obj, p in procs:
+        assert p.wait() == 0, (name, src)
+    for name in VARIANTS:
+        objs = [os.path.join(exp, s.replace(".hip", f"_{name}.o")) if s in BF else os.path.join(B.LIBDIR, s.replace(".hip", ".o"))
+                for s in B.SOURCES]
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(exp, f"lib_{name}.so")] + objs)
         print("built", name)

@@ -7,8 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsoundbubble_hip.so")
-SOURCES = ["sb_lstm.hip", "sb_lstm_vec.hip", "sb_lstm_bf.hip", "sb_lstm_stream.hip", "sb_attention.hip", "sb_linear.hip", "sb_elementwise.hip", "sb_mrstft.hip"]
-HEADERS = [os.path.join(CSRC, "sb_common.h"), os.path.join(HERE, "..", "include", "sound_bubble_hip.h")]
+SOURCES = ["sb_lstm.hip", "sb_lstm_vec.hip", "sb_lstm_bf_fwd.hip", "sb_lstm_bf_bwd.hip", "sb_lstm_stream.hip", "sb_attention.hip",
+           "sb_linear.hip", "sb_elementwise.hip", "sb_mrstft.hip"]
+HEADERS = [os.path.join(CSRC, "sb_common.h"), os.path.join(CSRC, "sb_lstm_bf_common.h"),
+           os.path.join(HERE, "..", "include", "sound_bubble_hip.h")]
 
 
 def _stale(target, deps):
@@ -23,13 +25,14 @@ def _stale(target, deps):
 # The streaming / GEMM kernels hold ~100 accumulator registers and are better off with AGPRs (hipcc's default).
 # -ffp-contract=off: every fused multiply-add in the recurrent kernels is written out (__builtin_fmaf), so all template
 # variants of a kernel (e.g. the time-segmented and the plain schedule) round identically -- bit-exact outputs.
-PER_FILE_FLAGS = {"sb_lstm_bf.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffp-contract=off"]}
+_BF_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffp-contract=off"]
+PER_FILE_FLAGS = {"sb_lstm_bf_fwd.hip": _BF_FLAGS, "sb_lstm_bf_bwd.hip": _BF_FLAGS}
 
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIBDIR, exist_ok=True)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
@@ -38,9 +41,16 @@ def build(force=False, verbose=True):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
             cmd[2:2] = os.environ.get("SB_EXTRA_HIPCC_FLAGS", "").split()     # e.g. -DSB_PHASE_TIMING (dev tool)
             cmd[2:2] = PER_FILE_FLAGS.get(src, [])
+            jobs.append(cmd)
+    if jobs:                                   # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

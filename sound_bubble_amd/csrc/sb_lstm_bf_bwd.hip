@@ -1,767 +1,18 @@
-// Recurrent LSTM kernels on the 16-bit matrix pipes with split fp32 operands.
-//
-// Why: on gfx950 the fp32-input MFMA runs at the fp32 vector rate and does not overlap the cell-update VALU work
-// of a co-resident wave (measured: two workgroups per CU give no throughput over one), so the fp32 kernels in
-// sb_lstm.hip top out at ~45-65 % of the 157 TFLOP/s fp32 peak.  The bf16 / fp16 matrix pipes are 16x faster and
-// truly concurrent with the VALU.  Every fp32 operand is split into 16-bit terms and the product evaluated term by
-// term, each 16-bit x 16-bit product being exact in the fp32 accumulator:
-//   fp16x3 (default):      x = hi + lo  (11 + 11 mantissa bits),  a*b = lo*hi + hi*lo + hi*hi   (dropped <= 2^-22)
-//   bf16x6 (SB_LSTM_BF16X6): x = h + m + l (8 + 8 + 8 bits),  a*b = l*h + h*l + m*m + m*h + h*m + h*h (<= 2^-24)
-// Both are fp32-class for this network (identical measured error against the reference goldens, 9e-7 .. 3e-6 rel-L2
-// on the output): required because the recurrence amplifies rounding noise over 625 steps and the parity bar is 1e-3.
-// In compact-BPTT mode the backward recurrence additionally carries its dgates as (scaled) fp16 -- see below.
-//
-// v_mfma_f32_16x16x32_{bf16,f16}: A lane l holds A[i = l&15][k = 8*(l>>4)..+7], B lane l holds B[k = 8*(l>>4)..+7][j = l&15],
-// C/D as in sb_common.h.  K is walked in chunks of 32: chunk 0 = the (LayerNormed) input u (zero-padded to 32),
-// chunks 1,2 = the hidden state.  Step pipeline: A: hidden part (MFMA) with the LayerNorm of row s+2 in its issue
-// gaps; B: input part of step s+1 (MFMA) || cell update; C: h -> LDS, stores, barrier.
-#include <type_traits>
-#include "sb_common.h"
-#ifndef SB_EXP_SKIP
-#define SB_EXP_SKIP 0
-#endif
-// Developer experiment (scripts/exp_gate_recompute.py; 0 in the shipped library): cost model of RECOMPUTING the four
-// gates in the backward recurrence from (u, h_prev) instead of loading the forward's gate records -- bit 0: issue the
-// recompute's instruction mix per step (12 fp16 MFMAs 16x16x32 = W[4 gates][3 K-chunks] . [u | h_prev], 16 gate
-// activations = 16 v_exp + 16 v_rcp, results folded into the gates at 1e-30 so nothing is eliminated); bit 1: do not
-// load the gate records (their bytes are what a recompute would save; the c_prev record stays).
-#ifndef SB_EXP_RECOMPUTE
-#define SB_EXP_RECOMPUTE 0
-#endif
-#include "../../include/sound_bubble_hip.h"
+// Backward (BPTT) recurrence of the LSTM passes on the 16-bit matrix pipes, with the streaming part of the backward fused in
+// (see sb_lstm_bf_common.h for the arithmetic): lstm_bwd_rec_bf_kernel and its launcher.  Forward: sb_lstm_bf_fwd.hip.
+#include "sb_lstm_bf_common.h"
 
-// Phase timing (developer tool): build with -DSB_PHASE_TIMING and pass a scratch buffer (fwd: save_u with
-// save_gates == NULL; bwd: dhs with dy == NULL) -- lane 0 of every wave of the first 4 tiles writes the average
-// s_memtime cycles per step of each phase.  scripts/phase_timing.py prints them.
+// Phase timing (developer tool): build with -DSB_PHASE_TIMING and pass a scratch buffer (dhs with dy == NULL).
 #ifdef SB_PHASE_TIMING
-#define SB_TICK(name) const unsigned long long name = __builtin_readcyclecounter()
-// the last launch of every forward kernel kind also leaves its table here (any SAVE mode: training steps of the whole model);
-// kind 0 plain, 1 fused Linear, 2 summed input + fused Linear (the inter-frame producer), 3 ordered consumer, 4 bidirectional
-// partial-Linear; read with sb_debug_phase_fwd()
-__device__ float g_phase_fwd[5][16][8];
 // chunk role of the role-split backward (wave 4 of workgroup 0): ticks per period of [work before the hand-over barrier, wait
 // at it, work after it, wait at the second barrier]; read with sb_debug_phase_bwd_split()
 __device__ float g_phase_bwd_split[8];
 extern "C" int sb_debug_phase_bwd_split(float* host_out) {
   return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_bwd_split), sizeof(g_phase_bwd_split));
 }
-extern "C" int sb_debug_phase_fwd(float* host_out) {
-  const int rc = -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_fwd), sizeof(g_phase_fwd));
-  static float zeros[5 * 16 * 8];
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_fwd), zeros, sizeof(zeros));      // the next read shows only what ran since
-  return rc;
-}
-#else
-#define SB_TICK(name) do {} while (0)
 #endif
 
 namespace {
-
-constexpr int H = SB_H;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-
-struct Split3 { bf16x8 h, m, l; };
-
-SB_DEVINL void split1(float x, __bf16& h, __bf16& m, __bf16& l) {
-  h = (__bf16)x;
-  float r = x - (float)h;
-  m = (__bf16)r;
-  r -= (float)m;
-  l = (__bf16)r;
-}
-SB_DEVINL Split3 split8(const float (&x)[8]) {
-  Split3 s;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { __bf16 h, m, l; split1(x[k], h, m, l); s.h[k] = h; s.m[k] = m; s.l[k] = l; }
-  return s;
-}
-SB_DEVINL f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-struct SplitH { h16x8 hi, lo; };            // fp32 = fp16 hi + fp16 lo (22 mantissa bits)
-SB_DEVINL SplitH splith8(const float (&x)[8]) {
-  SplitH s;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const _Float16 h = (_Float16)x[k];
-    s.hi[k] = h;
-    s.lo[k] = (_Float16)(x[k] - (float)h);
-  }
-  return s;
-}
-
-// Operand format of the forward split products.
-//   F16 = false: bf16, x = t0 + t1 + t2 (8+8+8 bits), six products, dropped terms <= 2^-24  ("bf16x6", fp32-exact class)
-//   F16 = true : fp16, x = t0 + t1      (11+11 bits), three products, dropped term   <= 2^-22  ("fp16x3"): half the
-//                MFMAs and a cheaper split; fp16 range is ample for LayerNorm outputs, hidden states in (-1, 1) and
-//                the weights, and an underflowing low term costs < 6e-8 absolute.
-template <bool F16> struct Prec;
-template <> struct Prec<false> {
-  typedef __bf16 elem;
-  typedef bf16x8 vec8;
-  typedef bf16x4 vec4;
-  static constexpr int NT = 3;
-  static SB_DEVINL f32x4 mma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Prec<true> {
-  typedef _Float16 elem;
-  typedef h16x8 vec8;
-  typedef h16x4 vec4;
-  static constexpr int NT = 2;
-  static SB_DEVINL f32x4 mma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-template <bool F16> struct SplitN { typename Prec<F16>::vec8 t[Prec<F16>::NT]; };      // t[0] = leading term
-template <bool F16>
-SB_DEVINL void splitn1(float x, typename Prec<F16>::elem (&out)[Prec<F16>::NT]) {
-  float r = x;
-#pragma unroll
-  for (int k = 0; k < Prec<F16>::NT; ++k) {
-    out[k] = (typename Prec<F16>::elem)r;
-    r -= (float)out[k];
-  }
-}
-template <bool F16>
-SB_DEVINL SplitN<F16> splitn8(const float (&x)[8]) {
-  SplitN<F16> s;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    typename Prec<F16>::elem e[Prec<F16>::NT];
-    splitn1<F16>(x[k], e);
-#pragma unroll
-    for (int n = 0; n < Prec<F16>::NT; ++n) s.t[n][k] = e[n];
-  }
-  return s;
-}
-
-// Hand-off wait of the time-segmented schedule: thread 0 polls the tile's flag until the predecessor segment has published
-// its state.  Bounded: progress depends on all workgroups of the launch being co-resident, which the launcher checks
-// against the kernel's occupancy but cannot guarantee on a shared / CU-masked device -- after kSegSpinLimit polls (seconds)
-// the watchdog word is set and the whole workgroup leaves; every other waiter sees the word and leaves too, so the
-// launch ends with garbage outputs and *status != 0 instead of hanging the process.  Returns false on abort (uniform
-// over the workgroup).
-constexpr unsigned kSegSpinLimit = 1u << 22;
-SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status) {
-  __shared__ int seg_abort;
-  if (threadIdx.x == 0) {
-    int bad = 0;
-    unsigned spins = 0;
-    while (__hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
-      ++spins;
-      if ((spins & 63u) == 0 &&
-          (spins > kSegSpinLimit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bad = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    seg_abort = bad;
-  }
-  __syncthreads();
-  return seg_abort == 0;
-}
-
-constexpr int UP = 32 + 8;    // padded 16-bit row of the input-term tiles  (80 B)
-constexpr int HP16 = 64 + 8;  // padded 16-bit row of the hidden-term tiles (144 B)
-
-template <int C>
-struct XVec { float v[C / 16]; };
-
-// LIN (single-direction passes): the Linear(64 -> C) + residual that follows the LSTM is applied in the kernel,
-// y[p] = x[p] + W_lin h[p] + b_lin, one step behind the recurrence from the hidden-state tiles that are in LDS anyway
-// (waves w < C/16 own channel tile w); hs is then only written when the caller wants it (training).
-// SEG (single-direction passes with more tiles than CUs): the time axis of every tile is cut into a.seg_count
-// segments and the (tile, segment) items are dealt round-robin to one resident workgroup per CU; a segment starts from
-// the (h, c) state its predecessor left in a.seg_state, published through a.seg_flags (release / acquire at agent
-// scope).  A tile is an indivisible serial chain, and a second co-resident tile costs ~1.8x, so 290 tiles on 256 CUs
-// run 1.8 T with most CUs idle half the time; cut into k segments the makespan is ceil(290 k / 256) / k ~ 1.14 T.
-// Item i = segment * ntiles + tile goes to workgroup i mod W in increasing order; its predecessor i - ntiles lies in an
-// earlier round (ntiles >= W), so every wait is on an item some resident workgroup is already past or working on.
-// SUM3 (single-direction passes that follow a bidirectional pass in partial-Linear mode): the input row is
-// x[p] + x_part[p, 0, :] + x_part[p, 1, :] -- the residual and the two directions' halves of the intra-frame Linear --
-// summed by the loader as it fetches the row (the separate elementwise pass, 16 C bytes per position, is gone); the sum
-// is written once to x_sum for the backward kernels (training) and handed to the fused Linear's residual through a
-// four-row LDS ring (the residual is needed two barriers after the row was normalised).
-// Overlapped forward (sb_lstm_fwd_produce / sb_lstm_fwd_consume): an inter-frame pass with fewer tiles than CUs publishes
-// its y rows (write-through, sc1) and counts itself into slab_flags[k] after every slab_len time steps (runtime flag:
-// a.slab_flags on a single-direction LIN launch); the NEXT block's intra-frame pass (ORD: 1-D grid, direction = workgroup
-// parity, tiles tile_order[0 .. ntiles) sorted by the latest time slab their 16 frames need, drawn by the workgroups of BOTH
-// launches of the pass from one atomic counter per direction) starts on the idle CUs and each item waits for
-// slab_flags[tile_need[i]] to reach slab_need.  An input row is one 128-byte line that only its frame's items ever read,
-// so no line of an unfinished slab enters the reader's L2.  Guarded launch (ord_guard, the one that runs NEXT to the
-// producer): a workgroup that does not find every producer workgroup started within ~50 us leaves at once -- should the
-// dispatcher have placed this launch first, it must not sit on the CUs the producer needs.
-SB_DEVINL void st4_sc1(float* p, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-template <int C, int SAVE, bool FULL, bool F16, bool LIN, bool SEG, bool SUM3 = false, bool ORD = false>
-__global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
-  typedef Prec<F16> PR;
-  typedef typename PR::elem elem;
-  typedef typename PR::vec8 vec8;
-  typedef typename PR::vec4 vec4;
-  constexpr int NT = PR::NT;
-  constexpr int VPT = C / 16;
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
-  const int dir = ORD ? (int)blockIdx.x & 1 : (int)blockIdx.y;
-  const int S = a.nsteps;
-  const bool rev = dir == 1;
-  const bool prod = LIN && !ORD && !SEG && a.slab_flags != nullptr;      // producer side of the overlapped forward
-  if (prod && tid == 0) __hip_atomic_fetch_add(a.ord_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __shared__ int ord_item;
-  auto ord_next = [&]() -> int {                     // next (tile, this direction) item; uniform over the workgroup
-    if (tid == 0) ord_item = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    return ord_item;
-  };
-  int ord_first = 0;
-  if constexpr (ORD) {
-    if (a.ord_guard) {
-      if (tid == 0) {
-        int ok = 0;
-        for (int i = 0; i < 200 && !ok; ++i) {
-          ok = __hip_atomic_load(a.ord_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.slab_need;
-          if (!ok) __builtin_amdgcn_s_sleep(8);
-        }
-        ord_item = ok;
-      }
-      __syncthreads();
-      if (!ord_item) return;
-      __syncthreads();
-    }
-    ord_first = ord_next();                           // before the weights are fetched: most late workgroups find nothing
-    if (ord_first >= (a.nseq + 15) / 16) return;
-  }
-
-  __shared__ __attribute__((aligned(16))) elem U16[2][NT][16][UP];      // [buf][term][seq][channel]
-  __shared__ __attribute__((aligned(16))) elem H16[2][NT][16][HP16];    // [buf][term][seq][unit]
-  __shared__ __attribute__((aligned(16))) float Bias[4][H];
-  __shared__ __attribute__((aligned(16))) float XS[SUM3 ? 4 : 1][SUM3 ? 16 : 1][SUM3 ? C + 4 : 1];   // summed input rows (ring)
-
-  // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
-  const float* __restrict__ wih = a.w_ih[dir];
-  const float* __restrict__ whh = a.w_hh[dir];
-  // The activations are evaluated as rcp(1 + 2^z): the factors z = -log2(e) x (sigmoid gates i, f, o) and
-  // z = -2 log2(e) x (tanh gate g) are folded into the weight and bias rows here, once, instead of a multiply
-  // per gate value and step.
-  SplitN<F16> Wt[4][3];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int row = g * H + 16 * w + j;
-    const float gsc = (g == 2 ? 2.0f : 1.0f) * SB_NLOG2E;
-    float t[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) t[kk] = (8 * q + kk < C) ? gsc * wih[(size_t)row * C + 8 * q + kk] : 0.f;
-    Wt[g][0] = splitn8<F16>(t);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) t[kk] = gsc * whh[(size_t)row * H + 32 * c + 8 * q + kk];
-      Wt[g][1 + c] = splitn8<F16>(t);
-    }
-  }
-  if (tid < 4 * H) Bias[tid >> 6][tid & 63] = ((tid >> 6) == 2 ? 2.0f : 1.0f) * SB_NLOG2E * (a.b_ih[dir][tid] + a.b_hh[dir][tid]);
-  const bool linw = LIN && w < C / 16;                  // this wave owns output channels 16w .. 16w+15 of y
-  // bidirectional passes (a.ndir == 2): PARTIAL mode -- each direction writes its half of the Linear(128 -> C),
-  // y[p, dir, :] = W_lin[:, dir*64 .. +63] . h_dir[p] (+ b_lin in direction 0), no residual: the two directions visit a
-  // position at different times in different workgroups, so the sum x + y[p,0] + y[p,1] is a cheap elementwise pass
-  // (sb_add3) instead of a pass over hs [P, 128] fp32 -- and hs itself only travels as the fp16 side output.
-  const bool lin_part = LIN && a.ndir == 2;
-  SplitN<F16> Wl[2];
-  f32x4 lbias = zero4(), yacc = zero4(), xres = zero4();
-  if constexpr (LIN) {
-    const int ldl = a.ndir * H;
-#pragma unroll
-    for (int ck = 0; ck < 2; ++ck) {
-      float t[8];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) t[kk] = linw ? a.lin_w[(size_t)(16 * w + j) * ldl + dir * H + 32 * ck + 8 * q + kk] : 0.f;
-      Wl[ck] = splitn8<F16>(t);
-    }
-    if (linw && dir == 0) lbias = ld4(a.lin_b + 16 * w + 4 * q);
-  }
-  // zero the padded channels of the input tiles once (C = 16: channels 16..31 stay zero)
-  for (int i = tid; i < 2 * NT * 16 * UP; i += 256) (&U16[0][0][0][0])[i] = (elem)0.f;
-  __syncthreads();
-
-  // ---- loader role ----
-  const int ls = tid >> 4, cpart = tid & 15;
-  bool lvalid = false, cvalid = false;          // per work item (tile): set by set_tile()
-  int64_t lbase = 0, cbase = 0;
-  // Per-lane element offsets of the tile, fixed at set_tile(): a per-step address is  pointer + lane offset + (uniform step
-  // term), i.e. one scalar multiply and a 64-bit add.  Formed as (lane base + st * p_step) * row width they cost a
-  // quarter-rate 64-bit multiply chain per address and step -- VALU time, which on this chip adds to the matrix time of
-  // the wave (microbenchmarks in scripts/micro/: a SIMD runs MFMA and VALU instructions back to back, never side by side).
-  int64_t lo_x = 0, lo_xp = 0, co_y = 0, co_h = 0;
-  const int ndir = a.ndir;
-  // ... and the uniform step terms are RUNNING sums: one 64-bit scalar add per step and quantity instead of a 64-bit scalar
-  // multiply chain per address (with one wave per SIMD every instruction, scalar ones included, costs its ~4 issue cycles:
-  // the ~70 scalar instructions of the old epilogue were 290 ticks of a 2 070-tick step).  Row s of the walk:
-  //   run_x = st(s) p_step C (x, x_sum, u, y, y_pre, residual), run_h = st(s) p_step ndir 64 (hs), run_blk = record block;
-  // set by walk_begin(), advanced at the end of every step.
-  int64_t run_x = 0, run_h = 0, run_blk = 0, run_x_last = 0, pend_h = 0, pend_blk = 0;
-  const int64_t d_x = (rev ? -1 : 1) * a.p_step * C, d_h = (rev ? -1 : 1) * a.p_step * (ndir * H), d_blk = rev ? -ndir : ndir;
-  int nc = 0;
-  int64_t rec_tile = 0;                         // tile * S: compact records are blocked per (tile, step, direction)
-  // FiLM of the NEXT block (dis_embd3 :509-513) in the y epilogue: y <- y * film_w[n] + film_b[n] with the planes of
-  // sequence n = (b, f) -- constant along this kernel's time walk, so eight registers per lane, loaded once per tile.
-  // The pre-FiLM value goes to y_pre when the backward needs it (training).  Replaces a pass over [B, T, F, C].
-  const bool film = LIN && a.film_w != nullptr;
-  f32x4 fw = {1.f, 1.f, 1.f, 1.f}, fb = zero4();
-  auto set_tile = [&](int tile) {
-    rec_tile = (int64_t)tile * S;
-    const int nl = tile * 16 + ls;
-    lvalid = FULL || nl < a.nseq;
-    lbase = lvalid ? ((int64_t)(nl / a.n_inner) * a.p_outer + (int64_t)(nl % a.n_inner) * a.p_inner) : 0;
-    nc = tile * 16 + j;
-    cvalid = FULL || nc < a.nseq;
-    cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
-    lo_x = lbase * C + cpart * VPT;
-    lo_xp = lbase * (2 * C) + cpart * VPT;
-    co_y = ((LIN && a.ndir == 2) ? cbase * 2 + dir : cbase) * C + 16 * w + 4 * q;
-    co_h = (cbase * ndir + dir) * H + 16 * w + 4 * q;
-    if (film && linw && cvalid) {
-      fw = ld4(a.film_w + (size_t)nc * C + 16 * w + 4 * q);
-      fb = ld4(a.film_b + (size_t)nc * C + 16 * w + 4 * q);
-    }
-  };
-  float gam[VPT], bet[VPT];
-#pragma unroll
-  for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; bet[v] = a.ln_b[cpart * VPT + v]; }
-
-  auto load_x = [&](int s) {
-    XVec<C> r;
-    const int st = rev ? S - 1 - s : s;
-    const int64_t sp = (int64_t)st * a.p_step;        // uniform
-    const float* p = a.x + sp * C + lo_x;
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) r.v[v] = (SB_EXP_SKIP & 64) ? (float)((s + v + lane) & 7) * 0.25f : (lvalid ? p[v] : 0.f);
-    if constexpr (SUM3) {
-      const float* p0 = a.x_part + sp * (2 * C) + lo_xp;
-#pragma unroll
-      for (int v = 0; v < VPT; ++v) r.v[v] = lvalid ? (r.v[v] + p0[v]) + p0[C + v] : 0.f;      // (x + part0) + part1, as sb_add3
-    }
-    return r;
-  };
-  auto ln_store = [&](const XVec<C>& xv, int buf, int s, int64_t ex) {      // ex = st(s) p_step C (uniform)
-    float sum = 0.f;
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) sum += xv.v[v];
-    const float mean = row16_sum(sum) * (1.0f / C);
-    float sq = 0.f;
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq = __builtin_fmaf(d, d, sq); }
-    const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(row16_sum(sq), 1.0f / C, 1e-5f));   // v_rsq_f32, 1 ulp
-    float u[VPT];
-    elem uterm[2][VPT];                            // the two leading terms (SAVE == 4 stores them)
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) {
-      u[v] = __builtin_fmaf((xv.v[v] - mean) * rstd, gam[v], bet[v]);
-      elem e[NT];
-      splitn1<F16>(u[v], e);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) U16[buf][n][ls][cpart * VPT + v] = e[n];
-      uterm[0][v] = e[0]; uterm[1][v] = e[1];
-    }
-    if constexpr (SUM3) {
-#pragma unroll
-      for (int v = 0; v < VPT; ++v) XS[s & 3][ls][cpart * VPT + v] = xv.v[v];
-      if (a.x_sum && lvalid) {
-        float* p = a.x_sum + ex + lo_x;
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) p[v] = xv.v[v];
-      }
-    }
-    if (SAVE && lvalid && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
-      const int64_t uo = ex + lo_x;
-      if constexpr (SAVE == 3) {            // only the streaming backward reads u, as a single fp16 term
-        _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + uo;
-        if constexpr (VPT == 2) *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)u[0], (_Float16)u[1]};
-        else p[0] = (_Float16)u[0];
-      } else if constexpr (SAVE == 4 && F16) {
-        // wide form: u travels as the fp16 hi + lo terms this kernel's own products use (same bytes as fp32, and the
-        // backward kernels take them as matrix operands without a split): [P][C/2][hi0, hi1, lo0, lo1] resp. [P][C][hi, lo]
-        _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + 2 * uo;
-        if constexpr (VPT == 2) *reinterpret_cast<h16x4*>(p) = h16x4{(_Float16)uterm[0][0], (_Float16)uterm[0][1], (_Float16)uterm[1][0], (_Float16)uterm[1][1]};
-        else *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)uterm[0][0], (_Float16)uterm[1][0]};
-      } else {
-        float* p = a.save_u + uo;
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) p[v] = u[v];
-      }
-    }
-  };
-
-  // ---- compute role ----
-  const int uoff = 16 * w + 4 * q;
-  f32x4 c = zero4(), h = zero4();
-  vec4 htv[NT];                                   // terms of the hidden state this lane stored last (SAVE == 4 writes them out)
-  auto store_h = [&](int buf, const f32x4& hv) {   // split the 4 hidden values of this lane, 3 x 8-byte LDS stores
-    vec4 (&tv)[NT] = htv;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      elem e[NT];
-      splitn1<F16>(hv[r], e);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) tv[n][r] = e[n];
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) *reinterpret_cast<vec4*>(&H16[buf][n][j][uoff]) = tv[n];
-  };
-  // acc[g] += W[g][chunk] * B (6-term split product).  The four gate accumulators are walked round-robin and the
-  // groups are fenced against MFMA reordering (mask: everything but MFMA may cross): hipcc otherwise chains all 12
-  // products of a gate back to back on one accumulator, and any VALU instruction that lands between two MFMAs on
-  // the SAME accumulator costs ~40 cycles.
-  constexpr int kNoMfmaCross = 0x7F6;
-  constexpr int kNoMfmaVmemCross = 0x786;
-  // Deferred record stores (compact / wide records): the ~6 sixteen-byte-per-lane stores of a step, issued back to back by all
-  // four waves right before the barrier, block the waves while the CU's store path drains (phase table: 700-800 ticks per
-  // step and wave in training against 90 in inference).  They are kept in registers instead and issued one at a time between
-  // the product groups of the NEXT step's W_hh h phase -- ~70 ticks of matrix work apart, no wave ever finds the path busy.
-  // (not for the C = 16 inter-frame walk: one wave carries its whole y epilogue there and is the pole of every step;
-  // measured 1.11 -> 1.17 ms with the stores moved into its phase A)
-#ifdef SB_NO_DEFER                                   // A/B switch (developer builds)
-  constexpr bool DEFER = false;
-#else
-  constexpr bool DEFER = SAVE >= 2 && !(LIN && C == 16);
-#endif
-  f32x4 rgi = zero4(), rgf = zero4(), rgg = zero4(), rgo = zero4(), rcp = zero4();     // records of step s_pend
-  int s_pend = -1;
-  auto rec_piece = [&](int k) __attribute__((always_inline)) {
-    if constexpr (SAVE >= 2) {
-      if (s_pend >= 0 && cvalid) {
-        const int64_t blk = pend_blk;
-        if (k == (SAVE == 4 ? 5 : 3)) {                  // hs of the step (h / htv still hold it: they change in phases B / C)
-          const int64_t ho = pend_h + co_h;
-          if constexpr (LIN && SAVE == 3) {   // the Linear is applied here: hs only feeds the backward kernels (fp16 terms)
-            h16x4 h16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h16[r] = (_Float16)h[r];
-            if (a.hs && !(SB_EXP_SKIP & 4)) *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.hs) + ho) = h16;
-          } else if constexpr (LIN && SAVE == 4 && F16) {
-            // wide form with the Linear applied here: hs only feeds the backward kernels' matrix products -- it travels as the
-            // fp16 hi + lo terms just stored to LDS: [P][ndir][16 unit quads][hi x 4, lo x 4], same bytes as fp32
-            h16x8 hp;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { hp[r] = (_Float16)htv[0][r]; hp[4 + r] = (_Float16)htv[1][r]; }
-            if (a.hs) *reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ho * 2) = hp;
-          } else {
-            if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + ho, h);
-          }
-        }
-        if constexpr (SAVE == 4) {
-          // wide records (sb_lstm_fwd_args.rec_f32): fp32, blocked per (tile, step, direction) in lane order like the
-          // compact ones -- [wave][gate][lane][4 floats] and [wave][lane][4 floats], one contiguous KB per store
-          // save_gates == NULL: records WITHOUT the gates (c_prev only) -- for a backward that recomputes them from u and
-          // h_prev with the forward weights (sb_lstm_bwd_args.recompute with `wide`)
-          if (k < 4 && a.save_gates) {
-            float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
-            if (k == 0) st4(rec, rgi);
-            if (k == 1) st4(rec + 256, rgf);
-            if (k == 2) st4(rec + 512, rgg);
-            if (k == 3) st4(rec + 768, rgo);
-          }
-          if (k == 4) st4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, rcp);
-        } else {
-          // Compact records are private to this kernel and the backward recurrence, which walks the same (tile, step)
-          // grid with the same lane ownership, so they are laid out per (tile, step, direction) block in LANE order:
-          // [wave][(i,f) | (g,o)][lane][8 halves] and [wave][lane][4 halves].  Every store instruction then writes one
-          // contiguous KB (512 B for c_prev).  In the position-major layout adjacent lanes (sequences j, j+1) hit
-          // different rows and the L1 splits each instruction into 64 sixteen-byte writes: measured 19 % of the
-          // inter-frame forward, 27 % of the intra-frame one.
-          if ((k == 0 || k == 1) && (SAVE != 3 || a.save_gates) && !(SB_EXP_SKIP & 1)) {   // SAVE == 3, no save_gates: recompute mode
-            _Float16* rec = reinterpret_cast<_Float16*>(a.save_gates) + blk * (16 * 4 * H) + (w * 128 + lane) * 8;
-            h16x8 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = (_Float16)(k == 0 ? rgi[r] : rgg[r]);
-              v[4 + r] = (_Float16)(k == 0 ? rgf[r] : rgo[r]);
-            }
-            *reinterpret_cast<h16x8*>(rec + 512 * k) = v;
-          }
-          if (k == 2 && !(SB_EXP_SKIP & 2)) {
-            h16x4 c16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c16[r] = (_Float16)rcp[r];
-            *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.save_c) + blk * (16 * H) + (w * 64 + lane) * 4) = c16;
-          }
-        }
-      }
-    }
-  };
-  auto rec_flush = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) rec_piece(k);
-    s_pend = -1;
-  };
-  // hook >= 0: after product group pi the pending record store number hook + pi is issued (see rec_piece) and pinned there
-  // (second fence: VMEM may not cross either)
-  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const vec8 (&b)[NT], int hook = -1) {
-    // (weight term, operand term) pairs, smallest products first
-    constexpr int NP = F16 ? 3 : 6;
-    constexpr int WT[6] = {F16 ? 1 : 2, F16 ? 0 : 0, F16 ? 0 : 1, 1, 0, 0};
-    constexpr int XT[6] = {F16 ? 0 : 0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
-#pragma unroll
-    for (int pi = 0; pi < NP; ++pi) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = PR::mma(Wt[g][chunk].t[WT[pi]], b[XT[pi]], acc[g]);
-      __builtin_amdgcn_sched_barrier(kNoMfmaCross);
-      if (hook >= 0) {
-        rec_piece(hook + pi);
-        __builtin_amdgcn_sched_barrier(kNoMfmaVmemCross);
-      }
-    }
-  };
-  auto x_part = [&](f32x4 (&acc)[4], int buf) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = ld4(&Bias[g][uoff]);
-    vec8 b[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&U16[buf][n][j][8 * q]);
-    mma6(acc, 0, b);
-  };
-  auto h_part = [&](f32x4 (&acc)[4], int buf) {
-#pragma unroll
-    for (int ck = 0; ck < 2; ++ck) {
-      vec8 b[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[buf][n][j][32 * ck + 8 * q]);
-      mma6(acc, 1 + ck, b, DEFER ? 3 * ck : -1);
-      if constexpr (LIN) {                             // W_lin . h of the step that produced this buffer
-        if (linw) {
-          if (ck == 0) yacc = zero4();
-          if constexpr (F16) {
-            yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
-            yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
-            yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
-          }
-        }
-      }
-    }
-  };
-  // y of step sy (its W_lin h is in yacc, its residual row in xres)
-  auto store_y = [&](int64_t ey) {                  // ey = st(sy) p_step C of the step sy whose y this is (uniform)
-    if (linw && cvalid && !(SB_EXP_SKIP & 16)) {
-      f32x4 v = yacc + lbias + xres;
-      if (film) {
-        if (a.y_pre) st4(a.y_pre + ey + co_y, v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], fw[r], fb[r]);
-      }
-      float* yp = a.y + (lin_part ? 2 * ey : ey) + co_y;
-      if (prod) st4_sc1(yp, v); else st4(yp, v);
-    }
-  };
-  auto load_res = [&](int sy, int64_t ey) {
-    if (linw && cvalid && !lin_part && !(SB_EXP_SKIP & 32)) {
-      if constexpr (SUM3) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);
-      else xres = ld4(a.x + ey + co_y);
-    }
-  };
-
-  // Input rows are fetched FOUR steps before their LayerNorm: loads and stores share one in-order counter (vmcnt),
-  // so waiting for a row also waits for every older store, and in training the record stores of the inter-frame walk
-  // take longer than two steps to be acknowledged (measured: SQ_WAIT_ANY 1050 cycles per step against 310 without
-  // the stores).  The loop body covers four steps and issues the rows of the next four at its top.
-  XVec<C> xa, xb, xc, xd;
-  f32x4 accx[4];
-  int s_begin = 0;                              // first step of the current work item
-
-#ifdef SB_PHASE_TIMING
-  unsigned long long tph[5] = {0, 0, 0, 0, 0};
-#endif
-  auto step = [&](int s, const XVec<C>& xrow) {        // xrow: input row s+2
-    const int cur = s & 1;
-    SB_TICK(c0);
-    // ---- A: hidden part on the matrix pipe || LayerNorm of row s+2 in the issue gaps (it does not depend on
-    //         this step; its U16[cur] buffer was last read in phase B of step s-1) ----
-    f32x4 acc[4];
-    {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = accx[g];
-      ln_store(xrow, cur, min(s + 2, S - 1), s + 2 <= S - 1 ? run_x + 2 * d_x : run_x_last);
-      h_part(acc, cur);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    SB_TICK(c1);
-    // ---- B: input part of step s+1 (matrix pipe) || cell update of step s (VALU) ----
-    f32x4 gi, gf, gg, go, cprev;
-    {
-      x_part(accx, cur ^ 1);
-      cprev = c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        gi[r] = sigmoid_pre(acc[0][r]);
-        gf[r] = sigmoid_pre(acc[1][r]);
-        gg[r] = tanh_pre(acc[2][r]);
-        go[r] = sigmoid_pre(acc[3][r]);
-        c[r] = __builtin_fmaf(gf[r], c[r], gi[r] * gg[r]);
-        h[r] = go[r] * tanhf_fast(c[r]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    SB_TICK(c2);
-    store_h(cur ^ 1, h);
-    __builtin_amdgcn_sched_barrier(0);
-    SB_TICK(c3);
-    // ---- C ----
-    if constexpr (SAVE >= 2) {        // records of this step: issued in phase A of the next one (or by the flush after the walk)
-      rgi = gi; rgf = gf; rgg = gg; rgo = go; rcp = cprev;
-      s_pend = s;
-      pend_blk = run_blk; pend_h = run_h;
-      if constexpr (!DEFER) rec_flush();              // ... or right here
-    } else {
-      if (cvalid) {
-        const int st = rev ? S - 1 - s : s;
-        const int64_t pos = cbase + (int64_t)st * a.p_step;
-        if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + run_h + co_h, h);
-        if (SAVE == 1) {
-          float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
-          st4(rec, gi); st4(rec + H, gf); st4(rec + 2 * H, gg); st4(rec + 3 * H, go); st4(rec + 4 * H, cprev);
-        }
-      }
-    }
-    if constexpr (LIN) {
-      if (s > s_begin) store_y(run_x - d_x);
-      load_res(s, run_x);
-    }
-    run_x += d_x; run_h += d_h; run_blk += d_blk;       // row s + 1
-    __builtin_amdgcn_sched_barrier(0);
-    SB_TICK(c4);
-    __syncthreads();
-#ifdef SB_PHASE_TIMING
-    SB_TICK(c5);
-    tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
-#endif
-  };
-  const int ntiles = (a.nseq + 15) / 16;
-  const int nitems = SEG ? ntiles * a.seg_count : ntiles;          // !SEG: gridDim.x == ntiles, one item each
-  float* const seg_hc = SEG ? a.seg_state : nullptr;               // [ntiles][2][16][64]: c, h
-  int next_slab = 0;                                               // producer: first slab not yet counted in
-  auto slab_signal = [&](int k) {                                  // every y row of slab k of this tile is on its way
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(a.slab_flags + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  const int item1 = ORD ? ntiles : nitems;
-  for (int item = ORD ? ord_first : (int)blockIdx.x; item < item1; item = ORD ? ord_next() : item + (int)gridDim.x) {
-    const int seg = SEG ? item / ntiles : 0;
-    const int tile = ORD ? a.tile_order[item] : SEG ? item - seg * ntiles : item;
-    s_begin = SEG ? seg * a.seg_len : 0;
-    const int s_end = SEG ? min(S, s_begin + a.seg_len) : S;
-    if constexpr (ORD) { if (!seg_wait(a.slab_flags, a.tile_need[item], a.slab_need, a.sched_status)) return; }
-    set_tile(tile);
-    // ---- initial state of this item ----
-    c = zero4();
-    h = zero4();
-    if (seg == 0) {
-      if (dir == 0 && cvalid) {
-        if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
-        if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
-      }
-    } else if constexpr (SEG) {
-      // wait until the previous segment of this tile has published its state.  Flag and state travel as agent-scope
-      // (sc1, write-through / cache-bypassing) accesses ordered by s_waitcnt + barrier -- no release / acquire fences:
-      // those write back / invalidate the whole L2, which is full of this kernel's own record stores.
-      if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return;
-      const float* st = seg_hc + ((size_t)tile * 2 * 16 + j) * H + uoff;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        c[r] = __hip_atomic_load(st + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h[r] = __hip_atomic_load(st + 16 * H + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    // ---- prologue: state and the first two normalised rows into LDS, four rows in flight ----
-    {
-      store_h(s_begin & 1, h);
-      XVec<C> x0 = load_x(s_begin);
-      XVec<C> x1 = load_x(min(s_begin + 1, S - 1));
-      {                                                // running step terms of row s_begin (see their declaration)
-        const int st0 = rev ? S - 1 - s_begin : s_begin;
-        run_x = (int64_t)st0 * a.p_step * C;
-        run_h = (int64_t)st0 * a.p_step * (ndir * H);
-        run_blk = (rec_tile + st0) * ndir + dir;
-        run_x_last = (int64_t)(rev ? 0 : S - 1) * a.p_step * C;
-      }
-      ln_store(x0, s_begin & 1, s_begin, run_x);
-      ln_store(x1, (s_begin + 1) & 1, min(s_begin + 1, S - 1), s_begin + 1 <= S - 1 ? run_x + d_x : run_x_last);
-      xa = load_x(min(s_begin + 2, S - 1));
-      xb = load_x(min(s_begin + 3, S - 1));
-      xc = load_x(min(s_begin + 4, S - 1));
-      xd = load_x(min(s_begin + 5, S - 1));
-    }
-    __syncthreads();
-    x_part(accx, s_begin & 1);
-
-    int s = s_begin;
-    for (; s + 3 < s_end; s += 4) {
-      const XVec<C> ca = xa, cb = xb, cc = xc, cd = xd;
-      xa = load_x(min(s + 6, S - 1));
-      xb = load_x(min(s + 7, S - 1));
-      xc = load_x(min(s + 8, S - 1));
-      xd = load_x(min(s + 9, S - 1));
-      step(s, ca);
-      step(s + 1, cb);
-      step(s + 2, cc);
-      step(s + 3, cd);
-      if (prod) {                                      // y of steps .. s + 2 has been issued
-        while ((next_slab + 1) * a.slab_len <= s + 3) slab_signal(next_slab++);
-      }
-    }
-    if (s < s_end) step(s, xa);
-    if (s + 1 < s_end) step(s + 1, xb);
-    if (s + 2 < s_end) step(s + 2, xc);
-    rec_flush();                                       // records of the last step
-    if constexpr (LIN) {                               // y of the item's last step from the final hidden-state tiles
-      if (linw) {
-#pragma unroll
-        for (int ck = 0; ck < 2; ++ck) {
-          vec8 b[NT];
-#pragma unroll
-          for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[s_end & 1][n][j][32 * ck + 8 * q]);
-          if (ck == 0) yacc = zero4();
-          if constexpr (F16) {
-            yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
-            yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
-            yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
-          }
-        }
-      }
-      store_y(run_x - d_x);                            // (run_x stands at row s_end)
-      if (prod) { while (next_slab * a.slab_len < S) slab_signal(next_slab++); }
-    }
-    // ---- final state: to the caller after the last step, to the next segment otherwise ----
-    if (s_end == S) {
-      if (dir == 0 && cvalid) {
-        if (a.hN) st4(a.hN + (size_t)nc * H + uoff, h);
-        if (a.cN) st4(a.cN + (size_t)nc * H + uoff, c);
-      }
-    } else if constexpr (SEG) {
-      float* st = seg_hc + ((size_t)tile * 2 * 16 + j) * H + uoff;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        __hip_atomic_store(st + r, c[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(st + 16 * H + r, h[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __builtin_amdgcn_s_waitcnt(0);                   // ... acknowledged at the device-coherent level ...
-      __syncthreads();                                 // ... by every wave, before the flag goes up
-      if (tid == 0) __hip_atomic_store(a.seg_flags + tile, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if constexpr (SEG || ORD) __syncthreads();         // LDS tiles are reused by the next item
-  }
-#ifdef SB_PHASE_TIMING
-  if (SAVE == 0 && a.save_u && lane == 0 && blockIdx.x < 4) {
-    float* d = a.save_u + (blockIdx.x * 4 + w) * 8;
-    for (int i = 0; i < 5; ++i) d[i] = (float)tph[i] / S;
-  }
-  if (lane == 0 && blockIdx.x < 4 && (ORD || blockIdx.y == 0)) {
-    const int kind = ORD ? 3 : (LIN && a.ndir == 2) ? 4 : SUM3 ? 2 : LIN ? 1 : 0;
-    for (int i = 0; i < 5; ++i) g_phase_fwd[kind][blockIdx.x * 4 + w][i] = (float)tph[i] / S;
-  }
-#endif
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // BPTT recurrence on the bf16 pipe.  Wave w owns gate rows {g*64 + 16w + 4q + r}; its 16 dgates per lane are the
@@ -2132,126 +1383,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
 #endif
 }
 
+
 }  // namespace
-
-// defined in sb_lstm_stream.hip: dW_ih / dW_hh / db += sum over `rows` partial rows of [256 * (C + 64) + 256] floats
-int sb_launch_stream_reduce(const float* partials, int rows, int64_t ld, int C, float* dW_ih, float* dW_hh, float* db_ih,
-                            float* db_hh, hipStream_t st, int n_extra = 0, const int* ex_off = nullptr,
-                            const int* ex_n = nullptr, float* const* ex_out = nullptr);
-
-// launch helpers used by sb_lstm.hip's C entry points (same argument structs)
-// Number of (tile, time-segment) work items per workgroup slot: pick the segment count k that minimises the makespan
-// ceil(ntiles * k / W) / k (in units of one tile's serial time) plus a small per-hand-off cost.
-static int choose_segments(int ntiles, int W, int S, double* cost_out) {
-  int best = 1;
-  double best_cost = (double)((ntiles + W - 1) / W);
-  for (int k = 2; k <= 16 && S / k >= 24; ++k) {
-    const double cost = (double)(((long)ntiles * k + W - 1) / W) / k + 0.006 * k;
-    if (cost < best_cost - 1e-9) { best_cost = cost; best = k; }
-  }
-  *cost_out = best_cost;
-  return best;
-}
-// one resident workgroup per CU is what the segmented schedule relies on: refuse it when the kernel does not fit a CU
-template <auto Kern, int BS = 256>
-static bool fits_one_per_cu() {
-  static const bool ok = [] {
-    int n = 0;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, Kern, BS, 0) == hipSuccess && n >= 1;
-  }();
-  return ok;
-}
-static int device_cu_count() {
-  static const int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus;
-  }();
-  return n;
-}
-
-int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
-  sb_lstm_fwd_args a = a_in;
-  const int ntiles = (a.nseq + 15) / 16;
-  const bool full = a.nseq % 16 == 0;
-  const bool f16 = a.mma != 2;                      // mma == 2: bf16x6 (fp32-exact class); default fp16x3
-  if (a.aux_f16 && !a.save_c) return -1003;
-  // aux_f16 with save_gates == NULL: records without the gates (the backward recomputes them: sb_lstm_bwd_args.recompute)
-  // rec_f32 with save_gates == NULL: wide records without the gates (c_prev, u and hs pairs only; single direction with the
-  // Linear applied here, so that hs is stored): the backward recomputes the gates
-  if (a.rec_f32 && (!a.save_c || a.aux_f16 || !f16 || (!a.save_gates && (a.ndir != 1 || !a.lin_w || !a.hs)))) return -1003;
-  const int save = a.rec_f32 ? 4 : a.save_gates == nullptr ? (a.save_c && a.aux_f16 ? 3 : 0)
-                                                           : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
-  dim3 grid(ntiles, a.ndir);
-  const bool lin = a.lin_w != nullptr;
-  if (lin && (!f16 || !a.lin_b || !a.y)) return -1003;         // ndir == 2: per-direction partial products (see the kernel)
-  if (a.film_w && (!lin || a.ndir != 1 || !a.film_b)) return -1003;
-  if (!lin && !a.hs) return -1003;
-  // time-segmented scheduling (see the kernel): single direction, scratch provided, more tiles than CUs
-  const int cus = device_cu_count();
-  if (a.sched_workers < 0 || a.sched_segments < 0 || a.sched_workers > cus) return -1003;
-  const int W = a.sched_workers > 0 ? a.sched_workers : cus, kforce = a.sched_segments;
-  bool seg = f16 && a.ndir == 1 && a.seg_state && a.seg_flags && a.sched_status && ntiles >= W &&
-             ((ntiles > W && ntiles <= 2 * W) || kforce > 0);
-  if (seg) {
-    double cost = 0.0;
-    const int k = kforce > 0 ? kforce : choose_segments(ntiles, W, a.nsteps, &cost);
-    // two co-resident tiles per CU cost ~1.4-1.6 T on the CUs that get them; only segment when clearly below that
-    if (k < 2 || (kforce == 0 && cost > 1.30)) seg = false;
-    else {
-      // segment starts on multiples of 4 steps: every step then runs through the same copy of the 4-step unrolled
-      // loop body (or the same tail code) as in the plain schedule, which keeps the two schedules bit-identical
-      a.seg_len = ((a.nsteps + k - 1) / k + 3) & ~3;
-      a.seg_count = (a.nsteps + a.seg_len - 1) / a.seg_len;      // drop empty trailing segments
-      grid.x = W;
-      (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
-    }
-  }
-  if (a.slab_flags && (seg || !lin || !f16 || a.slab_len < 4 || (a.slab_len & 3) || !a.ord_started)) return -1003;
-  if (a.tile_order) {    // consumer side of the overlapped forward: bidirectional partial-Linear pass, ordered 1-D grid
-    if (!a.slab_flags || !a.tile_need || !a.sched_status || !a.ord_counter || !a.ord_started || a.ndir != 2 || a.C != 32 ||
-        (save != 0 && save != 3 && save != 4) || a.ord_grid < 2 || (a.ord_grid & 1))
-      return -1003;
-    dim3 g1(a.ord_grid);
-#define SB_LO(SV, FL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, false, false, true>), g1, dim3(256), 0, st, a)
-    if (save == 0) { if (full) SB_LO(0, true); else SB_LO(0, false); }
-    else if (save == 4) { if (full) SB_LO(4, true); else SB_LO(4, false); }
-    else { if (full) SB_LO(3, true); else SB_LO(3, false); }
-#undef SB_LO
-    return 0;
-  }
-#define SB_L(CC, SV, FL, HF, LN, SG) do { \
-    if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>>()) return -1008; \
-    hipLaunchKernelGGL((lstm_fwd_bf_kernel<CC, SV, FL, HF, LN, SG>), grid, dim3(256), 0, st, a); } while (0)
-  if (a.x_part) {        // summed-input mode: single direction, fused Linear, C = 32, inference or fp16 side outputs
-    if (!lin || a.ndir != 1 || a.C != 32 || (save != 0 && save != 3 && save != 4)) return -1003;
-#define SB_L3(SV, FL, SG) do { \
-    if (SG && !fits_one_per_cu<lstm_fwd_bf_kernel<32, SV, FL, true, true, SG, true>>()) return -1008; \
-    hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, SG, true>), grid, dim3(256), 0, st, a); } while (0)
-#define SB_L3F(SV) do { if (full) { if (seg) SB_L3(SV, true, true); else SB_L3(SV, true, false); } \
-                        else { if (seg) SB_L3(SV, false, true); else SB_L3(SV, false, false); } } while (0)
-    if (save == 0) SB_L3F(0); else if (save == 4) SB_L3F(4); else SB_L3F(3);
-#undef SB_L3F
-#undef SB_L3
-    return 0;
-  }
-#define SB_LT(CC, SV, FL) do { \
-    if (seg) { if (lin) SB_L(CC, SV, FL, true, true, true); else SB_L(CC, SV, FL, true, false, true); } \
-    else if (lin) SB_L(CC, SV, FL, true, true, false); else if (f16) SB_L(CC, SV, FL, true, false, false); \
-    else SB_L(CC, SV, FL, false, false, false); } while (0)
-#define SB_LC(CC) do { \
-    if (save == 0) { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } \
-    else if (save == 1) { if (full) SB_LT(CC, 1, true); else SB_LT(CC, 1, false); } \
-    else if (save == 2) { if (full) SB_LT(CC, 2, true); else SB_LT(CC, 2, false); } \
-    else if (save == 4) { if (full) SB_LT(CC, 4, true); else SB_LT(CC, 4, false); } \
-    else { if (full) SB_LT(CC, 3, true); else SB_LT(CC, 3, false); } } while (0)
-  if (a.C == 32) SB_LC(32); else SB_LC(16);
-#undef SB_LC
-#undef SB_LT
-#undef SB_L
-  return 0;
-}
 
 int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   sb_lstm_bwd_args a = a_in;
@@ -2403,3 +1536,4 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
 #undef SB_B
   return 0;
 }
+
