@@ -206,6 +206,12 @@ typedef struct {
      store it -- sb_lstm_fwd_args.hs == NULL with the Linear fused): its recurrence waves recompute h of a step from the
      records, bit for bit as the forward kernel formed it, and hand it to the chunk waves through LDS. */
   int split;
+  /* WIDE gate recomputation (wide != 0, recompute != 0; the overlapped inter-frame pair sb_lstm_bwd_inter_overlapped /
+     _pair_serial only, single direction, C = C_lin = 32): the forward stored no gate records (sb_lstm_fwd_args.rec_f32 with
+     save_gates == NULL) -- save_gates is ignored and the gates of every step are recomputed from the forward call's u / hs
+     pair tensors (u, hs here), w_ih, w_hh[0], b_ih[0], b_hh[0] with the forward kernel's own three-product arithmetic, bit
+     for bit.  h0 [nseq, 64] (nullable = zeros): the initial hidden state the forward call was given (h_prev of step 0). */
+  const float* h0;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 

@@ -43,7 +43,8 @@ class LstmBwdArgs(C.Structure):
                 ("ln_x", c_fp), ("ln_g", c_fp), ("dx", c_fp), ("d_ln_g", c_fp), ("d_ln_b", c_fp),
                 ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp),
                 ("hs_f16", C.c_int), ("recompute", C.c_int), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
-                ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_started", C.c_void_p), ("wide", C.c_int), ("split", C.c_int)]
+                ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_started", C.c_void_p), ("wide", C.c_int), ("split", C.c_int),
+                ("h0", C.c_void_p)]
 
 
 class WView(C.Structure):

@@ -67,10 +67,18 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 // 50 % stalled, nothing to hide behind), and its 500+ registers force ~500 AGPR copies per pair.  Split, each role fits
 // 256 registers, the chunk role fills the recurrence role's stalls, and the copies are gone.  Both roles pass the same
 // two workgroup barriers per pair: the recurrence's partial-sum exchange barriers double as the hand-over points.
+// GREC (SLAB + XP, single direction, C = 32; sb_lstm_bwd_args.recompute with `wide`): the forward pass stored NO gate records
+// for this layer -- c_prev and the (hi, lo) pair tensors u / hs only, 512 + 128 of the 1536 bytes per position -- and the four
+// gates of a step are recomputed here exactly as the forward kernel formed them: the same scaled weight and bias terms, the
+// same three products per MAC in the same order on the same operand terms (u_s and h_{s-1} ARE the forward's own fp16 pairs),
+// so the recomputed gates are the forward's bit for bit.  36 MFMAs + 16 activations per step and wave, forward weights in
+// registers (96: this kernel runs one wave per SIMD and has them to spare).  The inter-frame forward is store-bound in
+// training: without its 1 KB of gates per position it runs 1.10 -> 0.84 ms, and the backward pair reads 1 KB less.
 template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
-          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false, bool SPLIT = false>
+          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false, bool SPLIT = false, bool GREC = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
   static_assert(!SPLIT || (FST > 0 && !RECOMP && !SLAB), "role split: fused forms");
+  static_assert(!GREC || (SLAB && XP && FUSE_C == 32 && !SPLIT), "wide gate recomputation: overlapped inter-frame recurrence, C = 32");
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, q = lane >> 4, j = lane & 15;
   const bool crole = SPLIT && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;       // chunk role (waves 4..7)
   const int dir = blockIdx.y;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   // k = 8 (lane >> 4) .. + 7 of chunk 0 (W_ih) / 1, 2 (W_hh), scaled like the forward kernel's (activations as rcp(1 + 2^z));
   // BR[gate][unit]: the scaled bias sums
   __shared__ __attribute__((aligned(16))) h16x8 WR[RECOMP ? 4 : 1][RECOMP ? 3 : 1][RECOMP ? 4 : 1][RECOMP ? 64 : 1];
-  __shared__ __attribute__((aligned(16))) float BR[RECOMP ? 4 : 1][RECOMP ? H : 1];
+  __shared__ __attribute__((aligned(16))) float BR[RECOMP || GREC ? 4 : 1][RECOMP || GREC ? H : 1];
   const float* __restrict__ whh = a.w_hh[dir];
   // [out tile ot][chunk]: A[i = out unit 16ot + j][k] = W_hh[gate row(k)][16ot + j].  DG16: the dgates enter the
   // product as the fp16 values that are stored (one term), W_hh as fp16 hi + lo -> 2 MFMAs per tile and chunk
@@ -157,6 +165,31 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     __syncthreads();
   }
 
+  // GREC: the forward kernel's weight terms (its Wt[gate][chunk]: rows gate * 64 + 16 w + j, k = 8q .. 8q + 7 of chunk 0 = W_ih,
+  // chunks 1, 2 = W_hh; activation scale folded in) and bias sums, formed by the same expressions
+  SplitH Wg[GREC ? 4 : 1][GREC ? 3 : 1];
+  if constexpr (GREC) {
+    const float* __restrict__ wih = a.w_ih;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = g * H + 16 * w + j;
+      const float gsc = (g == 2 ? 2.0f : 1.0f) * SB_NLOG2E;
+      float t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = gsc * wih[(size_t)row * FUSE_C + 8 * q + kk];
+      Wg[g][0] = splith8(t);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) t[kk] = gsc * whh[(size_t)row * H + 32 * c + 8 * q + kk];
+        Wg[g][1 + c] = splith8(t);
+      }
+    }
+    if (tid < 4 * H) BR[tid >> 6][tid & 63] = ((tid >> 6) == 2 ? 2.0f : 1.0f) * SB_NLOG2E * (a.b_ih[0][tid] + a.b_hh[0][tid]);
+    __syncthreads();
+  }
+  f32x4 H0h[GREC ? 2 : 1], H0l[GREC ? 2 : 1];     // GREC: the initial hidden state (h_prev of step 0) as operand terms, per tile
+
   // STG: this lane's pieces of a chunk's rows.  Wave w of the chunk role fetches slot rows 8w .. 8w + 7 (step sa - (w >> 1),
   // sequences 8 (w & 1) ..): h rows 8w + (lane >> 4) and 8w + 4 + (lane >> 4), piece lane & 15; u / dy row 8w + (lane >> 3),
   // piece lane & 7 -- so that one wave instruction fills one contiguous KB of LDS
@@ -175,6 +208,17 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     const int nc = tile * 16 + j;
     valid = FULL || nc < a.nseq;
     base = valid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
+    if constexpr (GREC) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) t[kk] = (a.h0 && valid) ? a.h0[(size_t)nc * H + 32 * c + 8 * q + kk] : 0.f;
+        const SplitH sp = splith8(t);
+        H0h[c] = __builtin_bit_cast(f32x4, sp.hi);
+        H0l[c] = __builtin_bit_cast(f32x4, sp.lo);
+      }
+    }
     if constexpr (SLAB) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -780,7 +824,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     }
   };
 
-  struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; h16x4 cp16; h16x8 ub, hb0, hb1; };   // RECOMP: u_s, h_{s-1} as B operands
+  // RECOMP: u_s, h_{s-1} as B operands; GREC: the same as raw 32-byte pieces of the pair tensors (gu: channels 8q .. 8q + 7 as
+  // [hi0 hi1 lo0 lo1] x 4; gh: units 8q .. + 7 of K-chunks 1 and 2 as [hi x 4, lo x 4] x 2 each)
+  struct Raw { f32x4 r0, r1, r2, r3, cp, dh, dy1; h16x4 cp16; h16x8 ub, hb0, hb1; f32x4 gu[2], gh[4]; };
   auto load_raw = [&](int s) {
     Raw r;
     const int st = rev ? S - 1 - s : s;
@@ -808,9 +854,18 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         r.cp16 = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(a.save_c) + blk * (16 * H) + (w * 64 + lane) * 4);
       } else if constexpr (XP) {           // blocked fp32 records of the forward kernel's SAVE == 4
         const int64_t blk = (rec_tile + st) * ndir + dir;
-        const float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
-        r.r0 = ld4(rec); r.r1 = ld4(rec + 256); r.r2 = ld4(rec + 512); r.r3 = ld4(rec + 768);
-        r.cp = ld4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4);
+        if constexpr (GREC) {              // no gate records: the operands of their recomputation instead
+          r.r0 = r.r1 = r.r2 = r.r3 = zero4();
+          const float* up = reinterpret_cast<const float*>(u16 + (pos * FUSE_C + 8 * q) * 2);
+          r.gu[0] = ld4(up); r.gu[1] = ld4(up + 4);
+          const int64_t posp = base + (int64_t)(s > 0 ? st - 1 : st) * a.p_step;      // h_prev: the row of the step before (masked at step 0)
+          const float* hp = reinterpret_cast<const float*>(hs16 + (posp * H + 8 * q) * 2);
+          r.gh[0] = ld4(hp); r.gh[1] = ld4(hp + 4); r.gh[2] = ld4(hp + 32); r.gh[3] = ld4(hp + 36);
+        } else {
+          const float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
+          r.r0 = ld4_rec(rec); r.r1 = ld4_rec(rec + 256); r.r2 = ld4_rec(rec + 512); r.r3 = ld4_rec(rec + 768);
+        }
+        r.cp = ld4_rec(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4);
       } else {
         const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
         r.r0 = ld4(rec); r.r1 = ld4(rec + H); r.r2 = ld4(rec + 2 * H); r.r3 = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
@@ -830,6 +885,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       r.cp16 = h16x4{0, 0, 0, 0};
       r.ub = r.hb0 = r.hb1 = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
+    if constexpr (GREC) { if (!valid) { r.gu[0] = r.gu[1] = r.gh[0] = r.gh[1] = r.gh[2] = r.gh[3] = zero4(); } }
     return r;
   };
 
@@ -844,9 +900,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   // -4 % on the small inter-frame pass, +2..6 % on the others -- the big intra-frame variant crosses 256 VGPRs.)
   auto consume = [&](Raw& raw) {      // pins the s_waitcnt of this record here
     if constexpr (RECOMP) asm volatile("" : "+v"(raw.ub), "+v"(raw.hb0), "+v"(raw.hb1), "+v"(raw.dh));
+    else if constexpr (GREC) asm volatile("" : "+v"(raw.gu[0]), "+v"(raw.gu[1]), "+v"(raw.gh[0]), "+v"(raw.gh[1]), "+v"(raw.gh[2]), "+v"(raw.gh[3]), "+v"(raw.dh));
     else asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.dh));
     if constexpr (REC16) asm volatile("" : "+v"(raw.cp16)); else asm volatile("" : "+v"(raw.cp));
-    if constexpr (!REC16) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
+    if constexpr (!REC16 && !GREC) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
   };
   // SLAB: a step's dgates rows leave one step late -- whole rows (one instruction = 64 lanes x 8 bytes = one row),
@@ -883,6 +940,45 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WR[g][1][w][lane], raw.hb0, z[g], 0, 0, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WR[g][2][w][lane], raw.hb1, z[g], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[r] = sigmoid_pre(z[0][r]);
+        gf[r] = sigmoid_pre(z[1][r]);
+        gg[r] = tanh_pre(z[2][r]);
+        go[r] = sigmoid_pre(z[3][r]);
+      }
+    } else if constexpr (GREC) {
+      // B operands from the pair pieces: u = dwords (0, 2, 4, 6) hi / (1, 3, 5, 7) lo; an h chunk = dwords (0, 1, 4, 5) hi /
+      // (2, 3, 6, 7) lo; step 0 sees the initial state
+      h16x8 bh[3], bl[3];
+      bh[0] = __builtin_bit_cast(h16x8, f32x4{raw.gu[0][0], raw.gu[0][2], raw.gu[1][0], raw.gu[1][2]});
+      bl[0] = __builtin_bit_cast(h16x8, f32x4{raw.gu[0][1], raw.gu[0][3], raw.gu[1][1], raw.gu[1][3]});
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 vh = {raw.gh[2 * c][0], raw.gh[2 * c][1], raw.gh[2 * c + 1][0], raw.gh[2 * c + 1][1]};
+        const f32x4 vl = {raw.gh[2 * c][2], raw.gh[2 * c][3], raw.gh[2 * c + 1][2], raw.gh[2 * c + 1][3]};
+        f32x4 sh, sl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sh[r] = s > 0 ? vh[r] : H0h[c][r]; sl[r] = s > 0 ? vl[r] : H0l[c][r]; }
+        bh[1 + c] = __builtin_bit_cast(h16x8, sh);
+        bl[1 + c] = __builtin_bit_cast(h16x8, sl);
+      }
+      f32x4 z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) z[g] = ld4(&BR[g][uoff]);
+      // the forward kernel's product order (its mma6): per K-chunk  W.lo x.hi, W.hi x.lo, W.hi x.hi, gates round-robin
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wg[g][c].lo, bh[c], z[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x7F6);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wg[g][c].hi, bl[c], z[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x7F6);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wg[g][c].hi, bh[c], z[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0x7F6);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         gi[r] = sigmoid_pre(z[0][r]);
@@ -1412,7 +1508,7 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   // fused streaming part (see the kernel): single direction, fused Linear backward with the same channel count
   const bool fst = a.wpart != nullptr;
   const bool wide = a.wide != 0;                    // fp32 records / u / hs, two-term gradients (see the kernel: XP)
-  if (wide && ((!fst && !a.slab_flags) || !dg16 || a.hs_f16 || a.recompute)) return -1003;
+  if (wide && ((!fst && !a.slab_flags) || !dg16 || a.hs_f16 || (a.recompute && !a.slab_flags))) return -1003;
   if (fst && a.ndir == 2) {                          // bidirectional fused form: persistent workgroups, one per CU
     // hs: not read by the wide role-split C = 32 form (its recurrence role recomputes h: see HREC in the kernel)
     const bool hrec = wide && a.split && a.C == 32 && fc == 32;
@@ -1513,7 +1609,11 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
       return -1003;
 #define SB_SLB(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC, true, false, 0, false, false, false, false, true>), grid, block, 0, st, a)
 #define SB_SLBX(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC, true, false, 0, false, false, false, false, true, true>), grid, block, 0, st, a)
-    if (wide) {
+    if (wide && a.recompute) {                      // no gate records: recomputed from the u / hs pairs (GREC in the kernel)
+      if (fc != 32 || !a.u || !a.hs || !a.w_ih || !a.b_ih[0] || !a.b_hh[0] || !a.save_c) return -1003;
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, false, 32, true, false, 0, false, false, false, false, true, true, false, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, false, 32, true, false, 0, false, false, false, false, true, true, false, true>), grid, block, 0, st, a);
+    } else if (wide) {
       if (fc == 32) { if (full) SB_SLBX(true, 32); else SB_SLBX(false, 32); }
       else { if (full) SB_SLBX(true, 16); else SB_SLBX(false, 16); }
     } else

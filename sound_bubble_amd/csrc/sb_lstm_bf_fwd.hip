@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       if (a.x_sum && lvalid) {
         float* p = a.x_sum + ex + lo_x;
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) p[v] = xv.v[v];
+        for (int v = 0; v < VPT; ++v) st_side(p + v, xv.v[v]);
       }
     }
     if (SAVE && lvalid && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         // wide form: u travels as the fp16 hi + lo terms this kernel's own products use (same bytes as fp32, and the
         // backward kernels take them as matrix operands without a split): [P][C/2][hi0, hi1, lo0, lo1] resp. [P][C][hi, lo]
         _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + 2 * uo;
-        if constexpr (VPT == 2) *reinterpret_cast<h16x4*>(p) = h16x4{(_Float16)uterm[0][0], (_Float16)uterm[0][1], (_Float16)uterm[1][0], (_Float16)uterm[1][1]};
-        else *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)uterm[0][0], (_Float16)uterm[1][0]};
+        if constexpr (VPT == 2) st_side(reinterpret_cast<h16x4*>(p), h16x4{(_Float16)uterm[0][0], (_Float16)uterm[0][1], (_Float16)uterm[1][0], (_Float16)uterm[1][1]});
+        else st_side(reinterpret_cast<h16x2*>(p), h16x2{(_Float16)uterm[0][0], (_Float16)uterm[1][0]});
       } else {
         float* p = a.save_u + uo;
 #pragma unroll
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
             h16x8 hp;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { hp[r] = (_Float16)htv[0][r]; hp[4 + r] = (_Float16)htv[1][r]; }
-            if (a.hs) *reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ho * 2) = hp;
+            if (a.hs) st_side(reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.hs) + ho * 2), hp);
           } else {
             if ((!LIN || a.hs) && !(SB_EXP_SKIP & 4)) st4(a.hs + ho, h);
           }
@@ -282,12 +282,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           // h_prev with the forward weights (sb_lstm_bwd_args.recompute with `wide`)
           if (k < 4 && a.save_gates) {
             float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
-            if (k == 0) st4(rec, rgi);
-            if (k == 1) st4(rec + 256, rgf);
-            if (k == 2) st4(rec + 512, rgg);
-            if (k == 3) st4(rec + 768, rgo);
+            if (k == 0) st4_rec(rec, rgi);
+            if (k == 1) st4_rec(rec + 256, rgf);
+            if (k == 2) st4_rec(rec + 512, rgg);
+            if (k == 3) st4_rec(rec + 768, rgo);
           }
-          if (k == 4) st4(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, rcp);
+          if (k == 4) st4_rec(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, rcp);
         } else {
           // Compact records are private to this kernel and the backward recurrence, which walks the same (tile, step)
           // grid with the same lane ownership, so they are laid out per (tile, step, direction) block in LANE order:
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     if (linw && cvalid && !(SB_EXP_SKIP & 16)) {
       f32x4 v = yacc + lbias + xres;
       if (film) {
-        if (a.y_pre) st4(a.y_pre + ey + co_y, v);
+        if (a.y_pre) st_side(reinterpret_cast<f32x4*>(a.y_pre + ey + co_y), v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], fw[r], fb[r]);
       }

@@ -258,8 +258,11 @@ class InterFn(torch.autograd.Function):
         if film_w is not None:
             assert fuse
             film = (film_w.contiguous(), film_b.contiguous(), torch.empty_like(x) if train else None)
+        # wide mode, C = 32, a geometry whose backward runs as the recurrence + stream-kernel pair: no gate records -- the
+        # backward recurrence recomputes them from the u / hs pairs (ops.inter_gate_recompute_ok)
+        no_gates = bool(train and fuse and ops.inter_gate_recompute_ok(geom, Cc, x.device))
         hs, (hN, cN), gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, [(wi, wh, bi, bh)], geom, h0=h0c, c0=c0c,
-                                              save=train, want_state=True,
+                                              save=train, want_state=True, no_gates=no_gates,
                                               lin=(lin_w.contiguous(), lin_b, y) if fuse else None,
                                               want_hs=train or not fuse,
                                               x_part=part.contiguous() if part is not None else None, x_sum=x_sum,
@@ -273,6 +276,8 @@ class InterFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *[t for t in gates if t is not None])
             ctx.dims = (B, T, F, Cc)
+            ctx.no_gates = gates[0] is None       # (then the one record tensor saved is c_prev)
+            ctx.h0 = h0c if ctx.no_gates else None
             ctx.deferred = part is not None
             ctx.film = (film[0], film[2], bank, film_k) if film is not None else None
         hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
@@ -288,7 +293,7 @@ class InterFn(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dy, _dh, _dc):
         x, ln_g, wi, wh, lin_w, hs, u, ln_b, bi, bh, lin_b, *g_ = ctx.saved_tensors
-        gates = (g_[0], g_[1] if len(g_) > 1 else None)
+        gates = (None, g_[0]) if getattr(ctx, "no_gates", False) else (g_[0], g_[1] if len(g_) > 1 else None)
         gt = _GradTargets()
         B, T, F, Cc = ctx.dims
         P = B * T * F
@@ -323,6 +328,18 @@ class InterFn(torch.autograd.Function):
             ops.linear(dy, lin_w.t().contiguous(), None, dhs, gP, sC, sH, Cc, H)
         # previous hidden state of (b,t,f) is hs[(b,t-1,f)] = position p - F; rows with t == 0 see h0 (zero in training)
         tg = [(gt("wi", wi), gt("wh", wh), gt("bi", bi), gt("bh", bh))]
+        if gates[0] is None:
+            # no gate records (wide gate recomputation): the recurrence + stream-kernel pair is the one backward that can run --
+            # overlapped when the side stream is there, in plain order otherwise
+            assert fuse and ops.BPTT == "wide"
+            args = (wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0], (gt("lin_w", lin_w), gt("lin_b", lin_b)),
+                    (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)))
+            dx = None
+            if ops.can_overlap_inter_bwd(geom, u, hs):
+                dx = ops.lstm_bwd_inter_overlapped(*args, recompute=(bi, bh, ctx.h0))
+            if dx is None:
+                dx = ops.lstm_bwd_inter_overlapped(*args, recompute=(bi, bh, ctx.h0), serial=True)
+            return ret(dx.view(B, T, F, Cc))
         if fuse and ops.BPTT == "wide" and ops.can_overlap_inter_bwd(geom, u, hs):
             # wide form with fewer tiles than CUs: recurrence || stream kernel (two-term dgates through L2) instead of the fused
             # single launch, which would leave the idle CUs idle

@@ -374,9 +374,6 @@ def can_overlap_fwd(B, T, F_, Cc, train, dev):
             and overlap_available())
 
 
-EXP_NO_INTER_GATES = False      # scripts/exp_fwd_nogates.py
-
-
 def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False, lin=None, want_hs=True,
              no_gates=False, x_part=None, x_sum=None, film=None, produce=None, consume=None):
     """x [P, C] pre-LayerNorm.  dirs: list of (w_ih, w_hh, b_ih, b_hh) per direction.
@@ -393,8 +390,6 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     aux16 = bool(save and AUX_FP16 and _compact() and DGATES_FP16 and LSTM_MMA in (1, 2))
     hs16 = aux16 and lin is not None
     wide = bool(save and _wide())
-    if EXP_NO_INTER_GATES and wide and len(dirs) == 1 and lin is not None:
-        no_gates = True
     # wide form: the tensors that only the backward kernels' matrix products read travel as the fp16 (hi, lo) term pairs
     # the forward kernel itself multiplies with -- same bytes as fp32, no split in the backward: u always ([P, 2C] halves),
     # hs when the Linear is applied inside this kernel ([P, ndir * 128] halves); kernel-private layouts (see the header)
@@ -639,6 +634,31 @@ BWD_OVERLAP_SLAB = int(os.environ.get("SB_BWD_OVERLAP_SLAB", "32"))
 BWD_PAIR_SERIAL = os.environ.get("SB_BWD_PAIR_SERIAL", "0") == "1"
 
 
+# Wide gate recomputation for the inter-frame pass (C = 32, the overlapped backward pair): the forward stores c_prev and
+# the u / hs pairs but NO gate records (1 KB of the 2 KB it writes per position), and the backward recurrence recomputes the
+# gates with the forward kernel's own arithmetic, bit for bit.  OPT-IN (SB_INTER_GATE_RECOMPUTE=1), a bytes / memory saver:
+# measured on the big train step (same box) the forward gains 1.0 ms (10.95 -> 9.95 ms: its producer
+# 1.10 -> 0.85 ms) and the backward pair loses 1.8 ms (6 x 1.46 -> 1.76 ms: +36 MFMAs and +170 VALU / copy instructions per
+# step on the serial chain of the recurrence, which IS the pair's critical path) -- 518 -> 500 utterances/s.
+INTER_GATE_RECOMPUTE = os.environ.get("SB_INTER_GATE_RECOMPUTE", "0") == "1"
+INTER_GATE_RECOMPUTE_FORCE = False       # tests: wherever the pair can run at all (tiny geometries: in plain order)
+
+
+def inter_gate_recompute_ok(geom, Cc, dev):
+    """forward-time decision: store no gate records for this single-direction pass?  Only where the backward will run as the
+    recurrence + stream-kernel pair (overlapped when a side stream is there, in plain order otherwise): wide mode, C = 32,
+    fused Linear, and a geometry the pair is chosen for (or merely CAN run on, when forced)."""
+    if not ((INTER_GATE_RECOMPUTE or INTER_GATE_RECOMPUTE_FORCE) and _wide() and LSTM_MMA == 1 and Cc == 32 and can_fuse_linear_fwd() and FUSED_BPTT
+            and BWD_OVERLAP and STREAM_LIN_WGRAD and FUSED_LN_BWD and SCHED_OVERRIDE is None):
+        return False
+    ntiles, cus = (geom.nseq + 15) // 16, _cu_count(dev)
+    if cus - ntiles < 16 or geom.n_inner * geom.nsteps < 32:
+        return False
+    if INTER_GATE_RECOMPUTE_FORCE:
+        return True
+    return OVERLAP_MIN_FILL * cus <= ntiles <= OVERLAP_MAX_FILL * cus and geom.nsteps >= 4 * BWD_OVERLAP_SLAB
+
+
 def can_overlap_inter_bwd(geom, u, hs):
     """the overlapped form pays when the recurrence leaves a good part of the chip idle and has enough slabs to pipeline"""
     if _wide():               # wide form: u / hs are the (hi, lo) pair tensors
@@ -658,7 +678,7 @@ def can_overlap_inter_bwd(geom, u, hs):
             and geom.n_inner * geom.nsteps >= 32 and (BWD_PAIR_SERIAL or overlap_available()))
 
 
-def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets, ln):
+def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets, ln, recompute=None, serial=False):
     """Inter-frame backward of one block, recurrence and streaming part overlapped (see can_overlap_inter_bwd):
     dy [P, C]; u / hs the fp16 side outputs; targets = (dW_ih, dW_hh, db_ih, db_hh), lin_targets = (dW_lin, db_lin),
     ln = (x [P, C], ln_g, d_ln_g, d_ln_b).  -> dx [P, C] = LN-backward(du) + dy (max |dx| left as a hint)."""
@@ -669,16 +689,23 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
     P = geom.P
     F_ = geom.n_inner
     gmax = absmax_or_hint(dy)
-    wide = rec.dtype == torch.float32                  # wide form: dgates rows [hi x 256 | scaled lo x 256] halves
+    wide = cprev.dtype == torch.float32                # wide form: dgates rows [hi x 256 | scaled lo x 256] halves
     dg = torch.empty(P, 1, 8 if wide else 4, H, device=dev, dtype=torch.float16)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 1
     a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
     a.w_hh[0] = _p(w_hh)
-    a.save_gates, a.save_c = C.c_void_p(rec.data_ptr()), C.c_void_p(cprev.data_ptr())
+    a.save_gates, a.save_c = (C.c_void_p(rec.data_ptr()) if rec is not None else None), C.c_void_p(cprev.data_ptr())
     a.dgates, a.gmax, a.mma = C.c_void_p(dg.data_ptr()), _p(gmax), LSTM_MMA
     a.wide = 1 if wide else 0
     a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
+    if recompute is not None:          # (b_ih, b_hh, h0 or None): no gate records -- recomputed from the u / hs pairs
+        assert wide and Cc == 32
+        a.recompute, a.u, a.hs, a.w_ih, a.C = 1, _ph(u), _ph(hs), _p(w_ih), Cc
+        a.b_ih[0], a.b_hh[0] = _p(recompute[0]), _p(recompute[1])
+        a.h0 = _p(recompute[2]) if recompute[2] is not None else None
+    else:
+        assert rec is not None
     s = L.LstmStreamArgs()
     s.P, s.ndir, s.C = P, 1, Cc
     s.shift_pos, s.seg_len, s.skip = F_, geom.nsteps * F_, F_
@@ -700,17 +727,21 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
         s.absmax_out = _p(gm)
     slab = BWD_OVERLAP_SLAB
     flags = torch.empty((geom.nsteps + slab - 1) // slab + 4, device=dev, dtype=torch.int32)      # + 4 control words
-    by = P * ((1280.0 + 3 * 1024.0 + 256 * 2 + 4.0 * Cc if wide else 640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc) + 4 * 4.0 * Cc)
+    serial = serial or BWD_PAIR_SERIAL
+    rec_b = (256.0 + 256.0 + 4.0 * Cc if recompute is not None else 1280.0) if wide else 640.0    # recurrence reads per position
+    by = P * ((rec_b + 3 * 1024.0 + 256 * 2 + 4.0 * Cc if wide else 640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc) + 4 * 4.0 * Cc)
     with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)" + (" [wide]" if wide else "")
-               + (" [in plain order: SB_BWD_PAIR_SERIAL]" if BWD_PAIR_SERIAL else ""),
-               (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc) * P, 8.0 * Cc * P, by):
-        fn = lib.sb_lstm_bwd_inter_pair_serial if BWD_PAIR_SERIAL else lib.sb_lstm_bwd_inter_overlapped
+               + (" [gates recomputed]" if recompute is not None else "")
+               + (" [in plain order]" if serial else ""),
+               (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
+                + (2.0 * 4 * H * (Cc + H) if recompute is not None else 0.0)) * P, 8.0 * Cc * P, by):
+        fn = lib.sb_lstm_bwd_inter_pair_serial if serial else lib.sb_lstm_bwd_inter_overlapped
         rc = fn(C.byref(a), C.byref(s), C.c_void_p(flags.data_ptr()), slab, _stream())
         if rc == -1009:                    # no side stream (any more): the caller takes the two plain launches
             overlap_lost()
             return None
         L.check(rc, "sb_lstm_bwd_inter_overlapped")
-        SCHED_COUNTS["bwd_plain" if BWD_PAIR_SERIAL else "bwd_overlapped"] += 1
+        SCHED_COUNTS["bwd_plain" if serial else "bwd_overlapped"] += 1
     if gm is not None:
         absmax_hint_put(dx, gm)
     return dx

@@ -197,8 +197,11 @@ def test_streaming_matches_reference(torch_gpu, name, cls):
 #                       backward recomputes the gates on the matrix pipe (memory-saving mode).
 # The four above run under SB_BPTT=compact (fp16 BPTT state, opt-in since round 3).  The DEFAULT mode is "wide":
 #   wide             -- fp32 records / side outputs, two-term gradients, the fused kernels (lstm_bwd_rec_bf_kernel<.., XP>);
-#   wide-segmented   -- the same under the time-segmented schedule.
-DISPATCH = ["wide", "wide-segmented", "default", "fused", "fused-segmented", "exact", "recompute"]
+#   wide-segmented   -- the same under the time-segmented schedule;
+#   wide-recompute   -- (round 4) the C = 32 inter-frame passes store no gate records: their backward is the recurrence + stream-
+#                       kernel pair whose recurrence recomputes the gates from the u / hs pairs (GREC) -- forced here on the tiny
+#                       geometry (in plain order or overlapped, whatever the box offers); the headline geometry takes it by itself.
+DISPATCH = ["wide", "wide-segmented", "wide-recompute", "default", "fused", "fused-segmented", "exact", "recompute"]
 COMPACT_MODES = ("default", "fused", "fused-segmented", "recompute")
 
 
@@ -206,6 +209,7 @@ def _set_dispatch(monkeypatch, ops, mode):
     monkeypatch.setattr(ops, "BPTT", "legacy" if mode == "exact" else "wide" if mode.startswith("wide") else "compact")
     monkeypatch.setattr(ops, "GATE_RECOMPUTE", mode == "recompute")
     monkeypatch.setattr(ops, "SCHED_OVERRIDE", (4, 2) if mode.endswith("-segmented") else None)
+    monkeypatch.setattr(ops, "INTER_GATE_RECOMPUTE_FORCE", mode == "wide-recompute")
     if mode in ("fused", "fused-segmented"):
         monkeypatch.setenv("SB_FORCE_FUSED_BPTT", "1")
     else:
@@ -1300,6 +1304,63 @@ def test_wide_overlapped_inter_backward_matches_the_fused_wide_launch(torch_gpu,
     assert dx2 is not None and torch.equal(dx2, dx1)
     for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh", "dW_lin", "db_lin", "d_ln_g", "d_ln_b"),
                             tg2 + list(lin2) + list(ln2), tg1 + list(lin1) + list(ln1)):
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6, name
+
+
+@pytest.mark.parametrize("with_h0", [False, True], ids=["zero-state", "carried-state"])
+@pytest.mark.parametrize("B_,T_,F_", [(2, 150, 21), (1, 37, 16)], ids=["ragged-150", "full-tiles-odd-37"])
+def test_wide_gate_recompute_equals_the_recorded_gates_bit_for_bit(torch_gpu, B_, T_, F_, with_h0, monkeypatch):
+    """Round 4 (record diet): the inter-frame forward with NO gate records (rec_f32 with save_gates == NULL: c_prev + the u / hs
+    pairs) writes the same y / hs / c_prev as with them, and the backward pair whose recurrence recomputes the gates
+    (lstm_bwd_rec_bf_kernel<.., SLAB, XP, GREC>) gives the gradients of the pair that reads recorded gates -- to the BIT:
+    same weight terms, same operand terms, same product order, so the recomputed gates are the forward's own.  Ragged and
+    whole tiles, odd and even step counts, zero and non-zero initial hidden state (h_prev of step 0)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    monkeypatch.setattr(ops, "BPTT", "wide")
+    monkeypatch.setattr(ops, "BWD_PAIR_SERIAL", True)              # plain order: deterministic partial-sum order for the bit compare
+    if not ops.wide_supported("inter", 32):
+        pytest.skip("wide fused kernels switched off")
+    C_ = 32
+    torch.manual_seed(29)
+    geom = ops.Geom.inter(B_, T_, F_)
+    x = torch.randn(geom.P, C_, device="cuda")
+    g, b = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.1
+    wi, wh = torch.randn(256, C_, device="cuda") * 0.2, torch.randn(256, 64, device="cuda") * 0.2
+    bi, bh = torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1
+    lin_w, lin_b = torch.randn(C_, 64, device="cuda") * 0.2, torch.randn(C_, device="cuda") * 0.1
+    h0 = torch.randn(geom.nseq, 64, device="cuda") * 0.5 if with_h0 else None
+    c0 = torch.randn(geom.nseq, 64, device="cuda") * 0.5 if with_h0 else None
+    ya, yb = torch.empty(geom.P, C_, device="cuda"), torch.empty(geom.P, C_, device="cuda")
+    hs_a, _, gates_a, u_a = ops.lstm_fwd(x, g, b, [(wi, wh, bi, bh)], geom, h0=h0, c0=c0, save=True, lin=(lin_w, lin_b, ya))
+    hs_b, _, gates_b, u_b = ops.lstm_fwd(x, g, b, [(wi, wh, bi, bh)], geom, h0=h0, c0=c0, save=True, lin=(lin_w, lin_b, yb),
+                                         no_gates=True)
+    assert gates_a[0] is not None and gates_b[0] is None
+    assert torch.equal(ya, yb) and torch.equal(hs_a, hs_b) and torch.equal(u_a, u_b)
+    if geom.nseq % 16 == 0:            # (ragged tiles: the record rows of sequences beyond nseq are never written)
+        assert torch.equal(gates_a[1], gates_b[1])
+    dy = torch.randn(geom.P, C_, device="cuda") * 0.01 * torch.logspace(-2, 0, geom.P, device="cuda")[:, None]
+
+    def targets():
+        return ([torch.zeros(256, C_, device="cuda"), torch.zeros(256, 64, device="cuda"), torch.zeros(256, device="cuda"),
+                 torch.zeros(256, device="cuda")], (torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")),
+                (torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")))
+
+    tg0, lin0, ln0 = targets()
+    ops.absmax_hints_clear()
+    dx0 = ops.lstm_bwd_inter_overlapped(wh, gates_a, geom, dy, lin_w, u_a, hs_a, wi, tg0, lin0, (x, g, ln0[0], ln0[1]))
+    tg1, lin1, ln1 = targets()
+    ops.absmax_hints_clear()
+    dx1 = ops.lstm_bwd_inter_overlapped(wh, gates_b, geom, dy, lin_w, u_b, hs_b, wi, tg1, lin1, (x, g, ln1[0], ln1[1]),
+                                        recompute=(bi, bh, h0))
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    assert dx0 is not None and dx1 is not None and torch.isfinite(dx1).all() and float(dx1.abs().max()) > 0
+    assert torch.equal(dx1, dx0)               # per-position result: same dgates bits in, same bits out
+    # (the weight gradients are sums of per-workgroup partial rows whose chunk units are drawn from an atomic counter: equal
+    # up to the summation order, as between any two runs of the same pair)
+    for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh", "dW_lin", "db_lin", "d_ln_g", "d_ln_b"),
+                            tg1 + list(lin1) + list(ln1), tg0 + list(lin0) + list(ln0)):
         assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6, name
 
 

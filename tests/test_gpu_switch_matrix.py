@@ -19,7 +19,7 @@ ALL = ["SB_BPTT", "SB_EXACT_BPTT", "SB_NO_ROLE_SPLIT", "SB_NO_HS_RECOMPUTE", "SB
        "SB_NO_FUSED_BPTT", "SB_FORCE_FUSED_BPTT", "SB_LINEAR_FP32", "SB_NO_FWD_OVERLAP", "SB_NO_BWD_OVERLAP",
        "SB_NO_FWD_OVERLAP_INFERENCE", "SB_NO_INTER_SUM3", "SB_NO_INTER_FILM", "SB_NO_STREAM_LIN_WGRAD",
        "SB_NO_INTRA_LIN_FUSION", "SB_GATE_RECOMPUTE", "SB_BWD_PAIR_SERIAL", "SB_FWD_OVERLAP_SLAB", "SB_BWD_OVERLAP_SLAB",
-       "SB_OVERLAP_MAX_FILL", "SB_NO_VEC_LSTM", "SB_NO_INFER_WORKSPACE"]
+       "SB_OVERLAP_MAX_FILL", "SB_NO_VEC_LSTM", "SB_NO_INFER_WORKSPACE", "SB_INTER_GATE_RECOMPUTE"]
 
 # (id, environment, gradient bar): 2e-4 = the wide (default) arithmetic's bar against the goldens, 2e-3 the compact one's
 WIDE, COMPACT = 2e-4, 2e-3
@@ -51,6 +51,9 @@ SWITCHES = [
     ("gate-recompute-compact", {"SB_BPTT": "compact", "SB_GATE_RECOMPUTE": "1"}, COMPACT),
     ("gate-recompute-wide", {"SB_GATE_RECOMPUTE": "1"}, WIDE),     # the compact-mode memory saver must not touch the wide path
     ("bwd-pair-serial", {"SB_BWD_PAIR_SERIAL": "1"}, WIDE),
+    # round 4: the C = 32 inter-frame passes keep no gate records, the backward pair's recurrence recomputes them (opt-in)
+    ("inter-gate-recompute", {"SB_INTER_GATE_RECOMPUTE": "1"}, WIDE),
+    ("inter-gate-recompute-pair-serial", {"SB_INTER_GATE_RECOMPUTE": "1", "SB_BWD_PAIR_SERIAL": "1"}, WIDE),
     ("no-vec-lstm", {"SB_NO_VEC_LSTM": "1"}, WIDE),
     ("no-infer-workspace", {"SB_NO_INFER_WORKSPACE": "1"}, WIDE),
     # every byte the medium stage allocates starts as NaN (debugging aid of the probe): a kernel that reads memory nobody
@@ -125,3 +128,5 @@ def test_switch_keeps_parity(baseline, sid, env, bar):
         assert not any("[producer]" in k for k in big), big
     if sid in ("no-bwd-overlap", "no-overlap-compact"):
         assert not any("inter overlapped" in k for k in big), big
+    if sid.startswith("inter-gate-recompute"):
+        assert any("[gates recomputed]" in k for k in big), big
