@@ -212,8 +212,44 @@ typedef struct {
      pair tensors (u, hs here), w_ih, w_hh[0], b_ih[0], b_hh[0] with the forward kernel's own three-product arithmetic, bit
      for bit.  h0 [nseq, 64] (nullable = zeros): the initial hidden state the forward call was given (h_prev of step 0). */
   const float* h0;
+  /* backward overlapped ACROSS the two passes of a block (set by sb_lstm_bwd_cross_produce / _consume below; leave NULL / 0
+     otherwise).  Consumer side: the item order / slab tables, the per-direction item counters, the guard flag, the number
+     of producer workgroups, the first partial row of this launch and its workgroups per direction; pro_*: the prologue's
+     operands -- dy1 = LN-backward(pro_du; pro_x, pro_ln_g) + pro_res -> pro_dy (which `dy` must point to as well). */
+  const int* tile_order; const int* tile_need; int* ord_counter; int ord_guard, slab_need, row_base, ord_grid;
+  const float* pro_du; const float* pro_x; const float* pro_res; const float* pro_ln_g; float* pro_dy;
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
+
+/* ---- inter-frame backward of a block OVERLAPPED with the intra-frame backward of the same block (round 4) -----------
+ * The wide (sb_lstm_bwd_args.wide) inter-frame backward of the BASELINE big configuration has 145 serial chains on 256 CUs.
+ * As ONE fused role-split launch (wpart != NULL, split != 0: dgates never leave the chip) it needs half the CU time of the
+ * recurrence + stream-kernel pair of sb_lstm_bwd_inter_overlapped, but leaves 111 CUs idle -- and the kernel that follows it
+ * in the backward pass, the bidirectional intra-frame backward of the same block, needs for a tile of 16 frames (b, t .. t +
+ * 15) only the inter-frame result of those frames.  Two calls, the mirror image of sb_lstm_fwd_produce / _consume:
+ *   sb_lstm_bwd_cross_produce(a, flags, slab_len, stream): sb_lstm_bwd_rec of the single-direction fused form (wide, split,
+ *     C = C_lin = 32, du written, no LayerNorm rider, fewer tiles than CUs - 16) on `stream`; its du rows are stored
+ *     write-through and after every slab_len steps (even), latest steps first, each tile t publishes its progress,
+ *     flags[4 + t] = slabs completed (a plain write-through store per tile, not a contended counter per slab).
+ *     flags: [4 + ceil(nseq / 16)] ints, zeroed by the call ([0] producer workgroups started, [1], [2] the consumer's item
+ *     counters, [3] spare).
+ *   sb_lstm_bwd_cross_consume(a, flags, slab_len, producer_tiles, order, need, stream): sb_lstm_bwd_rec of the bidirectional
+ *     fused form (wide, split, C = C_lin = 32, hs == NULL: h recomputed from the records) whose incoming gradient does not
+ *     exist yet: every (tile, direction) item first runs the block's inter-frame LayerNorm backward + residual over its own 16
+ *     nsteps positions, pro_dy = LN-backward(pro_du; pro_x, pro_ln_g) + pro_res (pro_du = the producer's du, a->dy must equal
+ *     pro_dy), deriving its fp16 scale per tile (gmax is not read; pass any valid scalar), and d_ln_g / d_ln_b [32] receive
+ *     that LayerNorm's parameter gradients.  Items are taken in the order order[ntiles] (need[i] packs, for tile order[i], the
+ *     producer slab that completes its frames -- bits 0..11 -- and the range lo..hi of producer tiles that hold the sequences of
+ *     its batch entries -- bits 12..21, 22..31) from one atomic counter per direction by TWO launches: persistent workgroups on the
+ *     library's side stream (one per CU the producer leaves idle, guarded as in sb_lstm_fwd_consume) and one per CU on
+ *     `stream` behind the producer.  wpart: sb_lstm_bwd_cross_rows(a->nseq, producer_tiles) rows of
+ *     256 * (32 + 64) + 256 + 32 * 128 + 32 + 64 floats.  Geometry: p_step == 1, p_inner == nsteps (rows of a tile contiguous).
+ * The consume call must be the next library call after its produce call on that device; memory the producer touches must stay
+ * allocated until it has returned.  -1003 bad geometry / arguments, -1009 without a concurrent side stream. */
+int sb_lstm_bwd_cross_rows(int nseq, int producer_tiles);
+int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a, int* flags, int slab_len, void* stream);
+int sb_lstm_bwd_cross_consume(const sb_lstm_bwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
+                              const int* need, void* stream);
 
 /* ---- position-wise linear (MFMA, weights staged in LDS) -------------------
  * out[p, n] = epi( sum_k in(p, k) * W[n, k] + bias[n] )  for every position

@@ -1,0 +1,7 @@
+#!/bin/bash
+R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
+rm -rf gpurun_out/prof_trace
+cd /tmp && timeout 500 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_trace" -o x -- python "$R/scripts/exp_cross_consume.py" > "$R/gpurun_out/prof_trace.log" 2>&1
+cd "$R"; python scripts/trace_lstm.py gpurun_out/prof_trace 36 > gpurun_out/r4_trace.txt 2>&1
+find gpurun_out -name "*kernel_trace.csv" -size +1M -delete; find gpurun_out -name "*.db" -delete
+cat gpurun_out/r4_trace.txt

@@ -44,7 +44,10 @@ class LstmBwdArgs(C.Structure):
                 ("w_ih1", c_fp), ("dW_ih1", c_fp), ("dW_hh1", c_fp), ("db_ih1", c_fp), ("db_hh1", c_fp),
                 ("hs_f16", C.c_int), ("recompute", C.c_int), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
                 ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_started", C.c_void_p), ("wide", C.c_int), ("split", C.c_int),
-                ("h0", C.c_void_p)]
+                ("h0", C.c_void_p),
+                ("tile_order", C.c_void_p), ("tile_need", C.c_void_p), ("ord_counter", C.c_void_p), ("ord_guard", C.c_int),
+                ("slab_need", C.c_int), ("row_base", C.c_int), ("ord_grid", C.c_int),
+                ("pro_du", c_fp), ("pro_x", c_fp), ("pro_res", c_fp), ("pro_ln_g", c_fp), ("pro_dy", c_fp)]
 
 
 class WView(C.Structure):
@@ -140,6 +143,9 @@ SYMBOLS = {
     "sb_lstm_fwd": (_ci, [C.POINTER(LstmFwdArgs), _vp]),
     "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
     "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),
+    "sb_lstm_bwd_cross_rows": (_ci, [_ci, _ci]),
+    "sb_lstm_bwd_cross_produce": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _vp]),
+    "sb_lstm_bwd_cross_consume": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),
     "sb_lstm_bwd_rec": (_ci, [C.POINTER(LstmBwdArgs), _vp]),
     "sb_linear_fwd": (_ci, [C.POINTER(LinearArgs), _vp]),
     "sb_linear_grid": (_ci, [i64]),

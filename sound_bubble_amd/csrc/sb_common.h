@@ -77,6 +77,12 @@ SB_DEVINL float row16_sum(float v) {
   v = dpp_add<0x140>(v);   // row_mirror
   return v;
 }
+SB_DEVINL float row8_sum(float v) {   // sum over the 8 lanes sharing l >> 3
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  return v;
+}
 SB_DEVINL float wave_sum(float v) {
   v = row16_sum(v);
   return quad_sum(v);

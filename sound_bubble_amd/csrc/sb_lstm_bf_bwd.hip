@@ -1,6 +1,9 @@
 // Backward (BPTT) recurrence of the LSTM passes on the 16-bit matrix pipes, with the streaming part of the backward fused in
 // (see sb_lstm_bf_common.h for the arithmetic): lstm_bwd_rec_bf_kernel and its launcher.  Forward: sb_lstm_bf_fwd.hip.
 #include "sb_lstm_bf_common.h"
+#ifndef SB_EXP_CONS          // developer experiments on the cross-pass overlap (0 in the shipped library): bit 0 consumer without its
+#define SB_EXP_CONS 0        // prologue loop, bit 1 producer with plain (not write-through) du stores, bit 2 producer without slab signals
+#endif
 
 // Phase timing (developer tool): build with -DSB_PHASE_TIMING and pass a scratch buffer (dhs with dy == NULL).
 #ifdef SB_PHASE_TIMING
@@ -74,17 +77,93 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 // so the recomputed gates are the forward's bit for bit.  36 MFMAs + 16 activations per step and wave, forward weights in
 // registers (96: this kernel runs one wave per SIMD and has them to spare).  The inter-frame forward is store-bound in
 // training: without its 1 KB of gates per position it runs 1.10 -> 0.84 ms, and the backward pair reads 1 KB less.
+// Backward overlapped ACROSS the two passes of a block (sb_lstm_bwd_cross_produce / _consume; round 4).  The inter-frame
+// backward has 145 serial chains for 256 CUs; run as the fused role-split kernel (dgates in LDS: no 2 KB per position of dgates
+// traffic, and half the CU time of the recurrence + stream-kernel pair) it leaves 111 CUs idle for 1.3 ms -- which the NEXT
+// kernel of the backward, the intra-frame bidirectional pass of the same block, can use, because a tile of 16 frames only
+// needs the inter-frame pass's result for those frames:
+// PROD (single direction, SPLIT + XP, C = 32): the chunk role stores its du rows write-through (sc1) and the workgroup counts
+//   itself into slab_flags[k] when the du rows of time slab k (slab_len steps, latest first) are on their way -- the protocol of
+//   the overlapped forward's producer.
+// CONS (bidirectional, SPLIT + XP, C = 32): persistent workgroups draw (tile, direction) items in the order tile_order (tiles
+//   sorted by the slab that completes their 16 frames) from one atomic counter per direction -- two launches, one on the
+//   library's side stream next to the producer (guarded) and one behind it, like the overlapped forward's consumer -- wait
+//   (bounded) for that slab, and then run a PROLOGUE over the tile's 16 F positions: the block's inter-frame LayerNorm
+//   backward + residual, dy1 = LN-backward(du; x) + res, which IS this pass's incoming gradient (written to pro_dy for this
+//   workgroup's own readers and for the LayerNorm backward that follows; both directions of a tile write the same values).
+//   Its scale S for the fp16 terms is derived PER TILE from max |dy1| (the running dW sums are rescaled by the power-of-two
+//   ratio when a workgroup moves to its next tile), so no gradient maximum has to be known before the launch.
 template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
-          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false, bool SPLIT = false, bool GREC = false>
+          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false, bool SPLIT = false, bool GREC = false,
+          bool PROD = false, bool CONS = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
+  static_assert(!PROD || (SPLIT && XP && !BI && FST == 32 && !SEG && !LNB), "cross-pass producer: role-split wide single-direction fused form");
+  static_assert(!CONS || (SPLIT && XP && BI && FST == 32 && FUSE_C == 32), "cross-pass consumer: role-split wide bidirectional fused form");
   static_assert(!SPLIT || (FST > 0 && !RECOMP && !SLAB), "role split: fused forms");
   static_assert(!GREC || (SLAB && XP && FUSE_C == 32 && !SPLIT), "wide gate recomputation: overlapped inter-frame recurrence, C = 32");
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, q = lane >> 4, j = lane & 15;
   const bool crole = SPLIT && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;       // chunk role (waves 4..7)
-  const int dir = blockIdx.y;
+  // CONS: 1-D grid, direction = workgroup parity -- whatever subset of a launch the dispatcher has resident, it serves both
+  // directions evenly (with a (workgroups, 2) grid the x index runs first: next to 110 resident side-stream workgroups only
+  // 128 + 18 of the main launch fit, direction 1 was served by 73 workgroups against 183 and set the pace: +50 %)
+  const int dir = CONS ? (int)(blockIdx.x & 1) : (int)blockIdx.y;
   const int S = a.nsteps, ndir = a.ndir;
   const bool rev = dir == 1;
-  if constexpr (SLAB) { if (tid == 0) __hip_atomic_fetch_add(a.slab_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if constexpr (SLAB || PROD) { if (tid == 0) __hip_atomic_fetch_add(a.slab_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  // CONS: wait until the producer tiles lo .. hi (the sequences of this tile's batch entries) have all completed `need` slabs;
+  // bounded like seg_wait (watchdog word), uniform result
+  auto cross_wait = [&](int packed) -> bool {
+    __shared__ int cw_abort;
+    if (tid == 0) {
+      const int need = (packed & 0xFFF) + 1, lo = (packed >> 12) & 0x3FF, hi = (packed >> 22) & 0x3FF;
+      int bad = 0;
+      unsigned spins = 0;
+      for (int t = lo; t <= hi && !bad; ++t) {
+        while (__hip_atomic_load(a.slab_flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          ++spins;
+          if ((spins & 63u) == 0 &&
+              (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(a.sched_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bad = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      cw_abort = bad;
+    }
+    __syncthreads();
+    return cw_abort == 0;
+  };
+  // CONS: the item draw (uniform over the workgroup) and the guard of the launch that runs NEXT to the producer
+  __shared__ int ord_item;
+  __shared__ float pro_red[8];
+  auto ord_next = [&]() -> int {
+    if (tid == 0) ord_item = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int v = ord_item;
+    __syncthreads();                                 // (the next draw may not overwrite it before everybody has read it)
+    return v;
+  };
+  int ord_first = 0;
+  if constexpr (CONS) {
+    bool take = true;
+    if (a.ord_guard) {
+      if (tid == 0) {
+        int ok = 0;
+        for (int i = 0; i < 200 && !ok; ++i) {
+          ok = __hip_atomic_load(a.slab_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.slab_need;
+          if (!ok) __builtin_amdgcn_s_sleep(8);
+        }
+        ord_item = ok;
+      }
+      __syncthreads();
+      take = ord_item != 0;
+      __syncthreads();
+    }
+    // a workgroup that may not (guard) or need not (counter exhausted) work still writes its zero partial row at the end
+    ord_first = take ? ord_next() : (a.nseq + 15) / 16;
+  }
   __shared__ __attribute__((aligned(16))) float P[2][4][4][64][4];
   constexpr int CK = FST > 0 ? FST / 16 : 1, KT = CK + 4;
   __shared__ __attribute__((aligned(16))) _Float16 DG[FST > 0 ? 4 : 1][FST > 0 ? 16 : 1][FST > 0 ? DGP : 8];
@@ -256,7 +335,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   };
   const int uoff = 16 * w + 4 * q;
 
-  const float gS = DG16 ? grad_scale(a.gmax) : 1.0f;
+  float gS = DG16 ? grad_scale(a.gmax) : 1.0f;       // (CONS: re-derived per tile by the prologue)
   // W_lin^T tile of this wave's units (FUSE): A[i = unit 16w + j][k = channel 8q + kk], 2-term split
   bf16x8 Lh, Ll;
   h16x8 Lxh, Lxl;                                   // XP: fp16 hi + lo of the UNSCALED weights (dy carries the scale)
@@ -785,7 +864,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     }
     }
   };
-  const float invS = 1.0f / gS;                    // gS is a power of two
+  float invS = 1.0f / gS;                          // gS is a power of two
   // du rows of a finished chunk (its R[buf] is complete after the barrier that followed it): wave w < 2 CK reduces
   // sub-tile sb = w / CK (step sa - sb), channel tile ct = w % CK
   auto flush = [&](int sa, int nsteps_in_chunk, int buf, const float (&xq)[2], const float (&rq)[2]) {
@@ -819,7 +898,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
                          ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
         const int64_t pos = base + (int64_t)st_of(sa - sb) * a.p_step;
-        st4(a.du + (pos * ndir + dir) * FST + 16 * ct + 4 * q, s4 * invS);
+        if constexpr (PROD && !(SB_EXP_CONS & 2)) st4_sc1(a.du + (pos * ndir + dir) * FST + 16 * ct + 4 * q, s4 * invS);
+        else st4(a.du + (pos * ndir + dir) * FST + 16 * ct + 4 * q, s4 * invS);
       }
     }
   };
@@ -1195,6 +1275,104 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   };
   const int ntiles = (a.nseq + 15) / 16;
   const int nitems = SEG ? ntiles * a.seg_count : ntiles;          // !SEG: gridDim.x == ntiles, one item each
+  // CONS prologue (all 512 threads): dy1 = LN-backward(du; x, gamma) + res over the tile's positions [16 tile nsteps, ..) --
+  // the arithmetic of ln_bwd_kernel<32> (16 lanes per position, two channels per lane) -- its LayerNorm parameter gradients
+  // (direction 0 only: both directions run the same rows), max |dy1| -> this tile's scale S
+  // The LayerNorm parameter sums of a tile go through the (idle between tiles) du exchange buffer R into a 64-float LDS
+  // accumulator: no registers carried through the tile loops of either role (the first version kept 8 per thread and pushed
+  // the kernel from 6 to 74 spilled registers).
+  __shared__ float pro_ln[CONS ? 64 : 1];
+  if constexpr (CONS) { if (tid < 64) pro_ln[tid] = 0.f; }
+  // (chunk_tag: compile-time role of the caller -- the rescaling of the chunk role's running sums must not even be instantiated
+  // in the recurrence role's loop, or its ~110 accumulator registers become live through that loop: 74 spilled registers and a
+  // 45 % slower tile in the first version)
+  auto prologue = [&](int tile, auto chunk_tag) {
+    constexpr bool kChunkRole = decltype(chunk_tag)::value;
+    constexpr int CC = FST > 0 ? FST : 32;
+    static_assert(!CONS || CC == 32, "prologue: 8 lanes x 4 channels per position");
+    const int cp8 = tid & 7;                         // this lane's channels 4 cp8 .. 4 cp8 + 3
+    const int64_t p_lo = (int64_t)tile * 16 * S, p_hi = (int64_t)min(tile * 16 + 16, a.nseq) * S;
+    const f32x4 gam = ld4(a.pro_ln_g + 4 * cp8);
+    float amax = 0.f;
+    f32x4 pdg = zero4(), pdb = zero4();
+    // 64 positions per pass and group of four passes: the 12 sixteen-byte loads of a lane are in flight before the first use
+    constexpr int U = 4;
+    for (int64_t pb = p_lo + (tid >> 3); pb < ((SB_EXP_CONS & 1) ? p_lo : p_hi); pb += 64 * U) {
+      f32x4 g[U], x[U], rs[U];
+#pragma unroll
+      for (int e = 0; e < U; ++e) {
+        const int64_t pp = pb + 64 * e;
+        const int64_t pc = (pp < p_hi ? pp : pb) * CC + 4 * cp8;             // (clamped: rows past the tile are masked below)
+        g[e] = ld4(a.pro_du + pc);
+        x[e] = ld4(a.pro_x + pc);
+        rs[e] = ld4(a.pro_res + pc);
+      }
+#pragma unroll
+      for (int e = 0; e < U; ++e) {
+        const int64_t pp = pb + 64 * e;
+        const bool ok = pp < p_hi;                                           // uniform over the 8 lanes of a position
+        const float mean = row8_sum((x[e][0] + x[e][1]) + (x[e][2] + x[e][3])) * (1.0f / CC);
+        f32x4 d, xh, gg, o;
+        float sq = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { d[v] = x[e][v] - mean; sq += d[v] * d[v]; }
+        const float rstd = 1.0f / sqrtf(row8_sum(sq) * (1.0f / CC) + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          xh[v] = d[v] * rstd;
+          gg[v] = g[e][v] * gam[v];
+          s1 += gg[v];
+          s2 += gg[v] * xh[v];
+          if (ok) { pdg[v] += g[e][v] * xh[v]; pdb[v] += g[e][v]; }
+        }
+        const float m1 = row8_sum(s1) * (1.0f / CC), m2 = row8_sum(s2) * (1.0f / CC);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v] = rstd * (gg[v] - m1 - xh[v] * m2) + rs[e][v];
+        if (ok) {
+          st4(a.pro_dy + pp * CC + 4 * cp8, o);
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
+      }
+    }
+    {                                                // this tile's LayerNorm parameter sums: 64 lane groups -> R
+      float* red = &R[0][0][0][0][0][0];
+      st4(red + (tid >> 3) * 64 + 4 * cp8, pdg);
+      st4(red + (tid >> 3) * 64 + 32 + 4 * cp8, pdb);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) pro_red[tid >> 6] = amax;
+    __builtin_amdgcn_s_waitcnt(0);                   // this wave's dy1 rows are out ...
+    __syncthreads();                                 // ... and so are everybody's: the tile's readers may start
+    if (dir == 0 && tid < 64) {                      // (both directions run the same rows: direction 0 reports the sums)
+      const float* red = &R[0][0][0][0][0][0];
+      float sum = 0.f;
+      for (int g = 0; g < 64; ++g) sum += red[g * 64 + tid];
+      pro_ln[tid] += sum;
+    }
+    float m = pro_red[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, pro_red[i]);
+    const float Sn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
+        (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f)));
+    const float ratio = Sn * invS;                   // a power of two: the running sums move to the new scale exactly
+    gS = Sn;
+    invS = 1.0f / Sn;
+    if constexpr (FST > 0 && kChunkRole) {
+      if (ratio != 1.0f) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) wacc[nt][kt] *= ratio;
+          csum[nt] *= ratio; csumx[nt] *= ratio;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CK; ++ct) { lacc[ct] *= ratio; lbs[ct] *= ratio; }
+      }
+    }
+    __syncthreads();                                 // (pro_red and R are rewritten: the next prologue, this tile's chunks)
+  };
   if constexpr (SPLIT) {
     // Periods of two barriers.  Recurrence role, period k: the two steps of pair k (dgates -> LDS slots 2 (k & 1), + 1); after
     // the last pair one empty period.  Chunk role, period 0: the Linear's top row; period k >= 1: the chunk of pair k - 1
@@ -1204,13 +1382,17 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     // Time segments (SEG): an item is (tile, segment) and walks steps s_hi .. s_lo; the hand-off wait and the state publish
     // carry workgroup barriers of their own, which the chunk role mirrors.
     if (!crole) {
-      for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      for (int item = CONS ? ord_first : (int)blockIdx.x; item < nitems; item = CONS ? ord_next() : item + (int)gridDim.x) {
         const int seg = SEG ? item / ntiles : 0;
-        const int tile = SEG ? item - seg * ntiles : item;
+        const int tile = CONS ? a.tile_order[item] : SEG ? item - seg * ntiles : item;
         const int s_hi = SEG ? S - 1 - seg * a.seg_len : S - 1;
         const int s_lo = SEG ? max(0, s_hi - a.seg_len + 1) : 0;
         const int npairs = (s_hi - s_lo + 2) / 2;                  // the last pair may be a single step
         set_tile(tile);
+        if constexpr (CONS) {                                      // the producer's slab that completes this tile's frames
+          if (!cross_wait(a.tile_need[item])) return;
+          prologue(tile, std::false_type{});
+        }
         dc = zero4();
         dhrec = zero4();
         if constexpr (SEG) {
@@ -1268,15 +1450,19 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         }
         __syncthreads();                                           // between items
       }
-      return;
-    }
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      if constexpr (!CONS) return;                                 // (CONS: the LayerNorm partial sums of this role's threads follow)
+    } else
+    for (int item = CONS ? ord_first : (int)blockIdx.x; item < nitems; item = CONS ? ord_next() : item + (int)gridDim.x) {
       const int seg = SEG ? item / ntiles : 0;
-      const int tile = SEG ? item - seg * ntiles : item;
+      const int tile = CONS ? a.tile_order[item] : SEG ? item - seg * ntiles : item;
       const int s_hi = SEG ? S - 1 - seg * a.seg_len : S - 1;
       const int s_lo = SEG ? max(0, s_hi - a.seg_len + 1) : 0;
       const int npairs = (s_hi - s_lo + 2) / 2;
       set_tile(tile);
+      if constexpr (CONS) {
+        if (!cross_wait(a.tile_need[item])) return;
+        prologue(tile, std::true_type{});
+      }
       if constexpr (SEG) { if (seg > 0) { if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return; } }
       if constexpr (LINW && !HREC) { if (s_hi == S - 1) lin_top(); }
       if constexpr (STG) stage_issue(s_hi, s_hi - 1 >= s_lo, 1, tile);     // the first chunk's rows: read in period 1 (buffer 1)
@@ -1285,6 +1471,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       if constexpr (STG) __builtin_amdgcn_s_waitcnt(0);                    // the first chunk's rows have landed
       __syncthreads();
       int s = s_hi;
+      int slab_fill = 0, slab_idx = 0;                             // PROD: steps flushed into the current slab, its index
 #ifdef SB_PHASE_TIMING
       unsigned long long cph[4] = {0, 0, 0, 0};
 #endif
@@ -1313,6 +1500,20 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         __builtin_amdgcn_sched_barrier(0);
         SB_TICK(q3);
         __syncthreads();
+        if constexpr (PROD) {
+          // every du row down to step (two ? s - 1 : s) is out (the s_waitcnt above drained this role's stores before the
+          // barrier): count the workgroup into the slab that just became complete (slab_len is even; the last one may be short)
+          // One PROGRESS WORD per producer tile (slab_flags[tile] = slabs complete), written through by every lane of the chunk
+          // role in EVERY period, branch-free (same address, same value: one 4-byte write).  Per-slab counters as in the
+          // overlapped forward cost +0.17 ms here, and so did a store behind `if (slab complete)`: the uniform branch cut the
+          // period loop into several basic blocks, and hipcc only pipelines loads / counts its waits inside one.
+          slab_fill += two ? 2 : 1;
+          const bool full = slab_fill >= a.slab_len || k == npairs;
+          slab_idx += full ? 1 : 0;
+          slab_fill = full ? 0 : slab_fill;
+          if constexpr (!(SB_EXP_CONS & 4))
+            __hip_atomic_store(a.slab_flags + tile, slab_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef SB_PHASE_TIMING
         SB_TICK(q4);
         cph[0] += q1 - q0; cph[1] += q2 - q1; cph[2] += q3 - q2; cph[3] += q4 - q3;
@@ -1434,8 +1635,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   if constexpr (FST > 0) {                           // this workgroup's partial row of the weight / bias gradients
     constexpr int Ktot = FST + H;
     constexpr int LW = BI ? 2 * H : H;               // row length of the dW_lin partial: both directions' columns
-    float* part = a.wpart + ((size_t)dir * gridDim.x + blockIdx.x) *
-                  ((size_t)4 * H * Ktot + 4 * H + (LINW ? FST * LW + FST : 0) + (LNB ? 2 * FST : 0));
+    if constexpr (CONS) { if (!crole) return; }      // (the recurrence role came along for the barriers of the draws)
+    float* part = a.wpart + (CONS ? (size_t)a.row_base + (size_t)dir * (gridDim.x >> 1) + (blockIdx.x >> 1)
+                                  : (size_t)dir * gridDim.x + blockIdx.x) *
+                  ((size_t)4 * H * Ktot + 4 * H + (LINW ? FST * LW + FST : 0) + (LNB || CONS ? 2 * FST : 0));
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -1460,6 +1663,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       }
       const float bs = quad_sum(lbs[ct]);              // both directions see every dy row: direction 0 reports the sum
       if (w == 0 && q == 0) plin[(size_t)FST * LW + 16 * ct + j] = dir == 0 ? bs * invS : 0.f;
+    }
+    if constexpr (CONS) {                            // d(ln gamma) [32], d(ln beta) [32] of the prologue's LayerNorm backward
+      const int te = tid & 255;
+      if (te < 64) plin[(size_t)FST * LW + FST + te] = pro_ln[te];
     }
     if constexpr (LNB) {                             // LayerNorm parameter gradients: waves 0 / 1 hold the two steps' sums
       __syncthreads();
@@ -1524,6 +1731,18 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
 #define SB_FBXS(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC_, true, false, CC, false, true, false, false, false, true, true>), g2, dim3(512), 0, st, a)
 #define SB_FBS(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_, false, false, false, true>), g2, dim3(512), 0, st, a)
     if (a.split && a.recompute) return -1003;
+    if (a.tile_order) {
+      // cross-pass consumer (sb_lstm_bwd_cross_consume launches it twice and runs the partial-row reductions itself)
+      if (!wide || !a.split || a.C != 32 || fc != 32 || !a.tile_need || !a.ord_counter || !a.slab_flags || !a.slab_started ||
+          !a.sched_status || a.ord_grid < 1 || !a.pro_du || !a.pro_x || !a.pro_res || !a.pro_ln_g || !a.pro_dy ||
+          a.pro_dy != a.dy || a.p_step != 1 || a.p_inner != a.nsteps || a.row_base < 0)
+        return -1003;
+      dim3 gc(2 * a.ord_grid);                       // direction = workgroup parity (see the kernel)
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, false, 32, true, false, 32, false, true, false, false, false, true, true, false, false, true>), gc, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, false, 32, true, false, 32, false, true, false, false, false, true, true, false, false, true>), gc, dim3(512), 0, st, a);
+      SB_CHECK_LAUNCH();
+      return 0;
+    }
     if (wide && a.split) {                            // role-split workgroups (8 waves): see the kernel
       if (a.C == 16 && fc == 0) { if (full) SB_FBXS(true, 0, 16); else SB_FBXS(false, 0, 16); }
       else if (a.C == 32 && fc == 32) { if (full) SB_FBXS(true, 32, 32); else SB_FBXS(false, 32, 32); }
@@ -1583,6 +1802,11 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16_, CC, true, SG, CC, LB, false, false, false, false, XP_, true>), grid, dim3(512), 0, st, a); } while (0)
 #define SB_FSC(R16_, CC, LB, XP_) do { if (full) { if (seg) SB_FS(true, R16_, CC, true, LB, XP_); else SB_FS(true, R16_, CC, false, LB, XP_); } \
                                        else { if (seg) SB_FS(false, R16_, CC, true, LB, XP_); else SB_FS(false, R16_, CC, false, LB, XP_); } } while (0)
+    if (a.slab_flags) {                               // cross-pass producer (sb_lstm_bwd_cross_produce)
+      if (!a.split || !wide || a.C != 32 || lnb || seg || !a.slab_started || a.slab_len < 2 || (a.slab_len & 1)) return -1003;
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, false, 32, true, false, 32, false, false, false, false, false, true, true, false, true>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, false, 32, true, false, 32, false, false, false, false, false, true, true, false, true>), grid, dim3(512), 0, st, a);
+    } else
     if (a.split && wide) { if (a.C == 16) { if (lnb) SB_FSC(false, 16, true, true); else SB_FSC(false, 16, false, true); } else SB_FSC(false, 32, false, true); }
     else if (a.split) { if (a.C == 16) { if (lnb) SB_FSC(true, 16, true, false); else SB_FSC(true, 16, false, false); } else SB_FSC(true, 32, false, false); }
     else

@@ -1409,6 +1409,86 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
   return rc;
 }
 
+// ---- backward overlapped across the two passes of a block (see the header) ----
+// flags layout as for the forward: [0] producer workgroups started, [1], [2] the consumer's item counters (one per
+// direction), [3] spare, [4 ..] the slab flags
+static void cross_grids(int nseq, int producer_tiles, int* g1, int* g2) {
+  const int ntiles = (nseq + 15) / 16, cus = device_cus();
+  int a = (cus - producer_tiles) / 2, b = cus / 2;     // workgroups PER DIRECTION: next to the producer / behind it
+  if (a < 1) a = 1;
+  if (a > ntiles) a = ntiles;
+  if (b < 1) b = 1;
+  if (b > ntiles) b = ntiles;
+  *g1 = a; *g2 = b;
+}
+extern "C" int sb_lstm_bwd_cross_rows(int nseq, int producer_tiles) {
+  int g1, g2;
+  cross_grids(nseq, producer_tiles, &g1, &g2);
+  return 2 * (g1 + g2);
+}
+
+extern "C" int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a_in, int* flags, int slab_len, void* stream) {
+  if (!a_in || !flags) return -1001;
+  sb_lstm_bwd_args a = *a_in;
+  hipStream_t main_st = (hipStream_t)stream;
+  const int ntiles = (a.nseq + 15) / 16;
+  if (a.ndir != 1 || !a.wide || !a.split || !a.wpart || !a.du || a.dx || slab_len < 2 || (slab_len & 1) ||
+      device_cus() - ntiles < 16)
+    return -1003;
+  SideStream* ss = side_stream(main_st);
+  if (!ss) return -1009;
+  // flags: [0] producer workgroups started, [1], [2] the consumer's item counters, [3] spare, [4 + tile] slabs completed by tile
+  if (hipMemsetAsync(flags, 0, (size_t)(ntiles + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
+  a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_started = flags;
+  a.seg_state = nullptr; a.seg_flags = nullptr;                           // (no time segments under the producer)
+  return sb_lstm_bwd_rec(&a, stream);
+}
+
+extern "C" int sb_lstm_bwd_cross_consume(const sb_lstm_bwd_args* a_in, int* flags, int slab_len, int producer_tiles,
+                                         const int* order, const int* need, void* stream) {
+  if (!a_in || !flags || !order || !need) return -1001;
+  sb_lstm_bwd_args a = *a_in;
+  hipStream_t main_st = (hipStream_t)stream;
+  if (a.ndir != 2 || !a.wide || !a.split || a.C != 32 || !a.dy || a.C_lin != 32 || !a.sched_status || !a.wpart ||
+      !a.d_ln_g || !a.d_ln_b || device_cus() - producer_tiles < 16 || slab_len < 2)
+    return -1003;
+  SideStream* ss = side_stream(main_st);
+  if (!ss) return -1009;
+  int g1, g2;
+  cross_grids(a.nseq, producer_tiles, &g1, &g2);
+  a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_need = producer_tiles; a.slab_started = flags;
+  a.tile_order = order; a.tile_need = need; a.ord_counter = flags + 1;
+  // next to the producer: one persistent workgroup (8 waves, 256 registers each: none fits on a producer's CU) per idle CU;
+  // one that cannot be placed at once starts later and draws fewer items
+  if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
+  a.ord_guard = 1; a.ord_grid = g1; a.row_base = 0;
+  int rc = sb_lstm_bwd_rec(&a, ss->s);
+  if (rc) return rc;
+  if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
+  // behind the producer on `stream` (every flag up): the same kernel taking what is left; then the join
+  a.ord_guard = 0; a.ord_grid = g2; a.row_base = 2 * g1;
+  rc = sb_lstm_bwd_rec(&a, stream);
+  if (hipStreamWaitEvent(main_st, ss->join, 0) != hipSuccess) return -1009;
+  if (rc) return rc;
+  // partial rows: [launch][direction][workgroup]; row = LSTM part, dW_lin [32][128] + db_lin [32], d(ln gamma / beta) [64]
+  const int C = a.C;
+  const int64_t ld = (int64_t)4 * H * (C + H) + 4 * H + C * 2 * H + C + 2 * C;
+  const float* base[2] = {a.wpart, a.wpart + (size_t)2 * g1 * ld};
+  const int gx[2] = {g1, g2};
+  for (int l = 0; l < 2 && !rc; ++l) {
+    rc = sb_launch_stream_reduce(base[l], gx[l], ld, C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, main_st, 0, nullptr, nullptr, nullptr);
+    if (!rc) rc = sb_launch_stream_reduce(base[l] + (size_t)gx[l] * ld, gx[l], ld, C, a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1, main_st, 0, nullptr, nullptr, nullptr);
+  }
+  const float* plin = a.wpart + (size_t)4 * H * (C + H) + 4 * H;
+  const int rows = 2 * (g1 + g2);
+  if (!rc && a.dW_lin) rc = sb_reduce_rows(plin, rows, ld, C * 2 * H, a.dW_lin, main_st);
+  if (!rc && a.db_lin) rc = sb_reduce_rows(plin + C * 2 * H, rows, ld, C, a.db_lin, main_st);
+  if (!rc) rc = sb_reduce_rows(plin + C * 2 * H + C, rows, ld, C, a.d_ln_g, main_st);
+  if (!rc) rc = sb_reduce_rows(plin + C * 2 * H + 2 * C, rows, ld, C, a.d_ln_b, main_st);
+  return rc;
+}
+
 // shared with the fused backward recurrence (sb_lstm_bf.hip), which emits the same partial rows
 int sb_launch_stream_reduce(const float* partials, int rows, int64_t ld, int C, float* dW_ih, float* dW_hh, float* db_ih,
                             float* db_hh, hipStream_t st, int n_extra, const int* ex_off, const int* ex_n,

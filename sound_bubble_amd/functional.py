@@ -128,13 +128,18 @@ class IntraPlainFn(torch.autograd.Function):
     optim/tfgridnet_causal.py:699-707."""
 
     @staticmethod
-    def forward(ctx, x, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, lin_w, lin_b, defer_sum=False, ovl=None):
+    def forward(ctx, x, ln_g, ln_b, wif, whf, bif, bhf, wir, whr, bir, bhr, lin_w, lin_b, defer_sum=False, ovl=None,
+                next_ln_g=None, next_ln_b=None):
         """defer_sum: return the two per-direction partial products `part` [B, T, F, 2, C] instead of
         y = x + part[..., 0, :] + part[..., 1, :]; the InterFn that follows forms the sum in its loader (and owns the
         residual's forward); the gradient that comes back for `part` is the gradient of that sum, broadcast.
         ovl (ops.FwdOverlap): x is being produced by the preceding InterFn's kernel right now -- this pass starts behind it
-        on the idle CUs (overlapped forward)."""
+        on the idle CUs (overlapped forward).
+        next_ln_g / next_ln_b (with defer_sum): the LayerNorm parameters of the InterFn that follows -- not used in the forward;
+        when the backward is overlapped across the two passes (ops.CrossBwd) this node's kernel runs that LayerNorm's backward
+        and returns its parameter gradients."""
         B, T, F, Cc = x.shape
+        ctx.next_ln = (next_ln_g, next_ln_b)
         x = x.contiguous()
         P = B * T * F
         train = GRAD_MODE and any(ctx.needs_input_grad)
@@ -187,6 +192,15 @@ class IntraPlainFn(torch.autograd.Function):
         P = B * T * F
         if ctx.defer_sum:                      # [B, T, F, 2, C], both halves equal (a stride-0 broadcast): take one
             dy = dy[..., 0, :]
+        pend = ops.CROSS_PENDING.pop(dy.data_ptr(), None) if ops.CROSS_PENDING else None
+        if pend is not None:                   # the gradients of the following InterFn's LayerNorm parameters are formed HERE
+            nlg, nlb = ctx.next_ln
+            pend.d_ln_g, pend.d_ln_b = gt("next_ln_g", nlg), gt("next_ln_b", nlb)
+        else:
+            gt.ret["next_ln_g"] = gt.ret["next_ln_b"] = None
+        if pend is not None and not dy.is_contiguous():
+            pend.materialize()
+            pend = None
         dy = dy.contiguous()
         geom = Geom.intra(B * T, F)
         gP, sC = dense(P, Cc)
@@ -200,11 +214,21 @@ class IntraPlainFn(torch.autograd.Function):
         # BPTT
         tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
               (gt("wir", wir), gt("whr", whr), gt("bir", bir), gt("bhr", bhr))]
+        if pend is not None and not (fuse and Cc == 32 and hs is None and gates[0] is not None and ops.can_fuse_stream_bi(u, hs)):
+            pend.materialize()                 # (the overlapped consumer is not available for this node after all)
+            pend = None
         if fuse and Cc == 32 and ops.can_fuse_stream_bi(u, hs):
             # recurrence + streaming part + the Linear's weight gradient in one launch (dgates stay in LDS)
-            du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w,
-                                       lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)),
-                                       biases=[(bif, bhf), (bir, bhr)])
+            du = None
+            if pend is not None:               # ... started next to the inter-frame backward that is producing its input (dy) right now
+                du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w,
+                                           lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)), consume=pend)
+                if du is None:
+                    pend.materialize()
+            if du is None:
+                du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w,
+                                           lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)),
+                                           biases=[(bif, bhf), (bir, bhr)])
         else:
             ops.wgrad(dy, Cc, Cc, hs, s2H, gP, 2 * H, gt("lin_w", lin_w), dbias=gt("lin_b", lin_b))
             dg = ops.lstm_bwd_rec([whf, whr], gates, dhs, geom, dy=dy.view(P, Cc) if fuse else None,
@@ -215,7 +239,7 @@ class IntraPlainFn(torch.autograd.Function):
                                  hint=True)
         dx = dx.view(B, T, F, Cc)
         return (dx, gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"], gt["wir"], gt["whr"], gt["bir"],
-                gt["bhr"], gt["lin_w"], gt["lin_b"], None, None)
+                gt["bhr"], gt["lin_w"], gt["lin_b"], None, None, gt["next_ln_g"], gt["next_ln_b"])
 
 
 class InterFn(torch.autograd.Function):
@@ -339,6 +363,28 @@ class InterFn(torch.autograd.Function):
                 dx = ops.lstm_bwd_inter_overlapped(*args, recompute=(bi, bh, ctx.h0))
             if dx is None:
                 dx = ops.lstm_bwd_inter_overlapped(*args, recompute=(bi, bh, ctx.h0), serial=True)
+            return ret(dx.view(B, T, F, Cc))
+        if (fuse and ops.BPTT == "wide" and ctx.deferred and gates[0] is not None
+                and ops.can_cross_overlap_bwd(geom, Cc, u, hs)):
+            # Backward overlapped across the two passes of the block: this pass as ONE fused role-split launch on its 145 CUs,
+            # publishing du slab by slab; the intra-frame backward of the same block (the next autograd node: `deferred` says its
+            # forward handed us the two halves) starts on the idle CUs and forms dx = LN-backward(du) + dy itself, tile by tile.
+            # What goes back through autograd is the dx BUFFER, filled by that kernel (ops.CROSS_PENDING carries the rest).
+            slab = ops.BWD_CROSS_SLAB
+            flags = torch.empty((geom.nseq + 15) // 16 + 4, device=dy.device, dtype=torch.int32)
+            du, overlapped, keep = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
+                                                      lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)),
+                                                      produce=(flags, slab))
+            dx = torch.empty(P, Cc, device=dy.device, dtype=torch.float32)
+            order, need = ops._cross_order(B, T, F, slab, dy.device)
+            pend = ops.CrossBwd(flags, slab, (geom.nseq + 15) // 16, order, need, du, x.view(P, Cc), dy.view(P, Cc), ln_g,
+                                None, None, dx, keep + [flags, du, x, dy, ln_g])
+            if overlapped:                     # (this LayerNorm's parameter gradients come out of the consumer node: IntraPlainFn)
+                ops.CROSS_PENDING[dx.data_ptr()] = pend
+                gt.ret["ln_g"] = gt.ret["ln_b"] = None
+            else:
+                pend.d_ln_g, pend.d_ln_b = gt("ln_g", ln_g), gt("ln_b", ln_b)
+                pend.materialize()
             return ret(dx.view(B, T, F, Cc))
         if fuse and ops.BPTT == "wide" and ops.can_overlap_inter_bwd(geom, u, hs):
             # wide form with fewer tiles than CUs: recurrence || stream kernel (two-term dgates through L2) instead of the fused

@@ -272,9 +272,13 @@ class _NetBase(nn.Module):
                 # the sum x + part0 + part1 that finishes the intra-frame Linear is formed by the inter-frame kernel's loader
                 defer = (Fn.ops.INTER_SUM3 and y.shape[-1] == 32 and
                          Fn.ops.intra_lin_fusion_ok(torch.is_grad_enabled(), y.shape[-1], y.shape[0] * y.shape[1]))
+                # (the inter-frame LayerNorm's parameters ride along when the sum is deferred: with the backward overlapped
+                # across the two passes it is THIS node's kernel that runs that LayerNorm's backward and owns its gradients)
                 part = Fn.IntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
                                              *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
-                                             blk.intra_linear.bias, defer, ovl)
+                                             blk.intra_linear.bias, defer, ovl,
+                                             blk.inter_norm.norm.weight if defer else None,
+                                             blk.inter_norm.norm.bias if defer else None)
                 if not defer:
                     y, part = part, None
             b = gb[f"buf{i}"]

@@ -777,7 +777,76 @@ def can_fuse_stream(u, hs, geom=None):
     return ok
 
 
-def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets=None, ln=None):
+# Backward overlapped ACROSS the two passes of a block (round 4): the inter-frame backward as ONE fused role-split launch on its
+# 145 CUs (producer) and the intra-frame bidirectional backward of the same block on the CUs it leaves idle, tile by tile as the
+# producer's time slabs complete (consumer, with the block's inter-frame LayerNorm backward as its per-tile prologue).
+# SB_NO_BWD_CROSS_OVERLAP=1: the recurrence + stream-kernel pair / plain order as before.
+BWD_CROSS_OVERLAP = os.environ.get("SB_NO_BWD_CROSS_OVERLAP", "0") != "1"
+BWD_CROSS_SLAB = int(os.environ.get("SB_BWD_CROSS_SLAB", "32"))
+CROSS_PENDING = {}        # data_ptr of the (not yet computed) dy1 buffer -> CrossBwd, from InterFn.backward to IntraPlainFn.backward
+
+
+class CrossBwd:
+    """hand-over between the two autograd nodes of a block: what the consumer's prologue needs, and everything the producer
+    touches (kept allocated until the consumer has been enqueued: the side stream is not ordered after later main-stream work)"""
+
+    def __init__(self, flags, slab, producer_tiles, order, need, du, x, res, ln_g, d_ln_g, d_ln_b, dy1, keep):
+        self.flags, self.slab, self.producer_tiles, self.order, self.need = flags, slab, producer_tiles, order, need
+        self.du, self.x, self.res, self.ln_g, self.d_ln_g, self.d_ln_b, self.dy1, self.keep = du, x, res, ln_g, d_ln_g, d_ln_b, dy1, keep
+
+    def materialize(self):
+        """plain order after all: dy1 by the LayerNorm-backward kernel on the current stream (behind the producer)"""
+        ln_bwd(self.du.view(-1, 1, self.du.shape[-1]), self.x, self.ln_g, res=self.res, d_g=self.d_ln_g, d_b=self.d_ln_b,
+               out=self.dy1)
+        self.keep.clear()
+
+
+def cross_tile_order_np(B, T, F_, slab):
+    """intra-frame tiles (16 consecutive frames n = b T + t) sorted by the slab of the inter-frame BACKWARD (which walks t from
+    T - 1 down: slab k covers steps T - 1 - k slab .. ) that completes them -> (order [ntiles] int32, packed [ntiles] int32):
+    packed[i] = need | lo << 12 | hi << 22 for tile order[i], lo .. hi the inter-frame (producer) tiles -- 16 consecutive
+    sequences b F + f -- that hold the sequences of the tile's batch entries"""
+    import numpy as np
+    n = np.arange((B * T + 15) // 16 * 16).reshape(-1, 16)
+    ok = n < B * T
+    need = np.where(ok, (T - 1 - n % T) // slab, 0).max(axis=1)
+    b = np.minimum(n // T, B - 1)
+    lo = (b.min(axis=1) * F_) // 16
+    hi = (b.max(axis=1) * F_ + F_ - 1) // 16
+    assert need.max() < 4096 and hi.max() < 1024
+    order = np.argsort(need, kind="stable")
+    packed = need | (lo << 12) | (hi << 22)
+    return order.astype(np.int32), packed[order].astype(np.int32)
+
+
+_CROSS_ORDER = {}
+
+
+def _cross_order(B, T, F_, slab, dev):
+    key = (B, T, F_, slab, dev.index if dev.index is not None else torch.cuda.current_device())
+    r = _CROSS_ORDER.get(key)
+    if r is None:
+        order, need = cross_tile_order_np(B, T, F_, slab)
+        r = _CROSS_ORDER[key] = (torch.from_numpy(order).to(dev), torch.from_numpy(need).to(dev))
+    return r
+
+
+def can_cross_overlap_bwd(geom, Cc, u, hs):
+    """inter-frame geometry `geom` (B F sequences x T steps): run its backward as the cross-pass producer?  Needs the wide
+    role-split kernels of both passes (C = 32, h recomputed from the records in the bidirectional one), an under-filled
+    producer and a side stream that really runs beside the main one."""
+    if not (BWD_CROSS_OVERLAP and _wide() and LSTM_MMA == 1 and Cc == 32 and ROLE_SPLIT and FUSED_BPTT and FUSED_BPTT_BI
+            and HS_FROM_RECORDS and INTRA_LIN_FUSION and can_fuse_linear_bwd() and SCHED_OVERRIDE is None
+            and u is not None and hs is not None and u.dtype == torch.float16 and hs.dtype == torch.float16):
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    ntiles, cus = (geom.nseq + 15) // 16, _cu_count(u.device)
+    return (OVERLAP_MIN_FILL * cus <= ntiles <= OVERLAP_MAX_FILL * cus and cus - ntiles >= 16
+            and geom.nsteps >= 4 * BWD_CROSS_SLAB and overlap_available())
+
+
+def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets=None, ln=None, produce=None):
     """Backward of a single-direction LSTM whose Linear is fused (see lstm_fwd(lin=...)): recurrence + streaming part in
     one launch.  dy [P, C]; u [P, C], hs [P, 64] fp16 side outputs of the forward; targets = (dW_ih, dW_hh, db_ih,
     db_hh), lin_targets = (dW_lin [C, 64], db_lin [C]) (optional): accumulated into.
@@ -803,7 +872,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
     ntiles = (geom.nseq + 15) // 16
     seg_scratch = None
-    if TIME_SEGMENTS:
+    if TIME_SEGMENTS and produce is None:
         seg_scratch = _seg_scratch(a, geom, dev)
     du = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32)
     wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H + Cc * H + Cc + (2 * Cc if ln is not None else 0), device=dev,
@@ -823,8 +892,19 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
           + hs.numel() * hs.element_size() + u.numel() * u.element_size())
     fl = (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc + 2.0 * H * Cc) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else "")
-               + (" [wide]" if a.wide else "") + (" [role-split]" if a.split else ""),
+               + (" [wide]" if a.wide else "") + (" [role-split]" if a.split else "")
+               + (" [cross-pass producer]" if produce is not None else ""),
                fl, 8.0 * Cc * geom.P, by):
+        if produce is not None:            # (flags, slab): publish du slab by slab for the intra-frame backward of the same block
+            rc = lib.sb_lstm_bwd_cross_produce(C.byref(a), C.c_void_p(produce[0].data_ptr()), produce[1], _stream())
+            if rc == -1009:                # no side stream (any more): the plain launch; the caller materialises dy1 itself
+                overlap_lost()
+                L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
+                SCHED_COUNTS["bwd_plain"] += 1
+                return du, False, [wpart, gmax, seg_scratch]
+            L.check(rc, "sb_lstm_bwd_cross_produce")
+            SCHED_COUNTS["bwd_overlapped"] += 1
+            return du, True, [wpart, gmax, dy, u, hs, rec, cprev, w_hh, w_lin, w_ih]
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
     SCHED_COUNTS["bwd_plain"] += 1
     return du
@@ -908,7 +988,7 @@ def add3(x, part):
 
 
 def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=None, dy=None, w_lin=None, gmax=None,
-                      lin_targets=None, biases=None):
+                      lin_targets=None, biases=None, consume=None):
     """Backward of a bidirectional LSTM pass, recurrence + streaming part in one launch (persistent workgroups, dgates in
     LDS).  Incoming gradient: dhs [P, 128], or dy [P, C] with w_lin [C, 128] (fused Linear backward, C == 32).
     u [P, C] fp16, hs [P, 128] fp32; targets[d] = (dW_ih, dW_hh, db_ih, db_hh) accumulated into.  -> du [P, 2, C]"""
@@ -917,7 +997,9 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     dev = u.device
     Cc = w_ih_list[0].shape[1]
     assert can_fuse_stream_bi(u, hs) and cprev is not None and len(w_hh_list) == 2
-    if gmax is None:
+    if consume is not None:       # (CrossBwd) dy does not exist yet: the kernel's per-tile prologue forms it and its own scale
+        gmax = zero_scalar(dev)
+    elif gmax is None:
         gmax = absmax_or_hint(dy if dy is not None else dhs)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 2
@@ -941,9 +1023,11 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
         a.dhs = _p(dhs)
     ntiles = (geom.nseq + 15) // 16
     rows = 2 * min(ntiles, max(1, _cu_count(dev) // 2))
+    if consume is not None:
+        rows = lib.sb_lstm_bwd_cross_rows(geom.nseq, consume.producer_tiles)
     du = torch.empty(geom.P, 2, Cc, device=dev, dtype=torch.float32)
-    wpart = torch.empty(rows, 4 * H * (Cc + H) + 4 * H + (Cc * 2 * H + Cc if dy is not None else 0), device=dev,
-                        dtype=torch.float32)
+    wpart = torch.empty(rows, 4 * H * (Cc + H) + 4 * H + (Cc * 2 * H + Cc if dy is not None else 0)
+                        + (2 * Cc if consume is not None else 0), device=dev, dtype=torch.float32)
     if lin_targets is not None:          # (dW_lin [C, 128], db_lin [C]) of the fused Linear (dy form only)
         assert dy is not None and lin_targets[0].shape == (Cc, 2 * H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
@@ -959,9 +1043,26 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
                     + 8.0 * Cc) + (hs.numel() * hs.element_size() if hs is not None else 0) + u.numel() * u.element_size())
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
+    if consume is not None:
+        assert a.wide and a.split and dy is not None and dy.data_ptr() == consume.dy1.data_ptr() and hs is None
+        a.pro_du, a.pro_x, a.pro_res, a.pro_ln_g, a.pro_dy = (_p(consume.du), _p(consume.x), _p(consume.res), _p(consume.ln_g),
+                                                              _p(consume.dy1))
+        a.d_ln_g, a.d_ln_b = _p(consume.d_ln_g), _p(consume.d_ln_b)
+        a.sched_status = C.c_void_p(sched_status(dev).data_ptr())
+        by += geom.P * 4 * 4.0 * Cc                                   # the prologue: du, x, res in, dy1 out (per direction: twice)
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} intra-frame fused BPTT (bidirectional, persistent)" + (" [wide]" if a.wide else "")
-               + (" [role-split]" if a.split else ""), fl,
+               + (" [role-split]" if a.split else "") + (" [cross-pass consumer, overlapped]" if consume is not None else ""), fl,
                8.0 * Cc * geom.P, by):
+        if consume is not None:
+            rc = lib.sb_lstm_bwd_cross_consume(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
+                                               consume.producer_tiles, C.c_void_p(consume.order.data_ptr()),
+                                               C.c_void_p(consume.need.data_ptr()), _stream())
+            if rc == -1009:                # the side stream went away between the two calls: plain order
+                overlap_lost()
+                return None
+            L.check(rc, "sb_lstm_bwd_cross_consume")
+            consume.keep.clear()
+            return du
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused, bidirectional)")
     return du
 
@@ -1027,7 +1128,7 @@ def lstm_bwd_stream(dg, u, hs, w_ih_list, shift_pos, seg_len, skip, targets=None
     return grads, du
 
 
-def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=None, hint=False):
+def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=None, hint=False, out=None):
     """LayerNorm(+PReLU) backward.  du_part [P, ndir, C] (summed over ndir), xin [P, C] pre-LN input.
     -> out [P, C], d_ln_g [C], d_ln_b [C], d_prelu [1] or None  (d_g / d_b / d_a: optional accumulation targets)"""
     lib = L.load()
@@ -1035,7 +1136,7 @@ def ln_bwd(du_part, xin, ln_g, prelu_a=None, res=None, d_g=None, d_b=None, d_a=N
     P = xin.numel() // Cc
     ndir = du_part.numel() // (P * Cc)
     dev = xin.device
-    out = torch.empty(P, Cc, device=dev, dtype=torch.float32)
+    out = torch.empty(P, Cc, device=dev, dtype=torch.float32) if out is None else out
     ng = lib.sb_ln_bwd_grid(P)
     partials = torch.empty(ng, 2 * Cc + 1, device=dev, dtype=torch.float32)
     a = L.LnBwdArgs()

@@ -1307,6 +1307,55 @@ def test_wide_overlapped_inter_backward_matches_the_fused_wide_launch(torch_gpu,
         assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6, name
 
 
+@pytest.mark.parametrize("B_,T_", [(2, 150), (3, 131)], ids=["B2-T150", "B3-T131-ragged"])
+def test_cross_pass_overlapped_backward_matches_the_plain_order(torch_gpu, B_, T_, monkeypatch):
+    """Round 4: sb_lstm_bwd_cross_produce / _consume -- a block's inter-frame backward as one fused role-split launch publishing
+    du slab by slab (latest steps first), the intra-frame bidirectional backward of the SAME block drawing its (tile, direction)
+    items next to and behind it, each forming its own incoming gradient dy1 = LN-backward(du) + dy in a per-tile prologue and
+    deriving its fp16 scale from it -- against the plain launch order (fused kernel, LayerNorm-backward kernel, bidirectional
+    kernel with a global scale) on the big-family model: loss and every parameter gradient.  T = 131 x B = 3: tiles that straddle
+    batch entries and a ragged last tile, an odd step count with a short last slab."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    rec, params, m = _build(torch, "tiny_big", "NetDisEmbd3")
+    torch.manual_seed(7)
+    x = (0.1 * torch.randn(B_, rec["mixture"].shape[1], 192 * T_ + 96)).cuda()
+    dis = torch.eye(3)[torch.arange(B_) % 3].cuda()
+    tgt = (0.05 * torch.randn(B_, 1, 192 * T_)).cuda()
+    if not ops.overlap_available():
+        pytest.skip("no side stream that runs concurrently with the main stream on this box")
+    monkeypatch.setattr(ops, "OVERLAP_MIN_FILL", 0.0)           # 19 / 28 inter-frame tiles here
+    monkeypatch.setattr(ops, "BPTT", "wide")
+    m.train()
+
+    def run(cross):
+        monkeypatch.setattr(ops, "BWD_CROSS_OVERLAP", cross)
+        monkeypatch.setattr(ops, "BWD_OVERLAP", False)          # reference order: fused inter-frame launch + LayerNorm-backward kernel
+        for p_ in m.parameters():
+            p_.grad = None
+        ops.PROFILE = {}
+        loss, _ = SnrlpLossFn.apply(m({"mixture": x, "dis_embed": dis}, pad=False)["output"], tgt, 100.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        labels, ops.PROFILE = list(ops.PROFILE), None
+        ops.check_sched_status()
+        assert not ops.CROSS_PENDING
+        return float(loss), {k: p_.grad.clone() for k, p_ in m.named_parameters()}, labels
+
+    l0, g0, lab0 = run(False)
+    l1, g1, lab1 = run(True)
+    assert not any("cross-pass" in k for k in lab0)
+    if not (ops.ROLE_SPLIT and ops.HS_FROM_RECORDS and ops.INTRA_LIN_FUSION and ops.FUSED_BPTT_BI):
+        pytest.skip("the cross-pass overlap needs the role-split wide kernels (switched off in this environment)")
+    assert any("cross-pass producer" in k for k in lab1) and any("cross-pass consumer" in k for k in lab1), lab1
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)      # (the loss reduction sums per-workgroup partials by atomics)
+    for k in g0:
+        a_, b_ = g1[k].cpu().numpy(), g0[k].cpu().numpy()
+        assert np.isfinite(a_).all(), k
+        assert rel_l2(a_, b_) < 2e-5 or float(np.abs(b_).max()) == 0, (k, rel_l2(a_, b_))
+
+
 @pytest.mark.parametrize("with_h0", [False, True], ids=["zero-state", "carried-state"])
 @pytest.mark.parametrize("B_,T_,F_", [(2, 150, 21), (1, 37, 16)], ids=["ragged-150", "full-tiles-odd-37"])
 def test_wide_gate_recompute_equals_the_recorded_gates_bit_for_bit(torch_gpu, B_, T_, F_, with_h0, monkeypatch):
