@@ -596,6 +596,17 @@ int sb_stft_mag_l1(const float* spec_x, const float* spec_y, int64_t rows, int n
 int sb_stft_mag_terms(const float* spec_x, const float* spec_y, int64_t rows, int nbins, int ld, float eps, float w_lin,
                       float w_log, float w_sc, float scale, float* dspec_x, float* partial, float* sums, float* loss,
                       void* stream);
+/* sb_stft_f64acc: spec[(b, t), n] = sum_k xp[b * ldp + t * hop + off + k] * w[n * K + k] for b < B, t < nframes, n < N,
+ * every fp32 product accumulated in double and the sum rounded once (rows of spec are dense, N floats).  The STFT the
+ * log-magnitude term of auraloss's MultiResolutionSTFTLoss is evaluated from (src/losses/MultiResoLoss.py:12 with w_log_mag != 0):
+ * its gradient weighs a bin by 1 / |X|^2, and the fp32 accumulation error of a K = 240 .. 1200 term dot product in the
+ * near-cancelled bins would otherwise dominate it.  With perceptual weighting the signal itself is the pair of planes sb_fir_pair
+ * returns (the A-weighted low bands lie below the fp32 rounding floor of the filtered signal). */
+int sb_stft_f64acc(const float* xp, const float* w, float* spec, int B, int nframes, int64_t ldp, int hop, int off, int K,
+                   int N, int64_t lo_off, void* stream);
+/* sb_fir_pair: sb_fir with the sum formed in double and returned as two fp32 planes, y + y_lo (sb_stft_f64acc adds them back
+ * up through lo_off, the element distance from xp to the low plane's padded copy; lo_off = 0: a single fp32 signal). */
+int sb_fir_pair(const float* x, const float* taps, float* y, float* y_lo, int B, int64_t N, int ntaps, void* stream);
 int sb_frames_fold(const float* dframes, float* dx, int B, int64_t N, int nframes, int K, int ldk, int hop, int off,
                    int pad, int accumulate, void* stream);
 int sb_l1_grad(const float* x, const float* y, int64_t n, float gscale, float* dx, int accumulate, float* partial,

@@ -4,6 +4,8 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from sound_bubble_amd import _lib as L, ops
+if os.environ.get("SB_LIB_VARIANT"):          # an instrumented build made here (scripts/build_variant.py phase -DSB_PHASE_TIMING)
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "exp", f"lib_{os.environ['SB_LIB_VARIANT']}.so")
 lib = ctypes.CDLL(L.LIB_PATH)
 KINDS = ["plain", "fused Linear", "summed input + fused Linear (inter-frame producer)", "ordered consumer (intra-frame)",
          "bidirectional partial-Linear (intra-frame, first block)"]

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsoundbubble_hip.so")
+# SB_LIB_PATH: a developer override (A/B runs against an experiment build under lib/exp/); the product default is the in-tree library
+LIB_PATH = os.environ.get("SB_LIB_PATH") or os.path.join(_HERE, "lib", "libsoundbubble_hip.so")
 
 c_fp = C.c_void_p          # device float*
 i64 = C.c_int64
@@ -187,6 +188,8 @@ SYMBOLS = {
     "sb_stft_mag_l1_grid": (_ci, [i64, _ci]),
     "sb_stft_mag_l1": (_ci, [c_fp, c_fp, i64, _ci, _ci, _cf, _cf, c_fp, c_fp, _cf, c_fp, _ci, _vp]),
     "sb_stft_mag_terms": (_ci, [c_fp, c_fp, i64, _ci, _ci, _cf, _cf, _cf, _cf, _cf, c_fp, c_fp, c_fp, c_fp, _vp]),
+    "sb_stft_f64acc": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, i64, _ci, _ci, _ci, _ci, i64, _vp]),
+    "sb_fir_pair": (_ci, [c_fp, c_fp, c_fp, c_fp, _ci, i64, _ci, _vp]),
     "sb_frames_fold": (_ci, [c_fp, c_fp, _ci, i64, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
     "sb_l1_grad": (_ci, [c_fp, c_fp, i64, _cf, c_fp, _ci, c_fp, _cf, c_fp, _ci, _vp]),
 }

@@ -179,13 +179,16 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   // The rows travel by async global -> LDS copies (global_load_lds_dwordx4: no registers at all; destination = wave-uniform
   // base + lane x 16 bytes, hence unpadded rows), issued one period ahead into the other buffer and waited for (vmcnt) just
   // before the hand-over barrier of the period that reads them.
-  // HREC (STG, bidirectional): the h_prev rows do not come from memory at all.  The recurrence role recomputes h of its step
+  // HREC (STG without time segments): the h_prev rows do not come from memory at all.  The recurrence role recomputes h of its step
   // from the records it holds anyway (h = o tanh(f c_prev + i g): the forward kernel's own expression on the same fp32
   // values, so the same bits), splits it like the forward kernel and leaves the (hi, lo) row in a four-step ring in LDS
   // (the SHP buffers); the chunk of steps (s, s - 1) runs one period later and reads h of steps s - 1 (written a period
   // ago) and s - 2 (written before this period's first barrier; the chunk needs it after that barrier).  The forward pass
   // then stores no hs for these layers: 512 of its 3456 bytes per position, and 512 fewer read here.
-  constexpr bool HREC = STG && BI;
+  // Single-direction passes too (round 4: the inter-frame backward of the cross-pass schedule is this role-split kernel): the
+  // forward then stores no hs pairs for them either, 256 of its 2 048 bytes per position.  Not with time segments: a segment's
+  // last chunk needs h of a step that another workgroup walks.
+  constexpr bool HREC = STG && (BI || !SEG);
   constexpr int SHROW = 256, SUROW = 4 * (FST > 0 ? FST : 16);                  // LDS rows (bytes)
   __shared__ __attribute__((aligned(16))) float R[FST > 0 ? (STG ? 1 : 2) : 1][4][2][CK][FST > 0 ? 64 : 1][4];
   __shared__ __attribute__((aligned(16))) char SHP[STG ? 2 : 1][STG ? 32 * SHROW : 16];   // h_prev pair rows of the chunk's 32 slots
@@ -1781,7 +1784,9 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     return rc;
   }
   if (fst) {
-    if (!dg16 || a.ndir != 1 || !a.u || !a.hs || !a.w_ih || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
+    // hs: not read by the wide role-split C = 32 form without time segments (HREC in the kernel: h recomputed from the records)
+    const bool hrec1 = wide && a.split && a.C == 32 && !seg;
+    if (!dg16 || a.ndir != 1 || !a.u || (!a.hs && !hrec1) || !a.w_ih || !a.dW_ih || !a.dW_hh || !a.db_ih || !a.db_hh ||
         (a.C != 16 && a.C != 32) || fc != a.C || (int64_t)a.nseq * a.nsteps >= (1ll << 31))
       return -1003;
     const bool lnb = a.dx != nullptr;

@@ -20,8 +20,13 @@ extern "C" int sb_debug_phase_fwd(float* host_out) {
 
 namespace {
 
+// The bidirectional C = 32 passes with the fused partial Linear (first block's intra-frame pass, ordered consumer) are meant to run
+// two workgroups per CU: at most 256 registers.  The inference forms stay below on their own (247 / 245); the training form of the
+// plain pass sat at exactly 256 and any edit of this file pushed it over: capped (second __launch_bounds__ argument = waves per
+// SIMD; the four registers it spills are outside the time loop).
 template <int C, int SAVE, bool FULL, bool F16, bool LIN, bool SEG, bool SUM3 = false, bool ORD = false>
-__global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
+__global__ __launch_bounds__(256, (LIN && C == 32 && !SUM3 && F16 && !SEG && SAVE == 4 && !ORD) ? 2 : 1)
+void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   typedef Prec<F16> PR;
   typedef typename PR::elem elem;
   typedef typename PR::vec8 vec8;
@@ -62,7 +67,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   __shared__ __attribute__((aligned(16))) elem U16[2][NT][16][UP];      // [buf][term][seq][channel]
   __shared__ __attribute__((aligned(16))) elem H16[2][NT][16][HP16];    // [buf][term][seq][unit]
   __shared__ __attribute__((aligned(16))) float Bias[4][H];
-  __shared__ __attribute__((aligned(16))) float XS[SUM3 ? 4 : 1][SUM3 ? 16 : 1][SUM3 ? C + 4 : 1];   // summed input rows (ring)
+  // TWO (kernels with the fused Linear): two-stage loader.  The y epilogue runs on the C / 16 waves that own an output-channel
+  // tile, and with one barrier per step the others wait for them (phase table r03: 320-400 of 2 070 ticks per step).  So the
+  // LayerNorm + operand split of the input rows moves to waves WITHOUT a tile, and into fewer, wider passes:
+  // stage 1 (every wave, 4 sequences each, as before): the fetched (summed) row of step s + 3 goes raw into a four-row LDS ring;
+  // stage 2 (one barrier later): the loader waves -- 2 and 3 for C = 32 (8 sequences each), 3 for C = 16 (all 16) -- read the rows
+  // back FOUR channels per lane (C / 4 lanes per row), normalise, split and store the operand tiles of step s + 2.
+  // Measured (r04 phase table): a pass of the 16-lanes-per-row LayerNorm costs 200-270 ticks however few rows it holds -- its
+  // price is instructions, not lanes -- so four such passes (one per wave) cost every wave as much as the y epilogue costs the
+  // tile owners; two passes of twice the width on the waves that have no epilogue take the LayerNorm off the tile owners'
+  // step altogether.  The ring doubles as the residual's source for the fused Linear (it always did in the summed-input form).
+  // Not for the bidirectional C = 32 passes (LIN without SUM3: the first block's intra-frame pass and the ordered consumer): they
+  // run TWO workgroups per CU -- 253 / 238 registers -- and the two-stage loader's state would cost them that (measured: ordered
+  // consumer 0.31 -> 0.41 ms at 264 registers); with a second wave on every SIMD the imbalance is the other workgroup's gain.
+  // The two loaders form bit-identical operand tiles (same summation trees: see ln2_piece).
+  constexpr bool HEAVY = !(LIN && C == 32 && !SUM3);
+  constexpr bool TWO = LIN && HEAVY;
+  __shared__ __attribute__((aligned(16))) float XS[TWO ? 4 : 1][TWO ? 16 : 1][TWO ? C + 4 : 1];      // raw input rows (ring)
 
   // ---- weights -> registers, split once: Wt[gate][chunk]: rows g*64+16w+j, k = 8q..8q+7 of the chunk ----
   const float* __restrict__ wih = a.w_ih[dir];
@@ -120,6 +141,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // the wave (microbenchmarks in scripts/micro/: a SIMD runs MFMA and VALU instructions back to back, never side by side).
   int64_t lo_x = 0, lo_xp = 0, co_y = 0, co_h = 0;
   const int ndir = a.ndir;
+  // stage-2 rows of this wave (TWO): lane -> sequence l2s, channels 4 l2c .. + 3
+  constexpr int LPR = C / 4;                                          // lanes per row
+  const bool lw2 = TWO && (C == 32 ? w >= 2 : w == 3);                // loader wave
+  const int l2c = lane & (LPR - 1);
+  const int l2s = C == 32 ? 8 * (w & 1) + (lane >> 3) : lane >> 2;
+  bool lvalid2 = false;
+  int64_t lo_u2 = 0;
   // ... and the uniform step terms are RUNNING sums: one 64-bit scalar add per step and quantity instead of a 64-bit scalar
   // multiply chain per address (with one wave per SIMD every instruction, scalar ones included, costs its ~4 issue cycles:
   // the ~70 scalar instructions of the old epilogue were 290 ticks of a 2 070-tick step).  Row s of the walk:
@@ -144,6 +172,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     cbase = cvalid ? ((int64_t)(nc / a.n_inner) * a.p_outer + (int64_t)(nc % a.n_inner) * a.p_inner) : 0;
     lo_x = lbase * C + cpart * VPT;
     lo_xp = lbase * (2 * C) + cpart * VPT;
+    if constexpr (TWO) {
+      const int n2 = tile * 16 + l2s;
+      lvalid2 = FULL || n2 < a.nseq;
+      lo_u2 = (lvalid2 ? ((int64_t)(n2 / a.n_inner) * a.p_outer + (int64_t)(n2 % a.n_inner) * a.p_inner) : 0) * C + 4 * l2c;
+    }
     co_y = ((LIN && a.ndir == 2) ? cbase * 2 + dir : cbase) * C + 16 * w + 4 * q;
     co_h = (cbase * ndir + dir) * H + 16 * w + 4 * q;
     if (film && linw && cvalid) {
@@ -169,37 +202,33 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     }
     return r;
   };
-  auto ln_store = [&](const XVec<C>& xv, int buf, int s, int64_t ex) {      // ex = st(s) p_step C (uniform)
+  // LayerNorm + operand split of one input row piece: values xr of sequence `seq` (16 lanes x VPT channels), position offset
+  // `lo`; operand terms to U16[buf], the saved copy of u (training) to row offset ex
+  auto ln_row = [&](const float (&xr)[VPT], int seq, bool lv, int64_t lo, int buf, int64_t ex) {
     float sum = 0.f;
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) sum += xv.v[v];
+    for (int v = 0; v < VPT; ++v) sum += xr[v];
     const float mean = row16_sum(sum) * (1.0f / C);
     float sq = 0.f;
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) { const float d = xv.v[v] - mean; sq = __builtin_fmaf(d, d, sq); }
+    for (int v = 0; v < VPT; ++v) { const float d = xr[v] - mean; sq = __builtin_fmaf(d, d, sq); }
     const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(row16_sum(sq), 1.0f / C, 1e-5f));   // v_rsq_f32, 1 ulp
     float u[VPT];
     elem uterm[2][VPT];                            // the two leading terms (SAVE == 4 stores them)
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-      u[v] = __builtin_fmaf((xv.v[v] - mean) * rstd, gam[v], bet[v]);
+      u[v] = __builtin_fmaf((xr[v] - mean) * rstd, gam[v], bet[v]);
+      // (u is rounded to fp32 HERE: left alone, hipcc folds the fma into the fp16 conversion of the leading term in some
+      //  instantiations -- v_fma_mixlo_f16, one rounding instead of two -- and the two loaders' operand tiles differ in rare bits)
+      asm volatile("" : "+v"(u[v]));
       elem e[NT];
       splitn1<F16>(u[v], e);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) U16[buf][n][ls][cpart * VPT + v] = e[n];
+      for (int n = 0; n < NT; ++n) U16[buf][n][seq][cpart * VPT + v] = e[n];
       uterm[0][v] = e[0]; uterm[1][v] = e[1];
     }
-    if constexpr (SUM3) {
-#pragma unroll
-      for (int v = 0; v < VPT; ++v) XS[s & 3][ls][cpart * VPT + v] = xv.v[v];
-      if (a.x_sum && lvalid) {
-        float* p = a.x_sum + ex + lo_x;
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) st_side(p + v, xv.v[v]);
-      }
-    }
-    if (SAVE && lvalid && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
-      const int64_t uo = ex + lo_x;
+    if (SAVE && lv && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
+      const int64_t uo = ex + lo;
       if constexpr (SAVE == 3) {            // only the streaming backward reads u, as a single fp16 term
         _Float16* p = reinterpret_cast<_Float16*>(a.save_u) + uo;
         if constexpr (VPT == 2) *reinterpret_cast<h16x2*>(p) = h16x2{(_Float16)u[0], (_Float16)u[1]};
@@ -216,6 +245,123 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         for (int v = 0; v < VPT; ++v) p[v] = u[v];
       }
     }
+  };
+  // one-stage loader (!TWO): the fetched row of step s straight through the LayerNorm
+  auto ln_store = [&](const XVec<C>& xv, int buf, int s, int64_t ex) {      // ex = st(s) p_step C (uniform)
+    ln_row(xv.v, ls, lvalid, lo_x, buf, ex);
+  };
+  // two-stage loader, stage 1: the fetched (summed) row of step s -> ring slot s & 3 (and x_sum for the backward kernels)
+  auto raw_store = [&](const XVec<C>& xv, int s, int64_t ex) {
+    if constexpr (TWO) {
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) XS[s & 3][ls][cpart * VPT + v] = xv.v[v];
+      if constexpr (SUM3) {
+        if (a.x_sum && lvalid) {
+          float* p = a.x_sum + ex + lo_x;
+#pragma unroll
+          for (int v = 0; v < VPT; ++v) st_side(p + v, xv.v[v]);
+        }
+      }
+    }
+  };
+  // ... stage 2 (loader waves; the row has been in the ring since before the last barrier): LPR lanes x 4 channels per row
+  f32x4 gam4 = zero4(), bet4 = zero4();
+  if constexpr (TWO) { gam4 = ld4(a.ln_g + 4 * l2c); bet4 = ld4(a.ln_b + 4 * l2c); }
+  auto rowsum2 = [&](float v) -> float {
+    v = dpp_add<0xB1>(v);                          // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);                          // quad_perm [2,3,0,1]
+    if constexpr (LPR == 8) v = dpp_add<0x141>(v); // row_half_mirror
+    return v;
+  };
+  // The pass is cut into SIX pieces that the hidden part issues one behind each of its product groups (h_part / mma6, like the
+  // deferred record stores): the pass is one dependent chain -- LDS read, sum, three DPP steps, deviations, three DPP steps,
+  // v_rsq, scale, split, LDS write -- and run as a block of its own it cost ~420 ticks for ~45 instructions (a SIMD with one
+  // wave has nothing else to issue while a link of the chain is in flight); a product group between two links covers that.
+  f32x4 l2x = zero4(), l2d = zero4();
+  float l2a = 0.f;
+  int l2buf = 0, l2slot = 0;
+  int64_t l2ex = 0;
+  auto ln2_begin = [&](int buf, int s, int64_t ex) { l2buf = buf; l2slot = s & 3; l2ex = ex; };
+  auto ln2_piece = [&](int k) __attribute__((always_inline)) {
+    if constexpr (TWO) {
+      // (the empty asm statements keep the optimiser from sinking a piece's arithmetic down to its first use in a later piece;
+      //  the scheduling barriers behind the pieces only bind the machine scheduler)
+      if (k == 0) l2x = ld4(&XS[l2slot][l2s][4 * l2c]);
+      if (k == 1) {
+        l2a = dpp_add<0xB1>((l2x[0] + l2x[1]) + (l2x[2] + l2x[3]));                     // quad_perm [1,0,3,2]
+        asm volatile("" : "+v"(l2a));
+      }
+      if (k == 2) {
+        l2a = dpp_add<0x4E>(l2a);                                                       // quad_perm [2,3,0,1]
+        if constexpr (LPR == 8) l2a = dpp_add<0x141>(l2a);                              // row_half_mirror
+        asm volatile("" : "+v"(l2a));
+      }
+      if (k == 3) {
+        // (sums in the one-stage loader's tree -- 16 lanes x C / 16 channels, then the DPP butterfly -- so that both loaders
+        //  round alike: C = 32: a lane pair's fma chains, added; C = 16: four squares, added pairwise)
+        const float mean = l2a * (1.0f / C);
+        float sq, d0, d1, d2, d3;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) l2d[v] = l2x[v] - mean;
+        if constexpr (C == 32) sq = __builtin_fmaf(l2d[1], l2d[1], __builtin_fmaf(l2d[0], l2d[0], 0.f)) +
+                                    __builtin_fmaf(l2d[3], l2d[3], __builtin_fmaf(l2d[2], l2d[2], 0.f));
+        else sq = (__builtin_fmaf(l2d[0], l2d[0], 0.f) + __builtin_fmaf(l2d[1], l2d[1], 0.f)) +
+                  (__builtin_fmaf(l2d[2], l2d[2], 0.f) + __builtin_fmaf(l2d[3], l2d[3], 0.f));
+        l2a = dpp_add<0xB1>(sq);
+        d0 = l2d[0]; d1 = l2d[1]; d2 = l2d[2]; d3 = l2d[3];
+        asm volatile("" : "+v"(l2a), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        l2d[0] = d0; l2d[1] = d1; l2d[2] = d2; l2d[3] = d3;
+      }
+      if (k == 4) {
+        l2a = dpp_add<0x4E>(l2a);
+        if constexpr (LPR == 8) l2a = dpp_add<0x141>(l2a);
+        l2a = __builtin_amdgcn_rsqf(__builtin_fmaf(l2a, 1.0f / C, 1e-5f));               // v_rsq_f32, 1 ulp
+        asm volatile("" : "+v"(l2a));
+      }
+      if (k == 5) {
+        f32x4 u;
+        vec4 ut[NT];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          u[v] = __builtin_fmaf(l2d[v] * l2a, gam4[v], bet4[v]);
+          { float uv = u[v]; asm volatile("" : "+v"(uv)); u[v] = uv; }      // (rounded to fp32 here: see ln_row)
+          elem e[NT];
+          splitn1<F16>(u[v], e);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) ut[n][v] = e[n];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) *reinterpret_cast<vec4*>(&U16[l2buf][n][l2s][4 * l2c]) = ut[n];
+        if (SAVE && lvalid2 && dir == 0 && !(SB_EXP_SKIP & 8)) {      // both directions normalise the same rows: one copy is enough
+          const int64_t uo = l2ex + lo_u2;
+          if constexpr (SAVE == 3) {            // only the streaming backward reads u, as a single fp16 term
+            h16x4 t;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[v] = (_Float16)u[v];
+            *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(a.save_u) + uo) = t;
+          } else if constexpr (SAVE == 4 && F16) {
+            // wide form: the fp16 hi + lo terms of this kernel's own products (see ln_row): [P][C/2][hi0, hi1, lo0, lo1] resp.
+            // [P][C][hi, lo] -- this lane's four channels are 16 contiguous bytes either way
+            h16x8 t;
+            if constexpr (C == 32) {
+              t = h16x8{(_Float16)ut[0][0], (_Float16)ut[0][1], (_Float16)ut[1][0], (_Float16)ut[1][1],
+                        (_Float16)ut[0][2], (_Float16)ut[0][3], (_Float16)ut[1][2], (_Float16)ut[1][3]};
+            } else {
+              t = h16x8{(_Float16)ut[0][0], (_Float16)ut[1][0], (_Float16)ut[0][1], (_Float16)ut[1][1],
+                        (_Float16)ut[0][2], (_Float16)ut[1][2], (_Float16)ut[0][3], (_Float16)ut[1][3]};
+            }
+            st_side(reinterpret_cast<h16x8*>(reinterpret_cast<_Float16*>(a.save_u) + 2 * uo), t);
+          } else {
+            st4(a.save_u + uo, u);
+          }
+        }
+      }
+    }
+  };
+  auto ln_stage2 = [&](int buf, int s, int64_t ex) {       // the whole pass at once (prologue of a work item)
+    ln2_begin(buf, s, ex);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ln2_piece(k);
   };
 
   // ---- compute role ----
@@ -322,7 +468,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   };
   // hook >= 0: after product group pi the pending record store number hook + pi is issued (see rec_piece) and pinned there
   // (second fence: VMEM may not cross either)
-  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const vec8 (&b)[NT], int hook = -1) {
+  auto mma6 = [&](f32x4 (&acc)[4], int chunk, const vec8 (&b)[NT], int hook = -1, int lnhook = -1) {
     // (weight term, operand term) pairs, smallest products first
     constexpr int NP = F16 ? 3 : 6;
     constexpr int WT[6] = {F16 ? 1 : 2, F16 ? 0 : 0, F16 ? 0 : 1, 1, 0, 0};
@@ -336,6 +482,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         rec_piece(hook + pi);
         __builtin_amdgcn_sched_barrier(kNoMfmaVmemCross);
       }
+      if (lnhook >= 0) {                               // piece lnhook + pi of the stage-2 LayerNorm, pinned behind this group
+        ln2_piece(lnhook + pi);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   auto x_part = [&](f32x4 (&acc)[4], int buf) {
@@ -346,15 +496,74 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&U16[buf][n][j][8 * q]);
     mma6(acc, 0, b);
   };
-  auto h_part = [&](f32x4 (&acc)[4], int buf) {
+  // Phase B with the cell update PINNED between the products of the input part (fp16x3 form): a SIMD issues in order, its matrix
+  // pipe takes a v_mfma every ~18 ticks and covers ~2 transcendentals issued behind it (r03 microbenchmarks: 1 MFMA + 2 trans =
+  // 27.6 ticks against 18.6 + 20), but left to itself hipcc issues ~26 of the step's 40 v_exp / v_rcp in front of the first
+  // product (its operands come from LDS) and 14 among them.  Here every product is followed by one piece of the update of ONE
+  // of the lane's four units -- 4 v_exp, then 4 v_rcp, then the cell state and its v_exp -- so 36 of the 40 sit behind a
+  // product; the operands are fetched before the first piece.  Same expressions as sigmoid_pre / tanh_pre / tanhf_fast: same bits.
+#ifdef SB_EXP_NO_CELLPIN
+  constexpr bool CELLPIN = false;
+#else
+  // (same-box A/B, r04: C = 32 inference producer 0.607 -> 0.595 ms; C = 16 0.62 -> 0.655 ms and the store-bound training forms
+  //  unchanged or slower: inference, C = 32 only)
+  constexpr bool CELLPIN = F16 && HEAVY && C == 32 && SAVE == 0;
+#endif
+  auto x_part_cell = [&](f32x4 (&accn)[4], int buf, const f32x4 (&acc)[4], f32x4& gi, f32x4& gf, f32x4& gg, f32x4& go, f32x4& tc) {
+    constexpr int WT[3] = {1, 0, 0}, XT[3] = {0, 1, 0};          // (weight term, operand term), smallest products first (as mma6)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accn[g] = ld4(&Bias[g][uoff]);
+    vec8 b[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&U16[buf][n][j][8 * q]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        accn[g] = PR::mma(Wt[g][0].t[WT[pi]], b[XT[pi]], accn[g]);
+        const int r = g;                                         // this piece's unit
+        if (pi == 0) {
+          float e0 = __builtin_amdgcn_exp2f(acc[0][r]), e1 = __builtin_amdgcn_exp2f(acc[1][r]);
+          float e2 = __builtin_amdgcn_exp2f(acc[2][r]), e3 = __builtin_amdgcn_exp2f(acc[3][r]);
+          asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+          gi[r] = e0; gf[r] = e1; gg[r] = e2; go[r] = e3;
+        } else if (pi == 1) {
+          float e0 = __builtin_amdgcn_rcpf(1.0f + gi[r]), e1 = __builtin_amdgcn_rcpf(1.0f + gf[r]);
+          float e2 = __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + gg[r]), -1.0f), e3 = __builtin_amdgcn_rcpf(1.0f + go[r]);
+          asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+          gi[r] = e0; gf[r] = e1; gg[r] = e2; go[r] = e3;
+        } else {
+          float cn = __builtin_fmaf(gf[r], c[r], gi[r] * gg[r]);
+          float e = __builtin_amdgcn_exp2f(2.0f * SB_NLOG2E * cn);
+          asm volatile("" : "+v"(cn), "+v"(e));
+          c[r] = cn; tc[r] = e;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // y_tag: std::true_type = this wave owns an output-channel tile of the fused Linear (its W_lin . h products ride along);
+  // the caller branches on the wave's role ONCE and calls the matching copy, so that each role's phase A is one basic block
+  // (hipcc interleaves the stage-2 LayerNorm's dependent chain -- LDS round trip, two DPP sums, v_rsq -- with the products only
+  // inside a block: behind a branch of its own the chain ran exposed, ~420 ticks for ~45 instructions)
+  auto h_part = [&](f32x4 (&acc)[4], int buf, auto y_tag, auto ln_tag) {
+    // y_tag: 0 = no output-channel tile, 1 = this wave owns one, 2 = decided here (linw: the one-stage loader's kernels)
+    constexpr int Y = decltype(y_tag)::value;
+#ifdef SB_EXP_NO_LNHOOK
+    constexpr bool LNH = false;
+    if constexpr (decltype(ln_tag)::value) ln_stage2(l2buf, l2slot, l2ex);
+#else
+    constexpr bool LNH = decltype(ln_tag)::value && F16;      // (three product groups per chunk)
+#endif
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck) {
       vec8 b[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const vec8*>(&H16[buf][n][j][32 * ck + 8 * q]);
-      mma6(acc, 1 + ck, b, DEFER ? 3 * ck : -1);
-      if constexpr (LIN) {                             // W_lin . h of the step that produced this buffer
-        if (linw) {
+      mma6(acc, 1 + ck, b, DEFER ? 3 * ck : -1, LNH ? 3 * ck : -1);
+      if constexpr (LIN && Y != 0) {                   // W_lin . h of the step that produced this buffer
+        if (Y == 1 || linw) {
           if (ck == 0) yacc = zero4();
           if constexpr (F16) {
             yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
@@ -380,7 +589,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   };
   auto load_res = [&](int sy, int64_t ey) {
     if (linw && cvalid && !lin_part && !(SB_EXP_SKIP & 32)) {
-      if constexpr (SUM3) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);
+      if constexpr (TWO) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);         // the raw row is in the ring
       else xres = ld4(a.x + ey + co_y);
     }
   };
@@ -396,7 +605,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #ifdef SB_PHASE_TIMING
   unsigned long long tph[5] = {0, 0, 0, 0, 0};
 #endif
-  auto step = [&](int s, const XVec<C>& xrow) {        // xrow: input row s+2
+  auto step = [&](int s, const XVec<C>& xrow) {        // xrow: input row s + 2 (TWO: s + 3)
     const int cur = s & 1;
     SB_TICK(c0);
     // ---- A: hidden part on the matrix pipe || LayerNorm of row s+2 in the issue gaps (it does not depend on
@@ -405,14 +614,35 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     {
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = accx[g];
-      ln_store(xrow, cur, min(s + 2, S - 1), s + 2 <= S - 1 ? run_x + 2 * d_x : run_x_last);
-      h_part(acc, cur);
+      if constexpr (TWO) {
+        raw_store(xrow, s + 3, s + 3 <= S - 1 ? run_x + 3 * d_x : run_x_last);
+        typedef std::integral_constant<int, 0> Y0;
+        typedef std::integral_constant<int, 1> Y1;
+        if (linw) {
+          h_part(acc, cur, Y1{}, std::false_type{});
+        } else if (C == 32 || lw2) {                   // (C = 32: every wave without a tile is a loader wave)
+          ln2_begin(cur, s + 2, s + 2 <= S - 1 ? run_x + 2 * d_x : run_x_last);
+          if constexpr (F16) h_part(acc, cur, Y0{}, std::true_type{});
+          else { ln_stage2(cur, s + 2, l2ex); h_part(acc, cur, Y0{}, std::false_type{}); }
+        } else {
+          h_part(acc, cur, Y0{}, std::false_type{});
+        }
+      } else {
+        ln_store(xrow, cur, min(s + 2, S - 1), s + 2 <= S - 1 ? run_x + 2 * d_x : run_x_last);
+        h_part(acc, cur, std::integral_constant<int, 2>{}, std::false_type{});
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     SB_TICK(c1);
     // ---- B: input part of step s+1 (matrix pipe) || cell update of step s (VALU) ----
     f32x4 gi, gf, gg, go, cprev;
-    {
+    if constexpr (CELLPIN) {
+      cprev = c;
+      f32x4 tc;
+      x_part_cell(accx, cur ^ 1, acc, gi, gf, gg, go, tc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = go[r] * __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + tc[r]), -1.0f);
+    } else {
       x_part(accx, cur ^ 1);
       cprev = c;
 #pragma unroll
@@ -509,12 +739,28 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         run_blk = (rec_tile + st0) * ndir + dir;
         run_x_last = (int64_t)(rev ? 0 : S - 1) * a.p_step * C;
       }
-      ln_store(x0, s_begin & 1, s_begin, run_x);
-      ln_store(x1, (s_begin + 1) & 1, min(s_begin + 1, S - 1), s_begin + 1 <= S - 1 ? run_x + d_x : run_x_last);
-      xa = load_x(min(s_begin + 2, S - 1));
-      xb = load_x(min(s_begin + 3, S - 1));
-      xc = load_x(min(s_begin + 4, S - 1));
-      xd = load_x(min(s_begin + 5, S - 1));
+      if constexpr (TWO) {
+        const XVec<C> x2 = load_x(min(s_begin + 2, S - 1));
+        raw_store(x0, s_begin, run_x);
+        raw_store(x1, s_begin + 1, s_begin + 1 <= S - 1 ? run_x + d_x : run_x_last);
+        raw_store(x2, s_begin + 2, s_begin + 2 <= S - 1 ? run_x + 2 * d_x : run_x_last);
+        xa = load_x(min(s_begin + 3, S - 1));
+        xb = load_x(min(s_begin + 4, S - 1));
+        xc = load_x(min(s_begin + 5, S - 1));
+        xd = load_x(min(s_begin + 6, S - 1));
+        __syncthreads();
+        if (lw2) {
+          ln_stage2(s_begin & 1, s_begin, run_x);
+          ln_stage2((s_begin + 1) & 1, s_begin + 1, s_begin + 1 <= S - 1 ? run_x + d_x : run_x_last);
+        }
+      } else {
+        ln_store(x0, s_begin & 1, s_begin, run_x);
+        ln_store(x1, (s_begin + 1) & 1, min(s_begin + 1, S - 1), s_begin + 1 <= S - 1 ? run_x + d_x : run_x_last);
+        xa = load_x(min(s_begin + 2, S - 1));
+        xb = load_x(min(s_begin + 3, S - 1));
+        xc = load_x(min(s_begin + 4, S - 1));
+        xd = load_x(min(s_begin + 5, S - 1));
+      }
     }
     __syncthreads();
     x_part(accx, s_begin & 1);
@@ -522,10 +768,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     int s = s_begin;
     for (; s + 3 < s_end; s += 4) {
       const XVec<C> ca = xa, cb = xb, cc = xc, cd = xd;
-      xa = load_x(min(s + 6, S - 1));
-      xb = load_x(min(s + 7, S - 1));
-      xc = load_x(min(s + 8, S - 1));
-      xd = load_x(min(s + 9, S - 1));
+      xa = load_x(min(s + 6 + (TWO ? 1 : 0), S - 1));
+      xb = load_x(min(s + 7 + (TWO ? 1 : 0), S - 1));
+      xc = load_x(min(s + 8 + (TWO ? 1 : 0), S - 1));
+      xd = load_x(min(s + 9 + (TWO ? 1 : 0), S - 1));
       step(s, ca);
       step(s + 1, cb);
       step(s + 2, cc);

@@ -7,6 +7,7 @@
 //   sb_reflect_pad  torch.stft(center=True, pad_mode="reflect") framing input
 //   sb_stft_mag_l1  |X|, |Y| from interleaved (re, im) spectra, sum |(|X| - |Y|)|, d(loss)/d(spectrum of X)
 //   sb_stft_mag_terms  the same with auraloss's other two terms (log-magnitude L1, spectral convergence): two passes
+//   sb_stft_f64acc  the STFT with double accumulation (what the log-magnitude term's gradient needs: see the kernel)
 //   sb_frames_fold  backward of framing + reflect padding: frame gradients -> signal gradient
 //   sb_l1_grad      sum |x - y| and its gradient
 // All HBM-bound single passes.
@@ -21,8 +22,11 @@ constexpr int FIR_TILE = 1024;        // outputs per workgroup
 constexpr int FIR_MAX_TAPS = 257;
 
 // y[b, n] = sum_k taps[k] * x[b, n + k - ntaps / 2]   (torch conv1d = cross-correlation, zero padding ntaps / 2)
+// PAIR: the sum is formed in double and leaves as TWO fp32 planes y + y_lo (the log-magnitude term's STFT adds them back up in
+// double: the A-weighted signal's low bands sit 50 dB and more below its rounding noise floor otherwise -- see stft_f64acc_kernel)
+template <bool PAIR>
 __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, const float* __restrict__ taps,
-                                                  float* __restrict__ y, int64_t N, int ntaps) {
+                                                  float* __restrict__ y, float* __restrict__ y_lo, int64_t N, int ntaps) {
   __shared__ float xs[FIR_TILE + FIR_MAX_TAPS + 3];
   __shared__ float ts[FIR_MAX_TAPS];
   const int b = blockIdx.y, tid = threadIdx.x, half = ntaps / 2;
@@ -34,16 +38,34 @@ __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, c
   }
   for (int i = tid; i < ntaps; i += 256) ts[i] = taps[i];
   __syncthreads();
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < ntaps; ++k) {
-    const float t = ts[k];
+  if constexpr (PAIR) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < ntaps; ++k) {
+      const double t = (double)ts[k];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(t, xs[tid + 256 * r + k], acc[r]);
-  }
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_fma(t, (double)xs[tid + 256 * r + k], acc[r]);
+    }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t n = n0 + tid + 256 * r;
-    if (n < N) y[(int64_t)b * N + n] = acc[r];
+    for (int r = 0; r < 4; ++r) {
+      const int64_t n = n0 + tid + 256 * r;
+      if (n < N) {
+        const float hi = (float)acc[r];
+        y[(int64_t)b * N + n] = hi;
+        y_lo[(int64_t)b * N + n] = (float)(acc[r] - (double)hi);
+      }
+    }
+  } else {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < ntaps; ++k) {
+      const float t = ts[k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(t, xs[tid + 256 * r + k], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t n = n0 + tid + 256 * r;
+      if (n < N) y[(int64_t)b * N + n] = acc[r];
+    }
   }
 }
 
@@ -206,6 +228,67 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)(red[0] * (double)scale);
 }
 
+// STFT of the log-magnitude term: spec[(b, t), n] = sum_k xp[b, t hop + off + k] * w[n, k], ACCUMULATED IN DOUBLE.
+// d log|X| = X / |X|^2 weighs every bin by the inverse of its energy, so the gradient of auraloss's log-magnitude term is
+// set by the few bins where the frame's K = 240 .. 1200 products cancel to ~1e-3 of their size: a sequential fp32 sum
+// (sb_linear_fwd's MFMA chain) carries ~K eps / sqrt(2) of the term size there -- 3e-4 .. 6e-4 of the gradient's norm,
+// 3 x what a fp32 FFT (log2 K stages) leaves.  Each fp32 x fp32 product is exact in double, the sum is rounded once: the
+// spectrum is the correctly rounded one, and the gradient meets the float64 oracle at the 1e-4 the other terms meet.
+// Vector fp64 FMA runs at the fp32 rate on gfx950; plain 64 x 64 x 8 LDS tiles, 4 x 4 outputs per thread (a loss term:
+// ~80 GFLOP per 16 five-second clips, a few ms).
+constexpr int DT_M = 64, DT_N = 64, DT_K = 8;
+__global__ __launch_bounds__(256) void stft_f64acc_kernel(const float* __restrict__ xp, const float* __restrict__ w,
+                                                          float* __restrict__ spec, int64_t rows, int nfr, int64_t ldp, int hop,
+                                                          int off, int K, int N, int64_t lo_off) {
+  // lo_off != 0: the signal is the pair xp[i] + xp[i + lo_off] (sb_fir_pair's two planes, reflect-padded alike)
+  __shared__ double As[DT_K][DT_M + 2];
+  __shared__ float Bs[DT_K][DT_N + 4];
+  const int tid = threadIdx.x, tm = tid >> 4, tn = tid & 15;
+  const int64_t m0 = (int64_t)blockIdx.x * DT_M;
+  const int n0 = blockIdx.y * DT_N;
+  // loader: thread -> (row lm, k pair lk) of the A tile and (column lm, k pair lk) of the B tile
+  const int lm = tid >> 2, lk = (tid & 3) * 2;
+  const int64_t ra = min(m0 + lm, rows - 1);
+  const float* pa = xp + (ra / nfr) * ldp + (ra % nfr) * (int64_t)hop + off;
+  const float* pb = w + (int64_t)min(n0 + lm, N - 1) * K;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int k0 = 0; k0 < K; k0 += DT_K) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = k0 + lk + e;
+      As[lk + e][lm] = k < K ? (double)pa[k] + (lo_off ? (double)pa[k + lo_off] : 0.0) : 0.0;
+      Bs[lk + e][lm] = k < K ? pb[k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DT_K; ++k) {
+      double av[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[k][4 * tm + i];
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(&Bs[k][4 * tn]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(av[i], (double)bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + 4 * tm + i;
+    if (m >= rows) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tn + j;
+      if (n < N) spec[m * N + n] = (float)acc[i][j];
+    }
+  }
+}
+
 // dx[b, m] (+)= sum over the padded indices i that map onto m (i = m + pad, the left mirror pad - m, the right mirror
 // pad + 2 (N - 1) - m) of  sum_t dframes[b, t, i - off - t * hop]  (0 <= i - off - t hop < K)
 __global__ __launch_bounds__(256) void frames_fold_kernel(const float* __restrict__ df, float* __restrict__ dx, int64_t N,
@@ -259,7 +342,15 @@ __global__ __launch_bounds__(256) void l1_grad_kernel(const float* __restrict__ 
 
 extern "C" int sb_fir(const float* x, const float* taps, float* y, int B, int64_t N, int ntaps, void* stream) {
   if (!x || !taps || !y || B <= 0 || N <= 0 || ntaps < 1 || ntaps > FIR_MAX_TAPS || !(ntaps & 1)) return -1001;
-  hipLaunchKernelGGL(fir_kernel, dim3(nblk(N, FIR_TILE), B), dim3(256), 0, (hipStream_t)stream, x, taps, y, N, ntaps);
+  hipLaunchKernelGGL(fir_kernel<false>, dim3(nblk(N, FIR_TILE), B), dim3(256), 0, (hipStream_t)stream, x, taps, y, nullptr, N,
+                     ntaps);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_fir_pair(const float* x, const float* taps, float* y, float* y_lo, int B, int64_t N, int ntaps, void* stream) {
+  if (!x || !taps || !y || !y_lo || B <= 0 || N <= 0 || ntaps < 1 || ntaps > FIR_MAX_TAPS || !(ntaps & 1)) return -1001;
+  hipLaunchKernelGGL(fir_kernel<true>, dim3(nblk(N, FIR_TILE), B), dim3(256), 0, (hipStream_t)stream, x, taps, y, y_lo, N, ntaps);
   SB_CHECK_LAUNCH();
   return 0;
 }
@@ -302,6 +393,20 @@ extern "C" int sb_stft_mag_terms(const float* spec_x, const float* spec_y, int64
   if (dspec_x)
     hipLaunchKernelGGL(stft_mag_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, spec_x, spec_y, rows, nbins, ld, eps,
                        cnt, w_lin, w_log, w_sc, scale, sums, dspec_x);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_stft_f64acc(const float* xp, const float* w, float* spec, int B, int nframes, int64_t ldp, int hop, int off,
+                              int K, int N, int64_t lo_off, void* stream) {
+  if (!xp || !w || !spec || B <= 0 || nframes <= 0 || hop <= 0 || off < 0 || K <= 0 || N <= 0 || lo_off < 0 ||
+      ldp < (int64_t)(nframes - 1) * hop + off + K)
+    return -1001;
+  const int64_t rows = (int64_t)B * nframes;
+  const int64_t gx = (rows + DT_M - 1) / DT_M;
+  if (gx >= (1ll << 31)) return -1002;
+  hipLaunchKernelGGL(stft_f64acc_kernel, dim3((unsigned)gx, (unsigned)((N + DT_N - 1) / DT_N)), dim3(256), 0,
+                     (hipStream_t)stream, xp, w, spec, rows, nframes, ldp, hop, off, K, N, lo_off);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -285,10 +285,13 @@ class InterFn(torch.autograd.Function):
         # wide mode, C = 32, a geometry whose backward runs as the recurrence + stream-kernel pair: no gate records -- the
         # backward recurrence recomputes them from the u / hs pairs (ops.inter_gate_recompute_ok)
         no_gates = bool(train and fuse and ops.inter_gate_recompute_ok(geom, Cc, x.device))
+        # ... and no hs where the backward will be the role-split fused kernel that recomputes h from the records (round 4: the
+        # cross-pass schedule's producer): 256 of the 2 048 bytes this store-bound pass writes per position
+        skip_hs = bool(train and fuse and part is not None and not no_gates and ops.inter_hs_from_records_ok(geom, Cc, x.device))
         hs, (hN, cN), gates, u = ops.lstm_fwd(x.view(P, Cc), ln_g, ln_b, [(wi, wh, bi, bh)], geom, h0=h0c, c0=c0c,
                                               save=train, want_state=True, no_gates=no_gates,
                                               lin=(lin_w.contiguous(), lin_b, y) if fuse else None,
-                                              want_hs=train or not fuse,
+                                              want_hs=(train and not skip_hs) or not fuse,
                                               x_part=part.contiguous() if part is not None else None, x_sum=x_sum,
                                               film=film, produce=ovl if fuse else None)
         if part is not None and train:
@@ -364,7 +367,13 @@ class InterFn(torch.autograd.Function):
             if dx is None:
                 dx = ops.lstm_bwd_inter_overlapped(*args, recompute=(bi, bh, ctx.h0), serial=True)
             return ret(dx.view(B, T, F, Cc))
-        if (fuse and ops.BPTT == "wide" and ctx.deferred and gates[0] is not None
+        du = None
+        if fuse and ops.BPTT == "wide" and hs is None and not ops.can_cross_overlap_bwd(geom, Cc, u, hs):
+            # hs was not stored (the forward counted on the cross-pass schedule) and the side stream has been lost since: the same
+            # fused role-split kernel in plain order (it recomputes h from the records), then the LayerNorm backward below
+            du = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, None, wi, tg[0],
+                                    lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b))).view(P, 1, Cc)
+        elif (fuse and ops.BPTT == "wide" and ctx.deferred and gates[0] is not None
                 and ops.can_cross_overlap_bwd(geom, Cc, u, hs)):
             # Backward overlapped across the two passes of the block: this pass as ONE fused role-split launch on its 145 CUs,
             # publishing du slab by slab; the intra-frame backward of the same block (the next autograd node: `deferred` says its
@@ -386,7 +395,7 @@ class InterFn(torch.autograd.Function):
                 pend.d_ln_g, pend.d_ln_b = gt("ln_g", ln_g), gt("ln_b", ln_b)
                 pend.materialize()
             return ret(dx.view(B, T, F, Cc))
-        if fuse and ops.BPTT == "wide" and ops.can_overlap_inter_bwd(geom, u, hs):
+        elif fuse and ops.BPTT == "wide" and ops.can_overlap_inter_bwd(geom, u, hs):
             # wide form with fewer tiles than CUs: recurrence || stream kernel (two-term dgates through L2) instead of the fused
             # single launch, which would leave the idle CUs idle
             dx = ops.lstm_bwd_inter_overlapped(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
@@ -394,7 +403,9 @@ class InterFn(torch.autograd.Function):
                                                (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)))
             if dx is not None:
                 return ret(dx.view(B, T, F, Cc))
-        if fuse and ops.can_fuse_stream(u, hs, geom):
+        if du is not None:                     # (hs-free fallback above)
+            pass
+        elif fuse and ops.can_fuse_stream(u, hs, geom):
             # recurrence + streaming part + the Linear's weight gradient in one launch (where it pays)
             ln = (x.view(P, Cc), ln_g, gt("ln_g", ln_g), gt("ln_b", ln_b)) if (Cc == 16 and ops.FUSED_LN_BWD) else None
             du = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
@@ -966,7 +977,13 @@ class MultiResoFuseLossFn(torch.autograd.Function):
         want_grad = ctx.needs_input_grad[0]
         loss = torch.zeros(1, device=dev, dtype=torch.float32)
         both = torch.cat([e, g], 0)                                   # [2R, T]: one set of launches for both signals
-        xw = ops.fir(both, cfg.taps) if cfg.taps is not None else both
+        # log-magnitude term: its gradient weighs a bin by 1 / |X|^2, so the A-weighted signal travels as a (hi, lo) pair of fp32
+        # planes and the spectrum is accumulated in double (ops.stft_f64acc); the other terms take the plain fp32 chain
+        pair = bool(cfg.w_log_mag) and cfg.taps is not None
+        if pair:
+            xw = ops.fir_pair(both, cfg.taps).view(4 * R, T)              # rows [0, 2R) hi, [2R, 4R) lo
+        else:
+            xw = ops.fir(both, cfg.taps) if cfg.taps is not None else both
         dxw = torch.empty(R, T, device=dev, dtype=torch.float32) if want_grad else None
         nres = len(cfg.res)
         for i, r in enumerate(cfg.res):
@@ -975,7 +992,10 @@ class MultiResoFuseLossFn(torch.autograd.Function):
             ldp = T + 2 * pad + 32
             xp = ops.reflect_pad(xw, pad, ldp)
             spec = torch.empty(2 * R * nfr, Npad, device=dev, dtype=torch.float32)
-            ops.linear(xp, r["w"], None, spec, (2 * R, nfr, 1), (ldp, hop, 0), (nfr * Npad, Npad, 0), K, Npad, in_off=off)
+            if cfg.w_log_mag:      # the log-magnitude gradient weighs a bin by 1 / |X|^2: its spectrum is accumulated in double
+                ops.stft_f64acc(xp, r["w"], spec, 2 * R, nfr, ldp, hop, off, K, Npad, lo_off=2 * R * ldp if pair else 0)
+            else:
+                ops.linear(xp, r["w"], None, spec, (2 * R, nfr, 1), (ldp, hop, 0), (nfr * Npad, Npad, 0), K, Npad, in_off=off)
             cnt = float(R * nfr * nbins)
             if cfg.w_sc or cfg.w_log_mag:     # auraloss's other two terms: two passes (the SC gradient needs the global norms)
                 dsx = ops.stft_mag_terms(spec[: R * nfr], spec[R * nfr:], R * nfr, nbins, Npad, cfg.eps, cfg.w_lin_mag,

@@ -831,19 +831,33 @@ def _cross_order(B, T, F_, slab, dev):
     return r
 
 
+def _cross_static_ok(geom, Cc, dev):
+    """switches and geometry of the cross-pass backward (everything but the tensors at hand and the side stream)"""
+    if not (BWD_CROSS_OVERLAP and BWD_OVERLAP and _wide() and LSTM_MMA == 1 and Cc == 32 and ROLE_SPLIT and FUSED_BPTT and FUSED_BPTT_BI
+            and HS_FROM_RECORDS and INTRA_LIN_FUSION and can_fuse_linear_bwd() and SCHED_OVERRIDE is None):
+        return False
+    ntiles, cus = (geom.nseq + 15) // 16, _cu_count(dev)
+    return (OVERLAP_MIN_FILL * cus <= ntiles <= OVERLAP_MAX_FILL * cus and cus - ntiles >= 16
+            and geom.nsteps >= 4 * BWD_CROSS_SLAB)
+
+
 def can_cross_overlap_bwd(geom, Cc, u, hs):
     """inter-frame geometry `geom` (B F sequences x T steps): run its backward as the cross-pass producer?  Needs the wide
     role-split kernels of both passes (C = 32, h recomputed from the records in the bidirectional one), an under-filled
-    producer and a side stream that really runs beside the main one."""
-    if not (BWD_CROSS_OVERLAP and _wide() and LSTM_MMA == 1 and Cc == 32 and ROLE_SPLIT and FUSED_BPTT and FUSED_BPTT_BI
-            and HS_FROM_RECORDS and INTRA_LIN_FUSION and can_fuse_linear_bwd() and SCHED_OVERRIDE is None
-            and u is not None and hs is not None and u.dtype == torch.float16 and hs.dtype == torch.float16):
+    producer and a side stream that really runs beside the main one.  hs None: not stored (inter_hs_from_records_ok)."""
+    if not (_cross_static_ok(geom, Cc, u.device if u is not None else None)
+            and u is not None and u.dtype == torch.float16 and (hs is None or hs.dtype == torch.float16)):
         return False
     if torch.cuda.is_current_stream_capturing():
         return False
-    ntiles, cus = (geom.nseq + 15) // 16, _cu_count(u.device)
-    return (OVERLAP_MIN_FILL * cus <= ntiles <= OVERLAP_MAX_FILL * cus and cus - ntiles >= 16
-            and geom.nsteps >= 4 * BWD_CROSS_SLAB and overlap_available())
+    return overlap_available()
+
+
+def inter_hs_from_records_ok(geom, Cc, dev):
+    """forward of a single-direction pass with the fused Linear, training: leave hs unstored?  Yes where the backward will be the
+    wide role-split fused kernel WITHOUT time segments -- the cross-pass producer, or (side stream lost in between) the same
+    kernel in plain order: its recurrence role recomputes h from the records (HREC), as the bidirectional kernel's does."""
+    return bool(_cross_static_ok(geom, Cc, dev) and not torch.cuda.is_current_stream_capturing() and overlap_available())
 
 
 def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targets=None, ln=None, produce=None):
@@ -857,8 +871,9 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     rec, cprev = gates
     dev = dy.device
     Cc = dy.shape[-1]
-    assert can_fuse_stream(u, hs) and cprev is not None and w_lin.shape == (Cc, H) and u.numel() * u.element_size() in (
-        2 * geom.P * Cc, 4 * geom.P * Cc)
+    # hs None (wide role-split C = 32 form, no time segments): not stored, the kernel recomputes h from the records
+    assert (can_fuse_stream(u, hs) or (hs is None and _wide() and ROLE_SPLIT and Cc == 32 and FUSED_BPTT and LSTM_MMA == 1))
+    assert cprev is not None and w_lin.shape == (Cc, H) and u.numel() * u.element_size() in (2 * geom.P * Cc, 4 * geom.P * Cc)
     gmax = absmax_or_hint(dy)
     a = L.LstmBwdArgs()
     a.nseq, a.nsteps, a.n_inner, a.ndir = geom.nseq, geom.nsteps, geom.n_inner, 1
@@ -872,7 +887,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     a.dy, a.w_lin, a.C_lin = _p(dy), _p(w_lin), Cc
     ntiles = (geom.nseq + 15) // 16
     seg_scratch = None
-    if TIME_SEGMENTS and produce is None:
+    if TIME_SEGMENTS and produce is None and hs is not None:
         seg_scratch = _seg_scratch(a, geom, dev)
     du = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32)
     wpart = torch.empty(ntiles, 4 * H * (Cc + H) + 4 * H + Cc * H + Cc + (2 * Cc if ln is not None else 0), device=dev,
@@ -889,7 +904,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
         assert lin_targets[0].shape == (Cc, H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
     by = (geom.P * ((1280.0 if a.wide else 640.0) + 4.0 * Cc + 4.0 * Cc + (8.0 * Cc if ln is not None else 0.0))
-          + hs.numel() * hs.element_size() + u.numel() * u.element_size())
+          + (hs.numel() * hs.element_size() if hs is not None else 0) + u.numel() * u.element_size())
     fl = (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc + 2.0 * H * Cc) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else "")
                + (" [wide]" if a.wide else "") + (" [role-split]" if a.split else "")
@@ -1449,6 +1464,19 @@ def stft_mag_terms(spec_x, spec_y, rows, nbins, ld, eps, w_lin, w_log, w_sc, sca
     L.check(lib.sb_stft_mag_terms(_p(spec_x), _p(spec_y), rows, nbins, ld, eps, w_lin, w_log, w_sc, scale, _p(dsx), _p(part),
                                   _p(sums), _p(loss), _stream()), "sb_stft_mag_terms")
     return dsx
+
+
+def stft_f64acc(xp, w, spec, B_, nframes, ldp, hop, off, K, N, lo_off=0):
+    """spec[(b, t), :N] = frames of xp (row stride ldp, hop, first sample off) x w[N, K]^T, accumulated in double;
+    lo_off: element distance to the low plane of a (hi, lo) pair signal (fir_pair), 0 = none"""
+    L.check(L.load().sb_stft_f64acc(_p(xp), _p(w), _p(spec), B_, nframes, ldp, hop, off, K, N, lo_off, _stream()), "sb_stft_f64acc")
+
+
+def fir_pair(x, taps):
+    """fir() with the sum formed in double -> [2, B, N]: planes hi, lo with hi + lo the double result"""
+    y = torch.empty(2, *x.shape, device=x.device, dtype=torch.float32)
+    L.check(L.load().sb_fir_pair(_p(x), _p(taps), _p(y[0]), _p(y[1]), x.shape[0], x.shape[1], taps.numel(), _stream()), "sb_fir_pair")
+    return y
 
 
 def frames_fold(dframes, dx, nframes, K, ldk, hop, off, pad, accumulate):

@@ -116,7 +116,8 @@ def test_full_size_default_dispatch_matches_oracle(wl):
             # a concurrent side stream, the fused launch otherwise
             assert any(("inter-frame fused BPTT" in k or "inter overlapped" in k) and "[wide]" in k for k in labels), labels
             if wl == "big" and ops.overlap_available():
-                assert any("inter overlapped" in k and "[wide]" in k for k in labels), labels
+                # overlapped backward: across the two passes of a block (round 4) or the recurrence || stream-kernel pair
+                assert any(("inter overlapped" in k or "[cross-pass consumer, overlapped]" in k) and "[wide]" in k for k in labels), labels
                 assert any("[producer]" in k for k in labels) and any("[consumer, overlapped]" in k for k in labels), labels
         elif wl == "big" and ops.overlap_available():
             assert any("inter overlapped" in k for k in labels), labels          # overlapped backward pair

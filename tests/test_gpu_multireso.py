@@ -68,18 +68,13 @@ def test_all_three_magnitude_terms_match_oracle(w, B, T, weighting, l1):
     want = multireso_fuse_loss(ed, gt.double(), l1_ratio=l1, **kw)
     want.backward()
     assert abs(float(loss.detach()) - float(want.detach())) < 1e-4 * abs(float(want.detach())), (float(loss.detach()), float(want.detach()))
-    # The log-magnitude gradient is sign / |X| * X / |X|: it is dominated by the LOWEST-energy bins (the A-weighted spectrum
-    # falls 50 dB towards DC), where an fp32 spectrum -- any fp32 spectrum, the reference's own torch.stft included -- carries
-    # the rounding of the high-energy samples it was summed from.  Measured on the CPU: the oracle evaluated in fp32 (what the
-    # reference runs) differs from its float64 self by 2-3e-4 here with w_log_mag on, 2e-6 with the convergence term alone.
-    # The HIP path (a direct DFT: 600 .. 1200 fp32 products per bin where torch.stft's FFT sums log2 K stages) measured
-    # 3.5e-4 .. 6.2e-4 on the same cases.  It is held to float64 within 1e-4 or three times the reference arithmetic's own
-    # distance from it -- the 1e-4 the linear term meets is not reachable in fp32 for this term, by the reference either.
+    # The log-magnitude gradient is sign / |X| * X / |X|: it is dominated by the LOWEST-energy bins, where an fp32 spectrum --
+    # any fp32 spectrum, the reference's own torch.stft included -- carries the rounding of the products it was summed from:
+    # the oracle evaluated in fp32 differs from its float64 self by 5e-5 .. 3e-4 here depending on the host's FFT, and a
+    # sequential fp32 DFT sum (sb_linear_fwd) measured 2.7e-4 .. 6.2e-4.  The product therefore accumulates THIS spectrum in
+    # double (sb_stft_f64acc: exact products, one rounding) and is held to float64 at the 1e-4 of the other terms.
     e64 = rel_l2(eg.grad.cpu().numpy(), ed.grad.numpy())
-    e32 = est.detach().clone().requires_grad_(True)
-    multireso_fuse_loss(e32, gt, l1_ratio=l1, **kw).backward()
-    ref32 = rel_l2(e32.grad.numpy(), ed.grad.numpy())
-    assert e64 < max(1e-4, 3.0 * ref32) or rel_l2(eg.grad.cpu().numpy(), e32.grad.numpy()) < 1e-4, (e64, ref32)
+    assert e64 < 1e-4, e64
 
 
 def test_default_constructed_loss_runs_with_a_silent_target():
@@ -100,10 +95,7 @@ def test_default_constructed_loss_runs_with_a_silent_target():
     want.backward()
     assert torch.isfinite(eg.grad).all()
     assert abs(float(loss.detach()) - float(want.detach())) < 1e-4 * abs(float(want.detach()))
-    e32 = est.clone().requires_grad_(True)
-    multireso_fuse_loss(e32, gt).backward()
-    ref32 = rel_l2(e32.grad.numpy(), ed.grad.numpy())             # the reference arithmetic's own distance from float64
-    assert rel_l2(eg.grad.cpu().numpy(), ed.grad.numpy()) < max(1e-4, 3.0 * ref32), ref32
+    assert rel_l2(eg.grad.cpu().numpy(), ed.grad.numpy()) < 1e-4
 
 
 def test_one_finetune_train_step_of_the_shipped_config():

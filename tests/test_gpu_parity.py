@@ -961,6 +961,17 @@ def test_wide_fused_bptt_single_direction_matches_float64_autograd(torch_gpu, C_
           torch.zeros(256, device="cuda")]
     ltg = [torch.zeros(C_, 64, device="cuda"), torch.zeros(C_, device="cuda")]
     du = ops.lstm_bwd_fused(wh, gates, geom, dy, lin_w, u, hs, wi, tg, lin_targets=ltg)
+    if C_ == 32 and hook is None and ops.ROLE_SPLIT:
+        # round 4: this form (role split, no time segments) recomputes h from the records and needs no hs at all -- the forward
+        # of the cross-pass schedule does not store it (functional.InterFn: skip_hs)
+        hs_n, _, gates_n, u_n = ops.lstm_fwd(x, g, b, [(wi, wh, bi, bh)], geom, save=True, lin=(lin_w, lin_b, torch.empty_like(y)),
+                                             want_hs=False)
+        assert hs_n is None and torch.equal(u_n, u)          # (the record blocks of the ragged tile's missing sequences are never written)
+        tgn, ltgn = [torch.zeros_like(t) for t in tg], [torch.zeros_like(t) for t in ltg]
+        du_n = ops.lstm_bwd_fused(wh, gates_n, geom, dy, lin_w, u_n, None, wi, tgn, lin_targets=ltgn)
+        assert torch.equal(du_n, du)
+        for a_, b_ in zip(tgn + ltgn, tg + ltg):
+            assert torch.equal(a_, b_)
     dx = dgf = dbf = None
     if C_ == 16:
         tg2 = [torch.zeros_like(t) for t in tg]
@@ -1331,7 +1342,7 @@ def test_cross_pass_overlapped_backward_matches_the_plain_order(torch_gpu, B_, T
 
     def run(cross):
         monkeypatch.setattr(ops, "BWD_CROSS_OVERLAP", cross)
-        monkeypatch.setattr(ops, "BWD_OVERLAP", False)          # reference order: fused inter-frame launch + LayerNorm-backward kernel
+        monkeypatch.setattr(ops, "BWD_OVERLAP", cross)          # off: reference order -- fused inter-frame launch + LayerNorm-backward kernel
         for p_ in m.parameters():
             p_.grad = None
         ops.PROFILE = {}
@@ -1535,4 +1546,5 @@ def test_overlapped_schedules_are_deterministic_with_changing_inputs(torch_gpu):
         ops.PROFILE = None
     ops.check_sched_status()
     if ops.overlap_available():
-        assert any("[producer]" in k for k in labels) and any("inter overlapped" in k for k in labels), labels
+        assert any("[producer]" in k for k in labels), labels
+        assert any("inter overlapped" in k or "[cross-pass consumer, overlapped]" in k for k in labels), labels

@@ -19,7 +19,8 @@ ALL = ["SB_BPTT", "SB_EXACT_BPTT", "SB_NO_ROLE_SPLIT", "SB_NO_HS_RECOMPUTE", "SB
        "SB_NO_FUSED_BPTT", "SB_FORCE_FUSED_BPTT", "SB_LINEAR_FP32", "SB_NO_FWD_OVERLAP", "SB_NO_BWD_OVERLAP",
        "SB_NO_FWD_OVERLAP_INFERENCE", "SB_NO_INTER_SUM3", "SB_NO_INTER_FILM", "SB_NO_STREAM_LIN_WGRAD",
        "SB_NO_INTRA_LIN_FUSION", "SB_GATE_RECOMPUTE", "SB_BWD_PAIR_SERIAL", "SB_FWD_OVERLAP_SLAB", "SB_BWD_OVERLAP_SLAB",
-       "SB_OVERLAP_MAX_FILL", "SB_NO_VEC_LSTM", "SB_NO_INFER_WORKSPACE", "SB_INTER_GATE_RECOMPUTE"]
+       "SB_OVERLAP_MAX_FILL", "SB_NO_VEC_LSTM", "SB_NO_INFER_WORKSPACE", "SB_INTER_GATE_RECOMPUTE",
+       "SB_NO_BWD_CROSS_OVERLAP", "SB_BWD_CROSS_SLAB"]
 
 # (id, environment, gradient bar): 2e-4 = the wide (default) arithmetic's bar against the goldens, 2e-3 the compact one's
 WIDE, COMPACT = 2e-4, 2e-3
@@ -54,6 +55,10 @@ SWITCHES = [
     # round 4: the C = 32 inter-frame passes keep no gate records, the backward pair's recurrence recomputes them (opt-in)
     ("inter-gate-recompute", {"SB_INTER_GATE_RECOMPUTE": "1"}, WIDE),
     ("inter-gate-recompute-pair-serial", {"SB_INTER_GATE_RECOMPUTE": "1", "SB_BWD_PAIR_SERIAL": "1"}, WIDE),
+    # round 4: the backward overlapped ACROSS the two passes of a block (inter-frame fused producer || intra-frame consumer); off =
+    # the recurrence || stream-kernel pair of round 3
+    ("no-bwd-cross-overlap", {"SB_NO_BWD_CROSS_OVERLAP": "1"}, WIDE),
+    ("bwd-cross-slab", {"SB_BWD_CROSS_SLAB": "16"}, WIDE),
     ("no-vec-lstm", {"SB_NO_VEC_LSTM": "1"}, WIDE),
     ("no-infer-workspace", {"SB_NO_INFER_WORKSPACE": "1"}, WIDE),
     # every byte the medium stage allocates starts as NaN (debugging aid of the probe): a kernel that reads memory nobody
@@ -109,7 +114,8 @@ def test_default_dispatch_takes_the_benched_paths_at_the_medium_geometry(baselin
     assert any("intra-frame fused BPTT" in k and "[wide]" in k for k in big), big
     assert any("inter-frame fused BPTT" in k and "[wide]" in k for k in small), small
     if out["overlap"]:
-        assert any("inter overlapped" in k for k in big), big
+        # overlapped backward: across the two passes of a block (round 4 default) or the recurrence || stream-kernel pair
+        assert any("inter overlapped" in k or "[cross-pass producer]" in k for k in big), big
         assert any("[producer]" in k for k in big) and any("[consumer, overlapped]" in k for k in big), big
 
 
@@ -127,6 +133,10 @@ def test_switch_keeps_parity(baseline, sid, env, bar):
     if sid in ("no-fwd-overlap", "no-overlap-compact"):
         assert not any("[producer]" in k for k in big), big
     if sid in ("no-bwd-overlap", "no-overlap-compact"):
-        assert not any("inter overlapped" in k for k in big), big
+        assert not any("inter overlapped" in k or "[cross-pass" in k for k in big), big
+    if sid == "no-bwd-cross-overlap":
+        assert not any("[cross-pass" in k for k in big), big
+        if base["overlap"]:
+            assert any("inter overlapped" in k for k in big), big
     if sid.startswith("inter-gate-recompute"):
         assert any("[gates recomputed]" in k for k in big), big
