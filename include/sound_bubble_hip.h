@@ -227,27 +227,31 @@ int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
  * recurrence + stream-kernel pair of sb_lstm_bwd_inter_overlapped, but leaves 111 CUs idle -- and the kernel that follows it
  * in the backward pass, the bidirectional intra-frame backward of the same block, needs for a tile of 16 frames (b, t .. t +
  * 15) only the inter-frame result of those frames.  Two calls, the mirror image of sb_lstm_fwd_produce / _consume:
- *   sb_lstm_bwd_cross_produce(a, flags, slab_len, stream): sb_lstm_bwd_rec of the single-direction fused form (wide, split,
+ *   sb_lstm_bwd_cross_produce(a, flags, n_flags, slab_len, stream): sb_lstm_bwd_rec of the single-direction fused form (wide, split,
  *     C = C_lin = 32, du written, no LayerNorm rider, fewer tiles than CUs - 16) on `stream`; its du rows are stored
  *     write-through and after every slab_len steps (even), latest steps first, each tile t publishes its progress,
  *     flags[4 + t] = slabs completed (a plain write-through store per tile, not a contended counter per slab).
- *     flags: [4 + ceil(nseq / 16)] ints, zeroed by the call ([0] producer workgroups started, [1], [2] the consumer's item
- *     counters, [3] spare).
+ *     flags: n_flags = 4 + ceil(nseq / 16) + 16 + 3 * (the consumer's tiles) ints, zeroed by the call ([0] producer workgroups
+ *     started, [1 .. 3] spare, the producer tiles' progress words, the consumer's 16 item counters -- one queue per XCD and
+ *     direction -- and three words per consumer tile: prologue claimed / done / max |dy1|).
  *   sb_lstm_bwd_cross_consume(a, flags, slab_len, producer_tiles, order, need, stream): sb_lstm_bwd_rec of the bidirectional
  *     fused form (wide, split, C = C_lin = 32, hs == NULL: h recomputed from the records) whose incoming gradient does not
- *     exist yet: every (tile, direction) item first runs the block's inter-frame LayerNorm backward + residual over its own 16
- *     nsteps positions, pro_dy = LN-backward(pro_du; pro_x, pro_ln_g) + pro_res (pro_du = the producer's du, a->dy must equal
- *     pro_dy), deriving its fp16 scale per tile (gmax is not read; pass any valid scalar), and d_ln_g / d_ln_b [32] receive
+ *     exist yet: the block's inter-frame LayerNorm backward + residual runs per TILE of 16 nsteps positions, pro_dy =
+ *     LN-backward(pro_du; pro_x, pro_ln_g) + pro_res (pro_du = the producer's du, a->dy must equal pro_dy), ONCE per tile and XCD
+ *     -- by whichever item claims the tile first (its own, or one looking ahead down its queue); the other direction's item,
+ *     drawn from the same XCD's queue, waits for the tile's `done` word and reads the rows through the shared L2 -- and every
+ *     item derives its fp16 scale per tile (gmax is not read; pass any valid scalar), and d_ln_g / d_ln_b [32] receive
  *     that LayerNorm's parameter gradients.  Items are taken in the order order[ntiles] (need[i] packs, for tile order[i], the
  *     producer slab that completes its frames -- bits 0..11 -- and the range lo..hi of producer tiles that hold the sequences of
- *     its batch entries -- bits 12..21, 22..31) from one atomic counter per direction by TWO launches: persistent workgroups on the
+ *     its batch entries -- bits 12..21, 22..31) from eight queues per direction (item i in queue i mod 8; a workgroup draws from
+ *     the queue of the XCD it runs on and steals from the others when that is empty) by TWO launches: persistent workgroups on the
  *     library's side stream (one per CU the producer leaves idle, guarded as in sb_lstm_fwd_consume) and one per CU on
  *     `stream` behind the producer.  wpart: sb_lstm_bwd_cross_rows(a->nseq, producer_tiles) rows of
  *     256 * (32 + 64) + 256 + 32 * 128 + 32 + 64 floats.  Geometry: p_step == 1, p_inner == nsteps (rows of a tile contiguous).
  * The consume call must be the next library call after its produce call on that device; memory the producer touches must stay
  * allocated until it has returned.  -1003 bad geometry / arguments, -1009 without a concurrent side stream. */
 int sb_lstm_bwd_cross_rows(int nseq, int producer_tiles);
-int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a, int* flags, int slab_len, void* stream);
+int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a, int* flags, int n_flags, int slab_len, void* stream);
 int sb_lstm_bwd_cross_consume(const sb_lstm_bwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
                               const int* need, void* stream);
 

@@ -39,7 +39,7 @@ def ev():
 
 def run(mode, sync_between):
     slab = ops.BWD_CROSS_SLAB
-    flags = torch.empty((B * F + 15) // 16 + 4, device=dev, dtype=torch.int32)
+    flags = torch.empty((B * F + 15) // 16 + 4 + 16 + 3 * ((B * T + 15) // 16) + 24, device=dev, dtype=torch.int32)
     ops.absmax_hints_clear()
     e0, e1, e2 = ev(), ev(), ev()
     e0.record()
@@ -70,6 +70,10 @@ def run(mode, sync_between):
     e2.record()
     torch.cuda.synchronize()
     ops.check_sched_status()
+    if mode == 'cross' and os.environ.get('SB_DBG'):
+        nt = (B * T + 15) // 16
+        d = flags[(B * F + 15) // 16 + 4 + 16 + 3 * nt:].tolist()
+        print('   dbg: wg per (xcd,dir)', d[:16], ' lookahead', d[16], 'own', d[17], 'recomputed', d[18], 'waited', d[19], 'stolen items', d[20], ' us: rows %.1f / tile, done-wait %.1f / wait, slab-wait %.1f / own' % (d[21] * 64 / 100.0 / max(1, d[16] + d[17] + d[18]), d[22] * 64 / 100.0 / max(1, d[19]), d[23] * 64 / 100.0 / max(1, d[17] + d[18])))
     return e0.elapsed_time(e1), e1.elapsed_time(e2), e0.elapsed_time(e2)
 
 

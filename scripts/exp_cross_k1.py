@@ -28,7 +28,7 @@ def tg():
 
 def run(prod):
     slab = 32
-    flags = torch.empty((B * F + 15) // 16 + 4, device=dev, dtype=torch.int32)
+    flags = torch.empty((B * F + 15) // 16 + 4 + 16 + 3 * ((B * T + 15) // 16) + 24, device=dev, dtype=torch.int32)
     ops.absmax_hints_clear()
     ops.PROFILE = {}
     for _ in range(6):

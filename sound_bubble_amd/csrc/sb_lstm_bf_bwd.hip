@@ -103,10 +103,15 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   static_assert(!GREC || (SLAB && XP && FUSE_C == 32 && !SPLIT), "wide gate recomputation: overlapped inter-frame recurrence, C = 32");
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, q = lane >> 4, j = lane & 15;
   const bool crole = SPLIT && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;       // chunk role (waves 4..7)
-  // CONS: 1-D grid, direction = workgroup parity -- whatever subset of a launch the dispatcher has resident, it serves both
-  // directions evenly (with a (workgroups, 2) grid the x index runs first: next to 110 resident side-stream workgroups only
-  // 128 + 18 of the main launch fit, direction 1 was served by 73 workgroups against 183 and set the pace: +50 %)
-  const int dir = CONS ? (int)(blockIdx.x & 1) : (int)blockIdx.y;
+  // CONS: 1-D grid, direction = bit 3 of the workgroup index -- whatever subset of a launch the dispatcher has resident, it serves
+  // both directions evenly (with a (workgroups, 2) grid the x index runs first: next to 110 resident side-stream workgroups only
+  // 128 + 18 of the main launch fit, direction 1 was served by 73 workgroups against 183 and set the pace: +50 %), and every XCD
+  // gets both: the dispatcher deals consecutive workgroups round the 8 XCDs, so with direction = parity an XCD only ever saw one
+  // direction (which defeats the per-XCD sharing of a tile's rows: see the prologue).  The grid is a multiple of 16.
+#ifndef SB_EXP_DD
+#define SB_EXP_DD 0
+#endif
+  const int dir = CONS ? ((SB_EXP_DD & 128) ? (int)(blockIdx.x & 1) : (int)((blockIdx.x >> 3) & 1)) : (int)blockIdx.y;
   const int S = a.nsteps, ndir = a.ndir;
   const bool rev = dir == 1;
   if constexpr (SLAB || PROD) { if (tid == 0) __hip_atomic_fetch_add(a.slab_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -138,8 +143,26 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   // CONS: the item draw (uniform over the workgroup) and the guard of the launch that runs NEXT to the producer
   __shared__ int ord_item;
   __shared__ float pro_red[8];
+  // CONS: EIGHT queues per direction, one per XCD: item i of the slab-ordered list belongs to queue i mod 8, and a workgroup
+  // draws from the queue of the XCD it runs on (HW_REG_XCC_ID) -- both directions of a tile are then walked by CUs behind ONE
+  // L2, which is what lets the tile's incoming-gradient rows be computed once and shared through it (see the prologue) -- and
+  // steals from the other queues when its own is empty (any number of XCDs in the partition, and no idle tail).
+  const int xcd = CONS ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7) : 0;      // hwreg(HW_REG_XCC_ID, 0, 4)
   auto ord_next = [&]() -> int {
-    if (tid == 0) ord_item = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      const int nt = (a.nseq + 15) / 16;
+      int it = nt;
+      if constexpr ((SB_EXP_DD & 64) != 0) {
+        it = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else
+      for (int qq = 0; qq < 8 && it >= nt; ++qq) {
+        const int qx = (xcd + qq) & 7;
+        if (__hip_atomic_load(a.ord_counter + 2 * qx + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8 + qx >= nt) continue;
+        const int k = __hip_atomic_fetch_add(a.ord_counter + 2 * qx + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (8 * k + qx < nt) it = 8 * k + qx;
+      }
+      ord_item = it;
+    }
     __syncthreads();
     const int v = ord_item;
     __syncthreads();                                 // (the next draw may not overwrite it before everybody has read it)
@@ -1289,8 +1312,78 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
   // (chunk_tag: compile-time role of the caller -- the rescaling of the chunk role's running sums must not even be instantiated
   // in the recurrence role's loop, or its ~110 accumulator registers become live through that loop: 74 spilled registers and a
   // 45 % slower tile in the first version)
-  auto prologue = [&](int tile, auto chunk_tag) {
-    constexpr bool kChunkRole = decltype(chunk_tag)::value;
+  // ONE prologue per tile and XCD (round 4, second step): both directions of a tile need the same dy1 rows, and run by both the
+  // prologue moved 1.5 GB per block -- 0.36 ms of a 2.9 ms block at the chip's HBM rate, against 0.2 ms for the plain order's
+  // LayerNorm-backward kernel (scripts/exp_cross_consume.py with -DSB_EXP_CONS=1).  Per consumer tile three words (pst: claim,
+  // done, max |dy1|; zeroed by the produce call): whoever claims a tile first computes its rows, publishes the maximum and raises
+  // `done`; the other direction's item waits for `done` (bounded) and reads the maximum -- IF it runs behind the same L2.  The
+  // rows are plain (write-back) stores: CUs of one XCD share them through their L2, another XCD's L2 would fetch the lines from
+  // memory, where they may not have arrived (write-through stores were tried: a reader in the SAME workgroup then saw unwritten
+  // memory).  The claim and done words therefore carry 1 + the XCD, and an item that finds a tile claimed from another XCD (it
+  // stole the item, or the partition has fewer XCDs than queues) computes the rows again for itself -- identical values, and it
+  // leaves the LayerNorm parameter sums to the owner.  So that a wait is rarely a wait, every item first LOOKS AHEAD: the tile
+  // kLook8 draws further down ITS queue is claimed and computed now if its slabs are in and nobody has it.
+  int* const pst = CONS ? a.seg_flags : nullptr;
+#ifndef SB_EXP_DD
+#define SB_EXP_DD 0            // developer experiments: bit 0 no look-ahead, bit 1 recompute instead of waiting for `done`
+#endif
+  #ifndef SB_EXP_LOOK
+#define SB_EXP_LOOK 20
+#endif
+  constexpr int kLook8 = (SB_EXP_DD & 1) ? (1 << 26) : SB_EXP_LOOK;
+  // developer statistics (bit 5): behind the per-tile words -- [0..15] workgroups per (XCD, direction), [16] look-ahead rows computed,
+  // [17] own, [18] recomputed (owner behind another L2), [19] waited for, [20] items taken from another XCD's queue
+  // [21] ticks / 64 in the row computation, [22] waiting for `done`, [23] waiting for the producer's slabs
+  auto dbg_add = [&](int i, int v = 1) {
+    if constexpr ((SB_EXP_DD & 32) != 0) { if (tid == 0) __hip_atomic_fetch_add(pst + 3 * ntiles + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  };
+  auto dbg_now = [&]() -> unsigned long long { return (SB_EXP_DD & 32) ? __builtin_readcyclecounter() : 0ull; };
+  auto pro_claim = [&](int t) __attribute__((always_inline)) -> int {               // 0: this workgroup owns tile t's rows; else 1 + the owner's XCD  (uniform)
+    if (tid == 0) {
+      int expected = 0;
+      __hip_atomic_compare_exchange_strong(pst + t, &expected, 1 + xcd, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ord_item = expected;                           // (the old value: 0 = exchanged)
+    }
+    __syncthreads();
+    const int v = ord_item;
+    __syncthreads();
+    return v;
+  };
+  auto pro_ready = [&](int packed) __attribute__((always_inline)) -> bool {         // non-blocking cross_wait: are the tile's producer slabs complete?  (uniform)
+    const int need = (packed & 0xFFF) + 1, lo = (packed >> 12) & 0x3FF, hi = (packed >> 22) & 0x3FF;
+    if (tid == 0) ord_item = 1;
+    __syncthreads();
+    for (int t = lo + tid; t <= hi; t += 512)
+      if (__hip_atomic_load(a.slab_flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) ord_item = 0;
+    __syncthreads();
+    const int v = ord_item;
+    __syncthreads();
+    return v != 0;
+  };
+  auto pro_done_wait = [&](int t) __attribute__((always_inline)) -> bool {          // bounded like cross_wait; uniform
+    __shared__ int dw_abort;
+    if (tid == 0) {
+      int bad = 0;
+      unsigned spins = 0;
+      while (__hip_atomic_load(pst + ntiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        ++spins;
+        if ((spins & 63u) == 0 &&
+            (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          __hip_atomic_store(a.sched_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      dw_abort = bad;
+    }
+    __syncthreads();
+    return dw_abort == 0;
+  };
+  // own: this workgroup owns the tile (it reports the LayerNorm sums and publishes); -> max |dy1| of the tile (uniform)
+  // (always_inline: called from four places, hipcc otherwise makes it a real function -- calls, a stack, 1 KB of scratch per lane
+  //  and a consumer 0.5 ms slower)
+  auto pro_compute = [&](int tile, bool own) __attribute__((always_inline)) -> float {
     constexpr int CC = FST > 0 ? FST : 32;
     static_assert(!CONS || CC == 32, "prologue: 8 lanes x 4 channels per position");
     const int cp8 = tid & 7;                         // this lane's channels 4 cp8 .. 4 cp8 + 3
@@ -1348,7 +1441,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     if (lane == 0) pro_red[tid >> 6] = amax;
     __builtin_amdgcn_s_waitcnt(0);                   // this wave's dy1 rows are out ...
     __syncthreads();                                 // ... and so are everybody's: the tile's readers may start
-    if (dir == 0 && tid < 64) {                      // (both directions run the same rows: direction 0 reports the sums)
+    if (own && tid < 64) {                           // (the tile's owner reports its sums)
       const float* red = &R[0][0][0][0][0][0];
       float sum = 0.f;
       for (int g = 0; g < 64; ++g) sum += red[g * 64 + tid];
@@ -1357,6 +1450,16 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     float m = pro_red[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) m = fmaxf(m, pro_red[i]);
+    if (own && tid == 0) {                           // publish: the maximum, then (acknowledged) the flag
+      __hip_atomic_store(pst + 2 * ntiles + tile, __float_as_int(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_store(pst + ntiles + tile, 1 + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                 // (pro_red and R are rewritten: the next prologue, this tile's chunks)
+    return m;
+  };
+  auto pro_scale = [&](float m, auto chunk_tag) __attribute__((always_inline)) {
+    constexpr bool kChunkRole = decltype(chunk_tag)::value;
     const float Sn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
         (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f)));
     const float ratio = Sn * invS;                   // a power of two: the running sums move to the new scale exactly
@@ -1374,8 +1477,36 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         for (int ct = 0; ct < CK; ++ct) { lacc[ct] *= ratio; lbs[ct] *= ratio; }
       }
     }
-    __syncthreads();                                 // (pro_red and R are rewritten: the next prologue, this tile's chunks)
   };
+  // an item's entry: look ahead, then this tile's rows -- computed here or awaited -- and its scale; false: watchdog
+  auto prologue = [&](int item, int tile, auto chunk_tag) __attribute__((always_inline)) -> bool {
+    if ((item & 7) != xcd) dbg_add(20);
+    const int la = item + 8 * kLook8;                // same queue (same residue mod 8): a tile this XCD is the home of
+    if ((item & 7) == xcd && la < nitems) {
+      const int tl = a.tile_order[la];
+      if (pro_ready(a.tile_need[la]) && pro_claim(tl) == 0) { const auto t0 = dbg_now(); pro_compute(tl, true); dbg_add(16); dbg_add(21, (int)((dbg_now() - t0) >> 6)); }
+    }
+    float m;
+    const int owner = (SB_EXP_DD & 2) ? 9 : pro_claim(tile);
+    if (owner == 0 || owner != 1 + xcd) {            // mine, or computed behind another L2: (re)compute the rows here
+      const auto t0 = dbg_now();
+      if (!cross_wait(a.tile_need[item])) return false;
+      const auto t1 = dbg_now();
+      m = pro_compute(tile, owner == 0);
+      dbg_add(owner == 0 ? 17 : 18);
+      dbg_add(23, (int)((t1 - t0) >> 6)); dbg_add(21, (int)((dbg_now() - t1) >> 6));
+    } else {
+      dbg_add(19);
+      const auto t0 = dbg_now();
+      if (!pro_done_wait(tile)) return false;
+      dbg_add(22, (int)((dbg_now() - t0) >> 6));
+      m = __int_as_float(__builtin_amdgcn_readfirstlane(
+          __hip_atomic_load(pst + 2 * ntiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    }
+    pro_scale(m, chunk_tag);
+    return true;
+  };
+  if constexpr (CONS) { if (ord_first < nitems) dbg_add(2 * xcd + dir); }
   if constexpr (SPLIT) {
     // Periods of two barriers.  Recurrence role, period k: the two steps of pair k (dgates -> LDS slots 2 (k & 1), + 1); after
     // the last pair one empty period.  Chunk role, period 0: the Linear's top row; period k >= 1: the chunk of pair k - 1
@@ -1392,9 +1523,8 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
         const int s_lo = SEG ? max(0, s_hi - a.seg_len + 1) : 0;
         const int npairs = (s_hi - s_lo + 2) / 2;                  // the last pair may be a single step
         set_tile(tile);
-        if constexpr (CONS) {                                      // the producer's slab that completes this tile's frames
-          if (!cross_wait(a.tile_need[item])) return;
-          prologue(tile, std::false_type{});
+        if constexpr (CONS) {                                      // this tile's incoming gradient rows (and the look-ahead)
+          if (!prologue(item, tile, std::false_type{})) return;
         }
         dc = zero4();
         dhrec = zero4();
@@ -1463,8 +1593,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
       const int npairs = (s_hi - s_lo + 2) / 2;
       set_tile(tile);
       if constexpr (CONS) {
-        if (!cross_wait(a.tile_need[item])) return;
-        prologue(tile, std::true_type{});
+        if (!prologue(item, tile, std::true_type{})) return;
       }
       if constexpr (SEG) { if (seg > 0) { if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return; } }
       if constexpr (LINW && !HREC) { if (s_hi == S - 1) lin_top(); }
@@ -1639,7 +1768,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_l
     constexpr int Ktot = FST + H;
     constexpr int LW = BI ? 2 * H : H;               // row length of the dW_lin partial: both directions' columns
     if constexpr (CONS) { if (!crole) return; }      // (the recurrence role came along for the barriers of the draws)
-    float* part = a.wpart + (CONS ? (size_t)a.row_base + (size_t)dir * (gridDim.x >> 1) + (blockIdx.x >> 1)
+    float* part = a.wpart + (CONS ? (size_t)a.row_base + (size_t)dir * (gridDim.x >> 1) + ((SB_EXP_DD & 128) ? (blockIdx.x >> 1) : (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)))
                                   : (size_t)dir * gridDim.x + blockIdx.x) *
                   ((size_t)4 * H * Ktot + 4 * H + (LINW ? FST * LW + FST : 0) + (LNB || CONS ? 2 * FST : 0));
 #pragma unroll

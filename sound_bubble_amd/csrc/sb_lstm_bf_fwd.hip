@@ -587,6 +587,24 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       if (prod) st4_sc1(yp, v); else st4(yp, v);
     }
   };
+  // the tile owners' epilogue of a step as ONE block (one-workgroup-per-CU kernels): y of the previous step, then this step's
+  // residual.  FiLM is always applied (planes 1 / 0 without it: v 1 + 0 = v), and the item's first step, which has no previous y,
+  // writes what it has to its OWN row -- the next step replaces it (same lane, same address, program order) -- so the block has
+  // two uniform tests left (y_pre, write-through) where store_y + load_res had seven: ~16 ticks each on a one-wave SIMD.
+  auto epilogue = [&](int64_t ey, int sy, int64_t er) {
+    if (cvalid) {
+      f32x4 v = yacc + lbias + xres;
+      if (a.y_pre) st_side(reinterpret_cast<f32x4*>(a.y_pre + ey + co_y), v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], fw[r], fb[r]);
+      float* yp = a.y + (lin_part ? 2 * ey : ey) + co_y;
+      if (prod) st4_sc1(yp, v); else st4(yp, v);
+      if (!lin_part) {
+        if constexpr (TWO) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);
+        else xres = ld4(a.x + er + co_y);
+      }
+    }
+  };
   auto load_res = [&](int sy, int64_t ey) {
     if (linw && cvalid && !lin_part && !(SB_EXP_SKIP & 32)) {
       if constexpr (TWO) xres = ld4(&XS[sy & 3][j][16 * w + 4 * q]);         // the raw row is in the ring
@@ -677,7 +695,14 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         }
       }
     }
-    if constexpr (LIN) {
+#ifdef SB_EXP_NO_EPI
+    constexpr bool EPI1 = false;
+#else
+    constexpr bool EPI1 = LIN && HEAVY && !SB_EXP_SKIP;
+#endif
+    if constexpr (EPI1) {
+      if (linw) epilogue(s > s_begin ? run_x - d_x : run_x, s, run_x);
+    } else if constexpr (LIN) {
       if (s > s_begin) store_y(run_x - d_x);
       load_res(s, run_x);
     }

@@ -1419,6 +1419,10 @@ static void cross_grids(int nseq, int producer_tiles, int* g1, int* g2) {
   if (a > ntiles) a = ntiles;
   if (b < 1) b = 1;
   if (b > ntiles) b = ntiles;
+  // multiples of 8 per direction: the consumer's direction is bit 3 of the workgroup index (see the kernel), so that the 16
+  // workgroups the dispatcher deals round the XCDs carry both directions to every XCD; a workgroup or two beyond the idle CUs
+  // just starts late and draws less
+  a = (a + 7) & ~7; b = (b + 7) & ~7;
   *g1 = a; *g2 = b;
 }
 extern "C" int sb_lstm_bwd_cross_rows(int nseq, int producer_tiles) {
@@ -1427,7 +1431,7 @@ extern "C" int sb_lstm_bwd_cross_rows(int nseq, int producer_tiles) {
   return 2 * (g1 + g2);
 }
 
-extern "C" int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a_in, int* flags, int slab_len, void* stream) {
+extern "C" int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a_in, int* flags, int n_flags, int slab_len, void* stream) {
   if (!a_in || !flags) return -1001;
   sb_lstm_bwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
@@ -1437,8 +1441,10 @@ extern "C" int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a_in, int* flag
     return -1003;
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
-  // flags: [0] producer workgroups started, [1], [2] the consumer's item counters, [3] spare, [4 + tile] slabs completed by tile
-  if (hipMemsetAsync(flags, 0, (size_t)(ntiles + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
+  // flags: [0] producer workgroups started, [1 .. 3] spare, [4 + tile] slabs completed by tile, then the consumer's 16 item
+  // counters and three words per CONSUMER tile (prologue claimed / done / max |dy1|)
+  if (n_flags < ntiles + 4) return -1003;
+  if (hipMemsetAsync(flags, 0, (size_t)n_flags * sizeof(int), main_st) != hipSuccess) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
   a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_started = flags;
   a.seg_state = nullptr; a.seg_flags = nullptr;                           // (no time segments under the producer)
@@ -1458,7 +1464,9 @@ extern "C" int sb_lstm_bwd_cross_consume(const sb_lstm_bwd_args* a_in, int* flag
   int g1, g2;
   cross_grids(a.nseq, producer_tiles, &g1, &g2);
   a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_need = producer_tiles; a.slab_started = flags;
-  a.tile_order = order; a.tile_need = need; a.ord_counter = flags + 1;
+  // behind the producer's progress words: 16 item counters (8 XCD queues x 2 directions), then three words per consumer tile
+  a.tile_order = order; a.tile_need = need; a.ord_counter = flags + 4 + producer_tiles;
+  a.seg_state = nullptr; a.seg_flags = flags + 4 + producer_tiles + 16;  // (no time segments here: the per-tile prologue words)
   // next to the producer: one persistent workgroup (8 waves, 256 registers each: none fits on a producer's CU) per idle CU;
   // one that cannot be placed at once starts later and draws fewer items
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;

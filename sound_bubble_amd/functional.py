@@ -380,7 +380,8 @@ class InterFn(torch.autograd.Function):
             # forward handed us the two halves) starts on the idle CUs and forms dx = LN-backward(du) + dy itself, tile by tile.
             # What goes back through autograd is the dx BUFFER, filled by that kernel (ops.CROSS_PENDING carries the rest).
             slab = ops.BWD_CROSS_SLAB
-            flags = torch.empty((geom.nseq + 15) // 16 + 4, device=dy.device, dtype=torch.int32)
+            # (4 + producer tiles + 16 item counters + three words per consumer tile of 16 frames: sb_lstm_bwd_cross_produce zeroes them)
+            flags = torch.empty((geom.nseq + 15) // 16 + 4 + 16 + 3 * ((B * T + 15) // 16) + 24, device=dy.device, dtype=torch.int32)
             du, overlapped, keep = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
                                                       lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)),
                                                       produce=(flags, slab))

@@ -911,7 +911,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
                + (" [cross-pass producer]" if produce is not None else ""),
                fl, 8.0 * Cc * geom.P, by):
         if produce is not None:            # (flags, slab): publish du slab by slab for the intra-frame backward of the same block
-            rc = lib.sb_lstm_bwd_cross_produce(C.byref(a), C.c_void_p(produce[0].data_ptr()), produce[1], _stream())
+            rc = lib.sb_lstm_bwd_cross_produce(C.byref(a), C.c_void_p(produce[0].data_ptr()), produce[0].numel(), produce[1], _stream())
             if rc == -1009:                # no side stream (any more): the plain launch; the caller materialises dy1 itself
                 overlap_lost()
                 L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
