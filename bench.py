@@ -328,14 +328,49 @@ DTYPE_FWD = "f32 storage/accumulate; matrix products on the fp16 pipe with hi+lo
 # its Linear in the kernel too: they are told apart by the grid (bidirectional = twice the workgroups of more tiles).
 # the overlapped inter-frame backward: recurrence (dgates to HBM, slab flags) + stream kernel, counted in plain order
 # (SB_BWD_PAIR_SERIAL=1 passes, profiles/r*_pmc_traffic_<wl>_wide_pair.json): the pair's traffic is the SUM of the two
-PMC_PAIR = (r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, false, 0, false, false, false, false, true", r"lstm_bwd_stream_f16_kernel")
+# The backward recurrence's variant switches: thirteen positional bools up to round 3 / the first r04 profiles
+# (lstm_bwd_rec_bf_kernel<FULL, REC16, FUSE_C, DG16, SEG, FST, LNB, BI, HS16B, RECOMP, SLAB, XP, ...>), one bit set since
+# (lstm_bwd_rec_bf_kernel<KF, FUSE_C, FST>, bits as in csrc/sb_lstm_bf_bwd.hip) -- both spellings occur in committed summaries.
+_KBITS = {"FULL": 0, "REC16": 1, "DG16": 2, "SEG": 3, "LNB": 4, "BI": 5, "HS16B": 6, "RECOMP": 7, "SLAB": 8, "XP": 9, "SPLIT": 10,
+          "GREC": 11, "PROD": 12, "CONS": 13}
+
+
+def _bwd_variant(name):
+    import re
+    m = re.search(r"lstm_bwd_rec_bf_kernel<([^<>]*)>", name)
+    if not m:
+        return None
+    args = [x.strip() for x in m.group(1).split(",")]
+    if len(args) == 3 and re.fullmatch(r"\d+[uU]?", args[0]):
+        kf = int(args[0].rstrip("uU"))
+        v = {k: bool(kf >> b & 1) for k, b in _KBITS.items()}
+        v["FUSE_C"], v["FST"] = int(args[1]), int(args[2])
+        return v
+    order = ["FULL", "REC16", "FUSE_C", "DG16", "SEG", "FST", "LNB", "BI", "HS16B", "RECOMP", "SLAB", "XP", "SPLIT", "GREC", "PROD", "CONS"]
+    v = {k: False for k in _KBITS}
+    v["FUSE_C"] = v["FST"] = 0
+    for k, x in zip(order, args):
+        v[k] = int(x) if k in ("FUSE_C", "FST") else x == "true"
+    return v
+
+
+def _is(pred):
+    return lambda name: (lambda v: v is not None and pred(v))(_bwd_variant(name))
+
+
+def _re(pat):
+    import re
+    return lambda name: re.search(pat, name) is not None
+
+
+PMC_PAIR = (_is(lambda v: v["DG16"] and not v["SEG"] and v["FST"] == 0 and v["SLAB"]), _re(r"lstm_bwd_stream_f16_kernel"))
 PMC_PATTERNS = [
-    ("intra-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, false, \d+, false, true", None),
-    ("inter-frame fused BPTT", r"lstm_bwd_rec_bf_kernel<\w+, \w+, \d+, true, \w+, (16|32), \w+, false", None),
-    ("recurrence only", r"lstm_bwd_rec_bf_kernel<\w+, true, \d+, true, \w+, 0, false, false", None),
-    ("lstm_bwd_stream", r"lstm_bwd_stream_f16_kernel", None),
-    ("intra-frame (bidirectional)", r"lstm_fwd_bf_kernel<", "max-grid"),
-    ("inter-frame (Linear fused)", r"lstm_fwd_bf_kernel<", "min-grid"),
+    ("intra-frame fused BPTT", _is(lambda v: v["DG16"] and v["BI"] and v["FST"] > 0), None),
+    ("inter-frame fused BPTT", _is(lambda v: v["DG16"] and not v["BI"] and v["FST"] in (16, 32)), None),
+    ("recurrence only", _is(lambda v: v["REC16"] and v["DG16"] and v["FST"] == 0 and not v["BI"]), None),
+    ("lstm_bwd_stream", _re(r"lstm_bwd_stream_f16_kernel"), None),
+    ("intra-frame (bidirectional)", _re(r"lstm_fwd_bf_kernel<"), "max-grid"),
+    ("inter-frame (Linear fused)", _re(r"lstm_fwd_bf_kernel<"), "min-grid"),
 ]
 
 
@@ -351,7 +386,7 @@ def pmc_traffic(workload, label, mode="wide"):
         ks = json.load(open(pf[-1]))["kernels"]
         parts = []
         for pat in PMC_PAIR:
-            m = [v for k, v in ks.items() if re.search(pat, k)]
+            m = [v for k, v in ks.items() if pat(k)]
             if not m:
                 return None, None
             parts.append(sum(v["hbm_bytes"] * v["launches"] for v in m) / sum(v["launches"] for v in m))
@@ -362,7 +397,7 @@ def pmc_traffic(workload, label, mode="wide"):
     if not files or ent is None:
         return None, None
     pat, sel = ent
-    ks = [(k, v) for k, v in json.load(open(files[-1]))["kernels"].items() if re.search(pat, k)]
+    ks = [(k, v) for k, v in json.load(open(files[-1]))["kernels"].items() if pat(k)]
     if sel and ks:
         grid = lambda k: int(re.search(r"grid=(\d+)", k).group(1))
         pick = (max if sel == "max-grid" else min)(grid(k) for k, _ in ks)

@@ -93,10 +93,17 @@ constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four p
 //   workgroup's own readers and for the LayerNorm backward that follows; both directions of a tile write the same values).
 //   Its scale S for the fp16 terms is derived PER TILE from max |dy1| (the running dW sums are rescaled by the power-of-two
 //   ratio when a workgroup moves to its next tile), so no gradient maximum has to be known before the launch.
-template <bool FULL, bool REC16, int FUSE_C, bool DG16, bool SEG, int FST = 0, bool LNB = false, bool BI = false,
-          bool HS16B = false, bool RECOMP = false, bool SLAB = false, bool XP = false, bool SPLIT = false, bool GREC = false,
-          bool PROD = false, bool CONS = false>
-__global__ __launch_bounds__(SPLIT ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
+// Variant switches of the kernel as ONE bit set (round 4; they were thirteen positional bools): instantiations read
+// lstm_bwd_rec_bf_kernel<K_FULL | K_DG16 | K_XP | K_SPLIT | K_BI | K_CONS, 32, 32>.  What each stands for is described above.
+enum : unsigned { K_FULL = 1u << 0, K_REC16 = 1u << 1, K_DG16 = 1u << 2, K_SEG = 1u << 3, K_LNB = 1u << 4, K_BI = 1u << 5,
+                  K_HS16B = 1u << 6, K_RECOMP = 1u << 7, K_SLAB = 1u << 8, K_XP = 1u << 9, K_SPLIT = 1u << 10, K_GREC = 1u << 11,
+                  K_PROD = 1u << 12, K_CONS = 1u << 13 };
+template <unsigned KF, int FUSE_C, int FST = 0>
+__global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_kernel(sb_lstm_bwd_args a) {
+  constexpr bool FULL = (KF & K_FULL) != 0, REC16 = (KF & K_REC16) != 0, DG16 = (KF & K_DG16) != 0, SEG = (KF & K_SEG) != 0,
+                 LNB = (KF & K_LNB) != 0, BI = (KF & K_BI) != 0, HS16B = (KF & K_HS16B) != 0, RECOMP = (KF & K_RECOMP) != 0,
+                 SLAB = (KF & K_SLAB) != 0, XP = (KF & K_XP) != 0, SPLIT = (KF & K_SPLIT) != 0, GREC = (KF & K_GREC) != 0,
+                 PROD = (KF & K_PROD) != 0, CONS = (KF & K_CONS) != 0;
   static_assert(!PROD || (SPLIT && XP && !BI && FST == 32 && !SEG && !LNB), "cross-pass producer: role-split wide single-direction fused form");
   static_assert(!CONS || (SPLIT && XP && BI && FST == 32 && FUSE_C == 32), "cross-pass consumer: role-split wide bidirectional fused form");
   static_assert(!SPLIT || (FST > 0 && !RECOMP && !SLAB), "role split: fused forms");
@@ -1858,10 +1865,10 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     dim3 g2(gx, 2);
-#define SB_FB(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_>), g2, block, 0, st, a)
-#define SB_FBX(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC_, true, false, CC, false, true, false, false, false, true>), g2, block, 0, st, a)
-#define SB_FBXS(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC_, true, false, CC, false, true, false, false, false, true, true>), g2, dim3(512), 0, st, a)
-#define SB_FBS(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC_, true, false, CC, false, true, H16_, false, false, false, true>), g2, dim3(512), 0, st, a)
+#define SB_FB(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_REC16 | K_DG16 | K_BI | (H16_) * K_HS16B, FC_, CC>), g2, block, 0, st, a)
+#define SB_FBX(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_DG16 | K_BI | K_XP, FC_, CC>), g2, block, 0, st, a)
+#define SB_FBXS(FL, FC_, CC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_DG16 | K_BI | K_XP | K_SPLIT, FC_, CC>), g2, dim3(512), 0, st, a)
+#define SB_FBS(FL, FC_, CC, H16_) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_REC16 | K_DG16 | K_BI | (H16_) * K_HS16B | K_SPLIT, FC_, CC>), g2, dim3(512), 0, st, a)
     if (a.split && a.recompute) return -1003;
     if (a.tile_order) {
       // cross-pass consumer (sb_lstm_bwd_cross_consume launches it twice and runs the partial-row reductions itself)
@@ -1870,8 +1877,8 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
           a.pro_dy != a.dy || a.p_step != 1 || a.p_inner != a.nsteps || a.row_base < 0)
         return -1003;
       dim3 gc(2 * a.ord_grid);                       // direction = workgroup parity (see the kernel)
-      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, false, 32, true, false, 32, false, true, false, false, false, true, true, false, false, true>), gc, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, false, 32, true, false, 32, false, true, false, false, false, true, true, false, false, true>), gc, dim3(512), 0, st, a);
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_FULL | K_DG16 | K_BI | K_XP | K_SPLIT | K_CONS, 32, 32>), gc, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_DG16 | K_BI | K_XP | K_SPLIT | K_CONS, 32, 32>), gc, dim3(512), 0, st, a);
       SB_CHECK_LAUNCH();
       return 0;
     }
@@ -1894,8 +1901,8 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     else if (a.C == 32 && fc == 32 && !a.recompute) { if (full) SB_FB(true, 32, 32, true); else SB_FB(false, 32, 32, true); }
     else if (a.C == 32 && fc == 32) {               // gate recomputation: no gate records, forward weights + biases needed
       if (!a.b_ih[0] || !a.b_hh[0] || !a.b_ih[1] || !a.b_hh[1]) return -1003;
-      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, true, 32, true, false, 32, false, true, true, true>), g2, block, 0, st, a);
-      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, true, 32, true, false, 32, false, true, true, true>), g2, block, 0, st, a);
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_FULL | K_REC16 | K_DG16 | K_BI | K_HS16B | K_RECOMP, 32, 32>), g2, block, 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_REC16 | K_DG16 | K_BI | K_HS16B | K_RECOMP, 32, 32>), g2, block, 0, st, a);
     }
     else return -1003;
 #undef SB_FBS
@@ -1922,24 +1929,24 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     if (lnb && (a.C != 16 || !a.ln_x || !a.ln_g)) return -1003;
     if (!lnb && !a.du) return -1003;
 #define SB_F(FL, CC, SG, LB) do { \
-    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC, LB>>()) return -1008; \
-    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, CC, true, SG, CC, LB>), grid, block, 0, st, a); } while (0)
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_REC16 | K_DG16 | (SG) * K_SEG | (LB) * K_LNB, CC, CC>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_REC16 | K_DG16 | (SG) * K_SEG | (LB) * K_LNB, CC, CC>), grid, block, 0, st, a); } while (0)
 #define SB_FC(CC, LB) do { if (full) { if (seg) SB_F(true, CC, true, LB); else SB_F(true, CC, false, LB); } \
                            else { if (seg) SB_F(false, CC, true, LB); else SB_F(false, CC, false, LB); } } while (0)
 #define SB_FX(FL, CC, SG, LB) do { \
-    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, false, CC, true, SG, CC, LB, false, false, false, false, true>>()) return -1008; \
-    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, CC, true, SG, CC, LB, false, false, false, false, true>), grid, block, 0, st, a); } while (0)
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_DG16 | (SG) * K_SEG | (LB) * K_LNB | K_XP, CC, CC>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_DG16 | (SG) * K_SEG | (LB) * K_LNB | K_XP, CC, CC>), grid, block, 0, st, a); } while (0)
 #define SB_FXC(CC, LB) do { if (full) { if (seg) SB_FX(true, CC, true, LB); else SB_FX(true, CC, false, LB); } \
                             else { if (seg) SB_FX(false, CC, true, LB); else SB_FX(false, CC, false, LB); } } while (0)
 #define SB_FS(FL, R16_, CC, SG, LB, XP_) do { \
-    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, R16_, CC, true, SG, CC, LB, false, false, false, false, XP_, true>, 512>()) return -1008; \
-    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16_, CC, true, SG, CC, LB, false, false, false, false, XP_, true>), grid, dim3(512), 0, st, a); } while (0)
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<(FL) * K_FULL | (R16_) * K_REC16 | K_DG16 | (SG) * K_SEG | (LB) * K_LNB | (XP_) * K_XP | K_SPLIT, CC, CC>, 512>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | (R16_) * K_REC16 | K_DG16 | (SG) * K_SEG | (LB) * K_LNB | (XP_) * K_XP | K_SPLIT, CC, CC>), grid, dim3(512), 0, st, a); } while (0)
 #define SB_FSC(R16_, CC, LB, XP_) do { if (full) { if (seg) SB_FS(true, R16_, CC, true, LB, XP_); else SB_FS(true, R16_, CC, false, LB, XP_); } \
                                        else { if (seg) SB_FS(false, R16_, CC, true, LB, XP_); else SB_FS(false, R16_, CC, false, LB, XP_); } } while (0)
     if (a.slab_flags) {                               // cross-pass producer (sb_lstm_bwd_cross_produce)
       if (!a.split || !wide || a.C != 32 || lnb || seg || !a.slab_started || a.slab_len < 2 || (a.slab_len & 1)) return -1003;
-      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, false, 32, true, false, 32, false, false, false, false, false, true, true, false, true>), grid, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, false, 32, true, false, 32, false, false, false, false, false, true, true, false, true>), grid, dim3(512), 0, st, a);
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_FULL | K_DG16 | K_XP | K_SPLIT | K_PROD, 32, 32>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_DG16 | K_XP | K_SPLIT | K_PROD, 32, 32>), grid, dim3(512), 0, st, a);
     } else
     if (a.split && wide) { if (a.C == 16) { if (lnb) SB_FSC(false, 16, true, true); else SB_FSC(false, 16, false, true); } else SB_FSC(false, 32, false, true); }
     else if (a.split) { if (a.C == 16) { if (lnb) SB_FSC(true, 16, true, false); else SB_FSC(true, 16, false, false); } else SB_FSC(true, 32, false, false); }
@@ -1965,12 +1972,12 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
   if (a.slab_flags) {                               // overlapped form: see sb_lstm_bwd_inter_overlapped
     if (seg || !dg16 || a.ndir != 1 || a.slab_len < 2 || (a.slab_len & 1) || (fc != 16 && fc != 32) || !a.slab_started)
       return -1003;
-#define SB_SLB(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, true, FC, true, false, 0, false, false, false, false, true>), grid, block, 0, st, a)
-#define SB_SLBX(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, false, FC, true, false, 0, false, false, false, false, true, true>), grid, block, 0, st, a)
+#define SB_SLB(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_REC16 | K_DG16 | K_SLAB, FC, 0>), grid, block, 0, st, a)
+#define SB_SLBX(FL, FC) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | K_DG16 | K_SLAB | K_XP, FC, 0>), grid, block, 0, st, a)
     if (wide && a.recompute) {                      // no gate records: recomputed from the u / hs pairs (GREC in the kernel)
       if (fc != 32 || !a.u || !a.hs || !a.w_ih || !a.b_ih[0] || !a.b_hh[0] || !a.save_c) return -1003;
-      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<true, false, 32, true, false, 0, false, false, false, false, true, true, false, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<false, false, 32, true, false, 0, false, false, false, false, true, true, false, true>), grid, block, 0, st, a);
+      if (full) hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_FULL | K_DG16 | K_SLAB | K_XP | K_GREC, 32, 0>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<K_DG16 | K_SLAB | K_XP | K_GREC, 32, 0>), grid, block, 0, st, a);
     } else if (wide) {
       if (fc == 32) { if (full) SB_SLBX(true, 32); else SB_SLBX(false, 32); }
       else { if (full) SB_SLBX(true, 16); else SB_SLBX(false, 16); }
@@ -1983,8 +1990,8 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
     return 0;
   }
 #define SB_B(FL, R16, FC, D16, SG) do { \
-    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>>()) return -1008; \
-    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<FL, R16, FC, D16, SG>), grid, block, 0, st, a); } while (0)
+    if (SG && !fits_one_per_cu<lstm_bwd_rec_bf_kernel<(FL) * K_FULL | (R16) * K_REC16 | (D16) * K_DG16 | (SG) * K_SEG, FC, 0>>()) return -1008; \
+    hipLaunchKernelGGL((lstm_bwd_rec_bf_kernel<(FL) * K_FULL | (R16) * K_REC16 | (D16) * K_DG16 | (SG) * K_SEG, FC, 0>), grid, block, 0, st, a); } while (0)
 #define SB_BR(FL, FC) do { if (seg) SB_B(FL, true, FC, true, true); else if (dg16) SB_B(FL, true, FC, true, false); \
                            else if (r16) SB_B(FL, true, FC, false, false); else SB_B(FL, false, FC, false, false); } while (0)
 #define SB_BF(FC) do { if (full) SB_BR(true, FC); else SB_BR(false, FC); } while (0)

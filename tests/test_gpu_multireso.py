@@ -77,6 +77,40 @@ def test_all_three_magnitude_terms_match_oracle(w, B, T, weighting, l1):
     assert e64 < 1e-4, e64
 
 
+@pytest.mark.parametrize("B,nfr,hop,off,K,N,pair", [(3, 37, 120, 212, 600, 1040, False), (2, 50, 50, 136, 240, 528, True),
+                                                     (1, 9, 240, 424, 1200, 70, True)])
+def test_double_accumulated_stft_matches_float64_gemm(B, nfr, hop, off, K, N, pair):
+    """sb_stft_f64acc: frames of the padded rows x basis, every product accumulated in double, rounded once -- against the
+    same sum formed in float64 by numpy (equal to the last bit of the fp32 rounding up to half an ulp of double accumulation
+    order); with lo_off the signal is the (hi, lo) pair of planes sb_fir_pair returns, and sb_fir_pair itself is held to a
+    float64 convolution (hi + lo within 1e-13 relative).  Row / column counts off the 64 x 64 tile, K off the k-tile of 8."""
+    import torch
+    from sound_bubble_amd import ops
+    torch.manual_seed(B * 1000 + K)
+    ldp = (nfr - 1) * hop + off + K + 5
+    rows = B * (2 if pair else 1)
+    xp = torch.randn(rows, ldp)
+    if pair:
+        xp[B:] *= 2.0 ** -25                                   # the low plane of a pair
+    w = torch.randn(N, K) / K ** 0.5
+    spec = torch.full((B * nfr, N), float("nan"), device="cuda")
+    ops.stft_f64acc(xp.cuda(), w.cuda(), spec, B, nfr, ldp, hop, off, K, N, lo_off=B * ldp if pair else 0)
+    sig = xp[:B].double() + (xp[B:].double() if pair else 0.0)
+    idx = off + hop * torch.arange(nfr)[:, None] + torch.arange(K)[None, :]
+    frames = sig[:, idx].reshape(B * nfr, K).numpy()
+    want = frames @ w.double().numpy().T
+    got = spec.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want.astype(np.float32)).max() <= 1.0 * np.spacing(np.abs(want).astype(np.float32)).max()
+    # the pair-form FIR
+    taps = torch.randn(101)
+    x = torch.randn(2, 5000)
+    y = ops.fir_pair(x.cuda(), taps.cuda()).cpu().double()
+    ref = torch.nn.functional.conv1d(x.double()[:, None], taps.double().view(1, 1, -1), padding=50)[:, 0]
+    assert float(((y[0] + y[1]) - ref).abs().max()) < 1e-12 * float(ref.abs().max()) + 1e-13
+    assert float(y[1].abs().max()) <= float(np.spacing(np.float32(y[0].abs().max()))) 
+
+
 def test_default_constructed_loss_runs_with_a_silent_target():
     """`MultiResoFuseLoss()` as the reference constructs it without arguments; one target row is all zero (|Y| on the clamp:
     log|Y| = log 1e-4, the convergence norm still positive through the other row): finite loss and gradient, equal to the oracle"""

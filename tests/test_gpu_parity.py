@@ -1367,6 +1367,53 @@ def test_cross_pass_overlapped_backward_matches_the_plain_order(torch_gpu, B_, T
         assert rel_l2(a_, b_) < 2e-5 or float(np.abs(b_).max()) == 0, (k, rel_l2(a_, b_))
 
 
+def test_hs_free_inter_pass_survives_a_lost_side_stream(torch_gpu, monkeypatch):
+    """Round 4: where the backward will be the cross-pass producer, the inter-frame forward stores NO hs (the role-split kernel
+    recomputes h from the records).  Should the side stream be lost between forward and backward, the same kernel runs in plain
+    order -- still without hs: gradients equal those of the run in which the overlap was never available (hs stored, plain order)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    rec, params, m = _build(torch, "tiny_big", "NetDisEmbd3")
+    torch.manual_seed(3)
+    B_, T_ = 2, 150
+    x = (0.1 * torch.randn(B_, rec["mixture"].shape[1], 192 * T_ + 96)).cuda()
+    dis = torch.eye(3)[torch.arange(B_) % 3].cuda()
+    tgt = (0.05 * torch.randn(B_, 1, 192 * T_)).cuda()
+    if not ops.overlap_available():
+        pytest.skip("no side stream that runs concurrently with the main stream on this box")
+    if not (ops.ROLE_SPLIT and ops.HS_FROM_RECORDS and ops.INTRA_LIN_FUSION and ops.FUSED_BPTT_BI and ops.BWD_CROSS_OVERLAP and ops.BWD_OVERLAP):
+        pytest.skip("the cross-pass overlap is switched off in this environment")
+    monkeypatch.setattr(ops, "OVERLAP_MIN_FILL", 0.0)
+    monkeypatch.setattr(ops, "BPTT", "wide")
+    m.train()
+    real = ops.overlap_available
+
+    def run(avail_fwd, avail_bwd):
+        for p_ in m.parameters():
+            p_.grad = None
+        monkeypatch.setattr(ops, "overlap_available", real if avail_fwd else (lambda: False))
+        ops.PROFILE = {}
+        loss, _ = SnrlpLossFn.apply(m({"mixture": x, "dis_embed": dis}, pad=False)["output"], tgt, 100.0)
+        monkeypatch.setattr(ops, "overlap_available", real if avail_bwd else (lambda: False))
+        loss.backward()
+        torch.cuda.synchronize()
+        labels, ops.PROFILE = list(ops.PROFILE), None
+        ops.check_sched_status()
+        assert not ops.CROSS_PENDING
+        return float(loss), {k: p_.grad.clone() for k, p_ in m.named_parameters()}, labels
+
+    l0, g0, lab0 = run(False, False)
+    l1, g1, lab1 = run(True, False)             # forward counted on the overlap (no hs), backward finds it gone
+    assert not any("cross-pass" in k for k in lab0 + lab1), (lab0, lab1)
+    assert any("inter-frame fused BPTT" in k for k in lab1), lab1
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    for k in g0:
+        a_, b_ = g1[k].cpu().numpy(), g0[k].cpu().numpy()
+        assert np.isfinite(a_).all(), k
+        assert rel_l2(a_, b_) < 2e-5 or float(np.abs(b_).max()) == 0, (k, rel_l2(a_, b_))
+
+
 @pytest.mark.parametrize("with_h0", [False, True], ids=["zero-state", "carried-state"])
 @pytest.mark.parametrize("B_,T_,F_", [(2, 150, 21), (1, 37, 16)], ids=["ragged-150", "full-tiles-odd-37"])
 def test_wide_gate_recompute_equals_the_recorded_gates_bit_for_bit(torch_gpu, B_, T_, F_, with_h0, monkeypatch):
