@@ -519,6 +519,18 @@ int sb_film_bwd(const float* x, const float* w, const float* dy, float* dx, floa
                 int B, int T, int F, int C, float* absmax_out /* optional: max |dx|, as sb_linear_args.absmax_out */,
                 void* stream);
 
+/* sb_ln_film_bwd (C = 32): the LayerNorm backward of a block's intra-frame pass (sb_ln_bwd with ndir = 2 and a residual) and the
+ * FiLM backward of the block in front of it in one pass -- dx = LN-bwd(du[p, 0, :] + du[p, 1, :]; xin, ln_g) + res never leaves
+ * the registers: out = dx * film_w[b, f, :];  dw[b, f, :] += sum_t dx * film_x;  dbias[b, f, :] += sum_t dx (atomics, pre-zeroed
+ * or accumulated into, as sb_film_bwd);  partials: sb_ln_film_bwd_rows(B, T, F) rows of 64 floats, (sum g xhat [32], sum g [32])
+ * per workgroup -- the caller reduces them (sb_reduce_rows) into the LayerNorm parameter gradients.  Replaces the pair
+ * sb_ln_bwd + sb_film_bwd between two blocks (tfgridnet_causal.py:818-827 backward, :59-68 backward): 768 instead of 1 024 bytes
+ * per position.  absmax_out optional: max |out|. */
+int sb_ln_film_bwd_rows(int B, int T, int F);
+int sb_ln_film_bwd(const float* du, const float* xin, const float* ln_g, const float* res, const float* film_x,
+                   const float* film_w, float* out, float* dw, float* dbias, float* partials, int B, int T, int F, int C,
+                   float* absmax_out, void* stream);
+
 /* y[p, :] = x[p, :] + part[p, 0, :] + part[p, 1, :]  (x, y [P, C]; part [P, 2, C]): the residual + the two directions'
  * partial products of the intra-frame Linear written by sb_lstm_fwd in partial mode (tfgridnet_causal.py:824-827). */
 int sb_add3(const float* x, const float* part, float* y, int64_t P, int C, void* stream);

@@ -174,6 +174,8 @@ SYMBOLS = {
     "sb_features": (_ci, [c_fp, i64, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_film_fwd": (_ci, [c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_film_bwd": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, c_fp, _vp]),
+    "sb_ln_film_bwd_rows": (_ci, [_ci, _ci, _ci]),
+    "sb_ln_film_bwd": (_ci, [c_fp] * 10 + [_ci, _ci, _ci, _ci, c_fp, _vp]),
     "sb_add3": (_ci, [c_fp, c_fp, c_fp, i64, _ci, _vp]),
     "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),

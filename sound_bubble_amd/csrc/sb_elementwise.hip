@@ -102,6 +102,97 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__
   }
 }
 
+// LayerNorm backward of a block's intra-frame pass + the FiLM backward of the block in front of it, in ONE pass over [B, T, F, C]
+// (C = 32; round 4).  Separately they were ln_bwd_kernel<32> (du planes, x, residual in; dx out: 640 B per position)
+// and film_bwd_kernel (dx, y_pre in; dx * w out: 384 B per position) with dx written and read back in between; fused, dx never
+// leaves the registers: 768 B per position.  Thread = (b, f, channel quad) as in film_bwd_kernel -- the 8 threads of a position are
+// consecutive, so the LayerNorm sums are three DPP steps -- walking a chunk of time steps with its FiLM sums in registers; the
+// LayerNorm parameter sums leave as one partial row per workgroup (x, y: grid), the FiLM sums by atomics like film_bwd_kernel's.
+//   g = du[p, 0, :] + du[p, 1, :];  dx = LN-bwd(g; xin, gamma) + res;  out = dx * w[b, f, :];
+//   dw[b, f, :] += sum_t dx * fx;  dbias[b, f, :] += sum_t dx;  partials[wg] = (sum g * xhat [32], sum g [32])
+__global__ __launch_bounds__(256) void ln_film_bwd_kernel(const float* __restrict__ du, const float* __restrict__ xin,
+                                                          const float* __restrict__ ln_g, const float* __restrict__ res,
+                                                          const float* __restrict__ fx, const float* __restrict__ w,
+                                                          float* __restrict__ out, float* __restrict__ dw,
+                                                          float* __restrict__ dbias, float* __restrict__ partials, int B, int T,
+                                                          int F, int tchunk, float* __restrict__ absmax_out) {
+  constexpr int C = 32;
+  const int tid = threadIdx.x, c4 = tid & 7;
+  const int64_t fc4 = (int64_t)F * (C / 4);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + tid;
+  const bool live = i < B * fc4;                     // (8 threads of a position are live or dead together: fc4 is a multiple of 8)
+  const int64_t ii = live ? i : 0;
+  const int64_t b = ii / fc4, r = ii % fc4;
+  const f32x4 wv = ld4(w + ii * 4), gam = ld4(ln_g + 4 * c4);
+  f32x4 aw = zero4(), ab = zero4(), dgam = zero4(), dbet = zero4();
+  float amax = 0.f;
+  const int t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
+  // (the five rows of step t + 1 are requested before step t is worked on: the LayerNorm sums are dependent DPP chains)
+  auto row_off = [&](int t) -> int64_t { return ((b * T + min(t, t1 - 1)) * fc4 + r) * 4; };
+  int64_t off = row_off(t0);
+  f32x4 ng0 = ld4(du + ((off >> 5) * 2) * C + 4 * c4), ng1 = ld4(du + ((off >> 5) * 2 + 1) * C + 4 * c4);
+  f32x4 nx = ld4(xin + off), nrs = ld4(res + off), nfv = ld4(fx + off);
+  for (int t = t0; t < t1; ++t) {
+    const f32x4 g0 = ng0, g1 = ng1, x = nx, rs = nrs, fv = nfv;
+    const int64_t offn = row_off(t + 1);
+    ng0 = ld4(du + ((offn >> 5) * 2) * C + 4 * c4); ng1 = ld4(du + ((offn >> 5) * 2 + 1) * C + 4 * c4);
+    nx = ld4(xin + offn); nrs = ld4(res + offn); nfv = ld4(fx + offn);
+    const f32x4 g = g0 + g1;
+    const float mean = row8_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / C);
+    f32x4 d, xh, gg, dx;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { d[v] = x[v] - mean; sq += d[v] * d[v]; }
+    const float rstd = 1.0f / sqrtf(row8_sum(sq) * (1.0f / C) + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      xh[v] = d[v] * rstd;
+      gg[v] = g[v] * gam[v];
+      s1 += gg[v];
+      s2 += gg[v] * xh[v];
+    }
+    const float m1 = row8_sum(s1) * (1.0f / C), m2 = row8_sum(s2) * (1.0f / C);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dx[v] = rstd * (gg[v] - m1 - xh[v] * m2) + rs[v];
+    if (live) {
+      const f32x4 o = dx * wv;
+      st4(out + off, o);
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+      aw += dx * fv;
+      ab += dx;
+      dgam += g * xh;
+      dbet += g;
+    }
+    off = offn;
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(dw + i * 4 + k, aw[k]);
+      atomicAdd(dbias + i * 4 + k, ab[k]);
+    }
+  }
+  // LayerNorm parameter sums: the 32 threads of a wave... 32 positions x 8 channel quads per workgroup -> [64] per workgroup
+  __shared__ float red[32][2 * C + 1];
+  const int rowi = tid >> 3;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { red[rowi][4 * c4 + v] = dgam[v]; red[rowi][C + 4 * c4 + v] = dbet[v]; }
+  __syncthreads();
+  if (tid < 2 * C) {
+    float s = 0.f;
+    for (int q = 0; q < 32; ++q) s += red[q][tid];
+    partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C) + tid] = s;
+  }
+  if (absmax_out) {                                  // max |out|: one atomic per workgroup
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    __shared__ float wm[4];
+    if ((tid & 63) == 0) wm[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(absmax_out), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+  }
+}
+
 __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ frames, float* __restrict__ wave,
                                                           int B, int T, int win, int hop) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,6 +481,24 @@ extern "C" int sb_film_bwd(const float* x, const float* w, const float* dy, floa
   const int tchunk = 25;
   dim3 grid(nblk(n), (T + tchunk - 1) / tchunk);
   hipLaunchKernelGGL(film_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, dy, dx, dw, dbias, B, T, F, C, tchunk, absmax_out);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_ln_film_bwd_rows(int B, int T, int F) {
+  return (int)(nblk((int64_t)B * F * 8) * ((T + 24) / 25));
+}
+
+extern "C" int sb_ln_film_bwd(const float* du, const float* xin, const float* ln_g, const float* res, const float* film_x,
+                              const float* film_w, float* out, float* dw, float* dbias, float* partials, int B, int T, int F,
+                              int C, float* absmax_out, void* stream) {
+  if (!du || !xin || !ln_g || !res || !film_x || !film_w || !out || !dw || !dbias || !partials || B <= 0 || T <= 0 || F <= 0)
+    return -1001;
+  if (C != 32 || (int64_t)B * T * F * 8 >= (1ll << 31)) return -1002;
+  const int tchunk = 25;
+  dim3 grid(nblk((int64_t)B * F * 8), (T + tchunk - 1) / tchunk);
+  hipLaunchKernelGGL(ln_film_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, du, xin, ln_g, res, film_x, film_w, out, dw,
+                     dbias, partials, B, T, F, tchunk, absmax_out);
   SB_CHECK_LAUNCH();
   return 0;
 }

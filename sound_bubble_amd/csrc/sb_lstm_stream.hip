@@ -1014,17 +1014,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(sb_ln_bwd_args a) {
   for (int v = 0; v < VPT; ++v) { gam[v] = a.ln_g[cpart * VPT + v]; dgam[v] = 0.f; dbet[v] = 0.f; }
   const int64_t nrow = a.P;
   float amax = 0.f;                                  // max |out| (a.absmax_out)
-  for (int64_t p = (int64_t)blockIdx.x * 16 + (tid >> 4); p < nrow; p += (int64_t)gridDim.x * 16) {
-    float g[VPT], raw[VPT], x[VPT];
+  // (the rows of the NEXT position are requested before this one is worked on -- the sums below are dependent DPP chains; round 4:
+  //  the same change took the fused LayerNorm + FiLM backward from 0.247 to 0.222 ms)
+  const int64_t pstride = (int64_t)gridDim.x * 16;
+  float ng[VPT], nraw[VPT], nres[VPT];
+  auto fetch = [&](int64_t p) {
+    const int64_t pc = p < nrow ? p : nrow - 1;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       const int c = cpart * VPT + v;
       float s = 0.f;
-      for (int d = 0; d < a.ndir; ++d) s += a.du_part[(p * a.ndir + d) * C + c];
-      g[v] = s;
-      raw[v] = a.xin[p * C + c];
+      for (int d = 0; d < a.ndir; ++d) s += a.du_part[(pc * a.ndir + d) * C + c];
+      ng[v] = s;
+      nraw[v] = a.xin[pc * C + c];
+      nres[v] = a.res ? a.res[pc * C + c] : 0.f;
+    }
+  };
+  fetch((int64_t)blockIdx.x * 16 + (tid >> 4));
+  for (int64_t p = (int64_t)blockIdx.x * 16 + (tid >> 4); p < nrow; p += pstride) {
+    float g[VPT], raw[VPT], x[VPT], rsd[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      g[v] = ng[v];
+      raw[v] = nraw[v];
+      rsd[v] = nres[v];
       x[v] = (a.prelu_a && raw[v] <= 0.f) ? alpha * raw[v] : raw[v];
     }
+    fetch(p + pstride);
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) sum += x[v];
@@ -1050,7 +1066,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(sb_ln_bwd_args a) {
       const int c = cpart * VPT + v;
       float dx = rstd * (gg[v] - m1 - xh[v] * m2);
       if (a.prelu_a && raw[v] <= 0.f) { dalpha += dx * raw[v]; dx *= alpha; }
-      if (a.res) dx += a.res[p * C + c];
+      dx += rsd[v];
       a.out[p * C + c] = dx;
       amax = fmaxf(amax, fabsf(dx));
     }

@@ -140,6 +140,7 @@ class IntraPlainFn(torch.autograd.Function):
         and returns its parameter gradients."""
         B, T, F, Cc = x.shape
         ctx.next_ln = (next_ln_g, next_ln_b)
+        ctx.film_of = ops.FILM_OF.pop(x.data_ptr(), None) if (ops.FILM_OF and GRAD_MODE) else None
         x = x.contiguous()
         P = B * T * F
         train = GRAD_MODE and any(ctx.needs_input_grad)
@@ -235,8 +236,20 @@ class IntraPlainFn(torch.autograd.Function):
                                   w_lin=lin_w if fuse else None)
             # one pass over dgates: weight/bias gradients + dU; then LayerNorm backward (+ residual)
             _, du = ops.lstm_bwd_stream(dg, u, hs, [wif, wir], 1, F, 1, targets=tg)
-        dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
-                                 hint=True)
+        fo = getattr(ctx, "film_of", None)
+        if fo is not None and Cc == 32 and du.numel() == 2 * P * Cc and ops.LN_FILM_FUSION:
+            # ... with the FiLM backward of the block in front (whose inter-frame epilogue applied it to our input) in the same
+            # pass: dx never reaches memory; that block's backward finds the gradient marked and skips its own FiLM kernel
+            f_w, y_pre, bank, k = fo
+            if bank.get("G") is None:
+                bank["G"] = torch.zeros(bank["n"], 2, *f_w.shape, device=f_w.device, dtype=torch.float32)
+            dx = ops.ln_film_bwd(du, x.view(P, Cc), ln_g, dy.view(P, Cc), y_pre, f_w, bank["G"][k, 0], bank["G"][k, 1],
+                                 gt("ln_g", ln_g), gt("ln_b", ln_b), (B, T, F, Cc))
+            ops.FILM_DONE.clear()
+            ops.FILM_DONE[dx.data_ptr()] = True
+        else:
+            dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
+                                     hint=True)
         dx = dx.view(B, T, F, Cc)
         return (dx, gt["ln_g"], gt["ln_b"], gt["wif"], gt["whf"], gt["bif"], gt["bhf"], gt["wir"], gt["whr"], gt["bir"],
                 gt["bhr"], gt["lin_w"], gt["lin_b"], None, None, gt["next_ln_g"], gt["next_ln_b"])
@@ -307,6 +320,10 @@ class InterFn(torch.autograd.Function):
             ctx.h0 = h0c if ctx.no_gates else None
             ctx.deferred = part is not None
             ctx.film = (film[0], film[2], bank, film_k) if film is not None else None
+        if train and film is not None and bank is not None and ops.LN_FILM_FUSION and Cc == 32:
+            # the IntraPlainFn that takes y as its input may run this FiLM's backward together with its own LayerNorm backward
+            ops.FILM_OF.clear()
+            ops.FILM_OF[y.data_ptr()] = (film[0], film[2], bank, film_k)
         hN, cN = hN.view(1, B * F, H), cN.view(1, B * F, H)
         ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
         ctx.mark_non_differentiable(hN, cN)
@@ -334,7 +351,10 @@ class InterFn(torch.autograd.Function):
                 if bank.get("G") is None:
                     bank["G"] = torch.zeros(bank["n"], 2, *f_w.shape, device=f_w.device, dtype=torch.float32)
                 out = (bank["G"][k, 0], bank["G"][k, 1])
-            dy, d_fw, d_fb = ops.film_bwd(y_pre, f_w, dy, out=out)
+            if ops.FILM_DONE.pop(dy.data_ptr(), None) is not None:
+                d_fw, d_fb = out               # (dy has the FiLM factor in it: the intra-frame backward's fused pass applied it)
+            else:
+                dy, d_fw, d_fb = ops.film_bwd(y_pre, f_w, dy, out=out)
 
         def ret(dx):
             # deferred sum: the gradient of x + part0 + part1 goes to `part` (broadcast over the two halves, no copy) and

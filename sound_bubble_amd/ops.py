@@ -1317,6 +1317,34 @@ def film_bwd(x, w, dy, out=None):
     return dx, dw, db
 
 
+# LayerNorm backward of an intra-frame pass + FiLM backward of the block in front of it in one kernel (round 4): the inter-frame
+# forward whose epilogue applied that FiLM leaves (f_w, y_pre, (dw, db) bank slices) here under the data pointer of its output;
+# the IntraPlainFn that takes that tensor as its input picks the entry up, and its backward runs the fused kernel and marks the
+# gradient it returns in FILM_DONE so that the inter-frame backward skips its own FiLM pass.  SB_NO_LN_FILM_FUSION=1: two kernels.
+LN_FILM_FUSION = os.environ.get("SB_NO_LN_FILM_FUSION", "0") != "1"
+FILM_OF = {}
+FILM_DONE = {}
+
+
+def ln_film_bwd(du_part, xin, ln_g, res, film_x, film_w, dw, db, d_g, d_b, dims):
+    """-> out [P, 32] = (LN-backward(du_part[:, 0] + du_part[:, 1]; xin) + res) * film_w; dw / db / d_g / d_b accumulated into"""
+    lib = L.load()
+    B_, T_, F_, Cc = dims
+    dev = xin.device
+    out = torch.empty(B_ * T_ * F_, Cc, device=dev, dtype=torch.float32)
+    rows = lib.sb_ln_film_bwd_rows(B_, T_, F_)
+    partials = torch.empty(rows, 2 * Cc, device=dev, dtype=torch.float32)
+    gm = zero_scalar(dev) if ABSMAX_HINTS else None
+    with _Prof("ln_film_bwd (intra-frame LayerNorm backward + FiLM backward)", 0.0, 8.0 * Cc * B_ * T_ * F_, 24.0 * Cc * B_ * T_ * F_):
+        L.check(lib.sb_ln_film_bwd(_p(du_part), _p(xin), _p(ln_g), _p(res), _p(film_x), _p(film_w), _p(out), _p(dw), _p(db),
+                                   _p(partials), B_, T_, F_, Cc, _p(gm), _stream()), "sb_ln_film_bwd")
+    if gm is not None:
+        absmax_hint_put(out, gm)
+    reduce_partials(partials, Cc, d_g, 0)
+    reduce_partials(partials, Cc, d_b, Cc)
+    return out
+
+
 def overlap_add(frames, B, T, win, hop):
     wave = torch.empty(B, hop * T, device=frames.device, dtype=torch.float32)
     L.check(L.load().sb_overlap_add(_p(frames), _p(wave), B, T, win, hop, _stream()), "sb_overlap_add")

@@ -1367,6 +1367,38 @@ def test_cross_pass_overlapped_backward_matches_the_plain_order(torch_gpu, B_, T
         assert rel_l2(a_, b_) < 2e-5 or float(np.abs(b_).max()) == 0, (k, rel_l2(a_, b_))
 
 
+@pytest.mark.parametrize("B_,T_,F_", [(2, 37, 145), (1, 26, 21), (3, 5, 16)])
+def test_fused_ln_film_backward_matches_the_two_kernels(torch_gpu, B_, T_, F_):
+    """sb_ln_film_bwd (round 4): LayerNorm backward of an intra-frame pass + FiLM backward of the block in front in one pass --
+    against sb_ln_bwd followed by sb_film_bwd on the same tensors (out, both FiLM sums, both LayerNorm parameter gradients), and
+    the out tensor against float64 autograd.  T not a multiple of the 25-step chunk, B F 8 not a multiple of the workgroup."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    torch.manual_seed(B_ * 100 + T_)
+    Cc = 32
+    P = B_ * T_ * F_
+    du = torch.randn(P, 2, Cc, device="cuda") * 0.3
+    x = torch.randn(P, Cc, device="cuda") * 2.0 + 0.5
+    g = torch.rand(Cc, device="cuda") + 0.5
+    res = torch.randn(P, Cc, device="cuda") * 0.2
+    fx = torch.randn(B_, T_, F_, Cc, device="cuda")
+    fw = torch.randn(B_, F_, Cc, device="cuda")
+    dg0, db0 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    dx0, _, _, _ = ops.ln_bwd(du, x, g, res=res, d_g=dg0, d_b=db0)
+    o0, dw0, dbb0 = ops.film_bwd(fx, fw, dx0.view(B_, T_, F_, Cc))
+    dg1, db1 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    dw1, dbb1 = torch.zeros(B_, F_, Cc, device="cuda"), torch.zeros(B_, F_, Cc, device="cuda")
+    o1 = ops.ln_film_bwd(du, x, g, res, fx, fw, dw1, dbb1, dg1, db1, (B_, T_, F_, Cc))
+    torch.cuda.synchronize()
+    for name, a_, b_ in (("out", o1.view(-1), o0.reshape(-1)), ("dw", dw1, dw0), ("dbias", dbb1, dbb0), ("d_ln_g", dg1, dg0), ("d_ln_b", db1, db0)):
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6, name
+    X = x.double().cpu().requires_grad_(True)
+    U = torch.nn.functional.layer_norm(X, (Cc,), g.double().cpu(), torch.zeros(Cc).double(), 1e-5)
+    (U * (du[:, 0] + du[:, 1]).double().cpu()).sum().backward()
+    want = (X.grad + res.double().cpu()).view(B_, T_, F_, Cc) * fw.double().cpu()[:, None]
+    assert rel_l2(o1.cpu().numpy().reshape(-1), want.numpy().reshape(-1)) < 2e-6
+
+
 def test_hs_free_inter_pass_survives_a_lost_side_stream(torch_gpu, monkeypatch):
     """Round 4: where the backward will be the cross-pass producer, the inter-frame forward stores NO hs (the role-split kernel
     recomputes h from the records).  Should the side stream be lost between forward and backward, the same kernel runs in plain
