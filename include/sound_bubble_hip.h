@@ -254,6 +254,15 @@ int sb_lstm_bwd_cross_rows(int nseq, int producer_tiles);
 int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a, int* flags, int n_flags, int slab_len, void* stream);
 int sb_lstm_bwd_cross_consume(const sb_lstm_bwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
                               const int* need, void* stream);
+/* The same two calls with the small launches around them taken off the critical path between two blocks' backward kernels:
+ *   flags_zeroed != 0: the caller has zeroed flags[0 .. n_flags) itself, in stream order before the call (one fill for all the
+ *     blocks of a step instead of a memset in front of every producer);
+ *   reduce_on_side != 0: the partial-row reductions into dW_ih .. d_ln_b run on the library's side stream behind both consumer
+ *     launches instead of on `stream`.  Nothing but the optimiser reads their results: the caller keeps wpart allocated and
+ *     calls sb_overlap_join(stream) before anything on `stream` reads (or another stream's work adds into) a gradient target. */
+int sb_lstm_bwd_cross_produce_ex(const sb_lstm_bwd_args* a, int* flags, int n_flags, int slab_len, int flags_zeroed, void* stream);
+int sb_lstm_bwd_cross_consume_ex(const sb_lstm_bwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
+                                 const int* need, int reduce_on_side, void* stream);
 
 /* ---- position-wise linear (MFMA, weights staged in LDS) -------------------
  * out[p, n] = epi( sum_k in(p, k) * W[n, k] + bias[n] )  for every position
@@ -445,11 +454,19 @@ int sb_lstm_overlap_rows(int64_t positions, int nseq);
  *     harness does once per epoch) and fall back to the plain calls when it returns 0.
  *   sb_overlap_available: the stored verdict, no side effects.
  *   sb_overlap_shutdown: destroys every side stream and event of the process.
- * The table behind them is mutex-guarded; everything else in the library is stateless. */
+ * The table behind them is mutex-guarded; everything else in the library is stateless.
+ * Small launches whose results nothing on the critical path reads (partial-row reductions into gradient targets) can ride on
+ * the same side stream (data path: event record / wait only, no allocation, no synchronisation):
+ *   sb_overlap_side_fork(stream, &side): the side stream of `stream` waits for everything enqueued on `stream` so far; *side
+ *     receives its handle, to be passed as the `stream` argument of e.g. sb_reduce_rows.  -1009 without a side stream.
+ *   sb_overlap_join(stream): `stream` waits for everything enqueued on its side stream so far (0 and no effect without one).
+ *     Memory such launches touch must stay allocated until the join has been enqueued. */
 int sb_overlap_init(void* stream, float* scratch, float* timings_ms);
 int sb_overlap_reprobe(void* stream, float* scratch, float* timings_ms);
 int sb_overlap_available(void* stream);
 int sb_overlap_shutdown(void);
+int sb_overlap_side_fork(void* stream, void** side);
+int sb_overlap_join(void* stream);
 
 /* ---- LayerNorm (+PReLU) backward over C channels ---------------------------
  * g = sum_d du_part[p, d, :];  x = xin[p] (PReLU(xin[p]) with slope *prelu_a when prelu_a != NULL);

@@ -147,6 +147,8 @@ SYMBOLS = {
     "sb_lstm_bwd_cross_rows": (_ci, [_ci, _ci]),
     "sb_lstm_bwd_cross_produce": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _ci, _vp]),
     "sb_lstm_bwd_cross_consume": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),
+    "sb_lstm_bwd_cross_produce_ex": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _ci, _ci, _vp]),
+    "sb_lstm_bwd_cross_consume_ex": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _ci, _vp, _vp, _ci, _vp]),
     "sb_lstm_bwd_rec": (_ci, [C.POINTER(LstmBwdArgs), _vp]),
     "sb_linear_fwd": (_ci, [C.POINTER(LinearArgs), _vp]),
     "sb_linear_grid": (_ci, [i64]),
@@ -162,6 +164,8 @@ SYMBOLS = {
     "sb_overlap_init": (_ci, [_vp, c_fp, C.POINTER(C.c_float)]),
     "sb_overlap_reprobe": (_ci, [_vp, c_fp, C.POINTER(C.c_float)]),
     "sb_overlap_shutdown": (_ci, []),
+    "sb_overlap_side_fork": (_ci, [_vp, C.POINTER(C.c_void_p)]),
+    "sb_overlap_join": (_ci, [_vp]),
     "sb_ln_bwd": (_ci, [C.POINTER(LnBwdArgs), _vp]),
     "sb_ln_bwd_grid": (_ci, [i64]),
     "sb_head_ln": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, c_fp, _vp]),

@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(256) void probe_busy_kernel(float* sink, int iters)
 // promises thread safety).  The overlapped entry points only LOOK UP: no allocation, no synchronisation, no probe inside a
 // data-path call.
 struct SideStream { int dev = -1; hipStream_t main = nullptr, s = nullptr; hipEvent_t fork = nullptr, join = nullptr;
+                    hipEvent_t dfork = nullptr, djoin = nullptr;   // deferred small launches (sb_overlap_side_fork / sb_overlap_join)
                     bool ok = false; };
 constexpr int kMaxSide = 64;
 SideStream g_side[kMaxSide];
@@ -1247,7 +1248,9 @@ extern "C" int sb_overlap_init(void* stream, float* scratch, float* timings_ms) 
   ++g_nside;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (cus < 32 || hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&t->join, hipEventDisableTiming) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+      hipEventCreateWithFlags(&t->join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->dfork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->djoin, hipEventDisableTiming) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
       hipEventCreate(&e1) != hipSuccess)
     return 0;
   const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 12000;          // ~0.2 ms each
@@ -1297,9 +1300,39 @@ extern "C" int sb_overlap_shutdown(void) {
     if (g_side[i].s) (void)hipStreamDestroy(g_side[i].s);
     if (g_side[i].fork) (void)hipEventDestroy(g_side[i].fork);
     if (g_side[i].join) (void)hipEventDestroy(g_side[i].join);
+    if (g_side[i].dfork) (void)hipEventDestroy(g_side[i].dfork);
+    if (g_side[i].djoin) (void)hipEventDestroy(g_side[i].djoin);
     g_side[i] = SideStream{};
   }
   g_nside = 0;
+  return 0;
+}
+
+// Small launches off the critical path (the partial-row reductions between two blocks' backward kernels: their results are
+// only read by the optimiser).  sb_overlap_side_fork: the side stream of `stream` waits for everything enqueued on `stream` so
+// far; *side receives its handle -- launches the caller then enqueues there run beside what follows on `stream`.
+// sb_overlap_join: `stream` waits for everything enqueued on its side stream so far (a no-op without one).  Memory such a
+// launch touches must stay allocated until the join has been enqueued.
+extern "C" int sb_overlap_side_fork(void* stream, void** side) {
+  if (!side) return -1001;
+  hipStream_t main_st = (hipStream_t)stream;
+  SideStream* ss = side_stream(main_st);
+  if (!ss || !ss->dfork) return -1009;
+  if (hipEventRecord(ss->dfork, main_st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->dfork, 0) != hipSuccess) return -1009;
+  *side = (void*)ss->s;
+  return 0;
+}
+extern "C" int sb_overlap_join(void* stream) {
+  hipStream_t main_st = (hipStream_t)stream;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1009;
+  SideStream* t;
+  {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    t = side_lookup_locked(dev, main_st);
+  }
+  if (!t || !t->s || !t->djoin) return 0;              // (also when the probe has since failed: pending work is still joined)
+  if (hipEventRecord(t->djoin, t->s) != hipSuccess || hipStreamWaitEvent(main_st, t->djoin, 0) != hipSuccess) return -1009;
   return 0;
 }
 
@@ -1448,6 +1481,11 @@ extern "C" int sb_lstm_bwd_cross_rows(int nseq, int producer_tiles) {
 }
 
 extern "C" int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a_in, int* flags, int n_flags, int slab_len, void* stream) {
+  return sb_lstm_bwd_cross_produce_ex(a_in, flags, n_flags, slab_len, 0, stream);
+}
+// flags_zeroed != 0: the caller hands over flags it has zeroed itself (on `stream`, e.g. one fill for all blocks of a step)
+extern "C" int sb_lstm_bwd_cross_produce_ex(const sb_lstm_bwd_args* a_in, int* flags, int n_flags, int slab_len, int flags_zeroed,
+                                            void* stream) {
   if (!a_in || !flags) return -1001;
   sb_lstm_bwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
@@ -1460,7 +1498,7 @@ extern "C" int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a_in, int* flag
   // flags: [0] producer workgroups started, [1 .. 3] spare, [4 + tile] slabs completed by tile, then the consumer's 16 item
   // counters and three words per CONSUMER tile (prologue claimed / done / max |dy1|)
   if (n_flags < ntiles + 4) return -1003;
-  if (hipMemsetAsync(flags, 0, (size_t)n_flags * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (!flags_zeroed && hipMemsetAsync(flags, 0, (size_t)n_flags * sizeof(int), main_st) != hipSuccess) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
   a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_started = flags;
   a.seg_state = nullptr; a.seg_flags = nullptr;                           // (no time segments under the producer)
@@ -1469,6 +1507,13 @@ extern "C" int sb_lstm_bwd_cross_produce(const sb_lstm_bwd_args* a_in, int* flag
 
 extern "C" int sb_lstm_bwd_cross_consume(const sb_lstm_bwd_args* a_in, int* flags, int slab_len, int producer_tiles,
                                          const int* order, const int* need, void* stream) {
+  return sb_lstm_bwd_cross_consume_ex(a_in, flags, slab_len, producer_tiles, order, need, 0, stream);
+}
+// reduce_on_side != 0: the partial-row reductions run on the library's side stream behind both consumer launches instead of on
+// `stream` (they sit between this block's backward and the next one's otherwise; nothing on the critical path reads their
+// results) -- the caller keeps wpart allocated and calls sb_overlap_join(stream) before anything on `stream` reads a gradient target
+extern "C" int sb_lstm_bwd_cross_consume_ex(const sb_lstm_bwd_args* a_in, int* flags, int slab_len, int producer_tiles,
+                                            const int* order, const int* need, int reduce_on_side, void* stream) {
   if (!a_in || !flags || !order || !need) return -1001;
   sb_lstm_bwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
@@ -1507,9 +1552,14 @@ extern "C" int sb_lstm_bwd_cross_consume(const sb_lstm_bwd_args* a_in, int* flag
   const int ex_off[4] = {o0, o0 + C * 2 * H, o0 + C * 2 * H + C, o0 + C * 2 * H + 2 * C};
   const int ex_n[4] = {C * 2 * H, C, C, C};
   float* const ex_out[4] = {a.dW_lin, a.db_lin, a.d_ln_g, a.d_ln_b};
+  hipStream_t red_st = main_st;
+  if (reduce_on_side && ss->dfork) {                   // behind the second launch too (the first one is on the side stream itself)
+    if (hipEventRecord(ss->dfork, main_st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->dfork, 0) != hipSuccess) return -1009;
+    red_st = ss->s;
+  }
   for (int l = 0; l < 2 && !rc; ++l) {
-    rc = sb_launch_stream_reduce(base[l], gx[l], ld, C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, main_st, 4, ex_off, ex_n, ex_out);
-    if (!rc) rc = sb_launch_stream_reduce(base[l] + (size_t)gx[l] * ld, gx[l], ld, C, a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1, main_st,
+    rc = sb_launch_stream_reduce(base[l], gx[l], ld, C, a.dW_ih, a.dW_hh, a.db_ih, a.db_hh, red_st, 4, ex_off, ex_n, ex_out);
+    if (!rc) rc = sb_launch_stream_reduce(base[l] + (size_t)gx[l] * ld, gx[l], ld, C, a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1, red_st,
                                           4, ex_off, ex_n, ex_out);
   }
   return rc;

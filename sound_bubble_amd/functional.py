@@ -50,6 +50,11 @@ class _GradTargets:
 
     def __getitem__(self, name):
         return self.ret[name]
+
+    def all_direct(self):
+        """every target handed out so far is a flat-bucket buffer (nothing goes back through autograd: nobody reads the sums
+        before the end of the backward pass, so their reductions may ride on the side stream -- ops.defer_small_launches)"""
+        return all(v is None for v in self.ret.values())
 # Inference workspaces (set by the Net wrapper per forward, None in training): the zero-bordered staging tensors of the
 # front end / back end (zp, yp, the spectrum rows) are kept per model and shape, zeroed ONCE -- their borders and padding
 # columns are never written afterwards, the interiors are rewritten by every call -- so a forward launches no fill kernels
@@ -222,8 +227,9 @@ class IntraPlainFn(torch.autograd.Function):
             # recurrence + streaming part + the Linear's weight gradient in one launch (dgates stay in LDS)
             du = None
             if pend is not None:               # ... started next to the inter-frame backward that is producing its input (dy) right now
+                lt = (gt("lin_w", lin_w), gt("lin_b", lin_b))
                 du = ops.lstm_bwd_fused_bi([whf, whr], gates, geom, u, hs, [wif, wir], tg, dy=dy.view(P, Cc), w_lin=lin_w,
-                                           lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)), consume=pend)
+                                           lin_targets=lt, consume=pend, defer_ok=gt.all_direct())
                 if du is None:
                     pend.materialize()
             if du is None:
@@ -243,8 +249,9 @@ class IntraPlainFn(torch.autograd.Function):
             f_w, y_pre, bank, k = fo
             if bank.get("G") is None:
                 bank["G"] = torch.zeros(bank["n"], 2, *f_w.shape, device=f_w.device, dtype=torch.float32)
+            lg, lb = gt("ln_g", ln_g), gt("ln_b", ln_b)
             dx = ops.ln_film_bwd(du, x.view(P, Cc), ln_g, dy.view(P, Cc), y_pre, f_w, bank["G"][k, 0], bank["G"][k, 1],
-                                 gt("ln_g", ln_g), gt("ln_b", ln_b), (B, T, F, Cc))
+                                 lg, lb, (B, T, F, Cc), defer_ok=gt["ln_g"] is None and gt["ln_b"] is None)
             ops.FILM_DONE.clear()
             ops.FILM_DONE[dx.data_ptr()] = True
         else:
@@ -401,10 +408,14 @@ class InterFn(torch.autograd.Function):
             # What goes back through autograd is the dx BUFFER, filled by that kernel (ops.CROSS_PENDING carries the rest).
             slab = ops.BWD_CROSS_SLAB
             # (4 + producer tiles + 16 item counters + three words per consumer tile of 16 frames: sb_lstm_bwd_cross_produce zeroes them)
-            flags = torch.empty((geom.nseq + 15) // 16 + 4 + 16 + 3 * ((B * T + 15) // 16) + 24, device=dy.device, dtype=torch.int32)
+            nfl = (geom.nseq + 15) // 16 + 4 + 16 + 3 * ((B * T + 15) // 16) + 24
+            flags = ops.zeroed_flags(nfl, dy.device)   # (one fill per step for all blocks; None: the library zeroes them itself)
+            prezeroed = flags is not None
+            if flags is None:
+                flags = torch.empty(nfl, device=dy.device, dtype=torch.int32)
             du, overlapped, keep = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
                                                       lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)),
-                                                      produce=(flags, slab))
+                                                      produce=(flags, slab, prezeroed))
             dx = torch.empty(P, Cc, device=dy.device, dtype=torch.float32)
             order, need = ops._cross_order(B, T, F, slab, dy.device)
             pend = ops.CrossBwd(flags, slab, (geom.nseq + 15) // 16, order, need, du, x.view(P, Cc), dy.view(P, Cc), ln_g,

@@ -350,6 +350,71 @@ def overlap_lost():
     _OVERLAP_OK[(torch.cuda.current_device(), _stream().value)] = False
 
 
+# Small launches that sit between two blocks' backward kernels -- the partial-row reductions into gradient targets, which nothing
+# but the optimiser reads (kernel trace, big step: ~120 us of them and their launch gaps per block boundary, 2.4 % of the step)
+# -- ride on the library's side stream behind the kernels that produced their input, and the main stream joins them ONCE, at the
+# end of the backward pass (autograd's final callbacks run after the last node, before backward() returns to the caller: every
+# reader of a .grad / the flat bucket is behind the join).  SB_NO_DEFERRED_REDUCE=1: everything on the main stream as before.
+DEFER_REDUCE = os.environ.get("SB_NO_DEFERRED_REDUCE", "0") != "1"
+_DEFER = {"armed": False, "stream": None, "keep": [], "pending": []}
+
+
+def deferred_flush():
+    """the parked small launches (defer_launch) go to the side stream, behind everything enqueued on the main stream so far"""
+    if _DEFER["pending"]:
+        fns, _DEFER["pending"] = _DEFER["pending"], []
+        side = deferred_side(_DEFER["stream"]) if _DEFER["armed"] else None
+        for fn in fns:
+            fn(side if side is not None else _DEFER["stream"])
+
+
+def deferred_join():
+    """the main stream waits for the deferred launches (idempotent; also the engine's end-of-backward callback)"""
+    deferred_flush()
+    if _DEFER["armed"]:
+        _DEFER["armed"] = False
+        L.check(L.load().sb_overlap_join(_DEFER["stream"]), "sb_overlap_join")
+    _DEFER["keep"].clear()
+
+
+def defer_small_launches(keep=()):
+    """-> True when the caller may put its next small launches on the side stream (deferred_side() / reduce_on_side): only inside
+    a backward pass of the autograd engine (the join is queued as its final callback) with a concurrent side stream.  `keep`:
+    tensors those launches read, held until the join."""
+    if not DEFER_REDUCE or torch.cuda.is_current_stream_capturing():
+        return False
+    st = _stream()
+    if not _OVERLAP_OK.get((torch.cuda.current_device(), st.value)):
+        return False
+    if _DEFER["armed"] and _DEFER["stream"].value != st.value:
+        return False                                    # (one main stream at a time)
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(deferred_join)
+    except RuntimeError:                                # not inside a backward pass: nobody would run the join
+        return False
+    _DEFER["armed"], _DEFER["stream"] = True, st
+    _DEFER["keep"].extend(keep)
+    return True
+
+
+def defer_launch(fn, keep=()):
+    """park fn(stream) -- a small launch whose input exists on the main stream now -- until the next deferred_flush(): the
+    cross-pass consumer flushes behind its own side-stream launch (a launch put on the side stream straight away would sit in
+    front of that consumer and delay it), the end-of-backward join flushes what is left.  -> False: not deferrable, launch now"""
+    if not defer_small_launches(keep):
+        return False
+    _DEFER["pending"].append(fn)
+    return True
+
+
+def deferred_side(stream=None):
+    """the side stream, made to wait for everything enqueued on the (current) main stream so far (None: not available)"""
+    side = C.c_void_p()
+    if L.load().sb_overlap_side_fork(stream if stream is not None else _stream(), C.byref(side)) != 0 or not side.value:
+        return None
+    return side
+
+
 class FwdOverlap:
     """One inter-frame (block k) -> intra-frame (block k + 1) boundary of the overlapped forward: created by the model,
     handed to lstm_fwd(produce=...) of the former and lstm_fwd(consume=...) of the latter."""
@@ -563,6 +628,42 @@ class _ScalarSlots:
 _SLOTS = _ScalarSlots()
 
 
+class _FlagPool:
+    """Zeroed int32 flag arrays of the cross-pass backward (sb_lstm_bwd_cross_produce_ex, flags_zeroed), cut from one buffer that
+    is zeroed with ONE fill per train step instead of a memset in front of every block's producer (a launch on the critical
+    path between two blocks).  A slice is handed out once; a full buffer is replaced by a fresh one."""
+
+    def __init__(self):
+        self.buf, self.i = {}, {}
+
+    def get(self, n, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        n = (n + 63) & ~63
+        b = self.buf.get(key)
+        if b is None or self.i[key] + n > b.numel():
+            b = self.buf[key] = torch.zeros(max(8 * n, 1 << 15), device=dev, dtype=torch.int32)
+            self.i[key] = 0
+        k = self.i[key]
+        self.i[key] = k + n
+        return b[k:k + n]
+
+    def new_step(self):
+        for key in list(self.buf):
+            if self.i[key]:
+                del self.buf[key]                         # (slices still held by a pending consumer keep the old buffer alive)
+
+
+_FLAGS = _FlagPool()
+
+
+def zeroed_flags(n, dev):
+    """n zeroed int32 words (zeroed in stream order before any later launch on the current stream), or None when the caller
+    should let the library zero its own (stream capture: no allocation-order games inside a graph)"""
+    if not DEFER_REDUCE or torch.cuda.is_current_stream_capturing():
+        return None
+    return _FLAGS.get(n, dev)
+
+
 def zero_scalar(dev):
     return _SLOTS.get(dev)
 
@@ -577,6 +678,7 @@ def absmax_hint_put(t, gmax):
 def absmax_hints_clear():
     _ABSMAX_HINTS.clear()
     _SLOTS.new_step()
+    _FLAGS.new_step()
 
 
 def absmax_or_hint(x):
@@ -911,7 +1013,8 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
                + (" [cross-pass producer]" if produce is not None else ""),
                fl, 8.0 * Cc * geom.P, by):
         if produce is not None:            # (flags, slab): publish du slab by slab for the intra-frame backward of the same block
-            rc = lib.sb_lstm_bwd_cross_produce(C.byref(a), C.c_void_p(produce[0].data_ptr()), produce[0].numel(), produce[1], _stream())
+            rc = lib.sb_lstm_bwd_cross_produce_ex(C.byref(a), C.c_void_p(produce[0].data_ptr()), produce[0].numel(), produce[1],
+                                                  1 if (len(produce) > 2 and produce[2]) else 0, _stream())
             if rc == -1009:                # no side stream (any more): the plain launch; the caller materialises dy1 itself
                 overlap_lost()
                 L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused)")
@@ -1003,7 +1106,7 @@ def add3(x, part):
 
 
 def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=None, dy=None, w_lin=None, gmax=None,
-                      lin_targets=None, biases=None, consume=None):
+                      lin_targets=None, biases=None, consume=None, defer_ok=False):
     """Backward of a bidirectional LSTM pass, recurrence + streaming part in one launch (persistent workgroups, dgates in
     LDS).  Incoming gradient: dhs [P, 128], or dy [P, C] with w_lin [C, 128] (fused Linear backward, C == 32).
     u [P, C] fp16, hs [P, 128] fp32; targets[d] = (dW_ih, dW_hh, db_ih, db_hh) accumulated into.  -> du [P, 2, C]"""
@@ -1069,14 +1172,19 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
                + (" [role-split]" if a.split else "") + (" [cross-pass consumer, overlapped]" if consume is not None else ""), fl,
                8.0 * Cc * geom.P, by):
         if consume is not None:
-            rc = lib.sb_lstm_bwd_cross_consume(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
-                                               consume.producer_tiles, C.c_void_p(consume.order.data_ptr()),
-                                               C.c_void_p(consume.need.data_ptr()), _stream())
+            # defer_ok: every target is a buffer nobody reads before the end of the backward pass (the flat bucket) -- NOT a fresh
+            # tensor handed back to autograd, whose AccumulateGrad would read it on the main stream straight after this node
+            on_side = 1 if defer_ok and defer_small_launches((wpart,) + tuple(t for d in targets for t in d) + tuple(lin_targets or ())
+                                                + (consume.d_ln_g, consume.d_ln_b)) else 0
+            rc = lib.sb_lstm_bwd_cross_consume_ex(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
+                                                  consume.producer_tiles, C.c_void_p(consume.order.data_ptr()),
+                                                  C.c_void_p(consume.need.data_ptr()), on_side, _stream())
             if rc == -1009:                # the side stream went away between the two calls: plain order
                 overlap_lost()
                 return None
             L.check(rc, "sb_lstm_bwd_cross_consume")
             consume.keep.clear()
+            deferred_flush()               # (the reductions parked by the block behind us: behind this consumer on the side stream)
             return du
         L.check(lib.sb_lstm_bwd_rec(C.byref(a), _stream()), "sb_lstm_bwd_rec (fused, bidirectional)")
     return du
@@ -1282,11 +1390,12 @@ def colsum(g, P, ldg, N, out, g_off=0):
     L.check(lib.sb_colsum(_poff(g, g_off), P, ldg, N, _p(out), _p(scratch), _stream()), "sb_colsum")
 
 
-def reduce_partials(partials, n, out, col_off=0):
+def reduce_partials(partials, n, out, col_off=0, stream=None):
     """out[:n] += sum_rows partials[:, col_off:col_off+n]"""
     lib = L.load()
     rows, ld = partials.shape
-    L.check(lib.sb_reduce_rows(_poff(partials, col_off), rows, ld, n, _p(out), _stream()), "sb_reduce_rows")
+    L.check(lib.sb_reduce_rows(_poff(partials, col_off), rows, ld, n, _p(out), stream if stream is not None else _stream()),
+            "sb_reduce_rows")
 
 
 def features(spec, ld_spec, zp, B, M, T, F):
@@ -1326,7 +1435,7 @@ FILM_OF = {}
 FILM_DONE = {}
 
 
-def ln_film_bwd(du_part, xin, ln_g, res, film_x, film_w, dw, db, d_g, d_b, dims):
+def ln_film_bwd(du_part, xin, ln_g, res, film_x, film_w, dw, db, d_g, d_b, dims, defer_ok=False):
     """-> out [P, 32] = (LN-backward(du_part[:, 0] + du_part[:, 1]; xin) + res) * film_w; dw / db / d_g / d_b accumulated into"""
     lib = L.load()
     B_, T_, F_, Cc = dims
@@ -1340,8 +1449,13 @@ def ln_film_bwd(du_part, xin, ln_g, res, film_x, film_w, dw, db, d_g, d_b, dims)
                                    _p(partials), B_, T_, F_, Cc, _p(gm), _stream()), "sb_ln_film_bwd")
     if gm is not None:
         absmax_hint_put(out, gm)
-    reduce_partials(partials, Cc, d_g, 0)
-    reduce_partials(partials, Cc, d_b, Cc)
+    # the LayerNorm parameter sums: off the critical path when the side stream is there (the next block's producer is waiting)
+    def red(st):
+        reduce_partials(partials, Cc, d_g, 0, st)
+        reduce_partials(partials, Cc, d_b, Cc, st)
+
+    if not (defer_ok and defer_launch(red, (partials, d_g, d_b))):      # (defer_ok: as in lstm_bwd_fused_bi)
+        red(None)
     return out
 
 

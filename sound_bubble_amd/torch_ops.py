@@ -221,6 +221,8 @@ def _backward_into(ent, d_output):
     need = [p for p in own if p.requires_grad]
     with _record_autograd():
         got = torch.autograd.grad(root, need, d_output.contiguous(), allow_unused=True)
+    from . import ops
+    ops.deferred_join()                      # (idempotent: the engine's final callback has normally done it)
     it = iter(got)
     outs = []
     seen = {d_output.untyped_storage().data_ptr()}

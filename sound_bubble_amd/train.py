@@ -162,6 +162,8 @@ def allreduce_grads(bucket, force=False):
     rank the collective is skipped unless `force` / FORCE_ALLREDUCE asks for it (RCCL then runs its kernel on the bucket --
     a sum over one rank -- in stream order between the backward and the optimiser: what tests/test_gpu_distributed.py checks)."""
     import torch.distributed as dist
+    from . import ops
+    ops.deferred_join()                      # reductions still on the library's side stream (normally joined at the end of backward)
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force or FORCE_ALLREDUCE):
         if _via_host(bucket.grad):
             h = bucket.grad.cpu()
@@ -183,6 +185,7 @@ def train_step(model, bucket, optim, inputs, target, neg_weight, grad_clip=None)
     loss, _ = SnrlpLossFn.apply(est, target, neg_weight)
     ops.absmax_hints_clear()
     loss.backward()
+    ops.deferred_join()                      # (the engine's final callback has done it: idempotent)
     ops.absmax_hints_clear()
     world = allreduce_grads(bucket)
     optim.step(grad_clip=grad_clip, world_size=world)

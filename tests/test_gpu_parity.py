@@ -1367,6 +1367,80 @@ def test_cross_pass_overlapped_backward_matches_the_plain_order(torch_gpu, B_, T
         assert rel_l2(a_, b_) < 2e-5 or float(np.abs(b_).max()) == 0, (k, rel_l2(a_, b_))
 
 
+def test_deferred_reductions_match_and_are_joined(torch_gpu, monkeypatch):
+    """Round 4: the partial-row reductions between two blocks' backward kernels ride on the library's side stream
+    (sb_lstm_bwd_cross_consume_ex reduce_on_side, sb_overlap_side_fork) and the main stream joins them in the autograd engine's
+    end-of-backward callback (sb_overlap_join); the cross-pass flags come zeroed from a pool (flags_zeroed).  Same launches, same
+    order per gradient target: every parameter gradient equals the main-stream order's (SB_NO_DEFERRED_REDUCE) to the rounding of
+    the consumer's dynamic item assignment (2e-5, the bar of the cross-pass test), read on the main stream straight after backward() with no synchronisation in
+    between, three times over (a missing join or a recycled partial buffer shows as NaN / a wrong sum under the NaN-poisoned
+    allocator of this suite)."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.functional import SnrlpLossFn
+    rec, params, m = _build(torch, "tiny_big", "NetDisEmbd3")
+    torch.manual_seed(11)
+    B_, T_ = 2, 150
+    x = (0.1 * torch.randn(B_, rec["mixture"].shape[1], 192 * T_ + 96)).cuda()
+    dis = torch.eye(3)[torch.arange(B_) % 3].cuda()
+    tgt = (0.05 * torch.randn(B_, 1, 192 * T_)).cuda()
+    if not ops.overlap_available():
+        pytest.skip("no side stream that runs concurrently with the main stream on this box")
+    if not (ops.ROLE_SPLIT and ops.HS_FROM_RECORDS and ops.INTRA_LIN_FUSION and ops.FUSED_BPTT_BI and ops.BWD_CROSS_OVERLAP
+            and ops.BWD_OVERLAP and ops.BPTT == "wide"):
+        pytest.skip("the cross-pass overlap is switched off in this environment")
+    monkeypatch.setattr(ops, "OVERLAP_MIN_FILL", 0.0)
+    m.train()
+    from sound_bubble_amd.train import FlatBucket
+    bucket = FlatBucket(m)               # deferral needs targets nobody reads inside the backward pass: the flat bucket's slices
+    joins = []
+    real_join = ops.deferred_join
+
+    def counting_join():
+        joins.append(ops._DEFER["armed"])
+        real_join()
+
+    monkeypatch.setattr(ops, "deferred_join", counting_join)
+
+    def run(defer):
+        monkeypatch.setattr(ops, "DEFER_REDUCE", defer)
+        bucket.zero_grad()
+        ops.absmax_hints_clear()
+        ops.PROFILE = {}
+        loss, _ = SnrlpLossFn.apply(m({"mixture": x, "dis_embed": dis}, pad=False)["output"], tgt, 100.0)
+        loss.backward()
+        g = bucket.grad.clone()                                          # main stream, no synchronisation before the read
+        labels, ops.PROFILE = list(ops.PROFILE), None
+        torch.cuda.synchronize()
+        ops.check_sched_status()
+        assert not ops._DEFER["armed"] and not ops._DEFER["keep"] and not ops._DEFER["pending"]
+        return {k: g[o:o + p_.numel()] for (k, p_), o in zip(m.named_parameters(), bucket.offsets)}, labels
+
+    g0, lab0 = run(False)
+    assert not any(joins)
+    assert any("cross-pass consumer" in k for k in lab0), lab0
+    for rep in range(3):
+        del joins[:]
+        g1, _ = run(True)
+        assert joins and joins[0] is True, joins               # the engine ran the callback, and the first one found work to join
+        for k in g0:
+            a_, b_ = g1[k].cpu().numpy(), g0[k].cpu().numpy()
+            assert np.isfinite(a_).all(), (rep, k)
+            assert rel_l2(a_, b_) < 2e-5 or float(np.abs(b_).max()) == 0, (rep, k, rel_l2(a_, b_))
+    # without the bucket the sums go back through autograd (AccumulateGrad reads them straight after the node): nothing is deferred
+    for p_ in m.parameters():
+        p_._sb_flat_grad = False
+        p_.grad = None
+    del joins[:]
+    monkeypatch.setattr(ops, "DEFER_REDUCE", True)
+    loss, _ = SnrlpLossFn.apply(m({"mixture": x, "dis_embed": dis}, pad=False)["output"], tgt, 100.0)
+    loss.backward()
+    assert not any(joins), joins
+    for k, p_ in m.named_parameters():
+        a_, b_ = p_.grad.reshape(-1).cpu().numpy(), g0[k].cpu().numpy()
+        assert rel_l2(a_, b_) < 2e-5 or float(np.abs(b_).max()) == 0, (k, rel_l2(a_, b_))
+
+
 @pytest.mark.parametrize("B_,T_,F_", [(2, 37, 145), (1, 26, 21), (3, 5, 16)])
 def test_fused_ln_film_backward_matches_the_two_kernels(torch_gpu, B_, T_, F_):
     """sb_ln_film_bwd (round 4): LayerNorm backward of an intra-frame pass + FiLM backward of the block in front in one pass --

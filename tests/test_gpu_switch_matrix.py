@@ -20,7 +20,7 @@ ALL = ["SB_BPTT", "SB_EXACT_BPTT", "SB_NO_ROLE_SPLIT", "SB_NO_HS_RECOMPUTE", "SB
        "SB_NO_FWD_OVERLAP_INFERENCE", "SB_NO_INTER_SUM3", "SB_NO_INTER_FILM", "SB_NO_STREAM_LIN_WGRAD",
        "SB_NO_INTRA_LIN_FUSION", "SB_GATE_RECOMPUTE", "SB_BWD_PAIR_SERIAL", "SB_FWD_OVERLAP_SLAB", "SB_BWD_OVERLAP_SLAB",
        "SB_OVERLAP_MAX_FILL", "SB_NO_VEC_LSTM", "SB_NO_INFER_WORKSPACE", "SB_INTER_GATE_RECOMPUTE",
-       "SB_NO_BWD_CROSS_OVERLAP", "SB_BWD_CROSS_SLAB", "SB_NO_LN_FILM_FUSION"]
+       "SB_NO_BWD_CROSS_OVERLAP", "SB_BWD_CROSS_SLAB", "SB_NO_LN_FILM_FUSION", "SB_NO_DEFERRED_REDUCE"]
 
 # (id, environment, gradient bar): 2e-4 = the wide (default) arithmetic's bar against the goldens, 2e-3 the compact one's
 WIDE, COMPACT = 2e-4, 2e-3
@@ -60,6 +60,9 @@ SWITCHES = [
     ("no-bwd-cross-overlap", {"SB_NO_BWD_CROSS_OVERLAP": "1"}, WIDE),
     ("bwd-cross-slab", {"SB_BWD_CROSS_SLAB": "16"}, WIDE),
     ("no-ln-film-fusion", {"SB_NO_LN_FILM_FUSION": "1"}, WIDE),     # intra-frame LayerNorm backward and FiLM backward as two kernels
+    # round 4: the partial-row reductions between two blocks' backward kernels on the main stream again (default: side stream,
+    # joined at the end of the backward pass), a flags memset in front of every producer
+    ("no-deferred-reduce", {"SB_NO_DEFERRED_REDUCE": "1"}, WIDE),
     ("no-vec-lstm", {"SB_NO_VEC_LSTM": "1"}, WIDE),
     ("no-infer-workspace", {"SB_NO_INFER_WORKSPACE": "1"}, WIDE),
     # every byte the medium stage allocates starts as NaN (debugging aid of the probe): a kernel that reads memory nobody
