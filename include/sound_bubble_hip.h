@@ -577,8 +577,10 @@ int sb_multi_copy(const sb_multi_copy_args* a, void* stream);
  * dy [B, T, F, C] (gradient w.r.t. the last block's output) from dspec
  * [B, T, F, 2] (interleaved re/im) and the ConvTranspose2d weight
  * w[C, 2, 3, 3] (tfgridnet_causal.py:401,520).  The forward and the weight
- * gradient of this layer are sb_linear_fwd / sb_wgrad over the padded grid. */
-int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int T, int F, int C, void* stream);
+ * gradient of this layer are sb_linear_fwd / sb_wgrad over the padded grid.
+ * absmax_out (nullable, one float zeroed by the caller): receives max |dy| (atomic max of the bit patterns, as the other
+ * absmax_out arguments) -- the fp16 scale of the backward recurrence that reads dy next, without a pass of its own. */
+int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int T, int F, int C, float* absmax_out, void* stream);
 
 /* ---- SNRLP loss (src/losses/SNRLP.py:17-42, asteroid SingleSrcNegSDR('snr')) ----
  * est, gt [B, N].  stats [B, 8] scratch.  loss_vec [B].  Negative (all-zero gt)

@@ -183,7 +183,7 @@ SYMBOLS = {
     "sb_add3": (_ci, [c_fp, c_fp, c_fp, i64, _ci, _vp]),
     "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
-    "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
+    "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, c_fp, _vp]),
     "sb_snrlp_loss": (_ci, [c_fp, c_fp, _ci, i64, _cf, c_fp, c_fp, c_fp, _vp]),
     "sb_signal_stats": (_ci, [c_fp, c_fp, c_fp, _ci, i64, i64, c_fp, _vp]),
     "sb_sumsq": (_ci, [c_fp, i64, c_fp, _vp]),

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void overlap_add_bwd_kernel(const float* __res
 // dy[b,t,f,c] = sum_{a,d,o} dspec[b, t+2-a, f+1-d, o] * W[c, o, 2-a, 2-d]   (valid t', f' only)
 __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __restrict__ dspec,
                                                               const float* __restrict__ w, float* __restrict__ dy,
-                                                              int B, int T, int F, int C) {
+                                                              int B, int T, int F, int C, float* __restrict__ absmax_out) {
   extern __shared__ float ws[];   // [C][18]
   for (int i = threadIdx.x; i < C * 18; i += blockDim.x) ws[i] = w[i];
   __syncthreads();
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __res
   // that the element count fits 31 bits) -- the kernel was bound by that integer arithmetic, not by its 4 B/element
   const unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned c4n = (unsigned)C / 4, total = (unsigned)B * T * F * c4n;
-  if (i4 >= total) return;
-  const unsigned p = i4 / c4n, c = (i4 - p * c4n) * 4;
+  const bool live = i4 < total;                      // (no early return: the wave reduces max |dy| below)
+  const unsigned p = (live ? i4 : 0u) / c4n, c = ((live ? i4 : 0u) - p * c4n) * 4;
   const unsigned bt = p / (unsigned)F;
   const int f = (int)(p - bt * F);
   const unsigned b = bt / (unsigned)T;
@@ -255,7 +255,12 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __res
         acc[k] = __builtin_fmaf(g.x, ws[(c + k) * 18 + tap], __builtin_fmaf(g.y, ws[(c + k) * 18 + 9 + tap], acc[k]));
     }
   }
-  st4(dy + (int64_t)i4 * 4, acc);
+  if (live) st4(dy + (int64_t)i4 * 4, acc);
+  if (absmax_out) {                                  // max |dy| (the fp16 scale of the backward recurrence that reads it): one atomic per wave
+    float mx = live ? fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) : 0.f;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax_out), __float_as_uint(mx));
+  }
 }
 
 // ---------------- SNRLP loss ----------------
@@ -526,10 +531,10 @@ extern "C" int sb_overlap_add_bwd(const float* dwave, float* dframes, int B, int
 }
 
 extern "C" int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int T, int F, int C,
-                                  void* stream) {
+                                  float* absmax_out, void* stream) {
   const int64_t total = (int64_t)B * T * F * C;
   if (C % 4 || total <= 0 || total >= (1ll << 31)) return -1002;
-  hipLaunchKernelGGL(deconv_bwd_data_kernel, dim3(nblk(total / 4)), dim3(256), C * 18 * sizeof(float), (hipStream_t)stream, dspec, w, dy, B, T, F, C);
+  hipLaunchKernelGGL(deconv_bwd_data_kernel, dim3(nblk(total / 4)), dim3(256), C * 18 * sizeof(float), (hipStream_t)stream, dspec, w, dy, B, T, F, C, absmax_out);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -882,8 +882,14 @@ class FrontEndFn(torch.autograd.Function):
             gt.ret["ln_g"] = gt.ret["ln_b"] = None
         s_in = ((T + 2) * (F + 2) * ZC, (F + 2) * ZC, ZC)
         # dW[co][(a*3 + d)*32 + ci] lands in conv_w's own [co, ci, a, d] layout (and in the flat bucket when it exists)
-        ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, gt("conv_w", conv_w), kseg=3 * ZC, is_seg=(F + 2) * ZC,
-                  dbias=gt("conv_b", conv_b), wview=L.WView.make(nfeat * 9, 9, kmod=ZC, sk_hi=1, kvalid=nfeat), f16=True)
+        tw, tb = gt("conv_w", conv_w), gt("conv_b", conv_b)
+        gm = ops.absmax_or_hint(dpre) if ops.LINEAR_F16X3 else None
+        # nothing in the backward pass reads this weight gradient, and what follows on the main stream are the tiny kernels of
+        # the FiLM bank's backward: with flat-bucket targets the launch goes to the side stream (joined at the end of the pass)
+        side = ops.deferred_side() if (gt.all_direct() and ops.defer_small_launches((dpre, zp, tw, tb, gm))) else None
+        with ops.on_stream(side):
+            ops.wgrad(dpre, Cc, Cc, zp, s_in, (B, T, F), 9 * ZC, tw, kseg=3 * ZC, is_seg=(F + 2) * ZC,
+                      dbias=tb, wview=L.WView.make(nfeat * 9, 9, kmod=ZC, sk_hi=1, kvalid=nfeat), f16=True, gmax=gm)
         return None, None, gt["conv_w"], gt["conv_b"], gt["ln_g"], gt["ln_b"], None, None, None, None
 
 
@@ -960,8 +966,18 @@ class BackEndFn(torch.autograd.Function):
         gt = _GradTargets()
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
         # dW[o][(a*3 + d)*C + c] lands in the parameter's own [c, o, 2-a, 2-d] layout
-        ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, gt("dw", dw), kseg=3 * Cc, is_seg=(F + 2) * Cc,
-                  dbias=gt("db", db), wview=L.WView.make(9, 18, off=8, kmod=Cc, sk_hi=-1, nvalid=2), f16=True)
+        tw, tb = gt("dw", dw), gt("db", db)
+        gm = ops.absmax_or_hint(dspec) if ops.LINEAR_F16X3 else None
+
+        def wg(st):
+            with ops.on_stream(st):
+                ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, tw, kseg=3 * Cc, is_seg=(F + 2) * Cc,
+                          dbias=tb, wview=L.WView.make(9, 18, off=8, kmod=Cc, sk_hi=-1, nvalid=2), f16=True, gmax=gm)
+
+        # the first kernel of the backward chain (the last block's inter-frame pass) is waiting for dy, not for this weight
+        # gradient: with flat-bucket targets it is parked and runs on the side stream behind that block's consumer
+        if not (gt.all_direct() and ops.defer_launch(wg, (dspec, yp, tw, tb, gm))):
+            wg(None)
         return dy, None, gt["dw"], gt["db"], None, None, None, None, None
 
 

@@ -105,8 +105,31 @@ class _Prof:
         return False
 
 
+_STREAM_OVERRIDE = None
+
+
 def _stream():
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class on_stream:
+    """library launches inside the block go to `stream` (a handle from deferred_side(); None: the current stream as usual).
+    Only for launches whose every buffer the caller keeps alive until the join (defer_small_launches(keep))."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        global _STREAM_OVERRIDE
+        self.prev, _STREAM_OVERRIDE = _STREAM_OVERRIDE, self.stream
+        return self
+
+    def __exit__(self, *exc):
+        global _STREAM_OVERRIDE
+        _STREAM_OVERRIDE = self.prev
+        return False
 
 
 def _p(t, name="tensor"):
@@ -1357,6 +1380,8 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     P = B_ * T_ * F_
     ng = lib.sb_wgrad_grid(P)
     scratch = torch.empty(ng * 4, N * (K + K2) + N, device=dW.device, dtype=torch.float32)   # one row per wave (every wave writes its row)
+    if _STREAM_OVERRIDE is not None:
+        _DEFER["keep"].append(scratch)                # (a side-stream launch: held until the join, see on_stream)
     a = L.WgradArgs()
     a.B, a.T, a.F, a.N, a.K = B_, T_, F_, N, K
     a.kseg = ((K + 15) // 16) * 16 if kseg is None else kseg
@@ -1489,7 +1514,10 @@ def overlap_add_bwd(dwave, B, T, win, hop):
 
 def deconv_bwd_data(dspec, w, B, T, F, Cc):
     dy = torch.empty(B, T, F, Cc, device=dspec.device, dtype=torch.float32)
-    L.check(L.load().sb_deconv_bwd_data(_p(dspec), _p(w), _p(dy), B, T, F, Cc, _stream()), "sb_deconv_bwd_data")
+    gm = zero_scalar(dspec.device) if ABSMAX_HINTS else None      # max |dy| measured on the way (the last block's backward reads dy next)
+    L.check(L.load().sb_deconv_bwd_data(_p(dspec), _p(w), _p(dy), B, T, F, Cc, _p(gm), _stream()), "sb_deconv_bwd_data")
+    if gm is not None:
+        absmax_hint_put(dy, gm)
     return dy
 
 
