@@ -523,8 +523,8 @@ int sb_attn_core_bwd(const sb_attn_bwd_args* a, void* stream);
 /* ---- front-end features --------------------------------------------------
  * spec [B*M, T, ld_spec] (cols 0..F-1 real, F..2F-1 imag: asteroid Encoder
  * layout) -> zp [B, T+2, F+2, 32] channels-last, written at time offset 2 and
- * frequency offset 1 (zero borders for the 3x3 conv; channels 27..31 zero).
- * Channel order: re x M, im x M, ILD x (M-1), (sin, cos) x (M-1).
+ * frequency offset 1 (zero borders for the 3x3 conv; channels 5M-3 .. 31 zero: 27.. for the shipped M = 6).
+ * Channel order: re x M, im x M, ILD x (M-1), (sin, cos) x (M-1).  2 <= M <= 7 (-1002 otherwise).
  * Replaces tfgridnet_causal.py:482-500 + MC_features_OMNX :72-93, IPD_OMNX :32-48. */
 int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int T, int F, void* stream);
 

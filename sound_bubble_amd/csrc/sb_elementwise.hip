@@ -465,8 +465,13 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(sb_multi_copy_args a) {
 extern "C" int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int T, int F, void* stream) {
   const int64_t total = (int64_t)B * T * (F + 2);
   if (total <= 0 || total >= (1ll << 31)) return -1002;
-  if (M == 6) hipLaunchKernelGGL(features_kernel<6>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, spec, ld_spec, zp, B, T, F);
-  else return -1002;
+  // 5 M - 3 feature channels in the ZC = 32 padded stack: 2 <= M <= 7 (every shipped JSON: 6; the reference's constructor default: 2)
+#define SB_FEAT(M_) case M_: hipLaunchKernelGGL(features_kernel<M_>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, spec, ld_spec, zp, B, T, F); break
+  switch (M) {
+    SB_FEAT(2); SB_FEAT(3); SB_FEAT(4); SB_FEAT(5); SB_FEAT(6); SB_FEAT(7);
+    default: return -1002;
+  }
+#undef SB_FEAT
   SB_CHECK_LAUNCH();
   return 0;
 }

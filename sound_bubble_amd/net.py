@@ -145,8 +145,9 @@ class _NetBase(nn.Module):
         if merge_method != "early_cat" or directional or spectral_masking or stft_back_pad != 0 or fb_type != "stft":
             raise NotImplementedError("only merge_method='early_cat', omnidirectional, no spectral masking, "
                                       "stft_back_pad=0 (every shipped config)")
-        if num_src != 1 or num_ch != 6:
-            raise NotImplementedError("num_src=1 and num_ch=6 only (every shipped config)")
+        if num_src != 1 or not 2 <= num_ch <= 7:
+            raise NotImplementedError("num_src=1 and 2 <= num_ch <= 7 (5 num_ch - 3 feature channels in the 32-channel front-end "
+                                      "stack; every shipped config has 6 microphones, the reference's constructor default is 2)")
         self.stft_chunk_size, self.stft_pad_size, self.stft_back_pad = stft_chunk_size, stft_pad_size, stft_back_pad
         self.num_ch, self.lookahead, self.embed_dim, self.E = num_ch, lookahead, D, E
         self.nfft = stft_back_pad + stft_chunk_size + stft_pad_size

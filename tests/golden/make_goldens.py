@@ -506,6 +506,12 @@ def main():
               needs_dis=True, out_dir=args.out)
     case(torch, NetSmall, "tiny_orange_attn4", dict(orange, B=2, use_attn=True, local_atten_len=4), B=2,
               n_frames=7, seed=16, needs_dis=False, out_dir=args.out)
+    # other microphone counts (every shipped JSON has num_ch=6; the reference's constructor default is 2): feature stack of
+    # 5 M - 3 channels -- 7 for M = 2, 17 for M = 4
+    case(torch, NetBig, "tiny_big_2ch", dict(big, B=2, num_ch=2), B=2, n_frames=7, seed=17, needs_dis=True,
+              out_dir=args.out)
+    case(torch, NetSmall, "tiny_small_4ch", dict(small, B=2, num_ch=4), B=2, n_frames=7, seed=18, needs_dis=False,
+              out_dir=args.out, with_stream=False)
     # real small config, 1 s clip (125 frames), forward only
     case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
               with_grads=False, with_stream=False, with_stages=False)

@@ -123,6 +123,8 @@ def test_linear_and_wgrad(torch_gpu):
 CASES = [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"), ("tiny_orange", "NetOptim"),
          ("tiny_big_convlstm", "NetDisEmbd3")]
 ATTN_CASES = [("tiny_big_attn100", "NetDisEmbd3"), ("tiny_orange_attn4", "NetOptim")]
+# other microphone counts (every shipped JSON: 6): num_ch = 2, the reference's constructor default, and 4
+NUMCH_CASES = [("tiny_big_2ch", "NetDisEmbd3"), ("tiny_small_4ch", "NetOptim")]
 
 
 def _build(torch, name, cls):
@@ -140,7 +142,7 @@ def _inputs(torch, rec):
     return d
 
 
-@pytest.mark.parametrize("name,cls", CASES + ATTN_CASES)
+@pytest.mark.parametrize("name,cls", CASES + ATTN_CASES + NUMCH_CASES)
 def test_forward_matches_reference_goldens(torch_gpu, name, cls):
     torch = torch_gpu
     rec, params, m = _build(torch, name, cls)
@@ -163,7 +165,7 @@ def test_forward_small_config_1s(torch_gpu):
     assert rel_l2(out, rec["output"]) < 5e-5
 
 
-@pytest.mark.parametrize("name,cls", CASES[:3] + ATTN_CASES)
+@pytest.mark.parametrize("name,cls", CASES[:3] + ATTN_CASES + NUMCH_CASES[:1])
 def test_streaming_matches_reference(torch_gpu, name, cls):
     torch = torch_gpu
     poison_free_memory(torch, 2)
@@ -239,6 +241,34 @@ def test_loss_and_gradients_match_reference(torch_gpu, name, cls, mode, monkeypa
             worst = (k, e)
     ops.check_sched_status()
     assert worst[1] < (TOL_GRAD if compact else 2e-4), worst
+
+
+@pytest.mark.parametrize("name,cls", NUMCH_CASES)
+def test_other_microphone_counts_match_reference(torch_gpu, name, cls):
+    """num_ch = 2 (the reference's constructor default: 7 feature channels) and 4 (17) in the default dispatch: loss vector and
+    every parameter gradient against the imported reference's goldens; an unsupported count is refused at construction and by
+    the C ABI (sb_features: -1002), never computed wrongly."""
+    torch = torch_gpu
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd import ops, _lib
+    rec, params, m = _build(torch, name, cls)
+    assert params["num_ch"] in (2, 4)
+    m.train()
+    est = m(_inputs(torch, rec))["output"]
+    loss, lv = SnrlpLossFn.apply(est, torch.from_numpy(rec["target"]).cuda(), 100.0)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), rec["loss_vec"], rtol=1e-4, atol=1e-4)
+    loss.backward()
+    for k, p in m.named_parameters():
+        g = rec["grad::" + k]
+        e = rel_l2(p.grad.cpu().numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max())
+        assert e < 2e-4, (k, e)
+    ops.check_sched_status()
+    with pytest.raises(NotImplementedError):
+        getattr(sb, cls)(**dict(params, num_ch=8))
+    z = torch.zeros(4, 4, 34, 32, device="cuda")
+    spec = torch.zeros(8, 2, 304, device="cuda")
+    assert _lib.load().sb_features(ops._p(spec), 304, ops._p(z), 1, 8, 2, 32, ops._stream()) == -1002
 
 
 def test_oracle_agrees_at_full_size_property(torch_gpu):

@@ -5,7 +5,8 @@ import pytest
 
 from conftest import load_golden, golden_state_dict, rel_l2, flatten_state
 
-CASES = ["tiny_big", "tiny_small", "tiny_orange", "tiny_big_convlstm"]
+# (the last two: num_ch = 2 -- the reference's constructor default -- and 4; every shipped JSON has 6)
+CASES = ["tiny_big", "tiny_small", "tiny_orange", "tiny_big_convlstm", "tiny_big_2ch", "tiny_small_4ch"]
 ATTN_CASES = ["tiny_big_attn100", "tiny_orange_attn4"]
 
 
@@ -59,7 +60,7 @@ def test_forward_matches_reference(name, torch_mod):
         assert rel_l2(v, rec["next_state::" + k]) < 2e-6, k
 
 
-@pytest.mark.parametrize("name", ["tiny_big", "tiny_small", "tiny_orange"] + ATTN_CASES)
+@pytest.mark.parametrize("name", ["tiny_big", "tiny_small", "tiny_orange", "tiny_big_2ch"] + ATTN_CASES)
 def test_streaming_matches_reference(name, torch_mod):
     torch = torch_mod
     rec, params, flavour = load_golden(name)
