@@ -259,7 +259,13 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __res
   if (absmax_out) {                                  // max |dy| (the fp16 scale of the backward recurrence that reads it): one atomic per wave
     float mx = live ? fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) : 0.f;
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax_out), __float_as_uint(mx));
+    // 45 000 workgroups: an atomic per wave on ONE address serialises the whole kernel (measured 110 us -> 2 ms).  The word only
+    // ever grows, so a (possibly stale) plain read filters out every wave that cannot raise it -- all but a handful
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned bits = __float_as_uint(mx);
+      if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(absmax_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned*>(absmax_out), bits);
+    }
   }
 }
 

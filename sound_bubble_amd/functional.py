@@ -962,22 +962,18 @@ class BackEndFn(torch.autograd.Function):
         _, s_r = dense(B * (T + 1), NSPEC)
         ops.linear(dframes, w_ana, None, drows, g, s_f, s_r, win, NSPEC)
         dspec = drows[:, 1:, : 2 * F].contiguous()                                # [B,T,F,2]
-        dy = ops.deconv_bwd_data(dspec, dw, B, T, F, Cc)
         gt = _GradTargets()
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
         # dW[o][(a*3 + d)*C + c] lands in the parameter's own [c, o, 2-a, 2-d] layout
         tw, tb = gt("dw", dw), gt("db", db)
         gm = ops.absmax_or_hint(dspec) if ops.LINEAR_F16X3 else None
-
-        def wg(st):
-            with ops.on_stream(st):
-                ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, tw, kseg=3 * Cc, is_seg=(F + 2) * Cc,
-                          dbias=tb, wview=L.WView.make(9, 18, off=8, kmod=Cc, sk_hi=-1, nvalid=2), f16=True, gmax=gm)
-
         # the first kernel of the backward chain (the last block's inter-frame pass) is waiting for dy, not for this weight
-        # gradient: with flat-bucket targets it is parked and runs on the side stream behind that block's consumer
-        if not (gt.all_direct() and ops.defer_launch(wg, (dspec, yp, tw, tb, gm))):
-            wg(None)
+        # gradient: with flat-bucket targets it runs on the side stream, beside the data gradient below
+        side = ops.deferred_side() if (gt.all_direct() and ops.defer_small_launches((dspec, yp, tw, tb, gm))) else None
+        with ops.on_stream(side):
+            ops.wgrad(dspec, 2, 2, yp, s_in, (B, T, F), 9 * Cc, tw, kseg=3 * Cc, is_seg=(F + 2) * Cc,
+                      dbias=tb, wview=L.WView.make(9, 18, off=8, kmod=Cc, sk_hi=-1, nvalid=2), f16=True, gmax=gm)
+        dy = ops.deconv_bwd_data(dspec, dw, B, T, F, Cc)
         return dy, None, gt["dw"], gt["db"], None, None, None, None, None
 
 
