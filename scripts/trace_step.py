@@ -6,10 +6,13 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at the features kernel of the front end
 starts = [i for i, r in enumerate(rows) if "features_kernel" in r["Kernel_Name"]]
 bw = [i for i, r in enumerate(rows) if "lstm_bwd_rec_bf_kernel" in r["Kernel_Name"]]
-i0 = max(i for i in starts if i < bw[-1])                 # the last step that has a backward (a parity forward may follow)
-i1 = min([i for i in starts if i > bw[-1]] + [len(rows)])
-adam = [i for i in range(i0, i1) if "adam" in rows[i]["Kernel_Name"]]
-if adam: i1 = adam[-1] + 1
+if bw:
+    i0 = max(i for i in starts if i < bw[-1])                 # the last step that has a backward (a parity forward may follow)
+    i1 = min([i for i in starts if i > bw[-1]] + [len(rows)])
+    adam = [i for i in range(i0, i1) if "adam" in rows[i]["Kernel_Name"]]
+    if adam: i1 = adam[-1] + 1
+else:                                                         # forward-only run: the last complete forward
+    i0, i1 = starts[-2], starts[-1]
 t0 = int(rows[i0]["Start_Timestamp"])
 busy_end = t0
 idle = 0
