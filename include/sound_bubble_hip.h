@@ -134,6 +134,9 @@ int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
  * writes must stay allocated until the consume call has returned (the side stream is not ordered after `stream`).
  * -1003 when fewer than 16 CUs stay idle, -1009 without a concurrent side stream (sb_overlap_available). */
 int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a, int* flags, int slab_len, void* stream);
+/* ... with flags_zeroed != 0 the caller has zeroed flags[0 .. 4 + ceil(nsteps / slab_len)) itself, in stream order before the
+ * call (one fill for many blocks instead of a memset in front of every producer) */
+int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a, int* flags, int slab_len, int flags_zeroed, void* stream);
 int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
                         const int* need, void* stream);
 

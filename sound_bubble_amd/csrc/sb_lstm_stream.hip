@@ -1414,6 +1414,10 @@ extern "C" int sb_lstm_bwd_inter_pair_serial(const sb_lstm_bwd_args* rec_in, con
 // flags layout: [0] producer workgroups started, [1], [2] the consumer's item counters (one per direction), [3] spare,
 // [4 ..] the slab flags
 extern "C" int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, void* stream) {
+  return sb_lstm_fwd_produce_ex(a_in, flags, slab_len, 0, stream);
+}
+// flags_zeroed != 0: the caller hands over flags it has zeroed itself, in stream order before the call
+extern "C" int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, int flags_zeroed, void* stream) {
   if (!a_in || !flags) return -1001;
   sb_lstm_fwd_args a = *a_in;
   hipStream_t main_st = (hipStream_t)stream;
@@ -1422,7 +1426,7 @@ extern "C" int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a_in, int* flags, int
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
   const int nslabs = (a.nsteps + slab_len - 1) / slab_len;
-  if (hipMemsetAsync(flags, 0, (size_t)(nslabs + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (!flags_zeroed && hipMemsetAsync(flags, 0, (size_t)(nslabs + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
   a.slab_flags = flags + 4; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
   a.ord_started = flags;

@@ -444,7 +444,11 @@ class FwdOverlap:
 
     def __init__(self, B, T, F_, dev):
         self.slab = FWD_OVERLAP_SLAB
-        self.flags = torch.empty((T + self.slab - 1) // self.slab + 4, device=dev, dtype=torch.int32)   # + 4 control words
+        nfl = (T + self.slab - 1) // self.slab + 4                               # + 4 control words
+        self.flags = zeroed_flags(nfl, dev)       # from the once-per-step zeroed pool (None: the library zeroes them itself)
+        self.prezeroed = self.flags is not None
+        if self.flags is None:
+            self.flags = torch.empty(nfl, device=dev, dtype=torch.int32)
         self.producer_tiles = (B * F_ + 15) // 16
         self.order, self.need = _tile_order(B, T, self.slab, dev)
         self.keep = []            # everything the producer touches stays allocated until the consumer has been launched
@@ -554,7 +558,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
                8.0 * Cc * geom.P, by):
         if produce is not None:
             assert ndir == 1 and lin is not None
-            rc = lib.sb_lstm_fwd_produce(C.byref(a), C.c_void_p(produce.flags.data_ptr()), produce.slab, _stream())
+            rc = lib.sb_lstm_fwd_produce_ex(C.byref(a), C.c_void_p(produce.flags.data_ptr()), produce.slab,
+                                            1 if produce.prezeroed else 0, _stream())
             if rc == -1009:                # no side stream (any more): the plain call; the consumer then runs in plain order too
                 overlap_lost()
                 L.check(lib.sb_lstm_fwd(C.byref(a), _stream()), "sb_lstm_fwd")
