@@ -24,3 +24,71 @@ def test_tile_order_is_a_permutation_sorted_by_the_slab_that_completes_the_tile(
         straddle = [i for i, tile in enumerate(order) if (16 * tile) // T != min(16 * tile + 15, B * T - 1) // T]
         assert straddle and all(need[i] == nslabs - 1 for i in straddle)
 
+
+
+def test_deferral_is_refused_outside_a_backward_pass_and_without_a_side_stream(monkeypatch):
+    """ops.defer_small_launches (round 4): small launches may ride on the library's side stream only when the autograd engine will
+    run the join at the end of the pass it is executing, for a stream whose side stream passed the probe; otherwise the caller
+    launches on its own stream.  Host logic only: no GPU, no library call."""
+    import torch
+    from sound_bubble_amd import ops
+    import ctypes as C
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(ops, "_stream", lambda: C.c_void_p(1234))
+    monkeypatch.setattr(ops, "_OVERLAP_OK", {})
+    monkeypatch.setitem(ops._DEFER, "armed", False)
+    monkeypatch.setitem(ops._DEFER, "keep", [])
+    monkeypatch.setitem(ops._DEFER, "pending", [])
+    assert not ops.defer_small_launches(("x",))                 # no probed side stream for this stream
+    ops._OVERLAP_OK[(0, 1234)] = True
+    assert not ops.defer_small_launches(("x",))                 # not inside a backward pass: nobody would run the join
+    assert not ops._DEFER["armed"] and not ops._DEFER["keep"]
+    ran = []
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            ran.append(ops.defer_launch(lambda st: ran.append(("launched", st.value)), ("held",)))
+            ran.append((ops._DEFER["armed"], list(ops._DEFER["keep"]), len(ops._DEFER["pending"])))
+            return g * 2
+
+    joins = []
+    monkeypatch.setattr(ops, "deferred_side", lambda stream=None: C.c_void_p(77))
+
+    class Lib:
+        @staticmethod
+        def sb_overlap_join(st):
+            joins.append(st.value)
+            return 0
+
+    monkeypatch.setattr(ops.L, "load", lambda: Lib)
+    x = torch.ones(3, requires_grad=True)
+    Fn.apply(x).sum().backward()
+    # inside the pass: parked, armed, the tensor held; at its end the engine's callback flushed to the side stream and joined
+    assert ran[0] is True and ran[1] == (True, ["held"], 1)
+    assert ran[2] == ("launched", 77) and joins == [1234]
+    assert not ops._DEFER["armed"] and not ops._DEFER["keep"] and not ops._DEFER["pending"]
+    monkeypatch.setattr(ops, "DEFER_REDUCE", False)             # SB_NO_DEFERRED_REDUCE=1
+    del ran[:]
+    Fn.apply(x).sum().backward()
+    assert ran[0] is False and joins == [1234]
+
+
+def test_grad_targets_know_when_nothing_goes_back_through_autograd():
+    """functional._GradTargets.all_direct: deferral is only allowed when every target is a flat-bucket slice (a fresh tensor
+    handed back to autograd is read by AccumulateGrad on the main stream straight after the node)"""
+    import torch
+    from sound_bubble_amd.functional import _GradTargets
+    p = torch.nn.Parameter(torch.zeros(4))
+    q = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.zeros(4)
+    p._sb_flat_grad = True                                      # what train.FlatBucket sets
+    gt = _GradTargets()
+    assert gt("p", p) is p.grad and gt["p"] is None and gt.all_direct()
+    z = gt("q", q)
+    assert z is gt["q"] and z is not None and not gt.all_direct()
