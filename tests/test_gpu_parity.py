@@ -243,6 +243,29 @@ def test_loss_and_gradients_match_reference(torch_gpu, name, cls, mode, monkeypa
     assert worst[1] < (TOL_GRAD if compact else 2e-4), worst
 
 
+def test_deconv_data_gradient_measures_its_own_absmax(torch_gpu):
+    """sb_deconv_bwd_data's absmax_out (round 4): the max |dy| hint the first backward recurrence takes instead of a pass of its
+    own is EXACT although most waves skip the atomic behind a stale read of the word (it only grows) -- at a size with thousands
+    of workgroups, against torch, and the data gradient itself against autograd of conv_transpose2d."""
+    torch = torch_gpu
+    from sound_bubble_amd import ops
+    torch.manual_seed(3)
+    B, T, F, Cc = 3, 97, 145, 32
+    dspec = torch.randn(B, T, F, 2, device="cuda") * torch.rand(B, T, 1, 1, device="cuda")
+    dspec[1, 40, 77, 1] = 37.5                                  # one outlier decides the maximum
+    w = torch.randn(Cc, 2, 3, 3, device="cuda") * 0.2
+    ops.absmax_hints_clear()
+    dy = ops.deconv_bwd_data(dspec, w, B, T, F, Cc)
+    if ops.ABSMAX_HINTS:
+        assert float(ops.absmax_or_hint(dy)) == float(dy.abs().max())
+    # reference: y [B,C,T+2,F] -> ConvTranspose2d(C->2, 3x3, padding (2,1)) -> [B,2,T,F]... the causal form: 2 leading frames
+    y = torch.zeros(B, Cc, T + 2, F, device="cuda", requires_grad=True)
+    o = torch.nn.functional.conv_transpose2d(y, w, padding=(2, 1))
+    o.backward(dspec.permute(0, 3, 1, 2).contiguous())
+    ref = y.grad[:, :, 2:].permute(0, 2, 3, 1)
+    assert rel_l2(dy.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("name,cls", NUMCH_CASES)
 def test_other_microphone_counts_match_reference(torch_gpu, name, cls):
     """num_ch = 2 (the reference's constructor default: 7 feature channels) and 4 (17) in the default dispatch: loss vector and
