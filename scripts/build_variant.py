@@ -11,7 +11,7 @@ name, flags = sys.argv[1], sys.argv[2:]
 exp = os.path.join(B.LIBDIR, "exp")
 os.makedirs(exp, exist_ok=True)
 B.build()
-only = [s for s in B.SOURCES if s.startswith("sb_lstm")]          # the translation units the experiment flags touch
+only = [s for s in B.SOURCES if s.startswith(os.environ.get("SB_VARIANT_TUS", "sb_lstm"))]      # the translation units the experiment flags touch
 
 
 def cc(src):
