@@ -665,7 +665,8 @@ class _FlagPool:
         self.buf, self.i = {}, {}
 
     def get(self, n, dev):
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        # per (device, stream): the fill is ordered in front of the slice's users only on the stream that ran it
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
         n = (n + 63) & ~63
         b = self.buf.get(key)
         if b is None or self.i[key] + n > b.numel():
