@@ -39,6 +39,14 @@ SB_DEVINL void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // +1.2 % on the big train step (same box, round 4: the overlapped intra-frame consumer 0.59 -> 0.52 ms; round 2 had measured
 // -20 % with the position-major record layout, whose 64-byte pieces no longer combined in L2)
 SB_DEVINL f32x4 ld4_rec(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+// read-once input streams of the streaming passes (ln_film_bwd, ln_bwd): non-temporal; -DSB_EXP_NO_NT_STREAMS: plain loads (A/B builds)
+#ifdef SB_EXP_NO_NT_STREAMS
+SB_DEVINL f32x4 ld4_once(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+SB_DEVINL float ld1_once(const float* p) { return *p; }
+#else
+SB_DEVINL f32x4 ld4_once(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+SB_DEVINL float ld1_once(const float* p) { return __builtin_nontemporal_load(p); }
+#endif
 SB_DEVINL void st4_rec(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 // side outputs only the backward reads (u / hs pairs, x_sum, y_pre): experiment switch
 #ifdef SB_EXP_NT_SIDE

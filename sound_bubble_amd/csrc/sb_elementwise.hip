@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void ln_film_bwd_kernel(const float* __restric
   int64_t off = row_off(t0);
   // the five input streams are read exactly once: non-temporal loads (no L2 / MALL allocation) -- isolated 285 -> 257 us, in the
   // train step 0.228 -> 0.209 ms (scripts/exp_ln_film.py; a non-temporal store of `out` and other time chunks gave nothing more)
-  auto lds_ = [&](const float* p) -> f32x4 { return ld4_rec(p); };
+  auto lds_ = [&](const float* p) -> f32x4 { return ld4_once(p); };
   f32x4 ng0 = lds_(du + ((off >> 5) * 2) * C + 4 * c4), ng1 = lds_(du + ((off >> 5) * 2 + 1) * C + 4 * c4);
   f32x4 nx = lds_(xin + off), nrs = lds_(res + off), nfv = lds_(fx + off);
   for (int t = t0; t < t1; ++t) {

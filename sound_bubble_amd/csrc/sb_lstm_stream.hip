@@ -1025,10 +1025,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(sb_ln_bwd_args a) {
       const int c = cpart * VPT + v;
       float s = 0.f;
       // (read-once streams: non-temporal loads, as in the fused LayerNorm + FiLM backward)
-      for (int d = 0; d < a.ndir; ++d) s += __builtin_nontemporal_load(a.du_part + (pc * a.ndir + d) * C + c);
+      for (int d = 0; d < a.ndir; ++d) s += ld1_once(a.du_part + (pc * a.ndir + d) * C + c);
       ng[v] = s;
-      nraw[v] = __builtin_nontemporal_load(a.xin + pc * C + c);
-      nres[v] = a.res ? __builtin_nontemporal_load(a.res + pc * C + c) : 0.f;
+      nraw[v] = ld1_once(a.xin + pc * C + c);
+      nres[v] = a.res ? ld1_once(a.res + pc * C + c) : 0.f;
     }
   };
   fetch((int64_t)blockIdx.x * 16 + (tid >> 4));
