@@ -559,7 +559,8 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
         "rccl": RUN.get("rccl"),
         "schedules": {"per_rank": schedules,
                       "note": "inter-frame launches of the timed steps per rank: overlapped (producer || consumer, recurrence || "
-                              "stream kernel on the library's side stream) or plain order"},
+                              "stream kernel on the library's side stream) or plain order; deferred_joins = backward passes "
+                              "whose small launches (partial-row reductions, 3x3 weight gradients) rode on the side stream"},
     }
     if not forward_only:
         from sound_bubble_amd import train as _train

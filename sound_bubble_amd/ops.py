@@ -336,7 +336,7 @@ def overlap_available():
 
 # which schedule the inter-frame passes took since the last reset (bench.py: `schedules`, all-gathered over the ranks -- a side
 # stream lost next to RCCL's kernels shows here as plain-order counts)
-SCHED_COUNTS = {"fwd_overlapped": 0, "fwd_plain": 0, "bwd_overlapped": 0, "bwd_plain": 0}
+SCHED_COUNTS = {"fwd_overlapped": 0, "fwd_plain": 0, "bwd_overlapped": 0, "bwd_plain": 0, "deferred_joins": 0}
 
 
 def sched_counts_reset():
@@ -396,6 +396,7 @@ def deferred_join():
     deferred_flush()
     if _DEFER["armed"]:
         _DEFER["armed"] = False
+        SCHED_COUNTS["deferred_joins"] += 1          # (bench.py `schedules`: backward passes whose small launches rode on the side stream)
         L.check(L.load().sb_overlap_join(_DEFER["stream"]), "sb_overlap_join")
     _DEFER["keep"].clear()
 
