@@ -28,6 +28,7 @@ ALIASES = {
     "src.losses.SNRLP.SNRLPLoss": "sound_bubble_amd.losses.SNRLPLoss",
     "src.losses.MultiResoLoss.MultiResoFuseLoss": "sound_bubble_amd.losses.MultiResoFuseLoss",
     "src.hl_modules.distance_based_hl_module.PLModule": "sound_bubble_amd.harness.PLModule",
+    "src.datasets.general_multisrc_dataset_dis_embed.Dataset": "sound_bubble_amd.data.BubbleFolderDataset",
 }
 
 

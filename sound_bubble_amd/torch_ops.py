@@ -294,7 +294,11 @@ def _separate_setup(ctx, inputs, output):
     ctx.handle = output[-1]
     ctx.n_state = len(inputs[3])
     ctx.n_params = len(inputs[2])
-    ctx.save_for_backward(inputs[7] if len(inputs) > 7 else None)
+    # The flat bucket is NOT a saved tensor: it is zeroed (FlatBucket.zero_grad) and added into (every backward of the model)
+    # in place between this forward and its backward as a matter of course, and autograd's saved-tensor version check would
+    # turn both into "modified by an inplace operation" errors.  Its VALUE at forward time is irrelevant -- the backward
+    # only adds into whatever it holds when it runs -- so it rides along as a plain attribute.
+    ctx.bucket = inputs[7] if len(inputs) > 7 else None
     ctx.set_materialize_grads(False)
 
 
@@ -304,7 +308,7 @@ def _separate_bwd(ctx, grads):
     d_out = grads[0]
     if d_out is None:
         return (None, None, [None] * ctx.n_params, [None] * ctx.n_state, None, None, None, None)[:n_in]
-    (bucket,) = ctx.saved_tensors
+    bucket = ctx.bucket
     if bucket is not None:        # every gradient lands in the flat bucket (declared mutated): nothing comes back through autograd
         torch.ops.sound_bubble.separate_backward_bucket(ctx.handle, d_out, ctx.model, bucket)
         return (None, None, [None] * ctx.n_params, [None] * ctx.n_state, None, None, None, None)[:n_in]

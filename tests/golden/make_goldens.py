@@ -385,6 +385,21 @@ def make_samples_6block(torch, NetBig, big_params, out_dir):
           f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def copy_all_samples_full(out_dir):
+    """All nine bundled demo scenes (test_samples/syn_{1m,1_5m,2m}/0000{0,1,2}: the reference's MIT-licensed fixtures) at
+    their full 5 s under test_samples_full/ -- the scene folders sound_bubble_amd.data.BubbleFolderDataset trains on
+    (experiments/overfit_test_samples.json) and eval_samples evaluates.  Data only."""
+    import shutil
+    for sset in ("syn_1m", "syn_1_5m", "syn_2m"):
+        for scene in ("00000", "00001", "00002"):
+            src = os.path.join(REF, "test_samples", sset, scene)
+            dst = os.path.join(out_dir, "test_samples_full", sset, scene)
+            os.makedirs(dst, exist_ok=True)
+            for fn in sorted(os.listdir(src)):
+                shutil.copyfile(os.path.join(src, fn), os.path.join(dst, fn))
+    print("test_samples_full: 9 scenes copied")
+
+
 def make_state_io(torch, nets, out_dir):
     """edge/flatbuf.py:8-25 name order: the reference's own flatten_state_buffers over init_buffers of each family
     (+ attention buffers), and the reference's named_parameters() order (= torch.optim.Adam state indices)."""
@@ -527,6 +542,8 @@ def main():
                               "tiny_small": (NetSmall, dict(small, B=2))}, args.out)
     if not only or "ckpt" in only:
         make_ckpt(torch, NetSmall, args.out)
+    if not only or "samples_full" in only:
+        copy_all_samples_full(args.out)
 
 
 if __name__ == "__main__":

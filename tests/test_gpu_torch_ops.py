@@ -97,6 +97,45 @@ def test_operator_gradients_equal_the_module_and_the_goldens(name, cls, bucket):
         assert e < 2e-4, (k, e)
 
 
+def test_bucket_may_be_zeroed_or_added_into_between_forward_and_backward():
+    """the flat gradient bucket is mutated in place between a forward and its backward as a matter of
+    course -- (a) forward, zero_grad(), backward; (b) two forwards feeding one loss (the first node's backward adds into the
+    bucket before the second node runs).  Neither may trip autograd's saved-tensor version check, and both must leave the
+    gradients of the plain module path in the bucket."""
+    import torch
+    from sound_bubble_amd import torch_ops as T
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd.train import FlatBucket
+    rec, m, inp = _build(torch, "tiny_small", "NetOptim")
+    m.train()
+    fb = FlatBucket(m)
+    tgt = torch.from_numpy(rec["target"]).cuda()
+    fb.zero_grad()
+    loss, _ = SnrlpLossFn.apply(m(inp)["output"], tgt, 100.0)
+    loss.backward()
+    want = fb.grad.clone()
+    w = T.separate_module(m)
+    # (a) zero_grad AFTER the forward
+    fb.grad.fill_(7.0)
+    est = w(inp)["output"]
+    fb.zero_grad()
+    torch.ops.sound_bubble.snrlp_loss(est, tgt, 100.0)[0].backward()
+    assert rel_l2(fb.grad.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    # (b) two pending forwards, one backward: both nodes add into the same bucket
+    fb.zero_grad()
+    e1, e2 = w(inp)["output"], w(inp)["output"]
+    assert len(T._PENDING) == 2
+    l = torch.ops.sound_bubble.snrlp_loss(e1, tgt, 100.0)[0] + torch.ops.sound_bubble.snrlp_loss(e2, tgt, 100.0)[0]
+    l.backward()
+    assert not T._PENDING
+    assert rel_l2(fb.grad.cpu().numpy(), 2.0 * want.cpu().numpy()) < 1e-5
+    # (c) Module.zero_grad(set_to_none=False) zeroes the views in place: same thing
+    est = w(inp)["output"]
+    m.zero_grad(set_to_none=False)
+    torch.ops.sound_bubble.snrlp_loss(est, tgt, 100.0)[0].backward()
+    assert rel_l2(fb.grad.cpu().numpy(), want.cpu().numpy()) < 1e-5
+
+
 def test_parked_forwards_raise_at_the_limit_and_backward_declares_its_bucket():
     """a ninth recorded forward without a backward RAISES (it used to drop the oldest graph silently);
     drop_pending() releases them; the backward operator takes the flat gradient bucket it adds into as a declared-mutated
