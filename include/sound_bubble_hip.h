@@ -470,6 +470,18 @@ int sb_overlap_available(void* stream);
 int sb_overlap_shutdown(void);
 int sb_overlap_side_fork(void* stream, void** side);
 int sb_overlap_join(void* stream);
+/* Measurement aid: arms a ONE-SHOT timer -- the next kernel an overlapped entry point (sb_lstm_fwd_consume,
+ * sb_lstm_bwd_inter_pair, sb_lstm_bwd_cross_consume[_ex]) places on a library side stream has `ev_start` recorded straight in
+ * front of it and `ev_stop` straight behind it ON THAT SIDE STREAM (caller-owned hipEvent_t with timing enabled; the caller reads
+ * hipEventElapsedTime after synchronising).  nullptrs disarm.  Returns 1 when a timer armed earlier was still waiting (it never
+ * fired: no side launch happened), else 0.  Never needed for results: bench.py's live roofline uses it to
+ * time launches its own stream never sees. */
+int sb_overlap_time_next_side_launch(void* ev_start, void* ev_stop);
+/* Measurement aid: after sb_overlap_init(stream, ...), take the overlapped code paths on `stream` whatever the timed probe said
+ * (a side stream is created if the probe left none) -- for counter collection under a profiler that serialises dispatches
+ * (rocprofv3 --pmc): the shipped producer / consumer kernels then run one after the other, which their protocols tolerate
+ * (producers are enqueued first; consumer waits are bounded).  1 on success, 0 without a probed entry.  Not a product path. */
+int sb_overlap_force(void* stream);
 
 /* ---- LayerNorm (+PReLU) backward over C channels ---------------------------
  * g = sum_d du_part[p, d, :];  x = xin[p] (PReLU(xin[p]) with slope *prelu_a when prelu_a != NULL);
@@ -539,6 +551,34 @@ int sb_film_bwd(const float* x, const float* w, const float* dy, float* dx, floa
                 int B, int T, int F, int C, float* absmax_out /* optional: max |dx|, as sb_linear_args.absmax_out */,
                 void* stream);
 
+/* ---- distance embedding -> FiLM plane bank ---------------------------------------------------------------------------------
+ * Dis_Embed_Conv (dis_embd3/tfgridnet_causal.py:150-173: Linear(K = 3 -> 4F, no bias) -> view [B, F, 4] -> LayerNorm(4)) and the
+ * two Conv1d(4 -> C, k = 1) of every FilmLayer (:51-68), evaluated once per forward for all n = n_layers - 1 layers (:509-513):
+ *   e[b, f, :] = LN_4(W_e[4f .. 4f+3, :] . dis[b, :])   (4 = d_in of dis_type "conv3"; 1 / 2 / 8 for conv1 / conv2 / conv4);   planes[j, b, f, c] = conv_b[j][c] + sum_i conv_w[j][c, i] e[b, f, i],
+ *   j = 2 layer + which (0: the scale plane `weight`, 1: the shift plane `bias`); planes dense [2n, B, F, C].
+ * sb_film_bank_bwd: G [2n, B, F, C] = d loss / d planes (the buffer sb_film_bwd / sb_ln_film_bwd accumulated into);
+ *   d_conv_w[j] [C, d_in], d_conv_b[j] [C], d_ln_w [d_in], d_ln_b [d_in], dW_e [d_in F, K] are ACCUMULATED into (+=, fixed summation order:
+ *   deterministic); partials: sb_film_bank_bwd_scratch(F, C, n, d_in) floats of caller scratch.  Two launches.
+ * Limits: n <= SB_FILM_BANK_MAX_LAYERS, 2 n C <= 1024, K <= 8 (-1002 otherwise). */
+#define SB_FILM_BANK_MAX_LAYERS 16
+typedef struct {
+  int B, F, C, n, K, d_in;   /* d_in = 1 / 2 / 4 / 8: dis_type conv1 .. conv4 (every shipped JSON: conv3 = 4) */
+  const float* dis;        /* [B, K] */
+  const float* W_e;        /* [d_in F, K] */
+  const float* ln_w; const float* ln_b;                       /* [d_in] */
+  const float* conv_w[2 * SB_FILM_BANK_MAX_LAYERS];           /* [C, d_in] each */
+  const float* conv_b[2 * SB_FILM_BANK_MAX_LAYERS];           /* [C] each */
+  float* planes;           /* forward out */
+  const float* G;          /* backward in */
+  float* dW_e; float* d_ln_w; float* d_ln_b;
+  float* d_conv_w[2 * SB_FILM_BANK_MAX_LAYERS];
+  float* d_conv_b[2 * SB_FILM_BANK_MAX_LAYERS];
+  float* partials;
+} sb_film_bank_args;
+int sb_film_bank_fwd(const sb_film_bank_args* a, void* stream);
+int sb_film_bank_bwd_scratch(int F, int C, int n, int d_in);
+int sb_film_bank_bwd(const sb_film_bank_args* a, void* stream);
+
 /* sb_ln_film_bwd (C = 32): the LayerNorm backward of a block's intra-frame pass (sb_ln_bwd with ndir = 2 and a residual) and the
  * FiLM backward of the block in front of it in one pass -- dx = LN-bwd(du[p, 0, :] + du[p, 1, :]; xin, ln_g) + res never leaves
  * the registers: out = dx * film_w[b, f, :];  dw[b, f, :] += sum_t dx * film_x;  dbias[b, f, :] += sum_t dx (atomics, pre-zeroed
@@ -586,11 +626,17 @@ int sb_multi_copy(const sb_multi_copy_args* a, void* stream);
 int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int T, int F, int C, float* absmax_out, void* stream);
 
 /* ---- SNRLP loss (src/losses/SNRLP.py:17-42, asteroid SingleSrcNegSDR('snr')) ----
- * est, gt [B, N].  stats [B, 8] scratch.  loss_vec [B].  Negative (all-zero gt)
+ * est, gt [B, N].  stats [B, 12] scratch.  loss_vec [B].  Negative (all-zero gt)
  * samples get neg_weight * mean|est| over ALL negative samples' elements.
- * dest (nullable) = d mean_b(loss_vec) / d est. */
+ * dest (nullable) = d mean_b(loss_vec) / d est.
+ * sb_snrlp_loss_ex: `mode` = the positive samples' term, SNRLosses(name) of src/losses/SNRLosses.py:10-52 --
+ *   0 'snr' (sb_snrlp_loss; every shipped config), 1 'sisdr', 2 'fused' = (sisdr + snr) / 2, 3 'max_fused' = max(sisdr, snr),
+ *   4 'sdsdr' = max(snr, sdsdr), 5 'full' = sisdr / 2 + max(snr, sdsdr) / 2; each term asteroid's SingleSrcNegSDR (zero-mean,
+ *   EPS 1e-8), evaluated from the per-sample zero-mean moments S_tt, S_et, sum ((e - me) - (t - mt))^2.  -1002: unknown mode. */
 int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight,
                   float* stats, float* loss_vec, float* dest, void* stream);
+int sb_snrlp_loss_ex(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode,
+                     float* stats, float* loss_vec, float* dest, void* stream);
 
 /* ---- metric moments (src/metrics/metrics.py:44-55, hl_module:326-373) -------
  * One pass over est, gt [B, N] and the reference mixture channel (row b at mix + b*mix_stride):

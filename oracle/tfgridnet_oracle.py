@@ -333,10 +333,41 @@ class OracleNet(nn.Module):
         return {"output": y, "next_state": st}
 
 
-def snrlp_loss(est, gt, neg_weight):
-    """src/losses/SNRLP.py:17-42 with SNRLosses('snr') = asteroid
-    SingleSrcNegSDR('snr') (third-party, restated: zero-mean, EPS=1e-8 in the
-    denominator and inside the log).  Returns the per-sample vector [B]."""
+def neg_sdr(e, t, kind):
+    """asteroid.losses.sdr.SingleSrcNegSDR(kind) for kind in 'snr' / 'sisdr' / 'sdsdr' (third-party, absent from the reference
+    tree -- PARITY UNPINNED for its constants; restated from its published form: zero_mean=True, take_log=True, EPS = 1e-8 in
+    the scaling denominator, the ratio's denominator and inside the log).  e, t [n, time] -> [n]"""
+    EPS = 1e-8
+    e = e - e.mean(dim=1, keepdim=True)
+    t = t - t.mean(dim=1, keepdim=True)
+    if kind in ("sisdr", "sdsdr"):
+        dot = (e * t).sum(1, keepdim=True)
+        scaled = dot * t / ((t ** 2).sum(1, keepdim=True) + EPS)
+    else:
+        scaled = t
+    noise = e - t if kind in ("sdsdr", "snr") else e - scaled
+    ratio = (scaled ** 2).sum(1) / ((noise ** 2).sum(1) + EPS)
+    return -10 * torch.log10(ratio + EPS)
+
+
+def snr_losses(e, t, name):
+    """src/losses/SNRLosses.py:10-52"""
+    if name in ("snr", "sisdr"):
+        return neg_sdr(e, t, name)
+    if name == "fused":
+        return 0.5 * neg_sdr(e, t, "sisdr") + 0.5 * neg_sdr(e, t, "snr")
+    if name == "max_fused":
+        return torch.maximum(neg_sdr(e, t, "sisdr"), neg_sdr(e, t, "snr"))
+    if name == "sdsdr":
+        return torch.maximum(neg_sdr(e, t, "snr"), neg_sdr(e, t, "sdsdr"))
+    if name == "full":
+        return 0.5 * neg_sdr(e, t, "sisdr") + 0.5 * torch.maximum(neg_sdr(e, t, "snr"), neg_sdr(e, t, "sdsdr"))
+    raise AssertionError(f"Invalid loss function used: Loss {name} not found")
+
+
+def snrlp_loss(est, gt, neg_weight, snr_loss_name="snr"):
+    """src/losses/SNRLP.py:17-42 with SNRLosses(snr_loss_name) (asteroid SingleSrcNegSDR, restated in neg_sdr).
+    Returns the per-sample vector [B]."""
     B = est.shape[0]
     comp = torch.zeros(B, dtype=est.dtype, device=est.device)
     mask = gt.abs().amax(dim=(1, 2)) == 0
@@ -345,10 +376,7 @@ def snrlp_loss(est, gt, neg_weight):
     if (~mask).any():
         e = est[~mask].reshape(-1, est.shape[-1])
         t = gt[~mask].reshape(-1, gt.shape[-1])
-        e = e - e.mean(dim=1, keepdim=True)
-        t = t - t.mean(dim=1, keepdim=True)
-        ratio = (t ** 2).sum(1) / (((e - t) ** 2).sum(1) + 1e-8)
-        comp[~mask] = -10 * torch.log10(ratio + 1e-8)
+        comp[~mask] = snr_losses(e, t, snr_loss_name)
     return comp
 
 

@@ -3,8 +3,10 @@
   * pmc_traffic_<wl>.json -- HBM bytes per launch of every kernel that takes >= 0.5 % of the traced time:
     2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md: wide coalesced reads are tallied at half) + WRITE_SIZE,
     both counters in KB -> bytes x 1024, with the kernel's average duration from the same pass;
-  * pmc_sq_<wl>.json -- SQ activity per kernel: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (matrix pipe busy share),
-    and the wave-cycle split SQ_WAIT_ANY (parked on s_waitcnt / barrier), SQ_WAIT_INST_ANY (issue stalls),
+  * pmc_sq_<wl>.json -- SQ activity per kernel: mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the chip's
+    1024 SIMDs) / (launch duration in the same pass x shader clock x 1024) -- the clock from GRBM_GUI_ACTIVE when the pass
+    collected it and it is plausible, else 2.0 GHz (MI355X_MICROARCH.md: profiled passes run 1.89-1.95 GHz); round 4 divided by
+    SQ_BUSY_CYCLES, a per-SE count, and got "fractions" of 3.5-10 -- and the wave-cycle split SQ_WAIT_ANY (parked on s_waitcnt / barrier), SQ_WAIT_INST_ANY (issue stalls),
     SQ_ACTIVE_INST_ANY (issuing), SQ_ACTIVE_INST_VALU over SQ_WAVE_CYCLES (quad-cycle units).
 usage: pmc_summary.py <workload> [gpurun_out dir] [traffic json] [sq json]"""
 import collections
@@ -71,8 +73,8 @@ def main():
         s, sd = per_kernel(spath)
         total = sum(v[0] for v in sd.values())
         out = {"note": f"rocprofv3 --pmc SQ_* pass of `bench.py --steps 2 --warmup 1 --workload {wl} --no-exact`; sums over "
-                       f"all SEs per launch, averaged over launches.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
-                       f"SQ_BUSY_CYCLES; the wave-cycle split is in quad-cycles (MI355X_MICROARCH.md): WAIT_ANY = parked on "
+                       f"all SEs per launch, averaged over launches.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                       f"(duration x shader clock x 1024 SIMDs); the wave-cycle split is in quad-cycles (MI355X_MICROARCH.md): WAIT_ANY = parked on "
                        f"s_waitcnt / barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY = issuing", "kernels": {}}
         for k in sorted(s, key=lambda k: -sd[k][0]):
             if sd[k][0] < 0.005 * total:
@@ -84,8 +86,19 @@ def main():
             for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
                       "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"):
                 ent[c] = g(c)
-            if mf is not None and busy:
-                ent["mfma_busy_frac"] = mf / busy
+            gui = g("GRBM_GUI_ACTIVE")
+            clk = None
+            if gui:                                     # summed over XCDs or not, depending on the profiler build: take what is sane
+                for div in (1.0, 8.0):
+                    c = gui / div / (ent["avg_us_in_pmc_pass"] * 1e-6)
+                    if 1.2e9 <= c <= 2.6e9:
+                        clk = c
+                        break
+            ent["GRBM_GUI_ACTIVE"] = gui
+            ent["shader_clock_hz"] = clk or 2.0e9
+            ent["shader_clock_source"] = "GRBM_GUI_ACTIVE / duration" if clk else "assumed 2.0 GHz"
+            if mf is not None:
+                ent["mfma_busy"] = mf / (ent["avg_us_in_pmc_pass"] * 1e-6 * ent["shader_clock_hz"] * 1024.0)
             if wc:
                 for c, n in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac"),
                              ("SQ_ACTIVE_INST_ANY", "active_inst_frac"), ("SQ_ACTIVE_INST_VALU", "active_valu_frac")):

@@ -127,6 +127,18 @@ class AttnBwdArgs(C.Structure):
                 ("delta", c_fp), ("dQ", c_fp), ("dK", c_fp), ("dV", c_fp)]
 
 
+FILM_BANK_MAX_LAYERS = 16
+
+
+class FilmBankArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("F", C.c_int), ("C", C.c_int), ("n", C.c_int), ("K", C.c_int), ("d_in", C.c_int),
+                ("dis", c_fp), ("W_e", c_fp), ("ln_w", c_fp), ("ln_b", c_fp),
+                ("conv_w", c_fp * (2 * FILM_BANK_MAX_LAYERS)), ("conv_b", c_fp * (2 * FILM_BANK_MAX_LAYERS)),
+                ("planes", c_fp), ("G", c_fp), ("dW_e", c_fp), ("d_ln_w", c_fp), ("d_ln_b", c_fp),
+                ("d_conv_w", c_fp * (2 * FILM_BANK_MAX_LAYERS)), ("d_conv_b", c_fp * (2 * FILM_BANK_MAX_LAYERS)),
+                ("partials", c_fp)]
+
+
 EPI_NONE, EPI_RES, EPI_PRELU, EPI_LN, EPI_LNBWD = range(5)
 
 # every symbol include/sound_bubble_hip.h declares: name -> (restype, argtypes)
@@ -167,6 +179,8 @@ SYMBOLS = {
     "sb_overlap_shutdown": (_ci, []),
     "sb_overlap_side_fork": (_ci, [_vp, C.POINTER(C.c_void_p)]),
     "sb_overlap_join": (_ci, [_vp]),
+    "sb_overlap_time_next_side_launch": (_ci, [_vp, _vp]),
+    "sb_overlap_force": (_ci, [_vp]),
     "sb_ln_bwd": (_ci, [C.POINTER(LnBwdArgs), _vp]),
     "sb_ln_bwd_grid": (_ci, [i64]),
     "sb_head_ln": (_ci, [c_fp, c_fp, c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, c_fp, _vp]),
@@ -182,10 +196,14 @@ SYMBOLS = {
     "sb_ln_film_bwd_rows": (_ci, [_ci, _ci, _ci]),
     "sb_ln_film_bwd": (_ci, [c_fp] * 10 + [_ci, _ci, _ci, _ci, c_fp, _vp]),
     "sb_add3": (_ci, [c_fp, c_fp, c_fp, i64, _ci, _vp]),
+    "sb_film_bank_fwd": (_ci, [C.POINTER(FilmBankArgs), _vp]),
+    "sb_film_bank_bwd_scratch": (_ci, [_ci, _ci, _ci, _ci]),
+    "sb_film_bank_bwd": (_ci, [C.POINTER(FilmBankArgs), _vp]),
     "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, c_fp, _vp]),
     "sb_snrlp_loss": (_ci, [c_fp, c_fp, _ci, i64, _cf, c_fp, c_fp, c_fp, _vp]),
+    "sb_snrlp_loss_ex": (_ci, [c_fp, c_fp, _ci, i64, _cf, _ci, c_fp, c_fp, c_fp, _vp]),
     "sb_signal_stats": (_ci, [c_fp, c_fp, c_fp, _ci, i64, i64, c_fp, _vp]),
     "sb_sumsq": (_ci, [c_fp, i64, c_fp, _vp]),
     "sb_absmax": (_ci, [c_fp, i64, c_fp, _vp]),

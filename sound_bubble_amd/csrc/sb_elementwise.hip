@@ -274,6 +274,11 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_kernel(const float* __res
 
 // ---------------- SNRLP loss ----------------
 // stats[b*8 + k]: 0 sum e, 1 sum t, 2 max|t| (as uint bits), 3 sum t'^2, 4 sum (e'-t')^2, 5 sum |e-t|
+// SNRLP loss, stats layout [B, 12]: 0 sum e, 1 sum t, 2 max |t| (bit pattern), 3 S_tt, 4 S_dd = sum ((e - me) - (t - mt))^2,
+// 5 sum |e - t|, 6 S_et = sum (e - me)(t - mt), 7 is_negative, 8 grad coefficient of (e - me), 9 grad coefficient of (t - mt),
+// 10 S_nn = sum ((e - me) - alpha (t - mt))^2 with alpha = S_et / (S_tt + EPS) (third pass, only for the modes with an 'sisdr' term:
+// formed from the moments it is S_ee - 2 alpha S_et + alpha^2 S_tt, which cancels to nothing at high SI-SDR)
+constexpr int kLs = 12;
 __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict__ est, const float* __restrict__ gt,
                                                          int64_t N, float* __restrict__ stats) {
   const int b = blockIdx.y;
@@ -286,9 +291,9 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
   se = wave_sum(se); st = wave_sum(st);
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(stats + b * 8 + 0, se);
-    atomicAdd(stats + b * 8 + 1, st);
-    atomicMax(reinterpret_cast<unsigned int*>(stats + b * 8 + 2), __float_as_uint(mx));
+    atomicAdd(stats + b * kLs + 0, se);
+    atomicAdd(stats + b * kLs + 1, st);
+    atomicMax(reinterpret_cast<unsigned int*>(stats + b * kLs + 2), __float_as_uint(mx));
   }
 }
 __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict__ est, const float* __restrict__ gt,
@@ -296,60 +301,125 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
   const int b = blockIdx.y;
   const float* e = est + (int64_t)b * N;
   const float* t = gt + (int64_t)b * N;
-  const float me = stats[b * 8 + 0] / (float)N, mt = stats[b * 8 + 1] / (float)N;
-  float s3 = 0.f, s4 = 0.f, s5 = 0.f;
+  const float me = stats[b * kLs + 0] / (float)N, mt = stats[b * kLs + 1] / (float)N;
+  float s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-    const float tt = t[i] - mt, d = (e[i] - me) - tt;
-    s3 += tt * tt; s4 += d * d; s5 += fabsf(e[i] - t[i]);
+    const float tt = t[i] - mt, ee = e[i] - me, d = ee - tt;
+    s3 += tt * tt; s4 += d * d; s5 += fabsf(e[i] - t[i]); s6 += ee * tt;
   }
-  s3 = wave_sum(s3); s4 = wave_sum(s4); s5 = wave_sum(s5);
+  s3 = wave_sum(s3); s4 = wave_sum(s4); s5 = wave_sum(s5); s6 = wave_sum(s6);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(stats + b * 8 + 3, s3);
-    atomicAdd(stats + b * 8 + 4, s4);
-    atomicAdd(stats + b * 8 + 5, s5);
+    atomicAdd(stats + b * kLs + 3, s3);
+    atomicAdd(stats + b * kLs + 4, s4);
+    atomicAdd(stats + b * kLs + 5, s5);
+    atomicAdd(stats + b * kLs + 6, s6);
   }
 }
-// single block: per-sample loss; stats[b*8+6] = grad coefficient (positive) ; stats[b*8+7] = is_negative
-__global__ void loss_final_kernel(float* __restrict__ stats, int B, int64_t N, float neg_weight,
+__global__ __launch_bounds__(256) void loss_pass3_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                         int64_t N, float* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const float* e = est + (int64_t)b * N;
+  const float* t = gt + (int64_t)b * N;
+  const float me = stats[b * kLs + 0] / (float)N, mt = stats[b * kLs + 1] / (float)N;
+  const float al = stats[b * kLs + 6] / (stats[b * kLs + 3] + 1e-8f);
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = (e[i] - me) - al * (t[i] - mt);
+    s += d * d;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(stats + b * kLs + 10, s);
+}
+// asteroid SingleSrcNegSDR (third-party, restated: zero-mean signals, EPS = 1e-8 in the denominators and inside the log) as a
+// function of the zero-mean moments; returns the loss and its derivatives w.r.t. S_ee and S_et (S_tt does not depend on est).
+//   kind 0 'snr':   target / (est - target);  1 'sisdr': scaled target / (est - scaled target);  2 'sdsdr': scaled target / (est - target)
+struct SdrTerm { float loss, d_see, d_set; };
+__device__ inline SdrTerm sdr_term(int kind, float Stt, float Sdd, float Set, float Snn) {
+  const float EPS = 1e-8f, k10 = 10.f / 2.302585092994046f;
+  SdrTerm r;
+  if (kind == 0) {                                   // (the round-1 formulas, kept to the bit)
+    const float Sn = Sdd + EPS, R = Stt / Sn;
+    r.loss = -10.f * log10f(R + EPS);
+    const float c = k10 / (R + EPS) * (Stt / (Sn * Sn));          // dL/dS_dd;  S_dd = S_ee - 2 S_et + S_tt
+    r.d_see = c; r.d_set = -2.f * c;
+    return r;
+  }
+  const float da = 1.f / (Stt + EPS), al = Set * da;
+  const float num = al * al * Stt, dnum_set = 2.f * al * Stt * da;
+  float noise, dn_see = 1.f, dn_set;
+  if (kind == 1) { noise = Snn; dn_set = -2.f * al + da * (-2.f * Set + 2.f * al * Stt); }   // = S_ee - 2 al S_et + al^2 S_tt
+  else { noise = Sdd; dn_set = -2.f; }
+  const float Sn = noise + EPS, R = num / Sn;
+  r.loss = -10.f * log10f(R + EPS);
+  const float g = -k10 / (R + EPS);                  // dL/dR
+  r.d_see = g * (-num / (Sn * Sn) * dn_see);
+  r.d_set = g * (dnum_set / Sn - num / (Sn * Sn) * dn_set);
+  return r;
+}
+// max of two terms with torch.maximum's gradient (ties: half each)
+__device__ inline SdrTerm sdr_max(SdrTerm x, SdrTerm y) {
+  if (x.loss > y.loss) return x;
+  if (y.loss > x.loss) return y;
+  SdrTerm r = {x.loss, 0.5f * (x.d_see + y.d_see), 0.5f * (x.d_set + y.d_set)};
+  return r;
+}
+// single block: per-sample loss and the two gradient coefficients.  mode (src/losses/SNRLosses.py:10-52): 0 'snr', 1 'sisdr',
+// 2 'fused' = (sisdr + snr) / 2, 3 'max_fused' = max(sisdr, snr), 4 'sdsdr' = max(snr, sdsdr), 5 'full' = sisdr / 2 + max(snr, sdsdr) / 2
+__global__ void loss_final_kernel(float* __restrict__ stats, int B, int64_t N, float neg_weight, int mode,
                                   float* __restrict__ loss_vec) {
   __shared__ float negsum;
   __shared__ int nneg;
   if (threadIdx.x == 0) {
     float s = 0.f; int c = 0;
     for (int b = 0; b < B; ++b)
-      if (stats[b * 8 + 2] == 0.f) { s += stats[b * 8 + 5]; ++c; }
+      if (stats[b * kLs + 2] == 0.f) { s += stats[b * kLs + 5]; ++c; }
     negsum = s; nneg = c;
   }
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const bool neg = stats[b * 8 + 2] == 0.f;
+    const bool neg = stats[b * kLs + 2] == 0.f;
     if (neg) {
       loss_vec[b] = neg_weight * negsum / ((float)nneg * (float)N);
-      stats[b * 8 + 6] = 0.f;
-      stats[b * 8 + 7] = 1.f;
+      stats[b * kLs + 8] = 0.f; stats[b * kLs + 9] = 0.f;
+      stats[b * kLs + 7] = 1.f;
     } else {
-      const float St = stats[b * 8 + 3], Sn = stats[b * 8 + 4] + 1e-8f;
-      const float R = St / Sn;
-      loss_vec[b] = -10.f * log10f(R + 1e-8f);
-      // dL/de_n = coef * (e'_n - t'_n)
-      stats[b * 8 + 6] = (10.f / 2.302585092994046f) / (R + 1e-8f) * (St / (Sn * Sn)) * 2.f;
-      stats[b * 8 + 7] = 0.f;
+      const float Stt = stats[b * kLs + 3], Sdd = stats[b * kLs + 4], Set = stats[b * kLs + 6], Snn = stats[b * kLs + 10];
+      SdrTerm r;
+      if (mode == 0) r = sdr_term(0, Stt, Sdd, Set, Snn);
+      else if (mode == 1) r = sdr_term(1, Stt, Sdd, Set, Snn);
+      else if (mode == 2 || mode == 3) {
+        const SdrTerm x = sdr_term(1, Stt, Sdd, Set, Snn), y = sdr_term(0, Stt, Sdd, Set, Snn);
+        if (mode == 3) r = sdr_max(x, y);
+        else { r.loss = 0.5f * x.loss + 0.5f * y.loss; r.d_see = 0.5f * (x.d_see + y.d_see); r.d_set = 0.5f * (x.d_set + y.d_set); }
+      } else {
+        r = sdr_max(sdr_term(0, Stt, Sdd, Set, Snn), sdr_term(2, Stt, Sdd, Set, Snn));
+        if (mode == 5) {
+          const SdrTerm z = sdr_term(1, Stt, Sdd, Set, Snn);
+          r.loss = 0.5f * z.loss + 0.5f * r.loss; r.d_see = 0.5f * (z.d_see + r.d_see); r.d_set = 0.5f * (z.d_set + r.d_set);
+        }
+      }
+      loss_vec[b] = r.loss;
+      // dL/de_n = 2 dL/dS_ee (e_n - me) + dL/dS_et (t_n - mt)   (both zero-mean: the mean subtraction's own gradient vanishes)
+      stats[b * kLs + 8] = 2.f * r.d_see;
+      stats[b * kLs + 9] = r.d_set;
+      stats[b * kLs + 7] = 0.f;
     }
   }
 }
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ est, const float* __restrict__ gt,
-                                                        int B, int64_t N, float neg_weight,
+                                                        int B, int64_t N, float neg_weight, int mode,
                                                         const float* __restrict__ stats, float* __restrict__ dest) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * N) return;
   const int b = (int)(i / N);
   const float invB = 1.0f / (float)B;
-  if (stats[b * 8 + 7] != 0.f) {
+  if (stats[b * kLs + 7] != 0.f) {
     const float d = est[i] - gt[i];
     dest[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * neg_weight * invB / (float)N;
   } else {
-    const float me = stats[b * 8 + 0] / (float)N, mt = stats[b * 8 + 1] / (float)N;
-    dest[i] = stats[b * 8 + 6] * ((est[i] - me) - (gt[i] - mt)) * invB;
+    const float me = stats[b * kLs + 0] / (float)N, mt = stats[b * kLs + 1] / (float)N;
+    if (mode == 0) dest[i] = stats[b * kLs + 8] * ((est[i] - me) - (gt[i] - mt)) * invB;       // (a = -b: the round-1 expression)
+    else dest[i] = (stats[b * kLs + 8] * (est[i] - me) + stats[b * kLs + 9] * (gt[i] - mt)) * invB;
   }
 }
 
@@ -469,6 +539,152 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(sb_multi_copy_args a) {
   for (int64_t i = 4 * n4 + i0; i < n; i += stride) d[i] = s[i];
 }
 
+// ---- distance embedding -> FiLM plane bank (Dis_Embed_Conv, tfgridnet_causal.py:150-173, and the two Conv1d(4 -> C, k = 1) of
+// every FilmLayer, :51-68, applied once per forward for all layers, :509-513) -------------------------------------------------
+// e[b, f, :] = LN_DIN(W_e[DIN f .. DIN f + DIN - 1, :] . dis[b, :])  (DIN = 1 / 2 / 4 / 8 for dis_type conv1 .. conv4);  planes[j, b, f, c] = conv_b[j][c] + sum_i conv_w[j][c, i] e[b, f, i],
+// j = 2 layer + (0 scale | 1 shift).  A few hundred KB of arithmetic: ONE launch forward, two backward (main + partial rows).
+constexpr int kFbRows = 8;          // (b, f) rows per workgroup, forward
+template <int DIN>
+__global__ __launch_bounds__(256) void film_bank_fwd_kernel(sb_film_bank_args a) {
+  __shared__ float e_s[kFbRows][DIN];
+  const int BF = a.B * a.F, r0 = blockIdx.x * kFbRows, tid = threadIdx.x;
+  if (tid < kFbRows && r0 + tid < BF) {
+    const int b = (r0 + tid) / a.F, f = (r0 + tid) % a.F;
+    float v[DIN], mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) {
+      float s = 0.f;
+      for (int k = 0; k < a.K; ++k) s = __builtin_fmaf(a.W_e[(DIN * f + i) * a.K + k], a.dis[b * a.K + k], s);
+      v[i] = s;
+      mean += s;
+    }
+    mean *= 1.0f / DIN;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) { v[i] -= mean; sq += v[i] * v[i]; }
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / DIN) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) e_s[tid][i] = v[i] * rstd * a.ln_w[i] + a.ln_b[i];
+  }
+  __syncthreads();
+  const int C = a.C, nj = 2 * a.n, per = kFbRows * C;
+  for (int o = tid; o < nj * per; o += 256) {
+    const int j = o / per, r = (o % per) / C, c = o % C;
+    if (r0 + r >= BF) continue;
+    const float* w = a.conv_w[j] + DIN * c;
+    float y = a.conv_b[j][c];
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) y = __builtin_fmaf(w[i], e_s[r][i], y);
+    a.planes[((int64_t)j * BF + r0 + r) * C + c] = y;
+  }
+}
+
+// backward: one workgroup per frequency bin f (it owns rows 4f .. 4f+3 of dW_e outright), thread = (plane j, channel c) over
+// the batch; the sums over (b, f) of the conv / LayerNorm parameter gradients leave as one partial row per workgroup:
+// [j][c][DIN] weights, [j][c] biases, d(ln_w)[DIN], d(ln_b)[DIN] -- reduced in fixed order by film_bank_reduce_kernel (deterministic)
+constexpr int kFbMaxB = 64;
+template <int DIN>
+__global__ __launch_bounds__(1024) void film_bank_bwd_kernel(sb_film_bank_args a) {
+  __shared__ float e_s[kFbMaxB][DIN], xh_s[kFbMaxB][DIN], rstd_s[kFbMaxB], de_s[kFbMaxB][DIN], red_s[16][DIN], dE_s[kFbMaxB][DIN];
+  const int f = blockIdx.x, tid = threadIdx.x, C = a.C, nj = 2 * a.n, njc = nj * C, BF = a.B * a.F;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = (blockDim.x + 63) >> 6;
+  const int j = tid / C, c = tid % C;
+  const bool act = tid < njc;
+  float w4[DIN], accw[DIN], accb = 0.f, dlw = 0.f, dlb = 0.f;
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) { w4[i] = act ? a.conv_w[j][DIN * c + i] : 0.f; accw[i] = 0.f; }
+  for (int b0 = 0; b0 < a.B; b0 += kFbMaxB) {
+    const int nb = min(kFbMaxB, a.B - b0);
+    __syncthreads();
+    if (tid < nb) {                                  // the forward's e, xhat, rstd of row (b0 + tid, f)
+      const int b = b0 + tid;
+      float v[DIN], mean = 0.f;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) {
+        float s = 0.f;
+        for (int k = 0; k < a.K; ++k) s = __builtin_fmaf(a.W_e[(DIN * f + i) * a.K + k], a.dis[b * a.K + k], s);
+        v[i] = s;
+        mean += s;
+      }
+      mean *= 1.0f / DIN;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) { v[i] -= mean; sq += v[i] * v[i]; }
+      const float rstd = 1.0f / sqrtf(sq * (1.0f / DIN) + 1e-5f);
+      rstd_s[tid] = rstd;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) { xh_s[tid][i] = v[i] * rstd; e_s[tid][i] = v[i] * rstd * a.ln_w[i] + a.ln_b[i]; }
+    }
+    __syncthreads();
+    for (int bb = 0; bb < nb; ++bb) {
+      const float g = act ? a.G[((int64_t)j * BF + (int64_t)(b0 + bb) * a.F + f) * C + c] : 0.f;
+      accb += g;
+      float p[DIN];
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) { accw[i] = __builtin_fmaf(g, e_s[bb][i], accw[i]); p[i] = g * w4[i]; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) p[i] += __shfl_xor(p[i], o, 64);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) red_s[wave][i] = p[i];
+      }
+      __syncthreads();
+      if (tid < DIN) {
+        float s = 0.f;
+        for (int w = 0; w < nwaves; ++w) s += red_s[w][tid];
+        de_s[bb][tid] = s;
+      }
+      __syncthreads();
+    }
+    if (tid < nb) {                                  // LayerNorm(DIN) backward of row (b0 + tid, f)
+      float dxh[DIN], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) {
+        dxh[i] = de_s[tid][i] * a.ln_w[i];
+        m1 += dxh[i];
+        m2 += dxh[i] * xh_s[tid][i];
+      }
+      m1 *= 1.0f / DIN; m2 *= 1.0f / DIN;
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) dE_s[tid][i] = rstd_s[tid] * (dxh[i] - m1 - xh_s[tid][i] * m2);
+    }
+    __syncthreads();
+    if (tid < DIN) {                                 // d(ln_w), d(ln_b): this workgroup's share, batch order
+      for (int bb = 0; bb < nb; ++bb) { dlw += de_s[bb][tid] * xh_s[bb][tid]; dlb += de_s[bb][tid]; }
+    }
+    if (tid >= 64 && tid < 64 + DIN * a.K) {         // dW_e[DIN f + i, k] += sum_b dE0[b, f, i] dis[b, k]: this workgroup owns the rows
+      const int i = (tid - 64) / a.K, k = (tid - 64) % a.K;
+      float s = 0.f;
+      for (int bb = 0; bb < nb; ++bb) s = __builtin_fmaf(dE_s[bb][i], a.dis[(b0 + bb) * a.K + k], s);
+      a.dW_e[(DIN * f + i) * a.K + k] += s;
+    }
+  }
+  float* row = a.partials + (int64_t)f * (njc * (DIN + 1) + 2 * DIN);
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) row[(j * C + c) * DIN + i] = accw[i];
+    row[njc * DIN + j * C + c] = accb;
+  }
+  if (tid < DIN) { row[njc * (DIN + 1) + tid] = dlw; row[njc * (DIN + 1) + DIN + tid] = dlb; }
+}
+
+// out[col] += sum over the F partial rows, fixed order; column -> (parameter tensor, element) through the pointer tables
+template <int DIN>
+__global__ __launch_bounds__(256) void film_bank_reduce_kernel(sb_film_bank_args a) {
+  const int C = a.C, njc = 2 * a.n * C, ld = njc * (DIN + 1) + 2 * DIN;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ld) return;
+  float s = 0.f;
+  for (int r = 0; r < a.F; ++r) s += a.partials[(int64_t)r * ld + col];
+  if (col < njc * DIN) a.d_conv_w[col / (DIN * C)][col % (DIN * C)] += s;
+  else if (col < njc * (DIN + 1)) a.d_conv_b[(col - njc * DIN) / C][(col - njc * DIN) % C] += s;
+  else if (col < njc * (DIN + 1) + DIN) a.d_ln_w[col - njc * (DIN + 1)] += s;
+  else a.d_ln_b[col - njc * (DIN + 1) - DIN] += s;
+}
+
 }  // namespace
 
 extern "C" int sb_features(const float* spec, int64_t ld_spec, float* zp, int B, int M, int T, int F, void* stream) {
@@ -500,6 +716,41 @@ extern "C" int sb_film_bwd(const float* x, const float* w, const float* dy, floa
   const int tchunk = 25;
   dim3 grid(nblk(n), (T + tchunk - 1) / tchunk);
   hipLaunchKernelGGL(film_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, dy, dx, dw, dbias, B, T, F, C, tchunk, absmax_out);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+static int film_bank_check(const sb_film_bank_args* a) {
+  if (!a || !a->dis || !a->W_e || !a->ln_w || !a->ln_b) return -1001;
+  if (a->B <= 0 || a->F <= 0 || a->C <= 0 || a->n <= 0 || a->K <= 0) return -1001;
+  if (a->n > SB_FILM_BANK_MAX_LAYERS || a->K > 8 || 2 * a->n * a->C > 1024 ||
+      (a->d_in != 1 && a->d_in != 2 && a->d_in != 4 && a->d_in != 8))
+    return -1002;
+  for (int j = 0; j < 2 * a->n; ++j) if (!a->conv_w[j] || !a->conv_b[j]) return -1001;
+  return 0;
+}
+extern "C" int sb_film_bank_fwd(const sb_film_bank_args* a, void* stream) {
+  if (int rc = film_bank_check(a)) return rc;
+  if (!a->planes) return -1001;
+  const int BF = a->B * a->F;
+#define SB_FB(D) hipLaunchKernelGGL(film_bank_fwd_kernel<D>, dim3((BF + kFbRows - 1) / kFbRows), dim3(256), 0, (hipStream_t)stream, *a)
+  if (a->d_in == 4) SB_FB(4); else if (a->d_in == 8) SB_FB(8); else if (a->d_in == 2) SB_FB(2); else SB_FB(1);
+#undef SB_FB
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sb_film_bank_bwd_scratch(int F, int C, int n, int d_in) { return F * (2 * n * C * (d_in + 1) + 2 * d_in); }
+extern "C" int sb_film_bank_bwd(const sb_film_bank_args* a, void* stream) {
+  if (int rc = film_bank_check(a)) return rc;
+  if (!a->G || !a->dW_e || !a->d_ln_w || !a->d_ln_b || !a->partials) return -1001;
+  for (int j = 0; j < 2 * a->n; ++j) if (!a->d_conv_w[j] || !a->d_conv_b[j]) return -1001;
+  const int njc = 2 * a->n * a->C;
+  const int bs = (njc + 63) / 64 * 64 < 128 ? 128 : (njc + 63) / 64 * 64;
+#define SB_FB(D) do { \
+    hipLaunchKernelGGL(film_bank_bwd_kernel<D>, dim3(a->F), dim3(bs), 0, (hipStream_t)stream, *a); \
+    hipLaunchKernelGGL(film_bank_reduce_kernel<D>, dim3((njc * (D + 1) + 2 * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a); } while (0)
+  if (a->d_in == 4) SB_FB(4); else if (a->d_in == 8) SB_FB(8); else if (a->d_in == 2) SB_FB(2); else SB_FB(1);
+#undef SB_FB
   SB_CHECK_LAUNCH();
   return 0;
 }
@@ -554,18 +805,26 @@ extern "C" int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy,
   return 0;
 }
 
-extern "C" int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight, float* stats,
-                             float* loss_vec, float* dest, void* stream) {
+extern "C" int sb_snrlp_loss_ex(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode, float* stats,
+                                float* loss_vec, float* dest, void* stream) {
+  if (!est || !gt || !stats || !loss_vec || B <= 0 || N <= 0) return -1001;
+  if (mode < 0 || mode > 5) return -1002;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(stats, 0, (size_t)B * 8 * sizeof(float), st);
+  (void)hipMemsetAsync(stats, 0, (size_t)B * kLs * sizeof(float), st);
   unsigned gx = nblk(N, 256 * 8);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(loss_pass1_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
   hipLaunchKernelGGL(loss_pass2_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, stats, B, N, neg_weight, loss_vec);
-  if (dest) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk((int64_t)B * N)), dim3(256), 0, st, est, gt, B, N, neg_weight, stats, dest);
+  if (mode == 1 || mode == 2 || mode == 3 || mode == 5)
+    hipLaunchKernelGGL(loss_pass3_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, stats, B, N, neg_weight, mode, loss_vec);
+  if (dest) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk((int64_t)B * N)), dim3(256), 0, st, est, gt, B, N, neg_weight, mode, stats, dest);
   SB_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight, float* stats,
+                             float* loss_vec, float* dest, void* stream) {
+  return sb_snrlp_loss_ex(est, gt, B, N, neg_weight, 0, stats, loss_vec, dest, stream);
 }
 
 extern "C" int sb_signal_stats(const float* est, const float* gt, const float* mix, int B, int64_t N, int64_t mix_stride,

@@ -8,6 +8,7 @@
 // "position on the k-lanes".  Instead of 4-byte loads, gate columns / hidden units are assigned to MFMA tiles
 // as  gate = 64*w + 4*i + tile  (unit = 4*i + tile), so ONE 16-byte load per lane per position yields the
 // operand of four tiles at once (4 x 256 B contiguous per wave-instruction instead of 16 x 64 B).
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -1202,6 +1203,19 @@ SideStream* side_stream(hipStream_t main_st) {       // data path: look-up only
   SideStream* t = side_lookup_locked(dev, main_st);
   return (t && t->ok && t->s) ? t : nullptr;
 }
+// Measurement aid (sb_overlap_time_next_side_launch): caller-owned events recorded on the side stream straight in front of and
+// behind the NEXT kernel an overlapped entry point places there -- the only way to time such a launch with HIP events on the
+// stream it runs on (bench.py's live roofline; the caller's own stream never sees it).  One-shot, process-wide, data-path cost
+// when disarmed: one relaxed load.
+std::atomic<int> g_side_timer_armed{0};
+hipEvent_t g_side_timer_ev[2] = {nullptr, nullptr};
+inline void side_timer_mark(hipStream_t side, int which) {
+  if (!g_side_timer_armed.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  if (!g_side_timer_armed.load(std::memory_order_relaxed) || !g_side_timer_ev[which]) return;
+  (void)hipEventRecord(g_side_timer_ev[which], side);
+  if (which == 1) { g_side_timer_armed.store(0, std::memory_order_relaxed); g_side_timer_ev[0] = g_side_timer_ev[1] = nullptr; }
+}
 // the timed pair: `a` on the caller's stream, `b` on `side` (fork / join choreography of the real calls) or, with
 // side == nullptr, behind `a` on the caller's stream.  ms, or < 0 on error.  Synchronises the caller's stream.
 float probe_timed(hipStream_t main_st, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipEvent_t e0, hipEvent_t e1,
@@ -1295,6 +1309,23 @@ extern "C" int sb_overlap_reprobe(void* stream, float* scratch, float* timings_m
   return t->ok ? 1 : 0;
 }
 
+// Measurement aid: make the overlapped entry points take their overlapped code paths on `stream` WHATEVER the timed probe said
+// -- under `rocprofv3 --pmc` every dispatch is serialised, the probe fails and the shipped kernels (cross-pass producer /
+// consumer, ordered forward consumer, slab pair) would never be seen by the counters.  Serialised, they still complete: every
+// producer is enqueued in front of its consumers, whose waits are bounded (watchdog word).  Creates the side stream if the
+// probe left none.  1 on success.  Never used by the product.
+extern "C" int sb_overlap_force(void* stream) {
+  hipStream_t main_st = (hipStream_t)stream;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1009;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream* t = side_lookup_locked(dev, main_st);
+  if (!t || !t->fork || !t->join || !t->dfork || !t->djoin) return 0;          // sb_overlap_init first
+  if (!t->s && hipStreamCreateWithFlags(&t->s, hipStreamNonBlocking) != hipSuccess) { t->s = nullptr; return 0; }
+  t->ok = true;
+  return 1;
+}
+
 extern "C" int sb_overlap_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_side_mu);
   for (int i = 0; i < g_nside; ++i) {
@@ -1335,6 +1366,14 @@ extern "C" int sb_overlap_join(void* stream) {
   if (!t || !t->s || !t->djoin) return 0;              // (also when the probe has since failed: pending work is still joined)
   if (hipEventRecord(t->djoin, t->s) != hipSuccess || hipStreamWaitEvent(main_st, t->djoin, 0) != hipSuccess) return -1009;
   return 0;
+}
+
+extern "C" int sb_overlap_time_next_side_launch(void* ev_start, void* ev_stop) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  const int was_armed = g_side_timer_armed.load(std::memory_order_relaxed);
+  g_side_timer_ev[0] = (hipEvent_t)ev_start; g_side_timer_ev[1] = (hipEvent_t)ev_stop;
+  g_side_timer_armed.store((ev_start && ev_stop) ? 1 : 0, std::memory_order_relaxed);
+  return was_armed;                                      // 1: the previous timer never fired (no side launch since it was armed)
 }
 
 extern "C" int sb_lstm_overlap_rows(int64_t positions, int nseq) {
@@ -1385,8 +1424,10 @@ static int inter_pair(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args*
   if (!serial) {
     if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
     sa.guard = 1; sa.row_base = 0;
+    side_timer_mark(ss->s, 0);
     if (C == 32) SB_SO(32, ss->s, g1); else SB_SO(16, ss->s, g1);
     SB_CHECK_LAUNCH();
+    side_timer_mark(ss->s, 1);
     if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
   }
   // behind the recurrence on `stream` (all flags up): the same kernel drawing what is left; then the join
@@ -1453,7 +1494,9 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
   if (g1 > 2 * ntiles) g1 = 2 * ntiles;
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
   a.ord_guard = 1; a.ord_grid = g1;
+  side_timer_mark(ss->s, 0);
   int rc = sb_lstm_fwd(&a, ss->s);
+  side_timer_mark(ss->s, 1);
   if (rc) return rc;
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
   // behind the producer on `stream` (all flags up): one workgroup per item, each taking what is left; then the join
@@ -1537,7 +1580,9 @@ extern "C" int sb_lstm_bwd_cross_consume_ex(const sb_lstm_bwd_args* a_in, int* f
   // one that cannot be placed at once starts later and draws fewer items
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
   a.ord_guard = 1; a.ord_grid = g1; a.row_base = 0;
+  side_timer_mark(ss->s, 0);
   int rc = sb_lstm_bwd_rec(&a, ss->s);
+  side_timer_mark(ss->s, 1);
   if (rc) return rc;
   if (hipEventRecord(ss->join, ss->s) != hipSuccess) return -1009;
   // behind the producer on `stream` (every flag up): the same kernel taking what is left; then the join

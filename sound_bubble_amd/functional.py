@@ -718,81 +718,44 @@ class FilmFn(torch.autograd.Function):
 
 class FilmBankFn(torch.autograd.Function):
     """All FiLM scale / shift planes of a forward pass in one autograd node (dis_embd3/tfgridnet_causal.py:150-173,
-    51-68, 509-513): e = LN_4(view(W_e . dis_embed, [B, F, 4])), plane[k, which] = e . W[k, which]^T + b[k, which] for
-    the n = n_layers - 1 FiLM layers (which = 0 scale, 1 shift).  A few hundred KB of arithmetic, done with a handful of
-    batched torch ops instead of 2 Linear calls per layer forward and ~16 tiny launches per layer backward; the
-    parameter gradients are added into the flat gradient bucket with ONE add when the 4n Conv1d(4 -> C, k = 1)
-    parameters sit back to back in it (train.FlatBucket), through autograd otherwise.
-    forward(dis_embed [B, 3], W_e [4F, 3], ln_w [4], ln_b [4], bank, *[w.weight, w.bias, b.weight, b.bias] * n)
+    51-68, 509-513): e = LN_d(view(W_e . dis_embed, [B, F, d])), plane[k, which] = e . W[k, which]^T + b[k, which] for
+    the n = n_layers - 1 FiLM layers (which = 0 scale, 1 shift).  ONE HIP launch forward (sb_film_bank_fwd), two backward
+    (sb_film_bank_bwd: one workgroup per frequency bin, partial rows reduced in fixed order), the parameter gradients
+    accumulated straight into their targets (the flat bucket under train.FlatBucket; fresh tensors handed to autograd
+    otherwise).  Round 4 did this with rocBLAS / ATen (mm, layer_norm, baddbmm, bmm, native_layer_norm_backward: ~30 launches).
+    forward(dis_embed [B, 3], W_e [dF, 3], ln_w [d], ln_b [d], bank, *[w.weight, w.bias, b.weight, b.bias] * n)
       -> 2n tensors [B, F, C]: (scale_0, shift_0, scale_1, ...), slices of one buffer."""
 
     @staticmethod
     def forward(ctx, dis, W_e, ln_w, ln_b, bank, *conv):
         n = len(conv) // 4
-        B = dis.shape[0]
-        d_in = ln_w.shape[0]
-        F_ = W_e.shape[0] // d_in
-        Cc = conv[0].shape[0]
-        E0 = torch.mm(dis.float(), W_e.t()).view(B * F_, d_in)
-        e = torch.nn.functional.layer_norm(E0, (d_in,), ln_w, ln_b, 1e-5)
-        Wall = torch.stack([conv[4 * k + 2 * wh].reshape(Cc, d_in) for k in range(n) for wh in range(2)])      # [2n, C, 4]
-        ball = torch.stack([conv[4 * k + 2 * wh + 1] for k in range(n) for wh in range(2)])                    # [2n, C]
-        planes = torch.baddbmm(ball[:, None, :], e.unsqueeze(0).expand(2 * n, -1, -1), Wall.transpose(1, 2))   # [2n, BF, C]
-        ctx.save_for_backward(dis, W_e, ln_w, ln_b, E0, e, Wall, *conv)
-        ctx.dims = (n, B, F_, Cc, d_in)
+        dis = dis.float().contiguous()
+        planes = ops.film_bank_fwd(dis, W_e, ln_w, ln_b, conv)
+        ctx.save_for_backward(dis, W_e, ln_w, ln_b, *conv)
         ctx.bank = bank
-        planes = planes.view(2 * n, B, F_, Cc)
         return tuple(planes[i] for i in range(2 * n))
 
     @staticmethod
     def backward(ctx, *gs):
-        dis, W_e, ln_w, ln_b, E0, e, Wall, *conv = ctx.saved_tensors
-        n, B, F_, Cc, d_in = ctx.dims
+        dis, W_e, ln_w, ln_b, *conv = ctx.saved_tensors
+        n = len(conv) // 4
+        B, F_, Cc = dis.shape[0], W_e.shape[0] // ln_w.shape[0], conv[0].shape[0]
         G = ctx.bank.get("G") if ctx.bank is not None else None
         nb = B * F_ * Cc * 4
         if G is None or any(g is None or g.data_ptr() != G.data_ptr() + i * nb for i, g in enumerate(gs)):
-            G = torch.stack([g if g is not None else torch.zeros(B, F_, Cc, device=e.device) for g in gs])
+            G = torch.stack([g if g is not None else torch.zeros(B, F_, Cc, device=dis.device) for g in gs])
         if ctx.bank is not None:
             ctx.bank["G"] = None
-        G = G.reshape(2 * n, B * F_, Cc)
-        dball = G.sum(1)                                                        # [2n, C]
-        dWall = torch.bmm(G.transpose(1, 2), e.unsqueeze(0).expand(2 * n, -1, -1))      # [2n, C, 4]
-        de = torch.bmm(G, Wall).sum(0)                                          # [BF, 4]
-        dE0, dlw, dlb = torch.ops.aten.native_layer_norm_backward(
-            de, E0, [d_in], *_ln_stats(E0, d_in), ln_w, ln_b, [True, True, True])
-        dW_e = torch.mm(dE0.view(B, F_ * d_in).t(), dis.float())               # [4F, 3]
-        # parameter gradients: one add into the flat bucket when the conv parameters are adjacent there
-        region = _adjacent_grad_region(conv)
-        if region is not None:
-            region.add_(torch.cat([dWall.reshape(2 * n, Cc * d_in), dball], 1).reshape(-1))
-            cg = [None] * (4 * n)
-        else:
-            cg = []
-            for k in range(n):
-                for wh in range(2):
-                    cg += [dWall[2 * k + wh].reshape(conv[4 * k + 2 * wh].shape), dball[2 * k + wh]]
-        return (None, dW_e, dlw, dlb, None, *cg)
-
-
-def _ln_stats(x, d):
-    mean = x.mean(-1, keepdim=True)
-    rstd = torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
-    return mean, rstd
-
-
-def _adjacent_grad_region(params):
-    """flat view over the .grad buffers of `params` when they are FlatBucket views lying back to back (in this order)"""
-    if not params or not all(getattr(p, "_sb_flat_grad", False) and p.grad is not None and p.requires_grad for p in params):
-        return None
-    g0 = params[0].grad
-    off, total = g0.data_ptr(), 0
-    for p in params:
-        g = p.grad
-        if g.data_ptr() != off or not g.is_contiguous() or g.dtype != torch.float32:
-            return None
-        off += g.numel() * 4
-        total += g.numel()
-    return torch.as_strided(g0, (total,), (1,), g0.storage_offset())
+        gt = _GradTargets()
+        need = ctx.needs_input_grad
+        def tgt(name, p, wanted):
+            return gt(name, p) if wanted else torch.zeros_like(p)       # (a frozen parameter: the sums go nowhere)
+        dW_e, dlw, dlb = tgt("W_e", W_e, need[1]), tgt("ln_w", ln_w, need[2]), tgt("ln_b", ln_b, need[3])
+        d_conv = [tgt(f"c{i}", p, need[5 + i]) for i, p in enumerate(conv)]
+        ops.film_bank_bwd(G.contiguous(), dis, W_e, ln_w, ln_b, conv, dW_e, dlw, dlb, d_conv)
+        ret = lambda name, wanted: gt[name] if wanted else None
+        return (None, ret("W_e", need[1]), ret("ln_w", need[2]), ret("ln_b", need[3]), None,
+                *[ret(f"c{i}", need[5 + i]) for i in range(len(conv))])
 
 
 # GEMM forms of the fixed STFT / iSTFT filter banks (module buffers, never trained): built once per (tensor, version)
@@ -978,16 +941,16 @@ class BackEndFn(torch.autograd.Function):
 
 
 class SnrlpLossFn(torch.autograd.Function):
-    """mean_b SNRLPLoss(est, gt)[b]  -- src/losses/SNRLP.py:17-42 + hl_module:321 (.mean())."""
+    """mean_b SNRLPLoss(est, gt)[b]  -- src/losses/SNRLP.py:17-42 + hl_module:321 (.mean()); mode = ops.SNR_LOSS_MODES[name]"""
 
     @staticmethod
-    def forward(ctx, est, gt, neg_weight):
+    def forward(ctx, est, gt, neg_weight, mode=0):
         if est.shape != gt.shape:
             raise ValueError(f"SNRLP: estimate {tuple(est.shape)} and target {tuple(gt.shape)} differ in shape")
         B = est.shape[0]
         e = est.reshape(B, -1).contiguous()
         t = gt.reshape(B, -1).contiguous()
-        lv, dest = ops.snrlp_loss(e, t, neg_weight, want_grad=ctx.needs_input_grad[0])
+        lv, dest = ops.snrlp_loss(e, t, neg_weight, want_grad=ctx.needs_input_grad[0], mode=mode)
         ctx.save_for_backward(dest)
         ctx.shape = est.shape
         ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
@@ -997,7 +960,7 @@ class SnrlpLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, _glv):
         (dest,) = ctx.saved_tensors
-        return (dest * gout).view(ctx.shape), None, None
+        return (dest * gout).view(ctx.shape), None, None, None
 
 
 class MultiResoFuseLossFn(torch.autograd.Function):

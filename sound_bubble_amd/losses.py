@@ -8,18 +8,22 @@ from .functional import MultiResoFuseLossFn, SnrlpLossFn
 
 
 class SNRLPLoss(nn.Module):
-    """src/losses/SNRLP.py:9-42 with snr_loss_name='snr' (the only name the shipped configs use).
+    """src/losses/SNRLP.py:9-42.  snr_loss_name: every name of src/losses/SNRLosses.py:10-29 -- 'snr' (all shipped
+    configs), 'sisdr', 'fused', 'max_fused', 'sdsdr', 'full' (each term asteroid's SingleSrcNegSDR, third-party, restated);
+    anything else raises, as the reference's assert does.
     forward(est, gt) -> per-sample loss vector [B] (the harness takes .mean(), hl_module:321).
     `.mean_loss(est, gt)` returns the differentiable batch mean computed by the fused HIP kernel."""
 
     def __init__(self, snr_loss_name="snr", neg_weight=1):
         super().__init__()
-        if snr_loss_name != "snr":
-            raise NotImplementedError("only snr_loss_name='snr' (every shipped pre-train config) is built")
+        from . import ops
+        if snr_loss_name not in ops.SNR_LOSS_MODES:
+            raise ValueError(f"Invalid loss function used: Loss {snr_loss_name} not found")
+        self.snr_loss_name, self.mode = snr_loss_name, ops.SNR_LOSS_MODES[snr_loss_name]
         self.neg_weight = float(neg_weight)
 
     def mean_loss(self, est, gt):
-        return SnrlpLossFn.apply(est, gt, self.neg_weight)        # (mean, per-sample vector)
+        return SnrlpLossFn.apply(est, gt, self.neg_weight, self.mode)        # (mean, per-sample vector)
 
     def forward(self, est, gt, **kwargs):
         return self.mean_loss(est, gt)[1]

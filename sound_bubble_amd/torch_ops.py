@@ -323,18 +323,18 @@ separate.register_autograd(_separate_bwd, setup_context=_separate_setup)
 
 # ---- losses ----
 @torch.library.custom_op("sound_bubble::snrlp_loss", mutates_args=(), device_types="cuda")
-def snrlp_loss(est: Tensor, gt: Tensor, neg_weight: float) -> Tuple[Tensor, Tensor, Tensor]:
+def snrlp_loss(est: Tensor, gt: Tensor, neg_weight: float, mode: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
     """(batch-mean loss, per-utterance loss vector, d loss / d est) -- src/losses/SNRLP.py:17-42; the fused kernel forms the
-    gradient in the same two passes (csrc/sb_elementwise.hip)"""
+    gradient in the same two passes (csrc/sb_elementwise.hip); mode = ops.SNR_LOSS_MODES[snr_loss_name] (0: 'snr')"""
     with _record_autograd(), torch.enable_grad():
         e = est.detach().requires_grad_(True)
-        loss, lv = Fn.SnrlpLossFn.apply(e, gt, neg_weight)
+        loss, lv = Fn.SnrlpLossFn.apply(e, gt, neg_weight, mode)
         (g,) = torch.autograd.grad(loss, e)
     return loss.detach(), lv.detach(), g
 
 
 @snrlp_loss.register_fake
-def _(est, gt, neg_weight):
+def _(est, gt, neg_weight, mode=0):
     return est.new_empty(()), est.new_empty((est.shape[0],)), torch.empty_like(est)
 
 
@@ -345,7 +345,7 @@ def _snrlp_setup(ctx, inputs, output):
 
 def _snrlp_bwd(ctx, g_loss, g_lv, g_d):
     (d,) = ctx.saved_tensors
-    return (d * g_loss if g_loss is not None else None), None, None
+    return ((d * g_loss if g_loss is not None else None), None, None, None)[:len(ctx.needs_input_grad)]
 
 
 snrlp_loss.register_autograd(_snrlp_bwd, setup_context=_snrlp_setup)

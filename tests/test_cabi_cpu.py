@@ -31,7 +31,8 @@ def test_struct_layouts_match_header(tmp_path):
     from sound_bubble_amd import _lib
     pairs = {"sb_lstm_fwd_args": _lib.LstmFwdArgs, "sb_lstm_bwd_args": _lib.LstmBwdArgs, "sb_linear_args": _lib.LinearArgs,
              "sb_wgrad_args": _lib.WgradArgs, "sb_lstm_stream_args": _lib.LstmStreamArgs, "sb_ln_bwd_args": _lib.LnBwdArgs,
-             "sb_attn_args": _lib.AttnArgs, "sb_attn_bwd_args": _lib.AttnBwdArgs, "sb_multi_copy_args": _lib.MultiCopyArgs}
+             "sb_attn_args": _lib.AttnArgs, "sb_attn_bwd_args": _lib.AttnBwdArgs, "sb_multi_copy_args": _lib.MultiCopyArgs,
+             "sb_film_bank_args": _lib.FilmBankArgs}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "sound_bubble_hip.h"', "int main(void) {"]
     want = []
     for cname, cls in pairs.items():

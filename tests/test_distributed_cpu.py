@@ -220,6 +220,28 @@ def test_bench_launcher_starts_n_ranks_from_the_plain_command():
     assert len({d["pid"] for d in line["rccl"]["devices"]}) == 2
 
 
+def test_bench_launcher_eight_ranks_is_the_configs3_job():
+    """BASELINE configs[3] as the driver will launch it (`bench.py --gpus 8`): eight ranks form ONE process group, every rank
+    draws its own slice of the global batch of 128 (distinct seeds), the three radii cycle inside every slice, and rank 0
+    alone prints -- checked here over gloo on CPU (VERDICT r4 #6a); the 8-GPU node itself is the driver's."""
+    import json
+    r = _run_bench(["--gpus", "8", "--launch-check"], {"SB_FORCE_DEVICE": "cpu", "SB_DIST_BACKEND": "gloo",
+                                                        "OMP_NUM_THREADS": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                      # one JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["rccl"]["world"] == 8
+    assert sorted(d["rank"] for d in line["rccl"]["devices"]) == list(range(8))
+    assert len({d["pid"] for d in line["rccl"]["devices"]}) == 8
+    plans = sorted(line["plans"], key=lambda p: p["rank"])
+    assert [p["rank"] for p in plans] == list(range(8))
+    assert len({p["seed"] for p in plans}) == 8                 # every rank its own slice of the synthetic set
+    assert all(p["batch_per_gpu"] == 16 and p["global_batch"] == 128 for p in plans)
+    for p in plans:                                             # mixed 1 / 1.5 / 2 m radii inside every rank's slice
+        assert sorted(set(p["radius_columns"])) == [0, 1, 2] and p["radius_columns"][:4] == [0, 1, 2, 0]
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     """no silent single-rank measurement under a multi-GPU flag: with fewer visible GPUs than --gpus the command exits
     non-zero and prints no bench line"""

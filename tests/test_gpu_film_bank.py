@@ -1,0 +1,91 @@
+"""sb_film_bank_fwd / sb_film_bank_bwd (the distance embedding -> FiLM plane bank of every layer in one launch forward, two
+backward) against the straightforward per-layer autograd formulation of the reference (Dis_Embed_Conv + the FilmLayer 1x1
+convolutions, dis_embd3/tfgridnet_causal.py:51-68,150-173) evaluated with stock torch ops in float64."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(torch, n, B, F, C, d_in, seed):
+    g = torch.Generator().manual_seed(seed)
+    dis = torch.eye(3)[torch.randint(0, 3, (B,), generator=g)]
+    W_e = torch.randn(F * d_in, 3, generator=g)
+    lw, lb = torch.rand(d_in, generator=g) + 0.5, torch.randn(d_in, generator=g)
+    conv = []
+    for _ in range(n):
+        conv += [torch.randn(C, d_in, 1, generator=g), torch.randn(C, generator=g),
+                 torch.randn(C, d_in, 1, generator=g), torch.randn(C, generator=g)]
+    coef = [torch.randn(B, F, C, generator=g) for _ in range(2 * n)]
+    return dis, W_e, lw, lb, conv, coef
+
+
+def _reference(torch, dis, W_e, lw, lb, conv, coef):
+    import torch.nn.functional as tF
+    ps = [t.double().requires_grad_(True) for t in (W_e, lw, lb, *conv)]
+    W, w, b, cv = ps[0], ps[1], ps[2], ps[3:]
+    B, d_in = dis.shape[0], lw.shape[0]
+    e = tF.layer_norm(tF.linear(dis.double(), W).view(B, -1, d_in), (d_in,), w, b, 1e-5)
+    planes = []
+    for k in range(len(cv) // 4):
+        planes.append(tF.linear(e, cv[4 * k][:, :, 0], cv[4 * k + 1]))
+        planes.append(tF.linear(e, cv[4 * k + 2][:, :, 0], cv[4 * k + 3]))
+    sum((p * c.double()).sum() for p, c in zip(planes, coef)).backward()
+    return planes, [p.grad for p in ps]
+
+
+@pytest.mark.parametrize("n,B,F,C,d_in", [(5, 16, 145, 32, 4), (1, 2, 145, 16, 4), (3, 70, 9, 32, 4), (2, 3, 7, 16, 1),
+                                          (2, 5, 11, 32, 2), (16, 4, 13, 32, 8)])
+def test_film_bank_matches_per_layer_autograd(n, B, F, C, d_in):
+    import torch
+    from sound_bubble_amd.functional import FilmBankFn
+    dis, W_e, lw, lb, conv, coef = _setup(torch, n, B, F, C, d_in, seed=n + B)
+    planes_ref, want = _reference(torch, dis, W_e, lw, lb, conv, coef)
+    ps = [t.cuda().requires_grad_(True) for t in (W_e, lw, lb, *conv)]
+    bank = {"n": n, "G": None}
+    planes = FilmBankFn.apply(dis.cuda(), ps[0], ps[1], ps[2], bank, *ps[3:])
+    assert len(planes) == 2 * n and planes[1].data_ptr() == planes[0].data_ptr() + 4 * B * F * C       # slices of one buffer
+    for a, b in zip(planes, planes_ref):
+        assert torch.allclose(a.cpu().double(), b, atol=2e-5, rtol=2e-5)
+    sum((p * c.cuda()).sum() for p, c in zip(planes, coef)).backward()
+    for t, w in zip(ps, want):
+        assert t.grad is not None and t.grad.shape == t.shape
+        err = float((t.grad.cpu().double() - w).norm() / max(float(w.norm()), 1e-30)) if float(w.norm()) > 0 \
+            else float(t.grad.abs().max())
+        assert err < 2e-5, (tuple(t.shape), err)
+
+
+def test_film_bank_accumulates_into_flat_bucket_targets_and_is_deterministic():
+    """with train.FlatBucket the reductions add straight into the parameters' .grad views (autograd is handed None); a second
+    backward accumulates (x 2); fixed summation order: two runs agree to the bit"""
+    import torch
+    from sound_bubble_amd.functional import FilmBankFn
+    from sound_bubble_amd.train import FlatBucket
+    n, B, F, C, d_in = 5, 16, 145, 32, 4
+    dis, W_e, lw, lb, conv, coef = _setup(torch, n, B, F, C, d_in, seed=1)
+    _, want = _reference(torch, dis, W_e, lw, lb, conv, coef)
+    holder = torch.nn.Module()
+    params = [torch.nn.Parameter(t.clone()) for t in (W_e, lw, lb, *conv)]
+    for i, p in enumerate(params):
+        holder.register_parameter(f"p{i}", p)
+    holder.cuda()
+    params = list(holder.parameters())
+    bucket = FlatBucket(holder)
+    runs = []
+    for _ in range(2):
+        bucket.zero_grad()
+        for rep in (1, 2):
+            planes = FilmBankFn.apply(dis.cuda(), params[0], params[1], params[2], {"n": n, "G": None}, *params[3:])
+            sum((p * c.cuda()).sum() for p, c in zip(planes, coef)).backward()
+            for p, w in zip(params, want):
+                assert p.grad.data_ptr() >= bucket.grad.data_ptr()
+                assert float((p.grad.cpu().double() - rep * w).norm()) <= 3e-5 * max(float(w.norm()), 1e-30) * rep
+        runs.append(bucket.grad.clone())
+    assert torch.equal(runs[0], runs[1])
+
+
+def test_film_bank_refuses_what_it_cannot_hold():
+    import torch
+    from sound_bubble_amd import _lib, ops
+    dis, W_e, lw, lb, conv, _ = _setup(torch, 17, 2, 5, 32, 4, seed=0)
+    with pytest.raises(_lib.SoundBubbleHipError):
+        ops.film_bank_fwd(dis.cuda(), W_e.cuda(), lw.cuda(), lb.cuda(), [c.cuda() for c in conv])
