@@ -26,6 +26,18 @@ extern "C" {
 
 #define SB_H 64 /* LSTM hidden size the recurrent kernels are built for */
 
+/* The watchdog word (sched_status) after a bounded wait gave up:  site << 28 | index << 14 | seen << 7 | wanted  (index: tile /
+   slab the wait was for, seen / wanted: the flag's value and the value waited for, both mod 128).  Only the FIRST wait to give up
+   writes; decode with sound_bubble_amd.ops.decode_trip. */
+enum {
+  SB_TRIP_FWD_SEGMENT = 1,    /* time-segmented forward: the previous segment of the tile never published its state */
+  SB_TRIP_FWD_CONSUMER = 2,   /* overlapped forward, intra-frame consumer: the producer's time slab never completed */
+  SB_TRIP_BWD_SEGMENT = 3,    /* time-segmented backward recurrence */
+  SB_TRIP_BWD_STREAM = 4,     /* overlapped inter-frame backward, stream kernel: the recurrence's dgates slab never completed */
+  SB_TRIP_CROSS_SLABS = 5,    /* cross-pass backward, consumer: a producer tile never reached the slab count waited for */
+  SB_TRIP_CROSS_ROWS = 6      /* cross-pass backward, consumer: the owner of a tile's prologue rows never raised `done` */
+};
+
 /* ---- recurrent LSTM (forward) -------------------------------------------
  * Replaces LayerNorm(C) + nn.LSTM forward of
  *   intra: dis_embd3/tfgridnet_causal.py:819-823 (plain), :804-808 (conv-LSTM)
@@ -80,7 +92,7 @@ typedef struct {
   /* Time-segmented scheduling needs its `sched_workers` workgroups co-resident (one per CU): a segment waits for the
      state its predecessor publishes.  sched_status (one int, zeroed once by the caller and then left alone; REQUIRED for
      the segmented schedule, which is otherwise not used) is the watchdog word: a wait that exceeds ~2^22 polls (seconds)
-     sets *sched_status = 1 and every workgroup of the launch (and of later launches that see the word set) bails out
+     sets *sched_status != 0 (a code naming the wait: SB_TRIP_* below) and every workgroup of the launch (and of later launches that see the word set) bails out
      instead of hanging -- the outputs of such a launch are garbage, and the caller must check the word after its next
      synchronisation (sound_bubble_amd.ops.check_sched_status).  sched_workers / sched_segments: 0 = automatic (CU count
      of the device, checked against the kernel's occupancy; segment count minimising the makespan); > 0 overrides them,
@@ -113,6 +125,11 @@ typedef struct {
      products, weights in registers, one barrier per step; sb_lstm_vec.hip): the streaming chunk step's intra-frame pass is ONE
      sequence per direction, for which a 16-sequence MFMA tile pays a 4x longer step.  no_vec != 0 keeps the tile kernels. */
   int no_vec;
+  /* products (mma == 1, inference calls only: no records, no side outputs): 0 / 3 = the default three products per MAC (weights
+     AND activations as fp16 hi + lo, the hi x lo cross terms kept: 22 mantissa bits, fp32-class); 2 = OPT-IN reduced-product
+     mode -- activations as ONE fp16 term against hi + lo weights, two products per MAC (11-bit activations: NOT fp32-class; the
+     bench reports its rel-L2 against the default beside its speed).  -1003 with records / side outputs requested. */
+  int products;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Stress the train_cli epoch loop (train steps with their one D2H each, a validation pass, on_epoch_end) on CACHED batches of the
+overfit experiment, counting watchdog trips (ops.LAST_TRIPS says which bounded wait gave up) and non-finite losses.
+usage: stress_train_loop.py [--epochs N] [--sleep MS] [--batch B] [--loader]
+  --sleep MS   random host sleep in [0, MS] ms in front of every step (the GPU idles between steps as it does behind a slow loader)
+  --loader     the real DataLoader of train_cli instead of cached batches"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sound_bubble_amd import ops                                 # noqa: E402
+from sound_bubble_amd.harness import import_attr                 # noqa: E402
+from sound_bubble_amd.train_cli import seed_all, to_device, make_loaders       # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--epochs", type=int, default=200)
+ap.add_argument("--sleep", type=float, default=0.0)
+ap.add_argument("--batch", type=int, default=0)
+ap.add_argument("--loader", action="store_true")
+ap.add_argument("--no-val", action="store_true")
+args = ap.parse_args()
+params = json.load(open(os.path.join(ROOT, "experiments", "overfit_test_samples.json")))
+if args.batch:
+    params["batch_size"] = params["eval_batch_size"] = args.batch
+seed_all(0)
+mk = lambda key, split: import_attr(params[f"{key}_dataset"])(**params[f"{key}_data_args"], split=split)
+train_loader, test_loader = make_loaders(mk("train", "train"), mk("val", "val"), params, 1, 0)
+hl = import_attr(params["pl_module"])(**params["pl_module_args"])
+dev = torch.device("cuda")
+if not args.loader:
+    train_batches = [b for b in train_loader]
+    val_batches = [b for b in test_loader]
+trips, nans, steps = 0, 0, 0
+t00 = time.time()
+for epoch in range(args.epochs):
+    seed_all(epoch)
+    hl.train()
+    it = train_loader if args.loader else random.sample(train_batches, len(train_batches))
+    for idx, batch in enumerate(it):
+        if args.sleep:
+            time.sleep(random.random() * args.sleep * 1e-3)
+        batch = to_device(batch, dev)
+        hl.reset_grad()
+        loss, B = hl.training_step(batch, idx)
+        loss.backward()
+        hl.backprop()
+        l = float(loss.detach())
+        steps += 1
+        if l != l:
+            nans += 1
+    hl.eval()
+    if not args.no_val:
+        with torch.no_grad():
+            for idx, batch in enumerate(test_loader if args.loader else val_batches):
+                vl, _ = hl.validation_step(to_device(batch, dev), idx)
+    try:
+        hl.on_epoch_end(os.devnull, None)
+    except Exception as e:
+        trips += 1
+        print(f"epoch {epoch}: TRIP {ops.LAST_TRIPS[-1:]} counts {ops.SCHED_COUNTS} loss {l}", flush=True)
+        hl.epoch += 1
+    if epoch % 50 == 0:
+        print(epoch, f"loss {l:.4f} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s", flush=True)
+print(f"DONE epochs {args.epochs} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s args {vars(args)}")

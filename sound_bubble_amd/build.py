@@ -27,6 +27,10 @@ def _stale(target, deps):
 # variants of a kernel (e.g. the time-segmented and the plain schedule) round identically -- bit-exact outputs.
 _BF_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffp-contract=off"]
 PER_FILE_FLAGS = {"sb_lstm_bf_fwd.hip": _BF_FLAGS, "sb_lstm_bf_bwd.hip": _BF_FLAGS}
+# translation units built a second time with another macro set: (source, object stem, extra flags).  The opt-in two-product
+# forward (sb_lstm_fwd_args.products == 2) is the forward file again with -DSB_FWD_2P: its inference kernels only, launcher
+# sb_launch_lstm_fwd_bf_2p.
+EXTRA_UNITS = [("sb_lstm_bf_fwd.hip", "sb_lstm_bf_fwd_2p", _BF_FLAGS + ["-DSB_FWD_2P"])]
 
 
 def build(force=False, verbose=True):
@@ -41,6 +45,15 @@ def build(force=False, verbose=True):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
             cmd[2:2] = os.environ.get("SB_EXTRA_HIPCC_FLAGS", "").split()     # e.g. -DSB_PHASE_TIMING (dev tool)
             cmd[2:2] = PER_FILE_FLAGS.get(src, [])
+            jobs.append(cmd)
+    for src, stem, flags in EXTRA_UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, stem + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
+            cmd[2:2] = os.environ.get("SB_EXTRA_HIPCC_FLAGS", "").split()
+            cmd[2:2] = flags
             jobs.append(cmd)
     if jobs:                                   # translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor

@@ -20,6 +20,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SB_DEVINL __device__ __forceinline__
 
+// Watchdog word of the guarded schedules (sb_*_args.sched_status): 0 = fine.  The FIRST bounded wait that gives up leaves a
+// code saying which one it was -- site << 28 | index << 14 | value seen << 7 | value wanted (include/sound_bubble_hip.h:
+// SB_TRIP_*) -- every later waiter finds the word set and leaves without touching it.
+SB_DEVINL void sb_trip(int* status, int site, int index, int seen, int want) {
+  int expected = 0;
+  const int code = (site << 28) | ((index & 0x3FFF) << 14) | ((seen & 0x7F) << 7) | (want & 0x7F);
+  __hip_atomic_compare_exchange_strong(status, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 SB_DEVINL f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -21,6 +21,7 @@
 
 // bf16 split-product variants (sb_lstm_bf.hip)
 int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a, hipStream_t st);
+int sb_launch_lstm_fwd_bf_2p(const sb_lstm_fwd_args& a, hipStream_t st);         // the same TU built with -DSB_FWD_2P (two products per MAC)
 bool sb_lstm_fwd_vec_ok(const sb_lstm_fwd_args& a);                         // sb_lstm_vec.hip: a handful of sequences, inference
 int sb_launch_lstm_fwd_vec(const sb_lstm_fwd_args& a, hipStream_t st);
 int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a, hipStream_t st);
@@ -357,7 +358,9 @@ extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
     SB_CHECK_LAUNCH();
     return 0;
   }
-  if (a->mma == 1 || a->mma == 2) { const int rc = sb_launch_lstm_fwd_bf(*a, (hipStream_t)stream); if (rc) return rc; }
+  if (a->products != 0 && a->products != 3 && !(a->products == 2 && a->mma == 1)) return -1003;
+  if (a->mma == 1 && a->products == 2) { const int rc = sb_launch_lstm_fwd_bf_2p(*a, (hipStream_t)stream); if (rc) return rc; }
+  else if (a->mma == 1 || a->mma == 2) { const int rc = sb_launch_lstm_fwd_bf(*a, (hipStream_t)stream); if (rc) return rc; }
   else if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);
   else launch_fwd<16>(*a, grid, (hipStream_t)stream);
   SB_CHECK_LAUNCH();

@@ -135,7 +135,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
           ++spins;
           if ((spins & 63u) == 0 &&
               (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            __hip_atomic_store(a.sched_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sb_trip(a.sched_status, SB_TRIP_CROSS_SLABS, t, __hip_atomic_load(a.slab_flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), need);
             bad = 1;
             break;
           }
@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         ++spins;
         if ((spins & 63u) == 0 &&
             (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          __hip_atomic_store(a.sched_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sb_trip(a.sched_status, SB_TRIP_CROSS_ROWS, t, __hip_atomic_load(pst + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1 + xcd);
           bad = 1;
           break;
         }
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         dhrec = zero4();
         if constexpr (SEG) {
           if (seg > 0) {
-            if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return;
+            if (!seg_wait(a.seg_flags, tile, seg, a.sched_status, SB_TRIP_BWD_SEGMENT)) return;
             const float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       if constexpr (CONS) {
         if (!prologue(item, tile, std::true_type{})) return;
       }
-      if constexpr (SEG) { if (seg > 0) { if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return; } }
+      if constexpr (SEG) { if (seg > 0) { if (!seg_wait(a.seg_flags, tile, seg, a.sched_status, SB_TRIP_BWD_SEGMENT)) return; } }
       if constexpr (LINW && !HREC) { if (s_hi == S - 1) lin_top(); }
       if constexpr (STG) stage_issue(s_hi, s_hi - 1 >= s_lo, 1, tile);     // the first chunk's rows: read in period 1 (buffer 1)
       __syncthreads();
@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     if constexpr (SEG) {
       float* st = a.seg_state + ((size_t)tile * 2 * 16 + j) * H + uoff;
       if (seg > 0) {                                   // see the forward kernel for the hand-off protocol
-        if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return;
+        if (!seg_wait(a.seg_flags, tile, seg, a.sched_status, SB_TRIP_BWD_SEGMENT)) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           dc[r] = __hip_atomic_load(st + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

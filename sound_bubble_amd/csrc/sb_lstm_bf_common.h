@@ -130,7 +130,7 @@ SB_DEVINL SplitN<F16> splitn8(const float (&x)[8]) {
 // launch ends with garbage outputs and *status != 0 instead of hanging the process.  Returns false on abort (uniform
 // over the workgroup).
 constexpr unsigned kSegSpinLimit = 1u << 22;
-SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status) {
+SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status, int site) {
   __shared__ int seg_abort;
   if (threadIdx.x == 0) {
     int bad = 0;
@@ -139,7 +139,7 @@ SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status) {
       ++spins;
       if ((spins & 63u) == 0 &&
           (spins > kSegSpinLimit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sb_trip(status, site, tile, __hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), seg);
         bad = 1;
         break;
       }

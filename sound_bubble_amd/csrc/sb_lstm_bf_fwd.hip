@@ -1,5 +1,8 @@
 // Forward recurrence of the LSTM passes on the 16-bit matrix pipes with split fp32 operands (see sb_lstm_bf_common.h for the
 // arithmetic): lstm_fwd_bf_kernel and its launcher.  Backward: sb_lstm_bf_bwd.hip.
+#ifdef SB_FWD_2P
+#undef SB_PHASE_TIMING                                  // (the phase tables belong to the default build of this file)
+#endif
 #include "sb_lstm_bf_common.h"
 
 // Phase timing (developer tool): build with -DSB_PHASE_TIMING and pass a scratch buffer (save_u with save_gates == NULL) --
@@ -470,9 +473,19 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // (second fence: VMEM may not cross either)
   auto mma6 = [&](f32x4 (&acc)[4], int chunk, const vec8 (&b)[NT], int hook = -1, int lnhook = -1) {
     // (weight term, operand term) pairs, smallest products first
+#ifdef SB_FWD_2P
+    // opt-in reduced-product build of this translation unit (sb_lstm_fwd_args.products == 2): activations as ONE fp16 term --
+    // W_lo x_hi + W_hi x_hi, two products per MAC; the low activation terms are still formed and parked in LDS (same code,
+    // same layout) but no product reads them
+    static_assert(F16, "two-product mode: fp16 operands");
+    constexpr int NP = 2;
+    constexpr int WT[6] = {1, 0, 0, 0, 0, 0};
+    constexpr int XT[6] = {0, 0, 0, 0, 0, 0};
+#else
     constexpr int NP = F16 ? 3 : 6;
     constexpr int WT[6] = {F16 ? 1 : 2, F16 ? 0 : 0, F16 ? 0 : 1, 1, 0, 0};
     constexpr int XT[6] = {F16 ? 0 : 0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
+#endif
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
 #pragma unroll
@@ -484,6 +497,9 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       }
       if (lnhook >= 0) {                               // piece lnhook + pi of the stage-2 LayerNorm, pinned behind this group
         ln2_piece(lnhook + pi);
+#ifdef SB_FWD_2P
+        if (pi == NP - 1) ln2_piece(lnhook + pi + 1);  // (three pieces per chunk over two product groups)
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -521,6 +537,9 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     for (int pi = 0; pi < 3; ++pi) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+#ifdef SB_FWD_2P
+        if (pi != 1)                                             // (no W_hi x_lo product; the cell-update piece stays where it is)
+#endif
         accn[g] = PR::mma(Wt[g][0].t[WT[pi]], b[XT[pi]], accn[g]);
         const int r = g;                                         // this piece's unit
         if (pi == 0) {
@@ -567,7 +586,9 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           if (ck == 0) yacc = zero4();
           if constexpr (F16) {
             yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
+#ifndef SB_FWD_2P
             yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
+#endif
             yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
           }
         }
@@ -730,7 +751,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     const int tile = ORD ? a.tile_order[item] : SEG ? item - seg * ntiles : item;
     s_begin = SEG ? seg * a.seg_len : 0;
     const int s_end = SEG ? min(S, s_begin + a.seg_len) : S;
-    if constexpr (ORD) { if (!seg_wait(a.slab_flags, a.tile_need[item], a.slab_need, a.sched_status)) return; }
+    if constexpr (ORD) { if (!seg_wait(a.slab_flags, a.tile_need[item], a.slab_need, a.sched_status, SB_TRIP_FWD_CONSUMER)) return; }
     set_tile(tile);
     // ---- initial state of this item ----
     c = zero4();
@@ -744,7 +765,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       // wait until the previous segment of this tile has published its state.  Flag and state travel as agent-scope
       // (sc1, write-through / cache-bypassing) accesses ordered by s_waitcnt + barrier -- no release / acquire fences:
       // those write back / invalidate the whole L2, which is full of this kernel's own record stores.
-      if (!seg_wait(a.seg_flags, tile, seg, a.sched_status)) return;
+      if (!seg_wait(a.seg_flags, tile, seg, a.sched_status, SB_TRIP_FWD_SEGMENT)) return;
       const float* st = seg_hc + ((size_t)tile * 2 * 16 + j) * H + uoff;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -819,7 +840,9 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           if (ck == 0) yacc = zero4();
           if constexpr (F16) {
             yacc = PR::mma(Wl[ck].t[1], b[0], yacc);
+#ifndef SB_FWD_2P
             yacc = PR::mma(Wl[ck].t[0], b[1], yacc);
+#endif
             yacc = PR::mma(Wl[ck].t[0], b[0], yacc);
           }
         }
@@ -860,6 +883,9 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 
 }  // namespace
 
+#ifdef SB_FWD_2P
+#define sb_launch_lstm_fwd_bf sb_launch_lstm_fwd_bf_2p        // second build of this file: the two-product inference kernels
+#endif
 int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   sb_lstm_fwd_args a = a_in;
   const int ntiles = (a.nseq + 15) / 16;
@@ -872,6 +898,9 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
   if (a.rec_f32 && (!a.save_c || a.aux_f16 || !f16 || (!a.save_gates && (a.ndir != 1 || !a.lin_w || !a.hs)))) return -1003;
   const int save = a.rec_f32 ? 4 : a.save_gates == nullptr ? (a.save_c && a.aux_f16 ? 3 : 0)
                                                            : (a.save_c ? (a.aux_f16 ? 3 : 2) : 1);
+#ifdef SB_FWD_2P
+  if (save != 0 || !f16) return -1003;                         // inference only: records / side outputs keep the default arithmetic
+#endif
   dim3 grid(ntiles, a.ndir);
   const bool lin = a.lin_w != nullptr;
   if (lin && (!f16 || !a.lin_b || !a.y)) return -1003;         // ndir == 2: per-direction partial products (see the kernel)
@@ -905,8 +934,10 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
     dim3 g1(a.ord_grid);
 #define SB_LO(SV, FL) hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, false, false, true>), g1, dim3(256), 0, st, a)
     if (save == 0) { if (full) SB_LO(0, true); else SB_LO(0, false); }
+#ifndef SB_FWD_2P
     else if (save == 4) { if (full) SB_LO(4, true); else SB_LO(4, false); }
     else { if (full) SB_LO(3, true); else SB_LO(3, false); }
+#endif
 #undef SB_LO
     return 0;
   }
@@ -920,11 +951,21 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
     hipLaunchKernelGGL((lstm_fwd_bf_kernel<32, SV, FL, true, true, SG, true>), grid, dim3(256), 0, st, a); } while (0)
 #define SB_L3F(SV) do { if (full) { if (seg) SB_L3(SV, true, true); else SB_L3(SV, true, false); } \
                         else { if (seg) SB_L3(SV, false, true); else SB_L3(SV, false, false); } } while (0)
+#ifdef SB_FWD_2P
+    SB_L3F(0);
+#else
     if (save == 0) SB_L3F(0); else if (save == 4) SB_L3F(4); else SB_L3F(3);
+#endif
 #undef SB_L3F
 #undef SB_L3
     return 0;
   }
+#ifdef SB_FWD_2P
+#define SB_LT(CC, SV, FL) do { \
+    if (seg) { if (lin) SB_L(CC, SV, FL, true, true, true); else SB_L(CC, SV, FL, true, false, true); } \
+    else if (lin) SB_L(CC, SV, FL, true, true, false); else SB_L(CC, SV, FL, true, false, false); } while (0)
+#define SB_LC(CC) do { if (full) SB_LT(CC, 0, true); else SB_LT(CC, 0, false); } while (0)
+#else
 #define SB_LT(CC, SV, FL) do { \
     if (seg) { if (lin) SB_L(CC, SV, FL, true, true, true); else SB_L(CC, SV, FL, true, false, true); } \
     else if (lin) SB_L(CC, SV, FL, true, true, false); else if (f16) SB_L(CC, SV, FL, true, false, false); \
@@ -935,6 +976,7 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
     else if (save == 2) { if (full) SB_LT(CC, 2, true); else SB_LT(CC, 2, false); } \
     else if (save == 4) { if (full) SB_LT(CC, 4, true); else SB_LT(CC, 4, false); } \
     else { if (full) SB_LT(CC, 3, true); else SB_LT(CC, 3, false); } } while (0)
+#endif
   if (a.C == 32) SB_LC(32); else SB_LC(16);
 #undef SB_LC
 #undef SB_LT

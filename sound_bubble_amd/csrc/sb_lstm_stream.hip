@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
         ++spins;
         if ((spins & 63u) == 0 &&
             (spins > (1u << 22) || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          __hip_atomic_store(a.sched_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sb_trip(a.sched_status, SB_TRIP_BWD_STREAM, k, __hip_atomic_load(a.slab_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.slab_need);
           slab_abort = 1;
           break;
         }

@@ -81,6 +81,10 @@ def layer_mode(kind, Cc):
 # recurrent GEMMs: bf16 matrix pipe with exact 3-way split / 6 products (fp32-class) unless SB_LSTM_FP32=1
 # forward operand split: fp16 hi+lo, 3 products (default, 2^-22) or SB_LSTM_BF16X6=1: bf16 3-way, 6 products (2^-24)
 LSTM_MMA = 0 if os.environ.get("SB_LSTM_FP32", "0") == "1" else (2 if os.environ.get("SB_LSTM_BF16X6", "0") == "1" else 1)
+# SB_LSTM_PRODUCTS=2 (opt-in, inference forward only): the recurrent products with ONE fp16 activation term against hi + lo weights
+# -- two products per MAC instead of three, 11-bit activations: NOT fp32-class.  bench.py reports its speed and its distance
+# from the default arithmetic side by side (secondary.forward_*_2prod); nothing else switches it on.
+LSTM_PRODUCTS = int(os.environ.get("SB_LSTM_PRODUCTS", "3"))
 # bench.py: dict  kernel label -> list of (start_event, end_event, algorithmic_flops, compulsory_bytes, design_bytes)
 # per launch of the recurrent kernels, HIP events on the launch stream.  compulsory = SURVEY.md 8(d): 4C in + 4C out per
 # position of a fused pass; design = what this implementation must move (BPTT records, side outputs, dgates).
@@ -217,14 +221,39 @@ def sched_status(dev):
     return t
 
 
+TRIP_SITES = {1: "time-segmented forward: a tile's previous segment never published its state",
+              2: "overlapped forward, intra-frame consumer: the producer's time slab never completed",
+              3: "time-segmented backward recurrence: a tile's previous segment never published its state",
+              4: "overlapped inter-frame backward, stream kernel: the recurrence's dgates slab never completed",
+              5: "cross-pass backward, consumer: a producer tile never reached the slab count waited for",
+              6: "cross-pass backward, consumer: the owner of a tile's prologue rows never raised `done`"}
+LAST_TRIPS = []           # decoded watchdog words read since start-up: (device, dict)
+
+
+def decode_trip(word):
+    """the watchdog word a bounded wait left (include/sound_bubble_hip.h, SB_TRIP_*) -> dict"""
+    word = int(word) & 0xFFFFFFFF
+    site = word >> 28
+    return {"word": word, "site": site, "what": TRIP_SITES.get(site, "unknown site (a pre-round-5 library writes 1)"),
+            "index": (word >> 14) & 0x3FFF, "seen": (word >> 7) & 0x7F, "wanted": word & 0x7F}
+
+
 def read_sched_status():
-    """synchronises; -> list of device indices whose watchdog word was set (and clears those words)"""
+    """synchronises; -> list of device indices whose watchdog word was set (and clears those words; what the words said is
+    appended to LAST_TRIPS)"""
     bad = []
     for i, t in _SCHED_STATUS.items():
-        if int(t.item()) != 0:
+        v = int(t.item())
+        if v != 0:
             t.zero_()
             bad.append(i)
+            LAST_TRIPS.append((i, decode_trip(v)))
     return bad
+
+
+def _trip_text(devs):
+    return "; ".join(f"cuda:{i}: {d['what']} (index {d['index']}, flag {d['seen']} of {d['wanted']} mod 128)"
+                     for i, d in LAST_TRIPS[-len(devs):]) if devs else ""
 
 
 def check_sched_status_all_ranks():
@@ -241,6 +270,7 @@ def check_sched_status_all_ranks():
     if flag:
         raise L.SoundBubbleHipError(
             f"a time-segmented / overlapped LSTM launch aborted on {'this rank (cuda:%s)' % bad if bad else 'another rank'} "
+            f"[{_trip_text(bad)}] "
             "(its workgroups were not co-resident -- GPU shared or CU-masked?).  Results since the last check are invalid; set "
             "SB_NO_TIME_SEGMENTS=1 / SB_NO_FWD_OVERLAP=1 / SB_NO_BWD_OVERLAP=1 or ops.SCHED_OVERRIDE.")
 
@@ -249,10 +279,12 @@ def check_sched_status():
     """Synchronises and raises if a segmented launch gave up waiting for a co-resident workgroup (its outputs are then
     garbage).  Called after the timed region by bench.py, once per epoch by the harness, and by the tests."""
     for i, t in _SCHED_STATUS.items():
-        if int(t.item()) != 0:
+        v = int(t.item())
+        if v != 0:
             t.zero_()
+            LAST_TRIPS.append((i, decode_trip(v)))
             raise L.SoundBubbleHipError(
-                f"cuda:{i}: a time-segmented LSTM launch aborted (its workgroups were not co-resident -- GPU shared or "
+                f"cuda:{i}: a time-segmented / overlapped LSTM launch aborted [{_trip_text([i])}] (its workgroups were not co-resident -- GPU shared or "
                 "CU-masked?).  Results since the last check are invalid; set SB_NO_TIME_SEGMENTS=1 or "
                 "ops.SCHED_OVERRIDE = (guaranteed_resident_workgroups, 0).")
 
@@ -549,6 +581,8 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
     a.aux_f16 = 1 if aux16 else 0
     a.rec_f32 = 1 if wide else 0
     a.no_vec = 0 if VEC_LSTM else 1
+    # opt-in reduced-product forward (inference calls only; never the default, never a training forward: see the header)
+    a.products = 2 if (LSTM_PRODUCTS == 2 and not save and LSTM_MMA == 1) else 0
     a.save_c = C.c_void_p(cprev.data_ptr()) if cprev is not None else None
     a.mma = LSTM_MMA
     if lin is not None:       # ndir == 2: partial mode, y is [P, 2, C] (see the header)
