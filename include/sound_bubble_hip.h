@@ -38,6 +38,19 @@ enum {
   SB_TRIP_CROSS_ROWS = 6      /* cross-pass backward, consumer: the owner of a tile's prologue rows never raised `done` */
 };
 
+/* ---- flag memory of the guarded schedules ----
+ * Every word one workgroup raises and another polls (slab_flags / seg_flags / the flags arrays of the overlapped entry points,
+ * sched_status) should live in memory the per-XCD L2s do not cache: those L2s are not coherent with each other, and a line that a
+ * zero-fill or a poll left resident was seen to serve stale counts (a consumer polling 52 of 82 for seconds while memory held 82).
+ * sb_flags_alloc: `bytes` of such memory on the current device (*kind: 3 = uncached, 1 = fine-grained fallback, 0 = ordinary device
+ * memory as the last resort); sb_flags_zero: n_ints words zeroed on `stream` with write-through stores (the library's own zeroing
+ * of caller flags uses it too); sb_flags_read: n_ints words to the host, synchronising `stream`.  Ordinary device memory still
+ * WORKS for every flags argument (rounds 2-4 ran on it); it carries the hazard above. */
+int sb_flags_alloc(int64_t bytes, void** ptr, int* kind);
+int sb_flags_free(void* ptr);
+int sb_flags_zero(void* ptr, int64_t n_ints, void* stream);
+int sb_flags_read(const void* ptr, int64_t n_ints, int* host_out, void* stream);
+
 /* ---- recurrent LSTM (forward) -------------------------------------------
  * Replaces LayerNorm(C) + nn.LSTM forward of
  *   intra: dis_embd3/tfgridnet_causal.py:819-823 (plain), :804-808 (conv-LSTM)
@@ -108,9 +121,12 @@ typedef struct {
   int* slab_flags; int slab_len, slab_need;
   const int* tile_order; const int* tile_need; int* ord_counter; int* ord_started; int ord_guard, ord_grid;
   /* WIDE BPTT state (mma == 1, save_gates and save_c given, aux_f16 == 0): rec_f32 != 0 keeps the reference's own
-     precision in everything the backward reads -- the gate records are fp32 (save_gates [R, ndir, 4, 64] floats, save_c
-     [R, ndir, 64] floats, R as for the compact records and blocked per (16-sequence tile, step, direction) in the
-     kernels' lane order like them: 1280 B per step and direction, one contiguous KB per store instruction).  The two side
+     precision in everything the backward reads -- save_c [R, ndir, 64] floats (c_prev) and save_gates
+     [R, ndir, sb_lstm_wide_rec_dwords()] dwords: the four post-activation gates, which lie in [0, 1] / [-1, 1], as 24-BIT FIXED
+     POINT (step 2^-24 / 2^-23: as fine as fp32 at the top of that range), four values in three dwords -- 192 dwords per
+     sequence, step and direction (256 = plain fp32 in a -DSB_REC_Q24=0 build); opaque, private to the forward / backward
+     kernel pair.  R as for the compact records, both blocked per (16-sequence tile, step, direction) in the kernels' lane
+     order like them: 1024 B per step and direction, one contiguous KB per store instruction.  The two side
      outputs only the backward kernels read keep their BYTE SIZE (4 bytes per element) but are OPAQUE pair-form buffers, not
      fp32 arrays: save_u [P][2 C halves] holds the fp16 (hi, lo) terms the forward kernel multiplies with
      ([P][C/2][hi0, hi1, lo0, lo1] for C = 32, [P][C][hi, lo] for C = 16), and hs -- when the Linear is applied in the kernel
@@ -132,6 +148,12 @@ typedef struct {
   int products;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
+/* dwords per (sequence, step, direction) of the wide gate records (save_gates with rec_f32): 192 (24-bit fixed point), or 256
+   in a fp32-record build.  The caller sizes save_gates with it. */
+int sb_lstm_wide_rec_dwords(void);
+/* test hook: n floats (a multiple of 16: gates i, f, g, o x 4 units per group, values in [0, 1] / [-1, 1] for g) through the
+   record packing and back; packed (nullable): the 12 dwords of every group */
+int sb_rec_q24_roundtrip(const float* in, float* out, uint32_t* packed, int64_t n, void* stream);
 
 /* ---- inter-frame forward of block k OVERLAPPED with the intra-frame forward of block k + 1 ------------------------
  * The inter-frame pass of the BASELINE big configuration has 145 serial chains on 256 CUs; the bidirectional intra-frame

@@ -24,6 +24,11 @@ def cc(src):
 with ThreadPoolExecutor(len(only)) as ex:
     objs = dict(zip(only, ex.map(cc, only)))
 allobjs = [objs.get(s, os.path.join(B.LIBDIR, s.replace(".hip", ".o"))) for s in B.SOURCES]
+for src, stem, xflags in B.EXTRA_UNITS:                  # second builds of a translation unit (their own macro sets) go in with the variant's flags too
+    obj = os.path.join(exp, f"{stem}_{name}.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *xflags, *flags, "-O3", "-std=c++17", "-fPIC",
+                           "-Wno-unused-value", "-c", os.path.join(B.CSRC, src), "-o", obj])
+    allobjs.append(obj)
 out = os.path.join(exp, f"lib_{name}.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + allobjs)
 print("built", out)

@@ -1,5 +1,7 @@
 #!/bin/bash
 R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
-( timeout 500 python scripts/stress_train_loop.py --epochs 600 > gpurun_out/stress_a.log 2>&1 ); tail -3 gpurun_out/stress_a.log
-( timeout 500 python scripts/stress_train_loop.py --epochs 300 --sleep 100 > gpurun_out/stress_b.log 2>&1 ); tail -3 gpurun_out/stress_b.log
-( timeout 400 python scripts/stress_train_loop.py --epochs 120 --loader > gpurun_out/stress_c.log 2>&1 ); tail -3 gpurun_out/stress_c.log
+run() { n=$1; shift; ( env "$@" timeout 420 python scripts/stress_train_loop.py --epochs 1200 > gpurun_out/stress_$n.log 2>&1 ); echo "== $n"; grep -c TRIP gpurun_out/stress_$n.log; tail -1 gpurun_out/stress_$n.log; }
+run base A=1
+run pollrmw SB_LIB_PATH=$R/sound_bubble_amd/lib/exp/lib_pollrmw.so
+run nodefer SB_NO_DEFERRED_REDUCE=1
+run base2 A=1

@@ -37,6 +37,35 @@ dev = torch.device("cuda")
 if not args.loader:
     train_batches = [b for b in train_loader]
     val_batches = [b for b in test_loader]
+# the last overlapped forwards' flag arrays, read back after a trip: did memory ever hold the full counts the poller never saw?
+import collections
+RECENT = collections.deque(maxlen=96)
+_init = ops.FwdOverlap.__init__
+
+
+def _patched(self, *a, **k):
+    _init(self, *a, **k)
+    RECENT.append(self)
+
+
+ops.FwdOverlap.__init__ = _patched
+
+
+def dump_recent():
+    torch.cuda.synchronize()
+    nbad = nzero = 0
+    for i, o in enumerate(RECENT):
+        f = o.flags.cpu().tolist()
+        nsl = (o.need.max().item() + 1) if hasattr(o, "need") else len(f) - 4
+        T_sl = f[4:4 + nsl]
+        if all(v == 0 for v in T_sl):
+            nzero += 1
+        elif any(v != o.producer_tiles for v in T_sl) or f[0] != o.producer_tiles:
+            nbad += 1
+            print(f"  overlap #{i} of {len(RECENT)} (oldest first): started {f[0]} counters {f[1:4]} tiles {o.producer_tiles} slabs {T_sl}", flush=True)
+    print(f"  of {len(RECENT)} recent flag arrays: {nbad} hold partial counts IN MEMORY, {nzero} are all zero (never produced)", flush=True)
+
+
 trips, nans, steps = 0, 0, 0
 t00 = time.time()
 for epoch in range(args.epochs):
@@ -55,6 +84,8 @@ for epoch in range(args.epochs):
         steps += 1
         if l != l:
             nans += 1
+            if nans == 1 or nans % 100 == 0:
+                print(f"epoch {epoch} step {idx}: non-finite loss (#{nans})", flush=True)
     hl.eval()
     if not args.no_val:
         with torch.no_grad():
@@ -65,7 +96,11 @@ for epoch in range(args.epochs):
     except Exception as e:
         trips += 1
         print(f"epoch {epoch}: TRIP {ops.LAST_TRIPS[-1:]} counts {ops.SCHED_COUNTS} loss {l}", flush=True)
-        hl.epoch += 1
+        dump_recent()
+        ep = hl.epoch + 1
+        seed_all(1000 + epoch)
+        hl = import_attr(params["pl_module"])(**params["pl_module_args"])           # (the parameters are garbage now: start over)
+        hl.epoch = ep
     if epoch % 50 == 0:
         print(epoch, f"loss {l:.4f} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s", flush=True)
 print(f"DONE epochs {args.epochs} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s args {vars(args)}")

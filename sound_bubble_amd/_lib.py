@@ -154,6 +154,12 @@ class MultiCopyArgs(C.Structure):
 SYMBOLS = {
     "sb_multi_copy": (_ci, [C.POINTER(MultiCopyArgs), _vp]),
     "sb_lstm_fwd": (_ci, [C.POINTER(LstmFwdArgs), _vp]),
+    "sb_lstm_wide_rec_dwords": (_ci, []),
+    "sb_flags_alloc": (_ci, [i64, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "sb_flags_free": (_ci, [_vp]),
+    "sb_flags_zero": (_ci, [_vp, i64, _vp]),
+    "sb_flags_read": (_ci, [_vp, i64, C.POINTER(C.c_int), _vp]),
+    "sb_rec_q24_roundtrip": (_ci, [c_fp, c_fp, _vp, i64, _vp]),
     "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
     "sb_lstm_fwd_produce_ex": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp]),
     "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),

@@ -20,6 +20,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SB_DEVINL __device__ __forceinline__
 
+// One poll of a flag another workgroup raises (bounded waits of the guarded schedules).  -DSB_EXP_POLL_RMW (developer A/B): a
+// returning read-modify-write, which executes at the point of coherence, instead of an sc1 load, which this XCD's L2 serves.
+SB_DEVINL int sb_poll(const int* p) {
+#ifdef SB_EXP_POLL_RMW
+  return __hip_atomic_fetch_or(const_cast<int*>(p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // Watchdog word of the guarded schedules (sb_*_args.sched_status): 0 = fine.  The FIRST bounded wait that gives up leaves a
 // code saying which one it was -- site << 28 | index << 14 | value seen << 7 | value wanted (include/sound_bubble_hip.h:
 // SB_TRIP_*) -- every later waiter finds the word set and leaves without touching it.

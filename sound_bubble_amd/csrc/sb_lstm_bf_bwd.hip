@@ -131,7 +131,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       int bad = 0;
       unsigned spins = 0;
       for (int t = lo; t <= hi && !bad; ++t) {
-        while (__hip_atomic_load(a.slab_flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        while (sb_poll(a.slab_flags + t) < need) {
           ++spins;
           if ((spins & 63u) == 0 &&
               (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -975,8 +975,13 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
           const float* hp = reinterpret_cast<const float*>(hs16 + (posp * H + 8 * q) * 2);
           r.gh[0] = ld4(hp); r.gh[1] = ld4(hp + 4); r.gh[2] = ld4(hp + 32); r.gh[3] = ld4(hp + 36);
         } else {
+#if SB_REC_Q24
+          const float* rec = a.save_gates + blk * (16 * kWideGateDwords) + (w * 192 + lane) * 4;      // three packed pieces (sb_lstm_bf_common.h)
+          r.r0 = ld4_rec(rec); r.r1 = ld4_rec(rec + 256); r.r2 = ld4_rec(rec + 512); r.r3 = zero4();
+#else
           const float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
           r.r0 = ld4_rec(rec); r.r1 = ld4_rec(rec + 256); r.r2 = ld4_rec(rec + 512); r.r3 = ld4_rec(rec + 768);
+#endif
         }
         r.cp = ld4_rec(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4);
       } else {
@@ -1016,7 +1021,9 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     else if constexpr (GREC) asm volatile("" : "+v"(raw.gu[0]), "+v"(raw.gu[1]), "+v"(raw.gh[0]), "+v"(raw.gh[1]), "+v"(raw.gh[2]), "+v"(raw.gh[3]), "+v"(raw.dh));
     else asm volatile("" : "+v"(raw.r0), "+v"(raw.r1), "+v"(raw.dh));
     if constexpr (REC16) asm volatile("" : "+v"(raw.cp16)); else asm volatile("" : "+v"(raw.cp));
-    if constexpr (!REC16 && !GREC) asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
+    if constexpr (!REC16 && !GREC) {
+      if constexpr (XP && SB_REC_Q24 != 0) asm volatile("" : "+v"(raw.r2)); else asm volatile("" : "+v"(raw.r2), "+v"(raw.r3));
+    }
     if constexpr (FUSE_C > 0) asm volatile("" : "+v"(raw.dy1));
   };
   // SLAB: a step's dgates rows leave one step late -- whole rows (one instruction = 64 lanes x 8 bytes = one row),
@@ -1103,6 +1110,8 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       const h16x8 lo = __builtin_bit_cast(h16x8, raw.r0), hi = __builtin_bit_cast(h16x8, raw.r1);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { gi[k] = (float)lo[k]; gf[k] = (float)lo[4 + k]; gg[k] = (float)hi[k]; go[k] = (float)hi[4 + k]; }
+    } else if constexpr (XP && SB_REC_Q24 != 0) {
+      q24_unpack(raw.r0, raw.r1, raw.r2, gi, gf, gg, go);
     } else {
       gi = raw.r0; gf = raw.r1; gg = raw.r2; go = raw.r3;
     }
@@ -1372,7 +1381,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     if (tid == 0) {
       int bad = 0;
       unsigned spins = 0;
-      while (__hip_atomic_load(pst + ntiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      while (sb_poll(pst + ntiles + t) == 0) {
         ++spins;
         if ((spins & 63u) == 0 &&
             (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -1848,7 +1857,7 @@ int sb_launch_lstm_bwd_bf(const sb_lstm_bwd_args& a_in, hipStream_t st) {
       a.seg_len = ((a.nsteps + k - 1) / k + 3) & ~3;              // as in the forward launcher (pair-unrolled loop here)
       a.seg_count = (a.nsteps + a.seg_len - 1) / a.seg_len;
       grid.x = W;
-      (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
+      (void)sb_flags_zero(a.seg_flags, ntiles, st);
     }
   }
   // fused streaming part (see the kernel): single direction, fused Linear backward with the same channel count

@@ -52,6 +52,81 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
+// Wide BPTT gate records (sb_lstm_fwd_args.rec_f32) as 24-BIT FIXED POINT (round 5): the four post-activation gates of a unit lie in
+// [0, 1] (i, f, o) / [-1, 1] (g), where a uniform 24-bit grid -- step 2^-24 resp. 2^-23, error <= half a step -- is as fine as fp32
+// is at the top of the range and finer nowhere it matters for a gradient (an ABSOLUTE gate error e changes every product the
+// backward forms with it by e times a factor of order one, whatever the gate's own size).  A lane's 16 gate values (4 gates x
+// 4 units) travel as 12 dwords = three 16-byte pieces instead of four: 768 instead of 1024 B per position and direction, records
+// 1280 -> 1024 B.  Layout per (tile, step, direction) block: [wave][piece 0..2][lane][4 dwords] (one contiguous KB per store /
+// load instruction, as before); dwords 3g .. 3g + 2 of the lane hold gate g's four values q0 .. q3 as bytes
+// [q0.0 q0.1 q0.2 q1.0 | q1.1 q1.2 q2.0 q2.1 | q2.2 q3.0 q3.1 q3.2].  c_prev stays fp32 (unbounded).
+// -DSB_REC_Q24=0: fp32 gate records as in rounds 3 / 4 (A/B builds; sb_lstm_wide_rec_dwords() tells the host which).
+#ifndef SB_REC_Q24
+#define SB_REC_Q24 1
+#endif
+constexpr int kWideGateDwords = SB_REC_Q24 ? 3 * SB_H : 4 * SB_H;      // per sequence, step and direction
+struct RecQ24 { f32x4 p[3]; };
+SB_DEVINL unsigned q24_sig(float x) {            // [0, 1] -> round(x 2^24), saturated
+  const unsigned u = (unsigned)__builtin_fmaf(x, 16777216.0f, 0.5f);
+  return u < 0xFFFFFFu ? u : 0xFFFFFFu;
+}
+SB_DEVINL unsigned q24_tanh(float x) {           // [-1, 1] -> round(x 2^23) as 24-bit two's complement, saturated at 1 - 2^-23
+  const int i = (int)__builtin_rintf(x * 8388608.0f);
+  return (unsigned)(i < 8388607 ? i : 8388607);  // (bits above 23 are dropped by the byte permutes below)
+}
+// Forward side: the gates of a step are parked as their 24-bit CODES (same sixteen registers as the values: q24_codes), and each
+// 16-byte piece (0 .. 2) of the lane's record is formed by four byte permutes when it is stored -- few temporaries at a time
+// (packing all twelve dwords at the end of the cell update, where the register pressure of the forward step peaks, or quantising
+// at store time, cost the two-workgroup bidirectional kernels 7-8 spilled registers).
+SB_DEVINL f32x4 q24_codes(const f32x4 g, bool tanh_gate) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = __builtin_bit_cast(float, tanh_gate ? q24_tanh(g[k]) : q24_sig(g[k]));
+  return r;
+}
+SB_DEVINL f32x4 q24_piece(int p, const f32x4 ci, const f32x4 cf, const f32x4 cg, const f32x4 co) {
+  auto u = [](float x) { return __builtin_bit_cast(unsigned, x); };
+  unsigned e0, e1, e2, e3;
+  if (p == 0) {
+    e0 = __builtin_amdgcn_perm(u(ci[1]), u(ci[0]), 0x04020100u); e1 = __builtin_amdgcn_perm(u(ci[2]), u(ci[1]), 0x05040201u);
+    e2 = __builtin_amdgcn_perm(u(ci[3]), u(ci[2]), 0x06050402u); e3 = __builtin_amdgcn_perm(u(cf[1]), u(cf[0]), 0x04020100u);
+  } else if (p == 1) {
+    e0 = __builtin_amdgcn_perm(u(cf[2]), u(cf[1]), 0x05040201u); e1 = __builtin_amdgcn_perm(u(cf[3]), u(cf[2]), 0x06050402u);
+    e2 = __builtin_amdgcn_perm(u(cg[1]), u(cg[0]), 0x04020100u); e3 = __builtin_amdgcn_perm(u(cg[2]), u(cg[1]), 0x05040201u);
+  } else {
+    e0 = __builtin_amdgcn_perm(u(cg[3]), u(cg[2]), 0x06050402u); e1 = __builtin_amdgcn_perm(u(co[1]), u(co[0]), 0x04020100u);
+    e2 = __builtin_amdgcn_perm(u(co[2]), u(co[1]), 0x05040201u); e3 = __builtin_amdgcn_perm(u(co[3]), u(co[2]), 0x06050402u);
+  }
+  return f32x4{__builtin_bit_cast(float, e0), __builtin_bit_cast(float, e1), __builtin_bit_cast(float, e2), __builtin_bit_cast(float, e3)};
+}
+// three dwords -> the four values, each TOP-ALIGNED in its 32 bits (q << 8): no sign extension, and the conversion below is exact
+SB_DEVINL void q24_unpack3(unsigned e0, unsigned e1, unsigned e2, unsigned (&q)[4]) {
+  q[0] = e0 << 8;
+  q[1] = __builtin_amdgcn_perm(e1, e0, 0x0504030Cu);
+  q[2] = __builtin_amdgcn_perm(e2, e1, 0x0403020Cu);
+  q[3] = e2 & 0xFFFFFF00u;
+}
+SB_DEVINL void q24_unpack(const f32x4 p0, const f32x4 p1, const f32x4 p2, f32x4& gi, f32x4& gf, f32x4& gg, f32x4& go) {
+  unsigned e[12];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    e[k] = __builtin_bit_cast(unsigned, p0[k]); e[4 + k] = __builtin_bit_cast(unsigned, p1[k]); e[8 + k] = __builtin_bit_cast(unsigned, p2[k]);
+  }
+  unsigned q[4];
+  q24_unpack3(e[0], e[1], e[2], q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gi[k] = (float)q[k] * 0x1p-32f;
+  q24_unpack3(e[3], e[4], e[5], q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gf[k] = (float)q[k] * 0x1p-32f;
+  q24_unpack3(e[6], e[7], e[8], q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gg[k] = (float)(int)q[k] * 0x1p-31f;
+  q24_unpack3(e[9], e[10], e[11], q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) go[k] = (float)q[k] * 0x1p-32f;
+}
+
 struct Split3 { bf16x8 h, m, l; };
 
 SB_DEVINL void split1(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -135,7 +210,7 @@ SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status, int si
   if (threadIdx.x == 0) {
     int bad = 0;
     unsigned spins = 0;
-    while (__hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+    while (sb_poll(flags + tile) < seg) {
       ++spins;
       if ((spins & 63u) == 0 &&
           (spins > kSegSpinLimit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {

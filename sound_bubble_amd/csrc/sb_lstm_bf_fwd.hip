@@ -430,11 +430,17 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           // save_gates == NULL: records WITHOUT the gates (c_prev only) -- for a backward that recomputes them from u and
           // h_prev with the forward weights (sb_lstm_bwd_args.recompute with `wide`)
           if (k < 4 && a.save_gates) {
+#if SB_REC_Q24
+            // 24-bit fixed-point gates: three 16-byte pieces per lane, each packed here from the parked gates
+            float* rec = a.save_gates + blk * (16 * kWideGateDwords) + (w * 192 + lane) * 4;
+            if (k < 3) st4_rec(rec + 256 * k, q24_piece(k, rgi, rgf, rgg, rgo));
+#else
             float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
             if (k == 0) st4_rec(rec, rgi);
             if (k == 1) st4_rec(rec + 256, rgf);
             if (k == 2) st4_rec(rec + 512, rgg);
             if (k == 3) st4_rec(rec + 768, rgo);
+#endif
           }
           if (k == 4) st4_rec(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4, rcp);
         } else {
@@ -701,7 +707,9 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     SB_TICK(c3);
     // ---- C ----
     if constexpr (SAVE >= 2) {        // records of this step: issued in phase A of the next one (or by the flush after the walk)
-      rgi = gi; rgf = gf; rgg = gg; rgo = go; rcp = cprev;
+      if constexpr (SAVE == 4 && SB_REC_Q24 != 0) {   // parked as the record's 24-bit codes (sb_lstm_bf_common.h)
+        rgi = q24_codes(gi, false); rgf = q24_codes(gf, false); rgg = q24_codes(gg, true); rgo = q24_codes(go, false); rcp = cprev;
+      } else { rgi = gi; rgf = gf; rgg = gg; rgo = go; rcp = cprev; }
       s_pend = s;
       pend_blk = run_blk; pend_h = run_h;
       if constexpr (!DEFER) rec_flush();              // ... or right here
@@ -881,7 +889,43 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #endif
 }
 
+#ifndef SB_FWD_2P
+// test hook (sb_rec_q24_roundtrip): 16 floats per thread through the record packing and back -- gates i, f, g, o x 4 units
+__global__ void rec_q24_roundtrip_kernel(const float* in, float* out, unsigned* packed, int n16) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n16) return;
+  f32x4 g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) g[k] = ld4(in + (size_t)t * 16 + 4 * k);
+  RecQ24 r;
+  const f32x4 ci = q24_codes(g[0], false), cf = q24_codes(g[1], false), cg = q24_codes(g[2], true), co = q24_codes(g[3], false);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) r.p[p] = q24_piece(p, ci, cf, cg, co);
+  if (packed) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) packed[(size_t)t * 12 + 4 * p + k] = __builtin_bit_cast(unsigned, r.p[p][k]);
+  }
+  f32x4 o[4];
+  q24_unpack(r.p[0], r.p[1], r.p[2], o[0], o[1], o[2], o[3]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) st4(out + (size_t)t * 16 + 4 * k, o[k]);
+}
+#endif
+
 }  // namespace
+
+#ifndef SB_FWD_2P
+extern "C" int sb_lstm_wide_rec_dwords(void) { return kWideGateDwords; }
+extern "C" int sb_rec_q24_roundtrip(const float* in, float* out, uint32_t* packed, int64_t n, void* stream) {
+  if (!in || !out || n <= 0 || n % 16) return -1001;
+  const int n16 = (int)(n / 16);
+  hipLaunchKernelGGL(rec_q24_roundtrip_kernel, dim3((n16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, out, packed, n16);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+#endif
 
 #ifdef SB_FWD_2P
 #define sb_launch_lstm_fwd_bf sb_launch_lstm_fwd_bf_2p        // second build of this file: the two-product inference kernels
@@ -923,7 +967,7 @@ int sb_launch_lstm_fwd_bf(const sb_lstm_fwd_args& a_in, hipStream_t st) {
       a.seg_len = ((a.nsteps + k - 1) / k + 3) & ~3;
       a.seg_count = (a.nsteps + a.seg_len - 1) / a.seg_len;      // drop empty trailing segments
       grid.x = W;
-      (void)hipMemsetAsync(a.seg_flags, 0, (size_t)ntiles * sizeof(int), st);
+      (void)sb_flags_zero(a.seg_flags, ntiles, st);
     }
   }
   if (a.slab_flags && (seg || !lin || !f16 || a.slab_len < 4 || (a.slab_len & 3) || !a.ord_started)) return -1003;

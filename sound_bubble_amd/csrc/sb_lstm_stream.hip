@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
   auto slab_poll = [&](int k) {
     if (tid == 0 && k > ready_k) {
       unsigned spins = 0;
-      while (__hip_atomic_load(a.slab_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.slab_need) {
+      while (sb_poll(a.slab_flags + k) < a.slab_need) {
         ++spins;
         if ((spins & 63u) == 0 &&
             (spins > (1u << 22) || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -1368,6 +1368,51 @@ extern "C" int sb_overlap_join(void* stream) {
   return 0;
 }
 
+// ---- flag memory of the guarded schedules (round 5) ----
+// Every word one workgroup raises and another polls -- slab counters, item counters, per-tile claim / done words, segment flags,
+// the watchdog word -- lives in memory the L2s do NOT cache (hipDeviceMallocUncached: MTYPE UC).  The per-XCD L2s are not
+// coherent with each other; agent-scope atomics and sc1 loads go to memory only while the line is not resident in the issuing
+// XCD's L2, and a line the zero-fill (plain stores) or an earlier poll left there was seen to serve stale counts for as long as
+// it stayed: in a 9 600-step training run one overlapped forward in a few thousand had a consumer poll a slab counter that never
+// moved (52 of 82) while memory held the full count, until the watchdog gave up -- and the watchdog word itself came back from a
+// stale line two epochs after the host had cleared it.  Uncached words have one home; they are a few KB per step, touched by one
+// lane per workgroup.  kind: 3 uncached, 1 fine-grained (fallback), 0 ordinary device memory (last resort; the caller is told).
+extern "C" int sb_flags_alloc(int64_t bytes, void** ptr, int* kind) {
+  if (!ptr || bytes <= 0) return -1001;
+  *ptr = nullptr;
+  const unsigned tries[2] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained};
+  for (int i = 0; i < 2; ++i) {
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, (size_t)bytes, tries[i]) == hipSuccess && p) { *ptr = p; if (kind) *kind = (int)tries[i]; return 0; }
+    (void)hipGetLastError();
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)bytes) != hipSuccess || !p) { (void)hipGetLastError(); return -1009; }
+  *ptr = p; if (kind) *kind = 0;
+  return 0;
+}
+extern "C" int sb_flags_free(void* ptr) { return (!ptr || hipFree(ptr) == hipSuccess) ? 0 : -1009; }
+namespace {
+__global__ void flags_zero_kernel(int* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) __hip_atomic_store(p + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (write-through: no line stays behind in this XCD's L2)
+}
+}  // namespace
+extern "C" int sb_flags_zero(void* ptr, int64_t n_ints, void* stream) {
+  if (!ptr || n_ints <= 0) return -1001;
+  hipLaunchKernelGGL(flags_zero_kernel, dim3((unsigned)((n_ints + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int*)ptr, n_ints);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+// host read-back (synchronises `stream`): the watchdog word, and flag arrays for diagnostics
+extern "C" int sb_flags_read(const void* ptr, int64_t n_ints, int* host_out, void* stream) {
+  if (!ptr || !host_out || n_ints <= 0) return -1001;
+  if (hipMemcpyAsync(host_out, ptr, (size_t)n_ints * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return -1009;
+  return 0;
+}
+
 extern "C" int sb_overlap_time_next_side_launch(void* ev_start, void* ev_stop) {
   std::lock_guard<std::mutex> lk(g_side_mu);
   const int was_armed = g_side_timer_armed.load(std::memory_order_relaxed);
@@ -1411,7 +1456,7 @@ static int inter_pair(const sb_lstm_bwd_args* rec_in, const sb_lstm_stream_args*
   // placed at once starts later and draws fewer units); behind it: one per CU
   const int g1 = serial ? 0 : idle, g2 = cus;
 
-  if (hipMemsetAsync(flags, 0, (size_t)(nslabs + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (sb_flags_zero(flags, nslabs + 4, main_st) != 0) return -1009;
   if (!serial && hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;
   rec.slab_flags = flags + 4; rec.slab_len = slab_len; rec.slab_started = flags;
   int rc = sb_lstm_bwd_rec(&rec, stream);
@@ -1468,7 +1513,7 @@ extern "C" int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a_in, int* flags, 
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
   const int nslabs = (a.nsteps + slab_len - 1) / slab_len;
-  if (!flags_zeroed && hipMemsetAsync(flags, 0, (size_t)(nslabs + 4) * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (!flags_zeroed && sb_flags_zero(flags, nslabs + 4, main_st) != 0) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
   a.slab_flags = flags + 4; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
   a.ord_started = flags;
@@ -1546,7 +1591,7 @@ extern "C" int sb_lstm_bwd_cross_produce_ex(const sb_lstm_bwd_args* a_in, int* f
   // flags: [0] producer workgroups started, [1 .. 3] spare, [4 + tile] slabs completed by tile, then the consumer's 16 item
   // counters and three words per CONSUMER tile (prologue claimed / done / max |dy1|)
   if (n_flags < ntiles + 4) return -1003;
-  if (!flags_zeroed && hipMemsetAsync(flags, 0, (size_t)n_flags * sizeof(int), main_st) != hipSuccess) return -1009;
+  if (!flags_zeroed && sb_flags_zero(flags, n_flags, main_st) != 0) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
   a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_started = flags;
   a.seg_state = nullptr; a.seg_flags = nullptr;                           // (no time segments under the producer)

@@ -412,7 +412,7 @@ class InterFn(torch.autograd.Function):
             flags = ops.zeroed_flags(nfl, dy.device)   # (one fill per step for all blocks; None: the library zeroes them itself)
             prezeroed = flags is not None
             if flags is None:
-                flags = torch.empty(nfl, device=dy.device, dtype=torch.int32)
+                flags = ops.flag_words(nfl, dy.device)
             du, overlapped, keep = ops.lstm_bwd_fused(wh, gates, geom, dy.view(P, Cc), lin_w, u, hs, wi, tg[0],
                                                       lin_targets=(gt("lin_w", lin_w), gt("lin_b", lin_b)),
                                                       produce=(flags, slab, prezeroed))

@@ -55,6 +55,22 @@ def _wide():
     return BPTT == "wide"
 
 
+_WIDE_REC_DW = None
+
+
+def wide_rec_dwords():
+    """dwords per (sequence, step, direction) of the wide gate records: 192 = the four gates as 24-bit fixed point (round 5), 256 =
+    fp32 (a -DSB_REC_Q24=0 build); the library says which"""
+    global _WIDE_REC_DW
+    if _WIDE_REC_DW is None:
+        _WIDE_REC_DW = int(L.load().sb_lstm_wide_rec_dwords())
+    return _WIDE_REC_DW
+
+
+def wide_rec_bytes():
+    return 4.0 * (wide_rec_dwords() + H)          # gates + fp32 c_prev, per position and direction
+
+
 def wide_supported(kind, Cc):
     """layer shapes the wide fused backward kernels cover: kind 'inter' (single direction, fused Linear, C in {16, 32}),
     'intra-plain' (bidirectional with the fused Linear backward, C == 32), 'intra-conv' (bidirectional, gradient of hs
@@ -207,12 +223,91 @@ SCHED_OVERRIDE = None
 _SCHED_STATUS = {}
 
 
+class FlagWords:
+    """n int32 words of UNCACHED device memory (a slice of the per-device flag arena; include/sound_bubble_hip.h, "flag memory of
+    the guarded schedules"): stands in for the int32 tensor the flags used to be -- data_ptr / numel / cpu / item / zero_."""
+    __slots__ = ("ptr", "n", "dev")
+
+    def __init__(self, ptr, n, dev):
+        self.ptr, self.n, self.dev = ptr, n, dev
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numel(self):
+        return self.n
+
+    def cpu(self):
+        """synchronises the current stream; -> int32 tensor on the host"""
+        out = (C.c_int * self.n)()
+        with torch.cuda.device(self.dev):
+            L.check(L.load().sb_flags_read(C.c_void_p(self.ptr), self.n, out, _stream()), "sb_flags_read")
+        return torch.tensor(list(out), dtype=torch.int32)
+
+    def item(self):
+        assert self.n == 1
+        return int(self.cpu()[0])
+
+    def zero_(self):
+        with torch.cuda.device(self.dev):
+            L.check(L.load().sb_flags_zero(C.c_void_p(self.ptr), self.n, _stream()), "sb_flags_zero")
+        return self
+
+
+class _FlagArena:
+    """One uncached allocation per device, cut into CHUNKS that are handed out round-robin; a chunk is zeroed (write-through
+    stores, on the stream that activates it) when it becomes current, its words are handed out once, and by the time the ring
+    comes back to it -- NCHUNK chunks = hundreds of train steps later -- the device is synchronised once, so no kernel can still
+    be polling the words.  Word 0 .. 63 are reserved (the watchdog word)."""
+    CHUNK = 1 << 15           # ints (128 KB): ~4 train steps of the big model's flags
+    NCHUNK = 64
+
+    def __init__(self, dev_index):
+        self.dev = dev_index
+        ptr, kind = C.c_void_p(), C.c_int(-1)
+        with torch.cuda.device(dev_index):
+            L.check(L.load().sb_flags_alloc(4 * (64 + self.CHUNK * self.NCHUNK), C.byref(ptr), C.byref(kind)), "sb_flags_alloc")
+            self.base, self.kind = ptr.value, kind.value
+            torch.cuda.synchronize(dev_index)
+            L.check(L.load().sb_flags_zero(C.c_void_p(self.base), 64, _stream()), "sb_flags_zero")
+            torch.cuda.synchronize(dev_index)
+        if self.kind != 3:
+            import warnings
+            warnings.warn(f"cuda:{dev_index}: no uncached device memory for the schedule flags (got kind {self.kind}); the "
+                          "overlapped schedules run on cached flag words, which were seen to go stale once in a few thousand steps")
+        self.next_chunk, self.gen = 0, [0] * self.NCHUNK
+        self.status = FlagWords(self.base, 1, dev_index)
+
+    def new_chunk(self):
+        """-> (chunk index, byte address, generation) of a fresh chunk, zeroed on the current stream"""
+        k = self.next_chunk
+        self.next_chunk = (k + 1) % self.NCHUNK
+        if k == 0 and self.gen[0] > 0 and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(self.dev)                 # (once per NCHUNK chunks: every word of the ring is dead)
+        self.gen[k] += 1
+        addr = self.base + 4 * (64 + k * self.CHUNK)
+        with torch.cuda.device(self.dev):
+            L.check(L.load().sb_flags_zero(C.c_void_p(addr), self.CHUNK, _stream()), "sb_flags_zero")
+        return k, addr, self.gen[k]
+
+
+_FLAG_ARENAS = {}
+
+
+def flag_arena(dev):
+    i = dev.index if isinstance(dev, torch.device) and dev.index is not None else (dev if isinstance(dev, int) else torch.cuda.current_device())
+    a = _FLAG_ARENAS.get(i)
+    if a is None:
+        a = _FLAG_ARENAS[i] = _FlagArena(i)
+    return a
+
+
 def sched_status(dev):
-    """the per-device watchdog word of the segmented schedule (one int32, zeroed once)"""
+    """the per-device watchdog word of the guarded schedules (one int32 of the flag arena, zeroed once)"""
     i = dev.index if dev.index is not None else torch.cuda.current_device()
     t = _SCHED_STATUS.get(i)
     if t is None:
-        t = _SCHED_STATUS[i] = torch.zeros(1, device=dev, dtype=torch.int32)
+        t = _SCHED_STATUS[i] = flag_arena(i).status
         # the word is read by kernels on the library's SIDE stream too, which is ordered after an event recorded BEFORE this
         # fill was enqueued when the first use is an overlapped consumer (SB_NO_TIME_SEGMENTS=1: no producer-side scratch
         # creates it earlier): the consumer then saw whatever the freshly allocated word held, took it for a tripped watchdog,
@@ -292,8 +387,7 @@ def check_sched_status():
 def _seg_scratch(a, geom, dev):
     """scratch + watchdog word + overrides of the segmented schedule into an LstmFwdArgs / LstmBwdArgs"""
     ntiles = (geom.nseq + 15) // 16
-    scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32),
-               torch.empty(ntiles, device=dev, dtype=torch.int32))
+    scratch = (torch.empty(ntiles * 2 * 16 * H, device=dev, dtype=torch.float32), flag_words(ntiles, dev))      # (flags: zeroed by the call)
     a.seg_state, a.seg_flags = _p(scratch[0]), C.c_void_p(scratch[1].data_ptr())
     a.sched_status = C.c_void_p(sched_status(dev).data_ptr())
     if SCHED_OVERRIDE is not None:
@@ -507,7 +601,7 @@ class FwdOverlap:
         self.flags = zeroed_flags(nfl, dev)       # from the once-per-step zeroed pool (None: the library zeroes them itself)
         self.prezeroed = self.flags is not None
         if self.flags is None:
-            self.flags = torch.empty(nfl, device=dev, dtype=torch.int32)
+            self.flags = flag_words(nfl, dev)
         self.producer_tiles = (B * F_ + 15) // 16
         self.order, self.need = _tile_order(B, T, self.slab, dev)
         self.keep = []            # everything the producer touches stays allocated until the consumer has been launched
@@ -552,7 +646,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         assert LSTM_MMA == 1 and (not no_gates or (ndir == 1 and hsp))
         Pr = (geom.nseq + 15) // 16 * 16 * geom.nsteps
         if not no_gates:      # no_gates: c_prev + the u / hs pairs only -- the backward recomputes the gates
-            gates = torch.empty(Pr, ndir, 4 * H, device=dev, dtype=torch.float32)
+            gates = torch.empty(Pr, ndir, wide_rec_dwords(), device=dev, dtype=torch.float32)   # (24-bit fixed-point gates: opaque dwords)
         cprev = torch.empty(Pr, ndir, H, device=dev, dtype=torch.float32)
     elif save and _compact():
         # opaque to the host: on the 16-bit matrix path the records are blocked per (16-sequence tile, step, direction)
@@ -718,39 +812,44 @@ _SLOTS = _ScalarSlots()
 
 
 class _FlagPool:
-    """Zeroed int32 flag arrays of the cross-pass backward (sb_lstm_bwd_cross_produce_ex, flags_zeroed), cut from one buffer that
-    is zeroed with ONE fill per train step instead of a memset in front of every block's producer (a launch on the critical
-    path between two blocks).  A slice is handed out once; a full buffer is replaced by a fresh one."""
+    """Flag arrays of the overlapped schedules (slab counters, item counters, per-tile words), cut from the current chunk of the
+    device's UNCACHED flag arena (_FlagArena): a chunk is zeroed with ONE launch when it becomes current -- not a memset in front
+    of every block's producer, a launch on the critical path between two blocks -- and a slice is handed out once."""
 
     def __init__(self):
-        self.buf, self.i = {}, {}
+        self.cur = {}             # (device, stream) -> [chunk address, ints used]
 
     def get(self, n, dev):
-        # per (device, stream): the fill is ordered in front of the slice's users only on the stream that ran it
-        key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        # per (device, stream): the chunk's zeroing is ordered in front of the slice's users only on the stream that ran it
+        i = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = (i, torch.cuda.current_stream().cuda_stream)
         n = (n + 63) & ~63
-        b = self.buf.get(key)
-        if b is None or self.i[key] + n > b.numel():
-            b = self.buf[key] = torch.zeros(max(8 * n, 1 << 15), device=dev, dtype=torch.int32)
-            self.i[key] = 0
-        k = self.i[key]
-        self.i[key] = k + n
-        return b[k:k + n]
+        arena = flag_arena(i)
+        assert n <= arena.CHUNK, n
+        c = self.cur.get(key)          # [chunk index, address, generation, ints used]
+        if c is None or c[3] + n > arena.CHUNK or arena.gen[c[0]] != c[2]:      # (last: another stream's pool has gone round the ring)
+            c = self.cur[key] = list(arena.new_chunk()) + [0]
+        w = FlagWords(c[1] + 4 * c[3], n, i)
+        c[3] += n
+        return w
 
     def new_step(self):
-        for key in list(self.buf):
-            if self.i[key]:
-                del self.buf[key]                         # (slices still held by a pending consumer keep the old buffer alive)
+        pass                      # (chunks are consumed linearly: nothing to do per step)
 
 
 _FLAGS = _FlagPool()
 
 
 def zeroed_flags(n, dev):
-    """n zeroed int32 words (zeroed in stream order before any later launch on the current stream), or None when the caller
-    should let the library zero its own (stream capture: no allocation-order games inside a graph)"""
+    """n zeroed int32 words of uncached flag memory (zeroed in stream order before any later launch on the current stream), or None
+    when the caller should take flag_words() and let the library zero them (SB_NO_DEFERRED_REDUCE=1: the round-3 launch order)"""
     if not DEFER_REDUCE or torch.cuda.is_current_stream_capturing():
         return None
+    return _FLAGS.get(n, dev)
+
+
+def flag_words(n, dev):
+    """n int32 words of uncached flag memory for a call that zeroes its flags itself (same chunks: they happen to be zero too)"""
     return _FLAGS.get(n, dev)
 
 
@@ -918,9 +1017,9 @@ def lstm_bwd_inter_overlapped(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets
         gm = zero_scalar(dev)
         s.absmax_out = _p(gm)
     slab = BWD_OVERLAP_SLAB
-    flags = torch.empty((geom.nsteps + slab - 1) // slab + 4, device=dev, dtype=torch.int32)      # + 4 control words
+    flags = flag_words((geom.nsteps + slab - 1) // slab + 4, dev)      # + 4 control words (uncached flag memory; zeroed by the call)
     serial = serial or BWD_PAIR_SERIAL
-    rec_b = (256.0 + 256.0 + 4.0 * Cc if recompute is not None else 1280.0) if wide else 640.0    # recurrence reads per position
+    rec_b = (256.0 + 256.0 + 4.0 * Cc if recompute is not None else wide_rec_bytes()) if wide else 640.0    # recurrence reads per position
     by = P * ((rec_b + 3 * 1024.0 + 256 * 2 + 4.0 * Cc if wide else 640.0 + 2 * 512.0 + 128 * 2 + 2.0 * Cc) + 4 * 4.0 * Cc)
     with _Prof(f"lstm_bwd inter overlapped C={Cc} (recurrence || stream kernel)" + (" [wide]" if wide else "")
                + (" [gates recomputed]" if recompute is not None else "")
@@ -1095,7 +1194,7 @@ def lstm_bwd_fused(w_hh, gates, geom, dy, w_lin, u, hs, w_ih, targets, lin_targe
     if lin_targets is not None:
         assert lin_targets[0].shape == (Cc, H)
         a.dW_lin, a.db_lin = _p(lin_targets[0]), _p(lin_targets[1])
-    by = (geom.P * ((1280.0 if a.wide else 640.0) + 4.0 * Cc + 4.0 * Cc + (8.0 * Cc if ln is not None else 0.0))
+    by = (geom.P * ((wide_rec_bytes() if a.wide else 640.0) + 4.0 * Cc + 4.0 * Cc + (8.0 * Cc if ln is not None else 0.0))
           + (hs.numel() * hs.element_size() if hs is not None else 0) + u.numel() * u.element_size())
     fl = (2.0 * 4 * H * H + 2.0 * H * Cc + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc + 2.0 * H * Cc) * geom.P
     with _Prof(f"lstm_bwd_rec_bf_kernel C={Cc} inter-frame fused BPTT" + (" + LayerNorm backward" if ln is not None else "")
@@ -1247,7 +1346,7 @@ def lstm_bwd_fused_bi(w_hh_list, gates, geom, u, hs, w_ih_list, targets, dhs=Non
     a.du, a.wpart = _p(du), _p(wpart)
     a.dW_ih, a.dW_hh, a.db_ih, a.db_hh = (_p(t) for t in targets[0])
     a.dW_ih1, a.dW_hh1, a.db_ih1, a.db_hh1 = (_p(t) for t in targets[1])
-    by = (geom.P * (2 * ((1280.0 if a.wide else 640.0) if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
+    by = (geom.P * (2 * ((wide_rec_bytes() if a.wide else 640.0) if rec is not None else 128.0) + (4.0 * Cc if dy is not None else 8.0 * H)
                     + 8.0 * Cc) + (hs.numel() * hs.element_size() if hs is not None else 0) + u.numel() * u.element_size())
     fl = 2 * (2.0 * 4 * H * H + (2.0 * H * Cc if dy is not None else 0.0) + 2.0 * 4 * H * (Cc + H) + 2.0 * 4 * H * Cc
               + (2.0 * H * Cc if lin_targets is not None else 0.0)) * geom.P
