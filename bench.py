@@ -249,6 +249,81 @@ def parity_check(torch, sb, dev):
             "reference_output": "tests/golden/samples_6block.npz (the imported reference model's own output)"}
 
 
+def parity_trained(torch, dev):
+    """`parity.trained` of the headline: the checkpoint this repo's HIP path TRAINED (tests/golden/trained_overfit_best.pt: train_cli on
+    experiments/overfit_test_samples.json) against what the IMPORTED REFERENCE network computes with the same file
+    (tests/golden/trained_overfit.npz, made by tests/golden/make_trained_fixture.py in the build container) -- SI-SDR at a
+    positive operating point instead of the -50 dB of seeded weights.  Outside the timed region; no oracle involved."""
+    import numpy as np
+    from sound_bubble_amd.eval_samples import load_testcase, run_testcase, si_sdr_np
+    from sound_bubble_amd.harness import import_attr
+    gold = os.path.join(ROOT, "tests", "golden")
+    ck, fx = os.path.join(gold, "trained_overfit_best.pt"), os.path.join(gold, "trained_overfit.npz")
+    if not (os.path.exists(ck) and os.path.exists(fx)):
+        return {"skipped": "tests/golden/trained_overfit_best.pt / trained_overfit.npz not present"}
+    p = json.load(open(os.path.join(ROOT, "experiments", "overfit_test_samples.json")))
+    hl = import_attr(p["pl_module"])(**dict(p["pl_module_args"], init_ckpt=None, use_dp=False))
+    hl.load_state(ck)
+    hl.eval()
+    ref = np.load(fx)
+    rows, worst_l2, worst_db = [], 0.0, 0.0
+    for sset, radius in (("syn_1m", 1.0), ("syn_1_5m", 1.5), ("syn_2m", 2.0)):
+        for scene in ("00001", "00002"):
+            key = f"{sset}/{scene}"
+            _, mix, gt, tg = load_testcase(os.path.join(gold, "test_samples_full", sset, scene), radius)
+            out = run_testcase(hl.model, mix, radius, device=dev)
+            s_, want = si_sdr_np(out[0], gt[0]), float(ref[key + "::si_sdr"])
+            row = {"scene": key, "si_sdr_db": s_, "si_sdr_ref_db": want, "si_sdr_i_ref_db": want - float(ref[key + "::input_si_sdr"])}
+            if key + "::output" in ref:
+                r = ref[key + "::output"].astype(np.float64)
+                row["fwd_rel_l2"] = float(np.sqrt(((out.astype(np.float64) - r) ** 2).sum() / (r ** 2).sum()))
+                worst_l2 = max(worst_l2, row["fwd_rel_l2"])
+            worst_db = max(worst_db, abs(s_ - want))
+            rows.append(row)
+    return {"checkpoint": "tests/golden/trained_overfit_best.pt (trained here on the nine bundled demo scenes: an overfit, not a "
+                          "generalisation claim), epoch %d" % int(ref["meta::ckpt_epoch"]),
+            "reference_output": "tests/golden/trained_overfit.npz (the imported reference network with the same checkpoint)",
+            "worst_fwd_rel_l2": worst_l2, "fwd_rel_l2_bar": 1e-3, "worst_si_sdr_delta_db": worst_db, "si_sdr_delta_bar_db": 0.05,
+            "mean_si_sdr_db": float(np.mean([r["si_sdr_db"] for r in rows])),
+            "mean_si_sdr_i_ref_db": float(np.mean([r["si_sdr_i_ref_db"] for r in rows])), "scenes": rows}
+
+
+def two_product_forward(torch, dist, sb, ops, args, dev, world, rank):
+    """secondary.forward_{small,big}_2prod: the OPT-IN reduced-product forward (sb_lstm_fwd_args.products = 2, SB_LSTM_PRODUCTS=2:
+    activations as ONE fp16 term against hi + lo weights in the recurrent products) -- its speed, and its distance from the
+    default arithmetic and from the reference on the committed scene.  Never the headline: 11-bit activations are not fp32-class."""
+    import numpy as np
+    res = {}
+    old = ops.LSTM_PRODUCTS
+    try:
+        base = {}
+        for w2 in ("small", "big"):                          # distance on the bench batch itself: default vs two products
+            cls, params, B = WORKLOADS[w2][0], WORKLOADS[w2][1], min(4, args.batch or WORKLOADS[w2][2])
+            torch.manual_seed(0)
+            model = getattr(sb, cls)(**params).to(dev).eval()
+            inputs, _ = synth_batch(torch, B, 1234, dev, cls != "NetOptim")
+            outs = []
+            for prod in (3, 2):
+                ops.LSTM_PRODUCTS = prod
+                with torch.no_grad():
+                    outs.append(model(inputs)["output"].double())
+            base[w2] = float((outs[1] - outs[0]).norm() / outs[0].norm())
+        ops.LSTM_PRODUCTS = 2
+        for w2 in ("small", "big"):
+            o = train_line(torch, dist, sb, ops, w2, args, dev, world, rank, forward_only=True, with_cpu=False)
+            res[f"forward_{w2}_2prod"] = {
+                "utt_s": o["value"], "ms_per_step": o["ms_per_step"], "hbm_frac": o["forward_roofline"]["hbm_frac"],
+                "rel_l2_vs_default_arithmetic": base[w2], "batch": o["config"]["batch_per_gpu"],
+                "dtype": "f32 storage/accumulate; recurrent products on the fp16 pipe with hi+lo WEIGHTS x single-term fp16 "
+                         "ACTIVATIONS (2 products per MAC, 11-bit activations: NOT fp32-class; opt-in SB_LSTM_PRODUCTS=2)"}
+        pc = parity_check(torch, sb, dev)
+        if "fwd_rel_l2" in pc:
+            res["forward_big_2prod"]["scene_vs_reference"] = {k: pc[k] for k in ("fwd_rel_l2", "si_sdr_delta_db", "fwd_rel_l2_bar")}
+    finally:
+        ops.LSTM_PRODUCTS = old
+    return res
+
+
 def vendor_gpu_baseline(torch, wl, B, dev, steps=3):
     """Second yardstick of SURVEY.md 8(d), measurement only: the same oracle restatement (stock torch.nn ops ->
     MIOpen RNN / rocBLAS / ATen kernels) moved onto the GPU -- i.e. what running the reference unmodified on
@@ -726,6 +801,10 @@ def train_line(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_only
         out["cpu_baseline"]["legs"]["stream_small"] = cpu_stream_leg(torch, "small")     # configs[4] on the CPU
     if not forward_only and rank == 0 and wl.startswith("big") and not args.no_parity:
         out["parity"] = parity_check(torch, sb, dev)
+        try:
+            out["parity"]["trained"] = parity_trained(torch, dev)
+        except Exception as e:
+            out["parity"]["trained"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -974,6 +1053,13 @@ def main():
                                               "hbm_frac": o["forward_roofline"]["hbm_frac"],
                                               "frac_of_fp16x3_ceiling": o["forward_roofline"]["frac_of_fp16x3_ceiling"],
                                               "batch": o["config"]["batch_per_gpu"]}
+            try:
+                tp = two_product_forward(torch, dist, sb, ops, args, dev, world, rank)
+                for k in ("small", "big"):                   # speed-up over the default arithmetic measured minutes earlier in this run
+                    tp[f"forward_{k}_2prod"]["speedup_vs_default"] = tp[f"forward_{k}_2prod"]["utt_s"] / secondary[f"forward_{k}"]["utt_s"]
+                secondary.update(tp)
+            except Exception as e:                           # an opt-in side measurement must not void the run
+                secondary["forward_2prod_error"] = f"{type(e).__name__}: {e}"
             o = train_line(torch, dist, sb, ops, "small", args, dev, world, rank, with_exact=not args.no_exact, with_cpu=False)
             emit(o)
             sib = SIBLING[o.get("bptt_mode", "wide")] + "_bptt"

@@ -26,9 +26,11 @@ extern "C" {
 
 #define SB_H 64 /* LSTM hidden size the recurrent kernels are built for */
 
-/* The watchdog word (sched_status) after a bounded wait gave up:  site << 28 | index << 14 | seen << 7 | wanted  (index: tile /
-   slab the wait was for, seen / wanted: the flag's value and the value waited for, both mod 128).  Only the FIRST wait to give up
-   writes; decode with sound_bubble_amd.ops.decode_trip. */
+/* The watchdog word (sched_status) after a bounded wait gave up:  site << 28 | timed_out << 27 | index << 14 | seen << 7 | wanted
+   (index: tile / slab the wait was for, seen / wanted: the flag's value and the value waited for, both mod 128; timed_out = 0: the
+   waiter left because it found the word already set).  Only the FIRST wait to give up writes; decode with
+   sound_bubble_amd.ops.decode_trip.  A caller that has read a non-zero word should move to a FRESH word rather than clear it in
+   place (sound_bubble_amd.ops does). */
 enum {
   SB_TRIP_FWD_SEGMENT = 1,    /* time-segmented forward: the previous segment of the tile never published its state */
   SB_TRIP_FWD_CONSUMER = 2,   /* overlapped forward, intra-frame consumer: the producer's time slab never completed */

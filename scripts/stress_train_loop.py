@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from sound_bubble_amd import ops                                 # noqa: E402
+from sound_bubble_amd import ops, _lib as L                      # noqa: E402
 from sound_bubble_amd.harness import import_attr                 # noqa: E402
 from sound_bubble_amd.train_cli import seed_all, to_device, make_loaders       # noqa: E402
 
@@ -93,14 +93,12 @@ for epoch in range(args.epochs):
                 vl, _ = hl.validation_step(to_device(batch, dev), idx)
     try:
         hl.on_epoch_end(os.devnull, None)
-    except Exception as e:
+    except L.SoundBubbleHipError as e:
         trips += 1
         print(f"epoch {epoch}: TRIP {ops.LAST_TRIPS[-1:]} counts {ops.SCHED_COUNTS} loss {l}", flush=True)
         dump_recent()
-        ep = hl.epoch + 1
         seed_all(1000 + epoch)
         hl = import_attr(params["pl_module"])(**params["pl_module_args"])           # (the parameters are garbage now: start over)
-        hl.epoch = ep
     if epoch % 50 == 0:
         print(epoch, f"loss {l:.4f} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s", flush=True)
 print(f"DONE epochs {args.epochs} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s args {vars(args)}")

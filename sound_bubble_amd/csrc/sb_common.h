@@ -31,12 +31,62 @@ SB_DEVINL int sb_poll(const int* p) {
 }
 
 // Watchdog word of the guarded schedules (sb_*_args.sched_status): 0 = fine.  The FIRST bounded wait that gives up leaves a
-// code saying which one it was -- site << 28 | index << 14 | value seen << 7 | value wanted (include/sound_bubble_hip.h:
-// SB_TRIP_*) -- every later waiter finds the word set and leaves without touching it.
-SB_DEVINL void sb_trip(int* status, int site, int index, int seen, int want) {
+// code saying which one it was -- site << 28 | timed_out << 27 | index << 14 | value seen << 7 | value wanted (include/
+// sound_bubble_hip.h: SB_TRIP_*; timed_out = 0: the waiter left because it found the word already set) -- every later waiter
+// finds the word set and leaves without touching it.  -DSB_TRIP_DEBUG (developer builds; the word then needs 8 ints, as the
+// library's own flag arena gives it): [1] polls done, [2] the word's value as the waiter read it, [3] XCC id << 16 | workgroup.
+// The pause between two polls of a bounded wait.  Round 5: up to 174 single-lane pollers used to re-read ONE word every ~0.3 us
+// (s_sleep 4); once in ~10 000 train steps the producer they were waiting for froze -- its slab counters stood still (read back by
+// returning atomics: memory itself held the partial counts) for the 2^22 polls of the watchdog, and it finished the moment the
+// pollers left: the read flood on the counters' line starved the producers' atomic increments, behind which their in-order memory
+// queues (and so their time loops) stalled.  A slab takes ~40 us to complete: a poll every ~1-2 us loses nothing and takes the
+// pressure off the line.  SB_POLL_SLEEP: the s_sleep operand (64 clocks each); the watchdog's poll budget scales with it (~seconds).
+#ifndef SB_POLL_SLEEP
+#define SB_POLL_SLEEP 32
+#endif
+constexpr unsigned kSpinLimit = (1u << 24) / (SB_POLL_SLEEP > 0 ? SB_POLL_SLEEP : 1);     // polls before a bounded wait gives up
+SB_DEVINL void sb_poll_pause() {
+#if SB_POLL_SLEEP > 0
+  __builtin_amdgcn_s_sleep(SB_POLL_SLEEP);
+#endif
+}
+SB_DEVINL void sb_trip(int* status, int site, int index, int seen, int want, unsigned spins, int status_seen) {
   int expected = 0;
-  const int code = (site << 28) | ((index & 0x3FFF) << 14) | ((seen & 0x7F) << 7) | (want & 0x7F);
-  __hip_atomic_compare_exchange_strong(status, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int code = (site << 28) | ((spins > kSpinLimit ? 1 : 0) << 27) | ((index & 0x1FFF) << 14) | ((seen & 0x7F) << 7) | (want & 0x7F);
+  const bool first = __hip_atomic_compare_exchange_strong(status, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SB_TRIP_DEBUG
+  if (first) {
+    __hip_atomic_store(status + 1, (int)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(status + 2, status_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(status + 3, (int)((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16) | (blockIdx.x & 0xFFFF)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#else
+  (void)first; (void)status_seen;
+#endif
+}
+// one look at the watchdog word from inside a bounded wait (every 64th poll): -> true when the wait must end (and the word is set)
+SB_DEVINL bool sb_wait_over(int* status, unsigned spins, int site, int index, const int* flag, int want) {
+  if ((spins & 63u) != 0) return false;
+  const int sv = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (spins <= kSpinLimit && sv == 0) return false;
+#ifdef SB_TRIP_DEBUG
+  if (sv == 0) {      // the timing-out waiter itself: the flag and its neighbours read two ways -- sc1 load vs returning read-modify-write
+    const int ld = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int rmw = __hip_atomic_fetch_or(const_cast<int*>(flag), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ld2 = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(status + 4, ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(status + 5, rmw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(status + 6, ld2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int* base = flag - index;                  // slab / tile flag 0 of the array (index = offset of `flag` in it)
+    for (int i = -4; i < 36; ++i) {                  // control words (-4 .. -1) and the first 36 flags, by RMW
+      const int v = __hip_atomic_fetch_or(const_cast<int*>(base + i), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(status + 12 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(status + 7, (int)(__builtin_readcyclecounter() >> 10), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
+  sb_trip(status, site, index, __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want, spins, sv);
+  return true;
 }
 
 SB_DEVINL f32x4 mfma16(float a, float b, f32x4 c) {

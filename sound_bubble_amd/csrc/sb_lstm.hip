@@ -352,13 +352,14 @@ extern "C" int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream) {
   if (a->save_gates && !a->save_u) return -1003;
   dim3 grid((a->nseq + 15) / 16, a->ndir);
   if (a->lin_w && a->mma != 1) return -1003;                         // fused Linear: fp16 path only
+  if (a->products != 0 && a->products != 3 && !(a->products == 2 && a->mma == 1)) return -1003;
+  if (a->products == 2 && (a->save_gates || a->save_c || a->save_u)) return -1003;      // two products: inference calls only
   if (sb_lstm_fwd_vec_ok(*a)) {                                      // <= 256 (sequence, direction) chains, hs only: one
     const int rc = sb_launch_lstm_fwd_vec(*a, (hipStream_t)stream);  // workgroup per chain, fp32 matrix-vector products
     if (rc) return rc;
     SB_CHECK_LAUNCH();
     return 0;
   }
-  if (a->products != 0 && a->products != 3 && !(a->products == 2 && a->mma == 1)) return -1003;
   if (a->mma == 1 && a->products == 2) { const int rc = sb_launch_lstm_fwd_bf_2p(*a, (hipStream_t)stream); if (rc) return rc; }
   else if (a->mma == 1 || a->mma == 2) { const int rc = sb_launch_lstm_fwd_bf(*a, (hipStream_t)stream); if (rc) return rc; }
   else if (a->C == 32) launch_fwd<32>(*a, grid, (hipStream_t)stream);

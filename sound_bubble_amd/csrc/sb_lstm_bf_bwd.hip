@@ -133,13 +133,8 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       for (int t = lo; t <= hi && !bad; ++t) {
         while (sb_poll(a.slab_flags + t) < need) {
           ++spins;
-          if ((spins & 63u) == 0 &&
-              (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            sb_trip(a.sched_status, SB_TRIP_CROSS_SLABS, t, __hip_atomic_load(a.slab_flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), need);
-            bad = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(4);
+          if (sb_wait_over(a.sched_status, spins, SB_TRIP_CROSS_SLABS, t, a.slab_flags + t, need)) { bad = 1; break; }
+          sb_poll_pause();
         }
       }
       cw_abort = bad;
@@ -1383,13 +1378,8 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       unsigned spins = 0;
       while (sb_poll(pst + ntiles + t) == 0) {
         ++spins;
-        if ((spins & 63u) == 0 &&
-            (spins > kSegSpinLimit || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          sb_trip(a.sched_status, SB_TRIP_CROSS_ROWS, t, __hip_atomic_load(pst + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1 + xcd);
-          bad = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
+        if (sb_wait_over(a.sched_status, spins, SB_TRIP_CROSS_ROWS, t, pst + t, 1 + xcd)) { bad = 1; break; }
+        sb_poll_pause();
       }
       dw_abort = bad;
     }

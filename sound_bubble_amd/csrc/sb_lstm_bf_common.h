@@ -65,7 +65,9 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #define SB_REC_Q24 1
 #endif
 constexpr int kWideGateDwords = SB_REC_Q24 ? 3 * SB_H : 4 * SB_H;      // per sequence, step and direction
-struct RecQ24 { f32x4 p[3]; };
+// (bits of a float BY VALUE: __builtin_bit_cast applied straight to an ext-vector element expression, bit_cast(unsigned, v[k]),
+//  read element 0 for every k with this compiler -- found by the record round-trip test)
+SB_DEVINL unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 SB_DEVINL unsigned q24_sig(float x) {            // [0, 1] -> round(x 2^24), saturated
   const unsigned u = (unsigned)__builtin_fmaf(x, 16777216.0f, 0.5f);
   return u < 0xFFFFFFu ? u : 0xFFFFFFu;
@@ -85,7 +87,7 @@ SB_DEVINL f32x4 q24_codes(const f32x4 g, bool tanh_gate) {
   return r;
 }
 SB_DEVINL f32x4 q24_piece(int p, const f32x4 ci, const f32x4 cf, const f32x4 cg, const f32x4 co) {
-  auto u = [](float x) { return __builtin_bit_cast(unsigned, x); };
+  auto u = [](float x) { return f2u(x); };
   unsigned e0, e1, e2, e3;
   if (p == 0) {
     e0 = __builtin_amdgcn_perm(u(ci[1]), u(ci[0]), 0x04020100u); e1 = __builtin_amdgcn_perm(u(ci[2]), u(ci[1]), 0x05040201u);
@@ -110,7 +112,7 @@ SB_DEVINL void q24_unpack(const f32x4 p0, const f32x4 p1, const f32x4 p2, f32x4&
   unsigned e[12];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    e[k] = __builtin_bit_cast(unsigned, p0[k]); e[4 + k] = __builtin_bit_cast(unsigned, p1[k]); e[8 + k] = __builtin_bit_cast(unsigned, p2[k]);
+    e[k] = f2u(p0[k]); e[4 + k] = f2u(p1[k]); e[8 + k] = f2u(p2[k]);
   }
   unsigned q[4];
   q24_unpack3(e[0], e[1], e[2], q);
@@ -204,7 +206,7 @@ SB_DEVINL SplitN<F16> splitn8(const float (&x)[8]) {
 // the watchdog word is set and the whole workgroup leaves; every other waiter sees the word and leaves too, so the
 // launch ends with garbage outputs and *status != 0 instead of hanging the process.  Returns false on abort (uniform
 // over the workgroup).
-constexpr unsigned kSegSpinLimit = 1u << 22;
+constexpr unsigned kSegSpinLimit = kSpinLimit;
 SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status, int site) {
   __shared__ int seg_abort;
   if (threadIdx.x == 0) {
@@ -212,13 +214,8 @@ SB_DEVINL bool seg_wait(const int* flags, int tile, int seg, int* status, int si
     unsigned spins = 0;
     while (sb_poll(flags + tile) < seg) {
       ++spins;
-      if ((spins & 63u) == 0 &&
-          (spins > kSegSpinLimit || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        sb_trip(status, site, tile, __hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), seg);
-        bad = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
+      if (sb_wait_over(status, spins, site, tile, flags + tile, seg)) { bad = 1; break; }
+      sb_poll_pause();
     }
     seg_abort = bad;
   }

@@ -897,18 +897,17 @@ __global__ void rec_q24_roundtrip_kernel(const float* in, float* out, unsigned* 
   f32x4 g[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) g[k] = ld4(in + (size_t)t * 16 + 4 * k);
-  RecQ24 r;
   const f32x4 ci = q24_codes(g[0], false), cf = q24_codes(g[1], false), cg = q24_codes(g[2], true), co = q24_codes(g[3], false);
-#pragma unroll
-  for (int p = 0; p < 3; ++p) r.p[p] = q24_piece(p, ci, cf, cg, co);
+  const f32x4 p0 = q24_piece(0, ci, cf, cg, co), p1 = q24_piece(1, ci, cf, cg, co), p2 = q24_piece(2, ci, cf, cg, co);
   if (packed) {
+    unsigned* pk = packed + (size_t)t * 12;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) packed[(size_t)t * 12 + 4 * p + k] = __builtin_bit_cast(unsigned, r.p[p][k]);
+    for (int k = 0; k < 4; ++k) {
+      pk[k] = f2u(p0[k]); pk[4 + k] = f2u(p1[k]); pk[8 + k] = f2u(p2[k]);
+    }
   }
   f32x4 o[4];
-  q24_unpack(r.p[0], r.p[1], r.p[2], o[0], o[1], o[2], o[3]);
+  q24_unpack(p0, p1, p2, o[0], o[1], o[2], o[3]);
 #pragma unroll
   for (int k = 0; k < 4; ++k) st4(out + (size_t)t * 16 + 4 * k, o[k]);
 }

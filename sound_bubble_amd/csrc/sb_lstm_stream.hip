@@ -497,13 +497,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_stream_f16_kernel(sb_lstm_stream
       unsigned spins = 0;
       while (sb_poll(a.slab_flags + k) < a.slab_need) {
         ++spins;
-        if ((spins & 63u) == 0 &&
-            (spins > (1u << 22) || __hip_atomic_load(a.sched_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          sb_trip(a.sched_status, SB_TRIP_BWD_STREAM, k, __hip_atomic_load(a.slab_flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.slab_need);
-          slab_abort = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
+        if (sb_wait_over(a.sched_status, spins, SB_TRIP_BWD_STREAM, k, a.slab_flags + k, a.slab_need)) { slab_abort = 1; break; }
+        sb_poll_pause();
       }
       ready_k = k;
     }

@@ -258,25 +258,43 @@ class _FlagArena:
     """One uncached allocation per device, cut into CHUNKS that are handed out round-robin; a chunk is zeroed (write-through
     stores, on the stream that activates it) when it becomes current, its words are handed out once, and by the time the ring
     comes back to it -- NCHUNK chunks = hundreds of train steps later -- the device is synchronised once, so no kernel can still
-    be polling the words.  Word 0 .. 63 are reserved (the watchdog word)."""
+    be polling the words.  The first RESERVED ints are 64 slots of 64 for the watchdog word, which is WRITE-ONCE: after a trip
+    the next slot becomes the word (new_status), the old one is never cleared in place -- in round 5 a word the host had zeroed
+    was seen to come back, two epochs later, with the code it had held."""
     CHUNK = 1 << 15           # ints (128 KB): ~4 train steps of the big model's flags
     NCHUNK = 64
+    RESERVED = 64 * 64
 
     def __init__(self, dev_index):
         self.dev = dev_index
         ptr, kind = C.c_void_p(), C.c_int(-1)
         with torch.cuda.device(dev_index):
-            L.check(L.load().sb_flags_alloc(4 * (64 + self.CHUNK * self.NCHUNK), C.byref(ptr), C.byref(kind)), "sb_flags_alloc")
+            L.check(L.load().sb_flags_alloc(4 * (self.RESERVED + self.CHUNK * self.NCHUNK), C.byref(ptr), C.byref(kind)), "sb_flags_alloc")
             self.base, self.kind = ptr.value, kind.value
             torch.cuda.synchronize(dev_index)
-            L.check(L.load().sb_flags_zero(C.c_void_p(self.base), 64, _stream()), "sb_flags_zero")
+            L.check(L.load().sb_flags_zero(C.c_void_p(self.base), self.RESERVED, _stream()), "sb_flags_zero")
             torch.cuda.synchronize(dev_index)
         if self.kind != 3:
             import warnings
             warnings.warn(f"cuda:{dev_index}: no uncached device memory for the schedule flags (got kind {self.kind}); the "
                           "overlapped schedules run on cached flag words, which were seen to go stale once in a few thousand steps")
         self.next_chunk, self.gen = 0, [0] * self.NCHUNK
+        self.status_slot = 0
         self.status = FlagWords(self.base, 1, dev_index)
+
+    def new_status(self):
+        """the watchdog word moves to the next slot (zeroed, device synchronised: rare path, after a trip)"""
+        self.status_slot = (self.status_slot + 1) % 64
+        self.status = FlagWords(self.base + 4 * 64 * self.status_slot, 1, self.dev)
+        with torch.cuda.device(self.dev):
+            torch.cuda.synchronize(self.dev)
+            L.check(L.load().sb_flags_zero(C.c_void_p(self.status.ptr), 64, _stream()), "sb_flags_zero")
+            torch.cuda.synchronize(self.dev)
+        return self.status
+
+    def status_debug(self):
+        """the 8 ints at the watchdog word (a -DSB_TRIP_DEBUG library fills [1..3]: polls, the word as read, XCC << 16 | workgroup)"""
+        return FlagWords(self.status.ptr, 56, self.dev).cpu().tolist()
 
     def new_chunk(self):
         """-> (chunk index, byte address, generation) of a fresh chunk, zeroed on the current stream"""
@@ -285,7 +303,7 @@ class _FlagArena:
         if k == 0 and self.gen[0] > 0 and not torch.cuda.is_current_stream_capturing():
             torch.cuda.synchronize(self.dev)                 # (once per NCHUNK chunks: every word of the ring is dead)
         self.gen[k] += 1
-        addr = self.base + 4 * (64 + k * self.CHUNK)
+        addr = self.base + 4 * (self.RESERVED + k * self.CHUNK)
         with torch.cuda.device(self.dev):
             L.check(L.load().sb_flags_zero(C.c_void_p(addr), self.CHUNK, _stream()), "sb_flags_zero")
         return k, addr, self.gen[k]
@@ -330,24 +348,27 @@ def decode_trip(word):
     word = int(word) & 0xFFFFFFFF
     site = word >> 28
     return {"word": word, "site": site, "what": TRIP_SITES.get(site, "unknown site (a pre-round-5 library writes 1)"),
-            "index": (word >> 14) & 0x3FFF, "seen": (word >> 7) & 0x7F, "wanted": word & 0x7F}
+            "timed_out": bool((word >> 27) & 1),       # False: the waiter left because it found the word already set
+            "index": (word >> 14) & 0x1FFF, "seen": (word >> 7) & 0x7F, "wanted": word & 0x7F}
 
 
 def read_sched_status():
     """synchronises; -> list of device indices whose watchdog word was set (and clears those words; what the words said is
     appended to LAST_TRIPS)"""
     bad = []
-    for i, t in _SCHED_STATUS.items():
+    for i, t in list(_SCHED_STATUS.items()):
         v = int(t.item())
         if v != 0:
-            t.zero_()
+            d = decode_trip(v)
+            d["debug_words"] = flag_arena(i).status_debug()
+            _SCHED_STATUS[i] = flag_arena(i).new_status()            # (write-once words: never cleared in place)
             bad.append(i)
-            LAST_TRIPS.append((i, decode_trip(v)))
+            LAST_TRIPS.append((i, d))
     return bad
 
 
 def _trip_text(devs):
-    return "; ".join(f"cuda:{i}: {d['what']} (index {d['index']}, flag {d['seen']} of {d['wanted']} mod 128)"
+    return "; ".join(f"cuda:{i}: {d['what']} (index {d['index']}, flag {d['seen']} of {d['wanted']} mod 128, {'timed out' if d['timed_out'] else 'found the word set'})"
                      for i, d in LAST_TRIPS[-len(devs):]) if devs else ""
 
 
@@ -373,11 +394,11 @@ def check_sched_status_all_ranks():
 def check_sched_status():
     """Synchronises and raises if a segmented launch gave up waiting for a co-resident workgroup (its outputs are then
     garbage).  Called after the timed region by bench.py, once per epoch by the harness, and by the tests."""
-    for i, t in _SCHED_STATUS.items():
+    for i, t in list(_SCHED_STATUS.items()):
         v = int(t.item())
         if v != 0:
-            t.zero_()
             LAST_TRIPS.append((i, decode_trip(v)))
+            _SCHED_STATUS[i] = flag_arena(i).new_status()
             raise L.SoundBubbleHipError(
                 f"cuda:{i}: a time-segmented / overlapped LSTM launch aborted [{_trip_text([i])}] (its workgroups were not co-resident -- GPU shared or "
                 "CU-masked?).  Results since the last check are invalid; set SB_NO_TIME_SEGMENTS=1 or "

@@ -157,6 +157,37 @@ def test_forward_matches_reference_goldens(torch_gpu, name, cls):
         assert e < TOL_FWD, (k, e)
 
 
+@pytest.mark.parametrize("name,cls", [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"), ("small_1s", "NetOptim")])
+def test_two_product_forward_is_opt_in_engaged_and_inside_the_north_star_bar(torch_gpu, name, cls, monkeypatch):
+    """SB_LSTM_PRODUCTS=2 (sb_lstm_fwd_args.products = 2): activations as one fp16 term in the recurrent products.  Not fp32-class
+    -- it must differ from the default arithmetic (else the switch did nothing), stay inside the north star's 1e-3 against the
+    reference goldens, never touch a training forward (records keep the default arithmetic), and refuse records at the C ABI."""
+    torch = torch_gpu
+    import ctypes as C
+    from sound_bubble_amd import _lib as L, ops
+    rec, params, m = _build(torch, name, cls)
+    with torch.no_grad():
+        base = m(_inputs(torch, rec))["output"].cpu().numpy()
+    monkeypatch.setattr(ops, "LSTM_PRODUCTS", 2)
+    with torch.no_grad():
+        two = m(_inputs(torch, rec))["output"].cpu().numpy()
+    e_ref, e_base = rel_l2(two, rec["output"]), rel_l2(two, base)
+    print(f"{name}: two-product forward rel-L2 {e_ref:.2e} vs the reference golden, {e_base:.2e} vs the default arithmetic")
+    assert 1e-7 < e_base and e_ref < 1e-3, (e_base, e_ref)
+    m.train()                                              # a training forward ignores the switch: bit-identical to the default
+    out_t = m(_inputs(torch, rec))["output"]
+    monkeypatch.setattr(ops, "LSTM_PRODUCTS", 3)
+    out_d = m(_inputs(torch, rec))["output"]
+    assert torch.equal(out_t, out_d)
+    a = L.LstmFwdArgs()                                    # records + two products: refused
+    a.nseq, a.nsteps, a.n_inner, a.ndir, a.C, a.mma, a.products = 16, 4, 16, 1, 32, 1, 2
+    dummy = torch.zeros(16 * 4 * 1024, device="cuda")
+    a.save_gates = a.save_c = a.save_u = C.c_void_p(dummy.data_ptr())
+    assert L.load().sb_lstm_fwd(C.byref(a), None) == -1003
+    a.products, a.save_gates, a.save_c, a.save_u = 5, None, None, None                  # unknown product count
+    assert L.load().sb_lstm_fwd(C.byref(a), None) == -1003
+
+
 def test_forward_small_config_1s(torch_gpu):
     torch = torch_gpu
     rec, params, m = _build(torch, "small_1s", "NetOptim")
@@ -1575,7 +1606,7 @@ def test_hs_free_inter_pass_survives_a_lost_side_stream(torch_gpu, monkeypatch):
 
 @pytest.mark.parametrize("with_h0", [False, True], ids=["zero-state", "carried-state"])
 @pytest.mark.parametrize("B_,T_,F_", [(2, 150, 21), (1, 37, 16)], ids=["ragged-150", "full-tiles-odd-37"])
-def test_wide_gate_recompute_equals_the_recorded_gates_bit_for_bit(torch_gpu, B_, T_, F_, with_h0, monkeypatch):
+def test_wide_gate_recompute_equals_the_recorded_gates(torch_gpu, B_, T_, F_, with_h0, monkeypatch):
     """Round 4 (record diet): the inter-frame forward with NO gate records (rec_f32 with save_gates == NULL: c_prev + the u / hs
     pairs) writes the same y / hs / c_prev as with them, and the backward pair whose recurrence recomputes the gates
     (lstm_bwd_rec_bf_kernel<.., SLAB, XP, GREC>) gives the gradients of the pair that reads recorded gates -- to the BIT:
@@ -1622,12 +1653,16 @@ def test_wide_gate_recompute_equals_the_recorded_gates_bit_for_bit(torch_gpu, B_
     torch.cuda.synchronize()
     ops.check_sched_status()
     assert dx0 is not None and dx1 is not None and torch.isfinite(dx1).all() and float(dx1.abs().max()) > 0
-    assert torch.equal(dx1, dx0)               # per-position result: same dgates bits in, same bits out
+    if ops.wide_rec_dwords() == 256:           # fp32 gate records (-DSB_REC_Q24=0): same dgates bits in, same bits out
+        assert torch.equal(dx1, dx0)
+    else:                                      # round 5: the RECORDED gates are 24-bit fixed point (error <= 2^-25 / 2^-24 absolute),
+        e = rel_l2(dx1.cpu().numpy(), dx0.cpu().numpy())   # the recomputed ones the forward's own fp32 values
+        assert e < 5e-6, e
     # (the weight gradients are sums of per-workgroup partial rows whose chunk units are drawn from an atomic counter: equal
     # up to the summation order, as between any two runs of the same pair)
     for name, a_, b_ in zip(("dW_ih", "dW_hh", "db_ih", "db_hh", "dW_lin", "db_lin", "d_ln_g", "d_ln_b"),
                             tg1 + list(lin1) + list(ln1), tg0 + list(lin0) + list(ln0)):
-        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-6, name
+        assert rel_l2(a_.cpu().numpy(), b_.cpu().numpy()) < (2e-6 if ops.wide_rec_dwords() == 256 else 1e-5), name
 
 
 @pytest.mark.parametrize("P,N,K,res", [(6, 304, 288, False), (2, 288, 304, False), (29, 80, 128, True), (200, 64, 32, True),
