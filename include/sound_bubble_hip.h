@@ -148,6 +148,10 @@ typedef struct {
      mode -- activations as ONE fp16 term against hi + lo weights, two products per MAC (11-bit activations: NOT fp32-class; the
      bench reports its rel-L2 against the default beside its speed).  -1003 with records / side outputs requested. */
   int products;
+  /* overlapped forward, consumer launch next to the producer (ord_guard != 0): its workgroups claim an item only once the slab it
+     needs is complete, so a wait that runs out (~seconds) costs nothing but their help -- the launch behind the producer does what
+     is left, the outputs stay correct.  ord_giveups (nullable): counts such waits, for the caller's health report. */
+  int* ord_giveups;
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 /* dwords per (sequence, step, direction) of the wide gate records (save_gates with rec_f32): 192 (24-bit fixed point), or 256

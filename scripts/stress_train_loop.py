@@ -67,6 +67,7 @@ def dump_recent():
 
 
 trips, nans, steps = 0, 0, 0
+ep_med, t_ep0 = 1.0, time.time()
 t00 = time.time()
 for epoch in range(args.epochs):
     seed_all(epoch)
@@ -99,6 +100,17 @@ for epoch in range(args.epochs):
         dump_recent()
         seed_all(1000 + epoch)
         hl = import_attr(params["pl_module"])(**params["pl_module_args"])           # (the parameters are garbage now: start over)
+    t_ep = time.time() - t_ep0 if epoch else 0.0
+    if epoch > 3 and t_ep > 3 * ep_med:
+        print(f"epoch {epoch}: SLOW {t_ep:.2f}s (typical {ep_med:.2f}s)", flush=True)
+    elif epoch > 0:
+        ep_med = 0.9 * ep_med + 0.1 * t_ep if epoch > 1 else t_ep
+    t_ep0 = time.time()
     if epoch % 50 == 0:
         print(epoch, f"loss {l:.4f} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s", flush=True)
+print("forward-consumer give-ups (harmless):", ops.read_giveups(), flush=True)
+try:
+    print("watchdog debug words at the end (a -DSB_TRIP_DEBUG library: [52] = longest wait in polls):", ops.flag_arena(0).status_debug(), flush=True)
+except Exception as e:
+    print("no debug words:", e)
 print(f"DONE epochs {args.epochs} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s args {vars(args)}")

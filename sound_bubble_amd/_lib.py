@@ -29,7 +29,7 @@ class LstmFwdArgs(C.Structure):
                 ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_need", C.c_int),
                 ("tile_order", C.c_void_p), ("tile_need", C.c_void_p), ("ord_counter", C.c_void_p),
                 ("ord_started", C.c_void_p), ("ord_guard", C.c_int), ("ord_grid", C.c_int), ("rec_f32", C.c_int),
-                ("no_vec", C.c_int), ("products", C.c_int)]
+                ("no_vec", C.c_int), ("products", C.c_int), ("ord_giveups", C.c_void_p)]
 
 
 class LstmBwdArgs(C.Structure):

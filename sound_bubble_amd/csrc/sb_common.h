@@ -40,11 +40,15 @@ SB_DEVINL int sb_poll(const int* p) {
 // returning atomics: memory itself held the partial counts) for the 2^22 polls of the watchdog, and it finished the moment the
 // pollers left: the read flood on the counters' line starved the producers' atomic increments, behind which their in-order memory
 // queues (and so their time loops) stalled.  A slab takes ~40 us to complete: a poll every ~1-2 us loses nothing and takes the
-// pressure off the line.  SB_POLL_SLEEP: the s_sleep operand (64 clocks each); the watchdog's poll budget scales with it (~seconds).
+// pressure off the line.  SB_POLL_SLEEP: the s_sleep operand (64 clocks each: 100 = ~3 us); the watchdog's poll budget scales with it (~2 s).
 #ifndef SB_POLL_SLEEP
-#define SB_POLL_SLEEP 32
+#define SB_POLL_SLEEP 100
 #endif
-constexpr unsigned kSpinLimit = (1u << 24) / (SB_POLL_SLEEP > 0 ? SB_POLL_SLEEP : 1);     // polls before a bounded wait gives up
+#ifdef SB_SPIN_LIMIT_LOG2
+constexpr unsigned kSpinLimit = 1u << SB_SPIN_LIMIT_LOG2;
+#else
+constexpr unsigned kSpinLimit = (3u << 24) / (SB_POLL_SLEEP > 0 ? SB_POLL_SLEEP : 1);     // polls before a bounded wait gives up (~2 s)
+#endif
 SB_DEVINL void sb_poll_pause() {
 #if SB_POLL_SLEEP > 0
   __builtin_amdgcn_s_sleep(SB_POLL_SLEEP);
@@ -67,6 +71,10 @@ SB_DEVINL void sb_trip(int* status, int site, int index, int seen, int want, uns
 // one look at the watchdog word from inside a bounded wait (every 64th poll): -> true when the wait must end (and the word is set)
 SB_DEVINL bool sb_wait_over(int* status, unsigned spins, int site, int index, const int* flag, int want) {
   if ((spins & 63u) != 0) return false;
+#ifdef SB_TRIP_DEBUG
+  if ((spins & 0xFFFFu) == 0)        // the longest wait seen so far, in polls (granularity 65 536): [52]
+    __hip_atomic_fetch_max(status + 52, (int)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   const int sv = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (spins <= kSpinLimit && sv == 0) return false;
 #ifdef SB_TRIP_DEBUG

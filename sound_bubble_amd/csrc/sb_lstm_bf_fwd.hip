@@ -43,8 +43,39 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   const bool prod = LIN && !ORD && !SEG && a.slab_flags != nullptr;      // producer side of the overlapped forward
   if (prod && tid == 0) __hip_atomic_fetch_add(a.ord_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __shared__ int ord_item;
-  auto ord_next = [&]() -> int {                     // next (tile, this direction) item; uniform over the workgroup
-    if (tid == 0) ord_item = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // next (tile, this direction) item; uniform over the workgroup.  Behind the producer (ord_guard == 0: every slab is complete) a
+  // plain draw.  NEXT to the producer (ord_guard != 0) a workgroup claims the next item only once the slab it needs is complete
+  // (items are sorted by that slab), so a WAITING workgroup holds nothing: whatever happens to it -- a producer that stands still
+  // for a second (seen once in ~10 000 train steps: see sb_common.h, SB_POLL_SLEEP), a wait that runs out -- every unclaimed item
+  // is left to the launch behind the producer and the outputs stay correct.  (Round 4 drew first and waited with the item in
+  // hand: a wait that ran out dropped it, and the step's outputs were garbage behind a watchdog word read once per epoch.)  A
+  // wait that runs out only stops this workgroup from helping and counts itself into *ord_giveups (nullable).
+  auto ord_next = [&]() -> int {
+    if (tid == 0) {
+      const int nt = (a.nseq + 15) / 16;
+      int it = nt;
+      if (!ORD || !a.ord_guard) {
+        it = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        unsigned spins = 0;
+        for (;;) {
+          const int c = __hip_atomic_load(a.ord_counter + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (c >= nt) { it = c; break; }
+          if (sb_poll(a.slab_flags + a.tile_need[c]) >= a.slab_need) {
+            int expected = c;
+            if (__hip_atomic_compare_exchange_strong(a.ord_counter + dir, &expected, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) { it = c; break; }
+            continue;                                  // somebody else took item c: look at the next one
+          }
+          if (++spins > kSpinLimit) {                  // stop helping; nothing is held, nothing is lost
+            if (a.ord_giveups) __hip_atomic_fetch_add(a.ord_giveups, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          sb_poll_pause();
+        }
+      }
+      ord_item = it;
+    }
     __syncthreads();
     return ord_item;
   };

@@ -252,8 +252,8 @@ class IntraPlainFn(torch.autograd.Function):
             lg, lb = gt("ln_g", ln_g), gt("ln_b", ln_b)
             dx = ops.ln_film_bwd(du, x.view(P, Cc), ln_g, dy.view(P, Cc), y_pre, f_w, bank["G"][k, 0], bank["G"][k, 1],
                                  lg, lb, (B, T, F, Cc), defer_ok=gt["ln_g"] is None and gt["ln_b"] is None)
-            ops.FILM_DONE.clear()
-            ops.FILM_DONE[dx.data_ptr()] = True
+            ops.FILM_DONE[dx.data_ptr()] = True           # (consumed by the previous block's InterFn.backward; leftovers raise at the end)
+            ops.arm_handover_check()
         else:
             dx, _, _, _ = ops.ln_bwd(du, x.view(P, Cc), ln_g, res=dy.view(P, Cc), d_g=gt("ln_g", ln_g), d_b=gt("ln_b", ln_b),
                                      hint=True)
@@ -422,6 +422,7 @@ class InterFn(torch.autograd.Function):
                                 None, None, dx, keep + [flags, du, x, dy, ln_g])
             if overlapped:                     # (this LayerNorm's parameter gradients come out of the consumer node: IntraPlainFn)
                 ops.CROSS_PENDING[dx.data_ptr()] = pend
+                ops.arm_handover_check()
                 gt.ret["ln_g"] = gt.ret["ln_b"] = None
             else:
                 pend.d_ln_g, pend.d_ln_b = gt("ln_g", ln_g), gt("ln_b", ln_b)

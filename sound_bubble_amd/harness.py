@@ -183,6 +183,13 @@ class PLModule(object):
         # raising rank would leave the others hanging in the next all-reduce); and is the side stream still concurrent?
         ops.check_sched_status_all_ranks()
         if ops._OVERLAP_OK:
+            g = ops.read_giveups()
+            if g != getattr(self, "_giveups_seen", 0):
+                import warnings
+                warnings.warn(f"{g - getattr(self, '_giveups_seen', 0)} workgroup(s) of the overlapped forward stopped waiting for their "
+                              "producer this epoch (results unaffected: the launch behind the producer did their items; the step "
+                              "that happened in took seconds)")
+                self._giveups_seen = g
             ops.overlap_reprobe()
         last = self.get_avg_metric_at_epoch(self.monitor)
         best = all(not (last > self.get_avg_metric_at_epoch(self.monitor, e)) for e in range(len(self.metric_values) - 1))

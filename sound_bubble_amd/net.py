@@ -321,6 +321,7 @@ class _NetBase(nn.Module):
             n = self.__dict__["_ovl_fwd_count"] = self.__dict__.get("_ovl_fwd_count", 0) + 1
             if n % 64 == 0:
                 Fn.ops.check_sched_status()
+        Fn.ops.FILM_OF.clear()                     # (a hand-over nobody took -- e.g. a conv-LSTM block -- must not outlive this forward)
         Fn.WORKSPACE = None                        # (the staging workspaces belong to THIS model's forward only)
         return {"output": out, "next_state": st}
 

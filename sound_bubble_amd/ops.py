@@ -284,7 +284,7 @@ class _FlagArena:
 
     def new_status(self):
         """the watchdog word moves to the next slot (zeroed, device synchronised: rare path, after a trip)"""
-        self.status_slot = (self.status_slot + 1) % 64
+        self.status_slot = (self.status_slot + 1) % 63
         self.status = FlagWords(self.base + 4 * 64 * self.status_slot, 1, self.dev)
         with torch.cuda.device(self.dev):
             torch.cuda.synchronize(self.dev)
@@ -350,6 +350,19 @@ def decode_trip(word):
     return {"word": word, "site": site, "what": TRIP_SITES.get(site, "unknown site (a pre-round-5 library writes 1)"),
             "timed_out": bool((word >> 27) & 1),       # False: the waiter left because it found the word already set
             "index": (word >> 14) & 0x1FFF, "seen": (word >> 7) & 0x7F, "wanted": word & 0x7F}
+
+
+def giveups_word(dev):
+    """one int32 of the flag arena: overlapped-forward consumer workgroups that stopped waiting for their producer (harmless to the
+    results -- the launch behind the producer does what is left -- but a sign that a producer stood still for seconds)"""
+    i = dev.index if isinstance(dev, torch.device) and dev.index is not None else (dev if isinstance(dev, int) else torch.cuda.current_device())
+    a = flag_arena(i)
+    return FlagWords(a.base + 4 * (a.RESERVED - 64), 1, i)         # (the last watchdog slot is never used as one: new_status cycles 0 .. 62)
+
+
+def read_giveups(dev=None):
+    """synchronises; -> give-ups counted on the device since start-up"""
+    return giveups_word(dev if dev is not None else torch.cuda.current_device()).item()
 
 
 def read_sched_status():
@@ -552,7 +565,7 @@ def overlap_lost():
 # end of the backward pass (autograd's final callbacks run after the last node, before backward() returns to the caller: every
 # reader of a .grad / the flat bucket is behind the join).  SB_NO_DEFERRED_REDUCE=1: everything on the main stream as before.
 DEFER_REDUCE = os.environ.get("SB_NO_DEFERRED_REDUCE", "0") != "1"
-_DEFER = {"armed": False, "stream": None, "keep": [], "pending": []}
+_DEFER = {"armed": False, "stream": None, "dev": 0, "keep": [], "pending": []}
 
 
 def deferred_flush():
@@ -570,7 +583,11 @@ def deferred_join():
     if _DEFER["armed"]:
         _DEFER["armed"] = False
         SCHED_COUNTS["deferred_joins"] += 1          # (bench.py `schedules`: backward passes whose small launches rode on the side stream)
-        L.check(L.load().sb_overlap_join(_DEFER["stream"]), "sb_overlap_join")
+        # the library finds the side stream through the CALLING thread's current device: the engine's final callback may run on a
+        # thread whose current device is not the model's -- join under the device the launches were deferred on
+        import contextlib
+        with (torch.cuda.device(_DEFER["dev"]) if torch.cuda.is_available() else contextlib.nullcontext()):
+            L.check(L.load().sb_overlap_join(_DEFER["stream"]), "sb_overlap_join")
     _DEFER["keep"].clear()
 
 
@@ -589,7 +606,7 @@ def defer_small_launches(keep=()):
         torch.autograd.Variable._execution_engine.queue_callback(deferred_join)
     except RuntimeError:                                # not inside a backward pass: nobody would run the join
         return False
-    _DEFER["armed"], _DEFER["stream"] = True, st
+    _DEFER["armed"], _DEFER["stream"], _DEFER["dev"] = True, st, torch.cuda.current_device()
     _DEFER["keep"].extend(keep)
     return True
 
@@ -729,6 +746,7 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
         consume = None
     if consume is not None:
         a.sched_status = C.c_void_p(sched_status(dev).data_ptr())
+        a.ord_giveups = C.c_void_p(giveups_word(dev).data_ptr())
     with _Prof(label + (" [producer]" if produce is not None else " [consumer, overlapped]" if consume is not None else ""),
                2.0 * 4 * H * (Cc + H) * geom.P * ndir + (2.0 * H * Cc * geom.P if lin is not None else 0.0),
                8.0 * Cc * geom.P, by, side=consume is not None):
@@ -1096,6 +1114,36 @@ def can_fuse_stream(u, hs, geom=None):
 BWD_CROSS_OVERLAP = os.environ.get("SB_NO_BWD_CROSS_OVERLAP", "0") != "1"
 BWD_CROSS_SLAB = int(os.environ.get("SB_BWD_CROSS_SLAB", "32"))
 CROSS_PENDING = {}        # data_ptr of the (not yet computed) dy1 buffer -> CrossBwd, from InterFn.backward to IntraPlainFn.backward
+_HANDOVER = {"armed": False}
+
+
+def arm_handover_check():
+    """The cross-pass backward hands an UNFILLED gradient buffer through autograd (CROSS_PENDING: the next node's kernel fills it),
+    and the fused LayerNorm + FiLM backward marks a gradient that already carries the FiLM factor (FILM_DONE); both hand-overs are
+    keyed by data_ptr and assume the very tensor reaches the next node.  A tensor hook, retain_grad or gradient accumulation in
+    between hands the node a COPY: the entry is then never consumed and the gradients are silently wrong.  Queued once
+    per backward pass as an engine final callback: anything left over raises."""
+    if _HANDOVER["armed"]:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_handover_check)
+    except RuntimeError:                                # not inside a backward pass (direct calls in tests): nothing to guard
+        return
+    _HANDOVER["armed"] = True
+
+
+def _handover_check():
+    _HANDOVER["armed"] = False
+    left_c, left_f = len(CROSS_PENDING), len(FILM_DONE)
+    for pend in CROSS_PENDING.values():
+        pend.keep.clear()
+    CROSS_PENDING.clear()
+    FILM_DONE.clear()
+    if left_c or left_f:
+        raise L.SoundBubbleHipError(
+            f"backward pass ended with {left_c} cross-pass and {left_f} FiLM hand-over(s) unconsumed: a gradient tensor between "
+            "InterFn and IntraPlainFn was copied on the way (tensor hook / retain_grad / accumulation?), the gradients of this pass "
+            "are invalid.  SB_NO_BWD_CROSS_OVERLAP=1 / SB_NO_LN_FILM_FUSION=1 run the plain order.")
 
 
 class CrossBwd:

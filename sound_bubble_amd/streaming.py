@@ -92,6 +92,8 @@ class StreamingSeparator(torch.nn.Module):
         self._param_key = None
         self._dirty = False
         self._seen_registrations = -1
+        ps = list(model.parameters())
+        self._ends, self._end_ptrs, self._feeds = (ps[0], ps[-1]), None, 0   # (Parameter objects: replaced ones are caught by the registration count)
         self._pinned = None                                       # (Workspaces, keys) held by the captured graph
         self.use_graph = use_graph
         me = weakref.ref(self)                                    # the hook must not keep the separator (and its graph) alive
@@ -177,7 +179,14 @@ class StreamingSeparator(torch.nn.Module):
         # module.weight = ...); in-place updates need nothing -- the weight-form refresh is one of the captured launches.
         # Walking all parameters costs ~50 us of Python, a sixth of a chunk: done only when a parameter was registered
         # somewhere since the last look (one integer compare per chunk) or a load_state_dict ran on the model.
-        if self.graph is None or self._dirty or self._seen_registrations != _PARAM_REGISTRATIONS[0]:
+        # ... and, cheaply, every chunk: the addresses of the first and the last parameter (model.to() / .half() / a FlatBucket built
+        # after this separator re-point p.data through neither hook; all parameters move together in those cases), with the full
+        # walk every 256th chunk as the backstop (a replay against freed weights is silently wrong audio)
+        self._feeds += 1
+        ends = (self._ends[0].data_ptr(), self._ends[1].data_ptr())
+        if (self.graph is None or self._dirty or self._seen_registrations != _PARAM_REGISTRATIONS[0] or ends != self._end_ptrs
+                or self._feeds % 256 == 0):
+            self._end_ptrs = ends
             self._seen_registrations = _PARAM_REGISTRATIONS[0]
             key = tuple((id(p), p.data_ptr()) for p in self.model.parameters())
             if self.graph is None or key != self._param_key:
