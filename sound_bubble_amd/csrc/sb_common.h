@@ -35,12 +35,16 @@ SB_DEVINL int sb_poll(const int* p) {
 // sound_bubble_hip.h: SB_TRIP_*; timed_out = 0: the waiter left because it found the word already set) -- every later waiter
 // finds the word set and leaves without touching it.  -DSB_TRIP_DEBUG (developer builds; the word then needs 8 ints, as the
 // library's own flag arena gives it): [1] polls done, [2] the word's value as the waiter read it, [3] XCC id << 16 | workgroup.
-// The pause between two polls of a bounded wait.  Round 5: up to 174 single-lane pollers used to re-read ONE word every ~0.3 us
-// (s_sleep 4); once in ~10 000 train steps the producer they were waiting for froze -- its slab counters stood still (read back by
-// returning atomics: memory itself held the partial counts) for the 2^22 polls of the watchdog, and it finished the moment the
-// pollers left: the read flood on the counters' line starved the producers' atomic increments, behind which their in-order memory
-// queues (and so their time loops) stalled.  A slab takes ~40 us to complete: a poll every ~1-2 us loses nothing and takes the
-// pressure off the line.  SB_POLL_SLEEP: the s_sleep operand (64 clocks each: 100 = ~3 us); the watchdog's poll budget scales with it (~2 s).
+// The pause between two polls of a bounded wait.  Round 5, measured (scripts/stress_train_loop.py, -DSB_TRIP_DEBUG builds): about
+// once in 5 000-10 000 train steps an overlapped FORWARD producer stops making progress while ~170 single-lane consumer pollers
+// wait on its slab counter -- the counters, read back by returning atomics from the timing-out waiter, stand still in memory
+// itself (no stale cache line: the words are uncached), tiles frozen at different steps -- and it resumes the moment the pollers
+// leave: with the watchdog at 2^22 polls the freeze lasts 0.5 s, at 2^24 polls 16.3 s, every time.  One hot word is incremented by
+// all 82 producer tiles and polled by every waiter; the cross-pass backward, whose producer tiles each own a word, never showed it
+// in 300 000 launches.  Poll rate (s_sleep 0 / 4 / 32) and poll flavour (sc1 load / returning atomic) did not change the rate of
+// the event.  What the library does about it: the forward consumer holds nothing while it waits (sb_lstm_bf_fwd.hip: ord_next) and
+// gives up after ~50 ms, so the event costs that step 50 ms and nothing else; polls are ~3 us apart (a slab takes ~40 us).
+// SB_POLL_SLEEP: the s_sleep operand (64 clocks each); the watchdog's poll budget scales with it (~2 s).
 #ifndef SB_POLL_SLEEP
 #define SB_POLL_SLEEP 100
 #endif
@@ -49,6 +53,8 @@ constexpr unsigned kSpinLimit = 1u << SB_SPIN_LIMIT_LOG2;
 #else
 constexpr unsigned kSpinLimit = (3u << 24) / (SB_POLL_SLEEP > 0 ? SB_POLL_SLEEP : 1);     // polls before a bounded wait gives up (~2 s)
 #endif
+// ... and of a wait that holds nothing (the overlapped forward's consumer next to its producer: giving up costs its help only): ~50 ms
+constexpr unsigned kHelpSpinLimit = kSpinLimit / 40 > 64 ? kSpinLimit / 40 : 64;
 SB_DEVINL void sb_poll_pause() {
 #if SB_POLL_SLEEP > 0
   __builtin_amdgcn_s_sleep(SB_POLL_SLEEP);

@@ -69,7 +69,9 @@ constexpr int kWideGateDwords = SB_REC_Q24 ? 3 * SB_H : 4 * SB_H;      // per se
 //  read element 0 for every k with this compiler -- found by the record round-trip test)
 SB_DEVINL unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 SB_DEVINL unsigned q24_sig(float x) {            // [0, 1] -> round(x 2^24), saturated
-  const unsigned u = (unsigned)__builtin_fmaf(x, 16777216.0f, 0.5f);
+  // (round to nearest: x 2^24 is already an integer for x >= 0.5 -- adding 0.5 and truncating rounded every odd one of those UP,
+  //  a whole step of error where the code is exact; found by the record test's error bound)
+  const unsigned u = (unsigned)__builtin_rintf(x * 16777216.0f);
   return u < 0xFFFFFFu ? u : 0xFFFFFFu;
 }
 SB_DEVINL unsigned q24_tanh(float x) {           // [-1, 1] -> round(x 2^23) as 24-bit two's complement, saturated at 1 - 2^-23

@@ -67,7 +67,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
                                                      __HIP_MEMORY_SCOPE_AGENT)) { it = c; break; }
             continue;                                  // somebody else took item c: look at the next one
           }
-          if (++spins > kSpinLimit) {                  // stop helping; nothing is held, nothing is lost
+          if (++spins > kHelpSpinLimit) {              // (~50 ms: dozens of producer passes) stop helping; nothing is held, nothing is lost
             if (a.ord_giveups) __hip_atomic_fetch_add(a.ord_giveups, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }

@@ -25,9 +25,8 @@ def _ref(x):
     """groups of 16 = gates i, f, g, o x 4 units -> (decoded fp32 values, the 24-bit codes)"""
     g = x.reshape(-1, 4, 4).astype(np.float64)
     q = np.empty(g.shape, np.int64)
-    for k in (0, 1, 3):                              # [0, 1]: trunc(fma(x, 2^24, 0.5)) saturated at 2^24 - 1
-        v = (g[:, k] * 2.0 ** 24 + 0.5).astype(np.float32)          # (one rounding, as the fma)
-        q[:, k] = np.minimum(np.trunc(v).astype(np.int64), 2 ** 24 - 1)
+    for k in (0, 1, 3):                              # [0, 1]: round-to-nearest-even of x 2^24 (exact in fp32), saturated at 2^24 - 1
+        q[:, k] = np.minimum(np.rint(g[:, k] * 2.0 ** 24).astype(np.int64), 2 ** 24 - 1)
     q[:, 2] = np.minimum(np.rint(g[:, 2] * 2.0 ** 23).astype(np.int64), 2 ** 23 - 1)           # [-1, 1]: two's complement
     dec = q.astype(np.float64)
     dec[:, (0, 1, 3)] *= 2.0 ** -24
