@@ -49,9 +49,12 @@ def test_film_bank_matches_per_layer_autograd(n, B, F, C, d_in):
     sum((p * c.cuda()).sum() for p, c in zip(planes, coef)).backward()
     for t, w in zip(ps, want):
         assert t.grad is not None and t.grad.shape == t.shape
-        err = float((t.grad.cpu().double() - w).norm() / max(float(w.norm()), 1e-30)) if float(w.norm()) > 0 \
-            else float(t.grad.abs().max())
-        assert err < 2e-5, (tuple(t.shape), err)
+        # LayerNorm over d_in = 1 feature is the constant beta (zero gradient into the embedding), over 2 features a sign with an
+        # eps-sized slope: W_e's gradient is then (nearly) zero against rounding noise of the terms that cancel -- measure it
+        # against the scale of what cancels, not against itself
+        scale = max(float(w.norm()), 1e-6 * float(sum(float(c.norm()) for c in coef)) if d_in <= 2 else 1e-30)
+        err = float((t.grad.cpu().double() - w).norm()) / scale
+        assert err < (2e-4 if d_in <= 2 else 2e-5), (tuple(t.shape), err)
 
 
 def test_film_bank_accumulates_into_flat_bucket_targets_and_is_deterministic():

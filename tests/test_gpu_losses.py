@@ -16,9 +16,12 @@ def _batch(torch, B=6, N=24000, seed=0):
     est = gt + 0.05 * torch.randn(B, 1, N, generator=g)
     est[1] = 0.3 * gt[1] + 0.001 * torch.randn(1, N, generator=g)      # a scaled target: SI-SDR high, SNR poor
     est[2] += 0.2                                                      # a DC offset: removed by the zero-mean convention
-    gt[3] = 0.0                                                        # silent targets: neg_weight * L1, shared by both
-    gt[5] = 0.0
-    est[4] = 2.5 * gt[4] + 0.02 * torch.randn(1, N, generator=g)       # an over-scaled target: sdsdr < sisdr
+    if B > 5:
+        gt[3] = 0.0                                                    # silent targets: neg_weight * L1, shared by both
+        gt[5] = 0.0
+        est[4] = 2.5 * gt[4] + 0.02 * torch.randn(1, N, generator=g)   # an over-scaled target: sdsdr < sisdr
+    else:
+        gt[B - 1] = 0.0
     return est, gt
 
 
@@ -36,7 +39,8 @@ def test_every_snr_loss_name_matches_the_oracle(name):
     loss, lv = mod.mean_loss(e, gt.cuda())
     (3.0 * loss).backward()
     np.testing.assert_allclose(lv.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(mod(est.cuda(), gt.cuda()).cpu().numpy(), lv.detach().cpu().numpy(), rtol=0, atol=0)
+    # (a second evaluation: the moment sums are atomic float adds, so two runs agree to rounding, not to the bit)
+    np.testing.assert_allclose(mod(est.cuda(), gt.cuda()).cpu().numpy(), lv.detach().cpu().numpy(), rtol=1e-6, atol=5e-6)
     g, w = e.grad.cpu().double() / 3.0, e64.grad
     for b in range(est.shape[0]):
         err = float((g[b] - w[b]).norm() / w[b].norm())
@@ -51,7 +55,7 @@ def test_snr_loss_names_differ_where_they_should_and_unknown_names_raise():
     assert lv["sisdr"][1] < lv["snr"][1] - 10                       # the scaled target: sisdr sees ~+50 dB, snr ~3 dB
     assert np.allclose(lv["max_fused"], np.maximum(lv["sisdr"], lv["snr"]), atol=1e-5)
     assert np.allclose(lv["fused"], 0.5 * (lv["sisdr"] + lv["snr"]), atol=1e-5)
-    assert np.array_equal(lv["snr"][[3, 5]], lv["full"][[3, 5]])   # the silent-target branch is the same for every name
+    assert np.allclose(lv["snr"][[3, 5]], lv["full"][[3, 5]], rtol=1e-6, atol=5e-6)   # the silent-target branch is the same for every name
     with pytest.raises(ValueError, match="not found"):
         SNRLPLoss("pesq")
 
@@ -68,4 +72,4 @@ def test_snrlp_operator_takes_the_mode():
         b = est.cuda().requires_grad_(True)
         l2, lv2 = SNRLPLoss(name, 50).mean_loss(b, gt.cuda())
         l2.backward()
-        assert torch.equal(lv, lv2) and torch.equal(a.grad, b.grad)
+        assert torch.allclose(lv, lv2, rtol=1e-6, atol=5e-6) and torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-9)

@@ -63,3 +63,30 @@ def test_q24_records_match_the_documented_format_bit_for_bit():
     err = np.abs(o - g)
     assert err[:, (0, 1, 3)].max() <= 2.0 ** -24 and (err[:, (0, 1, 3)][g[:, (0, 1, 3)] < 1 - 2.0 ** -24] <= 2.0 ** -25).all()
     assert err[:, 2].max() <= 2.0 ** -23 and (err[:, 2][g[:, 2] < 1 - 2.0 ** -23] <= 2.0 ** -24).all()
+
+
+def test_flag_arena_hands_out_zeroed_uncached_words_once():
+    """The guarded schedules' flag words: uncached device memory from the library, zeroed chunk-wise by
+    write-through stores, every slice handed out once; the watchdog word is write-once (a fresh slot after a trip)."""
+    from sound_bubble_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    arena = ops.flag_arena(dev)
+    assert arena.kind == 3, f"expected uncached flag memory (hipDeviceMallocUncached), got kind {arena.kind}"
+    a, b = ops.zeroed_flags(100, dev), ops.flag_words(37, dev)
+    assert a is not None and a.numel() == 128 and b.numel() == 64 and a.data_ptr() % 256 == 0
+    assert b.data_ptr() >= a.data_ptr() + 4 * a.numel() or b.data_ptr() + 4 * b.numel() <= a.data_ptr()      # disjoint
+    assert int(a.cpu().abs().sum()) == 0 and int(b.cpu().abs().sum()) == 0
+    lo, hi = arena.base + 4 * arena.RESERVED, arena.base + 4 * (arena.RESERVED + arena.CHUNK * arena.NCHUNK)
+    assert lo <= a.data_ptr() < hi and lo <= b.data_ptr() < hi
+    w0 = ops.sched_status(dev)
+    assert w0.item() == 0
+    w1 = arena.new_status()
+    assert w1.data_ptr() != w0.data_ptr() and w1.item() == 0
+    ops._SCHED_STATUS[dev.index] = w1
+
+
+def test_decode_trip_names_the_wait():
+    from sound_bubble_amd import ops
+    d = ops.decode_trip((2 << 28) | (1 << 27) | (8 << 14) | (6 << 7) | 82)
+    assert d["site"] == 2 and d["timed_out"] and d["index"] == 8 and d["seen"] == 6 and d["wanted"] == 82 and "forward" in d["what"]
+    assert ops.decode_trip(1)["site"] == 0        # a pre-round-5 library wrote 1
