@@ -148,10 +148,11 @@ typedef struct {
      mode -- activations as ONE fp16 term against hi + lo weights, two products per MAC (11-bit activations: NOT fp32-class; the
      bench reports its rel-L2 against the default beside its speed).  -1003 with records / side outputs requested. */
   int products;
-  /* overlapped forward, consumer launch next to the producer (ord_guard != 0): its workgroups claim an item only once the slab it
-     needs is complete, so a wait that runs out (~seconds) costs nothing but their help -- the launch behind the producer does what
-     is left, the outputs stay correct.  ord_giveups (nullable): counts such waits, for the caller's health report. */
+  /* overlapped forward, consumer launch next to the producer (ord_guard != 0): a workgroup whose wait for its item's slab runs
+     out (~5 ms) hands the item back and stops helping -- the launch behind the producer does it, the outputs stay correct.
+     ord_giveups (nullable): counts such waits, for the caller's health report. */
   int* ord_giveups;
+  int* ord_ret;              /* the consumer's hand-back block inside the flags (set by sb_lstm_fwd_consume; leave NULL) */
 } sb_lstm_fwd_args;
 int sb_lstm_fwd(const sb_lstm_fwd_args* a, void* stream);
 /* dwords per (sequence, step, direction) of the wide gate records (save_gates with rec_f32): 192 (24-bit fixed point), or 256
@@ -166,20 +167,24 @@ int sb_rec_q24_roundtrip(const float* in, float* out, uint32_t* packed, int64_t 
  * pass that follows it needs, for a tile of 16 frames (b, t .. t + 15), only the y rows of those frames.  Two calls:
  *   sb_lstm_fwd_produce(a, flags, slab_len, stream): sb_lstm_fwd of a single-direction pass with the fused Linear (y
  *     written; fewer tiles than CUs, no time segments) on `stream`; y rows are stored write-through and after every
- *     slab_len steps (multiple of 4) each tile counts itself into flags[4 + k].  flags: [4 + ceil(nsteps / slab_len)]
- *     ints, zeroed by the call ([0] producer workgroups started, [1], [2] the consumer's item counters, [3] spare).
+ *     slab_len steps (multiple of 4) each tile counts itself into its slab's flag.  flags: sb_lstm_fwd_flag_ints(nsteps,
+ *     slab_len) ints, zeroed by the call ([0] producer workgroups started, [1], [2] the consumer's item counters, [3] spare,
+ *     520 ints of the consumer's hand-back block, then one flag per slab); uncached memory recommended (sb_flags_alloc).
  *   sb_lstm_fwd_consume(a, flags, slab_len, producer_tiles, order, need, stream): sb_lstm_fwd of the bidirectional
  *     partial-Linear pass (ndir == 2, lin_w != NULL, C == 32; a->x is the producer's y) whose tiles are taken in the
  *     order order[ntiles] (a permutation sorted by need[], need[i] = time slab of the producer that completes the frames
  *     of tile order[i]) as (tile, direction) items drawn from one atomic counter per direction by TWO launches: persistent
  *     workgroups on a side stream of the library (two per CU the producer leaves idle; guarded: a workgroup that does not
- *     see all producer workgroups started within ~50 us leaves), each item waiting (bounded; a->sched_status required) for
- *     flags[4 + need] == producer_tiles, and one workgroup per item on `stream` behind the producer, taking what is left.
+ *     see all producer workgroups started within ~50 us leaves), each item waiting for its slab's flag == producer_tiles --
+ *     a wait that runs out (~5 ms) hands the item BACK and ends that workgroup's help -- and one workgroup per item on `stream`
+ *     behind the producer, taking what is left and what was handed back: every item is processed exactly once whatever the
+ *     timing (a->sched_status required: the draining launch's own bounded waits).
  * The consume call must be the next library call after its produce call on that device.  Memory the producer reads or
  * writes must stay allocated until the consume call has returned (the side stream is not ordered after `stream`).
  * -1003 when fewer than 16 CUs stay idle, -1009 without a concurrent side stream (sb_overlap_available). */
+int sb_lstm_fwd_flag_ints(int producer_steps, int slab_len);
 int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a, int* flags, int slab_len, void* stream);
-/* ... with flags_zeroed != 0 the caller has zeroed flags[0 .. 4 + ceil(nsteps / slab_len)) itself, in stream order before the
+/* ... with flags_zeroed != 0 the caller has zeroed all sb_lstm_fwd_flag_ints(...) flags itself, in stream order before the
  * call (one fill for many blocks instead of a memset in front of every producer) */
 int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a, int* flags, int slab_len, int flags_zeroed, void* stream);
 int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,

@@ -1,3 +1,17 @@
 #!/bin/bash
 R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
-( timeout 600 python -m pytest tests/test_gpu_losses.py tests/test_gpu_film_bank.py tests/test_gpu_records.py "tests/test_gpu_switch_matrix.py::test_every_documented_switch_is_in_the_matrix" -q --tb=short 2>&1 | grep -v "^$" | cut -c1-260 | head -150 ) > gpurun_out/r5i_tests.log 2>&1; tail -5 gpurun_out/r5i_tests.log
+( timeout 900 python -m pytest tests/test_gpu_losses.py tests/test_gpu_film_bank.py -q --tb=short 2>&1 | tail -4 ) > gpurun_out/r5i_tests.log 2>&1; tail -3 gpurun_out/r5i_tests.log
+( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -q -x -k "overlapped_forward or ragged or goldens or full_size or fullsize or side_stream or fall_back" 2>&1 | tail -4 ) > gpurun_out/r5i_tests2.log 2>&1; tail -3 gpurun_out/r5i_tests2.log
+rm -f gpurun_out/r5i_ab.txt
+for v in default nooverlap default nooverlap; do
+  if [ $v = nooverlap ]; then export SB_NO_FWD_OVERLAP=1; else unset SB_NO_FWD_OVERLAP; fi
+  timeout 300 python bench.py --workload big --forward-only --steps 40 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('fwd $v', round(d['value'],1), round(d['ms_per_step'],3))" | tee -a gpurun_out/r5i_ab.txt
+done
+for v in default nooverlap default; do
+  if [ $v = nooverlap ]; then export SB_NO_FWD_OVERLAP=1; else unset SB_NO_FWD_OVERLAP; fi
+  timeout 300 python bench.py --workload big --steps 30 --no-cpu-baseline --no-parity --no-exact 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('train $v', round(d['value'],1), round(d['ms_per_step'],3))" | tee -a gpurun_out/r5i_ab.txt
+done
+unset SB_NO_FWD_OVERLAP
+( timeout 600 python scripts/stress_train_loop.py --epochs 1700 > gpurun_out/stress_back1.log 2>&1 ); grep "TRIP\|SLOW\|give-ups" gpurun_out/stress_back1.log | head -8 | cut -c1-400; tail -1 gpurun_out/stress_back1.log | cut -c1-300

@@ -57,7 +57,7 @@ def dump_recent():
     for i, o in enumerate(RECENT):
         f = o.flags.cpu().tolist()
         nsl = (o.need.max().item() + 1) if hasattr(o, "need") else len(f) - 4
-        T_sl = f[4:4 + nsl]
+        T_sl = f[524:524 + nsl]               # (round 5: 4 control words + 520 ints of hand-back block in front of the slab flags)
         if all(v == 0 for v in T_sl):
             nzero += 1
         elif any(v != o.producer_tiles for v in T_sl) or f[0] != o.producer_tiles:

@@ -29,7 +29,7 @@ class LstmFwdArgs(C.Structure):
                 ("slab_flags", C.c_void_p), ("slab_len", C.c_int), ("slab_need", C.c_int),
                 ("tile_order", C.c_void_p), ("tile_need", C.c_void_p), ("ord_counter", C.c_void_p),
                 ("ord_started", C.c_void_p), ("ord_guard", C.c_int), ("ord_grid", C.c_int), ("rec_f32", C.c_int),
-                ("no_vec", C.c_int), ("products", C.c_int), ("ord_giveups", C.c_void_p)]
+                ("no_vec", C.c_int), ("products", C.c_int), ("ord_giveups", C.c_void_p), ("ord_ret", C.c_void_p)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -160,6 +160,7 @@ SYMBOLS = {
     "sb_flags_zero": (_ci, [_vp, i64, _vp]),
     "sb_flags_read": (_ci, [_vp, i64, C.POINTER(C.c_int), _vp]),
     "sb_rec_q24_roundtrip": (_ci, [c_fp, c_fp, _vp, i64, _vp]),
+    "sb_lstm_fwd_flag_ints": (_ci, [_ci, _ci]),
     "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
     "sb_lstm_fwd_produce_ex": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp]),
     "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),

@@ -42,8 +42,9 @@ SB_DEVINL int sb_poll(const int* p) {
 // leave: with the watchdog at 2^22 polls the freeze lasts 0.5 s, at 2^24 polls 16.3 s, every time.  One hot word is incremented by
 // all 82 producer tiles and polled by every waiter; the cross-pass backward, whose producer tiles each own a word, never showed it
 // in 300 000 launches.  Poll rate (s_sleep 0 / 4 / 32) and poll flavour (sc1 load / returning atomic) did not change the rate of
-// the event.  What the library does about it: the forward consumer holds nothing while it waits (sb_lstm_bf_fwd.hip: ord_next) and
-// gives up after ~50 ms, so the event costs that step 50 ms and nothing else; polls are ~3 us apart (a slab takes ~40 us).
+// the event.  What the library does about it: a forward consumer whose wait runs out (~5 ms) hands its item back to the launch
+// behind the producer (sb_lstm_bf_fwd.hip: ord_next), so the event costs that step ~5 ms and nothing else; polls are ~3 us apart
+// (a slab takes ~40 us).
 // SB_POLL_SLEEP: the s_sleep operand (64 clocks each); the watchdog's poll budget scales with it (~2 s).
 #ifndef SB_POLL_SLEEP
 #define SB_POLL_SLEEP 100
@@ -53,8 +54,12 @@ constexpr unsigned kSpinLimit = 1u << SB_SPIN_LIMIT_LOG2;
 #else
 constexpr unsigned kSpinLimit = (3u << 24) / (SB_POLL_SLEEP > 0 ? SB_POLL_SLEEP : 1);     // polls before a bounded wait gives up (~2 s)
 #endif
-// ... and of a wait that holds nothing (the overlapped forward's consumer next to its producer: giving up costs its help only): ~50 ms
-constexpr unsigned kHelpSpinLimit = kSpinLimit / 40 > 64 ? kSpinLimit / 40 : 64;
+// ... and of a wait whose item can be handed back (the overlapped forward's consumer next to its producer: giving up costs its help
+// only): ~5 ms, several producer passes
+constexpr unsigned kHelpSpinLimit = kSpinLimit / 400 > 64 ? kSpinLimit / 400 : 64;
+// overlapped forward: the control block between the four control words and the slab flags (see lstm_fwd_bf_kernel: ord_next)
+constexpr int kOrdRet = 256;                         // returned items per direction (at most one per workgroup of the side launch)
+constexpr int kOrdCtl = 8 + 2 * kOrdRet;             // ints
 SB_DEVINL void sb_poll_pause() {
 #if SB_POLL_SLEEP > 0
   __builtin_amdgcn_s_sleep(SB_POLL_SLEEP);

@@ -43,35 +43,63 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   const bool prod = LIN && !ORD && !SEG && a.slab_flags != nullptr;      // producer side of the overlapped forward
   if (prod && tid == 0) __hip_atomic_fetch_add(a.ord_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __shared__ int ord_item;
-  // next (tile, this direction) item; uniform over the workgroup.  Behind the producer (ord_guard == 0: every slab is complete) a
-  // plain draw.  NEXT to the producer (ord_guard != 0) a workgroup claims the next item only once the slab it needs is complete
-  // (items are sorted by that slab), so a WAITING workgroup holds nothing: whatever happens to it -- a producer that stands still
-  // for a second (seen once in ~10 000 train steps: see sb_common.h, SB_POLL_SLEEP), a wait that runs out -- every unclaimed item
-  // is left to the launch behind the producer and the outputs stay correct.  (Round 4 drew first and waited with the item in
-  // hand: a wait that ran out dropped it, and the step's outputs were garbage behind a watchdog word read once per epoch.)  A
-  // wait that runs out only stops this workgroup from helping and counts itself into *ord_giveups (nullable).
+  // next (tile, this direction) item; uniform over the workgroup.  The draw is one atomic add on the direction's counter (items are
+  // sorted by the producer slab they need).  NEXT to the producer (ord_guard != 0) the workgroup then waits for that slab -- and a
+  // wait that runs out HANDS THE ITEM BACK (per-direction return stack in the control block a.ord_ret) instead of dropping it;
+  // the launch BEHIND the producer (ord_guard == 0, every slab complete) drains the counter, then the return stacks, and leaves
+  // only when no workgroup of the other launch still holds an unprocessed item ([0] of the block).  So whatever happens to a waiting
+  // workgroup -- about once in 10 000 train steps a producer stands still for as long as its pollers wait (sb_common.h,
+  // SB_POLL_SLEEP) -- every item is processed exactly once and the outputs are those of the plain order; the event costs its step
+  // the ~5 ms of the help timeout and counts itself into *ord_giveups (nullable).  (Round 4 dropped the item: garbage activations
+  // behind a watchdog word read once per epoch.  A first round-5 form claimed an item only once its slab was complete -- nothing
+  // to hand back -- and serialised the claims of a slab on one compare-and-swap word: forward-only 2 295 -> 2 020 utt/s, slower
+  // than no overlap at all.)
+  // control block (ints, zeroed with the flags): [0] items held by waiting workgroups, [1 + dir] pushed, [3 + dir] popped,
+  // [8 + dir * kOrdRet + k] returned item k of the direction, stored as item + 1 (0 = not written yet)
   auto ord_next = [&]() -> int {
     if (tid == 0) {
       const int nt = (a.nseq + 15) / 16;
-      int it = nt;
-      if (!ORD || !a.ord_guard) {
-        it = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        unsigned spins = 0;
-        for (;;) {
-          const int c = __hip_atomic_load(a.ord_counter + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (c >= nt) { it = c; break; }
-          if (sb_poll(a.slab_flags + a.tile_need[c]) >= a.slab_need) {
-            int expected = c;
-            if (__hip_atomic_compare_exchange_strong(a.ord_counter + dir, &expected, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)) { it = c; break; }
-            continue;                                  // somebody else took item c: look at the next one
+      int it = __hip_atomic_fetch_add(a.ord_counter + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (ORD) {
+        int* const ctl = a.ord_ret;
+        if (a.ord_guard && it < nt) {
+          __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int* fl = a.slab_flags + a.tile_need[it];
+          unsigned spins = 0;
+          bool ok = true;
+          while (sb_poll(fl) < a.slab_need) {
+            if (++spins > kHelpSpinLimit) { ok = false; break; }
+            sb_poll_pause();
           }
-          if (++spins > kHelpSpinLimit) {              // (~50 ms: dozens of producer passes) stop helping; nothing is held, nothing is lost
-            if (a.ord_giveups) __hip_atomic_fetch_add(a.ord_giveups, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+          if (!ok) {                                   // hand the item back, stop helping
+            const int k = __hip_atomic_fetch_add(ctl + 1 + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int old = -1;
+            if (k < kOrdRet) old = __hip_atomic_exchange(ctl + 8 + dir * kOrdRet + k, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else sb_trip(a.sched_status, SB_TRIP_FWD_CONSUMER, it, k, kOrdRet & 0x7F, kSpinLimit + 1, 0);   // (cannot happen: <= one per side workgroup)
+            if (a.ord_giveups) __hip_atomic_fetch_add(a.ord_giveups, 1 + (old > 0 ? 1 << 20 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            it = nt;                                   // (the exchange has RETURNED before the release below is issued: `old` is used)
           }
-          sb_poll_pause();
+          __hip_atomic_fetch_add(ctl, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!a.ord_guard && it >= nt) {         // counter exhausted: what did the launch next to the producer hand back?
+          unsigned spins = 0;
+          for (;;) {
+            const int t = __hip_atomic_load(ctl + 3 + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int n = __hip_atomic_load(ctl + 1 + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < n && t < kOrdRet) {
+              int expected = t;
+              if (!__hip_atomic_compare_exchange_strong(ctl + 3 + dir, &expected, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT)) continue;
+              int v = 0;
+              while ((v = sb_poll(ctl + 8 + dir * kOrdRet + t)) == 0 && ++spins <= kSpinLimit) sb_poll_pause();
+              if (v > 0) { it = v - 1; break; }
+              sb_trip(a.sched_status, SB_TRIP_FWD_CONSUMER, t, 0, 1, spins, 0);      // a push that never landed: fatal
+              break;
+            }
+            if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+                __hip_atomic_load(ctl + 1 + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n) break;   // nobody holds, nothing new
+            if (++spins > kSpinLimit) { sb_trip(a.sched_status, SB_TRIP_FWD_CONSUMER, n, t, 0, spins, 0); break; }
+            sb_poll_pause();
+          }
         }
       }
       ord_item = it;

@@ -1494,7 +1494,10 @@ extern "C" int sb_lstm_bwd_inter_pair_serial(const sb_lstm_bwd_args* rec_in, con
 
 // ---- overlapped forward (see the header) ----
 // flags layout: [0] producer workgroups started, [1], [2] the consumer's item counters (one per direction), [3] spare,
-// [4 ..] the slab flags
+// [4 .. 4 + 520) the consumer's hand-back block (sb_lstm_fwd_flag_ints), then the slab flags
+extern "C" int sb_lstm_fwd_flag_ints(int producer_steps, int slab_len) {
+  return slab_len > 0 ? 4 + kOrdCtl + (producer_steps + slab_len - 1) / slab_len : -1001;
+}
 extern "C" int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, void* stream) {
   return sb_lstm_fwd_produce_ex(a_in, flags, slab_len, 0, stream);
 }
@@ -1508,9 +1511,9 @@ extern "C" int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a_in, int* flags, 
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
   const int nslabs = (a.nsteps + slab_len - 1) / slab_len;
-  if (!flags_zeroed && sb_flags_zero(flags, nslabs + 4, main_st) != 0) return -1009;
+  if (!flags_zeroed && sb_flags_zero(flags, 4 + kOrdCtl + nslabs, main_st) != 0) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
-  a.slab_flags = flags + 4; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
+  a.slab_flags = flags + 4 + kOrdCtl; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
   a.ord_started = flags;
   return sb_lstm_fwd(&a, stream);
 }
@@ -1525,9 +1528,9 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
   if (a.ndir != 2 || !a.lin_w || !a.sched_status || idle < 16 || slab_len < 4) return -1003;
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
-  a.slab_flags = flags + 4; a.slab_len = slab_len; a.slab_need = producer_tiles;
+  a.slab_flags = flags + 4 + kOrdCtl; a.slab_len = slab_len; a.slab_need = producer_tiles;
   a.tile_order = order; a.tile_need = need;
-  a.ord_started = flags; a.ord_counter = flags + 1;
+  a.ord_started = flags; a.ord_counter = flags + 1; a.ord_ret = flags + 4;
   // next to the producer: two persistent workgroups per idle CU (254 registers each; none fits on a producer's CU); one
   // that cannot be placed at once simply starts later and draws fewer items
   int g1 = 2 * idle;                                   // (1 per CU: -10 % forward-only, 3: no better)

@@ -635,7 +635,7 @@ class FwdOverlap:
 
     def __init__(self, B, T, F_, dev):
         self.slab = FWD_OVERLAP_SLAB
-        nfl = (T + self.slab - 1) // self.slab + 4                               # + 4 control words
+        nfl = int(L.load().sb_lstm_fwd_flag_ints(T, self.slab))                  # control words + the consumer's hand-back block + one flag per slab
         self.flags = zeroed_flags(nfl, dev)       # from the once-per-step zeroed pool (None: the library zeroes them itself)
         self.prezeroed = self.flags is not None
         if self.flags is None:

@@ -62,7 +62,7 @@ def test_snr_loss_names_differ_where_they_should_and_unknown_names_raise():
 
 def test_snrlp_operator_takes_the_mode():
     import torch
-    from sound_bubble_amd import ops
+    from sound_bubble_amd import ops, torch_ops  # noqa: F401  (registers torch.ops.sound_bubble.*)
     from sound_bubble_amd.losses import SNRLPLoss
     est, gt = _batch(torch, B=3, N=4800, seed=2)
     for name in ("snr", "full"):
