@@ -966,6 +966,58 @@ def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train
             assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-5, k      # atomic accumulation order
 
 
+def test_overlapped_forward_hands_items_back_when_the_producer_stands_still(torch_gpu, monkeypatch):
+    """Round 5: the consumer launch next to the producer draws its items and, when the slab an item needs does not
+    complete within the help timeout, hands the item back; the launch behind the producer drains the counter AND the return
+    stacks.  Staged here with a "producer" that has started (flags[0]) and then stands still: the main stream sleeps before the
+    slab flags are raised, so every workgroup of the side launch times out with an item in hand.  The result must be the plain
+    order's to the bit, the give-up counter must have moved, and the watchdog must stay silent."""
+    torch = torch_gpu
+    import ctypes as C
+    from sound_bubble_amd import ops, _lib as L
+    if not ops.overlap_available():
+        pytest.skip("no side stream that runs concurrently with the main stream on this box")
+    if not (ops.can_fuse_linear_fwd() and ops.INTRA_LIN_FUSION):
+        pytest.skip("the ordered consumer is the bidirectional pass with the fused Linear partials")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    C_, B_, T_, F_ = 32, 4, 160, 145                          # 40 consumer tiles per direction, 37 producer tiles, 5 slabs
+    torch.manual_seed(41)
+    geom = ops.Geom.intra(B_ * T_, F_)
+    x = torch.randn(geom.P, C_, device=dev)
+    g, b = torch.rand(C_, device=dev) + 0.5, torch.randn(C_, device=dev) * 0.1
+    dirs = [tuple(t.to(dev) for t in (torch.randn(256, C_) * 0.2, torch.randn(256, 64) * 0.2, torch.randn(256) * 0.1,
+                                      torch.randn(256) * 0.1)) for _ in range(2)]
+    lw, lb = torch.randn(C_, 128, device=dev) * 0.2, torch.randn(C_, device=dev) * 0.1
+    y0 = torch.empty(geom.P, 2, C_, device=dev)
+    ops.lstm_fwd(x, g, b, dirs, geom, lin=(lw, lb, y0), want_hs=False)
+    ovl = ops.FwdOverlap(B_, T_, F_, dev)
+    ovl.produced = True
+    nfl, tiles = ovl.flags.numel(), ovl.producer_tiles
+    nslabs = (T_ + ovl.slab - 1) // ovl.slab
+    src = torch.full((nfl,), tiles, dtype=torch.int32, device=dev).view(torch.float32)
+    lib = L.load()
+
+    def raise_flags(off, n):                                  # flags[off : off + n] = producer_tiles, on the current stream
+        a = L.MultiCopyArgs()
+        a.src[0], a.dst[0], a.n[0], a.njobs = src.data_ptr(), ovl.flags.data_ptr() + 4 * off, n, 1
+        L.check(lib.sb_multi_copy(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sb_multi_copy")
+
+    raise_flags(0, 1)                                         # every producer workgroup has "started"
+    torch.cuda.synchronize()
+    before = ops.read_giveups()
+    torch.cuda._sleep(40_000_000)                             # the producer stands still (tens of ms) ...
+    raise_flags(int(lib.sb_lstm_fwd_flag_ints(T_, ovl.slab)) - nslabs, nslabs)       # ... and then completes every slab
+    y1 = torch.empty(geom.P, 2, C_, device=dev)
+    ops.lstm_fwd(x, g, b, dirs, geom, lin=(lw, lb, y1), want_hs=False, consume=ovl)
+    torch.cuda.synchronize()
+    ops.check_sched_status()
+    after = ops.read_giveups()
+    ctl = ovl.flags.cpu().tolist()[4:12]
+    print("give-ups", after - before, "control block [held, pushed x 2, popped x 2]", ctl[:5])
+    assert torch.equal(y0, y1)
+    assert after > before and ctl[0] == 0 and ctl[1] == ctl[3] and ctl[2] == ctl[4] and ctl[1] + ctl[2] > 0
+
+
 @pytest.mark.parametrize("sched", [None, (4, 3)], ids=["plain", "time-segmented"])
 @pytest.mark.parametrize("save", [False, True], ids=["inference", "training"])
 def test_inter_forward_with_summed_input_is_bit_identical_to_add3(torch_gpu, sched, save, monkeypatch):
