@@ -189,6 +189,11 @@ int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a, int* flags, int slab_len, voi
 int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a, int* flags, int slab_len, int flags_zeroed, void* stream);
 int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
                         const int* need, void* stream);
+/* test hook: the consumer's hand-back path staged on one stream (guarded launch against a producer that has started but completed
+   no slab -> every item handed back; slab flags raised; the launch behind the producer drains counter and return stacks).  flags:
+   sb_lstm_fwd_flag_ints(...) ints with nslabs slab flags, zeroed by the call. */
+int sb_lstm_fwd_consume_staged_test(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, int nslabs,
+                                    const int* order, const int* need, void* stream);
 
 /* ---- recurrent LSTM (backward through time, recurrent part) --------------
  * Autograd of the nn.LSTM calls above (loss.backward(), tain_val.py:75).

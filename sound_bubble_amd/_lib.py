@@ -164,6 +164,7 @@ SYMBOLS = {
     "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
     "sb_lstm_fwd_produce_ex": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp]),
     "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),
+    "sb_lstm_fwd_consume_staged_test": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _ci, _vp, _vp, _vp]),
     "sb_lstm_bwd_cross_rows": (_ci, [_ci, _ci]),
     "sb_lstm_bwd_cross_produce": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _ci, _vp]),
     "sb_lstm_bwd_cross_consume": (_ci, [C.POINTER(LstmBwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),

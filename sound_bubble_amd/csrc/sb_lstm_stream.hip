@@ -1549,6 +1549,38 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
   return rc;
 }
 
+// Test hook: the hand-back path of the overlapped forward staged on ONE stream, no concurrency needed -- (1) the producer has
+// "started" but no slab is complete: the guarded launch draws its items, every wait runs out (~5 ms), every item is handed back;
+// (2) all `nslabs` slab flags are raised; (3) the launch behind the producer drains the counter and the return stacks.  The
+// caller compares y with the plain call's and reads the control block (flags[4 ..]).
+namespace {
+__global__ void flags_fill_kernel(int* p, int64_t n, int v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+extern "C" int sb_lstm_fwd_consume_staged_test(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, int producer_tiles,
+                                               int nslabs, const int* order, const int* need, void* stream) {
+  if (!a_in || !flags || !order || !need || nslabs < 1) return -1001;
+  sb_lstm_fwd_args a = *a_in;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = (a.nseq + 15) / 16;
+  if (a.ndir != 2 || !a.lin_w || !a.sched_status || slab_len < 4) return -1003;
+  if (sb_flags_zero(flags, 4 + kOrdCtl + nslabs, st) != 0) return -1009;
+  hipLaunchKernelGGL(flags_fill_kernel, dim3(1), dim3(64), 0, st, flags, (int64_t)1, producer_tiles);      // every producer workgroup "started"
+  a.slab_flags = flags + 4 + kOrdCtl; a.slab_len = slab_len; a.slab_need = producer_tiles;
+  a.tile_order = order; a.tile_need = need;
+  a.ord_started = flags; a.ord_counter = flags + 1; a.ord_ret = flags + 4;
+  a.ord_guard = 1; a.ord_grid = 2 * ntiles;
+  int rc = sb_lstm_fwd(&a, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(flags_fill_kernel, dim3((nslabs + 63) / 64), dim3(64), 0, st, flags + 4 + kOrdCtl, (int64_t)nslabs, producer_tiles);
+  a.ord_guard = 0; a.ord_grid = 2 * ntiles;
+  rc = sb_lstm_fwd(&a, st);
+  SB_CHECK_LAUNCH();
+  return rc;
+}
+
 // ---- backward overlapped across the two passes of a block (see the header) ----
 // flags layout as for the forward: [0] producer workgroups started, [1], [2] the consumer's item counters (one per
 // direction), [3] spare, [4 ..] the slab flags

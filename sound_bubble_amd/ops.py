@@ -636,6 +636,7 @@ class FwdOverlap:
     def __init__(self, B, T, F_, dev):
         self.slab = FWD_OVERLAP_SLAB
         nfl = int(L.load().sb_lstm_fwd_flag_ints(T, self.slab))                  # control words + the consumer's hand-back block + one flag per slab
+        self.nslabs = (T + self.slab - 1) // self.slab
         self.flags = zeroed_flags(nfl, dev)       # from the once-per-step zeroed pool (None: the library zeroes them itself)
         self.prezeroed = self.flags is not None
         if self.flags is None:
@@ -765,10 +766,17 @@ def lstm_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state
                 produce.produced = True
         elif consume is not None:
             assert ndir == 2 and lin is not None
-            L.check(lib.sb_lstm_fwd_consume(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
-                                            consume.producer_tiles, C.c_void_p(consume.order.data_ptr()),
-                                            C.c_void_p(consume.need.data_ptr()), _stream()),
-                    "sb_lstm_fwd_consume")
+            if getattr(consume, "staged_test", False):        # tests: the hand-back path staged on one stream (see the header)
+                L.check(lib.sb_lstm_fwd_consume_staged_test(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
+                                                            consume.producer_tiles, consume.nslabs,
+                                                            C.c_void_p(consume.order.data_ptr()),
+                                                            C.c_void_p(consume.need.data_ptr()), _stream()),
+                        "sb_lstm_fwd_consume_staged_test")
+            else:
+                L.check(lib.sb_lstm_fwd_consume(C.byref(a), C.c_void_p(consume.flags.data_ptr()), consume.slab,
+                                                consume.producer_tiles, C.c_void_p(consume.order.data_ptr()),
+                                                C.c_void_p(consume.need.data_ptr()), _stream()),
+                        "sb_lstm_fwd_consume")
             consume.keep.clear()
             consume.produced = False
         else:

@@ -969,53 +969,39 @@ def test_overlapped_forward_is_bit_identical_to_the_plain_order(torch_gpu, train
 def test_overlapped_forward_hands_items_back_when_the_producer_stands_still(torch_gpu, monkeypatch):
     """Round 5: the consumer launch next to the producer draws its items and, when the slab an item needs does not
     complete within the help timeout, hands the item back; the launch behind the producer drains the counter AND the return
-    stacks.  Staged here with a "producer" that has started (flags[0]) and then stands still: the main stream sleeps before the
-    slab flags are raised, so every workgroup of the side launch times out with an item in hand.  The result must be the plain
-    order's to the bit, the give-up counter must have moved, and the watchdog must stay silent."""
+    stacks.  Staged on one stream (sb_lstm_fwd_consume_staged_test): a "producer" that has started but completed no slab -> every
+    workgroup of the guarded launch times out with an item in hand; then the slab flags are raised and the draining launch runs.
+    The result must be the plain order's to the bit, every item handed back exactly once, the watchdog silent."""
     torch = torch_gpu
-    import ctypes as C
-    from sound_bubble_amd import ops, _lib as L
-    if not ops.overlap_available():
-        pytest.skip("no side stream that runs concurrently with the main stream on this box")
+    from sound_bubble_amd import ops
     if not (ops.can_fuse_linear_fwd() and ops.INTRA_LIN_FUSION):
         pytest.skip("the ordered consumer is the bidirectional pass with the fused Linear partials")
     dev = torch.device("cuda", torch.cuda.current_device())
-    C_, B_, T_, F_ = 32, 4, 160, 145                          # 40 consumer tiles per direction, 37 producer tiles, 5 slabs
-    torch.manual_seed(41)
-    geom = ops.Geom.intra(B_ * T_, F_)
-    x = torch.randn(geom.P, C_, device=dev)
-    g, b = torch.rand(C_, device=dev) + 0.5, torch.randn(C_, device=dev) * 0.1
-    dirs = [tuple(t.to(dev) for t in (torch.randn(256, C_) * 0.2, torch.randn(256, 64) * 0.2, torch.randn(256) * 0.1,
-                                      torch.randn(256) * 0.1)) for _ in range(2)]
-    lw, lb = torch.randn(C_, 128, device=dev) * 0.2, torch.randn(C_, device=dev) * 0.1
-    y0 = torch.empty(geom.P, 2, C_, device=dev)
-    ops.lstm_fwd(x, g, b, dirs, geom, lin=(lw, lb, y0), want_hs=False)
-    ovl = ops.FwdOverlap(B_, T_, F_, dev)
-    ovl.produced = True
-    nfl, tiles = ovl.flags.numel(), ovl.producer_tiles
-    nslabs = (T_ + ovl.slab - 1) // ovl.slab
-    src = torch.full((nfl,), tiles, dtype=torch.int32, device=dev).view(torch.float32)
-    lib = L.load()
-
-    def raise_flags(off, n):                                  # flags[off : off + n] = producer_tiles, on the current stream
-        a = L.MultiCopyArgs()
-        a.src[0], a.dst[0], a.n[0], a.njobs = src.data_ptr(), ovl.flags.data_ptr() + 4 * off, n, 1
-        L.check(lib.sb_multi_copy(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sb_multi_copy")
-
-    raise_flags(0, 1)                                         # every producer workgroup has "started"
-    torch.cuda.synchronize()
-    before = ops.read_giveups()
-    torch.cuda._sleep(40_000_000)                             # the producer stands still (tens of ms) ...
-    raise_flags(int(lib.sb_lstm_fwd_flag_ints(T_, ovl.slab)) - nslabs, nslabs)       # ... and then completes every slab
-    y1 = torch.empty(geom.P, 2, C_, device=dev)
-    ops.lstm_fwd(x, g, b, dirs, geom, lin=(lw, lb, y1), want_hs=False, consume=ovl)
-    torch.cuda.synchronize()
-    ops.check_sched_status()
-    after = ops.read_giveups()
-    ctl = ovl.flags.cpu().tolist()[4:12]
-    print("give-ups", after - before, "control block [held, pushed x 2, popped x 2]", ctl[:5])
-    assert torch.equal(y0, y1)
-    assert after > before and ctl[0] == 0 and ctl[1] == ctl[3] and ctl[2] == ctl[4] and ctl[1] + ctl[2] > 0
+    for B_, T_ in ((4, 160), (3, 131)):                       # 40 / 25 consumer tiles per direction (the second ragged), 5 slabs
+        C_, F_ = 32, 145
+        torch.manual_seed(41 + B_)
+        geom = ops.Geom.intra(B_ * T_, F_)
+        x = torch.randn(geom.P, C_, device=dev)
+        g, b = torch.rand(C_, device=dev) + 0.5, torch.randn(C_, device=dev) * 0.1
+        dirs = [tuple(t.to(dev) for t in (torch.randn(256, C_) * 0.2, torch.randn(256, 64) * 0.2, torch.randn(256) * 0.1,
+                                          torch.randn(256) * 0.1)) for _ in range(2)]
+        lw, lb = torch.randn(C_, 128, device=dev) * 0.2, torch.randn(C_, device=dev) * 0.1
+        y0 = torch.empty(geom.P, 2, C_, device=dev)
+        ops.lstm_fwd(x, g, b, dirs, geom, lin=(lw, lb, y0), want_hs=False)
+        ovl = ops.FwdOverlap(B_, T_, F_, dev)
+        ovl.produced, ovl.staged_test = True, True
+        before = ops.read_giveups()
+        y1 = torch.full((geom.P, 2, C_), float("nan"), device=dev)
+        ops.lstm_fwd(x, g, b, dirs, geom, lin=(lw, lb, y1), want_hs=False, consume=ovl)
+        torch.cuda.synchronize()
+        ops.check_sched_status()
+        fl = ovl.flags.cpu().tolist()
+        held, pushed, popped = fl[4], fl[5:7], fl[7:9]
+        nt = (geom.nseq + 15) // 16
+        gave = (ops.read_giveups() - before) & 0xFFFFF
+        print(f"B={B_} T={T_}: {nt} tiles per direction, give-ups {gave}, held {held}, pushed {pushed}, popped {popped}")
+        assert torch.equal(y0, y1)
+        assert held == 0 and pushed == [nt, nt] and popped == [nt, nt] and gave == 2 * nt
 
 
 @pytest.mark.parametrize("sched", [None, (4, 3)], ids=["plain", "time-segmented"])
