@@ -276,6 +276,12 @@ class PLModule(object):
         world = allreduce_grads(self.bucket)
         self.optimizer.step(grad_clip=self.grad_clip, world_size=world)
         self._flush_loss()
+        # the guarded schedules' watchdog word, every 50th step as well as at the epoch's end (an epoch of a real run is hours:
+        # a launch that gave up must not train on garbage that long).  Same step on every rank: the verdict is all-reduced.
+        self._opt_steps = getattr(self, "_opt_steps", 0) + 1
+        if self._opt_steps % 50 == 0:
+            from . import ops
+            ops.check_sched_status_all_ranks()
 
     def init_scheduler(self, scheduler, scheduler_params):
         """hl_module:460-481 ('sequential' -> SequentialLR with cumulative milestones)."""

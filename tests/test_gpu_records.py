@@ -83,10 +83,3 @@ def test_flag_arena_hands_out_zeroed_uncached_words_once():
     w1 = arena.new_status()
     assert w1.data_ptr() != w0.data_ptr() and w1.item() == 0
     ops._SCHED_STATUS[dev.index] = w1
-
-
-def test_decode_trip_names_the_wait():
-    from sound_bubble_amd import ops
-    d = ops.decode_trip((2 << 28) | (1 << 27) | (8 << 14) | (6 << 7) | 82)
-    assert d["site"] == 2 and d["timed_out"] and d["index"] == 8 and d["seen"] == 6 and d["wanted"] == 82 and "forward" in d["what"]
-    assert ops.decode_trip(1)["site"] == 0        # a pre-round-5 library wrote 1

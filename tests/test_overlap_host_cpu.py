@@ -26,6 +26,23 @@ def test_tile_order_is_a_permutation_sorted_by_the_slab_that_completes_the_tile(
 
 
 
+@pytest.mark.parametrize("B,T,F,slab", [(16, 625, 145, 32), (9, 625, 145, 32), (3, 131, 145, 32), (2, 150, 21, 16)])
+def test_tile_order_names_the_producer_tiles_an_item_waits_for(B, T, F, slab):
+    """round 5: one progress word per PRODUCER tile (16 consecutive sequences b F + f of the inter-frame pass); an intra-frame
+    item waits for the words of the tiles that hold the sequences of its frames' batch entries"""
+    from sound_bubble_amd.ops import tile_order_np
+    order, plain = tile_order_np(B, T, slab)
+    order2, packed = tile_order_np(B, T, slab, F)
+    assert np.array_equal(order, order2) and np.array_equal(packed & 0xFFF, plain)
+    lo, hi = (packed >> 12) & 0x3FF, (packed >> 22) & 0x3FF
+    ptiles = (B * F + 15) // 16
+    assert lo.min() >= 0 and hi.max() <= ptiles - 1 and np.all(lo <= hi)
+    for i, tile in enumerate(order):
+        bs = sorted({min(n // T, B - 1) for n in range(16 * tile, 16 * tile + 16)})
+        seqs = [b * F + f for b in bs for f in range(F)]
+        assert lo[i] == min(seqs) // 16 and hi[i] == max(seqs) // 16
+
+
 def test_deferral_is_refused_outside_a_backward_pass_and_without_a_side_stream(monkeypatch):
     """ops.defer_small_launches (round 4): small launches may ride on the library's side stream only when the autograd engine will
     run the join at the end of the pass it is executing, for a stream whose side stream passed the probe; otherwise the caller
@@ -92,3 +109,10 @@ def test_grad_targets_know_when_nothing_goes_back_through_autograd():
     assert gt("p", p) is p.grad and gt["p"] is None and gt.all_direct()
     z = gt("q", q)
     assert z is gt["q"] and z is not None and not gt.all_direct()
+
+
+def test_decode_trip_names_the_wait():
+    from sound_bubble_amd import ops
+    d = ops.decode_trip((2 << 28) | (1 << 27) | (8 << 14) | (6 << 7) | 82)
+    assert d["site"] == 2 and d["timed_out"] and d["index"] == 8 and d["seen"] == 6 and d["wanted"] == 82 and "forward" in d["what"]
+    assert ops.decode_trip(1)["site"] == 0        # a pre-round-5 library wrote 1
