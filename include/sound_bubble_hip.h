@@ -167,33 +167,31 @@ int sb_rec_q24_roundtrip(const float* in, float* out, uint32_t* packed, int64_t 
  * pass that follows it needs, for a tile of 16 frames (b, t .. t + 15), only the y rows of those frames.  Two calls:
  *   sb_lstm_fwd_produce(a, flags, slab_len, stream): sb_lstm_fwd of a single-direction pass with the fused Linear (y
  *     written; fewer tiles than CUs, no time segments) on `stream`; y rows are stored write-through and after every
- *     slab_len steps (multiple of 4) each tile writes the number of slabs it has completed into ITS progress word.  flags:
- *     sb_lstm_fwd_flag_ints(tiles) ints, zeroed by the call ([0] producer workgroups started, [1], [2] the consumer's item
- *     counters, [3] spare, 520 ints of the consumer's hand-back block, then one progress word per producer tile); uncached
- *     memory recommended (sb_flags_alloc).
+ *     slab_len steps (multiple of 4) each tile counts itself into its slab's flag.  flags: sb_lstm_fwd_flag_ints(nsteps,
+ *     slab_len) ints, zeroed by the call ([0] producer workgroups started, [1], [2] the consumer's item counters, [3] spare,
+ *     520 ints of the consumer's hand-back block, then one flag per slab); uncached memory recommended (sb_flags_alloc).
  *   sb_lstm_fwd_consume(a, flags, slab_len, producer_tiles, order, need, stream): sb_lstm_fwd of the bidirectional
  *     partial-Linear pass (ndir == 2, lin_w != NULL, C == 32; a->x is the producer's y) whose tiles are taken in the
- *     order order[ntiles] (a permutation sorted by the time slab of the producer that completes the frames of the tile;
- *     need[i] = that slab | lo << 12 | hi << 22, lo .. hi the producer tiles holding the sequences of tile order[i]'s batch
- *     entries) as (tile, direction) items drawn from one atomic counter per direction by TWO launches: persistent
+ *     order order[ntiles] (a permutation sorted by need[], need[i] = time slab of the producer that completes the frames
+ *     of tile order[i]) as (tile, direction) items drawn from one atomic counter per direction by TWO launches: persistent
  *     workgroups on a side stream of the library (two per CU the producer leaves idle; guarded: a workgroup that does not
- *     see all producer workgroups started within ~50 us leaves), each item waiting for the progress words lo .. hi > its slab --
+ *     see all producer workgroups started within ~50 us leaves), each item waiting for its slab's flag == producer_tiles --
  *     a wait that runs out (~5 ms) hands the item BACK and ends that workgroup's help -- and one workgroup per item on `stream`
  *     behind the producer, taking what is left and what was handed back: every item is processed exactly once whatever the
  *     timing (a->sched_status required: the draining launch's own bounded waits).
  * The consume call must be the next library call after its produce call on that device.  Memory the producer reads or
  * writes must stay allocated until the consume call has returned (the side stream is not ordered after `stream`).
  * -1003 when fewer than 16 CUs stay idle, -1009 without a concurrent side stream (sb_overlap_available). */
-int sb_lstm_fwd_flag_ints(int producer_tiles);
+int sb_lstm_fwd_flag_ints(int producer_steps, int slab_len);
 int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a, int* flags, int slab_len, void* stream);
-/* ... with flags_zeroed != 0 the caller has zeroed all sb_lstm_fwd_flag_ints(tiles) flags itself, in stream order before the
+/* ... with flags_zeroed != 0 the caller has zeroed all sb_lstm_fwd_flag_ints(...) flags itself, in stream order before the
  * call (one fill for many blocks instead of a memset in front of every producer) */
 int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a, int* flags, int slab_len, int flags_zeroed, void* stream);
 int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, const int* order,
                         const int* need, void* stream);
 /* test hook: the consumer's hand-back path staged on one stream (guarded launch against a producer that has started but completed
-   no slab -> every item handed back; progress words raised to nslabs; the launch behind the producer drains counter and return
-   stacks).  flags: sb_lstm_fwd_flag_ints(producer_tiles) ints, zeroed by the call. */
+   no slab -> every item handed back; slab flags raised; the launch behind the producer drains counter and return stacks).  flags:
+   sb_lstm_fwd_flag_ints(...) ints with nslabs slab flags, zeroed by the call. */
 int sb_lstm_fwd_consume_staged_test(const sb_lstm_fwd_args* a, int* flags, int slab_len, int producer_tiles, int nslabs,
                                     const int* order, const int* need, void* stream);
 

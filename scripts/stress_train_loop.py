@@ -56,14 +56,14 @@ def dump_recent():
     nbad = nzero = 0
     for i, o in enumerate(RECENT):
         f = o.flags.cpu().tolist()
-        words = f[524:524 + o.producer_tiles]          # 4 control words + 520 ints of hand-back block, then one progress word per producer tile
-        if all(v == 0 for v in words):
+        nsl = (o.need.max().item() + 1) if hasattr(o, "need") else len(f) - 4
+        T_sl = f[524:524 + nsl]               # (round 5: 4 control words + 520 ints of hand-back block in front of the slab flags)
+        if all(v == 0 for v in T_sl):
             nzero += 1
-        elif any(v != o.nslabs for v in words) or f[0] != o.producer_tiles:
+        elif any(v != o.producer_tiles for v in T_sl) or f[0] != o.producer_tiles:
             nbad += 1
-            print(f"  overlap #{i} of {len(RECENT)} (oldest first): started {f[0]} counters {f[1:4]} hand-back {f[4:9]} tiles {o.producer_tiles} "
-                  f"slabs {o.nslabs} progress words {words}", flush=True)
-    print(f"  of {len(RECENT)} recent flag arrays: {nbad} hold partial progress IN MEMORY, {nzero} are all zero (never produced)", flush=True)
+            print(f"  overlap #{i} of {len(RECENT)} (oldest first): started {f[0]} counters {f[1:4]} tiles {o.producer_tiles} slabs {T_sl}", flush=True)
+    print(f"  of {len(RECENT)} recent flag arrays: {nbad} hold partial counts IN MEMORY, {nzero} are all zero (never produced)", flush=True)
 
 
 trips, nans, steps = 0, 0, 0

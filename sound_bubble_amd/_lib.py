@@ -160,7 +160,7 @@ SYMBOLS = {
     "sb_flags_zero": (_ci, [_vp, i64, _vp]),
     "sb_flags_read": (_ci, [_vp, i64, C.POINTER(C.c_int), _vp]),
     "sb_rec_q24_roundtrip": (_ci, [c_fp, c_fp, _vp, i64, _vp]),
-    "sb_lstm_fwd_flag_ints": (_ci, [_ci]),
+    "sb_lstm_fwd_flag_ints": (_ci, [_ci, _ci]),
     "sb_lstm_fwd_produce": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _vp]),
     "sb_lstm_fwd_produce_ex": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp]),
     "sb_lstm_fwd_consume": (_ci, [C.POINTER(LstmFwdArgs), _vp, _ci, _ci, _vp, _vp, _vp]),

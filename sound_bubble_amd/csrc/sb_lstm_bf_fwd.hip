@@ -64,16 +64,12 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
         int* const ctl = a.ord_ret;
         if (a.ord_guard && it < nt) {
           __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // tile_need[it] = need | lo << 12 | hi << 22: the item needs slab `need` of the producer tiles lo .. hi (the sequences
-          // of its frames' batch entries), i.e. their progress words at need + 1
-          const int packed = a.tile_need[it], need = (packed & 0xFFF) + 1, lo = (packed >> 12) & 0x3FF, hi = (packed >> 22) & 0x3FF;
+          const int* fl = a.slab_flags + a.tile_need[it];
           unsigned spins = 0;
           bool ok = true;
-          for (int t = lo; t <= hi && ok; ++t) {
-            while (sb_poll(a.slab_flags + t) < need) {
-              if (++spins > kHelpSpinLimit) { ok = false; break; }
-              sb_poll_pause();
-            }
+          while (sb_poll(fl) < a.slab_need) {
+            if (++spins > kHelpSpinLimit) { ok = false; break; }
+            sb_poll_pause();
           }
           if (!ok) {                                   // hand the item back, stop helping
             const int k = __hip_atomic_fetch_add(ctl + 1 + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -814,10 +810,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   auto slab_signal = [&](int k) {                                  // every y row of slab k of this tile is on its way
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    // ONE word per producer tile = slabs it has completed, written by nobody else (a plain write-through store): round 4 counted
-    // every tile into one word per slab -- 82 read-modify-writes and ~170 polls on the same word -- and that word is where the
-    // producer was seen to freeze (sb_common.h, SB_POLL_SLEEP); the cross-pass backward has always published like this
-    if (tid == 0) __hip_atomic_store(a.slab_flags + blockIdx.x, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(a.slab_flags + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   const int item1 = ORD ? ntiles : nitems;
   for (int item = ORD ? ord_first : (int)blockIdx.x; item < item1; item = ORD ? ord_next() : item + (int)gridDim.x) {
@@ -825,12 +818,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     const int tile = ORD ? a.tile_order[item] : SEG ? item - seg * ntiles : item;
     s_begin = SEG ? seg * a.seg_len : 0;
     const int s_end = SEG ? min(S, s_begin + a.seg_len) : S;
-    if constexpr (ORD) {
-      // (the guarded launch has waited in ord_next; behind the producer every progress word is final -- a bounded look all the same)
-      const int packed = a.tile_need[item];
-      for (int t = (packed >> 12) & 0x3FF; t <= ((packed >> 22) & 0x3FF); ++t)
-        if (!seg_wait(a.slab_flags, t, (packed & 0xFFF) + 1, a.sched_status, SB_TRIP_FWD_CONSUMER)) return;
-    }
+    if constexpr (ORD) { if (!seg_wait(a.slab_flags, a.tile_need[item], a.slab_need, a.sched_status, SB_TRIP_FWD_CONSUMER)) return; }
     set_tile(tile);
     // ---- initial state of this item ----
     c = zero4();

@@ -1494,8 +1494,10 @@ extern "C" int sb_lstm_bwd_inter_pair_serial(const sb_lstm_bwd_args* rec_in, con
 
 // ---- overlapped forward (see the header) ----
 // flags layout: [0] producer workgroups started, [1], [2] the consumer's item counters (one per direction), [3] spare,
-// [4 .. 4 + 520) the consumer's hand-back block (sb_lstm_fwd_flag_ints), then one progress word per producer tile (slabs completed)
-extern "C" int sb_lstm_fwd_flag_ints(int producer_tiles) { return producer_tiles > 0 ? 4 + kOrdCtl + producer_tiles : -1001; }
+// [4 .. 4 + 520) the consumer's hand-back block (sb_lstm_fwd_flag_ints), then the slab flags
+extern "C" int sb_lstm_fwd_flag_ints(int producer_steps, int slab_len) {
+  return slab_len > 0 ? 4 + kOrdCtl + (producer_steps + slab_len - 1) / slab_len : -1001;
+}
 extern "C" int sb_lstm_fwd_produce(const sb_lstm_fwd_args* a_in, int* flags, int slab_len, void* stream) {
   return sb_lstm_fwd_produce_ex(a_in, flags, slab_len, 0, stream);
 }
@@ -1508,7 +1510,8 @@ extern "C" int sb_lstm_fwd_produce_ex(const sb_lstm_fwd_args* a_in, int* flags, 
   if (a.ndir != 1 || !a.lin_w || slab_len < 4 || (slab_len & 3) || device_cus() - ntiles < 16) return -1003;
   SideStream* ss = side_stream(main_st);
   if (!ss) return -1009;
-  if (!flags_zeroed && sb_flags_zero(flags, 4 + kOrdCtl + ntiles, main_st) != 0) return -1009;
+  const int nslabs = (a.nsteps + slab_len - 1) / slab_len;
+  if (!flags_zeroed && sb_flags_zero(flags, 4 + kOrdCtl + nslabs, main_st) != 0) return -1009;
   if (hipEventRecord(ss->fork, main_st) != hipSuccess) return -1009;      // the side stream starts from here
   a.slab_flags = flags + 4 + kOrdCtl; a.slab_len = slab_len; a.tile_order = nullptr; a.tile_need = nullptr;
   a.ord_started = flags;
@@ -1548,7 +1551,7 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
 
 // Test hook: the hand-back path of the overlapped forward staged on ONE stream, no concurrency needed -- (1) the producer has
 // "started" but no slab is complete: the guarded launch draws its items, every wait runs out (~5 ms), every item is handed back;
-// (2) every producer tile's progress word is raised to `nslabs`; (3) the launch behind the producer drains the counter and the return stacks.  The
+// (2) all `nslabs` slab flags are raised; (3) the launch behind the producer drains the counter and the return stacks.  The
 // caller compares y with the plain call's and reads the control block (flags[4 ..]).
 namespace {
 __global__ void flags_fill_kernel(int* p, int64_t n, int v) {
@@ -1563,7 +1566,7 @@ extern "C" int sb_lstm_fwd_consume_staged_test(const sb_lstm_fwd_args* a_in, int
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = (a.nseq + 15) / 16;
   if (a.ndir != 2 || !a.lin_w || !a.sched_status || slab_len < 4) return -1003;
-  if (sb_flags_zero(flags, 4 + kOrdCtl + producer_tiles, st) != 0) return -1009;
+  if (sb_flags_zero(flags, 4 + kOrdCtl + nslabs, st) != 0) return -1009;
   hipLaunchKernelGGL(flags_fill_kernel, dim3(1), dim3(64), 0, st, flags, (int64_t)1, producer_tiles);      // every producer workgroup "started"
   a.slab_flags = flags + 4 + kOrdCtl; a.slab_len = slab_len; a.slab_need = producer_tiles;
   a.tile_order = order; a.tile_need = need;
@@ -1571,7 +1574,7 @@ extern "C" int sb_lstm_fwd_consume_staged_test(const sb_lstm_fwd_args* a_in, int
   a.ord_guard = 1; a.ord_grid = 2 * ntiles;
   int rc = sb_lstm_fwd(&a, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(flags_fill_kernel, dim3((producer_tiles + 63) / 64), dim3(64), 0, st, flags + 4 + kOrdCtl, (int64_t)producer_tiles, nslabs);
+  hipLaunchKernelGGL(flags_fill_kernel, dim3((nslabs + 63) / 64), dim3(64), 0, st, flags + 4 + kOrdCtl, (int64_t)nslabs, producer_tiles);
   a.ord_guard = 0; a.ord_grid = 2 * ntiles;
   rc = sb_lstm_fwd(&a, st);
   SB_CHECK_LAUNCH();

@@ -463,32 +463,21 @@ FWD_OVERLAP_INFERENCE = os.environ.get("SB_NO_FWD_OVERLAP_INFERENCE", "0") != "1
 _TILE_ORDER = {}
 
 
-def tile_order_np(B, T, slab, F_=None):
+def tile_order_np(B, T, slab):
     """intra-frame tiles (16 consecutive frames n = b T + t) sorted by the inter-frame time slab that completes them:
-    -> (order [ntiles] int32: a permutation of the tiles, need [ntiles] int32: need[i] = slab that completes tile order[i]).
-    With F_ (round 5: one progress word per PRODUCER tile): need[i] = slab | lo << 12 | hi << 22, lo .. hi the inter-frame
-    (producer) tiles -- 16 consecutive sequences b F + f -- that hold the sequences of the tile's batch entries, as in
-    cross_tile_order_np."""
+    -> (order [ntiles] int32: a permutation of the tiles, need [ntiles] int32: need[i] = slab that completes tile order[i])"""
     import numpy as np
     n = np.arange((B * T + 15) // 16 * 16).reshape(-1, 16)
-    ok = n < B * T
-    need = np.where(ok, (n % T) // slab, 0).max(axis=1)
+    need = np.where(n < B * T, (n % T) // slab, 0).max(axis=1)
     order = np.argsort(need, kind="stable")
-    if F_ is None:
-        return order.astype(np.int32), need[order].astype(np.int32)
-    b = np.minimum(n // T, B - 1)
-    lo = (b.min(axis=1) * F_) // 16
-    hi = (b.max(axis=1) * F_ + F_ - 1) // 16
-    assert need.max() < 4096 and hi.max() < 1024
-    packed = need | (lo << 12) | (hi << 22)
-    return order.astype(np.int32), packed[order].astype(np.int32)
+    return order.astype(np.int32), need[order].astype(np.int32)
 
 
-def _tile_order(B, T, F_, slab, dev):
-    key = (B, T, F_, slab, dev.index if dev.index is not None else torch.cuda.current_device())
+def _tile_order(B, T, slab, dev):
+    key = (B, T, slab, dev.index if dev.index is not None else torch.cuda.current_device())
     r = _TILE_ORDER.get(key)
     if r is None:
-        order, need = tile_order_np(B, T, slab, F_)
+        order, need = tile_order_np(B, T, slab)
         r = _TILE_ORDER[key] = (torch.from_numpy(order).to(dev), torch.from_numpy(need).to(dev))
     return r
 
@@ -646,15 +635,14 @@ class FwdOverlap:
 
     def __init__(self, B, T, F_, dev):
         self.slab = FWD_OVERLAP_SLAB
-        self.producer_tiles = (B * F_ + 15) // 16
-        nfl = int(L.load().sb_lstm_fwd_flag_ints(self.producer_tiles))           # control words + the consumer's hand-back block + one progress word per producer tile
+        nfl = int(L.load().sb_lstm_fwd_flag_ints(T, self.slab))                  # control words + the consumer's hand-back block + one flag per slab
         self.nslabs = (T + self.slab - 1) // self.slab
         self.flags = zeroed_flags(nfl, dev)       # from the once-per-step zeroed pool (None: the library zeroes them itself)
         self.prezeroed = self.flags is not None
         if self.flags is None:
             self.flags = flag_words(nfl, dev)
         self.producer_tiles = (B * F_ + 15) // 16
-        self.order, self.need = _tile_order(B, T, F_, self.slab, dev)
+        self.order, self.need = _tile_order(B, T, self.slab, dev)
         self.keep = []            # everything the producer touches stays allocated until the consumer has been launched
         self.produced = False
 

@@ -26,23 +26,6 @@ def test_tile_order_is_a_permutation_sorted_by_the_slab_that_completes_the_tile(
 
 
 
-@pytest.mark.parametrize("B,T,F,slab", [(16, 625, 145, 32), (9, 625, 145, 32), (3, 131, 145, 32), (2, 150, 21, 16)])
-def test_tile_order_names_the_producer_tiles_an_item_waits_for(B, T, F, slab):
-    """round 5: one progress word per PRODUCER tile (16 consecutive sequences b F + f of the inter-frame pass); an intra-frame
-    item waits for the words of the tiles that hold the sequences of its frames' batch entries"""
-    from sound_bubble_amd.ops import tile_order_np
-    order, plain = tile_order_np(B, T, slab)
-    order2, packed = tile_order_np(B, T, slab, F)
-    assert np.array_equal(order, order2) and np.array_equal(packed & 0xFFF, plain)
-    lo, hi = (packed >> 12) & 0x3FF, (packed >> 22) & 0x3FF
-    ptiles = (B * F + 15) // 16
-    assert lo.min() >= 0 and hi.max() <= ptiles - 1 and np.all(lo <= hi)
-    for i, tile in enumerate(order):
-        bs = sorted({min(n // T, B - 1) for n in range(16 * tile, 16 * tile + 16)})
-        seqs = [b * F + f for b in bs for f in range(F)]
-        assert lo[i] == min(seqs) // 16 and hi[i] == max(seqs) // 16
-
-
 def test_deferral_is_refused_outside_a_backward_pass_and_without_a_side_stream(monkeypatch):
     """ops.defer_small_launches (round 4): small launches may ride on the library's side stream only when the autograd engine will
     run the join at the end of the pass it is executing, for a stream whose side stream passed the probe; otherwise the caller
