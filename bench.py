@@ -18,7 +18,7 @@ headline, whose `secondary` object carries all of them again (so the LAST line a
 
 The timed region is event-free; the per-kernel table behind `roofline` (the recurrent kernel with the largest total time,
 HIP events on the launch stream) comes from a separate, untimed pass of the same step.  Every train line names its
-BPTT-state precision (`bptt_mode`; default "wide": fp32 records, two-term gradient products = the reference's own
+BPTT-state precision (`bptt_mode`; default "wide": fp32-class records (fp32 c_prev, 24-bit fixed-point gates), two-term gradient products = the reference's own
 arithmetic) and carries the sibling mode's number (`compact_bptt`: fp16 BPTT state, opt-in) with its own roofline, and, at
 N = 1, `cpu_baseline` (the oracle -- a CPU port of the reference's algorithm -- on the host cores: train B = 1 / 4, eval
 forward B = 1 / 4, bounded).
@@ -400,7 +400,7 @@ def stream_bench(torch, sb, args, wl, cls, params, dev):
 
 
 DTYPE_BY_MODE = {
-    "wide": "f32 storage/accumulate incl. the BPTT state (fp32 gate / c_prev records, fp32 side outputs); every matrix product "
+    "wide": "f32 storage/accumulate; BPTT state: fp32 c_prev, post-activation gates as 24-bit fixed point (|error| <= 2^-25 / 2^-24 on [0, 1] / [-1, 1]: fp32-class), fp32-sized side outputs; every matrix product "
             "on the fp16 pipe with TWO-term split operands (3 products per MAC, 22 mantissa bits: fp32-class) in forward "
             "AND backward",
     "compact": "f32 storage/accumulate; forward products fp16 hi+lo split (fp32-class); BPTT state (gate / c_prev records, "

@@ -201,13 +201,16 @@ class OracleBlock(nn.Module):
 class OracleTFGridNet(nn.Module):
     def __init__(self, n_fft, stride, n_imics, emb_dim, n_layers, H, conv_lstm, lstm_down,
                  flavour, n_srcs=1, use_first_ln=True, dis_type="conv3", eps=1e-5, use_attn=False, n_head=4, E=2,
-                 local_atten_len=100):
+                 local_atten_len=100, merge_method="early_cat"):
         super().__init__()
-        assert flavour in ("dis_embd3", "optim")
+        assert flavour in ("dis_embd3", "optim") and merge_method in ("early_cat", "None")
         self.flavour, self.n_layers, self.M = flavour, n_layers, n_imics
         self.n_fft, self.stride, self.F = n_fft, stride, n_fft // 2 + 1
         self.C, self.H, self.n_srcs = emb_dim, H, n_srcs
-        self.n_feat = 2 * n_imics + 3 * (n_imics - 1)
+        # merge_method (tfgridnet_causal.py:341-347,404-409,486-500): "early_cat" = (re, im) of every microphone + the ILD / IPD
+        # features, "None" (the constructor default) = the 2 M (re, im) channels alone
+        self.merge_method = merge_method
+        self.n_feat = 2 * n_imics + (3 * (n_imics - 1) if merge_method == "early_cat" else 0)
         self.enc, self.dec = _EncDec(n_fft, stride), _EncDec(n_fft, stride)
         mods = [nn.Conv2d(self.n_feat, emb_dim, (3, 3), padding=(0, 1))]
         if use_first_ln:
@@ -250,6 +253,8 @@ class OracleTFGridNet(nn.Module):
         cos = (re[:, 1:] * re[:, :1] + im[:, 1:] * im[:, :1]) / den
         sin = (re[:, :1] * im[:, 1:] - im[:, :1] * re[:, 1:]) / den
         ipd = torch.stack([sin, cos], dim=2).reshape(spec.shape[0], -1, self.F, spec.shape[-1])
+        if self.merge_method == "None":
+            return torch.cat([re, im], dim=1)
         return torch.cat([re, im, ild, ipd], dim=1)
 
     def front(self, feats, st):                          # -> x[B,T,F,C] channels-last
@@ -304,7 +309,7 @@ class OracleNet(nn.Module):
                  fb_type="stft", dis_type="conv3"):
         super().__init__()
         assert not spectral_masking and not directional and stft_back_pad == 0
-        assert merge_method == "early_cat" and fb_type == "stft"
+        assert merge_method in ("early_cat", "None") and fb_type == "stft"
         if lstm_down is None:       # dis_embd3 Net never forwards lstm_down: core default 4 (:282)
             lstm_down = 4 if flavour == "dis_embd3" else 5
         self.flavour = flavour
@@ -313,7 +318,7 @@ class OracleNet(nn.Module):
                                          conv_lstm, lstm_down, flavour, n_srcs=num_src,
                                          use_first_ln=use_first_ln, dis_type=dis_type, use_attn=use_attn, n_head=L,
                                          E=E,   # block E = ceil(E*n_freqs / n_freqs) (tfgridnet_causal.py:591-593)
-                                         local_atten_len=local_atten_len)
+                                         local_atten_len=local_atten_len, merge_method=merge_method)
 
     def init_buffers(self, batch_size, device):
         return self.tfgridnet.init_buffers(batch_size, device)

@@ -98,10 +98,11 @@ def _block_params(C, H, conv_lstm, lstm_down, F_, flavour, use_attn=False, n_hea
 
 class _TFGridNetParams(nn.Module):
     def __init__(self, n_fft, stride, n_imics, C, n_layers, H, conv_lstm, lstm_down, flavour, n_srcs,
-                 use_first_ln, dis_type, use_attn=False, n_head=4, E=2):
+                 use_first_ln, dis_type, use_attn=False, n_head=4, E=2, merge_method="early_cat"):
         super().__init__()
         F_ = n_fft // 2 + 1
-        n_feat = 2 * n_imics + 3 * (n_imics - 1)
+        # merge_method "None" (tfgridnet_causal.py:341-342): the 3x3 convolution sees the 2 M (re, im) channels alone
+        n_feat = 2 * n_imics + (3 * (n_imics - 1) if merge_method == "early_cat" else 0)
         self.enc = _Params(filterbank=_FilterBank(n_fft, stride))
         self.dec = _Params(filterbank=_FilterBank(n_fft, stride))
         conv = _ParamList([_Params(nn.Conv2d(n_feat, C, (3, 3), padding=(0, 1)))])
@@ -142,9 +143,9 @@ class _NetBase(nn.Module):
             raise NotImplementedError("the recurrent HIP kernels are built for H=64 (every shipped config)")
         if D not in (16, 32):
             raise NotImplementedError("D must be 16 or 32 (shipped configs)")
-        if merge_method != "early_cat" or directional or spectral_masking or stft_back_pad != 0 or fb_type != "stft":
-            raise NotImplementedError("only merge_method='early_cat', omnidirectional, no spectral masking, "
-                                      "stft_back_pad=0 (every shipped config)")
+        if merge_method not in ("early_cat", "None") or directional or spectral_masking or stft_back_pad != 0 or fb_type != "stft":
+            raise NotImplementedError("merge_method 'early_cat' (every shipped config) or 'None' (the constructor default), "
+                                      "omnidirectional, no spectral masking, stft_back_pad=0")
         if num_src != 1 or not 2 <= num_ch <= 7:
             raise NotImplementedError("num_src=1 and 2 <= num_ch <= 7 (5 num_ch - 3 feature channels in the 32-channel front-end "
                                       "stack; every shipped config has 6 microphones, the reference's constructor default is 2)")
@@ -154,10 +155,12 @@ class _NetBase(nn.Module):
         self.n_freqs = self.nfft // 2 + 1
         self.n_layers, self.H, self.num_src = B, H, num_src
         self.conv_lstm, self.lstm_down, self.use_first_ln = conv_lstm, lstm_down, use_first_ln
-        self.n_feat = 2 * num_ch + 3 * (num_ch - 1)
+        # "None": the feature kernel still fills the ILD / IPD slots of the 32-channel front-end stack; the convolution's weight
+        # form has zero columns there (kvalid = n_feat) and conv_buf carries the first n_feat channels only
+        self.n_feat = 2 * num_ch + (3 * (num_ch - 1) if merge_method == "early_cat" else 0)
         self.use_attn, self.n_head, self.local_atten_len = use_attn, L, local_atten_len
         self.tfgridnet = _TFGridNetParams(self.nfft, stft_chunk_size, num_ch, D, B, H, conv_lstm, lstm_down,
-                                          self.flavour, num_src, use_first_ln, dis_type, use_attn, L, E)
+                                          self.flavour, num_src, use_first_ln, dis_type, use_attn, L, E, merge_method)
         if self.nfft % 16 or (self.nfft // 2 + 1) * 2 > Fn.NSPEC:
             raise NotImplementedError("n_fft must be a multiple of 16 and <= 302")
 

@@ -14,7 +14,7 @@ from . import _lib as L
 H = 64
 # Precision of the BPTT state (what the forward pass keeps for the backward pass, and what travels between the backward
 # kernels):
-#   "wide"    (default) -- the reference's own precision: fp32 gate / c_prev records (blocked in the kernels' lane order),
+#   "wide"    (default) -- fp32-class: fp32 c_prev + 24-bit fixed-point gate records (round 5; blocked in the kernels' lane order),
 #             fp32 LayerNorm-output and hs side outputs, gradients on the fp16 matrix pipe as two terms (hi + 2^-11 lo',
 #             22 mantissa bits) against hi + lo splits of activations and weights -- through the SAME fused launch
 #             structure as the compact mode (lstm_bwd_rec_bf_kernel<..., XP>).

@@ -527,6 +527,12 @@ def main():
               out_dir=args.out)
     case(torch, NetSmall, "tiny_small_4ch", dict(small, B=2, num_ch=4), B=2, n_frames=7, seed=18, needs_dis=False,
               out_dir=args.out, with_stream=False)
+    # merge_method "None" -- the reference constructor's default (tfgridnet_causal.py:341-342,486-493): the 3x3 convolution sees
+    # the 2 M (re, im) channels alone, no ILD / IPD features
+    case(torch, NetBig, "tiny_big_nomerge", dict(big, B=2, merge_method="None"), B=2, n_frames=7, seed=19, needs_dis=True,
+              out_dir=args.out)
+    case(torch, NetSmall, "tiny_small_nomerge", dict(small, B=2, merge_method="None"), B=2, n_frames=7, seed=20, needs_dis=False,
+              out_dir=args.out, with_stream=False)
     # real small config, 1 s clip (125 frames), forward only
     case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
               with_grads=False, with_stream=False, with_stages=False)

@@ -52,7 +52,8 @@ def test_struct_layouts_match_header(tmp_path):
 
 @pytest.mark.parametrize("name,cls", [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"),
                                       ("tiny_orange", "NetOptim"), ("tiny_big_convlstm", "NetDisEmbd3"),
-                                      ("tiny_big_2ch", "NetDisEmbd3"), ("tiny_small_4ch", "NetOptim")])
+                                      ("tiny_big_2ch", "NetDisEmbd3"), ("tiny_small_4ch", "NetOptim"),
+                                      ("tiny_big_nomerge", "NetDisEmbd3"), ("tiny_small_nomerge", "NetOptim")])
 def test_reference_state_dict_loads_strict(name, cls, torch_mod):
     import sound_bubble_amd as sb
     rec, params, _ = load_golden(name)

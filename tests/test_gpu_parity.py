@@ -125,6 +125,8 @@ CASES = [("tiny_big", "NetDisEmbd3"), ("tiny_small", "NetOptim"), ("tiny_orange"
 ATTN_CASES = [("tiny_big_attn100", "NetDisEmbd3"), ("tiny_orange_attn4", "NetOptim")]
 # other microphone counts (every shipped JSON: 6): num_ch = 2, the reference's constructor default, and 4
 NUMCH_CASES = [("tiny_big_2ch", "NetDisEmbd3"), ("tiny_small_4ch", "NetOptim")]
+# merge_method "None" -- the reference constructor's default: the 3x3 convolution on the (re, im) channels alone
+MERGE_CASES = [("tiny_big_nomerge", "NetDisEmbd3"), ("tiny_small_nomerge", "NetOptim")]
 
 
 def _build(torch, name, cls):
@@ -142,7 +144,7 @@ def _inputs(torch, rec):
     return d
 
 
-@pytest.mark.parametrize("name,cls", CASES + ATTN_CASES + NUMCH_CASES)
+@pytest.mark.parametrize("name,cls", CASES + ATTN_CASES + NUMCH_CASES + MERGE_CASES)
 def test_forward_matches_reference_goldens(torch_gpu, name, cls):
     torch = torch_gpu
     rec, params, m = _build(torch, name, cls)
@@ -196,7 +198,7 @@ def test_forward_small_config_1s(torch_gpu):
     assert rel_l2(out, rec["output"]) < 5e-5
 
 
-@pytest.mark.parametrize("name,cls", CASES[:3] + ATTN_CASES + NUMCH_CASES[:1])
+@pytest.mark.parametrize("name,cls", CASES[:3] + ATTN_CASES + NUMCH_CASES[:1] + MERGE_CASES[:1])
 def test_streaming_matches_reference(torch_gpu, name, cls):
     torch = torch_gpu
     poison_free_memory(torch, 2)
@@ -295,6 +297,28 @@ def test_deconv_data_gradient_measures_its_own_absmax(torch_gpu):
     o.backward(dspec.permute(0, 3, 1, 2).contiguous())
     ref = y.grad[:, :, 2:].permute(0, 2, 3, 1)
     assert rel_l2(dy.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("name,cls", MERGE_CASES)
+def test_merge_method_none_matches_reference(torch_gpu, name, cls):
+    """merge_method = "None" (the reference constructor's default, tfgridnet_causal.py:341-342,486-493): loss vector and every
+    parameter gradient against the imported reference's goldens; the carried conv_buf has the 2 M (re, im) channels only."""
+    torch = torch_gpu
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd import ops
+    rec, params, m = _build(torch, name, cls)
+    assert params["merge_method"] == "None"
+    m.train()
+    res = m(_inputs(torch, rec))
+    assert res["next_state"]["conv_buf"].shape[1] == 2 * params["num_ch"]
+    loss, lv = SnrlpLossFn.apply(res["output"], torch.from_numpy(rec["target"]).cuda(), 100.0)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), rec["loss_vec"], rtol=1e-4, atol=1e-4)
+    loss.backward()
+    for k, p in m.named_parameters():
+        g = rec["grad::" + k]
+        e = rel_l2(p.grad.cpu().numpy(), g) if np.abs(g).max() > 0 else float(p.grad.abs().max())
+        assert e < 2e-4, (k, e)
+    ops.check_sched_status()
 
 
 @pytest.mark.parametrize("name,cls", NUMCH_CASES)

@@ -6,7 +6,8 @@ import pytest
 from conftest import load_golden, golden_state_dict, rel_l2, flatten_state
 
 # (the last two: num_ch = 2 -- the reference's constructor default -- and 4; every shipped JSON has 6)
-CASES = ["tiny_big", "tiny_small", "tiny_orange", "tiny_big_convlstm", "tiny_big_2ch", "tiny_small_4ch"]
+CASES = ["tiny_big", "tiny_small", "tiny_orange", "tiny_big_convlstm", "tiny_big_2ch", "tiny_small_4ch", "tiny_big_nomerge",
+         "tiny_small_nomerge"]
 ATTN_CASES = ["tiny_big_attn100", "tiny_orange_attn4"]
 
 
