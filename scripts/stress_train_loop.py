@@ -25,8 +25,9 @@ ap.add_argument("--sleep", type=float, default=0.0)
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--loader", action="store_true")
 ap.add_argument("--no-val", action="store_true")
+ap.add_argument("--config", default="overfit_test_samples.json", help="experiment JSON under experiments/ (bubble_small_synthetic.json: the 0.3 M config, time-segmented passes at --batch 32)")
 args = ap.parse_args()
-params = json.load(open(os.path.join(ROOT, "experiments", "overfit_test_samples.json")))
+params = json.load(open(os.path.join(ROOT, "experiments", args.config)))
 if args.batch:
     params["batch_size"] = params["eval_batch_size"] = args.batch
 seed_all(0)
