@@ -604,6 +604,10 @@ def run_workload(torch, dist, sb, ops, wl, args, dev, world, rank, *, forward_on
                           0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2]), "min": per_step[0], "max": per_step[-1],
                           "n": steps}
         RUN["last_counts"] = dict(ops.SCHED_COUNTS, steps=steps)
+        try:                                                 # overlapped-forward workgroups that handed their item back (harmless; cumulative per process)
+            RUN["last_counts"]["fwd_giveups_total"] = int(ops.read_giveups()) & 0xFFFFF if ops._FLAG_ARENAS else 0
+        except Exception:
+            pass
         ops.check_sched_status()                             # a time-segmented launch that bailed out voids the run
         prof, prof_steps = {}, 0
         if profile:                                          # separate, untimed pass: HIP-event pairs (on the launch stream)

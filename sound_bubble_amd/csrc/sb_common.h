@@ -55,8 +55,12 @@ constexpr unsigned kSpinLimit = 1u << SB_SPIN_LIMIT_LOG2;
 constexpr unsigned kSpinLimit = (3u << 24) / (SB_POLL_SLEEP > 0 ? SB_POLL_SLEEP : 1);     // polls before a bounded wait gives up (~2 s)
 #endif
 // ... and of a wait whose item can be handed back (the overlapped forward's consumer next to its producer: giving up costs its help
-// only): ~5 ms, several producer passes
-constexpr unsigned kHelpSpinLimit = kSpinLimit / 400 > 64 ? kSpinLimit / 400 : 64;
+// only): ~2 ms, two producer passes -- an item legitimately waits for at most one.  (A first value of ~6 ms made one event cost a
+// forward pass up to 5 boundaries x 6 ms: seen once inside a 10-step forward-only bench region, 6.7 ms median, 9.1 ms mean.)
+#ifndef SB_HELP_DIV
+#define SB_HELP_DIV 1200
+#endif
+constexpr unsigned kHelpSpinLimit = kSpinLimit / SB_HELP_DIV > 64 ? kSpinLimit / SB_HELP_DIV : 64;
 // overlapped forward: the control block between the four control words and the slab flags (see lstm_fwd_bf_kernel: ord_next)
 constexpr int kOrdRet = 256;                         // returned items per direction (at most one per workgroup of the side launch)
 constexpr int kOrdCtl = 8 + 2 * kOrdRet;             // ints
