@@ -149,7 +149,7 @@ typedef struct {
      bench reports its rel-L2 against the default beside its speed).  -1003 with records / side outputs requested. */
   int products;
   /* overlapped forward, consumer launch next to the producer (ord_guard != 0): a workgroup whose wait for its item's slab runs
-     out (~5 ms) hands the item back and stops helping -- the launch behind the producer does it, the outputs stay correct.
+     out (~2 ms) hands the item back and stops helping -- the launch behind the producer does it, the outputs stay correct.
      ord_giveups (nullable): counts such waits, for the caller's health report. */
   int* ord_giveups;
   int* ord_ret;              /* the consumer's hand-back block inside the flags (set by sb_lstm_fwd_consume; leave NULL) */
@@ -176,7 +176,7 @@ int sb_rec_q24_roundtrip(const float* in, float* out, uint32_t* packed, int64_t 
  *     of tile order[i]) as (tile, direction) items drawn from one atomic counter per direction by TWO launches: persistent
  *     workgroups on a side stream of the library (two per CU the producer leaves idle; guarded: a workgroup that does not
  *     see all producer workgroups started within ~50 us leaves), each item waiting for its slab's flag == producer_tiles --
- *     a wait that runs out (~5 ms) hands the item BACK and ends that workgroup's help -- and one workgroup per item on `stream`
+ *     a wait that runs out (~2 ms) hands the item BACK and ends that workgroup's help -- and one workgroup per item on `stream`
  *     behind the producer, taking what is left and what was handed back: every item is processed exactly once whatever the
  *     timing (a->sched_status required: the draining launch's own bounded waits).
  * The consume call must be the next library call after its produce call on that device.  Memory the producer reads or

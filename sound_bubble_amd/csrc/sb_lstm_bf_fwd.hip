@@ -50,7 +50,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
   // only when no workgroup of the other launch still holds an unprocessed item ([0] of the block).  So whatever happens to a waiting
   // workgroup -- about once in 10 000 train steps a producer stands still for as long as its pollers wait (sb_common.h,
   // SB_POLL_SLEEP) -- every item is processed exactly once and the outputs are those of the plain order; the event costs its step
-  // the ~5 ms of the help timeout and counts itself into *ord_giveups (nullable).  (Round 4 dropped the item: garbage activations
+  // the ~2 ms of the help timeout and counts itself into *ord_giveups (nullable).  (Round 4 dropped the item: garbage activations
   // behind a watchdog word read once per epoch.  A first round-5 form claimed an item only once its slab was complete -- nothing
   // to hand back -- and serialised the claims of a slab on one compare-and-swap word: forward-only 2 295 -> 2 020 utt/s, slower
   // than no overlap at all.)

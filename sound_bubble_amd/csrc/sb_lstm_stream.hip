@@ -1550,7 +1550,7 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
 }
 
 // Test hook: the hand-back path of the overlapped forward staged on ONE stream, no concurrency needed -- (1) the producer has
-// "started" but no slab is complete: the guarded launch draws its items, every wait runs out (~5 ms), every item is handed back;
+// "started" but no slab is complete: the guarded launch draws its items, every wait runs out (~2 ms), every item is handed back;
 // (2) all `nslabs` slab flags are raised; (3) the launch behind the producer drains the counter and the return stacks.  The
 // caller compares y with the plain call's and reads the control block (flags[4 ..]).
 namespace {
