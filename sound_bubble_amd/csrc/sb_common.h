@@ -42,9 +42,10 @@ SB_DEVINL int sb_poll(const int* p) {
 // leave: with the watchdog at 2^22 polls the freeze lasts 0.5 s, at 2^24 polls 16.3 s, every time.  One hot word is incremented by
 // all 82 producer tiles and polled by every waiter; the cross-pass backward, whose producer tiles each own a word, never showed it
 // in 300 000 launches -- yet a forward build with one progress word per producer tile showed the same events.  Poll rate (s_sleep
-// 0 / 4 / 32) and poll flavour (sc1 load / returning atomic) did not change the rate of the event either: cause not established.  What the library does about it: a forward consumer whose wait runs out (~2 ms) hands its item back to the launch
-// behind the producer (sb_lstm_bf_fwd.hip: ord_next), so the event costs that step ~2 ms and nothing else; polls are ~3 us apart
-// (a slab takes ~40 us).
+// 0 / 4 / 32) and poll flavour (sc1 load / returning atomic) did not change the rate of the event either: cause not established.
+// What the library does about it: a forward consumer whose wait runs out (~2 ms) hands its item back to the launch behind the
+// producer (sb_lstm_bf_fwd.hip: ord_next), so the event costs a boundary ~2 ms and nothing else; polls are ~3 us apart (a slab
+// takes ~40 us).
 // SB_POLL_SLEEP: the s_sleep operand (64 clocks each); the watchdog's poll budget scales with it (~2 s).
 #ifndef SB_POLL_SLEEP
 #define SB_POLL_SLEEP 100
