@@ -131,3 +131,28 @@ def test_si_sdr_formula():
     # scale invariance: SI-SDR ignores the factor 3, plain SNR does not
     assert abs(si_sdr_np(est, gt) - si_sdr_np(est / 3.0, gt)) < 1e-6
     assert si_sdr_np(est, gt, scale_invariant=False) < 0 < si_sdr_np(est, gt)
+
+
+def test_oracle_with_the_trained_checkpoint_matches_the_imported_reference(torch_mod):
+    """Round 5: the oracle pinned at a TRAINED operating point too -- the checkpoint train_cli produced on the GPU box
+    (tests/golden/trained_overfit_best.pt), evaluated by the imported reference (tests/golden/trained_overfit.npz,
+    make_trained_fixture.py), against the oracle with the same file on one full 5 s scene: output rel-L2 and SI-SDR."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from oracle.tfgridnet_oracle import OracleNet
+    from sound_bubble_amd.eval_samples import load_testcase, si_sdr_np
+    torch = torch_mod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = json.load(open(os.path.join(root, "experiments", "overfit_test_samples.json")))["pl_module_args"]["model_params"]
+    ck = torch.load(os.path.join(GOLDEN, "trained_overfit_best.pt"), map_location="cpu", weights_only=False)
+    m = OracleNet("dis_embd3", **params).eval()
+    m.load_state_dict(ck["model"], strict=True)
+    ref = np.load(os.path.join(GOLDEN, "trained_overfit.npz"))
+    _, mix, gt, tg = load_testcase(os.path.join(GOLDEN, "test_samples_full", "syn_2m", "00001"), 2.0)
+    with torch.no_grad():
+        out = m({"mixture": torch.from_numpy(mix)[None], "dis_embed": torch.tensor([[1.0, 0.0, 0.0]])})["output"][0].numpy()
+    want = ref["syn_2m/00001::output"]
+    assert rel_l2(out, want) < 2e-5
+    s = si_sdr_np(out[0], gt[0])
+    assert abs(s - float(ref["syn_2m/00001::si_sdr"])) < 1e-3 and s > 20.0
