@@ -896,7 +896,12 @@ def zeroed_flags(n, dev):
 
 
 def flag_words(n, dev):
-    """n int32 words of uncached flag memory for a call that zeroes its flags itself (same chunks: they happen to be zero too)"""
+    """n int32 words of uncached flag memory for a call that zeroes its flags itself (same chunks: they happen to be zero too).
+    Under stream capture: a plain int32 tensor from the graph's own pool, as before round 5 -- activating an arena chunk inside a
+    capture would record its zeroing into the graph, and every replay would wipe slices handed out since (the guarded schedules
+    are not used under capture; only the never-engaged segment flags of the streaming chunk step come through here)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(n), 1), device=dev, dtype=torch.int32)
     return _FLAGS.get(n, dev)
 
 
