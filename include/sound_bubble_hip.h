@@ -507,9 +507,11 @@ int sb_lstm_overlap_rows(int64_t positions, int nseq);
  *     (nullable, HOST pointer to 2 floats): back-to-back and best pair time in ms.  Synchronises `stream` several times;
  *     not to be called while it is capturing.  Returns 1 (found) / 0 (none: overlapped calls unavailable on this stream);
  *     a second call for the same (device, stream) returns the stored verdict.
- *   sb_overlap_reprobe: re-times the stored pair (two timed launches) and updates the verdict -- a stream that was
- *     concurrent at start-up can lose that (another process on the GPU, more streams alive); call it now and then (the
- *     harness does once per epoch) and fall back to the plain calls when it returns 0.
+ *   sb_overlap_reprobe: re-times the stored pair and updates the verdict -- a stream that was concurrent at start-up can
+ *     lose that (another process on the GPU, more streams alive); call it now and then (the harness does once per epoch)
+ *     and fall back to the plain calls when it returns 0.  A failing measurement is repeated (up to 4, best pair counts:
+ *     a 0.1 ms host hiccup between the two launches of one measurement otherwise reads as a loss); a later call may find
+ *     the pair concurrent again and returns 1 then.
  *   sb_overlap_available: the stored verdict, no side effects.
  *   sb_overlap_shutdown: destroys every side stream and event of the process.
  * The table behind them is mutex-guarded; everything else in the library is stateless.

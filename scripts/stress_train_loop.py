@@ -110,6 +110,10 @@ for epoch in range(args.epochs):
     if epoch % 50 == 0:
         print(epoch, f"loss {l:.4f} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s", flush=True)
 print("forward-consumer give-ups (harmless):", ops.read_giveups(), flush=True)
+# which order the inter-frame passes really took (a re-probe that finds the side stream serialised switches to the plain order)
+rp = [e for e in ops.OVERLAP_LOG if e[0] == "reprobe"]
+print("schedule counts:", ops.SCHED_COUNTS, "| re-probes:", len(rp), "failed:", [(round(e[3], 3), round(e[4], 3)) for e in rp if e[2] != 1],
+      "| slowest passing pair (ms):", max([e[4] for e in rp if e[2] == 1], default=None), flush=True)
 try:
     print("watchdog debug words at the end (a -DSB_TRIP_DEBUG library: [52] = longest wait in polls):", ops.flag_arena(0).status_debug(), flush=True)
 except Exception as e:

@@ -41,8 +41,8 @@ SB_DEVINL int sb_poll(const int* p) {
 // itself (no stale cache line: the words are uncached), tiles frozen at different steps -- and it resumes the moment the pollers
 // leave: with the watchdog at 2^22 polls the freeze lasts 0.5 s, at 2^24 polls 16.3 s, every time.  One hot word is incremented by
 // all 82 producer tiles and polled by every waiter; the cross-pass backward, whose producer tiles each own a word, never showed it
-// in 300 000 launches -- yet a forward build with one progress word per producer tile showed the same events.  Poll rate (s_sleep
-// 0 / 4 / 32) and poll flavour (sc1 load / returning atomic) did not change the rate of the event either: cause not established.
+// in 300 000 launches -- yet a forward build with one progress word per producer tile showed the same events.  A slower poll
+// (s_sleep 32) and the poll flavour (sc1 load / returning atomic) did not lower the rate of the event either: cause not established.
 // What the library does about it: a forward consumer whose wait runs out (~2 ms) hands its item back to the launch behind the
 // producer (sb_lstm_bf_fwd.hip: ord_next), so the event costs a boundary ~2 ms and nothing else; polls are ~3 us apart (a slab
 // takes ~40 us).

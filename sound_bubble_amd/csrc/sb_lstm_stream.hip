@@ -1296,11 +1296,24 @@ extern "C" int sb_overlap_reprobe(void* stream, float* scratch, float* timings_m
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1009;
   const int ga = cus * 9 / 16, gb = cus * 3 / 8, iters = 12000;
-  const float solo = probe_timed(main_st, nullptr, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
-  const float pair = probe_timed(main_st, t->s, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+  // One measurement is two 0.2 ms kernels: a host hiccup of 0.1 ms between the two launches (the call comes straight out of an
+  // epoch's Python) reads as pair = 0.29-0.33 ms against 0.40 back-to-back -- a FALSE loss, seen about once per 3 000 calls in
+  // round 5's stress runs, after which the rest of the run silently took the plain order.  So a failing measurement is repeated
+  // (up to 4 in all, the first doubling as the warm-up of the others) and the best pair counts: a side stream that really
+  // serialises fails every time (pair >= back-to-back), a hiccup does not repeat.
+  float solo = -1.f, pair = -1.f;
+  bool ok = false;
+  for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
+    const float s1 = probe_timed(main_st, nullptr, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+    const float p1 = probe_timed(main_st, t->s, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
+    if (s1 <= 0.f || p1 <= 0.f) { solo = s1; pair = p1; break; }
+    if (solo < 0.f || s1 < solo) solo = s1;
+    if (pair < 0.f || p1 < pair) pair = p1;
+    ok = pair < 0.7f * solo;
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (timings_ms) { timings_ms[0] = solo; timings_ms[1] = pair; }
-  t->ok = solo > 0.f && pair > 0.f && pair < 0.7f * solo;
+  t->ok = ok;
   return t->ok ? 1 : 0;
 }
 

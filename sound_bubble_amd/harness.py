@@ -188,7 +188,7 @@ class PLModule(object):
                 import warnings
                 warnings.warn(f"{g - getattr(self, '_giveups_seen', 0)} workgroup(s) of the overlapped forward stopped waiting for their "
                               "producer this epoch (results unaffected: the launch behind the producer did their items; the step "
-                              "that happened in took seconds)")
+                              "that happened in took a few ms longer)")
                 self._giveups_seen = g
             ops.overlap_reprobe()
         last = self.get_avg_metric_at_epoch(self.monitor)

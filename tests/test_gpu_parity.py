@@ -1341,7 +1341,7 @@ def test_side_stream_management_api(torch_gpu):
     ptr = C.c_void_p(scratch.data_ptr())
     try:
         assert lib.sb_overlap_shutdown() == 0
-        ops._OVERLAP_OK.clear()
+        ops._OVERLAP_OK.clear(); ops._OVERLAP_LOST.clear()
         st = ops._stream()
         assert lib.sb_overlap_available(st) == 0                       # nothing initialised: look-up only, no probe
         assert lib.sb_overlap_init(st, None, None) == -1001
@@ -1362,7 +1362,7 @@ def test_side_stream_management_api(torch_gpu):
         assert lib.sb_overlap_available(st) == 0
     finally:
         lib.sb_overlap_shutdown()
-        ops._OVERLAP_OK.clear()
+        ops._OVERLAP_OK.clear(); ops._OVERLAP_LOST.clear()
     assert ops.overlap_available() in (True, False) and ops.OVERLAP_LOG[-1][0] == "init"
 
 
@@ -1402,7 +1402,7 @@ def test_overlapped_paths_fall_back_when_the_side_stream_is_gone(torch_gpu, monk
         g1 = grads()
         assert ops._OVERLAP_OK[key] is False                     # ... until the first -1009
     finally:
-        ops._OVERLAP_OK.clear()
+        ops._OVERLAP_OK.clear(); ops._OVERLAP_LOST.clear()
     for k in g0:
         assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-5, k
 

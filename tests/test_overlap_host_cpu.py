@@ -99,3 +99,44 @@ def test_decode_trip_names_the_wait():
     d = ops.decode_trip((2 << 28) | (1 << 27) | (8 << 14) | (6 << 7) | 82)
     assert d["site"] == 2 and d["timed_out"] and d["index"] == 8 and d["seen"] == 6 and d["wanted"] == 82 and "forward" in d["what"]
     assert ops.decode_trip(1)["site"] == 0        # a pre-round-5 library wrote 1
+
+
+def test_reprobe_switches_the_overlapped_order_off_and_on_again(monkeypatch):
+    """ops.overlap_reprobe (harness, once per epoch): a failed re-timing of the side stream switches this stream to the plain
+    order with a warning; LATER calls keep re-timing it and switch the overlapped order back on (round 5: a single noisy
+    measurement used to leave the rest of a run in the plain order).  A stream that never had a side stream is not re-timed.
+    Host logic only: the library is a stand-in returning scripted verdicts."""
+    import ctypes as C
+    import warnings
+    import torch
+    from sound_bubble_amd import ops, _lib as L
+    verdicts = []
+
+    class Lib:
+        def sb_overlap_reprobe(self, st, scratch, tm):
+            tm[0], tm[1] = 0.40, (0.21 if verdicts[0] == 1 else 0.41)
+            return verdicts.pop(0)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(ops, "_stream", lambda: C.c_void_p(77))
+    monkeypatch.setattr(ops, "_overlap_scratch", lambda dev: None)
+    monkeypatch.setattr(ops, "_p", lambda t: None)
+    monkeypatch.setattr(L, "load", lambda: Lib())
+    monkeypatch.setattr(ops, "_OVERLAP_OK", {})
+    monkeypatch.setattr(ops, "_OVERLAP_LOST", set())
+    monkeypatch.setattr(ops, "OVERLAP_LOG", [])
+    key = (0, 77)
+    assert ops.overlap_reprobe() is False and ops.OVERLAP_LOG == []           # never probed: no library call
+    ops._OVERLAP_OK[key] = False
+    assert ops.overlap_reprobe() is False and ops.OVERLAP_LOG == []           # init found no side stream: nothing to re-time
+    ops._OVERLAP_OK[key] = True
+    verdicts[:] = [1, 0, 0, 1, 1]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert ops.overlap_reprobe() is True and ops._OVERLAP_OK[key] and not w
+        assert ops.overlap_reprobe() is False and not ops._OVERLAP_OK[key] and key in ops._OVERLAP_LOST
+        assert len(w) == 1 and "plain launch order" in str(w[0].message)
+        assert ops.overlap_reprobe() is False and len(w) == 1                  # still lost: re-timed, no second warning
+        assert ops.overlap_reprobe() is True and ops._OVERLAP_OK[key] and key not in ops._OVERLAP_LOST
+        assert len(w) == 2 and "again" in str(w[1].message)
+        assert ops.overlap_reprobe() is True and len(w) == 2
+    assert [e[2] for e in ops.OVERLAP_LOG] == [1, 0, 0, 1, 1] and not verdicts
