@@ -533,6 +533,12 @@ def main():
               out_dir=args.out)
     case(torch, NetSmall, "tiny_small_nomerge", dict(small, B=2, merge_method="None"), B=2, n_frames=7, seed=20, needs_dis=False,
               out_dir=args.out, with_stream=False)
+    # the reference constructor's own widths (net.py:21-26: D = 64, H = 128), which no shipped JSON uses and the HIP kernels do
+    # not cover yet: two blocks, 6 frames, so that the oracle is pinned at those shapes before kernels exist
+    case(torch, NetBig, "tiny_big_h128d64", dict(big, B=2, D=64, H=128), B=2, n_frames=6, seed=22, needs_dis=True,
+              out_dir=args.out, with_stream=False)
+    case(torch, NetSmall, "tiny_small_h128d64", dict(small, B=2, D=64, H=128), B=2, n_frames=6, seed=23, needs_dis=False,
+              out_dir=args.out, with_stream=False)
     # real small config, 1 s clip (125 frames), forward only
     case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
               with_grads=False, with_stream=False, with_stages=False)
