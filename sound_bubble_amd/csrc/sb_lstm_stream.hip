@@ -1271,7 +1271,14 @@ extern "C" int sb_overlap_init(void* stream, float* scratch, float* timings_ms) 
   int nrej = 0;
   for (int c = 0; c < 8 && !t->s && solo > 0.f; ++c) {
     hipStream_t cand = nullptr;
-    if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+    // developer experiment for the stalled forward producer: SB_SIDE_STREAM_PRIORITY=low|high creates the
+    // side stream -- which carries the POLLING launches of the overlapped schedules -- at the device's least / greatest stream
+    // priority instead of the default.  Unset (the product): no priority, as in every measurement so far.
+    const char* pr = getenv("SB_SIDE_STREAM_PRIORITY");
+    int least = 0, greatest = 0;
+    if (pr && (pr[0] == 'l' || pr[0] == 'h') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {
+      if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest) != hipSuccess) break;
+    } else if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
     (void)probe_timed(main_st, cand, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
     const float pair = probe_timed(main_st, cand, t->fork, t->join, e0, e1, scratch, ga, gb, iters);
     if (best_pair < 0.f || (pair > 0.f && pair < best_pair)) best_pair = pair;
