@@ -67,6 +67,27 @@ def dump_recent():
     print(f"  of {len(RECENT)} recent flag arrays: {nbad} hold partial counts IN MEMORY, {nzero} are all zero (never produced)", flush=True)
 
 
+def kfd_evicted_ms():
+    """KFD's per-process queue-eviction clock (ms this process' queues spent evicted: waves context-saved, e.g. for a page-table
+    update behind an MMU notifier).  Hypothesis under test: the producer's 'freeze' is such an eviction, after
+    which the pollers get their CUs back first and the producer's saved waves find no room until the pollers leave.  None where
+    the sysfs node is absent."""
+    import glob
+    tot, seen = 0, False
+    # (every process directory: inside the GPU box's container os.getpid() is not the pid KFD knows this process by -- checked
+    #  at the end of round 5 -- and the box is single-tenant)
+    for f in glob.glob("/sys/class/kfd/kfd/proc/*/stats_*/evicted_ms"):
+        try:
+            tot += int(open(f).read().strip() or 0)
+            seen = True
+        except (OSError, ValueError):
+            pass
+    return tot if seen else None
+
+
+ev0 = ev_last = kfd_evicted_ms()
+gu_last = 0
+print("kfd evicted_ms at start:", ev0, flush=True)
 trips, nans, steps = 0, 0, 0
 ep_med, t_ep0 = 1.0, time.time()
 t00 = time.time()
@@ -101,6 +122,11 @@ for epoch in range(args.epochs):
         dump_recent()
         seed_all(1000 + epoch)
         hl = import_attr(params["pl_module"])(**params["pl_module_args"])           # (the parameters are garbage now: start over)
+    gu, ev = ops.read_giveups(), kfd_evicted_ms()
+    if gu != gu_last or ev != ev_last:          # a hand-back event and / or a queue eviction in this epoch: do they coincide?
+        print(f"epoch {epoch} t={time.time() - t00:.1f}s: give-ups +{gu - gu_last} (total {gu}), kfd evicted_ms "
+              f"{'n/a' if ev is None else f'+{ev - (ev_last or 0)} (total {ev})'}", flush=True)
+        gu_last, ev_last = gu, ev
     t_ep = time.time() - t_ep0 if epoch else 0.0
     if epoch > 3 and t_ep > 3 * ep_med:
         print(f"epoch {epoch}: SLOW {t_ep:.2f}s (typical {ep_med:.2f}s)", flush=True)
@@ -109,7 +135,7 @@ for epoch in range(args.epochs):
     t_ep0 = time.time()
     if epoch % 50 == 0:
         print(epoch, f"loss {l:.4f} steps {steps} trips {trips} nan-steps {nans} {time.time() - t00:.0f}s", flush=True)
-print("forward-consumer give-ups (harmless):", ops.read_giveups(), flush=True)
+print("forward-consumer give-ups (harmless):", ops.read_giveups(), "| kfd evicted_ms start / end:", ev0, "/", kfd_evicted_ms(), flush=True)
 # which order the inter-frame passes really took (a re-probe that finds the side stream serialised switches to the plain order)
 rp = [e for e in ops.OVERLAP_LOG if e[0] == "reprobe"]
 print("schedule counts:", ops.SCHED_COUNTS, "| re-probes:", len(rp), "failed:", [(round(e[3], 3), round(e[4], 3)) for e in rp if e[2] != 1],
