@@ -140,3 +140,160 @@ def test_reprobe_switches_the_overlapped_order_off_and_on_again(monkeypatch):
         assert len(w) == 2 and "again" in str(w[1].message)
         assert ops.overlap_reprobe() is True and len(w) == 2
     assert [e[2] for e in ops.OVERLAP_LOG] == [1, 0, 0, 1, 1] and not verdicts
+
+
+def _handback_model(rng, nt, n_guard, n_drain, n_slabs, help_polls, freeze):
+    """A step-by-step model of the overlapped forward's item protocol (sound_bubble_amd/csrc/sb_lstm_bf_fwd.hip: ord_next), one
+    direction: every yield is one device-scope atomic / poll, a random scheduler picks which workgroup moves next.  The producer
+    raises the slab flags one by one (never while `freeze` says it stands still); the DRAIN workgroups -- the launch behind the
+    producer in stream order -- only exist once every slab is up.  -> (times each item was processed, control block)."""
+    counter = [0]
+    ctl = {"held": 0, "pushed": 0, "popped": 0, "slot": [0] * 64}
+    slab = [0] * n_slabs
+    need = sorted(rng.randrange(n_slabs) for _ in range(nt))          # items sorted by the slab they need (ops.tile_order_np)
+    done = [0] * nt
+
+    def guarded():
+        while True:
+            it = counter[0]; counter[0] += 1; yield                    # the draw: one atomic add
+            if it >= nt:
+                return
+            ctl["held"] += 1; yield
+            ok, polls = True, 0
+            while True:
+                up = slab[need[it]]; yield                              # one poll
+                if up:
+                    break
+                polls += 1
+                if polls > help_polls:
+                    ok = False
+                    break
+            if ok:
+                ctl["held"] -= 1; yield
+                done[it] += 1; yield                                    # the item's work, then the next draw
+                continue
+            k = ctl["pushed"]; ctl["pushed"] += 1; yield                # hand the item back ...
+            ctl["slot"][k] = it + 1; yield
+            ctl["held"] -= 1; yield
+            return                                                      # ... and stop helping
+
+    def drain():
+        while True:
+            it = counter[0]; counter[0] += 1; yield
+            if it >= nt:
+                while True:
+                    t = ctl["popped"]; yield
+                    n = ctl["pushed"]; yield
+                    if t < n:
+                        if ctl["popped"] != t:                          # compare-and-swap lost
+                            yield
+                            continue
+                        ctl["popped"] = t + 1; yield
+                        while ctl["slot"][t] == 0:                      # the push's exchange has not landed yet
+                            yield
+                        it = ctl["slot"][t] - 1
+                        break
+                    h = ctl["held"]; yield
+                    n2 = ctl["pushed"]; yield
+                    if h == 0 and n2 == n:
+                        return
+            done[it] += 1; yield
+
+    def producer():
+        for s in range(n_slabs):
+            for _ in range(rng.randrange(1, 6)):
+                yield
+            while freeze():
+                yield
+            slab[s] = 1; yield
+
+    prod = producer()
+    live = [guarded() for _ in range(n_guard)]
+    prod_done, drains_started, steps, asleep = False, False, 0, {}
+    while live or not prod_done or not drains_started:
+        steps += 1
+        assert steps < 5_000_000, "the model does not terminate"
+        if not prod_done and (not live or rng.random() < 0.3):
+            try:
+                next(prod)
+            except StopIteration:
+                prod_done = True
+            continue
+        if prod_done and not drains_started:
+            live += [drain() for _ in range(n_drain)]                   # stream order: behind the producer
+            drains_started = True
+        if not live:
+            continue
+        g = rng.choice(live)
+        if asleep.get(id(g), 0) > steps:
+            continue
+        if rng.random() < 0.02:                                         # a wave that is not scheduled for a long while, at ANY point
+            asleep[id(g)] = steps + rng.randrange(1, 3000)
+            continue
+        try:
+            next(g)
+        except StopIteration:
+            live.remove(g)
+    return done, ctl
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_handback_protocol_processes_every_item_exactly_once_under_any_interleaving(seed):
+    """Model check of ord_next's protocol (draw, bounded wait, hand-back stack, drain, `held == 0` exit) under random
+    interleavings -- with producers that stand still for as long as somebody polls (round 5's event), help budgets from 0 polls
+    (every item handed back) to plenty (none), more or fewer workgroups than items."""
+    import random
+    rng = random.Random(seed)
+    nt = rng.randrange(1, 40)
+    n_guard = rng.randrange(1, 24)
+    help_polls = rng.choice([0, 1, 3, 10, 10_000])
+    state = {"left": rng.choice([0, 50, 400, 5000])}
+
+    def freeze():                                                       # stands still for a while, now and then
+        if state["left"] > 0 and rng.random() < 0.9:
+            state["left"] -= 1
+            return True
+        return False
+    done, ctl = _handback_model(rng, nt, n_guard, rng.randrange(1, 24), rng.randrange(1, 6), help_polls, freeze)
+    assert done == [1] * nt, (seed, done)
+    assert ctl["held"] == 0 and ctl["pushed"] == ctl["popped"] <= n_guard
+
+
+def test_handback_model_can_tell_a_broken_protocol():
+    """The model above has teeth: three one-line mutations of the protocol -- the drain leaves without looking at `held`, without
+    re-reading `pushed` behind `held`, or the waiting workgroup releases `held` BEFORE its push -- each lose items in some of 300
+    seeded interleavings (descheduled waves included), the shipped protocol in none."""
+    import inspect
+    import random
+    src = inspect.getsource(_handback_model)
+    exit_check = "if h == 0 and n2 == n:"
+    push = '            k = ctl["pushed"]; ctl["pushed"] += 1; yield                # hand the item back ...\n'
+    release = '            ctl["slot"][k] = it + 1; yield\n            ctl["held"] -= 1; yield\n'
+    assert exit_check in src and push in src and release in src
+    mutants = {"shipped": src,
+               "no held check": src.replace(exit_check, "if n2 == n:"),
+               "no second read of pushed": src.replace(exit_check, "if h == 0:"),
+               "held released before the push": src.replace(push, '            ctl["held"] -= 1; yield\n' + push)
+                                                   .replace(release, '            ctl["slot"][k] = it + 1; yield\n')}
+    lost = {}
+    for name, text in mutants.items():
+        ns = {}
+        exec(text, ns)
+        bad = 0
+        for seed in range(300):
+            rng = random.Random(seed)
+            nt, n_guard, help_polls = rng.randrange(1, 40), rng.randrange(1, 24), rng.choice([0, 1, 3, 10])
+            state = {"left": rng.choice([50, 400, 5000])}
+
+            def freeze():
+                if state["left"] > 0 and rng.random() < 0.9:
+                    state["left"] -= 1
+                    return True
+                return False
+            try:
+                done, _ = ns["_handback_model"](rng, nt, n_guard, rng.randrange(1, 24), rng.randrange(1, 6), help_polls, freeze)
+                bad += done != [1] * nt
+            except AssertionError:
+                bad += 1
+        lost[name] = bad
+    assert lost["shipped"] == 0 and all(v > 0 for k, v in lost.items() if k != "shipped"), lost
