@@ -1554,6 +1554,14 @@ extern "C" int sb_lstm_fwd_consume(const sb_lstm_fwd_args* a_in, int* flags, int
   // next to the producer: two persistent workgroups per idle CU (254 registers each; none fits on a producer's CU); one
   // that cannot be placed at once simply starts later and draws fewer items
   int g1 = 2 * idle;                                   // (1 per CU: -10 % forward-only, 3: no better)
+  // developer experiment (unmeasured): workgroups are dealt round the 8 XCDs, the producer's ceil(tiles / 8) on
+  // the fullest XCD leave 2 x (CUs per XCD - that) slots there -- SB_FWD_GUARD_XCD_EXACT=1 launches 8 x that many, so that no
+  // guarded workgroup ever waits for a slot (82 tiles: 336 instead of 348).  Unset (the product): as measured all round.
+  static const bool xcd_exact = [] { const char* e = getenv("SB_FWD_GUARD_XCD_EXACT"); return e && e[0] == '1'; }();
+  if (xcd_exact) {
+    const int per_xcd = device_cus() / 8 - (producer_tiles + 7) / 8;
+    if (per_xcd > 0 && 16 * per_xcd < g1) g1 = 16 * per_xcd;
+  }
   if (g1 > 2 * ntiles) g1 = 2 * ntiles;
   if (hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return -1009;
   a.ord_guard = 1; a.ord_grid = g1;
