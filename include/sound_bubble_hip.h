@@ -279,6 +279,38 @@ typedef struct {
 } sb_lstm_bwd_args;
 int sb_lstm_bwd_rec(const sb_lstm_bwd_args* a, void* stream);
 
+/* ---- generic-shape recurrence (round 6) -------------------------------------------------------------------------
+ * The reference constructors' OWN defaults -- Net(D = 64, H = 128, ...): src/models/tfgridnet_realtime_clean_dis_embd3/net.py:21-26,
+ * src/models/tfgridnet_realtime_clean_optim/net.py:21-26 -- and any other width the tuned kernels above (C in {16, 32}, H = 64) are
+ * not built for.  Same operation as sb_lstm_fwd / sb_lstm_bwd_rec with mma == 0 (LayerNorm(C) + nn.LSTM forward and its BPTT:
+ * tfgridnet_causal.py:804-808,819-823,832-843), same position addressing (n_inner / p_outer / p_inner / p_step), for
+ * C in {16, 32, 64} and H in {64, 128} (sb_lstm_gen_supported): H / 16 waves per 16-sequence tile, exact fp32 products
+ * (v_mfma_f32_16x16x4_f32), W_hh in registers, W_ih in LDS.
+ *   hs [P, ndir * H];  save_gates (nullable) [P, ndir, 5, H] fp32 = i, f, g, o (post-activation), c_prev;  save_u [P, C]
+ *   (LayerNorm output; required with save_gates);  h0 / c0 (nullable = zeros), hN / cN (nullable): [nseq, H], direction 0.
+ * sb_lstm_gen_bwd_rec: reads save_gates and dhs [P, ndir * H] (gradient w.r.t. hs), writes dgates [P, ndir, 4 H] (gradient
+ *   w.r.t. the pre-activation gates, rows i, f, g, o).  The input / weight gradients are then position-wise GEMMs:
+ *   du = dgates . W_ih (sb_linear_fwd), dW_ih / dW_hh / db (sb_wgrad, two sources: u, and hs shifted by one step with the
+ *   first step of every sequence masked).  Initial-state gradients are not produced (training starts from zero state). */
+typedef struct {
+  int nseq, nsteps, n_inner, ndir, C, H;
+  int64_t p_outer, p_inner, p_step;
+  const float* x;
+  const float* ln_g; const float* ln_b;
+  const float* w_ih[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2];
+  const float* h0; const float* c0; float* hN; float* cN;
+  float* hs; float* save_gates; float* save_u;
+} sb_lstm_gen_fwd_args;
+int sb_lstm_gen_fwd(const sb_lstm_gen_fwd_args* a, void* stream);
+typedef struct {
+  int nseq, nsteps, n_inner, ndir, H;
+  int64_t p_outer, p_inner, p_step;
+  const float* w_hh[2];
+  const float* save_gates; const float* dhs; float* dgates;
+} sb_lstm_gen_bwd_args;
+int sb_lstm_gen_bwd_rec(const sb_lstm_gen_bwd_args* a, void* stream);
+int sb_lstm_gen_supported(int C, int H);      /* 1 when the two calls above are built for (C, H) */
+
 /* ---- inter-frame backward of a block OVERLAPPED with the intra-frame backward of the same block (round 4) -----------
  * The wide (sb_lstm_bwd_args.wide) inter-frame backward of the BASELINE big configuration has 145 serial chains on 256 CUs.
  * As ONE fused role-split launch (wpart != NULL, split != 0: dgates never leave the chip) it needs half the CU time of the
@@ -425,6 +457,11 @@ typedef struct {
 } sb_wgrad_args;
 int sb_wgrad(const sb_wgrad_args* a, void* stream);
 int sb_wgrad_grid(int64_t positions);
+/* partial rows sb_wgrad will write for these arguments (the row count `scratch` must hold, rows of N*(K+K2)+N floats): 4 *
+   sb_wgrad_grid(P) for the shapes with a register-accumulator kernel; for every other shape (any N, any K, K2 % 16 == 0,
+   fp32 sources, mma == 0) sb_wgrad runs a generic tiled form -- 64 x 64 tiles of dW per workgroup over ranges of positions,
+   one partial row per range -- and this returns its (much smaller) row count.  Negative: the error sb_wgrad would return. */
+int sb_wgrad_scratch_rows(const sb_wgrad_args* a);
 
 /* column sums: out[n] += sum_p g[p*ldg + n], n < N (bias gradients) */
 int sb_colsum(const float* g, int64_t P, int64_t ldg, int N, float* out, float* scratch, void* stream);
@@ -651,6 +688,12 @@ int sb_ln_film_bwd(const float* du, const float* xin, const float* ln_g, const f
 /* y[p, :] = x[p, :] + part[p, 0, :] + part[p, 1, :]  (x, y [P, C]; part [P, 2, C]): the residual + the two directions'
  * partial products of the intra-frame Linear written by sb_lstm_fwd in partial mode (tfgridnet_causal.py:824-827). */
 int sb_add3(const float* x, const float* part, float* y, int64_t P, int C, void* stream);
+
+/* out[r, f, :] = in[r, f, :] (+ bias[:] when bias != NULL) for the tail frequencies Fm <= f < F of every row r (in, out: [rows, F, C]):
+ * the residual of the conv-LSTM intra path at the frequencies beyond down * floor(F / down), which the k = s = down
+ * ConvTranspose1d does not reach (bias: only the `optim` flavour, whose deconvolution has output_padding -- optim/
+ * tfgridnet_causal.py:706-707; dis_embd3 :811-813 crops instead), and, with bias == NULL, the same rows of its backward. */
+int sb_tail_rows(const float* in, const float* bias, float* out, int64_t rows, int F, int Fm, int C, void* stream);
 
 /* ---- iSTFT overlap-add ---------------------------------------------------
  * frames [B, T+1, 288] (row 0 = carried istft_buf frame) -> wave [B, hop*T]:

@@ -93,6 +93,22 @@ class WgradArgs(C.Structure):
                 ("scratch", c_fp), ("in_f16", C.c_int), ("perm_k", C.c_int), ("perm_n", C.c_int), ("bias_mod", C.c_int), ("wv", WView), ("gmax", c_fp), ("mma", C.c_int)]
 
 
+class LstmGenFwdArgs(C.Structure):
+    """sb_lstm_gen_fwd_args: the generic-shape recurrence (reference constructor defaults D = 64 / H = 128)"""
+    _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int), ("C", C.c_int), ("H", C.c_int),
+                ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
+                ("x", c_fp), ("ln_g", c_fp), ("ln_b", c_fp),
+                ("w_ih", c_fp * 2), ("w_hh", c_fp * 2), ("b_ih", c_fp * 2), ("b_hh", c_fp * 2),
+                ("h0", c_fp), ("c0", c_fp), ("hN", c_fp), ("cN", c_fp),
+                ("hs", c_fp), ("save_gates", c_fp), ("save_u", c_fp)]
+
+
+class LstmGenBwdArgs(C.Structure):
+    _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int), ("H", C.c_int),
+                ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
+                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp)]
+
+
 class LstmStreamArgs(C.Structure):
     _fields_ = [("P", i64), ("ndir", C.c_int), ("C", C.c_int),
                 ("shift_pos", i64), ("seg_len", C.c_int), ("skip", C.c_int),
@@ -176,6 +192,10 @@ SYMBOLS = {
     "sb_wview_gather": (_ci, [c_fp, _ci, _ci, _vp]),
     "sb_wgrad": (_ci, [C.POINTER(WgradArgs), _vp]),
     "sb_wgrad_grid": (_ci, [i64]),
+    "sb_wgrad_scratch_rows": (_ci, [C.POINTER(WgradArgs)]),
+    "sb_lstm_gen_fwd": (_ci, [C.POINTER(LstmGenFwdArgs), _vp]),
+    "sb_lstm_gen_bwd_rec": (_ci, [C.POINTER(LstmGenBwdArgs), _vp]),
+    "sb_lstm_gen_supported": (_ci, [_ci, _ci]),
     "sb_lstm_bwd_stream": (_ci, [C.POINTER(LstmStreamArgs), _vp]),
     "sb_lstm_stream_grid": (_ci, [i64]),
     "sb_lstm_bwd_inter_overlapped": (_ci, [C.POINTER(LstmBwdArgs), C.POINTER(LstmStreamArgs), _vp, _ci, _vp]),
@@ -207,6 +227,7 @@ SYMBOLS = {
     "sb_film_bank_fwd": (_ci, [C.POINTER(FilmBankArgs), _vp]),
     "sb_film_bank_bwd_scratch": (_ci, [_ci, _ci, _ci, _ci]),
     "sb_film_bank_bwd": (_ci, [C.POINTER(FilmBankArgs), _vp]),
+    "sb_tail_rows": (_ci, [c_fp, c_fp, c_fp, i64, _ci, _ci, _ci, _vp]),
     "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, c_fp, _vp]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsoundbubble_hip.so")
-SOURCES = ["sb_lstm.hip", "sb_lstm_vec.hip", "sb_lstm_bf_fwd.hip", "sb_lstm_bf_bwd.hip", "sb_lstm_stream.hip", "sb_attention.hip",
+SOURCES = ["sb_lstm.hip", "sb_lstm_gen.hip", "sb_lstm_vec.hip", "sb_lstm_bf_fwd.hip", "sb_lstm_bf_bwd.hip", "sb_lstm_stream.hip", "sb_attention.hip",
            "sb_linear.hip", "sb_elementwise.hip", "sb_mrstft.hip"]
 HEADERS = [os.path.join(CSRC, "sb_common.h"), os.path.join(CSRC, "sb_lstm_bf_common.h"),
            os.path.join(HERE, "..", "include", "sound_bubble_hip.h")]

@@ -524,6 +524,21 @@ __global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ x, 
   }
 }
 
+// out[r, f, :] = in[r, f, :] (+ bias) for the tail frequencies f in [Fm, F) of every row r (= (b, t)): the residual of the
+// conv-LSTM intra path beyond down * floor(F / down) frequencies, and its backward (bias == NULL)
+__global__ __launch_bounds__(256) void tail_rows_kernel(const float* __restrict__ in, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int64_t rows, int F, int Fm, int C) {
+  const int tw = (F - Fm) * C;
+  const int64_t total = rows * tw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / tw;
+    const int e = (int)(i - r * tw);
+    const int64_t off = (r * F + Fm) * C + e;
+    const float v = in[off];
+    out[off] = bias ? v + bias[e % C] : v;
+  }
+}
+
 inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 // several small dense copies in one launch (workgroup row y = job y): the streaming chunk step's state write-back
@@ -780,6 +795,15 @@ extern "C" int sb_add3(const float* x, const float* part, float* y, int64_t P, i
   unsigned gx = nblk(n4);
   if (gx > 8192) gx = 8192;
   hipLaunchKernelGGL(add3_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, x, part, y, n4, C / 4);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sb_tail_rows(const float* in, const float* bias, float* out, int64_t rows, int F, int Fm, int C, void* stream) {
+  if (!in || !out || rows <= 0 || C <= 0 || Fm < 0 || Fm >= F) return -1001;
+  unsigned gx = nblk(rows * (F - Fm) * C);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(tail_rows_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, in, bias, out, rows, F, Fm, C);
   SB_CHECK_LAUNCH();
   return 0;
 }

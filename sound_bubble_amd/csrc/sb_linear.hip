@@ -781,6 +781,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   wgrad16_body<2, NSEG, TS>(a, P);
 }
 
+// Generic form of the weight gradient (any N, any K / K2 that are multiples of 16; fp32 sources): the fallback of sb_wgrad for
+// the shapes no register-accumulator instantiation above covers -- the 512-row LSTM gradients and the 256 / 320-column
+// Conv1d / ConvTranspose1d gradients of the reference constructor's default widths (D = 64, H = 128).  A workgroup owns a
+// 64 x 64 tile of dW (blockIdx.y: rows n, blockIdx.z: columns k over [K | K2]) and a contiguous range of positions
+// (blockIdx.x): 32 positions at a time are staged TRANSPOSED in LDS ([column][position], padded), so that both MFMA operands
+// are one ds_read_b128 per lane and 16-position chunk; wave w owns rows 16w .. 16w + 15 of the tile.  One partial row per
+// position range, reduced by wgrad_reduce_kernel like the rows of the kernels above (same scratch layout).
+constexpr int WGEN_POS = 32, WGEN_LD = WGEN_POS + 4;
+__global__ __launch_bounds__(256) void wgrad_gen_kernel(sb_wgrad_args a, int64_t P, int64_t per) {
+  __shared__ __attribute__((aligned(16))) float GT[64][WGEN_LD];
+  __shared__ __attribute__((aligned(16))) float IT[64][WGEN_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
+  const int Ktot = a.K + a.K2;
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
+  const int64_t p_begin = (int64_t)blockIdx.x * per, p_end = min(P, p_begin + per);
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  float csum = 0.f;
+  // staging role: thread -> column c = tid & 63, positions 4 * (tid >> 6) + 8 i' ... (8 positions per thread and operand)
+  const int sc = tid & 63, sp = tid >> 6;
+  const int gn = n0 + sc;
+  const bool gok = gn < a.N;
+  const int kk = k0 + sc;
+  const bool k1 = kk < a.K, k2 = !k1 && kk < Ktot;
+  int64_t koff = 0;
+  if (k1) { const int seg = kk / a.kseg; koff = (int64_t)seg * a.is_seg + (kk - seg * a.kseg); }
+  const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
+  for (int64_t pc = p_begin; pc < p_end; pc += WGEN_POS) {
+#pragma unroll
+    for (int i = 0; i < WGEN_POS / 4; ++i) {
+      const int pl = sp + 4 * i;
+      const int64_t p = pc + pl;
+      const bool ok = p < p_end;
+      float gv = 0.f, iv = 0.f;
+      if (ok && gok) gv = a.g[p * a.ldg + gn];
+      if (ok && k1) {
+        const int64_t ioff = in_dense ? p * a.is_f : off3(split_pos((unsigned)p, a.T, a.F), a.is_b, a.is_t, a.is_f);
+        iv = a.in[ioff + koff];
+      } else if (ok && k2) {
+        const int idx = (int)((unsigned)p % (unsigned)a.seg_len);
+        if (idx >= a.skip_first && idx < a.seg_len - a.skip_last) iv = a.in2[p * a.ld2 + a.shift2 + (kk - a.K)];
+      }
+      GT[sc][pl] = gv;
+      IT[sc][pl] = iv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < WGEN_POS / 16; ++m) {
+      const f32x4 a4 = ld4(&GT[16 * w + j][16 * m + 4 * q]);
+      csum += a4[0] + a4[1] + a4[2] + a4[3];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) acc[kt] = mfma16x4(a4, ld4(&IT[16 * kt + j][16 * m + 4 * q]), acc[kt]);
+    }
+    __syncthreads();
+  }
+  float* part = a.scratch + (size_t)blockIdx.x * ((size_t)a.N * Ktot + a.N);
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * w + 4 * q + r, k = k0 + 16 * kt + j;
+      if (n < a.N && k < Ktot) part[(size_t)n * Ktot + k] = acc[kt][r];
+    }
+  if (blockIdx.z == 0) {
+    const float cs = quad_sum(csum);
+    const int n = n0 + 16 * w + j;
+    if (q == 0 && n < a.N) part[(size_t)a.N * Ktot + n] = cs;
+  }
+}
+// position ranges (= partial rows) of the generic form: enough workgroups to fill the chip a few times over, ranges of whole
+// 32-position chunks
+static int wgrad_gen_rows(int64_t P, int N, int Ktot, int64_t* per_out) {
+  const int tiles = ((N + 63) / 64) * ((Ktot + 63) / 64);
+  int64_t rows = (1536 + tiles - 1) / tiles;
+  const int64_t chunks = (P + WGEN_POS - 1) / WGEN_POS;
+  if (rows > chunks) rows = chunks;
+  if (rows < 1) rows = 1;
+  const int64_t per = (chunks + rows - 1) / rows * WGEN_POS;
+  rows = (P + per - 1) / per;
+  if (per_out) *per_out = per;
+  return (int)rows;
+}
+
 // out (+)= sum over partial rows; 2-D grid (columns x row-chunks) + atomics so that the reduction of
 // 512 x 24 K partials is itself a wide, short kernel.  Columns route to dW1 / dW2 / the bias gradients.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int rows, int N, int K1,
@@ -898,7 +980,7 @@ int launch_linear(const sb_linear_args& a, int64_t P, hipStream_t st, int ny) {
     case SB_EPI_NONE: return launch_linear2<NT, SB_EPI_NONE>(a, P, st, ny);
     case SB_EPI_RES: return launch_linear2<NT, SB_EPI_RES>(a, P, st, ny);
     case SB_EPI_PRELU: return launch_linear2<NT, SB_EPI_PRELU>(a, P, st, 1);
-    case SB_EPI_LN: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LN>(a, P, st, 1); else return -1006;
+    case SB_EPI_LN: if constexpr (NT <= 2 || NT == 4) return launch_linear2<NT, SB_EPI_LN>(a, P, st, 1); else return -1006;
     case SB_EPI_LNBWD: if constexpr (NT <= 2) return launch_linear2<NT, SB_EPI_LNBWD>(a, P, st, 1); else return -1006;
     default: return -1007;
   }
@@ -987,9 +1069,9 @@ extern "C" int sb_wview_gather(const sb_wview_job* jobs, int njobs, int max_elem
   return 0;
 }
 
-extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
-  if (!ap) return -1001;
-  const sb_wgrad_args& a = *ap;
+// One body for the launch and for the question "how many partial rows will this call write" (sb_wgrad_scratch_rows): the
+// dispatch below is the only place that knows which kernel serves a shape.  launch == false: nothing is launched, *rows_out is set.
+static int wgrad_dispatch(const sb_wgrad_args& a, void* stream, bool launch, int* rows_out) {
   const int64_t P = (int64_t)a.B * a.T * a.F;
   if (P <= 0 || P >= (1ll << 31)) return -1001;          // 32-bit position arithmetic in the kernels
   const int nblk = (a.N + 15) / 16, kt1 = (a.K + 15) / 16, kt2 = a.K2 / 16, ntw = nblk;
@@ -1005,7 +1087,7 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   const bool wide = kt2 == 0 && a.K % 16 == 0 && a.N % 16 == 0 && ts > 0 && kt1 % ts == 0 && a.is_b % 4 == 0 &&
                     a.is_t % 4 == 0 && a.is_f % 4 == 0 && a.is_seg % 4 == 0 && a.ldg % 4 == 0 &&
                     (reinterpret_cast<uintptr_t>(a.in) % (4 * es)) == 0 && (reinterpret_cast<uintptr_t>(a.g) % 16) == 0;
-  bool launched = false;
+  bool launched = false, generic = false;
   // fp16 matrix-pipe form for the K = 288 / 144 convolutions (mma == 1): single source, whole segments of 6 or 3 tiles
   if (a.mma == 1) {
     const bool ok16 = kt2 == 0 && a.K % 16 == 0 && ts > 0 && kt1 % ts == 0 && a.is_b % 4 == 0 && a.is_t % 4 == 0 &&
@@ -1014,16 +1096,17 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
     if (!ok16 || a.in_f16 || ntw > 2) return -1004;
 #define SB_W16(NTW_, NSEG_, TS_) \
     if (!launched && ntw == NTW_ && kt1 == NSEG_ * TS_ && ts == TS_) { \
-      hipLaunchKernelGGL((wgrad16_kernel<NTW_, NSEG_, TS_>), grid, block, 0, st, a, P); launched = true; }
+      if (launch) hipLaunchKernelGGL((wgrad16_kernel<NTW_, NSEG_, TS_>), grid, block, 0, st, a, P); launched = true; }
     SB_W16(1, 3, 6) SB_W16(1, 3, 3)
 #undef SB_W16
     if (!launched && ntw == 2 && kt1 == 18 && ts == 6) {
-      hipLaunchKernelGGL((wgrad16_n32_kernel<3, 6>), grid, block, 0, st, a, P); launched = true; }
+      if (launch) hipLaunchKernelGGL((wgrad16_n32_kernel<3, 6>), grid, block, 0, st, a, P);
+      launched = true; }
     if (!launched) return -1004;
   }
 #define SB_WW(NTW_, KT1_, TS_, H16_) \
   if (!launched && wide && ntw == NTW_ && kt1 == KT1_ && ts == TS_ && (a.in_f16 != 0) == H16_) { \
-    hipLaunchKernelGGL((wgrad_wide_kernel<NTW_, KT1_, TS_, H16_>), grid, block, 0, st, a, P); launched = true; }
+    if (launch) hipLaunchKernelGGL((wgrad_wide_kernel<NTW_, KT1_, TS_, H16_>), grid, block, 0, st, a, P); launched = true; }
   SB_WW(1, 4, 4, true) SB_WW(2, 4, 4, true)
   SB_WW(1, 1, 1, false) SB_WW(1, 2, 2, false) SB_WW(1, 4, 4, false) SB_WW(1, 8, 8, false) SB_WW(1, 5, 5, false)
   SB_WW(1, 9, 3, false) SB_WW(1, 18, 6, false) SB_WW(2, 1, 1, false) SB_WW(2, 2, 2, false) SB_WW(2, 4, 4, false)
@@ -1034,22 +1117,47 @@ extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
   if (launched) {
   } else if (a.in_f16) {
     if (kt1 != 4 || kt2 != 0 || ntw > 2) return -1004;
-    if (ntw == 1) hipLaunchKernelGGL((wgrad_kernel<1, 4, 0, true>), grid, block, 0, st, a, P);
+    if (!launch) {}
+    else if (ntw == 1) hipLaunchKernelGGL((wgrad_kernel<1, 4, 0, true>), grid, block, 0, st, a, P);
     else hipLaunchKernelGGL((wgrad_kernel<2, 4, 0, true>), grid, block, 0, st, a, P);
   } else
 #define SB_WG(NTW_, KT1_, KT2_) \
-  if (ntw == NTW_ && kt1 == KT1_ && kt2 == KT2_) { hipLaunchKernelGGL((wgrad_kernel<NTW_, KT1_, KT2_>), grid, block, 0, st, a, P); } else
+  if (ntw == NTW_ && kt1 == KT1_ && kt2 == KT2_) { if (launch) hipLaunchKernelGGL((wgrad_kernel<NTW_, KT1_, KT2_>), grid, block, 0, st, a, P); } else
   SB_WG(1, 1, 0) SB_WG(1, 2, 0) SB_WG(1, 4, 0) SB_WG(1, 8, 0) SB_WG(1, 5, 0) SB_WG(1, 9, 0) SB_WG(1, 18, 0)
   SB_WG(2, 1, 0) SB_WG(2, 2, 0) SB_WG(2, 4, 0) SB_WG(2, 8, 0) SB_WG(2, 10, 0) SB_WG(2, 18, 0)
-  SB_WG(3, 8, 0) SB_WG(4, 8, 0) SB_WG(5, 8, 0) SB_WG(8, 8, 0) SB_WG(10, 8, 0) SB_WG(1, 3, 0) SB_WG(1, 6, 0) SB_WG(2, 5, 0) SB_WG(2, 6, 0) SB_WG(1, 1, 4) SB_WG(2, 2, 4) { return -1004; }
+  SB_WG(3, 8, 0) SB_WG(4, 8, 0) SB_WG(5, 8, 0) SB_WG(8, 8, 0) SB_WG(10, 8, 0) SB_WG(1, 3, 0) SB_WG(1, 6, 0) SB_WG(2, 5, 0) SB_WG(2, 6, 0) SB_WG(1, 1, 4) SB_WG(2, 2, 4)
+  { generic = true; }
 #undef SB_WG
+  int rows = (int)grid.x * 4;
+  if (generic) {
+    // any other shape: the generic tiled form (fp32 sources, whole 16-column K tiles)
+    if (a.kseg <= 0) return -1004;
+    int64_t per = 0;
+    rows = wgrad_gen_rows(P, a.N, a.K + a.K2, &per);
+    if (launch)
+      hipLaunchKernelGGL(wgrad_gen_kernel, dim3(rows, (a.N + 63) / 64, (a.K + a.K2 + 63) / 64), block, 0, st, a, P, per);
+  }
+  if (rows_out) *rows_out = rows;
+  if (!launch) return 0;
   SB_CHECK_LAUNCH();
   const int total = a.N * (a.K + a.K2) + a.N;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, grid.x >= 64 ? 16 : 1), dim3(256), 0, st, a.scratch,
-                     (int)grid.x * 4, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out, a.perm_k, a.perm_n,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, rows >= 256 ? 16 : 1), dim3(256), 0, st, a.scratch,
+                     rows, a.N, a.K, a.K2, a.dW, a.dW2, a.dbias, a.dbias2, a.transpose_out, a.perm_k, a.perm_n,
                      a.bias_mod, a.wv);
   SB_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sb_wgrad(const sb_wgrad_args* ap, void* stream) {
+  if (!ap) return -1001;
+  return wgrad_dispatch(*ap, stream, true, nullptr);
+}
+
+extern "C" int sb_wgrad_scratch_rows(const sb_wgrad_args* ap) {
+  if (!ap) return -1001;
+  int rows = 0;
+  const int rc = wgrad_dispatch(*ap, nullptr, false, &rows);
+  return rc ? rc : rows;
 }
 
 extern "C" int sb_colsum(const float* g, int64_t P, int64_t ldg, int N, float* out, float* scratch, void* stream) {

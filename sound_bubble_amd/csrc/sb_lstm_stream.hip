@@ -1747,6 +1747,7 @@ extern "C" int sb_ln_bwd(const sb_ln_bwd_args* ap, void* stream) {
   dim3 grid(sb_ln_bwd_grid(ap->P)), block(256);
   if (ap->C == 32) hipLaunchKernelGGL(ln_bwd_kernel<32>, grid, block, 0, (hipStream_t)stream, *ap);
   else if (ap->C == 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, 0, (hipStream_t)stream, *ap);
+  else if (ap->C == 64) hipLaunchKernelGGL(ln_bwd_kernel<64>, grid, block, 0, (hipStream_t)stream, *ap);
   else return -1002;
   SB_CHECK_LAUNCH();
   return 0;

@@ -516,7 +516,7 @@ class IntraConvFn(torch.autograd.Function):
         s_h = (Kd * 2 * H, 0, 2 * H)
         ops.linear(hs, wd, bd, y, grid, s_h, s_x, 2 * H, down * Cc, epi=L.EPI_RES, res=x)
         if Fm < F:      # tail frequencies: residual (+ bias when ConvTranspose1d has output_padding)
-            y[:, :, Fm:, :] = x[:, :, Fm:, :] + (dec_b if bias_tail else 0.0)
+            ops.tail_rows(x, dec_b if bias_tail else None, y, B * T, F, Fm, Cc)
         if train:
             ctx.save_for_backward(x, act_a, ln_g, wif, whf, wir, whr, hs, u, v_pre, ln_b, bif, bhf, bir, bhr,
                                   conv_w, conv_b, dec_w, dec_b, wdT, wcT, *[t for t in gates if t is not None])
@@ -554,7 +554,8 @@ class IntraConvFn(torch.autograd.Function):
         t_dec_w, t_dec_b = gt("dec_w", dec_w), gt("dec_b", dec_b)
         ops.wgrad(dym, NC, NC, hs, s2H, gP2, 2 * H, t_dec_w, dbias=t_dec_b, transpose_out=True, perm_n=Cc, bias_mod=Cc)
         if Fm < F and bias_tail:
-            t_dec_b += dy[:, :, Fm:, :].sum((0, 1, 2))
+            for f in range(Fm, F):
+                ops.colsum(dy, B * T, F * Cc, Cc, t_dec_b, g_off=f * Cc)
         # BPTT
         geom = Geom.intra(B * T, Kd)
         tg = [(gt("wif", wif), gt("whf", whf), gt("bif", bif), gt("bhf", bhf)),
@@ -575,7 +576,7 @@ class IntraConvFn(torch.autograd.Function):
         gm_dx = ops.zero_scalar(dev) if (ops.ABSMAX_HINTS and Fm == F) else None
         ops.linear(dv, wcT, None, dx, grid, s_v, s_x, Cc, NC, epi=L.EPI_RES, res=dy, absmax_out=gm_dx)
         if Fm < F:
-            dx[:, :, Fm:, :] = dy[:, :, Fm:, :]
+            ops.tail_rows(dy, None, dx, B * T, F, Fm, Cc)
         if gm_dx is not None:
             ops.absmax_hint_put(dx, gm_dx)
         # dW[co][k = j*C + ci] -> conv_w [co, ci, j]
@@ -776,12 +777,17 @@ def _cached_filter_form(filters, tag, build):
     return ent[1]
 
 
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
 def _stft_weight(filters):
-    """[290,1,288] asteroid filter bank -> [304, 288] analysis GEMM weight (zero rows 290..303)"""
+    """[2F, 1, win] asteroid filter bank -> [304, win16] analysis GEMM weight (zero rows 2F..303; zero columns win..win16-1 when
+    the window is not a multiple of the GEMM's 16-wide K chunks: the reference constructor's n_fft = 280)"""
     def build(flt):
         f = flt.reshape(flt.shape[0], -1)
-        w = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
-        w[: f.shape[0]] = f
+        w = torch.zeros(NSPEC, _pad16(f.shape[1]), device=f.device, dtype=torch.float32)
+        w[: f.shape[0], : f.shape[1]] = f
         return w
     return _cached_filter_form(filters, "stft", build)
 
@@ -803,10 +809,14 @@ class FrontEndFn(torch.autograd.Function):
         dev = mix.device
         mix = mix.contiguous()
         train = GRAD_MODE and any(ctx.needs_input_grad)
-        # 1. STFT as a position-wise GEMM over overlapping rows
+        # 1. STFT as a position-wise GEMM over overlapping rows (K = the window rounded up to whole 16-sample chunks against zero
+        # filter columns: the rows are then padded so that the last frame's chunk stays inside the tensor)
         spec = torch.empty(B * M, T, NSPEC, device=dev, dtype=torch.float32)
-        ops.linear(mix, _stft_weight(enc_filters), None, spec, (B * M, T, 1), (Np, hop, 0), (T * NSPEC, NSPEC, 0),
-                   win, NSPEC)
+        winp = _pad16(win)
+        if winp != win:
+            mix = torch.nn.functional.pad(mix, (0, winp - win))
+        ops.linear(mix, _stft_weight(enc_filters), None, spec, (B * M, T, 1), (mix.shape[-1], hop, 0), (T * NSPEC, NSPEC, 0),
+                   winp, NSPEC)
         # 2. features into the zero-bordered, channel-padded tensor zp [B, T+2, F+2, 32]
         zp = _ws_zeros("zp", (B, T + 2, F + 2, ZC), dev)
         if zp is None:
@@ -858,14 +868,16 @@ class FrontEndFn(torch.autograd.Function):
 
 
 def _istft_weights(dec_filters):
-    """asteroid synthesis bank [290,1,288] -> GEMM weights for interleaved (re,im) spectra rows:
-    w_syn [288, 304] (frames = spec_row . w_syn^T) and w_ana [304, 288] (its transpose, for the gradient)."""
+    """asteroid synthesis bank [2F, 1, win] -> GEMM weights for interleaved (re,im) spectra rows:
+    w_syn [win16, 304] (frames = spec_row . w_syn^T) and w_ana [304, win16] (its transpose, for the gradient); win16 = the
+    window rounded up to 16 samples, the extra synthesis samples identically zero (n_fft = 280: a 288-sample frame whose
+    last 8 samples add nothing in the overlap-add)."""
     def build(flt):
         f = flt.reshape(flt.shape[0], -1)                               # [2F, win], rows: re(0..F-1), im(F..2F-1)
         Fq = f.shape[0] // 2
         inter = torch.stack([f[:Fq], f[Fq:]], dim=1).reshape(2 * Fq, -1)    # row 2f+o
-        w_ana = torch.zeros(NSPEC, f.shape[1], device=f.device, dtype=torch.float32)
-        w_ana[: 2 * Fq] = inter
+        w_ana = torch.zeros(NSPEC, _pad16(f.shape[1]), device=f.device, dtype=torch.float32)
+        w_ana[: 2 * Fq, : f.shape[1]] = inter
         return w_ana.t().contiguous(), w_ana
     return _cached_filter_form(dec_filters, "istft", build)
 
@@ -879,7 +891,7 @@ class BackEndFn(torch.autograd.Function):
     def forward(ctx, y, dec_filters, dw, db, deconv_buf, istft_buf, hop, wk, bk):
         B, T, F, Cc = y.shape
         dev = y.device
-        win = dec_filters.shape[-1]
+        win = _pad16(dec_filters.shape[-1])      # (frames of whole 16-sample chunks: see _istft_weights)
         train = GRAD_MODE and any(ctx.needs_input_grad)
         assert dw.shape[1] == 2, "num_src=1 only (every shipped config)"
         yp = _ws_zeros("yp", (B, T + 2, F + 2, Cc), dev)

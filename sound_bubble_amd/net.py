@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as tF
 
 from . import functional as Fn
+from . import functional_gen as Gn
 from . import _lib as L
 from .forms import WeightForms
 
@@ -137,12 +138,20 @@ class _NetBase(nn.Module):
                local_atten_len, E, chunk_causal, num_src, spectral_masking, use_first_ln, merge_method, directional,
                conv_lstm, lstm_down, fb_type, dis_type):
         n_freqs = (stft_back_pad + stft_chunk_size + stft_pad_size) // 2 + 1
+        if L == 0:
+            # the reference divides by its head count in every block's constructor, attention on or off (`emb_dim // n_head`:
+            # dis_embd3/tfgridnet_causal.py:596, optim :484), so Net() at its own default L = 0 raises exactly this there
+            # (tests/golden/ctor_behaviour.json, recorded from the imported reference) -- same error behaviour here
+            raise ZeroDivisionError("integer division or modulo by zero")
         if use_attn and (L <= 0 or D % L or L > 8 or n_freqs * D > 5120):
             raise NotImplementedError("use_attn=True needs 1 <= L <= 8 heads dividing D and F*D <= 5120")
-        if H != 64:
-            raise NotImplementedError("the recurrent HIP kernels are built for H=64 (every shipped config)")
-        if D not in (16, 32):
-            raise NotImplementedError("D must be 16 or 32 (shipped configs)")
+        # D in {16, 32} with H = 64 (every shipped config): the tuned fp16x3 kernels and their overlapped schedules.  Any other
+        # width the library's generic-shape kernels are built for -- first of all the reference constructor's own defaults,
+        # D = 64 / H = 128 (net.py:21-26) -- runs the same stages on them (functional_gen.py, csrc/sb_lstm_gen.hip)
+        self._generic = not (H == 64 and D in (16, 32))
+        if D not in (16, 32, 64) or H not in (64, 128):
+            raise NotImplementedError("D must be 16, 32 or 64 and H 64 or 128 (the shipped configs' and the reference "
+                                      "constructor's own widths)")
         if merge_method not in ("early_cat", "None") or directional or spectral_masking or stft_back_pad != 0 or fb_type != "stft":
             raise NotImplementedError("merge_method 'early_cat' (every shipped config) or 'None' (the constructor default), "
                                       "omnidirectional, no spectral masking, stft_back_pad=0")
@@ -161,8 +170,9 @@ class _NetBase(nn.Module):
         self.use_attn, self.n_head, self.local_atten_len = use_attn, L, local_atten_len
         self.tfgridnet = _TFGridNetParams(self.nfft, stft_chunk_size, num_ch, D, B, H, conv_lstm, lstm_down,
                                           self.flavour, num_src, use_first_ln, dis_type, use_attn, L, E, merge_method)
-        if self.nfft % 16 or (self.nfft // 2 + 1) * 2 > Fn.NSPEC:
-            raise NotImplementedError("n_fft must be a multiple of 16 and <= 302")
+        if self.nfft % 4 or stft_chunk_size % 4 or (self.nfft // 2 + 1) * 2 > Fn.NSPEC or self.nfft > 2 * stft_chunk_size:
+            raise NotImplementedError("n_fft and the hop must be multiples of 4 (16-byte rows), n_fft <= 302 and <= 2 hops "
+                                      "(one carried iSTFT frame)")
 
     # ---- kernel-layout weight forms (one arena, one refresh launch per optimiser step: forms.py) ----
     def _weight_forms(self):
@@ -261,6 +271,9 @@ class _NetBase(nn.Module):
         ovl = None                 # overlapped forward: block i-1's inter-frame kernel is still producing y
         used_overlap = False
         for i, blk in enumerate(tg.blocks):
+            if self._generic:
+                y = self._generic_block(y, e, i, blk, gb[f"buf{i}"], wf)
+                continue
             if not film_done:
                 y = self._film(y, e, i)
             film_done = False
@@ -327,6 +340,35 @@ class _NetBase(nn.Module):
         Fn.ops.FILM_OF.clear()                     # (a hand-over nobody took -- e.g. a conv-LSTM block -- must not outlive this forward)
         Fn.WORKSPACE = None                        # (the staging workspaces belong to THIS model's forward only)
         return {"output": out, "next_state": st}
+
+
+    def _generic_block(self, y, e, i, blk, b, wf):
+        """one GridNet block at a layer width the tuned kernels are not built for (functional_gen.py): FiLM, intra-frame pass,
+        inter-frame pass, attention -- stage by stage, no fusion across stages"""
+        y = self._film(y, e, i)
+        rnn = blk.intra_rnn
+        if self.conv_lstm:
+            y = Gn.GenIntraConvFn.apply(y, blk.conv.weight, blk.conv.bias, blk.act.weight, blk.norm.norm.weight,
+                                        blk.norm.norm.bias, *_lstm_dir(rnn, False), *_lstm_dir(rnn, True),
+                                        blk.deconv.weight, blk.deconv.bias, self.lstm_down,
+                                        self.flavour == "optim", wf[f"wc{i}"], wf[f"wd{i}"], wf[f"bd{i}"],
+                                        wf[f"wdT{i}"], wf[f"wcT{i}"])
+        else:
+            y = Gn.GenIntraPlainFn.apply(y, blk.intra_norm.norm.weight, blk.intra_norm.norm.bias,
+                                         *_lstm_dir(rnn, False), *_lstm_dir(rnn, True), blk.intra_linear.weight,
+                                         blk.intra_linear.bias)
+        y, b["h0"], b["c0"] = Gn.GenInterFn.apply(y, blk.inter_norm.norm.weight, blk.inter_norm.norm.bias,
+                                                  *_lstm_dir(blk.inter_rnn, False), blk.inter_linear.weight,
+                                                  blk.inter_linear.bias, b["h0"], b["c0"])
+        if self.use_attn:
+            args = []
+            for name in ("attn_conv_Q", "attn_conv_K", "attn_conv_V", "attn_concat_proj"):
+                br = getattr(blk, name)
+                lin, act, ln = getattr(br, "0"), getattr(br, "1"), getattr(br, "3").norm
+                args += [lin.weight, lin.bias, act.weight, ln.weight, ln.bias]
+            y, b["K_buf"], b["V_buf"] = Fn.AttentionFn.apply(y, b["K_buf"], b["V_buf"], *args, self.n_head, self.E,
+                                                             self.local_atten_len)
+        return y
 
 
 class NetDisEmbd3(_NetBase):

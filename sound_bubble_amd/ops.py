@@ -1379,6 +1379,12 @@ INTER_FILM = os.environ.get("SB_NO_INTER_FILM", "0") != "1"
 STREAM_LIN_WGRAD = os.environ.get("SB_NO_STREAM_LIN_WGRAD", "0") != "1"
 
 
+def tail_rows(inp, bias, out, rows, F_, Fm, Cc):
+    """out[r, f, :] = inp[r, f, :] (+ bias) for Fm <= f < F_ of every row (inp, out [rows, F_, C]): the conv-LSTM intra path's
+    residual at the frequencies its k = s = down convolutions do not reach"""
+    L.check(L.load().sb_tail_rows(_p(inp), _p(bias), _p(out), rows, F_, Fm, Cc, _stream()), "sb_tail_rows")
+
+
 def add3(x, part):
     """x [P, C] + part[:, 0] + part[:, 1]  (part [P, 2, C])"""
     y = torch.empty_like(x)
@@ -1585,8 +1591,11 @@ def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None,
     cap = max(c for c in (16, 32, 48, 64, 80, 96, 128) if c <= cap)
     # a handful of positions (the streaming chunk step): ONE launch, column-sliced over grid.y inside the library -- the
     # 304 x 288 STFT basis is then read by 19 workgroups instead of three launches of one workgroup each
+    # the fp16x3 form is built for N <= 32 and K = 9 x 32 / 9 x 16 (C in {16, 32}); wider layers (the reference constructor's
+    # D = 64) take the fp32-input kernel
+    f16x3 = bool(f16x3 and LINEAR_F16X3 and N <= 32 and (K + 31) // 32 in (9, 5))
     one_launch = (B_ * T_ * F_ <= 256 and epi in (L.EPI_NONE, L.EPI_RES) and not want_partials and N >= 64 and N % 16 == 0
-                  and not (f16x3 and LINEAR_F16X3))
+                  and not f16x3)
     while n0 < N:
         nc = N if one_launch else min(cap, N - n0)
         if not one_launch and nc not in (16, 32, 48, 64, 80, 96, 128):       # NT in {1,2,3,4,5,6,8}
@@ -1617,7 +1626,7 @@ def linear(inp, w, bias, out, grid, in_strides, out_strides, K, N, *, kseg=None,
             partials = torch.empty(g, 2 * N + 1, device=out.device, dtype=torch.float32)
             a.partials = _p(partials)
         a.accumulate = 1 if accumulate else 0
-        a.mma = 1 if (f16x3 and LINEAR_F16X3) else 0      # long-K narrow convolutions on the fp16 pipe (fp32-class split)
+        a.mma = 1 if f16x3 else 0      # long-K narrow convolutions on the fp16 pipe (fp32-class split)
         if a.n_valid > 0:
             L.check(lib.sb_linear_fwd(C.byref(a), _stream()), "sb_linear_fwd")
         n0 += nc
@@ -1637,10 +1646,6 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     lib = L.load()
     B_, T_, F_ = grid
     P = B_ * T_ * F_
-    ng = lib.sb_wgrad_grid(P)
-    scratch = torch.empty(ng * 4, N * (K + K2) + N, device=dW.device, dtype=torch.float32)   # one row per wave (every wave writes its row)
-    if _STREAM_OVERRIDE is not None:
-        _DEFER["keep"].append(scratch)                # (a side-stream launch: held until the join, see on_stream)
     a = L.WgradArgs()
     a.B, a.T, a.F, a.N, a.K = B_, T_, F_, N, K
     a.kseg = ((K + 15) // 16) * 16 if kseg is None else kseg
@@ -1660,9 +1665,17 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     a.perm_k, a.perm_n, a.bias_mod = perm_k, perm_n, bias_mod     # native-layout destinations (see the header)
     if wview is not None:                                         # ... general form: a weight view over dW's tensor
         a.wv = wview
-    a.mma = 1 if (f16 and LINEAR_F16X3) else 0                    # 3x3 convolutions' dW on the fp16 pipe, hi+lo operands
+    # 3x3 convolutions' dW on the fp16 pipe, hi+lo operands: built for N <= 32, K = 9 x 32 (or 9 x 16 with N <= 16)
+    a.mma = 1 if (f16 and LINEAR_F16X3 and ((N <= 32 and K == 288 and a.kseg == 96) or (N <= 16 and K == 144 and a.kseg == 48))) else 0
     if a.mma:
         a.gmax = _p(gmax if gmax is not None else absmax_or_hint(g))   # power-of-two scale against fp16 underflow
+    # partial rows: four per workgroup for the shapes with a register-accumulator kernel; the library's generic tiled form (any
+    # other shape: the D = 64 / H = 128 layers) says how many position ranges it will use
+    rows = lib.sb_wgrad_scratch_rows(C.byref(a))
+    L.check(min(rows, 0), "sb_wgrad_scratch_rows")
+    scratch = torch.empty(rows, N * (K + K2) + N, device=dW.device, dtype=torch.float32)   # one row per wave / position range (fully written)
+    if _STREAM_OVERRIDE is not None:
+        _DEFER["keep"].append(scratch)                # (a side-stream launch: held until the join, see on_stream)
     a.dW, a.dW2, a.dbias, a.dbias2, a.scratch = _p(dW, "dW"), _p(dW2), _p(dbias), _p(dbias2), _p(scratch)
     L.check(lib.sb_wgrad(C.byref(a), _stream()), "sb_wgrad")
 
@@ -1963,3 +1976,71 @@ def l1_grad(x, y, gscale, dx, accumulate, loss, loss_scale):
     part = torch.empty((n + 255) // 256, device=x.device, dtype=torch.float32)
     L.check(L.load().sb_l1_grad(_p(x), _p(y), n, gscale, _p(dx), 1 if accumulate else 0, _p(part), loss_scale, _p(loss), 1,
                                 _stream()), "sb_l1_grad")
+
+
+# ---- generic-shape recurrence (sb_lstm_gen.hip): the reference constructor's own widths, D = 64 / H = 128 ----
+def lstm_gen_supported(Cc, Hh):
+    return bool(L.load().sb_lstm_gen_supported(int(Cc), int(Hh)))
+
+
+def lstm_gen_fwd(x, ln_g, ln_b, dirs, geom, h0=None, c0=None, save=False, want_state=False):
+    """LayerNorm(C) + LSTM forward for any (C, H) sb_lstm_gen_supported names.  x [P, C] pre-LayerNorm; dirs: list of
+    (w_ih [4H, C], w_hh [4H, H], b_ih, b_hh) per direction.
+    -> hs [P, ndir*H], (hN, cN) or None, records [P, ndir, 5, H] or None, u [P, C] or None"""
+    lib = L.load()
+    ndir, Cc, Hh = len(dirs), x.shape[-1], dirs[0][1].shape[1]
+    assert x.numel() == geom.P * Cc
+    dev = x.device
+    hs = torch.empty(geom.P, ndir * Hh, device=dev, dtype=torch.float32)
+    rec = torch.empty(geom.P, ndir, 5, Hh, device=dev, dtype=torch.float32) if save else None
+    u = torch.empty(geom.P, Cc, device=dev, dtype=torch.float32) if save else None
+    hN = torch.empty(geom.nseq, Hh, device=dev, dtype=torch.float32) if want_state else None
+    cN = torch.empty(geom.nseq, Hh, device=dev, dtype=torch.float32) if want_state else None
+    a = L.LstmGenFwdArgs()
+    a.nseq, a.nsteps, a.n_inner, a.ndir, a.C, a.H = geom.nseq, geom.nsteps, geom.n_inner, ndir, Cc, Hh
+    a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
+    a.x, a.ln_g, a.ln_b = _p(x, "x"), _p(ln_g, "ln_g"), _p(ln_b, "ln_b")
+    for d, (wi, wh, bi, bh) in enumerate(dirs):
+        assert wi.shape == (4 * Hh, Cc) and wh.shape == (4 * Hh, Hh)
+        a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = _p(wi), _p(wh), _p(bi), _p(bh)
+    a.h0, a.c0, a.hN, a.cN = _p(h0), _p(c0), _p(hN), _p(cN)
+    a.hs, a.save_gates, a.save_u = _p(hs), _p(rec), _p(u)
+    by = 4.0 * Cc * geom.P + 4.0 * hs.numel() + (4.0 * (rec.numel() + u.numel()) if save else 0.0)
+    with _Prof(f"lstm_gen_fwd_kernel C={Cc} H={Hh} " + ("bidirectional" if ndir == 2 else "single direction"),
+               2.0 * 4 * Hh * (Cc + Hh) * geom.P * ndir, 8.0 * Cc * geom.P, by):
+        L.check(lib.sb_lstm_gen_fwd(C.byref(a), _stream()), "sb_lstm_gen_fwd")
+    return hs, ((hN, cN) if want_state else None), rec, u
+
+
+def lstm_gen_bwd(dirs, rec, dhs, u, hs, geom, targets):
+    """BPTT of lstm_gen_fwd: the recurrence (dgates of every step), then the position-wise GEMMs over the dgates.
+    dhs [P, ndir*H]: gradient w.r.t. hs; targets: per direction (dW_ih, dW_hh, db_ih, db_hh), accumulated into.
+    -> du_part [P, ndir, C]: per-direction gradient w.r.t. the LayerNorm output (ln_bwd sums the directions)."""
+    lib = L.load()
+    ndir, Cc, Hh = len(dirs), u.shape[-1], dirs[0][1].shape[1]
+    dev = u.device
+    P = geom.P
+    dg = torch.empty(P, ndir, 4 * Hh, device=dev, dtype=torch.float32)
+    a = L.LstmGenBwdArgs()
+    a.nseq, a.nsteps, a.n_inner, a.ndir, a.H = geom.nseq, geom.nsteps, geom.n_inner, ndir, Hh
+    a.p_outer, a.p_inner, a.p_step = geom.p_outer, geom.p_inner, geom.p_step
+    for d, (wi, wh, bi, bh) in enumerate(dirs):
+        a.w_hh[d] = _p(wh)
+    a.save_gates, a.dhs, a.dgates = _p(rec), _p(dhs), _p(dg)
+    with _Prof(f"lstm_gen_bwd_rec_kernel H={Hh} " + ("bidirectional" if ndir == 2 else "single direction"),
+               2.0 * 4 * Hh * Hh * P * ndir, 8.0 * Cc * P, 4.0 * (rec.numel() + dhs.numel() + dg.numel())):
+        L.check(lib.sb_lstm_gen_bwd_rec(C.byref(a), _stream()), "sb_lstm_gen_bwd_rec")
+    du = torch.empty(P, ndir, Cc, device=dev, dtype=torch.float32)
+    gP, sC = dense(P, Cc)
+    ldg, ldh = ndir * 4 * Hh, ndir * Hh
+    for d, (wi, wh, bi, bh) in enumerate(dirs):
+        # du[:, d] = dgates[:, d] . W_ih   (position-wise GEMM, K = 4H)
+        linear(dg, wi.t().contiguous(), None, du, gP, (0, 0, ldg), (0, 0, ndir * Cc), 4 * Hh, Cc, in_off=d * 4 * Hh, out_off=d * Cc)
+        # dW_ih += dgates^T u ; dW_hh += dgates^T h_prev ; db_ih, db_hh += column sums -- one pass over the dgates.  h_prev of a
+        # position is hs one step earlier in the direction's own walk, zero at the first step of every sequence
+        back = -geom.p_step if d == 0 else geom.p_step
+        t_wi, t_wh, t_bi, t_bh = targets[d]
+        wgrad(dg, ldg, 4 * Hh, u, sC, gP, Cc, t_wi, g_off=d * 4 * Hh, in2=hs, ld2=ldh, in2_off=d * Hh, shift2=back * ldh, K2=Hh,
+              dW2=t_wh, seg_len=geom.nsteps * geom.p_step, skip_first=geom.p_step if d == 0 else 0,
+              skip_last=geom.p_step if d == 1 else 0, dbias=t_bi, dbias2=t_bh)
+    return du

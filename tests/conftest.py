@@ -33,6 +33,49 @@ def golden_state_dict(rec, torch):
     return sd
 
 
+def grad_fingerprint(np_grad, key, nproj=16):
+    """as tests/golden/make_goldens.py: L2 norm and `nproj` seeded +-1 projections of a gradient tensor (float64)"""
+    import zlib
+    g = np.asarray(np_grad, np.float64).ravel()
+    rng = np.random.default_rng(zlib.crc32(key.encode()))
+    signs = rng.integers(0, 2, size=(nproj, g.size), dtype=np.int8) * 2 - 1
+    return np.concatenate([[np.sqrt((g * g).sum())], signs @ g])
+
+
+def build_default_ctor(factory, rec, torch):
+    """A default_ctor_* fixture stores no weights: the model is rebuilt from the fixture's seed (same initialisers in the same
+    order as the reference) and held to the stored per-tensor sums / norms.  factory: callable(**kwargs) -> module."""
+    torch.manual_seed(int(rec["meta::seed"]))
+    m = factory(L=4)
+    sd = m.state_dict()
+    for k, v in rec.items():
+        if k.startswith("wsum::"):
+            w = sd[k[len("wsum::"):]].double().numpy()
+            np.testing.assert_allclose([w.sum(), np.sqrt((w * w).sum())], v, rtol=1e-9, atol=1e-9, err_msg=k)
+    filt = torch.from_numpy(rec["filters"])
+    m.load_state_dict({"tfgridnet.enc.filterbank._filters": filt.clone(), "tfgridnet.dec.filterbank._filters": filt.clone()},
+                      strict=False)
+    return m
+
+
+def check_default_ctor_grads(named_grads, rec, tol):
+    """full gradients where the fixture stores them (everything outside the blocks, first and last block), fingerprints for
+    every tensor: the RMS over the projections of |delta| / |g| estimates the relative L2 error"""
+    worst = ("", 0.0)
+    for k, g in named_grads:
+        g = np.asarray(g)
+        fp_ref = rec["gfp::" + k]
+        fp = grad_fingerprint(g, k)
+        e = float(np.sqrt(((fp[1:] - fp_ref[1:]) ** 2).mean()) / (fp_ref[0] + 1e-30)) if fp_ref[0] > 0 else float(np.abs(g).max())
+        if "grad::" + k in rec:
+            ref = rec["grad::" + k]
+            e = max(e, rel_l2(g, ref) if np.abs(ref).max() > 0 else float(np.abs(g).max()))
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < tol, worst
+    return worst
+
+
 def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)

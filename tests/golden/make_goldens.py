@@ -239,6 +239,111 @@ def make_case(torch, Net, name, params, B, n_frames, seed, needs_dis, out_dir,
           f"({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def grad_fingerprint(np_grad, key, nproj=16):
+    """L2 norm and `nproj` seeded +-1 projections of a gradient tensor, in float64: what the 6-block default-constructor fixtures
+    keep for the tensors whose full gradient they do not store (a random +-1 projection of an error vector e has magnitude
+    ~|e|, so |delta projection| / |g| estimates the relative L2 error)."""
+    import zlib
+    g = np.asarray(np_grad, np.float64).ravel()
+    rng = np.random.default_rng(zlib.crc32(key.encode()))
+    signs = rng.integers(0, 2, size=(nproj, g.size), dtype=np.int8) * 2 - 1
+    return np.concatenate([[np.sqrt((g * g).sum())], signs @ g])
+
+
+def make_default_ctor(torch, Net, name, seed, needs_dis, out_dir, B=2, n_frames=6):
+    """The reference constructor's own defaults (net.py:21-26: stft 160 / 120 -> n_fft 280, F 141; num_ch 2, D 64, H 128,
+    six blocks, conv-LSTM intra path, merge_method "None", no first LayerNorm) -- every default but ONE: Net() itself raises
+    ZeroDivisionError in the reference (L = 0 heads -> `emb_dim // n_head`, tfgridnet_causal.py:596 / optim :484; see
+    make_ctor_behaviour), so L = 4, the value of every shipped JSON (unused without attention).  ~2.4 M parameters: the weights are NOT stored
+    -- the test rebuilds them from the seed (same initialisers in the same order; per-tensor sums / norms are stored as the
+    check) -- and full gradients are stored for everything outside the blocks and for the first and the last block; every
+    tensor (those included) also gets a fingerprint (grad_fingerprint)."""
+    torch.manual_seed(seed)
+    model = Net(L=4).eval()
+    chunk, pad, num_ch = 160, 120, 2
+    N = n_frames * chunk - 37
+    g = torch.Generator().manual_seed(seed + 1)
+    base = 0.1 * torch.randn(B, 1, N + 8, generator=g)
+    mix = torch.cat([base[..., 4 - min(m, 4):4 - min(m, 4) + N] for m in range(num_ch)], 1)
+    mix = (mix + 0.02 * torch.randn(B, num_ch, N, generator=g)).clamp(-1, 1)
+    inputs = {"mixture": mix}
+    if needs_dis:
+        dis = torch.zeros(B, 3)
+        for b in range(B):
+            dis[b, (b + 1) % 3] = 1.0
+        inputs["dis_embed"] = dis
+    with torch.no_grad():
+        res = model(dict(inputs))
+    rec = {"output": res["output"].numpy().copy(), "mixture": mix.numpy(), "meta::seed": np.int64(seed)}
+    if needs_dis:
+        rec["dis_embed"] = inputs["dis_embed"].numpy()
+    for k, v in _flatten_state(res["next_state"]).items():
+        rec["next_state::" + k] = v
+    for k, v in model.state_dict().items():
+        if k.endswith("filterbank._filters") or k.endswith("_sample_rate"):
+            continue
+        w = v.double().numpy()
+        rec["wsum::" + k] = np.array([w.sum(), np.sqrt((w * w).sum())])
+    rec["filters"] = model.tfgridnet.enc.filterbank._filters.numpy().copy()
+    model.train()
+    g2 = torch.Generator().manual_seed(seed + 2)
+    tgt = 0.05 * torch.randn(B, 1, N, generator=g2)
+    tgt[B - 1] = 0.0
+    model.zero_grad()
+    est = model(dict(inputs))["output"]
+    loss_vec = snrlp_loss(torch, est, tgt, neg_weight=100.0)
+    loss_vec.mean().backward()
+    rec["target"] = tgt.numpy()
+    rec["loss_vec"] = loss_vec.detach().numpy()
+    n_blocks = len(model.tfgridnet.blocks)
+    for k, p in model.named_parameters():
+        gnp = p.grad.numpy()
+        rec["gfp::" + k] = grad_fingerprint(gnp, k)
+        inner = k.startswith("tfgridnet.blocks.") and int(k.split(".")[2]) not in (0, n_blocks - 1)
+        if not inner:
+            rec["grad::" + k] = gnp.copy()
+    model.eval()
+    x = mix[..., : 3 * chunk + pad]
+    state = model.init_buffers(B, "cpu")
+    outs = []
+    with torch.no_grad():
+        for c in range(3):
+            fr = {"mixture": x[..., c * chunk: c * chunk + chunk + pad]}
+            if needs_dis:
+                fr["dis_embed"] = inputs["dis_embed"]
+            r = model(fr, state, pad=False)
+            state = r["next_state"]
+            outs.append(r["output"].numpy().copy())
+        for k, v in _flatten_state(state).items():
+            rec["stream::state::" + k] = v
+    rec["stream::output"] = np.concatenate(outs, -1)
+    rec["stream::input"] = x.numpy().copy()
+    rec["meta::params"] = np.array(repr([("L", 4)]))
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    nparam = sum(p.numel() for p in model.parameters())
+    print(f"{name}: params={nparam} out_rms={np.sqrt((rec['output']**2).mean()):.4e} -> {path} "
+          f"({os.path.getsize(path)/1e6:.2f} MB)")
+
+
+def make_ctor_behaviour(nets, out_dir):
+    """What the reference's constructors do when called with NO arguments, and with L alone given: the exception type and
+    text, or the parameter count.  (Both raise ZeroDivisionError at their own defaults: L = 0.)"""
+    import json
+    out = {}
+    for tag, Net in nets.items():
+        for label, kw in (("no_arguments", {}), ("L=4", {"L": 4})):
+            try:
+                m = Net(**kw)
+                out[f"{tag}::{label}"] = {"constructs": True, "parameters": sum(p.numel() for p in m.parameters()),
+                                          "n_freqs": int(m.tfgridnet.n_freqs) if hasattr(m.tfgridnet, "n_freqs") else None}
+            except Exception as e:       # noqa: BLE001 -- the point is to record whatever the reference does
+                out[f"{tag}::{label}"] = {"constructs": False, "exception": type(e).__name__, "message": str(e)}
+    with open(os.path.join(out_dir, "ctor_behaviour.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("ctor_behaviour.json:", out)
+
+
 def make_samples(torch, NetBig, out_dir, n_keep=36000):
     """test_samples/syn_1m scenes (reference fixtures, MIT licence), trimmed to 1.5 s, pushed through the REFERENCE
     model (weights of tiny_big.npz) with the reference's own NumPy metrics (helpers/eval_utils.py)."""
@@ -539,6 +644,13 @@ def main():
               out_dir=args.out, with_stream=False)
     case(torch, NetSmall, "tiny_small_h128d64", dict(small, B=2, D=64, H=128), B=2, n_frames=6, seed=23, needs_dis=False,
               out_dir=args.out, with_stream=False)
+    # the reference constructors called with NO arguments (net.py:21-26): n_fft 280, 2 microphones, D = 64, H = 128, six conv-LSTM blocks
+    if not only or "default_ctor_big" in only:
+        make_default_ctor(torch, NetBig, "default_ctor_big", seed=24, needs_dis=True, out_dir=args.out)
+    if not only or "default_ctor_small" in only:
+        make_default_ctor(torch, NetSmall, "default_ctor_small", seed=25, needs_dis=False, out_dir=args.out)
+    if not only or "ctor_behaviour" in only:
+        make_ctor_behaviour({"dis_embd3": NetBig, "optim": NetSmall}, args.out)
     # real small config, 1 s clip (125 frames), forward only
     case(torch, NetSmall, "small_1s", small, B=1, n_frames=125, seed=21, needs_dis=False, out_dir=args.out,
               with_grads=False, with_stream=False, with_stages=False)

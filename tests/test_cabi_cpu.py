@@ -32,7 +32,8 @@ def test_struct_layouts_match_header(tmp_path):
     pairs = {"sb_lstm_fwd_args": _lib.LstmFwdArgs, "sb_lstm_bwd_args": _lib.LstmBwdArgs, "sb_linear_args": _lib.LinearArgs,
              "sb_wgrad_args": _lib.WgradArgs, "sb_lstm_stream_args": _lib.LstmStreamArgs, "sb_ln_bwd_args": _lib.LnBwdArgs,
              "sb_attn_args": _lib.AttnArgs, "sb_attn_bwd_args": _lib.AttnBwdArgs, "sb_multi_copy_args": _lib.MultiCopyArgs,
-             "sb_film_bank_args": _lib.FilmBankArgs}
+             "sb_film_bank_args": _lib.FilmBankArgs, "sb_lstm_gen_fwd_args": _lib.LstmGenFwdArgs,
+             "sb_lstm_gen_bwd_args": _lib.LstmGenBwdArgs}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "sound_bubble_hip.h"', "int main(void) {"]
     want = []
     for cname, cls in pairs.items():
@@ -103,3 +104,26 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_constructor_defaults_behave_as_the_reference(torch_mod):
+    """tests/golden/ctor_behaviour.json (recorded from the imported reference): Net() with NO arguments raises ZeroDivisionError
+    in both families (L = 0 heads: `emb_dim // n_head`, tfgridnet_causal.py:596 / optim :484) -- so does the drop-in; with L
+    given, every other default constructs (n_fft 280, F 141, D 64, H 128, six conv-LSTM blocks) with the reference's own
+    parameter count, and the generic-shape kernels are what serves those widths."""
+    import json
+    import sound_bubble_amd as sb
+    beh = json.load(open(os.path.join(ROOT, "tests", "golden", "ctor_behaviour.json")))
+    for tag, cls in (("dis_embd3", sb.NetDisEmbd3), ("optim", sb.NetOptim)):
+        want = beh[f"{tag}::no_arguments"]
+        assert not want["constructs"] and want["exception"] == "ZeroDivisionError"
+        with pytest.raises(ZeroDivisionError, match=want["message"]):
+            cls()
+        m = cls(L=4)
+        assert sum(p.numel() for p in m.parameters()) == beh[f"{tag}::L=4"]["parameters"]
+        assert m.n_freqs == beh[f"{tag}::L=4"]["n_freqs"] == 141 and m.H == 128 and m.embed_dim == 64 and m._generic
+        st = m.init_buffers(2, "cpu")
+        assert st["conv_buf"].shape == (2, 4, 2, 141) and st["gridnet_bufs"]["buf5"]["h0"].shape == (1, 2 * 141, 128)
+    from sound_bubble_amd import _lib
+    lib = _lib.load()
+    assert lib.sb_lstm_gen_supported(64, 128) == 1 and lib.sb_lstm_gen_supported(64, 96) == 0

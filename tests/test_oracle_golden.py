@@ -158,3 +158,43 @@ def test_oracle_with_the_trained_checkpoint_matches_the_imported_reference(torch
     assert rel_l2(out, want) < 2e-5
     s = si_sdr_np(out[0], gt[0])
     assert abs(s - float(ref["syn_2m/00001::si_sdr"])) < 1e-3 and s > 20.0
+
+
+# ---- the reference constructors' own defaults (net.py:21-26): n_fft 280, 2 microphones, D = 64, H = 128, six conv-LSTM blocks ----
+DEFAULT_CTOR = [("default_ctor_big", "dis_embd3"), ("default_ctor_small", "optim")]
+
+
+@pytest.mark.parametrize("name,flavour", DEFAULT_CTOR)
+def test_default_constructor_widths_match_reference(name, flavour, torch_mod):
+    """forward, carried state, 3-chunk streaming trace, loss vector and every parameter gradient (full tensors outside the
+    blocks and for the first / last block, fingerprints for all) of Net(L=4) -- every constructor default but L, at which the
+    reference itself divides by zero (tests/golden/ctor_behaviour.json)."""
+    torch = torch_mod
+    from conftest import build_default_ctor, check_default_ctor_grads
+    from oracle.tfgridnet_oracle import OracleNet, snrlp_loss
+    rec, params, _ = load_golden(name)
+    assert params == {"L": 4}
+    m = build_default_ctor(lambda **kw: OracleNet(flavour, **kw), rec, torch).eval()
+    with torch.no_grad():
+        res = m(inputs_of(rec, torch))
+    assert rel_l2(res["output"].numpy(), rec["output"]) < 2e-6
+    for k, v in flatten_state(res["next_state"]).items():
+        assert rel_l2(v, rec["next_state::" + k]) < 2e-6, k
+    x = torch.from_numpy(rec["stream::input"])
+    st = m.init_buffers(x.shape[0], "cpu")
+    outs = []
+    with torch.no_grad():
+        for c in range(3):
+            fr = dict(inputs_of(rec, torch), mixture=x[..., c * 160: c * 160 + 280])
+            r = m(fr, st, pad=False)
+            st = r["next_state"]
+            outs.append(r["output"])
+    assert rel_l2(torch.cat(outs, -1).numpy(), rec["stream::output"]) < 2e-6
+    for k, v in flatten_state(st).items():
+        assert rel_l2(v, rec["stream::state::" + k]) < 2e-6, k
+    m.train()
+    est = m(inputs_of(rec, torch))["output"]
+    lv = snrlp_loss(est, torch.from_numpy(rec["target"]), 100.0)
+    np.testing.assert_allclose(lv.detach().numpy(), rec["loss_vec"], rtol=2e-5, atol=1e-5)
+    lv.mean().backward()
+    check_default_ctor_grads(((k, p.grad.numpy()) for k, p in m.named_parameters()), rec, 5e-4)
