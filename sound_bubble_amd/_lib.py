@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SB_LIB_PATH: a developer override (A/B runs against an experiment build under lib/exp/); the product default is the in-tree library
 LIB_PATH = os.environ.get("SB_LIB_PATH") or os.path.join(_HERE, "lib", "libsoundbubble_hip.so")
+if os.environ.get("SB_LIB_VARIANT"):      # developer A/B builds (scripts/build_variant.py): lib/exp/lib_<name>.so
+    LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "exp", f"lib_{os.environ['SB_LIB_VARIANT']}.so")
 
 c_fp = C.c_void_p          # device float*
 i64 = C.c_int64

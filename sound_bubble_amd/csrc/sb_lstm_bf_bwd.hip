@@ -1545,21 +1545,39 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
             }
           }
         }
-        // records ONE step ahead (two in the one-role kernel: 56 registers this role does not have)
+        // records ONE step ahead (-DSB_SPLIT_LOOK=2: TWO, as in the one-role kernel -- round 6 A/B, see DESIGN.md 9: with the
+        // 3-piece Q24 records a Raw is 24 registers and the recurrence role's loop holds no spill)
+#ifndef SB_SPLIT_LOOK
+#define SB_SPLIT_LOOK 1
+#endif
         Raw nxt = load_raw(s_hi);
+#if SB_SPLIT_LOOK == 2
+        Raw nxt2 = load_raw(max(s_hi - 1, 0));
+#endif
         int s = s_hi;
         for (int k = 0; k < npairs; ++k, s -= 2) {
           Raw curA = nxt;
           consume(curA);
           __builtin_amdgcn_sched_barrier(0);
+#if SB_SPLIT_LOOK == 2
+          nxt = load_raw(max(s - 2, 0));
+#else
           nxt = load_raw(max(s - 1, 0));
+#endif
           __builtin_amdgcn_sched_barrier(0);
           step(s, curA, 2 * (k & 1));
           if (s - 1 >= s_lo) {
+#if SB_SPLIT_LOOK == 2
+            Raw curB = nxt2;
+            consume(curB);
+            __builtin_amdgcn_sched_barrier(0);
+            nxt2 = load_raw(max(s - 3, 0));
+#else
             Raw curB = nxt;
             consume(curB);
             __builtin_amdgcn_sched_barrier(0);
             nxt = load_raw(max(s - 2, 0));
+#endif
             __builtin_amdgcn_sched_barrier(0);
             step(s - 1, curB, 2 * (k & 1) + 1);
           } else {                                                 // odd step count: an empty second half
