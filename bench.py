@@ -507,6 +507,22 @@ def _newest(pattern):
     return files[-1] if files else None
 
 
+_DIGEST = []
+
+
+def profile_provenance(pf):
+    """-> {file, tree, csrc_sha16, stale_profile}: the counter summary's stamp (scripts/pmc_summary.py) against the digest of the
+    kernel sources this process runs (sound_bubble_amd.build.csrc_digest); an unstamped (pre-round-6) summary is stale by definition"""
+    if not pf:
+        return None
+    if not _DIGEST:
+        from sound_bubble_amd.build import csrc_digest
+        _DIGEST.append(csrc_digest())
+    prov = json.load(open(pf)).get("provenance") or {}
+    return {"file": os.path.relpath(pf, ROOT), "tree": prov.get("tree"), "csrc_sha16": prov.get("csrc_sha16"),
+            "running_csrc_sha16": _DIGEST[0], "stale_profile": prov.get("csrc_sha16") != _DIGEST[0]}
+
+
 def pmc_traffic(workload, label, mode="wide"):
     """HBM bytes per launch of the kernel behind `label` from the newest committed rocprofv3 --pmc summary
     (profiles/r*_pmc_traffic_<workload>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied).
@@ -730,6 +746,17 @@ def roofline_of(table, wl, step_s, steps, forward_only, utt_s_per_gpu, params, m
             "share_of_step": w / (step_s * pair["steps"])}
     roof["kernels"] = per
     roof.update(extra)
+    if not forward_only:
+        # where `traffic` / `mfma_busy` come from: committed rocprofv3 --pmc summaries, NOT this run -- with the digest of the
+        # kernel sources they were taken on against this tree's
+        sfx = "" if mode == "compact" else "_" + mode
+        tp, sp = profile_provenance(_newest(f"r*_pmc_traffic_{wl}{sfx}.json")), profile_provenance(_newest(f"r*_pmc_sq_{wl}{sfx}.json"))
+        roof["counter_profiles"] = {"traffic": tp, "sq": sp}
+        roof["stale_profile"] = bool((tp and tp["stale_profile"]) or (sp and sp["stale_profile"]))
+        roof["north_star_note"] = ("north_star's 0.30 of the HBM roof on the forward = ~7.9 k utt/s (big) = ~700 TFLOP/s sustained "
+                                   "(SURVEY 8d): at this path's parity-grade arithmetic -- 3 fp16 products per MAC -- that is ~84 % "
+                                   "utilisation of the 2.5 PFLOP/s matrix pipe by a 625-step serial recurrence; not reachable at "
+                                   "fp32-class parity (secondary.forward_*: 0.08-0.09 measured)")
     return roof
 
 

@@ -802,6 +802,13 @@ int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
  * when clip > 0 (clip_grad_norm_ semantics), else by gscale. */
 int sb_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, int step, float gscale, float clip, const float* sumsq, void* stream);
+/* ... guarded (round 6): `guard` (nullable) is the watchdog word of the guarded schedules (sched_status of the step's launches).
+ * When *guard != 0 -- a bounded wait of this step gave up, the gradients are garbage -- the update is a NO-OP: parameters and
+ * moments keep their last good values without a host synchronisation, and *skipped (nullable, int) counts the skipped steps
+ * for the report the caller raises at its next look at the word (tain_val.py:51-88 never takes a non-finite step silently). */
+int sb_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, int step, float gscale, float clip, const float* sumsq, const int* guard, int* skipped,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,11 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sound_bubble_amd.build import csrc_digest            # noqa: E402
+PROVENANCE = {"csrc_sha16": csrc_digest(), "what": "sha256[:16] over sound_bubble_amd/csrc/*.{hip,h} + include/sound_bubble_hip.h of the "
+              "tree the counters were taken on (sound_bubble_amd.build.csrc_digest); bench.py flags a summary whose digest differs "
+              "from the running tree's as stale_profile", "tree": os.environ.get("SB_TREE_ID")}
 wl = sys.argv[1] if len(sys.argv) > 1 else "small"
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
 dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{wl}.json")
@@ -66,6 +71,7 @@ def main():
             out["kernels"][k] = {"launches": fe[1], "avg_us_in_pmc_pass": avg_us, "fetch_bytes_corrected": fb,
                                  "write_bytes": wb, "hbm_bytes": fb + wb, "hbm_tbs": (fb + wb) / (avg_us * 1e-6) / 1e12,
                                  "share_of_traced_time": fd[k][0] / total}
+        out["provenance"] = PROVENANCE
         json.dump(out, open(dst, "w"), indent=1)
         print(dst, len(out["kernels"]), "kernels")
     spath = os.path.join(src, f"pmc_sq_{wl}", "s_counter_collection.csv")
@@ -105,6 +111,7 @@ def main():
                     if g(c) is not None:
                         ent[n] = g(c) / wc
             out["kernels"][k] = ent
+        out["provenance"] = PROVENANCE
         json.dump(out, open(dst_sq, "w"), indent=1)
         print(dst_sq, len(out["kernels"]), "kernels")
 

@@ -239,6 +239,7 @@ SYMBOLS = {
     "sb_sumsq": (_ci, [c_fp, i64, c_fp, _vp]),
     "sb_absmax": (_ci, [c_fp, i64, c_fp, _vp]),
     "sb_adam_step": (_ci, [c_fp, c_fp, c_fp, c_fp, i64, _cf, _cf, _cf, _cf, _ci, _cf, _cf, c_fp, _vp]),
+    "sb_adam_step_guarded": (_ci, [c_fp, c_fp, c_fp, c_fp, i64, _cf, _cf, _cf, _cf, _ci, _cf, _cf, c_fp, _vp, _vp, _vp]),
     "sb_fir": (_ci, [c_fp, c_fp, c_fp, _ci, i64, _ci, _vp]),
     "sb_reflect_pad": (_ci, [c_fp, c_fp, _ci, i64, _ci, i64, _vp]),
     "sb_stft_mag_l1_grid": (_ci, [i64, _ci]),

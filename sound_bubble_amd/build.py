@@ -13,6 +13,18 @@ HEADERS = [os.path.join(CSRC, "sb_common.h"), os.path.join(CSRC, "sb_lstm_bf_com
            os.path.join(HERE, "..", "include", "sound_bubble_hip.h")]
 
 
+def csrc_digest():
+    """sha256 (first 16 hex digits) over the kernel sources and the C-ABI header, names and bytes in sorted order: what a
+    committed counter profile is stamped with (scripts/pmc_summary.py) and what bench.py compares it against (`stale_profile`)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.normpath(HEADERS[-1])]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

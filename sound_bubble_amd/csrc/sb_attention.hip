@@ -84,11 +84,25 @@ __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ 
     for (int e = FD + threadIdx.x; e < ldo; e += 256) out[((size_t)(b * Hh + h) * rows + t_off + t) * ldo + e] = 0.f;
 }
 
-// attention core: grid (ceil(T/16), B*Hh)
+// Workgroup -> (batch*head, 16-frame tile), XCD-aware (round 6).  Neighbouring tiles of one (batch, head) share 99 of their 115
+// K / V window rows, but workgroups are dealt to the 8 XCDs round-robin by their linear id and every XCD has its own L2: with
+// tiles along blockIdx.x the 40 tiles of a head landed on all 8 XCDs and each fetched its whole window from HBM -- 2.8 / 5.0 /
+// 3.2 GB per launch against 0.5 GB of K, V, Q, O (profiles/r05_pmc_traffic_big_attn_wide.json: 5.6-7x, at 0.75-0.84 of the HBM
+// peak).  Here the linear id g goes to XCD g % 8, so head bh = g % 8 + 8 (g / 8 / ntiles) keeps ALL tiles of a head on ONE XCD,
+// in time order: a tile finds its predecessor's window rows in that L2.  (The heads beyond a multiple of 8 take the plain order.)
+SB_DEVINL void attn_tile(int ntiles, int BH, int& bh, int& tile) {
+  const int g = blockIdx.x, full = BH & ~7, nfull = full * ntiles;
+  if (g < nfull) { const int i = g >> 3; bh = (g & 7) + 8 * (i / ntiles); tile = i % ntiles; }
+  else { const int i = g - nfull; bh = full + i / ntiles; tile = i % ntiles; }
+}
+
+// attention core: 1-D grid of ceil(T/16) * B*Hh workgroups (attn_tile)
 __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
   extern __shared__ __attribute__((aligned(16))) float PT[];     // [16 queries][NRp + 4]  scores -> probabilities
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
-  const int bh = blockIdx.y, t0 = blockIdx.x * 16;
+  int bh, tile0;
+  attn_tile((a.T + 15) / 16, a.BH, bh, tile0);
+  const int t0 = tile0 * 16;
   const int L = a.L, NRp = a.NRp, ldp = NRp + 4;
   const int rows = L - 1 + a.T;
   const float* __restrict__ Kb = a.K + (size_t)bh * rows * a.ldk;
@@ -286,7 +300,9 @@ __device__ __forceinline__ f32x4 lds_times_rows(const float* Pl, int ldp, int nk
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(sb_attn_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) float SM[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
-  const int bh = blockIdx.y, t0 = blockIdx.x * 16;
+  int bh, tile0;
+  attn_tile((a.T + 15) / 16, a.BH, bh, tile0);
+  const int t0 = tile0 * 16;
   const int L = a.L, NRp = a.NRp, ldp = NRp + 4, rows = L - 1 + a.T;
   float* PT = SM;                       // [16 queries][ldp] probabilities
   float* DP = SM + 16 * ldp;            // [16 queries][ldp] dP -> dS
@@ -334,7 +350,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(sb_attn_bwd_args a) {
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(sb_attn_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) float SM[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
-  const int bh = blockIdx.y, tb = blockIdx.x * 16;
+  int bh, tile0;
+  attn_tile((a.T + 15) / 16, a.BH, bh, tile0);
+  const int tb = tile0 * 16;
   const int L = a.L, NRp = a.NRp, ldp = NRp + 4, rows = L - 1 + a.T;
   float* PT = SM;                       // [16 key rows][ldp queries]
   float* DS = SM + 16 * ldp;
@@ -410,7 +428,7 @@ extern "C" int sb_attn_core_bwd(const sb_attn_bwd_args* ap, void* stream) {
   if (!ap || ap->ldk % 16 || ap->ldv % 16 || ap->NRp % 16 || ap->NRp < ap->L + 15) return -1002;
   const size_t lds = (size_t)2 * 16 * (ap->NRp + 4) * sizeof(float);
   if (lds > 64 * 1024) return -1005;
-  dim3 grid((ap->T + 15) / 16, ap->BH);
+  dim3 grid(((ap->T + 15) / 16) * ap->BH);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ap);
   SB_CHECK_LAUNCH();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ap);
@@ -421,7 +439,7 @@ extern "C" int sb_attn_core_bwd(const sb_attn_bwd_args* ap, void* stream) {
 extern "C" int sb_attn_core(const sb_attn_args* ap, void* stream) {
   if (!ap || ap->ldk % 16 || ap->ldv % 16 || ap->NRp % 16 || ap->NRp < ap->L + 15) return -1002;
   const size_t lds = (size_t)16 * (ap->NRp + 4) * sizeof(float);
-  dim3 grid((ap->T + 15) / 16, ap->BH);
+  dim3 grid(((ap->T + 15) / 16) * ap->BH);
   hipLaunchKernelGGL(attn_core_kernel, grid, dim3(256), lds, (hipStream_t)stream, *ap);
   SB_CHECK_LAUNCH();
   return 0;

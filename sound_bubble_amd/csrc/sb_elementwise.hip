@@ -496,8 +496,16 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2, float gscale,
-                                                   float clip, const float* __restrict__ sumsq) {
+                                                   float clip, const float* __restrict__ sumsq, const int* __restrict__ guard,
+                                                   int* __restrict__ skipped) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // guard: the watchdog word of the guarded schedules (sched_status).  Non-zero = a bounded wait of this step's launches gave
+  // up, the gradients in g are garbage: the update is a no-op (parameters and moments keep their last good values; the host
+  // finds out at its next look at the word, and `skipped` counts what that look will report)
+  if (guard && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    if (i == 0 && skipped) atomicAdd(skipped, 1);
+    return;
+  }
   if (i >= n) return;
   float sc = gscale;
   if (clip > 0.f) {
@@ -880,13 +888,20 @@ extern "C" int sb_absmax(const float* x, int64_t n, float* out, void* stream) {
   return 0;
 }
 
+extern "C" int sb_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                    float beta2, float eps, int step, float gscale, float clip, const float* sumsq,
+                                    const int* guard, int* skipped, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return -1001;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2,
+                     gscale, clip, sumsq, guard, skipped);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int sb_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, int step, float gscale, float clip, const float* sumsq,
                             void* stream) {
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, gscale, clip, sumsq);
-  SB_CHECK_LAUNCH();
-  return 0;
+  return sb_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, clip, sumsq, nullptr, nullptr, stream);
 }
 
 extern "C" int sb_multi_copy(const sb_multi_copy_args* ap, void* stream) {

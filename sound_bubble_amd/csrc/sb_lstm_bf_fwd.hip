@@ -67,6 +67,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
           const int* fl = a.slab_flags + a.tile_need[it];
           unsigned spins = 0;
           bool ok = true;
+          int hold_dec = -1;
           while (sb_poll(fl) < a.slab_need) {
             if (++spins > kHelpSpinLimit) { ok = false; break; }
             sb_poll_pause();
@@ -77,9 +78,15 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
             if (k < kOrdRet) old = __hip_atomic_exchange(ctl + 8 + dir * kOrdRet + k, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else sb_trip(a.sched_status, SB_TRIP_FWD_CONSUMER, it, k, kOrdRet & 0x7F, kSpinLimit + 1, 0);   // (cannot happen: <= one per side workgroup)
             if (a.ord_giveups) __hip_atomic_fetch_add(a.ord_giveups, 1 + (old > 0 ? 1 << 20 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            it = nt;                                   // (the exchange has RETURNED before the release below is issued: `old` is used)
+            it = nt;
+            // ORDER (round 6): the drain side may leave once it reads hold == 0 and an unchanged `pushed`, so the push
+            // must have been PERFORMED before the release of the hold below is issued.  Every step is a returning atomic on an
+            // uncached word whose result the next step needs -- pushed++ returns k, the slot address; the exchange returns `old`
+            // -- and the empty asm makes the decrement's operand depend on `old` for the compiler as well (with ord_giveups ==
+            // NULL nothing else used it): no fence, no L2 write-back, just the data dependence spelled out.
+            asm volatile("" : "+v"(hold_dec), "+v"(old));
           }
-          __hip_atomic_fetch_add(ctl, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(ctl, hold_dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (!a.ord_guard && it >= nt) {         // counter exhausted: what did the launch next to the producer hand back?
           unsigned spins = 0;
           for (;;) {
@@ -95,8 +102,11 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
               sb_trip(a.sched_status, SB_TRIP_FWD_CONSUMER, t, 0, 1, spins, 0);      // a push that never landed: fatal
               break;
             }
-            if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-                __hip_atomic_load(ctl + 1 + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n) break;   // nobody holds, nothing new
+            // (the re-read of `pushed` is ISSUED only after `hold` has come back as 0: the asm pins the first load's result in
+            //  front of the second load for the compiler; the hardware returns a wave's loads in issue order)
+            int held = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" : "+v"(held) : : "memory");
+            if (held == 0 && __hip_atomic_load(ctl + 1 + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n) break;   // nobody holds, nothing new
             if (++spins > kSpinLimit) { sb_trip(a.sched_status, SB_TRIP_FWD_CONSUMER, n, t, 0, spins, 0); break; }
             sb_poll_pause();
           }

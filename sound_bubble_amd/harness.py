@@ -176,12 +176,26 @@ class PLModule(object):
             ev = ep.setdefault(k, dict(step=None, epoch=None))
             ev["epoch"], ev["num_elements"] = s_, n_
 
+    def _check_sched(self):
+        """the guarded schedules' watchdog word (all ranks together).  A trip is FATAL for the run but harmless for the weights:
+        from the tripped step on the optimiser's kernel sees the word and skips its update (train.FusedAdam.skipped), so what
+        is raised here reports garbage gradients that were never applied -- last.pt / best.pt hold the last good state."""
+        from . import ops, _lib as L
+        try:
+            ops.check_sched_status_all_ranks()
+        except L.SoundBubbleHipError as e:
+            n = int(self.optimizer.skipped.item())
+            self.optimizer.skipped.zero_()
+            raise L.SoundBubbleHipError(
+                f"{e}  The optimiser turned {n} step(s) since the trip into no-ops on this rank: parameters and Adam moments hold "
+                "their last good values.") from None
+
     def on_epoch_end(self, best_path, wandb_run=None):
         self.sync_epoch_metrics()
         from . import ops
         # one sync per epoch: did a time-segmented / overlapped launch bail out?  (verdict shared by all ranks: a lone
         # raising rank would leave the others hanging in the next all-reduce); and is the side stream still concurrent?
-        ops.check_sched_status_all_ranks()
+        self._check_sched()
         if ops._OVERLAP_OK:
             g = ops.read_giveups()
             if g != getattr(self, "_giveups_seen", 0):
@@ -191,6 +205,12 @@ class PLModule(object):
                               "that happened in took a few ms longer)")
                 self._giveups_seen = g
             ops.overlap_reprobe()
+            # which order the passes of this epoch really took (a lost side stream switches to the plain order: same results,
+            # other throughput -- the number a slow epoch is explained by)
+            seen = getattr(self, "_sched_seen", {})
+            print(f"schedules this epoch: { {k: v - seen.get(k, 0) for k, v in ops.SCHED_COUNTS.items()} }"
+                  + (" [side stream LOST: plain order]" if ops._OVERLAP_LOST else ""))
+            self._sched_seen = dict(ops.SCHED_COUNTS)
         last = self.get_avg_metric_at_epoch(self.monitor)
         best = all(not (last > self.get_avg_metric_at_epoch(self.monitor, e)) for e in range(len(self.metric_values) - 1))
         if best:
@@ -280,8 +300,7 @@ class PLModule(object):
         # a launch that gave up must not train on garbage that long).  Same step on every rank: the verdict is all-reduced.
         self._opt_steps = getattr(self, "_opt_steps", 0) + 1
         if self._opt_steps % 50 == 0:
-            from . import ops
-            ops.check_sched_status_all_ranks()
+            self._check_sched()
 
     def init_scheduler(self, scheduler, scheduler_params):
         """hl_module:460-481 ('sequential' -> SequentialLR with cumulative milestones)."""

@@ -258,6 +258,8 @@ class _NetBase(nn.Module):
         tg = self.tfgridnet
         st = input_state
         Fn.GRAD_MODE = torch.is_grad_enabled()      # BPTT records are written only when a backward pass can follow
+        if Fn.GRAD_MODE:
+            Fn.ops.handover_reset()                 # (hand-over marks of a backward pass that died half-way must not outlive it)
         Fn.WORKSPACE = None if (Fn.GRAD_MODE or not Fn.INFER_WORKSPACE) else self.__dict__.setdefault("_ws", Fn.Workspaces())      # inference: persistent zero-bordered staging
         e = self._embed(inputs.get("dis_embed"))
         wf = self._weight_forms().refresh()

@@ -302,6 +302,11 @@ class _FlagArena:
         self.next_chunk = (k + 1) % self.NCHUNK
         if k == 0 and self.gen[0] > 0 and not torch.cuda.is_current_stream_capturing():
             torch.cuda.synchronize(self.dev)                 # (once per NCHUNK chunks: every word of the ring is dead)
+            # ... and every (device, stream) pool lets go of the chunk it was cutting slices from: another stream's pool could
+            # otherwise keep a chunk k != 0 across this wrap and go on handing out words that this ring is about to re-zero
+            # under kernels still polling them (two streams running guarded schedules on one device)
+            for key in [key for key in _FLAGS.cur if key[0] == self.dev]:
+                del _FLAGS.cur[key]
         self.gen[k] += 1
         addr = self.base + 4 * (self.RESERVED + k * self.CHUNK)
         with torch.cuda.device(self.dev):
@@ -1156,6 +1161,20 @@ def arm_handover_check():
     _HANDOVER["armed"] = True
 
 
+def handover_reset():
+    """Start of a training forward (no backward pass is in flight then): drop whatever a FAILED backward left behind.  PyTorch
+    does not run the engine's final callbacks when a backward raises (out of memory, a user hook, an error from a node): without
+    this the `armed` flag would stay set for the rest of the process -- the leftover check never queued again -- and stale
+    data_ptr keys in CROSS_PENDING / FILM_DONE could match a recycled allocator address in a later pass."""
+    _HANDOVER["armed"] = False
+    if CROSS_PENDING:
+        for pend in CROSS_PENDING.values():
+            pend.keep.clear()
+        CROSS_PENDING.clear()
+    if FILM_DONE:
+        FILM_DONE.clear()
+
+
 def _handover_check():
     _HANDOVER["armed"] = False
     left_c, left_f = len(CROSS_PENDING), len(FILM_DONE)
@@ -1910,9 +1929,16 @@ def sumsq(g, out):
     L.check(L.load().sb_sumsq(_p(g), g.numel(), _p(out), _stream()), "sb_sumsq")
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gscale=1.0, clip=0.0, sumsq_buf=None):
-    L.check(L.load().sb_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step),
-                                  float(gscale), float(clip), _p(sumsq_buf), _stream()), "sb_adam_step")
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gscale=1.0, clip=0.0, sumsq_buf=None, skipped=None):
+    """skipped (int32 [1], optional): the update is GUARDED by the device's watchdog word when a guarded schedule has ever run
+    on it -- a step whose launches gave up a bounded wait leaves parameters and moments untouched and counts itself here"""
+    dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
+    guard = _SCHED_STATUS.get(dev)
+    L.check(L.load().sb_adam_step_guarded(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step),
+                                          float(gscale), float(clip), _p(sumsq_buf),
+                                          C.c_void_p(guard.data_ptr()) if guard is not None else None,
+                                          C.c_void_p(skipped.data_ptr()) if (skipped is not None and guard is not None) else None,
+                                          _stream()), "sb_adam_step_guarded")
 
 
 # ---- fine-tune loss (include/sound_bubble_hip.h: multi-resolution STFT magnitude L1 + waveform L1) ----

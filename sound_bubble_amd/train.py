@@ -51,6 +51,9 @@ class FusedAdam:
         self.v = torch.zeros_like(bucket.flat)
         self.step_count = 0
         self.sumsq = torch.zeros(1, device=bucket.flat.device, dtype=torch.float32)
+        # optimiser steps the kernel turned into no-ops because the watchdog word of the guarded schedules was set (a bounded
+        # wait of that step's launches gave up: garbage gradients).  Read with the word itself (ops.check_sched_status*).
+        self.skipped = torch.zeros(1, device=bucket.flat.device, dtype=torch.int32)
         self.param_groups = [{"lr": lr}]        # scheduler-facing view (get_current_lr, hl_module:158-160)
 
     def step(self, grad_clip=None, world_size=1):
@@ -63,7 +66,7 @@ class FusedAdam:
             self.sumsq.zero_()
             ops.sumsq(b.grad, self.sumsq)
         ops.adam_step(b.flat, b.grad, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.step_count,
-                      gscale=1.0 / world_size, clip=clip, sumsq_buf=self.sumsq)
+                      gscale=1.0 / world_size, clip=clip, sumsq_buf=self.sumsq, skipped=self.skipped)
         bump_weight_epoch()       # the kernel wrote the parameters behind torch's version counters: weight forms are stale
 
     def state_dict(self):

@@ -412,3 +412,90 @@ def test_bench_one_gpu_line_through_rccl():
     assert d["rccl"]["devices"][0]["device"] == "cuda:0" and d["rccl"].get("rccl_version")
     s = d["schedules"]["per_rank"][0]
     assert s["fwd_overlapped"] + s["fwd_plain"] == 6 * 2 and s["bwd_overlapped"] + s["bwd_plain"] == 6 * 2
+
+
+# ---- turns itself on when the box has more than one GPU: one rank per GPU over RCCL --------------------------
+def _multi_gpu_worker(rank, world, port, q):
+    """one rank of BASELINE configs[3] in miniature: its own GPU, RCCL, its own utterances (seed + rank), radii cycling over the
+    global batch; one train step of the two-block big model"""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import sound_bubble_amd as sb
+    from sound_bubble_amd.functional import SnrlpLossFn
+    from sound_bubble_amd.train import FlatBucket, FusedAdam, allreduce_grads, broadcast_replica
+    rec, params, _ = load_golden("tiny_big")
+    Bl, N = 2, 192 * 40 - 37
+
+    def shard(r):
+        g = torch.Generator().manual_seed(1234 + r)
+        mix = (0.1 * torch.randn(Bl, 6, N, generator=g)).clamp(-1, 1)
+        tgt = 0.05 * torch.randn(Bl, 1, N, generator=g)
+        if r % 2 == 1:
+            tgt[0] = 0.0                                   # silent-target utterances on the odd ranks (the shared negative term)
+        dis = torch.eye(3)[(torch.arange(Bl) + r * Bl) % 3]   # radii cycle over the GLOBAL batch
+        return mix, tgt, dis
+
+    torch.manual_seed(100 + rank)                          # different initial weights per rank: broadcast_replica must sync them
+    m = sb.NetDisEmbd3(**params).to(dev).train()
+    bucket = FlatBucket(m)
+    optim = FusedAdam(bucket, lr=1e-3)
+    broadcast_replica(bucket, optim)
+    mix, tgt, dis = (t.to(dev) for t in shard(rank))
+    bucket.zero_grad()
+    loss, _ = SnrlpLossFn.apply(m({"mixture": mix, "dis_embed": dis})["output"], tgt, 100.0)
+    loss.backward()
+    w = allreduce_grads(bucket)
+    g_dp = (bucket.grad / w).clone()
+    optim.step(grad_clip=1.0, world_size=w)
+    torch.cuda.synchronize()
+    # replicas identical after the step: every rank's parameter bits against rank 0's
+    ref = bucket.flat.clone()
+    dist.broadcast(ref, 0)
+    same = torch.tensor([int(torch.equal(ref, bucket.flat))], device=dev)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        # the global-batch gradient of mean_b SNRLP on ONE GPU, same weights (the pre-step parameters were rank 0's own)
+        torch.manual_seed(100)
+        m1 = sb.NetDisEmbd3(**params).to(dev).train()
+        b1 = FlatBucket(m1)
+        b1.zero_grad()
+        parts = [shard(r) for r in range(world)]
+        mixg, tgtg, disg = (torch.cat([p[i] for p in parts]).to(dev) for i in range(3))
+        l1, _ = SnrlpLossFn.apply(m1({"mixture": mixg, "dis_embed": disg})["output"], tgtg, 100.0)
+        l1.backward()
+        torch.cuda.synchronize()
+        q.put((w, dist.get_backend(), int(same.item()), g_dp.cpu().numpy(), b1.grad.cpu().numpy(),
+               ".".join(str(v) for v in torch.cuda.nccl.version())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_per_gpu_over_rccl_when_the_box_has_several_gpus():
+    """Skipped on a one-GPU box.  With N >= 2 devices visible: N = min(count, 8) ranks, one per GPU, backend "nccl" (= RCCL over
+    xGMI), different initial weights per rank synchronised by broadcast_replica, one train step per rank on its own shard
+    (seed + rank, radii cycling over the global batch, silent-target utterances on the odd ranks): RCCL reports N ranks, the
+    all-reduced flat bucket / N equals the single-GPU GLOBAL-batch gradient of mean_b SNRLP (the assertion of the gloo tests
+    above: hl_module:34-35's nn.DataParallel gradient), and every rank holds the same parameter bits after the fused Adam."""
+    import torch
+    import torch.multiprocessing as mp
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip("one GPU visible: the N-rank RCCL step needs >= 2 (the 2-ranks-on-one-GPU gloo tests above cover the logic)")
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_multi_gpu_worker, args=(r, n, port, q)) for r in range(n)]
+    for p in procs:
+        p.start()
+    w, backend, same, g_dp, g_ref, ver = q.get()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    err = rel_l2(g_dp, g_ref)
+    print(f"RCCL {ver}: {w} ranks on {n} GPUs; all-reduced bucket vs global-batch gradient rel-L2 {err:.2e}; replicas identical: {bool(same)}")
+    assert w == n and backend == "nccl" and same == 1
+    assert err < 5e-5, err          # (summation order over N shards: the 2-rank gloo form above measures 1e-5)

@@ -98,3 +98,78 @@ def test_loss_comes_down_over_a_short_run_with_a_silent_watchdog():
     print("epoch-mean loss:", [round(m, 3) for m in means])
     assert means[-1] < 0.1 * means[0], means
     assert all(b <= a + abs(a) / 3 + 0.2 for a, b in zip(means[2:], means[3:])), means
+
+
+def test_b9_stress_1000_train_steps_no_trip_no_skipped_update_finite_loss():
+    """>= 1 000 B = 9 train steps of the harness loop (ragged 82-tile inter-frame passes: the one geometry at
+    which the overlapped forward's producer was ever seen to stand still; every overlapped schedule engaged), cached batches, one
+    loss read per 8 epochs: no bounded wait gives up, the guarded optimiser skipped nothing, every loss read is finite, and the
+    overlapped orders really were the ones that ran."""
+    import time
+    from sound_bubble_amd import ops
+    from sound_bubble_amd.harness import import_attr
+    from sound_bubble_amd.train_cli import make_loaders, seed_all, to_device
+    p = _params()
+    seed_all(0)
+    mk = lambda key, split: import_attr(p[f"{key}_dataset"])(**p[f"{key}_data_args"], split=split)
+    loader, _ = make_loaders(mk("train", "train"), mk("val", "val"), p, 1, 0)
+    dev = torch.device("cuda")
+    batches = [to_device(b, dev) for b in loader]
+    assert batches[0][0]["mixture"].shape[0] == 9          # (inputs, targets) pairs, as tain_val.py:66-70 takes them
+    hl = import_attr(p["pl_module"])(**p["pl_module_args"])
+    hl.train()
+    ops.sched_counts_reset()
+    g0 = ops.read_giveups() if ops._OVERLAP_OK else 0
+    t0 = time.time()
+    steps = 0
+    while steps < 1000:
+        for idx, batch in enumerate(batches):
+            hl.reset_grad()
+            loss, B = hl.training_step(batch, idx)
+            loss.backward()
+            hl.backprop()                         # (checks the watchdog word every 50th step and raises on a trip)
+            steps += 1
+        if (steps // len(batches)) % 8 == 0:
+            assert np.isfinite(float(loss.detach())), steps
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    assert np.isfinite(float(loss.detach()))
+    assert ops.read_sched_status() == [], ops.LAST_TRIPS[-1:]
+    assert int(hl.optimizer.skipped.item()) == 0
+    counts = dict(ops.SCHED_COUNTS)
+    print(f"{steps} B = 9 train steps in {dt:.1f} s ({1e3 * dt / steps:.1f} ms / step): schedules {counts}, "
+          f"hand-back events {(ops.read_giveups() - g0) if ops._OVERLAP_OK else 'n/a'}")
+    if ops.overlap_available() and not ops._OVERLAP_LOST:
+        assert counts["fwd_overlapped"] > 0 and counts["bwd_overlapped"] > 0, counts
+
+
+def test_guarded_adam_skips_the_update_when_the_watchdog_word_is_set():
+    """sb_adam_step_guarded: with *guard != 0 parameters and moments stay bit-identical and *skipped counts the step; with
+    *guard == 0 (and with guard == NULL, the legacy entry) the update is torch.optim.Adam's."""
+    import ctypes as C
+    from sound_bubble_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(0)
+    n = 10007
+    p0, g = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    ref.grad = g.clone()
+    opt.step()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    for guard_val in (1, 0, None):
+        p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        guard = torch.full((1,), guard_val, dtype=torch.int32, device="cuda") if guard_val is not None else None
+        skipped = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if guard is None:
+            rc = lib.sb_adam_step(vp(p), vp(g), vp(m), vp(v), n, 1e-2, 0.9, 0.999, 1e-8, 1, 1.0, 0.0, None, None)
+        else:
+            rc = lib.sb_adam_step_guarded(vp(p), vp(g), vp(m), vp(v), n, 1e-2, 0.9, 0.999, 1e-8, 1, 1.0, 0.0, None, vp(guard),
+                                          vp(skipped), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        if guard_val == 1:
+            assert torch.equal(p, p0) and not m.any() and not v.any() and int(skipped) == 1
+        else:
+            assert int(skipped) == 0
+            assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-7)
