@@ -689,6 +689,18 @@ int sb_ln_film_bwd(const float* du, const float* xin, const float* ln_g, const f
  * partial products of the intra-frame Linear written by sb_lstm_fwd in partial mode (tfgridnet_causal.py:824-827). */
 int sb_add3(const float* x, const float* part, float* y, int64_t P, int C, void* stream);
 
+/* ---- staging of the 3x3 convolutions' inputs and of the iSTFT's spectrum rows (round 6; rounds 1-5: ATen fills and strided copies) ----
+ * sb_stage_frames: dst [B, Tp, F + 2, Cd] channels-last with zero frequency borders (columns 0 and F + 1).  Frame rows 0, 1 <- the
+ *   carried context `state` [B, Cs, 2, F] (conv_buf / deconv_buf of tfgridnet_causal.py:403-421; channels Cs .. Cd - 1 zero);
+ *   with src != NULL ([B, Tp - 2, F, Cd]: the last block's output, :517-520) frame rows 2 .. <- src as well (borders zeroed);
+ *   with src == NULL only the two carried rows are written (the feature kernel sb_features fills the rest, :482-493).
+ * sb_frames_to_state: the new carried context [B, Cs, 2, F] <- frame rows r0, r0 + 1 of such a tensor (interior, channels < Cs).
+ * sb_spec_rows: spectrum rows [B, T + 1, ld] (interleaved re / im, ld >= 2 F).  mode 0: zero the padding columns 2 F .. ld - 1
+ *   of every row and fill row 0 from the carried istft_buf [B, 2, F] (:533-536); mode 1: the new istft_buf <- row T. */
+int sb_stage_frames(const float* state, const float* src, float* dst, int B, int Tp, int F, int Cs, int Cd, void* stream);
+int sb_frames_to_state(const float* rows, float* state, int B, int Tp, int F, int Cs, int Cd, int r0, void* stream);
+int sb_spec_rows(float* rows, float* buf, int B, int T, int F, int ld, int mode, void* stream);
+
 /* out[r, f, :] = in[r, f, :] (+ bias[:] when bias != NULL) for the tail frequencies Fm <= f < F of every row r (in, out: [rows, F, C]):
  * the residual of the conv-LSTM intra path at the frequencies beyond down * floor(F / down), which the k = s = down
  * ConvTranspose1d does not reach (bias: only the `optim` flavour, whose deconvolution has output_padding -- optim/
@@ -730,13 +742,21 @@ int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy, int B, int
  * samples get neg_weight * mean|est| over ALL negative samples' elements.
  * dest (nullable) = d mean_b(loss_vec) / d est.
  * sb_snrlp_loss_ex: `mode` = the positive samples' term, SNRLosses(name) of src/losses/SNRLosses.py:10-52 --
- *   0 'snr' (sb_snrlp_loss; every shipped config), 1 'sisdr', 2 'fused' = (sisdr + snr) / 2, 3 'max_fused' = max(sisdr, snr),
+ *   0 'snr' (every shipped config), 1 'sisdr', 2 'fused' = (sisdr + snr) / 2, 3 'max_fused' = max(sisdr, snr),
  *   4 'sdsdr' = max(snr, sdsdr), 5 'full' = sisdr / 2 + max(snr, sdsdr) / 2; each term asteroid's SingleSrcNegSDR (zero-mean,
  *   EPS 1e-8), evaluated from the per-sample zero-mean moments S_tt, S_et, sum ((e - me) - (t - mt))^2.  -1002: unknown mode. */
-int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight,
-                  float* stats, float* loss_vec, float* dest, void* stream);
 int sb_snrlp_loss_ex(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode,
                      float* stats, float* loss_vec, float* dest, void* stream);
+/* The same in two calls (round 6): _fwd fills stats and loss_vec and, when loss_mean != NULL, *loss_mean = mean_b loss_vec[b]
+ * (hl_module:321's loss.mean(), no reduction launch of the caller's); _bwd forms dest = gout[0] * d mean_b(loss_vec) / d est from
+ * the SAME stats (gout: device scalar, the incoming gradient of the mean; NULL = 1) -- the gradient is then computed in the
+ * backward pass, scaled in the kernel, and never materialised for a forward that is not followed by one.
+ * (rounds 1-5 exported sb_snrlp_loss, mode 0 with stats [B, 8]: REMOVED in round 6 -- stats grew to [B, 12] with the other modes, and
+ * a caller built against the old size would have overrun its scratch silently; it now fails at load time.  Use _ex with mode 0.) */
+int sb_snrlp_loss_fwd(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode,
+                      float* stats, float* loss_vec, float* loss_mean, void* stream);
+int sb_snrlp_loss_bwd(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode,
+                      const float* stats, const float* gout, float* dest, void* stream);
 
 /* ---- metric moments (src/metrics/metrics.py:44-55, hl_module:326-373) -------
  * One pass over est, gt [B, N] and the reference mixture channel (row b at mix + b*mix_stride):
@@ -796,7 +816,8 @@ int sb_frames_fold(const float* dframes, float* dx, int B, int64_t N, int nframe
 int sb_l1_grad(const float* x, const float* y, int64_t n, float gscale, float* dx, int accumulate, float* partial,
                float loss_scale, float* loss, int accumulate_loss, void* stream);
 
-int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream);                       /* sumsq[0] += sum g^2 */
+int sb_sumsq_ex(const float* g, int64_t n, float* sumsq, int accumulate, void* stream);      /* accumulate == 0: sumsq[0] = sum g^2 (no zero-fill in front) */
 /* Adam step (torch.optim.Adam, no weight decay / amsgrad) over a flat bucket.
  * grad is first scaled by gscale * min(1, clip / (sqrt(sumsq[0]) * gscale + 1e-6))
  * when clip > 0 (clip_grad_norm_ semantics), else by gscale. */

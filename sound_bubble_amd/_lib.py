@@ -233,7 +233,12 @@ SYMBOLS = {
     "sb_overlap_add": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_overlap_add_bwd": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _vp]),
     "sb_deconv_bwd_data": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, c_fp, _vp]),
-    "sb_snrlp_loss": (_ci, [c_fp, c_fp, _ci, i64, _cf, c_fp, c_fp, c_fp, _vp]),
+    "sb_snrlp_loss_fwd": (_ci, [c_fp, c_fp, _ci, i64, _cf, _ci, c_fp, c_fp, c_fp, _vp]),
+    "sb_snrlp_loss_bwd": (_ci, [c_fp, c_fp, _ci, i64, _cf, _ci, c_fp, c_fp, c_fp, _vp]),
+    "sb_stage_frames": (_ci, [c_fp, c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "sb_frames_to_state": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "sb_spec_rows": (_ci, [c_fp, c_fp, _ci, _ci, _ci, _ci, _ci, _vp]),
+    "sb_sumsq_ex": (_ci, [c_fp, i64, c_fp, _ci, _vp]),
     "sb_snrlp_loss_ex": (_ci, [c_fp, c_fp, _ci, i64, _cf, _ci, c_fp, c_fp, c_fp, _vp]),
     "sb_signal_stats": (_ci, [c_fp, c_fp, c_fp, _ci, i64, i64, c_fp, _vp]),
     "sb_sumsq": (_ci, [c_fp, i64, c_fp, _vp]),

@@ -366,7 +366,7 @@ __device__ inline SdrTerm sdr_max(SdrTerm x, SdrTerm y) {
 // single block: per-sample loss and the two gradient coefficients.  mode (src/losses/SNRLosses.py:10-52): 0 'snr', 1 'sisdr',
 // 2 'fused' = (sisdr + snr) / 2, 3 'max_fused' = max(sisdr, snr), 4 'sdsdr' = max(snr, sdsdr), 5 'full' = sisdr / 2 + max(snr, sdsdr) / 2
 __global__ void loss_final_kernel(float* __restrict__ stats, int B, int64_t N, float neg_weight, int mode,
-                                  float* __restrict__ loss_vec) {
+                                  float* __restrict__ loss_vec, float* __restrict__ loss_mean) {
   __shared__ float negsum;
   __shared__ int nneg;
   if (threadIdx.x == 0) {
@@ -405,14 +405,23 @@ __global__ void loss_final_kernel(float* __restrict__ stats, int B, int64_t N, f
       stats[b * kLs + 7] = 0.f;
     }
   }
+  if (loss_mean) {                                   // hl_module:321: loss.mean() over the batch, in batch order
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += loss_vec[b];
+      loss_mean[0] = s / (float)B;
+    }
+  }
 }
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ est, const float* __restrict__ gt,
                                                         int B, int64_t N, float neg_weight, int mode,
-                                                        const float* __restrict__ stats, float* __restrict__ dest) {
+                                                        const float* __restrict__ stats, float* __restrict__ dest,
+                                                        const float* __restrict__ gout) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * N) return;
   const int b = (int)(i / N);
-  const float invB = 1.0f / (float)B;
+  const float invB = (gout ? gout[0] : 1.0f) / (float)B;
   if (stats[b * kLs + 7] != 0.f) {
     const float d = est[i] - gt[i];
     dest[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * neg_weight * invB / (float)N;
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256) void signal_stats_kernel(const float* __restri
 // data-parallel rank must derive bit-identical clip factors from the bit-identical all-reduced bucket, or the replicas
 // drift apart in the last bit (found by tests/test_gpu_distributed.py with the atomicAdd version).  The bucket is
 // 1-2 MB: one CU reads it in ~10 us.
-__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out, int accumulate) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   const int64_t n4 = n / 4;
   int64_t i = threadIdx.x;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += ws[k];
-    out[0] += t;
+    out[0] = accumulate ? out[0] + t : t;
   }
 }
 
@@ -544,6 +553,62 @@ __global__ __launch_bounds__(256) void tail_rows_kernel(const float* __restrict_
     const int64_t off = (r * F + Fm) * C + e;
     const float v = in[off];
     out[off] = bias ? v + bias[e % C] : v;
+  }
+}
+
+// ---- staging of the two 3x3 convolutions' inputs and of the iSTFT's spectrum rows (round 6: was ATen fills / strided copies) ----
+// dst [B, Tp, F + 2, Cd] channels-last, zero frequency borders.  Frame rows 0, 1 <- the carried state [B, Cs, 2, F] (channels
+// >= Cs zero); frame rows 2 .. <- src [B, Tp - 2, F, Cd] (src != NULL; the output convolution's input), borders zeroed.
+__global__ __launch_bounds__(256) void stage_frames_kernel(const float* __restrict__ state, const float* __restrict__ src,
+                                                           float* __restrict__ dst, int B, int Tp, int F, int Cs, int Cd) {
+  const int64_t nrow = src ? (int64_t)B * Tp : (int64_t)B * 2;           // (b, frame row) pairs this launch writes
+  const int rw = (F + 2) * Cd;
+  const int64_t total = nrow * rw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / rw;
+    const int e = (int)(i - row * rw);
+    const int fp = e / Cd, c = e - fp * Cd;
+    const int b = (int)(src ? row / Tp : row / 2), r = (int)(src ? row % Tp : row % 2);
+    float v = 0.f;
+    if (fp >= 1 && fp <= F) {
+      if (r < 2) { if (c < Cs) v = state[(((int64_t)b * Cs + c) * 2 + r) * F + (fp - 1)]; }
+      else v = src[(((int64_t)b * (Tp - 2) + (r - 2)) * F + (fp - 1)) * Cd + c];
+    }
+    dst[((int64_t)b * Tp + r) * rw + e] = v;
+  }
+}
+// new_state [B, Cs, 2, F] <- frame rows r0, r0 + 1 of rows [B, Tp, F + 2, Cd] (interior, channels < Cs)
+__global__ __launch_bounds__(256) void frames_to_state_kernel(const float* __restrict__ rows, float* __restrict__ state, int B,
+                                                              int Tp, int F, int Cs, int Cd, int r0) {
+  const int64_t total = (int64_t)B * Cs * 2 * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F), r = (int)((i / F) % 2), c = (int)((i / (2 * F)) % Cs), b = (int)(i / ((int64_t)2 * F * Cs));
+    state[i] = rows[(((int64_t)b * Tp + r0 + r) * (F + 2) + f + 1) * Cd + c];
+  }
+}
+// spectrum rows [B, T + 1, ld] (interleaved re / im per frequency, columns 2F .. ld - 1 padding): mode 0 -- zero the padding
+// columns of every row and fill row 0 from the carried istft_buf [B, 2, F] (re | im); mode 1 -- new istft_buf <- row T
+__global__ __launch_bounds__(256) void spec_rows_kernel(float* __restrict__ rows, float* __restrict__ buf, int B, int T, int F,
+                                                        int ld, int mode) {
+  if (mode == 1) {
+    const int64_t total = (int64_t)B * 2 * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int f = (int)(i % F), o = (int)((i / F) % 2), b = (int)(i / (2 * F));
+      buf[i] = rows[((int64_t)b * (T + 1) + T) * ld + 2 * f + o];
+    }
+    return;
+  }
+  const int pad = ld - 2 * F;
+  const int64_t npad = (int64_t)B * (T + 1) * pad, nrow0 = (int64_t)B * 2 * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad + nrow0; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < npad) {
+      const int64_t row = i / pad;
+      rows[row * ld + 2 * F + (i - row * pad)] = 0.f;
+    } else {
+      const int64_t k = i - npad;
+      const int f = (int)(k % F), o = (int)((k / F) % 2), b = (int)(k / (2 * F));
+      rows[(int64_t)b * (T + 1) * ld + 2 * f + o] = buf[k];
+    }
   }
 }
 
@@ -837,11 +902,10 @@ extern "C" int sb_deconv_bwd_data(const float* dspec, const float* w, float* dy,
   return 0;
 }
 
-extern "C" int sb_snrlp_loss_ex(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode, float* stats,
-                                float* loss_vec, float* dest, void* stream) {
+static int snrlp_forward(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode, float* stats,
+                         float* loss_vec, float* loss_mean, hipStream_t st) {
   if (!est || !gt || !stats || !loss_vec || B <= 0 || N <= 0) return -1001;
   if (mode < 0 || mode > 5) return -1002;
-  hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(stats, 0, (size_t)B * kLs * sizeof(float), st);
   unsigned gx = nblk(N, 256 * 8);
   if (gx > 64) gx = 64;
@@ -849,14 +913,31 @@ extern "C" int sb_snrlp_loss_ex(const float* est, const float* gt, int B, int64_
   hipLaunchKernelGGL(loss_pass2_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
   if (mode == 1 || mode == 2 || mode == 3 || mode == 5)
     hipLaunchKernelGGL(loss_pass3_kernel, dim3(gx, B), dim3(256), 0, st, est, gt, N, stats);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, stats, B, N, neg_weight, mode, loss_vec);
-  if (dest) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk((int64_t)B * N)), dim3(256), 0, st, est, gt, B, N, neg_weight, mode, stats, dest);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, stats, B, N, neg_weight, mode, loss_vec, loss_mean);
+  return 0;
+}
+extern "C" int sb_snrlp_loss_fwd(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode, float* stats,
+                                 float* loss_vec, float* loss_mean, void* stream) {
+  if (int rc = snrlp_forward(est, gt, B, N, neg_weight, mode, stats, loss_vec, loss_mean, (hipStream_t)stream)) return rc;
   SB_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int sb_snrlp_loss(const float* est, const float* gt, int B, int64_t N, float neg_weight, float* stats,
-                             float* loss_vec, float* dest, void* stream) {
-  return sb_snrlp_loss_ex(est, gt, B, N, neg_weight, 0, stats, loss_vec, dest, stream);
+extern "C" int sb_snrlp_loss_bwd(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode,
+                                 const float* stats, const float* gout, float* dest, void* stream) {
+  if (!est || !gt || !stats || !dest || B <= 0 || N <= 0) return -1001;
+  if (mode < 0 || mode > 5) return -1002;
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk((int64_t)B * N)), dim3(256), 0, (hipStream_t)stream, est, gt, B, N, neg_weight,
+                     mode, stats, dest, gout);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sb_snrlp_loss_ex(const float* est, const float* gt, int B, int64_t N, float neg_weight, int mode, float* stats,
+                                float* loss_vec, float* dest, void* stream) {
+  if (int rc = snrlp_forward(est, gt, B, N, neg_weight, mode, stats, loss_vec, nullptr, (hipStream_t)stream)) return rc;
+  if (dest) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk((int64_t)B * N)), dim3(256), 0, (hipStream_t)stream, est, gt, B, N,
+                               neg_weight, mode, stats, dest, (const float*)nullptr);
+  SB_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int sb_signal_stats(const float* est, const float* gt, const float* mix, int B, int64_t N, int64_t mix_stride,
@@ -870,9 +951,37 @@ extern "C" int sb_signal_stats(const float* est, const float* gt, const float* m
   return 0;
 }
 
-extern "C" int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
+extern "C" int sb_sumsq_ex(const float* g, int64_t n, float* sumsq, int accumulate, void* stream) {
   if (n <= 0 || (reinterpret_cast<uintptr_t>(g) & 15)) return -1002;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, sumsq);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, sumsq, accumulate);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sb_sumsq(const float* g, int64_t n, float* sumsq, void* stream) { return sb_sumsq_ex(g, n, sumsq, 1, stream); }
+
+extern "C" int sb_stage_frames(const float* state, const float* src, float* dst, int B, int Tp, int F, int Cs, int Cd, void* stream) {
+  if (!state || !dst || B <= 0 || Tp < 2 || F <= 0 || Cs <= 0 || Cd < Cs) return -1001;
+  const int64_t total = (src ? (int64_t)B * Tp : (int64_t)B * 2) * (F + 2) * Cd;
+  unsigned gx = nblk(total);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(stage_frames_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, state, src, dst, B, Tp, F, Cs, Cd);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sb_frames_to_state(const float* rows, float* state, int B, int Tp, int F, int Cs, int Cd, int r0, void* stream) {
+  if (!rows || !state || B <= 0 || r0 < 0 || r0 + 2 > Tp || F <= 0 || Cs <= 0 || Cd < Cs) return -1001;
+  unsigned gx = nblk((int64_t)B * Cs * 2 * F);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(frames_to_state_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, rows, state, B, Tp, F, Cs, Cd, r0);
+  SB_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int sb_spec_rows(float* rows, float* buf, int B, int T, int F, int ld, int mode, void* stream) {
+  if (!rows || !buf || B <= 0 || T <= 0 || F <= 0 || ld < 2 * F || (mode != 0 && mode != 1)) return -1001;
+  const int64_t total = mode == 1 ? (int64_t)B * 2 * F : (int64_t)B * (T + 1) * (ld - 2 * F) + (int64_t)B * 2 * F;
+  unsigned gx = nblk(total);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(spec_rows_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, rows, buf, B, T, F, ld, mode);
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -821,10 +821,11 @@ class FrontEndFn(torch.autograd.Function):
         zp = _ws_zeros("zp", (B, T + 2, F + 2, ZC), dev)
         if zp is None:
             zp = torch.empty(B, T + 2, F + 2, ZC, device=dev, dtype=torch.float32)
-            zp[:, :2].zero_()
-        zp[:, :2, 1:F + 1, :nfeat] = conv_buf.permute(0, 2, 3, 1)
+        # the two carried frames (conv_buf, channels-first) -> frame rows 0, 1 with their zero borders and padding channels; the
+        # feature kernel writes rows 2 .. (borders included); the new conv_buf is the last two frame rows
+        ops.stage_frames(conv_buf.contiguous(), None, zp, B, T + 2, F, nfeat, ZC)
         ops.features(spec, NSPEC, zp, B, M, T, F)
-        new_buf = zp[:, T:T + 2, 1:F + 1, :nfeat].permute(0, 3, 1, 2).contiguous()
+        new_buf = ops.frames_to_state(zp, B, T + 2, F, nfeat, ZC, T)
         # 3. 3x3 conv as 3 K-segments of 96 contiguous floats (+ fused LayerNorm)
         # wk: kernel-layout form of the Conv2d weight, [co][(a*3 + d)*32 + ci] with channels 27..31 zero (forms.WeightForms)
         x0 = torch.empty(B, T, F, Cc, device=dev, dtype=torch.float32)
@@ -896,18 +897,16 @@ class BackEndFn(torch.autograd.Function):
         assert dw.shape[1] == 2, "num_src=1 only (every shipped config)"
         yp = _ws_zeros("yp", (B, T + 2, F + 2, Cc), dev)
         if yp is None:
-            yp = torch.empty(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)      # only the frequency borders are zero
-            yp[:, :, 0].zero_()
-            yp[:, :, F + 1].zero_()
-        yp[:, :2, 1:F + 1] = deconv_buf.permute(0, 2, 3, 1)
-        yp[:, 2:, 1:F + 1] = y
-        new_dbuf = yp[:, T:T + 2, 1:F + 1].permute(0, 3, 1, 2).contiguous()
-        # spectrum rows [B, T+1, 304], interleaved (re,im) per frequency; row 0 = carried frame
-        rows = _ws_zeros("rows", (B, T + 1, NSPEC), dev)        # columns 2F .. NSPEC-1 are padding: never written, stay zero
+            yp = torch.empty(B, T + 2, F + 2, Cc, device=dev, dtype=torch.float32)
+        # one launch: carried frames (deconv_buf) -> rows 0, 1; y -> rows 2 ..; zero frequency borders; then the new deconv_buf
+        ops.stage_frames(deconv_buf.contiguous(), y.contiguous(), yp, B, T + 2, F, Cc, Cc)
+        new_dbuf = ops.frames_to_state(yp, B, T + 2, F, Cc, Cc, T)
+        # spectrum rows [B, T+1, 304], interleaved (re,im) per frequency; row 0 = carried frame; columns 2F .. 303 padding (zero:
+        # they meet zero synthesis weights, and 0 x garbage could be NaN)
+        rows = _ws_zeros("rows", (B, T + 1, NSPEC), dev)
         if rows is None:
-            rows = torch.zeros(B, T + 1, NSPEC, device=dev, dtype=torch.float32)
-        ib = istft_buf.reshape(B, 2, F)                                           # [re | im]
-        rows[:, 0, : 2 * F] = ib.permute(0, 2, 1).reshape(B, 2 * F)
+            rows = torch.empty(B, T + 1, NSPEC, device=dev, dtype=torch.float32)
+        ops.spec_rows(rows, istft_buf.reshape(B, 2, F).contiguous(), B, T, F, NSPEC, 0)
         # wk [16][(a*3 + d)*C + c] = dw[c, o, 2-a, 2-d] (rows 2..15 zero), bk [16]: kernel-layout forms (forms.WeightForms)
         s_in = ((T + 2) * (F + 2) * Cc, (F + 2) * Cc, Cc)
         ops.linear(yp, wk, bk, rows, (B, T, F), s_in, ((T + 1) * NSPEC, NSPEC, 2), 9 * Cc, 16, kseg=3 * Cc,
@@ -918,8 +917,8 @@ class BackEndFn(torch.autograd.Function):
         _, s_f = dense(B * (T + 1), win)
         ops.linear(rows, w_syn, None, frames, g, s_r, s_f, NSPEC, win)
         wave = ops.overlap_add(frames, B, T, win, hop)
-        last = rows[:, T, : 2 * F].reshape(B, F, 2).permute(0, 2, 1)              # [B, 2, F]
-        new_ibuf = last.reshape(B, 1, 2 * F, 1).contiguous()
+        new_ibuf = torch.empty(B, 1, 2 * F, 1, device=dev, dtype=torch.float32)
+        ops.spec_rows(rows, new_ibuf, B, T, F, NSPEC, 1)                          # [re | im] of the last frame's row
         if train:
             ctx.save_for_backward(yp, dw, w_ana, db)
             ctx.dims = (B, T, F, Cc, win, hop)
@@ -963,17 +962,22 @@ class SnrlpLossFn(torch.autograd.Function):
         B = est.shape[0]
         e = est.reshape(B, -1).contiguous()
         t = gt.reshape(B, -1).contiguous()
-        lv, dest = ops.snrlp_loss(e, t, neg_weight, want_grad=ctx.needs_input_grad[0], mode=mode)
-        ctx.save_for_backward(dest)
-        ctx.shape = est.shape
+        # per-sample losses, their batch mean (formed by the final kernel: no reduction launch) and the moments the gradient
+        # kernel needs; the gradient itself is formed in backward, scaled by the incoming gradient inside the kernel
+        lv, mean, stats = ops.snrlp_loss_fwd(e, t, neg_weight, mode=mode)
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(e, t, stats)
+            ctx.cfg = (est.shape, float(neg_weight), int(mode))
         ctx.set_materialize_grads(False)     # no zero tensors for the state outputs' (absent) gradients
         ctx.mark_non_differentiable(lv)
-        return lv.mean(), lv
+        return mean.reshape(()), lv
 
     @staticmethod
     def backward(ctx, gout, _glv):
-        (dest,) = ctx.saved_tensors
-        return (dest * gout).view(ctx.shape), None, None, None
+        e, t, stats = ctx.saved_tensors
+        shape, neg_weight, mode = ctx.cfg
+        g = gout.reshape(1).to(torch.float32).contiguous()
+        return ops.snrlp_loss_bwd(e, t, neg_weight, stats, g, mode=mode).view(shape), None, None, None
 
 
 class MultiResoFuseLossFn(torch.autograd.Function):

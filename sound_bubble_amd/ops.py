@@ -1856,6 +1856,41 @@ def deconv_bwd_data(dspec, w, B, T, F, Cc):
 SNR_LOSS_MODES = {"snr": 0, "sisdr": 1, "fused": 2, "max_fused": 3, "sdsdr": 4, "full": 5}     # src/losses/SNRLosses.py:10-29
 
 
+def snrlp_loss_fwd(est, gt, neg_weight, mode=0):
+    """est, gt [B, N] -> loss_vec [B], mean_b loss_vec [1], stats [B, 12] (what snrlp_loss_bwd needs)"""
+    B_, N = est.shape
+    stats = torch.empty(B_, 12, device=est.device, dtype=torch.float32)
+    lv = torch.empty(B_, device=est.device, dtype=torch.float32)
+    mean = torch.empty(1, device=est.device, dtype=torch.float32)
+    L.check(L.load().sb_snrlp_loss_fwd(_p(est), _p(gt), B_, N, float(neg_weight), int(mode), _p(stats), _p(lv), _p(mean),
+                                       _stream()), "sb_snrlp_loss_fwd")
+    return lv, mean, stats
+
+
+def snrlp_loss_bwd(est, gt, neg_weight, stats, gout, mode=0):
+    """-> gout * d(mean_b loss)/d est [B, N]; gout: device scalar tensor [1] (or None = 1)"""
+    B_, N = est.shape
+    dest = torch.empty_like(est)
+    L.check(L.load().sb_snrlp_loss_bwd(_p(est), _p(gt), B_, N, float(neg_weight), int(mode), _p(stats), _p(gout), _p(dest),
+                                       _stream()), "sb_snrlp_loss_bwd")
+    return dest
+
+
+def stage_frames(state, src, dst, B, Tp, F_, Cs, Cd):
+    """carried 2-frame context (+ src rows) -> the zero-bordered channels-last staging tensor of a 3x3 convolution"""
+    L.check(L.load().sb_stage_frames(_p(state), _p(src), _p(dst), B, Tp, F_, Cs, Cd, _stream()), "sb_stage_frames")
+
+
+def frames_to_state(rows, B, Tp, F_, Cs, Cd, r0):
+    st = torch.empty(B, Cs, 2, F_, device=rows.device, dtype=torch.float32)
+    L.check(L.load().sb_frames_to_state(_p(rows), _p(st), B, Tp, F_, Cs, Cd, r0, _stream()), "sb_frames_to_state")
+    return st
+
+
+def spec_rows(rows, buf, B, T, F_, ld, mode):
+    L.check(L.load().sb_spec_rows(_p(rows), _p(buf), B, T, F_, ld, mode, _stream()), "sb_spec_rows")
+
+
 def snrlp_loss(est, gt, neg_weight, want_grad, mode=0):
     """est, gt [B, N] -> loss_vec [B], d(mean loss)/d est or None; mode: SNR_LOSS_MODES[snr_loss_name]"""
     B_, N = est.shape
@@ -1925,8 +1960,9 @@ def signal_stats(est, gt, mix_ref):
     return out
 
 
-def sumsq(g, out):
-    L.check(L.load().sb_sumsq(_p(g), g.numel(), _p(out), _stream()), "sb_sumsq")
+def sumsq(g, out, accumulate=True):
+    """out[0] (+)= sum g^2 (accumulate=False: plain store -- no zero-fill in front of the call)"""
+    L.check(L.load().sb_sumsq_ex(_p(g), g.numel(), _p(out), 1 if accumulate else 0, _stream()), "sb_sumsq_ex")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gscale=1.0, clip=0.0, sumsq_buf=None, skipped=None):

@@ -63,8 +63,7 @@ class FusedAdam:
         lr = self.param_groups[0]["lr"]
         clip = float(grad_clip) if grad_clip else 0.0
         if clip > 0:
-            self.sumsq.zero_()
-            ops.sumsq(b.grad, self.sumsq)
+            ops.sumsq(b.grad, self.sumsq, accumulate=False)
         ops.adam_step(b.flat, b.grad, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.step_count,
                       gscale=1.0 / world_size, clip=clip, sumsq_buf=self.sumsq, skipped=self.skipped)
         bump_weight_epoch()       # the kernel wrote the parameters behind torch's version counters: weight forms are stale
