@@ -96,6 +96,52 @@ SB_DEVINL void attn_tile(int ntiles, int BH, int& bh, int& tile) {
   else { const int i = g - nfull; bh = full + i / ntiles; tile = i % ntiles; }
 }
 
+// Both contractions below are LATENCY-bound as first written (one or two loads, then the MFMAs that need them, per loop trip:
+// ~2 loads in flight per wave, 0.17 of the fp32 matrix peak -- round 5): the loads of a whole GROUP of K chunks are now issued
+// before the first MFMA of the group (8 x 16-byte row pieces, resp. 32 scalar column elements in flight per lane); indices past
+// the end are clamped to valid memory and meet a zero operand, so the loops have no tail branch.
+// D[i][j] = sum_k X[xrow(lane&15)][k] * Y[yrow(lane&15)][k] over ld features (both fetched as 16-byte row pieces);
+// lane (j, q) ends up with D[4q + r][j].
+__device__ __forceinline__ f32x4 rowdot_tile(const float* __restrict__ X, size_t xrow, const float* __restrict__ Y,
+                                             size_t yrow, int ld, int q) {
+  constexpr int G = 4;
+  f32x4 acc = zero4();
+  const int nk = ld / 16;
+  const float* __restrict__ xp = X + xrow * ld + 4 * q;
+  const float* __restrict__ yp = Y + yrow * ld + 4 * q;
+  for (int m0 = 0; m0 < nk; m0 += G) {
+    f32x4 xa[G], ya[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int m = min(m0 + g, nk - 1);
+      xa[g] = ld4(xp + 16 * m);
+      ya[g] = ld4(yp + 16 * m);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc = mfma16x4(xa[g], (m0 + g < nk) ? ya[g] : zero4(), acc);
+  }
+  return acc;
+}
+// D[i][j] = sum_k Pl[i][k] * Z[clamp(zrow0 + k)][col]  (Pl: LDS, leading dim ldp; k < 16*nk16)
+__device__ __forceinline__ f32x4 lds_times_rows(const float* Pl, int ldp, int nk16, const float* __restrict__ Z,
+                                                int zrow0, int zmax, int ld, int col, int j, int q) {
+  constexpr int G = 8;
+  f32x4 acc = zero4();
+  for (int m0 = 0; m0 < nk16; m0 += G) {
+    f32x4 b[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[g][r] = Z[(size_t)min(zrow0 + 16 * (m0 + g) + 4 * q + r, zmax) * ld + col];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const f32x4 a4 = ld4(&Pl[j * ldp + 16 * min(m0 + g, nk16 - 1) + 4 * q]);
+      acc = mfma16x4((m0 + g < nk16) ? a4 : zero4(), b[g], acc);
+    }
+  }
+  return acc;
+}
+
 // attention core: 1-D grid of ceil(T/16) * B*Hh workgroups (attn_tile)
 __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
   extern __shared__ __attribute__((aligned(16))) float PT[];     // [16 queries][NRp + 4]  scores -> probabilities
@@ -115,12 +161,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
   const int tq = min(t0 + j, a.T - 1);                         // clamped query row for the B operand
   for (int rt = w; rt < nrt; rt += 4) {
     const int krow = min(t0 + 16 * rt + j, rows - 1);
-    f32x4 acc = zero4();
-    for (int m = 0; m < a.ldk / 16; ++m) {
-      const f32x4 a4 = ld4(Kb + (size_t)krow * a.ldk + 16 * m + 4 * q);
-      const f32x4 b4 = ld4(Qb + (size_t)tq * a.ldk + 16 * m + 4 * q);
-      acc = mfma16x4(a4, b4, acc);
-    }
+    const f32x4 acc = rowdot_tile(Kb, krow, Qb, tq, a.ldk, q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * rt + 4 * q + r;                       // window row, query j
@@ -147,17 +188,8 @@ __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
   const int nft = a.ldv / 16;
   const int b = bh / a.Hh, h = bh % a.Hh;
   for (int nt = w; nt < nft; nt += 4) {
-    f32x4 acc = zero4();
-    for (int m = 0; m < nrt; ++m) {
-      const f32x4 a4 = ld4(&PT[j * ldp + 16 * m + 4 * q]);         // A[i = query j][k = rows 16m+4q..+3]
-      f32x4 b4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int vrow = min(t0 + 16 * m + 4 * q + r, rows - 1);
-        b4[r] = Vb[(size_t)vrow * a.ldv + 16 * nt + j];           // B[k = row][j = feature 16nt + j]
-      }
-      acc = mfma16x4(a4, b4, acc);
-    }
+    // A[i = query j][k = window rows], B[k = row][j = feature 16nt + j]
+    const f32x4 acc = lds_times_rows(PT, ldp, nrt, Vb, t0, rows - 1, a.ldv, 16 * nt + j, j, q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = t0 + 4 * q + r;                               // query frame, feature n = 16nt + j
@@ -271,29 +303,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
   if (ln == 0) red[0][wv][0][0] = da;
   __syncthreads();
   if (threadIdx.x == 0) prow[2 * n] = red[0][0][0][0] + red[0][1][0][0] + red[0][2][0][0] + red[0][3][0][0];
-}
-
-// D[i][j] = sum_k X[xrow(lane&15)][k] * Y[yrow(lane&15)][k] over ld features (both fetched as 16-byte row pieces);
-// lane (j, q) ends up with D[4q + r][j].
-__device__ __forceinline__ f32x4 rowdot_tile(const float* __restrict__ X, size_t xrow, const float* __restrict__ Y,
-                                             size_t yrow, int ld, int q) {
-  f32x4 acc = zero4();
-  for (int m = 0; m < ld / 16; ++m)
-    acc = mfma16x4(ld4(X + xrow * ld + 16 * m + 4 * q), ld4(Y + yrow * ld + 16 * m + 4 * q), acc);
-  return acc;
-}
-// D[i][j] = sum_k Pl[i][k] * Z[clamp(zrow0 + k)][col0 + j]  (Pl: LDS, leading dim ldp; k < 16*nk16)
-__device__ __forceinline__ f32x4 lds_times_rows(const float* Pl, int ldp, int nk16, const float* __restrict__ Z,
-                                                int zrow0, int zmax, int ld, int col, int j, int q) {
-  f32x4 acc = zero4();
-  for (int m = 0; m < nk16; ++m) {
-    const f32x4 a4 = ld4(&Pl[j * ldp + 16 * m + 4 * q]);
-    f32x4 b4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b4[r] = Z[(size_t)min(zrow0 + 16 * m + 4 * q + r, zmax) * ld + col];
-    acc = mfma16x4(a4, b4, acc);
-  }
-  return acc;
 }
 
 // dQ (+ delta_t = sum_l p_l dp_l): grid (ceil(T/16), B*Hh), same tiling as the forward.
