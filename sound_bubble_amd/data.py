@@ -28,7 +28,12 @@ class BubbleFolderDataset(torch.utils.data.Dataset):
     scenes longer than `sig_len` seconds (at the constructor's `sr`: the reference's default 48 000 makes that 9 s of
     24 kHz audio, so 5 s scenes pass whole) are cropped at a random offset (:173-177).
     Not built: the audio perturbations (host-side augmentation) -- a non-empty list raises.
-    Extension: `repeat` (each scene appears that many times per epoch)."""
+    Extension: `repeat` (each scene appears that many times per epoch).
+    Where this class is MORE LENIENT than the reference's (none of it matters for the bundled scenes): (1) the radius
+    folder is accepted as the LAST path component as well as the second-to-last (`binural_1_5m` as third-to-last or in the last
+    two), where the reference looks at split('/')[-2] only ([-3] for binural); (2) `targets_outside` is allocated at the CROPPED
+    length, the reference allocates it before cropping, at the uncropped one; (3) a missing metadata['real'] / ['n_BG'] reads as
+    False / 0 where the reference raises KeyError."""
 
     def __init__(self, dataset_dirs, n_mics=6, sr=48000, directional=True, fair_compare=False, prob_neg=0,
                  perturbations=[], downsample=1, mic_config=[], sig_len=4.5, reference_channels=None, split="val",
