@@ -1521,6 +1521,16 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     // compiler would keep each role's loop-carried registers (dW sums; weights) alive through the other role's body.
     // Time segments (SEG): an item is (tile, segment) and walks steps s_hi .. s_lo; the hand-off wait and the state publish
     // carry workgroup barriers of their own, which the chunk role mirrors.
+    // Issue priority for the chunk role's waves (round 6).  The phase table (profiles/r06_phase_table.txt) shows them busy 92 % of
+    // a period with the recurrence waves parked at its barriers, and every SIMD hosts one wave of each role: when both are
+    // ready the chunk wave should issue.  Same-box A/B (profiles/r06_ab_prio.txt): C = 32 (big) +1.2 .. +1.4 % on the train step
+    // at priority 1, 2 or 3 alike; C = 16 (small) -1 % -- so only the C = 32 instantiations raise it.  -DSB_CHUNK_PRIO=n overrides
+    // (n = 0: off) for every width.
+#ifdef SB_CHUNK_PRIO
+    if (crole && SB_CHUNK_PRIO > 0) __builtin_amdgcn_s_setprio(SB_CHUNK_PRIO);
+#else
+    if constexpr (FST == 32) { if (crole) __builtin_amdgcn_s_setprio(1); }
+#endif
     if (!crole) {
       for (int item = CONS ? ord_first : (int)blockIdx.x; item < nitems; item = CONS ? ord_next() : item + (int)gridDim.x) {
         const int seg = SEG ? item / ntiles : 0;
