@@ -33,4 +33,5 @@ for wl in ("big", "small"):
             b = (ctypes.c_float * 8)()
             if lib.sb_debug_phase_bwd_split(b) == 0 and sum(b[:4]) > 0:
                 print(f"{wl} / train, {mode}: chunk role of the last role-split backward launch, ticks per period: work before hand-over "
-                      f"{b[0]:.0f}, wait {b[1]:.0f}, work after {b[2]:.0f}, wait at second barrier {b[3]:.0f}  (sum {sum(b[:4]):.0f})")
+                      f"{b[0]:.0f}, wait {b[1]:.0f}, work after {b[2]:.0f}, wait at second barrier {b[3]:.0f}  (sum {sum(b[:4]):.0f}); "
+                      f"work after = stage issue {b[4]:.0f} + flush {b[5]:.0f} + dW chunk {b[6]:.0f} + wait for the staged rows {b[7]:.0f}")

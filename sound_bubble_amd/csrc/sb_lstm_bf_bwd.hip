@@ -300,6 +300,12 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
   // STG: this lane's pieces of a chunk's rows.  Wave w of the chunk role fetches slot rows 8w .. 8w + 7 (step sa - (w >> 1),
   // sequences 8 (w & 1) ..): h rows 8w + (lane >> 4) and 8w + 4 + (lane >> 4), piece lane & 15; u / dy row 8w + (lane >> 3),
   // piece lane & 7 -- so that one wave instruction fills one contiguous KB of LDS
+  // Round 6: these per-lane, per-tile constants (and `base` for the chunk role's flush) are PARKED IN LDS, 4 ints per chunk-role
+  // thread.  Kept in registers through the period loop they were what hipcc spilled in the register-starved instantiations
+  // (cross-pass consumer: 111 spilled registers), and a scratch reload inside the loop is a vector-memory load that misses the
+  // L2 the record stream flows through: ~1 500 ticks each, twice per period (profiles/r06_phase_table.txt: "stage issue" 1 490 +
+  // "flush" 1 286 of a 8 900-tick period for four copy instructions and one store).  An LDS read costs ~100 and no registers.
+  __shared__ int PARK[(STG && SPLIT) ? 4 : 1][(STG && SPLIT) ? 256 : 1];
   int64_t stg_b[3] = {0, 0, 0};                   // step-0 positions of those three sequences (set_tile)
   bool stg_v[3] = {false, false, false};
   int stg_sel = 0;                                // LDS staging buffer of the chunk in hand
@@ -348,6 +354,13 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         const int n = tile * 16 + sq[i];
         stg_v[i] = FULL || n < a.nseq;
         stg_b[i] = stg_v[i] ? (int64_t)(n / a.n_inner) * a.p_outer + (int64_t)(n % a.n_inner) * a.p_inner : 0;
+      }
+      if constexpr (SPLIT) {                       // (positions are 32-bit: the launchers check P < 2^31)
+        if (crole) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) PARK[i][tid & 255] = (int)stg_b[i];
+          PARK[3][tid & 255] = (int)base;
+        }
       }
     }
     if constexpr (FST > 0) {
@@ -481,19 +494,42 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
   // rows of the chunk of steps (sa, sa - 1) -> staging buffer sel.  Direct (async) copies when every row counts; else -- the
   // last pair of a tile (h_prev / dy of walk index 0 are zero), a missing second step, a ragged tile -- through registers
   // with the rows that must not count zeroed (rare: the stall does not matter)
-  auto stage_issue = [&](int sa, bool two, int sel, int tile) {
+  auto stage_issue = [&](int sa, bool two, int sel, int tile, auto&& between) {
     const int i = w >> 1;
     const int sw = i == 0 ? sa : (two ? sa - 1 : sa);
     const bool cnt = sw > 0 && (i == 0 || two);                    // uniform over the wave
     const int64_t sp = (int64_t)st_of(sw) * a.p_step, sph = (int64_t)st_of(sw > 0 ? sw - 1 : sw) * a.p_step;
-    const float* gh0 = reinterpret_cast<const float*>(hs16 + ((stg_b[0] + sph) * LDH + (BI ? dir * H : 0)) * 2 + 8 * (lane & 15));
-    const float* gh1 = reinterpret_cast<const float*>(hs16 + ((stg_b[1] + sph) * LDH + (BI ? dir * H : 0)) * 2 + 8 * (lane & 15));
-    const float* gu = reinterpret_cast<const float*>(u16 + ((stg_b[2] + sp) * FST) * 2 + 8 * (lane & 7));
-    const float* gd = a.dy + (stg_b[2] + sph) * FST + 4 * (lane & 7);
+    int64_t b0, b1, b2;
+    if constexpr (SPLIT) { b0 = PARK[0][tid & 255]; b1 = PARK[1][tid & 255]; b2 = PARK[2][tid & 255]; }
+    else { b0 = stg_b[0]; b1 = stg_b[1]; b2 = stg_b[2]; }
+    // (the lane's column pieces go into the INDEX, through an opaque copy: `pointer + lane piece` is loop-invariant, and hipcc
+    //  would hoist that 64-bit per-lane sum out of the period loop -- into a register it then has to spill)
+    // (... and the lane id itself is re-derived from the execution mask by a volatile asm -- every lane is active here --, or the
+    //  invariant `lane & 7` would be the value that gets spilled)
+    int ln = lane;
+    if constexpr (SPLIT) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int l15 = ln & 15, l7 = ln & 7;
+    const float* gh0 = reinterpret_cast<const float*>(hs16 + (((b0 + sph) * LDH + (BI ? dir * H : 0)) * 2 + 8 * l15));
+    const float* gh1 = reinterpret_cast<const float*>(hs16 + (((b1 + sph) * LDH + (BI ? dir * H : 0)) * 2 + 8 * l15));
+    const float* gu = reinterpret_cast<const float*>(u16 + (((b2 + sp) * FST) * 2 + 8 * l7));
+    const float* gd = a.dy + ((b2 + sph) * FST + 4 * l7);
     char* lh = &SHP[sel][(8 * w) * SHROW];
     char* lu = &SUP[sel][(8 * w) * SUROW];
     char* ld = &SDY[sel][(8 * w) * SUROW];
     const bool whole = FULL || tile * 16 + 16 <= a.nseq;
+    // Round 6: every source address is complete BEFORE the first copy is issued.  Some of the per-lane 64-bit bases live in
+    // scratch in the register-starved instantiations (the cross-pass consumer: 111 spilled registers), a scratch reload is a
+    // vector-memory load, and hipcc waits for it with vmcnt(0): placed between two copies, that wait sat out the full latency of
+    // the copy issued just before it -- once per period (the phase table's "stage issue": 1 490 ticks for four instructions).
+    // `between` (the flush of this period's du rows, whose store address may be a third reload) runs HERE: after the copies'
+    // addresses are in registers -- so that nothing is reloaded behind its store or behind the copies -- and before the copies.
+#ifndef SB_EXP_NO_STAGE_PIN
+    asm volatile("" : "+v"(gh0), "+v"(gh1), "+v"(gu), "+v"(gd));
+#endif
+    between();
+#ifndef SB_EXP_NO_STAGE_PIN
+    asm volatile("" : "+v"(gh0), "+v"(gh1), "+v"(gu), "+v"(gd));
+#endif
     if (cnt && whole) {
       if constexpr (!HREC) {
         __builtin_amdgcn_global_load_lds(gh0, (__attribute__((address_space(3))) void*)(lh), 16, 0, 0);
@@ -895,7 +931,20 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
   float invS = 1.0f / gS;                          // gS is a power of two
   // du rows of a finished chunk (its R[buf] is complete after the barrier that followed it): wave w < 2 CK reduces
   // sub-tile sb = w / CK (step sa - sb), channel tile ct = w % CK
-  auto flush = [&](int sa, int nsteps_in_chunk, int buf, const float (&xq)[2], const float (&rq)[2]) {
+  // where this lane's du row of the chunk (sa, ..) goes (!LNB): computed -- and, where the base lives in scratch, reloaded -- at
+  // the TOP of the chunk role's second phase, in front of the next period's copies (see stage_issue)
+  auto flush_ptr = [&](int sa) -> float* {
+    if constexpr (LNB) return nullptr;
+    else {
+      const int sb = w / CK, ct = w % CK;
+      int64_t bb = base;
+      int qq = q;
+      if constexpr (STG && SPLIT) { bb = PARK[3][tid & 255]; asm volatile("" : "+v"(qq)); }      // (parked: see PARK; opaque: see stage_issue)
+      const int64_t pos = bb + (int64_t)st_of(sa - sb) * a.p_step;
+      return a.du + ((pos * ndir + dir) * FST + 16 * ct + 4 * qq);
+    }
+  };
+  auto flush = [&](int sa, int nsteps_in_chunk, int buf, const float (&xq)[2], const float (&rq)[2], float* dst = nullptr) {
     if constexpr (LNB) {
       const int sbf = w >> 1;
       if (sbf < nsteps_in_chunk) {
@@ -925,9 +974,9 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       if (w < 2 * CK && sb < nsteps_in_chunk && valid) {
         const f32x4 s4 = ld4(&R[buf][0][sb][ct][lane][0]) + ld4(&R[buf][1][sb][ct][lane][0]) +
                          ld4(&R[buf][2][sb][ct][lane][0]) + ld4(&R[buf][3][sb][ct][lane][0]);
-        const int64_t pos = base + (int64_t)st_of(sa - sb) * a.p_step;
-        if constexpr (PROD && !(SB_EXP_CONS & 2)) st4_sc1(a.du + (pos * ndir + dir) * FST + 16 * ct + 4 * q, s4 * invS);
-        else st4(a.du + (pos * ndir + dir) * FST + 16 * ct + 4 * q, s4 * invS);
+        float* const o = dst ? dst : flush_ptr(sa);
+        if constexpr (PROD && !(SB_EXP_CONS & 2)) st4_sc1(o, s4 * invS);
+        else st4(o, s4 * invS);
       }
     }
   };
@@ -1526,6 +1575,9 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     // ready the chunk wave should issue.  Same-box A/B (profiles/r06_ab_prio.txt): C = 32 (big) +1.2 .. +1.4 % on the train step
     // at priority 1, 2 or 3 alike; C = 16 (small) -1 % -- so only the C = 32 instantiations raise it.  -DSB_CHUNK_PRIO=n overrides
     // (n = 0: off) for every width.
+#ifdef SB_REC_PRIO
+    if (!crole) __builtin_amdgcn_s_setprio(SB_REC_PRIO);
+#endif
 #ifdef SB_CHUNK_PRIO
     if (crole && SB_CHUNK_PRIO > 0) __builtin_amdgcn_s_setprio(SB_CHUNK_PRIO);
 #else
@@ -1631,7 +1683,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       }
       if constexpr (SEG) { if (seg > 0) { if (!seg_wait(a.seg_flags, tile, seg, a.sched_status, SB_TRIP_BWD_SEGMENT)) return; } }
       if constexpr (LINW && !HREC) { if (s_hi == S - 1) lin_top(); }
-      if constexpr (STG) stage_issue(s_hi, s_hi - 1 >= s_lo, 1, tile);     // the first chunk's rows: read in period 1 (buffer 1)
+      if constexpr (STG) stage_issue(s_hi, s_hi - 1 >= s_lo, 1, tile, [] {});     // the first chunk's rows: read in period 1 (buffer 1)
       __syncthreads();
       if constexpr (LINW && HREC) lin_top();                               // h of walk index S - 1 is in the ring by now
       if constexpr (STG) __builtin_amdgcn_s_waitcnt(0);                    // the first chunk's rows have landed
@@ -1639,7 +1691,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       int s = s_hi;
       int slab_fill = 0, slab_idx = 0;                             // PROD: steps flushed into the current slab, its index
 #ifdef SB_PHASE_TIMING
-      unsigned long long cph[4] = {0, 0, 0, 0};
+      unsigned long long cph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
       for (int k = 1; k <= npairs; ++k, s -= 2) {                  // chunk of pair k - 1: steps (s, s - 1)
         SB_TICK(q0);
@@ -1657,11 +1709,34 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         SB_TICK(q1);
         __syncthreads();
         SB_TICK(q2);
+        // (round 6: the flush's du store address may be a scratch reload too: it runs INSIDE stage_issue, between the address
+        //  reloads and the copies -- behind the copies its vmcnt(0) waited for them to land, a second full memory latency per period)
+#ifndef SB_EXP_NO_STAGE_PIN
         if constexpr (STG) {
-          if (k < npairs) stage_issue(s - 2, s - 3 >= s_lo, (k + 1) & 1, tile);  // the next period's rows, a period ahead
+          if (k < npairs) stage_issue(s - 2, s - 3 >= s_lo, (k + 1) & 1, tile, [&] { flush(s, two ? 2 : 1, rb, ops2.xq, ops2.rq); });
+          else flush(s, two ? 2 : 1, rb, ops2.xq, ops2.rq);
+        } else flush(s, two ? 2 : 1, rb, ops2.xq, ops2.rq);
+#else
+        if constexpr (STG) {
+          if (k < npairs) stage_issue(s - 2, s - 3 >= s_lo, (k + 1) & 1, tile, [] {});  // the next period's rows, a period ahead
         }
+#endif
+#ifdef SB_PHASE_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        SB_TICK(qa);
+#ifdef SB_EXP_NO_STAGE_PIN
         flush(s, two ? 2 : 1, rb, ops2.xq, ops2.rq);
+#endif
+#ifdef SB_PHASE_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        SB_TICK(qb);
         chunk(2 * pb, rb, ops2, s, two, 1);
+#ifdef SB_PHASE_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        SB_TICK(qc);
         if constexpr (STG) __builtin_amdgcn_s_waitcnt(0);          // the next period's rows (issued at the top of this phase) have landed
         __builtin_amdgcn_sched_barrier(0);
         SB_TICK(q3);
@@ -1683,11 +1758,12 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
 #ifdef SB_PHASE_TIMING
         SB_TICK(q4);
         cph[0] += q1 - q0; cph[1] += q2 - q1; cph[2] += q3 - q2; cph[3] += q4 - q3;
+        cph[4] += qa - q2; cph[5] += qb - qa; cph[6] += qc - qb; cph[7] += q3 - qc;      // phase B split: stage issue, flush, dW chunk, wait for the staged rows
 #endif
       }
 #ifdef SB_PHASE_TIMING
       if (blockIdx.x == 0 && blockIdx.y == 0 && w == 0 && lane == 0 && item == (int)blockIdx.x)
-        for (int i = 0; i < 4; ++i) g_phase_bwd_split[i] = (float)cph[i] / npairs;
+        for (int i = 0; i < 8; ++i) g_phase_bwd_split[i] = (float)cph[i] / npairs;
 #endif
       if constexpr (SEG) { if (s_lo > 0) __syncthreads(); }        // (the recurrence role publishes its state)
       __syncthreads();                                             // between items
