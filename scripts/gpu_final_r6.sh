@@ -10,6 +10,10 @@ cp gpurun_out/pmc_traffic_small_wide.json profiles/r06_pmc_traffic_small_wide.js
 prof() { cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$1" -o k -- python "$R/bench.py" $2 --no-cpu-baseline --no-exact --no-parity > "$R/gpurun_out/prof_$1.log" 2>&1
   cd "$R"; f=$(find gpurun_out/prof_$1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r06_train_$1_kernel_stats.csv; }
 prof big_wide "--steps 3 --warmup 1 --workload big"
+prof small_wide "--steps 5 --warmup 2 --workload small"
+prof big_attn "--steps 3 --warmup 1 --workload big-attn"
+( timeout 300 python bench.py --workload big-attn --steps 10 --no-cpu-baseline --no-exact --no-parity 2>/dev/null | grep '^{' > gpurun_out/r06_bench_big_attn.jsonl )
+( timeout 300 python bench.py --workload big-attn --forward-only --steps 20 --no-cpu-baseline 2>/dev/null | grep '^{' >> gpurun_out/r06_bench_big_attn.jsonl )
 (time (timeout 1200 python bench.py 2>gpurun_out/r06_final_bench.err | grep '^{' > gpurun_out/r06_final_bench_lines.jsonl)) > gpurun_out/r06_final_bench_time.log 2>&1
 python - <<'PY'
 import json

@@ -20,12 +20,14 @@ namespace {
 //   in  [B, T, F, ldi] (head h, component d at column h*D + d; ldi >= Hh*D); prelu_a (nullable): PReLU applied on load
 //   out row (b*Hh + h, t_off + t) of a [B*Hh, rows, ldo] matrix, element f*D + d; columns [F*D, ldo) zeroed
 //   res (nullable, Hh == 1 only): out = res[b,t,:] + LN(...)
+template <int MAXV>
 __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ in, const float* __restrict__ gam,
                                                       const float* __restrict__ bet, float* __restrict__ out,
                                                       const float* __restrict__ res, int B, int T, int F, int Hh, int D,
                                                       int rows, int t_off, int ldo, int ldi,
                                                       const float* __restrict__ prelu_a) {
-  constexpr int MAXV = 20;                       // F*Hh*D <= 256*MAXV  (145*32 = 4640 fits)
+  // F*Hh*D <= 256*MAXV (145*32 = 4640 needs 20; the Q / K heads, 145*4*2 = 1160, need 5: round 6 instantiates 5 / 10 / 20 --
+  // the fully unrolled, masked slot loops cost their instructions whether a slot holds an element or not)
   const int bt = blockIdx.x, b = bt / T, t = bt % T;
   const int n = F * Hh * D, HD = Hh * D, FD = F * D;
   const float* x = in + (size_t)bt * F * ldi;
@@ -208,12 +210,13 @@ __global__ __launch_bounds__(256) void attn_core_kernel(sb_attn_args a) {
 //   dout: head-major rows as written by the forward (row (b*Hh+h, t_off+t) of [B*Hh, rows, ldo]);  din [B,T,F,ldi]
 // Thread mapping: thread = (frequency lane tid / HD, column hd = tid % HD), so a thread's head is fixed and the
 // per-head statistics are scalars (Hh masked wave reductions + one LDS exchange per statistic pair).
+template <int MAXV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void head_ln_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gam,
                                                           const float* __restrict__ dout, float* __restrict__ din,
                                                           float* __restrict__ partials, int B, int T, int F, int Hh,
                                                           int D, int rows, int t_off, int ldo, int ldi,
                                                           const float* __restrict__ prelu_a, int rpb) {
-  constexpr int MAXV = 20;                       // ceil(F / (256 / (Hh*D))) <= MAXV
+  // ceil(F / (256 / (Hh*D))) <= MAXV (instantiated for 5 / 10 / 20: see head_ln_kernel)
   const int HD = Hh * D, n = F * HD;
   const float invFD = 1.0f / (F * D);
   const float pa = prelu_a ? prelu_a[0] : 1.0f;
@@ -413,8 +416,11 @@ extern "C" int sb_head_ln(const float* in, const float* gamma, const float* beta
                           int T, int F, int Hh, int D, int rows, int t_off, int ldo, int ldi, const float* prelu_a,
                           void* stream) {
   if (Hh > 8 || F * Hh * D > 256 * 20 || (res && Hh != 1) || ldi < Hh * D) return -1002;
-  hipLaunchKernelGGL(head_ln_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, in, gamma, beta, out, res, B, T, F,
-                     Hh, D, rows, t_off, ldo, ldi, prelu_a);
+  const int need = (F * Hh * D + 255) / 256;
+#define SB_HL(M_) hipLaunchKernelGGL(head_ln_kernel<M_>, dim3(B * T), dim3(256), 0, (hipStream_t)stream, in, gamma, beta, out, res, B, T, F, \
+                                     Hh, D, rows, t_off, ldo, ldi, prelu_a)
+  if (need <= 5) SB_HL(5); else if (need <= 10) SB_HL(10); else SB_HL(20);
+#undef SB_HL
   SB_CHECK_LAUNCH();
   return 0;
 }
@@ -426,9 +432,12 @@ extern "C" int sb_head_ln_bwd(const float* in, const float* gamma, const float* 
                               int T, int F, int Hh, int D, int rows, int t_off, int ldo, int ldi, const float* prelu_a,
                               void* stream) {
   if (Hh > 8 || Hh * D > 256 || ldi < Hh * D) return -1002;
-  if ((F + 256 / (Hh * D) - 1) / (256 / (Hh * D)) > 20) return -1002;
-  hipLaunchKernelGGL(head_ln_bwd_kernel, dim3(sb_head_ln_bwd_grid(B, T)), dim3(256), 0, (hipStream_t)stream, in, gamma,
-                     dout, din, partials, B, T, F, Hh, D, rows, t_off, ldo, ldi, prelu_a, kHeadLnBwdRows);
+  const int need = (F + 256 / (Hh * D) - 1) / (256 / (Hh * D));
+  if (need > 20) return -1002;
+#define SB_HB(M_) hipLaunchKernelGGL(head_ln_bwd_kernel<M_>, dim3(sb_head_ln_bwd_grid(B, T)), dim3(256), 0, (hipStream_t)stream, in, gamma, \
+                                     dout, din, partials, B, T, F, Hh, D, rows, t_off, ldo, ldi, prelu_a, kHeadLnBwdRows)
+  if (need <= 5) SB_HB(5); else if (need <= 10) SB_HB(10); else SB_HB(20);
+#undef SB_HB
   SB_CHECK_LAUNCH();
   return 0;
 }

@@ -610,7 +610,9 @@ class AttentionFn(torch.autograd.Function):
             wpad[:n_out] = w
             bpad = torch.zeros(npad, device=dev, dtype=torch.float32)
             bpad[:n_out] = b
-            out = torch.zeros(P, npad, device=dev, dtype=torch.float32)
+            out = torch.empty(P, npad, device=dev, dtype=torch.float32)       # (the GEMM writes columns < n_out of every row)
+            if npad > n_out:
+                out[:, n_out:].zero_()
             ops.linear(x, wpad, bpad, out, gP, sC, (0, 0, npad), Cc, npad, n_valid=n_out)
             return out, npad
 
@@ -619,10 +621,16 @@ class AttentionFn(torch.autograd.Function):
         rows = Lw - 1 + T
         BH = B * n_head
         Qn = torch.empty(BH, T, ldk, device=dev, dtype=torch.float32)
-        Kc = torch.zeros(BH, rows, ldk, device=dev, dtype=torch.float32)
-        Vc = torch.zeros(BH, rows, ldv, device=dev, dtype=torch.float32)
+        # (rows Lw - 1 .. are written whole -- padding columns included -- by sb_head_ln below: only the carried rows' padding
+        #  needs zeroing, not 216 MB of V window per block)
+        Kc = torch.empty(BH, rows, ldk, device=dev, dtype=torch.float32)
+        Vc = torch.empty(BH, rows, ldv, device=dev, dtype=torch.float32)
         Kc[:, : Lw - 1, : F * E] = K_buf
         Vc[:, : Lw - 1, : F * Cv] = V_buf
+        if ldk > F * E:
+            Kc[:, : Lw - 1, F * E:].zero_()
+        if ldv > F * Cv:
+            Vc[:, : Lw - 1, F * Cv:].zero_()
         pq, ldq = proj(wq, bq, HE)
         pk, _ = proj(wk, bk, HE)
         pv, ldvp = proj(wv, bv, Cc)
@@ -666,7 +674,9 @@ class AttentionFn(torch.autograd.Function):
         dO = torch.empty(P, Cc, device=dev, dtype=torch.float32)
         ops.linear(dpp, wp.t().contiguous(), None, dO, gP, sC, sC, Cc, Cc)
         # head-major, zero-padded copy of dO (layout glue), then the attention core
-        dOh = torch.zeros(BH, T, ldv, device=dev, dtype=torch.float32)
+        dOh = torch.empty(BH, T, ldv, device=dev, dtype=torch.float32)
+        if ldv > F * Cv:
+            dOh[:, :, F * Cv:].zero_()
         dOh[:, :, : F * Cv] = dO.view(B, T, F, n_head, Cv).permute(0, 3, 1, 2, 4).reshape(BH, T, F * Cv)
         dQn, dKn, dVn = ops.attn_core_bwd(Qn, Kc, Vc, dOh, lse, BH, n_head, T, F, Cv, Lw, ldk, ldv, scale)
         # per-head LayerNorms + PReLUs of the three projections

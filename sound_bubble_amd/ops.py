@@ -1912,7 +1912,9 @@ def head_ln_bwd(x, gamma, dout, B, T, F, Hh, D, rows, t_off, ldo, ldi, prelu_a=N
     """-> (din [B*T*F, ldi] (columns beyond Hh*D zero), dgamma [F*D], dbeta [F*D], dalpha [1])"""
     lib = L.load()
     n = F * Hh * D
-    din = torch.zeros(B * T * F, ldi, device=x.device, dtype=torch.float32)
+    din = torch.empty(B * T * F, ldi, device=x.device, dtype=torch.float32)      # (the kernel writes columns < Hh*D of every row)
+    if ldi > Hh * D:
+        din[:, Hh * D:].zero_()
     part = torch.empty(lib.sb_head_ln_bwd_grid(B, T), 2 * n + 1, device=x.device, dtype=torch.float32)
     L.check(lib.sb_head_ln_bwd(_p(x), _p(gamma), _p(dout), _p(din), _p(part), B, T, F, Hh, D, rows, t_off, ldo, ldi,
                                _p(prelu_a), _stream()), "sb_head_ln_bwd")
