@@ -127,3 +127,34 @@ def test_constructor_defaults_behave_as_the_reference(torch_mod):
     from sound_bubble_amd import _lib
     lib = _lib.load()
     assert lib.sb_lstm_gen_supported(64, 128) == 1 and lib.sb_lstm_gen_supported(64, 96) == 0
+
+
+def test_wgrad_scratch_rows_says_which_form_serves_a_shape():
+    """sb_wgrad_scratch_rows is pure host code: shapes with a register-accumulator kernel take 4 rows per workgroup of
+    sb_wgrad_grid(P); every other shape takes the generic tiled form's (much smaller) count; bad arguments come back as the
+    status sb_wgrad itself would return."""
+    import ctypes as C
+    from sound_bubble_amd import _lib
+    lib = _lib.load()
+    a = _lib.WgradArgs()
+    a.B, a.T, a.F, a.N, a.K, a.kseg = 1, 1, 100000, 32, 64, 64            # Linear(64 -> 32): tuned (NTW 2, KT1 4)
+    a.ldg, a.is_f, a.seg_len = 32, 64, 100000
+    assert lib.sb_wgrad_scratch_rows(C.byref(a)) == 4 * lib.sb_wgrad_grid(100000)
+    a.N, a.K, a.K2, a.ldg, a.ld2 = 512, 64, 128, 1024, 256                 # the H = 128 LSTM gradients: generic
+    rows = lib.sb_wgrad_scratch_rows(C.byref(a))
+    assert 0 < rows <= 256 and rows < 4 * lib.sb_wgrad_grid(100000)
+    a.K2 = 100                                                              # second source not a multiple of 16
+    assert lib.sb_wgrad_scratch_rows(C.byref(a)) == -1002
+    a.K2, a.B = 128, 0
+    assert lib.sb_wgrad_scratch_rows(C.byref(a)) == -1001
+
+
+def test_kernel_source_digest_is_stable_and_sensitive(tmp_path):
+    """the stamp of the committed counter profiles (sound_bubble_amd.build.csrc_digest): same tree -> same digest; the committed
+    round-6 summaries carry one"""
+    import json
+    from sound_bubble_amd.build import csrc_digest
+    d = csrc_digest()
+    assert d == csrc_digest() and len(d) == 16
+    prov = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic_big_wide.json")))["provenance"]
+    assert len(prov["csrc_sha16"]) == 16
