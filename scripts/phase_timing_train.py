@@ -4,8 +4,8 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from sound_bubble_amd import _lib as L, ops
-if os.environ.get("SB_LIB_VARIANT"):          # an instrumented build made here (scripts/build_variant.py phase -DSB_PHASE_TIMING)
-    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "exp", f"lib_{os.environ['SB_LIB_VARIANT']}.so")
+# (SB_LIB_VARIANT=phase: an instrumented build made beforehand by `scripts/build_variant.py phase -DSB_PHASE_TIMING` -- _lib.py
+#  resolves the variant's path itself)
 lib = ctypes.CDLL(L.LIB_PATH)
 KINDS = ["plain", "fused Linear", "summed input + fused Linear (inter-frame producer)", "ordered consumer (intra-frame)",
          "bidirectional partial-Linear (intra-frame, first block)"]
@@ -35,3 +35,10 @@ for wl in ("big", "small"):
                 print(f"{wl} / train, {mode}: chunk role of the last role-split backward launch, ticks per period: work before hand-over "
                       f"{b[0]:.0f}, wait {b[1]:.0f}, work after {b[2]:.0f}, wait at second barrier {b[3]:.0f}  (sum {sum(b[:4]):.0f}); "
                       f"work after = stage issue {b[4]:.0f} + flush {b[5]:.0f} + dW chunk {b[6]:.0f} + wait for the staged rows {b[7]:.0f}")
+            r = (ctypes.c_float * 24)()
+            if hasattr(lib, "sb_debug_phase_bwd_rec") and lib.sb_debug_phase_bwd_rec(r) == 0 and sum(r) > 0:
+                for w in range(4):
+                    v = r[6 * w:6 * w + 6]
+                    print(f"    recurrence role, wave {w}, ticks per step: wait for the records {v[0]:.0f}  next records' loads {v[1]:.0f}  "
+                          f"gates + dgates {v[2]:.0f}  LDS dgates + MFMA {v[3]:.0f}  partial sums out {v[4]:.0f}  barrier + reduction {v[5]:.0f}   "
+                          f"sum {sum(v):.0f}")

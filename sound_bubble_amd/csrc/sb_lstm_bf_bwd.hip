@@ -10,6 +10,12 @@
 // chunk role of the role-split backward (wave 4 of workgroup 0): ticks per period of [work before the hand-over barrier, wait
 // at it, work after it, wait at the second barrier]; read with sb_debug_phase_bwd_split()
 __device__ float g_phase_bwd_split[8];
+// ... and of the recurrence role's four waves, ticks per STEP: [wait for this step's records, issue of the next records' loads,
+// records consumed .. dgates formed, LDS dgates + MFMA, partial sums out, barrier + reduction]; read with sb_debug_phase_bwd_rec()
+__device__ float g_phase_bwd_rec[4][6];
+extern "C" int sb_debug_phase_bwd_rec(float* host_out) {
+  return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_bwd_rec), sizeof(g_phase_bwd_rec));
+}
 extern "C" int sb_debug_phase_bwd_split(float* host_out) {
   return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_bwd_split), sizeof(g_phase_bwd_split));
 }
@@ -26,6 +32,41 @@ namespace {
 // 16x16x32 tile per wave with a 2-term split (hi, lo) -- it enters the recurrence additively, un-amplified.
 // DG16: dgates leave as fp16 of S * dgates, S = 2^-ceil(log2 max|incoming gradient|) (see sb_lstm_bwd_args.gmax): the
 // recurrence is linear in the incoming gradient, so scaling it once at the entry scales everything consistently.
+// {(fp16) fma((float) h[0], m, c0), (fp16) fma((float) h[1], m, c1)} of a packed fp16 pair h: one v_fma_mixlo_f16 / v_fma_mixhi_f16
+// each -- the fp16 -> fp32 conversion of h, the fp32 fma and the rounding of its result to fp16 in ONE instruction (what hipcc
+// emits for the scalar expression; after its SLP pass packed the fp32 halves it wrote two conversions, a v_pk_fma_f32 and a
+// v_cvt_pk instead: two instructions more per pair, ~28 a step in the recurrence role, whose own instruction stream is what
+// bounds the role-split kernels).  -DSB_FMA_MIX=0: the plain expressions.
+#ifndef SB_FMA_MIX
+#define SB_FMA_MIX 1
+#endif
+SB_DEVINL unsigned mix_pair(unsigned h, float m, float c0, float c1) {
+#if SB_FMA_MIX
+  unsigned d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "s"(m), "v"(c0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h), "s"(m), "v"(c1));
+  return d;
+#else
+  const h16x2 hv = __builtin_bit_cast(h16x2, h);
+  const h16x2 r = {(_Float16)__builtin_fmaf((float)hv[0], m, c0), (_Float16)__builtin_fmaf((float)hv[1], m, c1)};
+  return __builtin_bit_cast(unsigned, r);
+#endif
+}
+// lo terms of 8 values v with their fp16 heads hi: (fp16)(s v[k] - s (float) hi[k])
+SB_DEVINL h16x8 mix_lo8(const h16x8 hi, const float (&v)[8], float s) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 hp = __builtin_bit_cast(u32x4, hi);
+  u32x4 d;
+#pragma unroll
+  for (int p2 = 0; p2 < 4; ++p2) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 c = f32x2{v[2 * p2], v[2 * p2 + 1]} * s;       // (one packed multiply: pinned as a pair, or hipcc splits it for the asm operands)
+    asm("" : "+v"(c));
+    d[p2] = mix_pair(hp[p2], -s, c[0], c[1]);
+  }
+  return __builtin_bit_cast(h16x8, d);
+}
+
 SB_DEVINL float grad_scale(const float* gmax) {
   const float m = gmax[0];
   return (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f;
@@ -40,6 +81,12 @@ SB_DEVINL float grad_scale(const float* gmax) {
 // end) and into du = W_ih^T dgates (partial sums over the four waves through LDS, stored one step later).  u and
 // h_prev arrive as the fp16 side outputs of the forward kernel.  Saves the 512 B/position dgates round trip (the
 // store alone was 17-45 % of this kernel) and the whole streaming launch.
+#ifndef SB_TR_DGATES
+#define SB_TR_DGATES 1     // 0: row-major LDS reads + register shuffles for the chunk role's dgates fragments (rounds 3-5)
+#endif
+#ifndef SB_EXP_IDX64
+#define SB_EXP_IDX64 0      // 1: the 64-bit record / dy index arithmetic of rounds 3-5 (A/B switch)
+#endif
 constexpr int DGP = 260;      // halves per dgates row in LDS (520 B: the four position groups of a load hit distinct banks)
 // LNB (FST == 16): the LayerNorm backward of the block runs in the flush of the du rows (one wave holds all 16 channels
 // of its 16 positions), dx = LN-backward(du) + dy goes out instead of du.
@@ -376,7 +423,10 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
   };
   const int uoff = 16 * w + 4 * q;
 
-  float gS = DG16 ? grad_scale(a.gmax) : 1.0f;       // (CONS: re-derived per tile by the prologue)
+  // (uniform values, kept in scalar registers: as per-lane values the compiler holds them -- and {x, x} pairs for the packed
+  //  multiplies -- in vector registers through the period loops, where the role-split kernels have none to spare)
+  auto uniform_f = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+  float gS = DG16 ? uniform_f(grad_scale(a.gmax)) : 1.0f;       // (CONS: re-derived per tile by the prologue)
   // W_lin^T tile of this wave's units (FUSE): A[i = unit 16w + j][k = channel 8q + kk], 2-term split
   bf16x8 Lh, Ll;
   h16x8 Lxh, Lxl;                                   // XP: fp16 hi + lo of the UNSCALED weights (dy carries the scale)
@@ -428,6 +478,9 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
   // XP: u is the forward kernel's fp16 (hi, lo) pair tensor; so is hs when the Linear was applied in the forward kernel
   // (HSP: every form with the fused Linear backward), else hs is fp32 (the conv-LSTM flavour, whose ConvTranspose reads it)
   constexpr bool HSP = XP && FUSE_C > 0;
+  // TRA: the chunk's dgates A fragments come from transposing LDS reads; M-tile nt of wave w then covers gate columns
+  // 64 w + 16 nt + (0 .. 15) instead of 64 w + 4 (0 .. 15) + nt (the write-out below follows)
+  constexpr bool TRA = XP && SB_TR_DGATES;
   constexpr bool H32 = (XP && !HSP) || (BI && !HS16B && !XP);   // hs as fp32 rows
   struct PairOps { h16x4 hh4[H32 || HSP ? 1 : 8]; f32x4 hh32[H32 ? 8 : 1]; h16x2 uh2[CK == 2 && !XP ? 8 : 1]; _Float16 uh1[CK == 2 || XP ? 1 : 8];
                    h16x8 hp8[HSP ? 8 : 1];                    // XP + HSP: h_prev units 4j .. 4j + 3 as (hi x 4, lo x 4)
@@ -582,12 +635,37 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       };
       // dgates of this lane's 8 k-slots, gate columns 64w + 4j .. + 3: hi and scaled low terms
       auto build_A = [&](h16x8 (&Aoh)[4], h16x8 (&Aol)[4]) __attribute__((always_inline)) {
+        if constexpr (TRA) {
+          // transposing LDS reads (ds_read_b64_tr_b16, gfx950): a 16-lane group fetches a [4 rows][16 columns] block as 8-byte row
+          // pieces (lane i: row i >> 2, columns 4 (i & 3) .. + 3) and lane c receives COLUMN c of it -- the A fragment itself.
+          // Row-major reads + the 4 x 8 -> 8 x 4 shuffle in registers were 32 v_perm_b32 per call, two calls a period.
+          // (role-split kernels: the lane id is re-derived from the execution mask -- every lane is active here -- by a volatile
+          //  asm, or the loop-invariant per-lane address pieces are hoisted out of the period loop into registers that spill: see
+          //  stage_issue)
+          int ln = lane;
+          if constexpr (SPLIT) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+          const int i16 = ln & 15, qq = ln >> 4;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int row = 8 * (qq & 1) + 4 * hf + (i16 >> 2), col = 64 * w + 16 * nt + 4 * (i16 & 3);
+              const s16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4*)(&DG[sl + (qq >> 1)][row][col]));
+              const s16x4 vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4*)(&DGL[sl + (qq >> 1)][row][col]));
+              const h16x4 fh = __builtin_bit_cast(h16x4, vh), fl = __builtin_bit_cast(h16x4, vl);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { Aoh[nt][4 * hf + r] = fh[r]; Aol[nt][4 * hf + r] = fl[r]; }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const h16x4 th = *reinterpret_cast<const h16x4*>(&DG[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
           const h16x4 tl = *reinterpret_cast<const h16x4*>(&DGL[sl + (q >> 1)][8 * (q & 1) + kk][64 * w + 4 * j]);
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) { Aoh[nt][kk] = th[nt]; Aol[nt][kk] = tl[nt]; }
+        }
         }
       };
       auto col_sums = [&](const h16x8 (&Aoh)[4], const h16x8 (&Aol)[4]) __attribute__((always_inline)) {
@@ -928,7 +1006,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     }
     }
   };
-  float invS = 1.0f / gS;                          // gS is a power of two
+  float invS = uniform_f(1.0f / gS);               // gS is a power of two
   // du rows of a finished chunk (its R[buf] is complete after the barrier that followed it): wave w < 2 CK reduces
   // sub-tile sb = w / CK (step sa - sb), channel tile ct = w % CK
   // where this lane's du row of the chunk (sa, ..) goes (!LNB): computed -- and, where the base lives in scratch, reloaded -- at
@@ -939,7 +1017,12 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       const int sb = w / CK, ct = w % CK;
       int64_t bb = base;
       int qq = q;
-      if constexpr (STG && SPLIT) { bb = PARK[3][tid & 255]; asm volatile("" : "+v"(qq)); }      // (parked: see PARK; opaque: see stage_issue)
+      if constexpr (STG && SPLIT) {                  // (parked: see PARK; the lane's row re-derived, not kept: see stage_issue)
+        bb = PARK[3][tid & 255];
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        qq = ln >> 4;
+      }
       const int64_t pos = bb + (int64_t)st_of(sa - sb) * a.p_step;
       return a.du + ((pos * ndir + dir) * FST + 16 * ct + 4 * qq);
     }
@@ -1010,7 +1093,11 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         r.r2 = r.r3 = r.cp = zero4();
         r.cp16 = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(a.save_c) + blk * (16 * H) + (w * 64 + lane) * 4);
       } else if constexpr (XP) {           // blocked fp32 records of the forward kernel's SAVE == 4
-        const int64_t blk = (rec_tile + st) * ndir + dir;
+        // (FST > 0: block and position indices in 32 bits -- the fused launchers check nseq nsteps < 2^31 -- and ONE widening
+        //  multiply per pointer: the 64-bit index arithmetic was ~25 scalar instructions of the recurrence role's step)
+        typedef std::conditional_t<(FST > 0 && !SB_EXP_IDX64), unsigned, int64_t> blk_t;
+        const blk_t blk = (FST > 0 && !SB_EXP_IDX64) ? (blk_t)(((unsigned)rec_tile + (unsigned)st) * (unsigned)ndir + (unsigned)dir)
+                                    : (blk_t)((rec_tile + st) * ndir + dir);
         if constexpr (GREC) {              // no gate records: the operands of their recomputation instead
           r.r0 = r.r1 = r.r2 = r.r3 = zero4();
           const float* up = reinterpret_cast<const float*>(u16 + (pos * FUSE_C + 8 * q) * 2);
@@ -1020,21 +1107,22 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
           r.gh[0] = ld4(hp); r.gh[1] = ld4(hp + 4); r.gh[2] = ld4(hp + 32); r.gh[3] = ld4(hp + 36);
         } else {
 #if SB_REC_Q24
-          const float* rec = a.save_gates + blk * (16 * kWideGateDwords) + (w * 192 + lane) * 4;      // three packed pieces (sb_lstm_bf_common.h)
+          const float* rec = a.save_gates + (size_t)blk * (16 * kWideGateDwords) + (w * 192 + lane) * 4;      // three packed pieces (sb_lstm_bf_common.h)
           r.r0 = ld4_rec(rec); r.r1 = ld4_rec(rec + 256); r.r2 = ld4_rec(rec + 512); r.r3 = zero4();
 #else
-          const float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
+          const float* rec = a.save_gates + (size_t)blk * (16 * 4 * H) + (w * 256 + lane) * 4;
           r.r0 = ld4_rec(rec); r.r1 = ld4_rec(rec + 256); r.r2 = ld4_rec(rec + 512); r.r3 = ld4_rec(rec + 768);
 #endif
         }
-        r.cp = ld4_rec(a.save_c + blk * (16 * H) + (w * 64 + lane) * 4);
+        r.cp = ld4_rec(a.save_c + (size_t)blk * (16 * H) + (w * 64 + lane) * 4);
       } else {
         const float* rec = a.save_gates + (pos * ndir + dir) * (5 * H) + uoff;
         r.r0 = ld4(rec); r.r1 = ld4(rec + H); r.r2 = ld4(rec + 2 * H); r.r3 = ld4(rec + 3 * H); r.cp = ld4(rec + 4 * H);
       }
       if constexpr (FUSE_C > 0) {          // dy[pos][8q .. 8q+7] (channels beyond C are zero)
         const bool okc = 8 * q < FUSE_C;
-        const float* dyp = a.dy + pos * FUSE_C + (okc ? 8 * q : 0);
+        const float* dyp = (XP && !SB_EXP_IDX64) ? a.dy + (size_t)((unsigned)base + (unsigned)st * (unsigned)a.p_step) * FUSE_C + (okc ? 8 * q : 0)
+                              : a.dy + pos * FUSE_C + (okc ? 8 * q : 0);
         const f32x4 d0 = ld4(dyp), d1 = ld4(dyp + 4);
         r.dh = okc ? d0 : zero4();
         r.dy1 = okc ? d1 : zero4();
@@ -1054,6 +1142,8 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
   f32x4 dc = zero4(), dhrec = zero4();
 #ifdef SB_PHASE_TIMING
   unsigned long long tph[5] = {0, 0, 0, 0, 0};
+  unsigned tph_n = 0;
+  unsigned long long tpc[2] = {0, 0};
 #endif
   // Records are fetched TWO steps ahead: along the inter-frame walk consecutive steps are F positions (tens of KB,
   // a new page) apart and the measured load-to-use latency there exceeds one step.  The loop body covers a PAIR of
@@ -1183,13 +1273,13 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     if constexpr (DG16 && FUSE_C == 0) dhext *= gS;
     if constexpr (FUSE_C > 0 && XP) {
       h16x8 bh, bl;
+      float dv[8];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        const float v = (kk < 4 ? raw.dh[kk] : raw.dy1[kk - 4]) * gS;
-        const _Float16 hh = (_Float16)v;
-        bh[kk] = hh;
-        bl[kk] = (_Float16)__builtin_fmaf((float)hh, -kLoUp, v * kLoUp);
+        dv[kk] = (kk < 4 ? raw.dh[kk] : raw.dy1[kk - 4]) * gS;
+        bh[kk] = (_Float16)dv[kk];
       }
+      bl = mix_lo8(bh, dv, kLoUp);
       const f32x4 dxl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxh, bl, zero4(), 0, 0, 0);
       dhext = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxl, bh, zero4(), 0, 0, 0);
       dhext = __builtin_amdgcn_mfma_f32_16x16x32_f16(Lxh, bh, dhext, 0, 0, 0);
@@ -1235,10 +1325,8 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       for (int kk = 0; kk < 8; ++kk) t[kk] = dG[2 * c + (kk >> 2)][kk & 3];
       if constexpr (DG16) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          Bh[c][kk] = (_Float16)t[kk];
-          if constexpr (XP) Bl[c][kk] = (_Float16)__builtin_fmaf((float)Bh[c][kk], -kLoUp, t[kk] * kLoUp);
-        }
+        for (int kk = 0; kk < 8; ++kk) Bh[c][kk] = (_Float16)t[kk];
+        if constexpr (XP) Bl[c] = mix_lo8(Bh[c], t, kLoUp);
       } else {
         Bop[c] = split8(t);
       }
@@ -1260,14 +1348,12 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         }
       }
       if constexpr (HREC) {                            // (hi x 4, lo x 4) of units 16w + 4q .. + 3: the forward kernel's hs pair
-        h16x8 hp8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const _Float16 hh = (_Float16)hrow[r];
-          hp8[r] = hh;
-          hp8[4 + r] = (_Float16)(hrow[r] - (float)hh);
-        }
-        *reinterpret_cast<h16x8*>(hring(s, j) + 16 * (4 * w + q)) = hp8;
+        const h16x4 hh4 = {(_Float16)hrow[0], (_Float16)hrow[1], (_Float16)hrow[2], (_Float16)hrow[3]};
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x2 hi2 = __builtin_bit_cast(u32x2, hh4);
+        const u32x4 hp8 = {hi2[0], hi2[1], mix_pair(hi2[0], -1.0f, hrow[0], hrow[1]), mix_pair(hi2[1], -1.0f, hrow[2], hrow[3])};
+        *reinterpret_cast<u32x4*>(hring(s, j) + 16 * (4 * w + q)) = hp8;
       }
     } else if constexpr (SLAB) {
 #pragma unroll
@@ -1357,6 +1443,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     asm volatile("" : "+v"(dhrec));
     SB_TICK(c5);
     tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4;
+    ++tph_n;
 #endif
   };
   const int ntiles = (a.nseq + 15) / 16;
@@ -1519,7 +1606,7 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f)));
     const float ratio = Sn * invS;                   // a power of two: the running sums move to the new scale exactly
     gS = Sn;
-    invS = 1.0f / Sn;
+    invS = uniform_f(1.0f / Sn);
     if constexpr (FST > 0 && kChunkRole) {
       if (ratio != 1.0f) {
 #pragma unroll
@@ -1619,14 +1706,20 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         int s = s_hi;
         for (int k = 0; k < npairs; ++k, s -= 2) {
           Raw curA = nxt;
+          SB_TICK(p0);
           consume(curA);
           __builtin_amdgcn_sched_barrier(0);
+          SB_TICK(p1);
 #if SB_SPLIT_LOOK == 2
           nxt = load_raw(max(s - 2, 0));
 #else
           nxt = load_raw(max(s - 1, 0));
 #endif
           __builtin_amdgcn_sched_barrier(0);
+#ifdef SB_PHASE_TIMING
+          SB_TICK(p2);
+          tpc[0] += p1 - p0; tpc[1] += p2 - p1;
+#endif
           step(s, curA, 2 * (k & 1));
           if (s - 1 >= s_lo) {
 #if SB_SPLIT_LOOK == 2
@@ -1669,6 +1762,14 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
         }
         __syncthreads();                                           // between items
       }
+#ifdef SB_PHASE_TIMING
+      if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && tph_n > 0)
+      {
+        // (the first step of a pair is the timed one for the two leading columns: per pair -> per step as measured)
+        g_phase_bwd_rec[w][0] = (float)tpc[0] * 2 / tph_n; g_phase_bwd_rec[w][1] = (float)tpc[1] * 2 / tph_n;
+        for (int i = 0; i < 4; ++i) g_phase_bwd_rec[w][2 + i] = (float)tph[i + 1] / tph_n;
+      }
+#endif
       if constexpr (!CONS) return;                                 // (CONS: the LayerNorm partial sums of this role's threads follow)
     } else
     for (int item = CONS ? ord_first : (int)blockIdx.x; item < nitems; item = CONS ? ord_next() : item + (int)gridDim.x) {
@@ -1885,14 +1986,14 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gate = 64 * w + 4 * (4 * q + r) + nt;
+        const int gate = TRA ? 64 * w + 16 * nt + 4 * q + r : 64 * w + 4 * (4 * q + r) + nt;
 #pragma unroll
         for (int kt = 0; kt < CK; ++kt) part[(size_t)gate * Ktot + (CK == 2 ? 2 * j + kt : j)] = wacc[nt][kt][r] * invS;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) part[(size_t)gate * Ktot + FST + 4 * j + kt] = wacc[nt][CK + kt][r] * invS;
       }
       const float cs = quad_sum(XP ? __builtin_fmaf(csumx[nt], kLoDn, csum[nt]) : csum[nt]);
-      if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + 4 * j + nt] = cs * invS;
+      if (q == 0) part[(size_t)4 * H * Ktot + 64 * w + (TRA ? 16 * nt + j : 4 * j + nt)] = cs * invS;
     }
     float* plin = part + (size_t)4 * H * Ktot + 4 * H;           // [C][64] dW_lin, then [C] db_lin
     if constexpr (LINW)

@@ -50,6 +50,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));      // what the transposing LDS read builtin returns
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 // Wide BPTT gate records (sb_lstm_fwd_args.rec_f32) as 24-BIT FIXED POINT (round 5): the four post-activation gates of a unit lie in
