@@ -514,10 +514,15 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
     const int sw = (q >> 1) == 0 ? sa : (two ? sa - 1 : sa);
     const bool hp = sw > 0;                        // h_prev of the first step is the (zero) initial state: masked in chunk()
     const int st = st_of(sw), sth = st_of(hp ? sw - 1 : sw);
+    // positions in 32 bits (the fused launchers check nseq nsteps < 2^31): one add per position and a widening shift per address --
+    // as 64-bit sums these 28 addresses were ~100 vector instructions a period, a quarter of the chunk role's arithmetic in the
+    // C = 16 kernels, where the chunk role sets the pace
+    typedef std::conditional_t<SB_EXP_IDX64 != 0, int64_t, size_t> pidx_t;
+    const unsigned ps = (unsigned)st * (unsigned)a.p_step, psh = (unsigned)sth * (unsigned)a.p_step;      // uniform
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const int64_t pos = (int64_t)posb[kk] + (int64_t)st * a.p_step;
-      const int64_t posh = (int64_t)posb[kk] + (int64_t)sth * a.p_step;
+      const pidx_t pos = SB_EXP_IDX64 ? (pidx_t)((int64_t)posb[kk] + (int64_t)st * a.p_step) : (pidx_t)((unsigned)posb[kk] + ps);
+      const pidx_t posh = SB_EXP_IDX64 ? (pidx_t)((int64_t)posb[kk] + (int64_t)sth * a.p_step) : (pidx_t)((unsigned)posb[kk] + psh);
       if constexpr (HSP) o.hp8[kk] = *reinterpret_cast<const h16x8*>(hs16 + (posh * LDH + (BI ? dir * H : 0) + 4 * j) * 2);
       else if constexpr (H32) o.hh32[kk] = ld4(hs32 + posh * LDH + 4 * j);
       else if constexpr (BI) o.hh4[kk] = *reinterpret_cast<const h16x4*>(hs16 + posh * (2 * H) + dir * H + 4 * j);
@@ -537,7 +542,8 @@ __global__ __launch_bounds__((KF & K_SPLIT) ? 512 : 256) void lstm_bwd_rec_bf_ke
       const int stf = sa - ((w >> 1) && two ? 1 : 0);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int64_t posf = (int64_t)posq[r] + (int64_t)stf * a.p_step;
+        const pidx_t posf = SB_EXP_IDX64 ? (pidx_t)((int64_t)posq[r] + (int64_t)stf * a.p_step)
+                                         : (pidx_t)((unsigned)posq[r] + (unsigned)stf * (unsigned)a.p_step);
         o.xq[r] = a.ln_x[posf * FST + j];
         o.rq[r] = a.dy[posf * FST + j];
       }
