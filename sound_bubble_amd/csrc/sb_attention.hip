@@ -20,7 +20,7 @@ namespace {
 //   in  [B, T, F, ldi] (head h, component d at column h*D + d; ldi >= Hh*D); prelu_a (nullable): PReLU applied on load
 //   out row (b*Hh + h, t_off + t) of a [B*Hh, rows, ldo] matrix, element f*D + d; columns [F*D, ldo) zeroed
 //   res (nullable, Hh == 1 only): out = res[b,t,:] + LN(...)
-template <int MAXV>
+template <int MAXV, bool FIX>
 __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ in, const float* __restrict__ gam,
                                                       const float* __restrict__ bet, float* __restrict__ out,
                                                       const float* __restrict__ res, int B, int T, int F, int Hh, int D,
@@ -28,21 +28,33 @@ __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ 
                                                       const float* __restrict__ prelu_a) {
   // F*Hh*D <= 256*MAXV (145*32 = 4640 needs 20; the Q / K heads, 145*4*2 = 1160, need 5: round 6 instantiates 5 / 10 / 20 --
   // the fully unrolled, masked slot loops cost their instructions whether a slot holds an element or not)
+  // FIX (256 % (Hh*D) == 0 -- every shipped configuration): slot k of thread tid is element tid + 256 k either way, but then its
+  // column tid % (Hh*D) -- head and component -- is the same for every k and its frequency is k (256 / (Hh*D)) + tid / (Hh*D): one
+  // integer division per thread instead of two per element and loop (the kernel was instruction-bound on them: 2.1 TB/s), and
+  // one running sum per thread instead of eight masked ones.  Same elements per thread, same order of every sum: same bits.
   const int bt = blockIdx.x, b = bt / T, t = bt % T;
   const int n = F * Hh * D, HD = Hh * D, FD = F * D;
   const float* x = in + (size_t)bt * F * ldi;
   const float pa = prelu_a ? prelu_a[0] : 1.0f;
+  const int fpi = 256 / HD, fl = threadIdx.x / HD, hdt = threadIdx.x % HD, ht = hdt / D, dt = hdt % D;      // (FIX)
   float v[MAXV];
   __shared__ float red[4][8];                    // [wave][head] (Hh <= 8)
   __shared__ float stat[8][2];
-  float part[8];
+  float part[FIX ? 1 : 8];
 #pragma unroll
-  for (int h = 0; h < 8; ++h) part[h] = 0.f;
+  for (int h = 0; h < (FIX ? 1 : 8); ++h) part[h] = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int i = threadIdx.x + 256 * k;
     v[k] = 0.f;
-    if (i < n) {
+    if constexpr (FIX) {
+      const int f = k * fpi + fl;
+      if (f < F) {
+        const float xv = x[f * ldi + hdt];
+        v[k] = xv > 0.f ? xv : pa * xv;
+        part[0] += v[k];
+      }
+    } else if (i < n) {
       const float xv = x[(size_t)(i / HD) * ldi + i % HD];
       v[k] = xv > 0.f ? xv : pa * xv;
       const int h = (i % HD) / D;
@@ -51,26 +63,44 @@ __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ 
     }
   }
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = threadIdx.x & 63;
-  for (int h = 0; h < Hh; ++h) { const float s = wave_sum(part[h]); if (ln == 0) red[wv][h] = s; }
+  for (int h = 0; h < Hh; ++h) { const float s = wave_sum(FIX ? (h == ht ? part[0] : 0.f) : part[h]); if (ln == 0) red[wv][h] = s; }
   __syncthreads();
   if (threadIdx.x < Hh) stat[threadIdx.x][0] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / FD;
   __syncthreads();
 #pragma unroll
-  for (int h = 0; h < 8; ++h) part[h] = 0.f;
+  for (int h = 0; h < (FIX ? 1 : 8); ++h) part[h] = 0.f;
+  const float mean_t = FIX ? stat[ht][0] : 0.f;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int i = threadIdx.x + 256 * k;
-    if (i < n) {
+    if constexpr (FIX) {
+      if (k * fpi + fl < F) { const float d = v[k] - mean_t; part[0] += d * d; }
+    } else if (i < n) {
       const int h = (i % HD) / D;
       const float d = v[k] - stat[h][0];
 #pragma unroll
       for (int hh = 0; hh < 8; ++hh) part[hh] += hh == h ? d * d : 0.f;
     }
   }
-  for (int h = 0; h < Hh; ++h) { const float s = wave_sum(part[h]); if (ln == 0) red[wv][h] = s; }
+  for (int h = 0; h < Hh; ++h) { const float s = wave_sum(FIX ? (h == ht ? part[0] : 0.f) : part[h]); if (ln == 0) red[wv][h] = s; }
   __syncthreads();
   if (threadIdx.x < Hh) stat[threadIdx.x][1] = 1.0f / sqrtf((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / FD + 1e-5f);
   __syncthreads();
+  if constexpr (FIX) {
+    const float rstd_t = stat[ht][1];
+    float* orow = out + ((size_t)(b * Hh + ht) * rows + t_off + t) * ldo + dt;
+    const float* rrow = res ? res + (size_t)bt * n + hdt : nullptr;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int f = k * fpi + fl;
+      if (f < F) {
+        const int e = f * D + dt;
+        float y = (v[k] - mean_t) * rstd_t * gam[e] + bet[e];
+        if (res) y += rrow[f * HD];
+        orow[f * D] = y;
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int i = threadIdx.x + 256 * k;
@@ -81,6 +111,7 @@ __global__ __launch_bounds__(256) void head_ln_kernel(const float* __restrict__ 
       if (res) y += res[(size_t)bt * n + i];
       out[((size_t)(b * Hh + h) * rows + t_off + t) * ldo + e] = y;
     }
+  }
   }
   for (int h = 0; h < Hh; ++h)
     for (int e = FD + threadIdx.x; e < ldo; e += 256) out[((size_t)(b * Hh + h) * rows + t_off + t) * ldo + e] = 0.f;
@@ -417,9 +448,11 @@ extern "C" int sb_head_ln(const float* in, const float* gamma, const float* beta
                           void* stream) {
   if (Hh > 8 || F * Hh * D > 256 * 20 || (res && Hh != 1) || ldi < Hh * D) return -1002;
   const int need = (F * Hh * D + 255) / 256;
-#define SB_HL(M_) hipLaunchKernelGGL(head_ln_kernel<M_>, dim3(B * T), dim3(256), 0, (hipStream_t)stream, in, gamma, beta, out, res, B, T, F, \
-                                     Hh, D, rows, t_off, ldo, ldi, prelu_a)
-  if (need <= 5) SB_HL(5); else if (need <= 10) SB_HL(10); else SB_HL(20);
+#define SB_HL(M_, X_) hipLaunchKernelGGL((head_ln_kernel<M_, X_>), dim3(B * T), dim3(256), 0, (hipStream_t)stream, in, gamma, beta, out, res, B, T, F, \
+                                         Hh, D, rows, t_off, ldo, ldi, prelu_a)
+  const bool fix = 256 % (Hh * D) == 0;             // a thread's column is the same in every slot: see the kernel
+  if (fix) { if (need <= 5) SB_HL(5, true); else if (need <= 10) SB_HL(10, true); else SB_HL(20, true); }
+  else { if (need <= 5) SB_HL(5, false); else if (need <= 10) SB_HL(10, false); else SB_HL(20, false); }
 #undef SB_HL
   SB_CHECK_LAUNCH();
   return 0;
