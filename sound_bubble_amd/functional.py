@@ -603,13 +603,20 @@ class AttentionFn(torch.autograd.Function):
         HE = n_head * E
         gP, sC = dense(P, Cc)
 
-        def proj(w, b, n_out):
+        # zero-padded copies of the two narrow projections' weights: ONE fill for both (the padded rows of a projection whose
+        # width is a multiple of 16 -- V -- are the parameter itself)
+        hpad = (HE + 15) // 16 * 16
+        arena = torch.zeros(2, hpad * Cc + hpad, device=dev, dtype=torch.float32) if hpad > HE else None
+
+        def proj(w, b, n_out, slot):
             """pre-activation of Linear(C -> n_out), stored with a 16-padded row stride (padding columns zero)"""
             npad = (n_out + 15) // 16 * 16
-            wpad = torch.zeros(npad, Cc, device=dev, dtype=torch.float32)
-            wpad[:n_out] = w
-            bpad = torch.zeros(npad, device=dev, dtype=torch.float32)
-            bpad[:n_out] = b
+            if npad == n_out:
+                wpad, bpad = w.contiguous(), b.contiguous()
+            else:
+                wpad, bpad = arena[slot, : npad * Cc].view(npad, Cc), arena[slot, npad * Cc:]
+                wpad[:n_out] = w
+                bpad[:n_out] = b
             out = torch.empty(P, npad, device=dev, dtype=torch.float32)       # (the GEMM writes columns < n_out of every row)
             if npad > n_out:
                 out[:, n_out:].zero_()
@@ -631,9 +638,9 @@ class AttentionFn(torch.autograd.Function):
             Kc[:, : Lw - 1, F * E:].zero_()
         if ldv > F * Cv:
             Vc[:, : Lw - 1, F * Cv:].zero_()
-        pq, ldq = proj(wq, bq, HE)
-        pk, _ = proj(wk, bk, HE)
-        pv, ldvp = proj(wv, bv, Cc)
+        pq, ldq = proj(wq, bq, HE, 0)
+        pk, _ = proj(wk, bk, HE, 1)
+        pv, ldvp = proj(wv, bv, Cc, 0)
         ops.head_ln(pq, gq, eq, Qn, B, T, F, n_head, E, T, 0, ldk, ldi=ldq, prelu_a=aq)
         ops.head_ln(pk, gk, ek, Kc, B, T, F, n_head, E, rows, Lw - 1, ldk, ldi=ldq, prelu_a=ak)
         ops.head_ln(pv, gv, ev, Vc, B, T, F, n_head, Cv, rows, Lw - 1, ldv, ldi=ldvp, prelu_a=av)
@@ -668,8 +675,22 @@ class AttentionFn(torch.autograd.Function):
         dy = dy.contiguous()
         # LayerNorm(F*C) + PReLU of the output projection (the residual passes dy through)
         dpp, d_gp, d_ep, d_ap = ops.head_ln_bwd(pp, gp, dy, B, T, F, 1, Cc, T, 0, F * Cc, Cc, prelu_a=ap_)
-        d_wp = torch.zeros_like(wp)
-        d_bp = torch.zeros(Cc, device=dev, dtype=torch.float32)
+        # every zero-initialised gradient target / padded transposed weight of this backward out of ONE zero fill
+        lds = (ldq, ldq, ldvp)
+        zsize = Cc * Cc + Cc + sum(2 * ld * Cc + ld for ld in lds)
+        zbuf = torch.zeros(zsize, device=dev, dtype=torch.float32)
+        zoff = [0]
+
+        def carve(*shape):
+            n = 1
+            for d_ in shape:
+                n *= d_
+            t = zbuf[zoff[0]: zoff[0] + n].view(*shape)
+            zoff[0] += n
+            return t
+
+        d_wp = carve(Cc, Cc)
+        d_bp = carve(Cc)
         ops.wgrad(dpp, Cc, Cc, O, sC, gP, Cc, d_wp, dbias=d_bp)
         dO = torch.empty(P, Cc, device=dev, dtype=torch.float32)
         ops.linear(dpp, wp.t().contiguous(), None, dO, gP, sC, sC, Cc, Cc)
@@ -688,17 +709,17 @@ class AttentionFn(torch.autograd.Function):
         outs = []
         first = True
         for dpre, w, n_out, ld in ((dpq, wq, HE, ldq), (dpk, wk, HE, ldq), (dpv, wv, Cc, ldvp)):
-            wt = torch.zeros(Cc, ld, device=dev, dtype=torch.float32)
+            wt = carve(Cc, ld)
             wt[:, :n_out] = w.t()
             if first:
                 ops.linear(dpre, wt, None, dx, gP, (0, 0, ld), sC, ld, Cc, epi=L.EPI_RES, res=dy)
             else:
                 ops.linear(dpre, wt, None, dx, gP, (0, 0, ld), sC, ld, Cc, accumulate=True)
             first = False
-            dwp_ = torch.zeros(ld, Cc, device=dev, dtype=torch.float32)
-            dbp_ = torch.zeros(ld, device=dev, dtype=torch.float32)
+            dwp_ = carve(ld, Cc)
+            dbp_ = carve(ld)
             ops.wgrad(dpre, ld, ld, x, sC, gP, Cc, dwp_, dbias=dbp_)
-            outs.append((dwp_[:n_out].contiguous(), dbp_[:n_out].contiguous()))
+            outs.append((dwp_[:n_out], dbp_[:n_out]))      # (leading rows of a contiguous block: contiguous views)
         (d_wq, d_bq), (d_wk, d_bk), (d_wv, d_bv) = outs
         return (dx, None, None, d_wq, d_bq, d_aq, d_gq, d_eq, d_wk, d_bk, d_ak, d_gk, d_ek, d_wv, d_bv, d_av, d_gv,
                 d_ev, d_wp, d_bp, d_ap, d_gp, d_ep, None, None, None)
