@@ -8,9 +8,12 @@
 //   * H / 16 waves per workgroup (8 for H = 128: two per SIMD, 256 registers each), so W_hh stays register-resident
 //     (H registers per lane) and W_ih is parked in LDS in MFMA-fragment order -- one conflict-free ds_read_b128 per lane and
 //     K chunk (131 KB for C = 64, H = 128: the kernel asks for 157 KB of the CU's 160 KB);
-//   * v_mfma_f32_16x16x4_f32 throughout: exact fp32 products (bitwise an fma chain), position-major fp32 records
-//     (i, f, g, o, c_prev: the "legacy" record form of sb_lstm_fwd), fp32 dgates -- correctness first; the byte and issue diets
-//     of the tuned kernels (fp16 hi + lo operands, blocked Q24 records, fused streaming part) are not repeated here;
+//   * forward: fp16 hi + lo operands, three products per multiply-accumulate on v_mfma_f32_16x16x32_f16 -- the tuned forward's
+//     arithmetic (late round 6: the exact fp32 form, v_mfma_f32_16x16x4_f32, was matrix-pipe-bound at 7.1 us per step at H = 128 /
+//     C = 64; this one measures 2.7x faster end to end at the reference constructor's widths and holds the same 5e-6 bars);
+//     backward recurrence: v_mfma_f32_16x16x4_f32, exact fp32 products (its operands are gradients: an fp16 form needs the
+//     tuned kernels' scaling, not repeated here); position-major fp32 records (i, f, g, o, c_prev: the "legacy" record form of
+//     sb_lstm_fwd), fp32 dgates; the byte diets of the tuned kernels (blocked Q24 records, fused streaming part) are not repeated;
 //   * the backward recurrence passes its dgates through LDS as the B operand of dh^T = W_hh^T . dgates (wave w owns output
 //     tile w over the full K = 4H), one barrier per step, instead of reducing per-wave partial products.
 // The weight / input gradients that follow are position-wise GEMMs over the dgates (sb_linear_fwd, sb_wgrad's generic form).
@@ -22,13 +25,32 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 g16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
+struct HiLo8 { g16x8 hi, lo; };
+// x = hi + lo with both terms fp16 (the tuned kernels' operand form: sb_lstm_bf_common.h splitn1)
+SB_DEVINL void split1(float x, _Float16& hi, _Float16& lo) { hi = (_Float16)x; lo = (_Float16)(x - (float)hi); }
+SB_DEVINL HiLo8 split8(const float (&x)[8]) {
+  HiLo8 r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { _Float16 h, l; split1(x[k], h, l); r.hi[k] = h; r.lo[k] = l; }
+  return r;
+}
+// acc += W x over one 32-wide K chunk with W = Wh + Wl, x = xh + xl: the three leading products, smallest first (the order of
+// the tuned forward's mma6); Wl xl (2^-22 relative) is dropped
+SB_DEVINL f32x4 mma3(const HiLo8& W, const g16x8 xh, const g16x8 xl, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.lo, xh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.hi, xl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(W.hi, xh, acc, 0, 0, 0);
+}
+
 template <int C, int H, bool SAVE>
 __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_args a) {
-  constexpr int NW = H / 16;        // waves
-  constexpr int KX = C / 16;        // 16-wide K chunks of the input part
-  constexpr int KH = H / 16;        // ... of the hidden part
-  constexpr int VPT = C / 16;       // floats per loader thread
-  constexpr int CP = C + 4, HP = H + 4;
+  constexpr int NW = H / 16;             // waves
+  constexpr int KX = (C + 31) / 32;      // 32-wide K chunks of the input part (C = 16: one chunk, upper half zero)
+  constexpr int KH = H / 32;             // ... of the hidden part
+  constexpr int VPT = C / 16;            // floats per loader thread
+  constexpr int CP = 32 * KX + 8, HP = H + 8;      // LDS rows in halves (16-byte aligned, 4-dword bank shift per row)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int n0 = blockIdx.x * 16;
@@ -36,23 +58,41 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_arg
   const bool rev = dir == 1;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x4* WL = reinterpret_cast<f32x4*>(smem);                              // [4][NW][KX][64] fragments of W_ih
-  float* U = smem + 4 * NW * KX * 64 * 4;                                  // [2][16][CP]
-  float* Hb = U + 2 * 16 * CP;                                             // [2][16][HP]
+  g16x8* WL = reinterpret_cast<g16x8*>(smem);                                       // [4][NW][KX][2 terms][64] fragments of W_ih
+  _Float16* U = reinterpret_cast<_Float16*>(WL + 4 * NW * KX * 2 * 64);             // [2 bufs][2 terms][16][CP]
+  _Float16* Hb = U + 2 * 2 * 16 * CP;                                               // [2 bufs][2 terms][16][HP]
 
-  // ---- weights: W_hh -> registers, W_ih -> LDS (fragment order), bias -> registers ----
+  // ---- weights as fp16 hi + lo fragments (A operand of v_mfma_f32_16x16x32_f16: lane (i = j, k = 8q .. 8q + 7)):
+  //      W_hh -> registers (H per lane, as the fp32 fragments of round 6's first version), W_ih -> LDS, bias -> registers ----
   const float* __restrict__ wih = a.w_ih[dir];
   const float* __restrict__ whh = a.w_hh[dir];
-  f32x4 Ahh[4][KH], bias[4];
+  HiLo8 Ahh[4][KH];
+  f32x4 bias[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int row = g * H + 16 * w + j;
 #pragma unroll
-    for (int m = 0; m < KX; ++m) WL[((g * NW + w) * KX + m) * 64 + lane] = ld4(wih + (size_t)row * C + 16 * m + 4 * q);
+    for (int m = 0; m < KX; ++m) {
+      float t[8];
 #pragma unroll
-    for (int m = 0; m < KH; ++m) Ahh[g][m] = ld4(whh + (size_t)row * H + 16 * m + 4 * q);
+      for (int k = 0; k < 8; ++k) { const int col = 32 * m + 8 * q + k; t[k] = col < C ? wih[(size_t)row * C + col] : 0.f; }
+      const HiLo8 f = split8(t);
+      WL[(((g * NW + w) * KX + m) * 2 + 0) * 64 + lane] = f.hi;
+      WL[(((g * NW + w) * KX + m) * 2 + 1) * 64 + lane] = f.lo;
+    }
+#pragma unroll
+    for (int m = 0; m < KH; ++m) {
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = whh[(size_t)row * H + 32 * m + 8 * q + k];
+      Ahh[g][m] = split8(t);
+    }
     const int u0 = g * H + 16 * w + 4 * q;
     bias[g] = ld4(a.b_ih[dir] + u0) + ld4(a.b_hh[dir] + u0);
+  }
+  if constexpr (32 * KX > C) {               // the K padding of the input operand stays zero (the loader writes columns < C)
+    for (int i = tid; i < 2 * 2 * 16 * CP; i += H * 4) U[i] = (_Float16)0.f;
+    __syncthreads();
   }
 
   // ---- loader role (the first 256 threads): thread -> (sequence ls, channel slice) ----
@@ -88,7 +128,10 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_arg
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       u[v] = (xv.v[v] - mean) * rstd * gam[v] + bet[v];
-      U[(buf * 16 + ls) * CP + cpart * VPT + v] = u[v];
+      _Float16 hh, ll;
+      split1(u[v], hh, ll);
+      U[((buf * 2 + 0) * 16 + ls) * CP + cpart * VPT + v] = hh;
+      U[((buf * 2 + 1) * 16 + ls) * CP + cpart * VPT + v] = ll;
     }
     if (SAVE && lvalid && dir == 0) {
       const int st = rev ? S - 1 - s : s;
@@ -108,7 +151,14 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_arg
     if (a.c0) c = ld4(a.c0 + (size_t)nc * H + uoff);
     if (a.h0) h = ld4(a.h0 + (size_t)nc * H + uoff);
   }
-  st4(&Hb[(0 * 16 + j) * HP + uoff], h);
+  auto store_h = [&](int buf) {              // h of this lane's four units as hi / lo halves
+    g16x4 hh, ll;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { _Float16 x, y; split1(h[r], x, y); hh[r] = x; ll[r] = y; }
+    *reinterpret_cast<g16x4*>(&Hb[((buf * 2 + 0) * 16 + j) * HP + uoff]) = hh;
+    *reinterpret_cast<g16x4*>(&Hb[((buf * 2 + 1) * 16 + j) * HP + uoff]) = ll;
+  };
+  store_h(0);
 
   {
     XV x0 = load_x(0);
@@ -124,11 +174,14 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_arg
     for (int g = 0; g < 4; ++g) out[g] = bias[g];
 #pragma unroll
     for (int m = 0; m < KX; ++m) {
-      const f32x4 b4 = ld4(&U[(buf * 16 + j) * CP + 16 * m + 4 * q]);
+      const g16x8 xh = *reinterpret_cast<const g16x8*>(&U[((buf * 2 + 0) * 16 + j) * CP + 32 * m + 8 * q]);
+      const g16x8 xl = *reinterpret_cast<const g16x8*>(&U[((buf * 2 + 1) * 16 + j) * CP + 32 * m + 8 * q]);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 a4 = WL[((g * NW + w) * KX + m) * 64 + lane];
-        out[g] = mfma16x4(a4, b4, out[g]);
+        HiLo8 W;
+        W.hi = WL[(((g * NW + w) * KX + m) * 2 + 0) * 64 + lane];
+        W.lo = WL[(((g * NW + w) * KX + m) * 2 + 1) * 64 + lane];
+        out[g] = mma3(W, xh, xl, out[g]);
       }
     }
   };
@@ -141,9 +194,10 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_arg
     f32x4 acc[4] = {accx[0], accx[1], accx[2], accx[3]};
 #pragma unroll
     for (int m = 0; m < KH; ++m) {
-      const f32x4 b4 = ld4(&Hb[(cur * 16 + j) * HP + 16 * m + 4 * q]);
+      const g16x8 xh = *reinterpret_cast<const g16x8*>(&Hb[((cur * 2 + 0) * 16 + j) * HP + 32 * m + 8 * q]);
+      const g16x8 xl = *reinterpret_cast<const g16x8*>(&Hb[((cur * 2 + 1) * 16 + j) * HP + 32 * m + 8 * q]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = mfma16x4(Ahh[g][m], b4, acc[g]);
+      for (int g = 0; g < 4; ++g) acc[g] = mma3(Ahh[g][m], xh, xl, acc[g]);
     }
     // ---- input part of step s + 1 (independent MFMAs) next to the cell update of step s ----
     input_part(cur ^ 1, accx);
@@ -158,7 +212,7 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_arg
       h[r] = go[r] * tanhf_fast(c[r]);
     }
     ln_store(xnext, cur, min(s + 2, S - 1));                    // u_{s+2} -> U[s & 1] (its readers passed the last barrier)
-    st4(&Hb[((cur ^ 1) * 16 + j) * HP + uoff], h);
+    store_h(cur ^ 1);
     if (cvalid) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = cbase + (int64_t)st * a.p_step;
@@ -178,7 +232,9 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_fwd_kernel(sb_lstm_gen_fwd_arg
 }
 
 template <int C, int H>
-constexpr size_t fwd_lds_bytes() { return (size_t)(4 * (H / 16) * (C / 16) * 64 * 4 + 2 * 16 * (C + 4) + 2 * 16 * (H + 4)) * sizeof(float); }
+constexpr size_t fwd_lds_bytes() {       // W_ih fragments (hi + lo, 16 bytes per lane each) + the U and H operand tiles (halves)
+  return (size_t)4 * (H / 16) * ((C + 31) / 32) * 2 * 64 * 16 + (size_t)(2 * 2 * 16 * (32 * ((C + 31) / 32) + 8) + 2 * 2 * 16 * (H + 8)) * 2;
+}
 
 template <int C, int H>
 int launch_gen_fwd(const sb_lstm_gen_fwd_args& a, hipStream_t st) {
