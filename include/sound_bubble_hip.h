@@ -307,6 +307,7 @@ typedef struct {
   int64_t p_outer, p_inner, p_step;
   const float* w_hh[2];
   const float* save_gates; const float* dhs; float* dgates;
+  const float* gmax;          /* device scalar: max |dhs| (sb_absmax), the fp16 scale of the dgates operand; NULL: scale 1 */
 } sb_lstm_gen_bwd_args;
 int sb_lstm_gen_bwd_rec(const sb_lstm_gen_bwd_args* a, void* stream);
 int sb_lstm_gen_supported(int C, int H);      /* 1 when the two calls above are built for (C, H) */

@@ -108,7 +108,7 @@ class LstmGenFwdArgs(C.Structure):
 class LstmGenBwdArgs(C.Structure):
     _fields_ = [("nseq", C.c_int), ("nsteps", C.c_int), ("n_inner", C.c_int), ("ndir", C.c_int), ("H", C.c_int),
                 ("p_outer", i64), ("p_inner", i64), ("p_step", i64),
-                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp)]
+                ("w_hh", c_fp * 2), ("save_gates", c_fp), ("dhs", c_fp), ("dgates", c_fp), ("gmax", c_fp)]
 
 
 class LstmStreamArgs(C.Structure):

@@ -256,22 +256,40 @@ int launch_gen_fwd(const sb_lstm_gen_fwd_args& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_gen_bwd_rec_kernel(sb_lstm_gen_bwd_args a) {
-  constexpr int KG = 4 * H / 16;          // 16-wide K chunks over the 4H gate rows
-  constexpr int GP = 4 * H + 4;           // padded dgates row of one sequence
+  // dh^T[H x 16] = W_hh^T[H x 4H] . dgates[4H x 16] on fp16 operands (late round 6; the exact fp32 form chained 4H / 4 dependent
+  // v_mfma_f32_16x16x4_f32 on one accumulator every step): W_hh^T as hi + lo fragments in registers (H per lane), the step's
+  // dgates as S dgates = hi + 2^-11 lo' through LDS -- S = 2^-ceil(log2 gmax) from the incoming gradient's maximum
+  // (sb_lstm_gen_bwd_args.gmax; the recurrence is linear in it: the tuned kernels' DG16 scaling, sb_lstm_bf_bwd.hip) --, three
+  // products per multiply-accumulate on six independent accumulators.  The dgates that LEAVE are the fp32 values, unscaled.
+  constexpr int KG = 4 * H / 32;          // 32-wide K chunks over the 4H gate rows
+  constexpr int GP = 4 * H + 8;           // padded dgates row of one sequence (halves)
+  constexpr float kLoUp = 2048.0f, kLoDn = 1.0f / 2048.0f;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
   const int dir = blockIdx.y;
   const int n0 = blockIdx.x * 16;
   const int S = a.nsteps, ndir = a.ndir;
   const bool rev = dir == 1;
-  extern __shared__ __attribute__((aligned(16))) float DG[];      // [2][16][GP]
+  extern __shared__ __attribute__((aligned(16))) float smem_b[];
+  _Float16* DG = reinterpret_cast<_Float16*>(smem_b);      // [2 bufs][2 terms][16][GP]
 
-  // A operand of dh^T[H x 16] = W_hh^T[H x 4H] . dgates[4H x 16]: lane (i = j, kk = q) holds W_hh[16m + 4q + r][16w + j]
+  float gS = 1.0f;
+  if (a.gmax) {
+    const float m = a.gmax[0];
+    gS = (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f;
+  }
+  gS = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gS)));
+  const float invS = 1.0f / gS;
+
+  // A operand: lane (i = j, k = 8q .. 8q + 7 of chunk m) holds W_hh[32m + 8q + k][16w + j]
   const float* __restrict__ whh = a.w_hh[dir];
-  f32x4 At[KG];
+  HiLo8 At[KG];
 #pragma unroll
-  for (int m = 0; m < KG; ++m)
+  for (int m = 0; m < KG; ++m) {
+    float t[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) At[m][r] = whh[(size_t)(16 * m + 4 * q + r) * H + 16 * w + j];
+    for (int k = 0; k < 8; ++k) t[k] = whh[(size_t)(32 * m + 8 * q + k) * H + 16 * w + j];
+    At[m] = split8(t);
+  }
 
   const int nc = n0 + j;
   const bool valid = nc < a.nseq;
@@ -312,9 +330,21 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_bwd_rec_kernel(sb_lstm_gen_bwd
       dG[3][r] = dO * rc.o[r] * (1.0f - rc.o[r]);
       dc[r] = dct * rc.f[r];
     }
-    float* row = &DG[(cur * 16 + j) * GP];
+    _Float16* rowh = &DG[((cur * 2 + 0) * 16 + j) * GP];
+    _Float16* rowl = &DG[((cur * 2 + 1) * 16 + j) * GP];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) st4(row + g * H + uoff, dG[g]);
+    for (int g = 0; g < 4; ++g) {
+      g16x4 hh, ll;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = dG[g][r] * gS;
+        const _Float16 h1 = (_Float16)v;
+        hh[r] = h1;
+        ll[r] = (_Float16)__builtin_fmaf((float)h1, -kLoUp, v * kLoUp);
+      }
+      *reinterpret_cast<g16x4*>(rowh + g * H + uoff) = hh;
+      *reinterpret_cast<g16x4*>(rowl + g * H + uoff) = ll;
+    }
     if (valid) {
       const int st = rev ? S - 1 - s : s;
       const int64_t pos = base + (int64_t)st * a.p_step;
@@ -324,17 +354,25 @@ __global__ __launch_bounds__(H * 4) void lstm_gen_bwd_rec_kernel(sb_lstm_gen_bwd
     nxt = load_raw(max(s - 1, 0));
     __syncthreads();
     // dh_{s-1}^T tile w = sum over the 4H gate rows (all waves' dgates, from LDS)
-    f32x4 acc = zero4();
+    f32x4 ah[4] = {zero4(), zero4(), zero4(), zero4()}, al[2] = {zero4(), zero4()};
 #pragma unroll
-    for (int m = 0; m < KG; ++m) acc = mfma16x4(At[m], ld4(row + 16 * m + 4 * q), acc);
-    dhrec = acc;
+    for (int m = 0; m < KG; ++m) {
+      const g16x8 bh = *reinterpret_cast<const g16x8*>(rowh + 32 * m + 8 * q);
+      const g16x8 bl = *reinterpret_cast<const g16x8*>(rowl + 32 * m + 8 * q);
+      al[m & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(At[m].hi, bl, al[m & 1], 0, 0, 0);
+      ah[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(At[m].lo, bh, ah[m & 3], 0, 0, 0);
+      ah[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(At[m].hi, bh, ah[m & 3], 0, 0, 0);
+    }
+    const f32x4 sh = (ah[0] + ah[1]) + (ah[2] + ah[3]), sl = al[0] + al[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dhrec[r] = __builtin_fmaf(sl[r], kLoDn, sh[r]) * invS;
   }
 }
 
 template <int H>
 int launch_gen_bwd(const sb_lstm_gen_bwd_args& a, hipStream_t st) {
   dim3 grid((a.nseq + 15) / 16, a.ndir), block(H * 4);
-  constexpr size_t lds = (size_t)2 * 16 * (4 * H + 4) * sizeof(float);
+  constexpr size_t lds = (size_t)2 * 2 * 16 * (4 * H + 8) * sizeof(_Float16);
   (void)hipFuncSetAttribute((const void*)lstm_gen_bwd_rec_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((lstm_gen_bwd_rec_kernel<H>), grid, block, lds, st, a);
   return 0;

@@ -2091,6 +2091,8 @@ def lstm_gen_bwd(dirs, rec, dhs, u, hs, geom, targets):
     for d, (wi, wh, bi, bh) in enumerate(dirs):
         a.w_hh[d] = _p(wh)
     a.save_gates, a.dhs, a.dgates = _p(rec), _p(dhs), _p(dg)
+    gmax = absmax(dhs)                  # the fp16 scale of the recurrence's dgates operand (as the tuned kernels' gmax)
+    a.gmax = _p(gmax)
     with _Prof(f"lstm_gen_bwd_rec_kernel H={Hh} " + ("bidirectional" if ndir == 2 else "single direction"),
                2.0 * 4 * Hh * Hh * P * ndir, 8.0 * Cc * P, 4.0 * (rec.numel() + dhs.numel() + dg.numel())):
         L.check(lib.sb_lstm_gen_bwd_rec(C.byref(a), _stream()), "sb_lstm_gen_bwd_rec")
