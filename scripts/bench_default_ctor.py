@@ -47,6 +47,26 @@ with torch.no_grad():
     torch.cuda.synchronize()
     out["forward_ms"] = 1e3 * (time.time() - t0) / args.steps
     out["forward_utt_s"] = args.batch / (out["forward_ms"] * 1e-3)
+# streaming: one 8 ms chunk at a time through the captured hipGraph (B = 1): the reference's real-time use
+from sound_bubble_amd.streaming import StreamingSeparator                 # noqa: E402
+with torch.no_grad():
+    de = torch.eye(3)[:1].to(dev) if args.family == "dis_embd3" else None
+    sep = StreamingSeparator(m, batch_size=1, dis_embed=de)
+    chunk = (0.1 * torch.randn(1, 2, m.stft_chunk_size + m.stft_pad_size, generator=g)).to(dev)
+    for _ in range(20):
+        sep.feed(chunk)
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        sep.feed(chunk)
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - t0))
+    lat.sort()
+    out["stream_chunk_ms_p50"], out["stream_chunk_ms_p99"] = lat[100], lat[197]
+    out["stream_chunk_samples"] = int(m.stft_chunk_size)
+    out["stream_realtime_factor"] = (m.stft_chunk_size / 24000.0 * 1e3) / lat[100]
+    del sep
 m.train()
 bucket = FlatBucket(m)
 optim = FusedAdam(bucket, lr=1e-3)
