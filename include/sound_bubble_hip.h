@@ -454,7 +454,10 @@ typedef struct {
                 gmax (nullable; a device scalar max |g|, e.g. from sb_absmax) makes the kernel scale g by the power of two
                 2^-ceil(log2 *gmax) before the fp16 split and the sums back afterwards: gradients of 1e-7 would otherwise
                 underflow fp16.  Single fp32 source, N <= 32 padded to whole 16-row tiles in g (ldg >= 16 * ceil(N/16)), K = 3 segments of
-                96 or 48 columns (the 3x3 convolutions) */
+                96 or 48 columns (the 3x3 convolutions);
+                2: a hint for the GENERIC tiled form only (the shapes no register-accumulator kernel covers: any N, K, K2 multiples
+                of 16, fp32 sources): the same fp16 hi + lo arithmetic with the same gmax scaling; shapes that have a tuned
+                kernel ignore it */
 } sb_wgrad_args;
 int sb_wgrad(const sb_wgrad_args* a, void* stream);
 int sb_wgrad_grid(int64_t positions);

@@ -849,6 +849,98 @@ __global__ __launch_bounds__(256) void wgrad_gen_kernel(sb_wgrad_args a, int64_t
     if (q == 0 && n < a.N) part[(size_t)a.N * Ktot + n] = cs;
   }
 }
+// The same tiling on the fp16 matrix pipe (sb_wgrad_args.mma == 2, late round 6): both operands as fp16 hi + lo, three
+// v_mfma_f32_16x16x32_f16 per 32-position chunk and 16 x 16 tile instead of eight fp32 instructions; g is scaled by the power of
+// two 2^-ceil(log2 *gmax) before its split (lo' scaled by 2^11 more, accumulated apart) and the sums scaled back: the gradients'
+// range is not fp16's.  A staging thread holds 8 CONSECUTIVE positions of its column, so an operand leaves as one 16-byte LDS
+// write per term; the bias sums are exact fp32 sums of what the staging threads read.
+typedef _Float16 w16x8 __attribute__((ext_vector_type(8)));
+constexpr int WG16_LD = WGEN_POS + 8;          // halves per LDS row (80 B: 16-byte aligned, 16 lanes x 16 B hit 64 distinct banks)
+__global__ __launch_bounds__(256) void wgrad_gen16_kernel(sb_wgrad_args a, int64_t P, int64_t per) {
+  __shared__ __attribute__((aligned(16))) _Float16 GT[2][64][WG16_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 IT[2][64][WG16_LD];
+  __shared__ float BS[4][64];
+  constexpr float kLoUp = 2048.0f, kLoDn = 1.0f / 2048.0f;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, j = lane & 15;
+  const int Ktot = a.K + a.K2;
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
+  const int64_t p_begin = (int64_t)blockIdx.x * per, p_end = min(P, p_begin + per);
+  float gS = 1.0f;
+  if (a.gmax) { const float m = a.gmax[0]; gS = (m > 0.f && m < 3.0e38f) ? exp2f(-ceilf(log2f(m))) : 1.0f; }
+  gS = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gS)));
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()}, accx[4] = {zero4(), zero4(), zero4(), zero4()};
+  float bsum = 0.f;
+  // staging role: thread -> column c = tid & 63, positions 8 (tid >> 6) .. + 7 of the chunk
+  const int sc = tid & 63, sp = tid >> 6;
+  const int gn = n0 + sc;
+  const bool gok = gn < a.N;
+  const int kk = k0 + sc;
+  const bool k1 = kk < a.K, k2 = !k1 && kk < Ktot;
+  int64_t koff = 0;
+  if (k1) { const int seg = kk / a.kseg; koff = (int64_t)seg * a.is_seg + (kk - seg * a.kseg); }
+  const bool in_dense = dense_strides(a.T, a.F, a.is_b, a.is_t, a.is_f);
+  for (int64_t pc = p_begin; pc < p_end; pc += WGEN_POS) {
+    float gv[8], iv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t p = pc + 8 * sp + i;
+      const bool ok = p < p_end;
+      gv[i] = 0.f; iv[i] = 0.f;
+      if (ok && gok) gv[i] = a.g[p * a.ldg + gn];
+      if (ok && k1) {
+        const int64_t ioff = in_dense ? p * a.is_f : off3(split_pos((unsigned)p, a.T, a.F), a.is_b, a.is_t, a.is_f);
+        iv[i] = a.in[ioff + koff];
+      } else if (ok && k2) {
+        const int idx = (int)((unsigned)p % (unsigned)a.seg_len);
+        if (idx >= a.skip_first && idx < a.seg_len - a.skip_last) iv[i] = a.in2[p * a.ld2 + a.shift2 + (kk - a.K)];
+      }
+    }
+    w16x8 gh, gl, ih, il;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bsum += gv[i];
+      const float v = gv[i] * gS;
+      const _Float16 h1 = (_Float16)v;
+      gh[i] = h1;
+      gl[i] = (_Float16)__builtin_fmaf((float)h1, -kLoUp, v * kLoUp);
+      const _Float16 h2 = (_Float16)iv[i];
+      ih[i] = h2;
+      il[i] = (_Float16)(iv[i] - (float)h2);
+    }
+    *reinterpret_cast<w16x8*>(&GT[0][sc][8 * sp]) = gh;
+    *reinterpret_cast<w16x8*>(&GT[1][sc][8 * sp]) = gl;
+    *reinterpret_cast<w16x8*>(&IT[0][sc][8 * sp]) = ih;
+    *reinterpret_cast<w16x8*>(&IT[1][sc][8 * sp]) = il;
+    __syncthreads();
+    {
+      const w16x8 ah = *reinterpret_cast<const w16x8*>(&GT[0][16 * w + j][8 * q]);
+      const w16x8 al = *reinterpret_cast<const w16x8*>(&GT[1][16 * w + j][8 * q]);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const w16x8 bh = *reinterpret_cast<const w16x8*>(&IT[0][16 * kt + j][8 * q]);
+        const w16x8 bl = *reinterpret_cast<const w16x8*>(&IT[1][16 * kt + j][8 * q]);
+        accx[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accx[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[kt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const float invS = 1.0f / gS;
+  float* part = a.scratch + (size_t)blockIdx.x * ((size_t)a.N * Ktot + a.N);
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * w + 4 * q + r, k = k0 + 16 * kt + j;
+      if (n < a.N && k < Ktot) part[(size_t)n * Ktot + k] = __builtin_fmaf(accx[kt][r], kLoDn, acc[kt][r]) * invS;
+    }
+  if (blockIdx.z == 0) {                       // (uniform over the workgroup)
+    BS[sp][sc] = bsum;
+    __syncthreads();
+    if (tid < 64 && n0 + tid < a.N) part[(size_t)a.N * Ktot + n0 + tid] = (BS[0][tid] + BS[1][tid]) + (BS[2][tid] + BS[3][tid]);
+  }
+}
 // position ranges (= partial rows) of the generic form: enough workgroups to fill the chip a few times over, ranges of whole
 // 32-position chunks
 static int wgrad_gen_rows(int64_t P, int N, int Ktot, int64_t* per_out) {
@@ -1134,8 +1226,10 @@ static int wgrad_dispatch(const sb_wgrad_args& a, void* stream, bool launch, int
     if (a.kseg <= 0) return -1004;
     int64_t per = 0;
     rows = wgrad_gen_rows(P, a.N, a.K + a.K2, &per);
-    if (launch)
-      hipLaunchKernelGGL(wgrad_gen_kernel, dim3(rows, (a.N + 63) / 64, (a.K + a.K2 + 63) / 64), block, 0, st, a, P, per);
+    if (launch) {
+      if (a.mma == 2) hipLaunchKernelGGL(wgrad_gen16_kernel, dim3(rows, (a.N + 63) / 64, (a.K + a.K2 + 63) / 64), block, 0, st, a, P, per);
+      else hipLaunchKernelGGL(wgrad_gen_kernel, dim3(rows, (a.N + 63) / 64, (a.K + a.K2 + 63) / 64), block, 0, st, a, P, per);
+    }
   }
   if (rows_out) *rows_out = rows;
   if (!launch) return 0;

@@ -1659,7 +1659,7 @@ def dense(P, ld):
 
 def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=None, is_seg=0, in2=None, ld2=0,
           in2_off=0, shift2=0, K2=0, dW2=None, seg_len=None, skip_first=0, skip_last=0, dbias=None, dbias2=None,
-          transpose_out=False, perm_k=0, perm_n=0, bias_mod=0, wview=None, f16=False, gmax=None):
+          transpose_out=False, perm_k=0, perm_n=0, bias_mod=0, wview=None, f16=False, gmax=None, gen_f16=False):
     """dW[N,K] += sum_p g[p,:N]^T in(p,:K);  dW2[N,K2] += sum_p g^T in2[p*ld2+shift2 : +K2] (segment-masked);
     dbias (+dbias2) += column sums of g.  One pass over g."""
     lib = L.load()
@@ -1688,6 +1688,8 @@ def wgrad(g, ldg, N, inp, in_strides, grid, K, dW, *, g_off=0, in_off=0, kseg=No
     a.mma = 1 if (f16 and LINEAR_F16X3 and ((N <= 32 and K == 288 and a.kseg == 96) or (N <= 16 and K == 144 and a.kseg == 48))) else 0
     if a.mma:
         a.gmax = _p(gmax if gmax is not None else absmax_or_hint(g))   # power-of-two scale against fp16 underflow
+    elif gen_f16 and gmax is not None:
+        a.mma, a.gmax = 2, _p(gmax)       # the generic tiled form (if this shape takes it) on fp16 hi + lo operands, g scaled by gmax
     # partial rows: four per workgroup for the shapes with a register-accumulator kernel; the library's generic tiled form (any
     # other shape: the D = 64 / H = 128 layers) says how many position ranges it will use
     rows = lib.sb_wgrad_scratch_rows(C.byref(a))
@@ -2108,5 +2110,5 @@ def lstm_gen_bwd(dirs, rec, dhs, u, hs, geom, targets):
         t_wi, t_wh, t_bi, t_bh = targets[d]
         wgrad(dg, ldg, 4 * Hh, u, sC, gP, Cc, t_wi, g_off=d * 4 * Hh, in2=hs, ld2=ldh, in2_off=d * Hh, shift2=back * ldh, K2=Hh,
               dW2=t_wh, seg_len=geom.nsteps * geom.p_step, skip_first=geom.p_step if d == 0 else 0,
-              skip_last=geom.p_step if d == 1 else 0, dbias=t_bi, dbias2=t_bh)
+              skip_last=geom.p_step if d == 1 else 0, dbias=t_bi, dbias2=t_bh, gen_f16=True, gmax=gmax)
     return du
