@@ -21,6 +21,9 @@ extern "C" int sb_debug_phase_fwd(float* host_out) {
 }
 #endif
 
+#ifndef SB_EPI_EARLY
+#define SB_EPI_EARLY 1
+#endif
 namespace {
 
 // The bidirectional C = 32 passes with the fused partial Linear (first block's intra-frame pass, ordered consumer) are meant to run
@@ -758,6 +761,14 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
       for (int r = 0; r < 4; ++r) h[r] = go[r] * __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + tc[r]), -1.0f);
     } else {
       x_part(accx, cur ^ 1);
+#if SB_EPI_EARLY
+      // (late round 6: the tile owners' y epilogue of the PREVIOUS step -- its W_lin h products finished in phase A -- issued here,
+      //  behind the input part's products, instead of at the end of the step, where it ran exposed: the owners' phase D was 340
+      //  ticks longer than the loader waves', who waited for them at the barrier)
+      if constexpr (LIN && (HEAVY || (ORD && SB_EPI_EARLY == 2)) && !SB_EXP_SKIP) { if (linw) epilogue(s > s_begin ? run_x - d_x : run_x, s, run_x); }
+      else if constexpr (LIN && SB_EPI_EARLY == 3) { if (s > s_begin) store_y(run_x - d_x); load_res(s, run_x); }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       cprev = c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -796,11 +807,15 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #ifdef SB_EXP_NO_EPI
     constexpr bool EPI1 = false;
 #else
-    constexpr bool EPI1 = LIN && HEAVY && !SB_EXP_SKIP;
+    constexpr bool EPI1 = LIN && (HEAVY || (ORD && SB_EPI_EARLY == 2)) && !SB_EXP_SKIP;      // (SB_EPI_EARLY = 2: the ordered consumer too)
 #endif
     if constexpr (EPI1) {
+#if SB_EPI_EARLY
+      if constexpr (CELLPIN) { if (linw) epilogue(s > s_begin ? run_x - d_x : run_x, s, run_x); }      // (the pinned inference form keeps it here)
+#else
       if (linw) epilogue(s > s_begin ? run_x - d_x : run_x, s, run_x);
-    } else if constexpr (LIN) {
+#endif
+    } else if constexpr (LIN && SB_EPI_EARLY != 3) {
       if (s > s_begin) store_y(run_x - d_x);
       load_res(s, run_x);
     }
