@@ -21,6 +21,9 @@ extern "C" int sb_debug_phase_fwd(float* host_out) {
 }
 #endif
 
+#ifndef SB_Q24_LATE
+#define SB_Q24_LATE 1
+#endif
 #ifndef SB_EPI_EARLY
 #define SB_EPI_EARLY 1
 #endif
@@ -474,6 +477,14 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #endif
   f32x4 rgi = zero4(), rgf = zero4(), rgg = zero4(), rgo = zero4(), rcp = zero4();     // records of step s_pend
   int s_pend = -1;
+  // QLATE (late round 6): in the one-workgroup-per-CU kernels the parked gates are quantised to their 24-bit codes WHERE THEY ARE
+  // STORED -- in the issue gaps of the next step's hidden-part products -- instead of at the end of the cell update, where the
+  // 24 instructions ran exposed on a SIMD with nothing else to issue.  Same function on the same values: same bits.  (The
+  // two-workgroup bidirectional kernels keep the early form: quantising at store time cost them 7-8 spilled registers, round 5.)
+  // (... and the ordered consumer: same-box A/B, producer 1.055 -> 1.015 ms per launch, consumer 1.098 -> 1.109: SB_Q24_LATE = 2
+  //  includes it)
+  constexpr bool QLATE = SB_Q24_LATE != 0 && SAVE == 4 && SB_REC_Q24 != 0 && DEFER &&
+                         !(LIN && C == 32 && !SUM3 && F16 && !SEG && !(ORD && SB_Q24_LATE == 2));
   auto rec_piece = [&](int k) __attribute__((always_inline)) {
     if constexpr (SAVE >= 2) {
       if (s_pend >= 0 && cvalid) {
@@ -505,6 +516,11 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
 #if SB_REC_Q24
             // 24-bit fixed-point gates: three 16-byte pieces per lane, each packed here from the parked gates
             float* rec = a.save_gates + blk * (16 * kWideGateDwords) + (w * 192 + lane) * 4;
+            if constexpr (QLATE) {                       // (pieces are issued in order: 0 needs i and f, 1 adds g, 2 adds o)
+              if (k == 0) { rgi = q24_codes(rgi, false); rgf = q24_codes(rgf, false); }
+              if (k == 1) rgg = q24_codes(rgg, true);
+              if (k == 2) rgo = q24_codes(rgo, false);
+            }
             if (k < 3) st4_rec(rec + 256 * k, q24_piece(k, rgi, rgf, rgg, rgo));
 #else
             float* rec = a.save_gates + blk * (16 * 4 * H) + (w * 256 + lane) * 4;
@@ -787,7 +803,7 @@ void lstm_fwd_bf_kernel(sb_lstm_fwd_args a) {
     SB_TICK(c3);
     // ---- C ----
     if constexpr (SAVE >= 2) {        // records of this step: issued in phase A of the next one (or by the flush after the walk)
-      if constexpr (SAVE == 4 && SB_REC_Q24 != 0) {   // parked as the record's 24-bit codes (sb_lstm_bf_common.h)
+      if constexpr (SAVE == 4 && SB_REC_Q24 != 0 && !QLATE) {   // parked as the record's 24-bit codes (sb_lstm_bf_common.h)
         rgi = q24_codes(gi, false); rgf = q24_codes(gf, false); rgg = q24_codes(gg, true); rgo = q24_codes(go, false); rcp = cprev;
       } else { rgi = gi; rgf = gf; rgg = gg; rgo = go; rcp = cprev; }
       s_pend = s;
